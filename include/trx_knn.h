@@ -1,0 +1,124 @@
+/*
+ * trx_knn.h -- C ABI of libtrxknn.so: exact brute-force k-NN ("flat index") on one MI355X.
+ *
+ * This is the drop-in boundary for the retrieval hot path of thomas0809/textreact.  The reference
+ * has no native code; what it binds is the FAISS Python object protocol, used at
+ *     retrieve/retrieve_faiss.py:65   index = faiss.IndexFlatL2(d)        -> trx_index_create
+ *     retrieve/retrieve_faiss.py:66   index.add(train_fps)                -> trx_index_add
+ *     retrieve/retrieve_faiss.py:71   distance, rank = index.search(q, k) -> trx_index_search
+ * (the inner-product form of the same protocol, faiss.IndexFlatIP, is what the external dense
+ * retriever named at README.md:44-47 runs; BASELINE.json configs[0..2]).  Each entry point below
+ * names the call it replaces.  Plain pointers and sizes only: no torch / HIP types in signatures
+ * (streams travel as void*).  Functions return 0 on success or a negative TRX_E* code and never
+ * throw; trx_last_error() gives the message for the calling thread.
+ *
+ * Threading: thread-compatible -- one index per thread at a time.  Calls block until the result
+ * is complete unless a *_device variant is given a stream, in which case work is enqueued on that
+ * stream and the outputs are valid once the stream reaches that point.
+ *
+ * Results (both metrics): neighbours are the k best by the total order
+ *   (score best-first, then id ascending), score = fp64 fma chain over the d components,
+ *   IP: sum x*y;  L2: sum (x-y)^2;  D = (float)score.  When fewer than k vectors are indexed the
+ *   trailing slots are I = -1, D = +FLT_MAX (L2) / -FLT_MAX (IP) -- the FAISS convention.
+ * See DESIGN.md "Exactness" and oracle/flat_knn_ref.c (trxo_knn_canonical).
+ */
+#ifndef TRX_KNN_H
+#define TRX_KNN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct trx_index trx_index;
+
+enum { TRX_METRIC_IP = 0, TRX_METRIC_L2 = 1 };
+enum { TRX_DTYPE_F32 = 0, TRX_DTYPE_BF16 = 1 };
+
+enum {
+    TRX_OK = 0,
+    TRX_EINVAL = -1,   /* bad argument (d mismatch, k out of range, null pointer, ...) */
+    TRX_ENOMEM = -2,   /* host or device allocation failed */
+    TRX_EHIP = -3,     /* a HIP runtime call or kernel launch failed */
+    TRX_ENODEV = -4    /* no usable gfx950 device */
+};
+
+#define TRX_MAX_K 2048   /* largest k any path accepts (FAISS GPU's own limit) */
+#define TRX_FAST_MAX_K 24 /* k above this takes the exact-scan path for every query */
+
+/* faiss.IndexFlatIP(d) / faiss.IndexFlatL2(d)  [retrieve_faiss.py:65].
+ * device = HIP device ordinal this index lives on (one process per GPU: pass LOCAL_RANK). */
+int trx_index_create(int d, int metric, int device, trx_index** out);
+
+/* index.add(x)  [retrieve_faiss.py:66]: append n vectors (row-major, contiguous, d components
+ * each) from HOST memory; the caller keeps ownership of x.  Ids are assigned sequentially. */
+int trx_index_add(trx_index* idx, const void* x, int64_t n, int dtype);
+
+/* Same, x already in DEVICE memory of the index's device; enqueued on `stream` (hipStream_t). */
+int trx_index_add_device(trx_index* idx, const void* x, int64_t n, int dtype, void* stream);
+
+/* index.ntotal */
+int64_t trx_index_ntotal(const trx_index* idx);
+
+/* index.d */
+int trx_index_dim(const trx_index* idx);
+
+/* index.reset(): drop all vectors, keep d / metric / device. */
+int trx_index_reset(trx_index* idx);
+
+/* del index */
+void trx_index_destroy(trx_index* idx);
+
+/* distance, rank = index.search(q, k)  [retrieve_faiss.py:70-71]: HOST in, HOST out.
+ * D: float[nq*k], I: int64[nq*k], caller-allocated. */
+int trx_index_search(trx_index* idx, const void* q, int64_t nq, int dtype, int k, float* D,
+                     int64_t* I);
+
+/* Same with q, D, I in DEVICE memory; enqueued on `stream`.  This is the form bench.py times
+ * (inputs resident in HBM) and the one the row-sharded multi-GPU path uses. */
+int trx_index_search_device(trx_index* idx, const void* q, int64_t nq, int dtype, int k, float* D,
+                            int64_t* I, void* stream);
+
+/* Same as trx_index_search_device, and additionally writes the fp64 canonical scores S[nq*k]
+ * (pads: +-FLT_MAX as double).  The row-sharded search all-gathers (S, I + shard offset) so that
+ * the merge below orders by exactly the values a single unsharded index orders by. */
+int trx_index_search_device_s64(trx_index* idx, const void* q, int64_t nq, int dtype, int k, float* D,
+                                int64_t* I, double* S, void* stream);
+
+/* Merge step of the row-sharded search: nlists result lists per query,
+ * ids already global, DEVICE memory, layout S_lists/I_lists [nlists][nq][k] exactly as an
+ * all-gather of per-shard (S, I) leaves them (nlists <= 16).  Same total order as a single
+ * unsharded index: score best first on the fp64 value, then id ascending; D = (float)S. */
+int trx_merge_topk_device(int metric, int nlists, int64_t nq, int k, const double* S_lists,
+                          const int64_t* I_lists, float* D, int64_t* I, void* stream);
+
+/* Counters of the most recent search on this index (all zero before the first one). */
+typedef struct trx_search_stats {
+    int64_t nq;            /* queries in the call */
+    int64_t n_uncertified; /* queries whose candidate set could not be certified exact and were
+                              re-done by the exact fp64 scan (0 on benign inputs) */
+    int32_t k_split;       /* K of the bf16 MFMA contraction: d (inputs exact in bf16) or 3d */
+    int32_t n_splits;      /* corpus column-splits per query tile in the scan kernel */
+    int32_t exact_class;   /* 1 = all partial sums exactly representable (integer inputs) */
+    int32_t scan_launches; /* scan-kernel launches in the call */
+    float scan_ms;         /* HIP-event time of the scan kernel(s), valid when timing is enabled */
+    float total_ms;        /* HIP-event time of the whole call on its stream, ditto */
+} trx_search_stats;
+
+int trx_index_last_stats(const trx_index* idx, trx_search_stats* out);
+
+/* Enable (1) / disable (0) HIP-event timing of the scan kernel inside search calls.  Timing makes
+ * the call synchronise at its end; leave it off for overlapped pipelines. */
+int trx_index_set_timing(trx_index* idx, int enabled);
+
+/* Message of the last error on this thread ("" if none). */
+const char* trx_last_error(void);
+
+/* Library version string, e.g. "trxknn 0.1 (gfx950)". */
+const char* trx_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRX_KNN_H */

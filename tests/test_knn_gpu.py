@@ -1,0 +1,169 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle, bit for bit.
+
+Bar: I identical (int64) and D identical (float32 bits) to oracle.knn_canonical on every input
+class; on inputs whose fp32 partial sums are exact the oracle's literal FAISS restatement gives
+the same answer too (checked in tests/test_oracle.py on the CPU side).
+"""
+import numpy as np
+import pytest
+
+from _data import bf16_round, gaussian, grid, morgan_like, reaction_fp_like
+
+pytestmark = pytest.mark.gpu
+
+IP, L2 = 0, 1
+
+
+def _index(metric, d):
+    import textreact_amd.faiss_compat as faiss
+    return faiss.IndexFlatIP(d) if metric == IP else faiss.IndexFlatL2(d)
+
+
+def _check(metric, x, y, k, chunks=1, expect_exact_class=None):
+    from oracle import flat_knn as oracle
+    idx = _index(metric, y.shape[1])
+    for part in np.array_split(y, chunks):
+        idx.add(part)
+    assert idx.ntotal == y.shape[0]
+    D, I = idx.search(x, k)
+    Dr, Ir = oracle.knn_canonical(metric, x, y, k)
+    st = idx.last_stats()
+    bad = np.argwhere(I != Ir)
+    assert bad.size == 0, "index mismatch at %r (first: got %r want %r) stats=%r" % (
+        bad[:5].tolist(), I[bad[0][0]].tolist() if bad.size else None, Ir[bad[0][0]].tolist() if bad.size else None, st)
+    assert np.array_equal(D.view(np.uint32), Dr.view(np.uint32)), "distance bits differ, stats=%r" % (st,)
+    if expect_exact_class is not None:
+        assert st["exact_class"] == int(expect_exact_class), st
+    return st
+
+
+@pytest.mark.parametrize("metric", [IP, L2])
+def test_c0_gaussian_fp32(metric):
+    # BASELINE.json configs[0]: 10k x 768 fp32 corpus, 1k queries, top-10 (split-bf16 operand, K = 3d)
+    st = _check(metric, gaussian(1000, 768, 5678), gaussian(10000, 768, 1234), 10)
+    assert st["k_split"] == 3 * 768 and st["n_uncertified"] == 0
+
+
+@pytest.mark.parametrize("metric", [IP, L2])
+def test_gaussian_bf16_values(metric):
+    # bf16-representable inputs -> plain operand, K = d
+    st = _check(metric, bf16_round(gaussian(700, 768, 5678)), bf16_round(gaussian(20000, 768, 1234)), 10)
+    assert st["k_split"] == 768 and st["n_uncertified"] == 0
+
+
+@pytest.mark.parametrize("metric", [IP, L2])
+def test_grid_ties(metric):
+    _check(metric, grid(300, 128, 2), grid(9000, 128, 1), 10)
+
+
+def test_reaction_fingerprints_l2_k20():
+    # the reference's own call: IndexFlatL2, k = 20, d = 2048 integer counts, train searches itself
+    y = reaction_fp_like(6000, 2048, 7)
+    st = _check(L2, y[:500], y, 20, expect_exact_class=True)
+    assert st["n_uncertified"] == 0
+
+
+def test_morgan_fingerprints_l2_k20():
+    y = morgan_like(8000, 1024, 8)
+    y[100:140] = y[100]  # exact duplicates: distance-0 ties resolved by id
+    _check(L2, y[:300], y, 20, expect_exact_class=True)
+
+
+@pytest.mark.parametrize("metric", [IP, L2])
+def test_fingerprints_ip_and_l2_ties(metric):
+    y = morgan_like(5000, 256, 9)
+    _check(metric, y[:200], y, 20)
+
+
+@pytest.mark.parametrize("nq", [1, 5, 19, 20, 257])
+def test_small_query_counts(nq):
+    _check(IP, gaussian(nq, 96, 3), gaussian(3000, 96, 4), 10)
+
+
+@pytest.mark.parametrize("n,d", [(1, 8), (7, 100), (255, 33), (256, 64), (257, 65), (1000, 130)])
+def test_ragged_shapes(n, d):
+    for metric in (IP, L2):
+        _check(metric, gaussian(33, d, 11), gaussian(n, d, 12), 10)
+
+
+def test_k_larger_than_n_and_empty():
+    import textreact_amd.faiss_compat as faiss
+    idx = faiss.IndexFlatIP(16)
+    D, I = idx.search(gaussian(3, 16, 1), 4)
+    assert (I == -1).all() and (D == -np.finfo(np.float32).max).all()
+    _check(IP, gaussian(9, 16, 1), gaussian(4, 16, 2), 6)
+    _check(L2, gaussian(9, 16, 1), gaussian(4, 16, 2), 6)
+
+
+def test_sorted_corpus_bursts():
+    # adversarial order: similarity to every query increases with the row id, so each tile beats
+    # everything before it and every append buffer overflows (dense rebuild path)
+    rng = np.random.default_rng(5)
+    base = rng.standard_normal(64).astype(np.float32)
+    scale = np.linspace(0.1, 4.0, 5000, dtype=np.float32)[:, None]
+    y = scale * base[None, :] + 0.01 * rng.standard_normal((5000, 64)).astype(np.float32)
+    x = base[None, :] + 0.05 * rng.standard_normal((300, 64)).astype(np.float32)
+    _check(IP, x, y, 10)
+
+
+def test_add_in_chunks_and_mode_transition():
+    y = np.concatenate([bf16_round(gaussian(3000, 64, 1)), gaussian(2000, 64, 2)])  # exact block, then fp32 block
+    _check(IP, gaussian(100, 64, 3), y, 10, chunks=5)
+    _check(L2, gaussian(100, 64, 3), y, 10, chunks=5)
+
+
+def test_bf16_corpus_fp32_queries():
+    _check(IP, gaussian(100, 64, 3), bf16_round(gaussian(3000, 64, 1)), 10)
+
+
+@pytest.mark.parametrize("k", [1, 12, 13, 24, 25, 64])
+def test_k_range(k):
+    _check(IP, gaussian(40, 48, 3), gaussian(2500, 48, 4), k)
+    _check(L2, gaussian(40, 48, 3), gaussian(2500, 48, 4), k)
+
+
+def test_near_duplicate_cluster_forces_exact_scan():
+    # 200 rows within ~1e-7 of each other: the certificate must fail and the exact scan take over
+    rng = np.random.default_rng(6)
+    y = gaussian(4000, 64, 1)
+    c = gaussian(1, 64, 2)
+    y[1000:1200] = c * (1.0 + 1e-7 * rng.standard_normal((200, 1)).astype(np.float32))
+    x = np.repeat(c, 8, axis=0) + 1e-3 * gaussian(8, 64, 3)
+    st = _check(IP, x, y, 10)
+    assert st["n_uncertified"] > 0
+
+
+def test_dimension_mismatch_raises():
+    import textreact_amd.faiss_compat as faiss
+    idx = faiss.IndexFlatL2(32)
+    with pytest.raises(AssertionError):
+        idx.add(np.zeros((4, 31), dtype=np.float32))
+    idx.add(np.zeros((4, 32), dtype=np.float32))
+    with pytest.raises(AssertionError):
+        idx.search(np.zeros((2, 33), dtype=np.float32), 3)
+
+
+def test_torch_device_path_bf16():
+    import torch
+    import textreact_amd.faiss_compat as faiss
+    from oracle import flat_knn as oracle
+    y = bf16_round(gaussian(30000, 768, 1234)); x = bf16_round(gaussian(1000, 768, 5678))
+    idx = faiss.IndexFlatIP(768)
+    idx.add(torch.from_numpy(y).cuda().bfloat16())
+    D, I = idx.search(torch.from_numpy(x).cuda().bfloat16(), 10)
+    Dr, Ir = oracle.knn_canonical(IP, x, y, 10)
+    assert np.array_equal(I.cpu().numpy(), Ir)
+    assert np.array_equal(D.cpu().numpy().view(np.uint32), Dr.view(np.uint32))
+
+
+def test_int_inputs_like_reference():
+    # the reference hands faiss int64 / int8 arrays (retrieve_faiss.py:26,39)
+    import textreact_amd.faiss_compat as faiss
+    from oracle import flat_knn as oracle
+    y = reaction_fp_like(3000, 512, 3).astype(np.int64)
+    idx = faiss.IndexFlatL2(512)
+    idx.add(y)
+    D, I = idx.search(y[:50].astype(np.int8), 20)
+    Dr, Ir = oracle.knn_faiss(L2, y[:50].astype(np.float32), y.astype(np.float32), 20)
+    assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
+    assert (I[:, 0] == np.arange(50)).all() or (D[:, 0] == 0).all()  # self is a distance-0 neighbour

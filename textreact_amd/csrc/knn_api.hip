@@ -1,0 +1,447 @@
+// knn_api.hip -- the C ABI of include/trx_knn.h over the gfx950 kernels.  Host-side orchestration
+// only: storage of the flat index in HBM, operand layout decisions, launch geometry, the
+// certificate-driven fall-back.  No CPU compute path exists: without a HIP device every entry
+// point that would compute returns TRX_ENODEV / TRX_EHIP.
+#include "../../include/trx_knn.h"
+#include "knn_common.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace trx {
+hipError_t launch_row_stats(const void*, int, int64_t, int, int64_t, void*, float*, hipStream_t);
+hipError_t launch_build_operand(const void*, int, int, int64_t, int, int64_t, bf16_t*, int, hipStream_t);
+hipError_t launch_fill_bias(const float*, int64_t, int64_t, float*, hipStream_t);
+hipError_t launch_widen_rows(const bf16_t*, int64_t, int, int64_t, float*, hipStream_t);
+hipError_t launch_exact_scan(int, int, int, const int*, int, int64_t, const void*, int64_t, const void*,
+                             int64_t, int, int, double*, float*, int64_t*, double*, hipStream_t);
+hipError_t launch_merge(int, int, int64_t, int, const double*, const int64_t*, float*, int64_t*, hipStream_t);
+}  // namespace trx
+
+using namespace trx;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIPCHK(expr)                                                                       \
+    do {                                                                                   \
+        hipError_t e__ = (expr);                                                           \
+        if (e__ != hipSuccess)                                                             \
+            return fail(e__ == hipErrorOutOfMemory ? TRX_ENOMEM : TRX_EHIP,                \
+                        std::string(#expr) + ": " + hipGetErrorString(e__));               \
+    } while (0)
+
+struct HostStats { uint32_t inexact_any, nonint_any, maxabs_bits, maxnorm2_bits; };
+static float bits2f(uint32_t b) { float f; std::memcpy(&f, &b, 4); return f; }
+
+// grow-only device buffer
+struct DevBuf {
+    void* p = nullptr; size_t bytes = 0;
+    int reserve(size_t need) {
+        if (need <= bytes) return TRX_OK;
+        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+        size_t want = need + need / 8;
+        HIPCHK(hipMalloc(&p, want));
+        bytes = want;
+        return TRX_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+};
+
+enum { MODE_EMPTY = 0, MODE_PLAIN = 1, MODE_SPLIT = 2 };
+static int round_up(int64_t v, int m) { return (int)((v + m - 1) / m * m); }
+static int64_t round_up64(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+struct trx_index {
+    int d = 0, metric = 0, device = 0;
+    int64_t n = 0, cap = 0;  // rows stored, row capacity (multiple of TILE_M)
+    int mode = MODE_EMPTY;
+    int Kp = 0;              // row stride of Cg
+    bf16_t* Cg = nullptr;    // GEMM operand [cap][Kp]
+    float* Co = nullptr;     // exact values as f32 [cap][d], SPLIT mode only
+    float* cnorm2 = nullptr; // [cap]
+    float* cbias = nullptr;  // [cap]
+    float maxabs = 0.f, maxnorm2 = 0.f;
+    bool nonint = false;
+    // workspaces
+    DevBuf w_stats, w_qg, w_qnorm2, w_cand, w_cnt, w_thr, w_scratch, w_flag, w_exact, w_io, w_tmp;
+    trx_search_stats stats{};
+    bool timing = false;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+
+    int Kp_for(int mode_) const { return round_up(mode_ == MODE_SPLIT ? 3 * (int64_t)d : d, BK); }
+};
+
+static int set_device(const trx_index* idx) { HIPCHK(hipSetDevice(idx->device)); return TRX_OK; }
+
+static int read_stats(trx_index* idx, hipStream_t st, HostStats* out) {
+    HIPCHK(hipMemcpyAsync(out, idx->w_stats.p, sizeof(HostStats), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return TRX_OK;
+}
+
+// (re)allocate corpus arrays for `newcap` rows in `newmode`, carrying existing rows over.
+static int restructure(trx_index* idx, int64_t newcap, int newmode, hipStream_t st) {
+    const int newKp = idx->Kp_for(newmode);
+    bf16_t* nCg = nullptr; float* nCo = nullptr; float* nn2 = nullptr; float* nb = nullptr;
+    HIPCHK(hipMalloc((void**)&nCg, (size_t)newcap * newKp * sizeof(bf16_t)));
+    HIPCHK(hipMemsetAsync(nCg, 0, (size_t)newcap * newKp * sizeof(bf16_t), st));
+    HIPCHK(hipMalloc((void**)&nn2, (size_t)newcap * sizeof(float)));
+    HIPCHK(hipMemsetAsync(nn2, 0, (size_t)newcap * sizeof(float), st));
+    HIPCHK(hipMalloc((void**)&nb, (size_t)newcap * sizeof(float)));
+    if (newmode == MODE_SPLIT) {
+        HIPCHK(hipMalloc((void**)&nCo, (size_t)newcap * idx->d * sizeof(float)));
+    }
+    if (idx->n > 0) {
+        if (idx->mode == newmode) {
+            HIPCHK(hipMemcpyAsync(nCg, idx->Cg, (size_t)idx->n * newKp * sizeof(bf16_t),
+                                  hipMemcpyDeviceToDevice, st));
+            if (newmode == MODE_SPLIT)
+                HIPCHK(hipMemcpyAsync(nCo, idx->Co, (size_t)idx->n * idx->d * sizeof(float),
+                                      hipMemcpyDeviceToDevice, st));
+        } else {
+            // PLAIN -> SPLIT: exact values are the bf16 ones; widen, then lay out [hi|lo=0|hi]
+            HIPCHK(launch_widen_rows(idx->Cg, idx->n, idx->d, idx->Kp, nCo, st));
+            HIPCHK(launch_build_operand(nCo, 0, 1, idx->n, idx->d, idx->d, nCg, newKp, st));
+        }
+        HIPCHK(hipMemcpyAsync(nn2, idx->cnorm2, (size_t)idx->n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    if (idx->Cg) (void)hipFree(idx->Cg);
+    if (idx->Co) (void)hipFree(idx->Co);
+    if (idx->cnorm2) (void)hipFree(idx->cnorm2);
+    if (idx->cbias) (void)hipFree(idx->cbias);
+    idx->Cg = nCg; idx->Co = nCo; idx->cnorm2 = nn2; idx->cbias = nb;
+    idx->cap = newcap; idx->mode = newmode; idx->Kp = newKp;
+    return TRX_OK;
+}
+
+extern "C" {
+
+const char* trx_last_error(void) { return g_err.c_str(); }
+const char* trx_version(void) { return "trxknn 0.1 (gfx950)"; }
+
+int trx_index_create(int d, int metric, int device, trx_index** out) {
+    if (!out) return fail(TRX_EINVAL, "out is null");
+    *out = nullptr;
+    if (d <= 0 || d > (1 << 20)) return fail(TRX_EINVAL, "d must be in [1, 2^20]");
+    if (metric != TRX_METRIC_IP && metric != TRX_METRIC_L2) return fail(TRX_EINVAL, "unknown metric");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(TRX_ENODEV, "no HIP device visible (this library has no CPU path)");
+    if (device < 0 || device >= ndev) return fail(TRX_EINVAL, "device ordinal out of range");
+    trx_index* idx = new (std::nothrow) trx_index();
+    if (!idx) return fail(TRX_ENOMEM, "host allocation failed");
+    idx->d = d; idx->metric = metric; idx->device = device;
+    *out = idx;
+    return TRX_OK;
+}
+
+void trx_index_destroy(trx_index* idx) {
+    if (!idx) return;
+    (void)hipSetDevice(idx->device);
+    if (idx->Cg) (void)hipFree(idx->Cg);
+    if (idx->Co) (void)hipFree(idx->Co);
+    if (idx->cnorm2) (void)hipFree(idx->cnorm2);
+    if (idx->cbias) (void)hipFree(idx->cbias);
+    DevBuf* bufs[] = {&idx->w_stats, &idx->w_qg, &idx->w_qnorm2, &idx->w_cand, &idx->w_cnt, &idx->w_thr,
+                      &idx->w_scratch, &idx->w_flag, &idx->w_exact, &idx->w_io, &idx->w_tmp};
+    for (DevBuf* b : bufs) b->release();
+    for (auto& e : idx->ev) if (e) (void)hipEventDestroy(e);
+    delete idx;
+}
+
+int64_t trx_index_ntotal(const trx_index* idx) { return idx ? idx->n : -1; }
+int trx_index_dim(const trx_index* idx) { return idx ? idx->d : -1; }
+
+int trx_index_reset(trx_index* idx) {
+    if (!idx) return fail(TRX_EINVAL, "index is null");
+    int rc = set_device(idx); if (rc) return rc;
+    if (idx->Cg) (void)hipFree(idx->Cg);
+    if (idx->Co) (void)hipFree(idx->Co);
+    if (idx->cnorm2) (void)hipFree(idx->cnorm2);
+    if (idx->cbias) (void)hipFree(idx->cbias);
+    idx->Cg = nullptr; idx->Co = nullptr; idx->cnorm2 = nullptr; idx->cbias = nullptr;
+    idx->n = 0; idx->cap = 0; idx->mode = MODE_EMPTY; idx->Kp = 0;
+    idx->maxabs = 0.f; idx->maxnorm2 = 0.f; idx->nonint = false;
+    return TRX_OK;
+}
+
+int trx_index_set_timing(trx_index* idx, int enabled) {
+    if (!idx) return fail(TRX_EINVAL, "index is null");
+    int rc = set_device(idx); if (rc) return rc;
+    idx->timing = enabled != 0;
+    if (idx->timing)
+        for (auto& e : idx->ev) if (!e) HIPCHK(hipEventCreate(&e));
+    return TRX_OK;
+}
+
+int trx_index_last_stats(const trx_index* idx, trx_search_stats* out) {
+    if (!idx || !out) return fail(TRX_EINVAL, "null argument");
+    *out = idx->stats;
+    return TRX_OK;
+}
+
+int trx_index_add_device(trx_index* idx, const void* x, int64_t n, int dtype, void* stream) {
+    if (!idx) return fail(TRX_EINVAL, "index is null");
+    if (n < 0 || (n > 0 && !x)) return fail(TRX_EINVAL, "bad vector block");
+    if (dtype != TRX_DTYPE_F32 && dtype != TRX_DTYPE_BF16) return fail(TRX_EINVAL, "unknown dtype");
+    if (n == 0) return TRX_OK;
+    if (idx->n + n >= (int64_t)0x7fffff00) return fail(TRX_EINVAL, "more than 2^31 rows per index");
+    int rc = set_device(idx); if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int is_bf = dtype == TRX_DTYPE_BF16;
+
+    // classify the block
+    rc = idx->w_stats.reserve(sizeof(HostStats)); if (rc) return rc;
+    rc = idx->w_tmp.reserve((size_t)n * sizeof(float)); if (rc) return rc;
+    HIPCHK(hipMemsetAsync(idx->w_stats.p, 0, sizeof(HostStats), st));
+    HIPCHK(launch_row_stats(x, is_bf, n, idx->d, idx->d, idx->w_stats.p, (float*)idx->w_tmp.p, st));
+    HostStats hs; rc = read_stats(idx, st, &hs); if (rc) return rc;
+
+    int newmode = idx->mode;
+    if (idx->mode == MODE_EMPTY) newmode = hs.inexact_any ? MODE_SPLIT : MODE_PLAIN;
+    else if (idx->mode == MODE_PLAIN && hs.inexact_any) newmode = MODE_SPLIT;
+    int64_t need = idx->n + n, newcap = idx->cap;
+    if (need > newcap) newcap = round_up64(std::max<int64_t>(need, idx->cap + idx->cap / 2), TILE_M);
+    if (newcap != idx->cap || newmode != idx->mode) { rc = restructure(idx, newcap, newmode, st); if (rc) return rc; }
+
+    // append
+    bf16_t* dstg = idx->Cg + idx->n * idx->Kp;
+    if (idx->mode == MODE_SPLIT) {
+        HIPCHK(launch_build_operand(x, is_bf, 1, n, idx->d, idx->d, dstg, idx->Kp, st));
+        float* dsto = idx->Co + idx->n * idx->d;
+        if (is_bf) HIPCHK(launch_widen_rows((const bf16_t*)x, n, idx->d, idx->d, dsto, st));
+        else HIPCHK(hipMemcpyAsync(dsto, x, (size_t)n * idx->d * sizeof(float), hipMemcpyDeviceToDevice, st));
+    } else {
+        HIPCHK(launch_build_operand(x, is_bf, 0, n, idx->d, idx->d, dstg, idx->Kp, st));
+    }
+    HIPCHK(hipMemcpyAsync(idx->cnorm2 + idx->n, idx->w_tmp.p, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    idx->n += n;
+    HIPCHK(launch_fill_bias(idx->cnorm2, idx->n, idx->cap, idx->cbias, st));
+    idx->maxabs = std::max(idx->maxabs, bits2f(hs.maxabs_bits));
+    idx->maxnorm2 = std::max(idx->maxnorm2, bits2f(hs.maxnorm2_bits));
+    idx->nonint = idx->nonint || hs.nonint_any;
+    HIPCHK(hipStreamSynchronize(st));  // x may be freed by the caller on return
+    return TRX_OK;
+}
+
+int trx_index_add(trx_index* idx, const void* x, int64_t n, int dtype) {
+    if (!idx) return fail(TRX_EINVAL, "index is null");
+    if (n < 0 || (n > 0 && !x)) return fail(TRX_EINVAL, "bad vector block");
+    if (dtype != TRX_DTYPE_F32 && dtype != TRX_DTYPE_BF16) return fail(TRX_EINVAL, "unknown dtype");
+    if (n == 0) return TRX_OK;
+    int rc = set_device(idx); if (rc) return rc;
+    const size_t esz = dtype == TRX_DTYPE_BF16 ? 2 : 4;
+    // stream the block through a bounded staging buffer (<= 1 GiB at a time)
+    const int64_t rows_per = std::max<int64_t>(1, ((int64_t)1 << 30) / (int64_t)(idx->d * esz));
+    void* dev = nullptr;
+    HIPCHK(hipMalloc(&dev, (size_t)std::min(rows_per, n) * idx->d * esz));
+    for (int64_t r0 = 0; r0 < n; r0 += rows_per) {
+        const int64_t m = std::min(rows_per, n - r0);
+        hipError_t e = hipMemcpy(dev, (const char*)x + (size_t)r0 * idx->d * esz, (size_t)m * idx->d * esz,
+                                 hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(dev); return fail(TRX_EHIP, hipGetErrorString(e)); }
+        rc = trx_index_add_device(idx, dev, m, dtype, nullptr);
+        if (rc) { (void)hipFree(dev); return rc; }
+    }
+    (void)hipFree(dev);
+    return TRX_OK;
+}
+
+// ---- search --------------------------------------------------------------------------------
+
+static int search_batch(trx_index* idx, const void* q, int64_t nq, int is_bf, int q_split, int exact_class,
+                        float eps_rel, int k, float* D, int64_t* I, double* S64, hipStream_t st) {
+    const int d = idx->d, Kp = idx->Kp;
+    const int64_t q_pad = round_up64(nq, TILE_N);
+    const int nqt = (int)(q_pad / TILE_N);
+    const int64_t n_pad = round_up64(idx->n, TILE_M);
+    const int ntiles = (int)(n_pad / TILE_M);
+    int nsplits = (2048 + nqt - 1) / nqt;
+    nsplits = std::max(1, std::min(nsplits, std::min(ntiles, 256)));
+    int tps = (ntiles + nsplits - 1) / nsplits;
+    nsplits = (ntiles + tps - 1) / tps;  // drop empty trailing splits
+    const int kprime = k <= 12 ? 16 : 32;
+    const int csoft = kprime + (CAP - kprime) / 2;
+    const int nwg = nqt * nsplits;
+
+    int rc;
+    if ((rc = idx->w_qg.reserve((size_t)q_pad * Kp * sizeof(bf16_t)))) return rc;
+    if ((rc = idx->w_qnorm2.reserve((size_t)q_pad * sizeof(float)))) return rc;
+    if ((rc = idx->w_cand.reserve((size_t)q_pad * nsplits * CAP * sizeof(u64)))) return rc;
+    if ((rc = idx->w_cnt.reserve((size_t)q_pad * nsplits * sizeof(u32)))) return rc;
+    if ((rc = idx->w_thr.reserve((size_t)q_pad * nsplits * sizeof(u64)))) return rc;
+    if ((rc = idx->w_scratch.reserve((size_t)nwg * TILE_N * TILE_M * sizeof(float)))) return rc;
+    if ((rc = idx->w_flag.reserve((size_t)(nq + 4) * sizeof(int)))) return rc;
+
+    // query operand + norms
+    HIPCHK(hipMemsetAsync(idx->w_qg.p, 0, (size_t)q_pad * Kp * sizeof(bf16_t), st));
+    HIPCHK(launch_build_operand(q, is_bf, q_split ? 2 : 0, nq, d, d, (bf16_t*)idx->w_qg.p, Kp, st));
+    HIPCHK(hipMemsetAsync(idx->w_stats.p, 0, sizeof(HostStats), st));
+    HIPCHK(launch_row_stats(q, is_bf, nq, d, d, idx->w_stats.p, (float*)idx->w_qnorm2.p, st));
+    int* nflag = (int*)idx->w_flag.p;
+    int* flagged = nflag + 4;
+    HIPCHK(hipMemsetAsync(nflag, 0, 4 * sizeof(int), st));
+
+    ScanParams sp{};
+    sp.corpus = idx->Cg; sp.queries = (const bf16_t*)idx->w_qg.p; sp.cbias = idx->cbias;
+    sp.Kp = Kp; sp.n_valid = (int)idx->n; sp.ntiles = ntiles; sp.tiles_per_split = tps; sp.nsplits = nsplits;
+    sp.nqtiles = nqt; sp.kprime = kprime; sp.csoft = csoft;
+    sp.cand = (u64*)idx->w_cand.p; sp.cand_cnt = (u32*)idx->w_cnt.p; sp.cand_thr = (u64*)idx->w_thr.p;
+    sp.scratch = (float*)idx->w_scratch.p;
+    if (idx->timing) HIPCHK(hipEventRecord(idx->ev[0], st));
+    HIPCHK(launch_scan(sp, idx->metric, st));
+    if (idx->timing) HIPCHK(hipEventRecord(idx->ev[1], st));
+
+    SelectParams se{};
+    se.cand = sp.cand; se.cand_cnt = sp.cand_cnt; se.cand_thr = sp.cand_thr; se.nsplits = nsplits;
+    if (idx->mode == MODE_SPLIT) { se.corpus_orig = idx->Co; se.ld_c = d; se.corpus_is_bf16 = 0; }
+    else { se.corpus_orig = idx->Cg; se.ld_c = Kp; se.corpus_is_bf16 = 1; }
+    se.query_orig = q; se.ld_q = d; se.query_is_bf16 = is_bf;
+    se.d = d; se.metric = idx->metric; se.k = k; se.nq = (int)nq; se.exact_class = exact_class;
+    se.eps_rel = eps_rel; se.qnorm2 = (const float*)idx->w_qnorm2.p; se.ymax_norm2 = idx->maxnorm2;
+    se.D = D; se.I = I; se.S64 = S64; se.flagged = flagged; se.nflagged = nflag;
+    HIPCHK(launch_select(se, st));
+
+    // certificate failures -> exact scan of those queries
+    int nf = 0;
+    HIPCHK(hipMemcpyAsync(&nf, nflag, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (idx->timing) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, idx->ev[0], idx->ev[1]));
+        idx->stats.scan_ms += ms;
+    }
+    idx->stats.scan_launches += 1;
+    idx->stats.n_splits = nsplits;
+    idx->stats.n_uncertified += nf;
+    if (nf > 0) {
+        const int64_t per = std::max<int64_t>(1, ((int64_t)1 << 29) / std::max<int64_t>(1, idx->n * 8));
+        if ((rc = idx->w_exact.reserve((size_t)std::min<int64_t>(per, nf) * idx->n * sizeof(double)))) return rc;
+        for (int f0 = 0; f0 < nf; f0 += (int)per) {
+            const int m = (int)std::min<int64_t>(per, nf - f0);
+            HIPCHK(launch_exact_scan(idx->metric, se.corpus_is_bf16, is_bf, flagged + f0, m, idx->n,
+                                     se.corpus_orig, se.ld_c, q, d, d, k, (double*)idx->w_exact.p, D, I, S64, st));
+        }
+    }
+    return TRX_OK;
+}
+
+static int search_device_impl(trx_index* idx, const void* q, int64_t nq, int dtype, int k, float* D,
+                              int64_t* I, double* S64, void* stream) {
+    if (!idx) return fail(TRX_EINVAL, "index is null");
+    if (nq < 0 || (nq > 0 && (!q || !D || !I))) return fail(TRX_EINVAL, "null query/result pointer");
+    if (k <= 0 || k > TRX_MAX_K) return fail(TRX_EINVAL, "k must be in [1, 2048]");
+    if (dtype != TRX_DTYPE_F32 && dtype != TRX_DTYPE_BF16) return fail(TRX_EINVAL, "unknown dtype");
+    int rc = set_device(idx); if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    idx->stats = trx_search_stats{};
+    idx->stats.nq = nq;
+    if (nq == 0) return TRX_OK;
+    const int is_bf = dtype == TRX_DTYPE_BF16;
+    const int d = idx->d;
+    if (idx->timing) HIPCHK(hipEventRecord(idx->ev[2], st));
+
+    if (idx->n == 0 || k > TRX_FAST_MAX_K) {
+        // empty index: all pads.  large k: exact scan for every query (documented slow path)
+        const int64_t per = std::max<int64_t>(1, ((int64_t)1 << 29) / std::max<int64_t>(1, idx->n * 8));
+        if ((rc = idx->w_exact.reserve((size_t)std::min<int64_t>(per, nq) * std::max<int64_t>(idx->n, 1) * sizeof(double)))) return rc;
+        const void* corig = idx->mode == MODE_SPLIT ? (const void*)idx->Co : (const void*)idx->Cg;
+        const int64_t ldc = idx->mode == MODE_SPLIT ? d : idx->Kp;
+        const int cbf = idx->mode == MODE_SPLIT ? 0 : 1;
+        const size_t esz = is_bf ? 2 : 4;
+        for (int64_t f0 = 0; f0 < nq; f0 += per) {
+            const int m = (int)std::min<int64_t>(per, nq - f0);
+            HIPCHK(launch_exact_scan(idx->metric, cbf, is_bf, nullptr, m, idx->n, corig, ldc,
+                                     (const char*)q + (size_t)f0 * d * esz, d, d, k, (double*)idx->w_exact.p,
+                                     D + f0 * k, I + f0 * k, S64 ? S64 + f0 * k : nullptr, st));
+        }
+        idx->stats.n_uncertified = nq;
+        HIPCHK(hipStreamSynchronize(st));
+        return TRX_OK;
+    }
+
+    // classify the queries once
+    rc = idx->w_stats.reserve(sizeof(HostStats)); if (rc) return rc;
+    HIPCHK(hipMemsetAsync(idx->w_stats.p, 0, sizeof(HostStats), st));
+    HIPCHK(launch_row_stats(q, is_bf, nq, d, d, idx->w_stats.p, nullptr, st));
+    HostStats hs; rc = read_stats(idx, st, &hs); if (rc) return rc;
+    if (hs.inexact_any && idx->mode == MODE_PLAIN) {
+        rc = restructure(idx, idx->cap, MODE_SPLIT, st); if (rc) return rc;
+        HIPCHK(launch_fill_bias(idx->cnorm2, idx->n, idx->cap, idx->cbias, st));
+    }
+    const int q_split = idx->mode == MODE_SPLIT;
+    const float qmax = bits2f(hs.maxabs_bits);
+    // exact class: integer inputs small enough that every fp32 partial sum (and the L2 key) is exact
+    const double prod = (double)idx->Kp * (double)qmax * (double)idx->maxabs;
+    const double keymag = idx->metric == TRX_METRIC_L2 ? 2.0 * prod + (double)idx->d * idx->maxabs * idx->maxabs : prod;
+    const int exact_class = (!q_split && !hs.nonint_any && !idx->nonint && qmax <= 256.f && idx->maxabs <= 256.f &&
+                             keymag < 16777216.0) ? 1 : 0;
+    const float eps_rel = (float)((idx->Kp + 64) * std::ldexp(1.0, -23)) + (q_split ? (float)std::ldexp(1.0, -15) : 0.f);
+    idx->stats.k_split = idx->Kp;
+    idx->stats.exact_class = exact_class;
+
+    const int64_t QB = 65536;
+    const size_t esz = is_bf ? 2 : 4;
+    for (int64_t q0 = 0; q0 < nq; q0 += QB) {
+        const int64_t m = std::min(QB, nq - q0);
+        rc = search_batch(idx, (const char*)q + (size_t)q0 * d * esz, m, is_bf, q_split, exact_class, eps_rel, k,
+                          D + q0 * k, I + q0 * k, S64 ? S64 + q0 * k : nullptr, st);
+        if (rc) return rc;
+    }
+    if (idx->timing) {
+        HIPCHK(hipEventRecord(idx->ev[3], st));
+        HIPCHK(hipEventSynchronize(idx->ev[3]));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, idx->ev[2], idx->ev[3]));
+        idx->stats.total_ms = ms;
+    }
+    return TRX_OK;
+}
+
+int trx_index_search_device(trx_index* idx, const void* q, int64_t nq, int dtype, int k, float* D,
+                            int64_t* I, void* stream) {
+    return search_device_impl(idx, q, nq, dtype, k, D, I, nullptr, stream);
+}
+
+// internal-but-exported: same as above plus the fp64 scores the cross-shard merge orders by
+int trx_index_search_device_s64(trx_index* idx, const void* q, int64_t nq, int dtype, int k, float* D,
+                                int64_t* I, double* S64, void* stream) {
+    return search_device_impl(idx, q, nq, dtype, k, D, I, S64, stream);
+}
+
+int trx_index_search(trx_index* idx, const void* q, int64_t nq, int dtype, int k, float* D, int64_t* I) {
+    if (!idx) return fail(TRX_EINVAL, "index is null");
+    if (nq < 0 || (nq > 0 && (!q || !D || !I))) return fail(TRX_EINVAL, "null query/result pointer");
+    if (k <= 0 || k > TRX_MAX_K) return fail(TRX_EINVAL, "k must be in [1, 2048]");
+    if (dtype != TRX_DTYPE_F32 && dtype != TRX_DTYPE_BF16) return fail(TRX_EINVAL, "unknown dtype");
+    if (nq == 0) return TRX_OK;
+    int rc = set_device(idx); if (rc) return rc;
+    const size_t esz = dtype == TRX_DTYPE_BF16 ? 2 : 4;
+    const size_t qb = (size_t)nq * idx->d * esz, db = (size_t)nq * k * sizeof(float), ib = (size_t)nq * k * sizeof(int64_t);
+    const size_t qoff = 0, doff = round_up64((int64_t)qb, 256), ioff = doff + round_up64((int64_t)db, 256);
+    if ((rc = idx->w_io.reserve(ioff + ib))) return rc;
+    char* base = (char*)idx->w_io.p;
+    HIPCHK(hipMemcpy(base + qoff, q, qb, hipMemcpyHostToDevice));
+    rc = search_device_impl(idx, base + qoff, nq, dtype, k, (float*)(base + doff), (int64_t*)(base + ioff), nullptr, nullptr);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(D, base + doff, db, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(I, base + ioff, ib, hipMemcpyDeviceToHost));
+    return TRX_OK;
+}
+
+int trx_merge_topk_device(int metric, int nlists, int64_t nq, int k, const double* S_lists,
+                          const int64_t* I_lists, float* D, int64_t* I, void* stream) {
+    if (metric != TRX_METRIC_IP && metric != TRX_METRIC_L2) return fail(TRX_EINVAL, "unknown metric");
+    if (nlists <= 0 || nlists > 16) return fail(TRX_EINVAL, "nlists must be in [1, 16]");
+    if (nq < 0 || k <= 0 || k > TRX_MAX_K) return fail(TRX_EINVAL, "bad nq / k");
+    if (nq > 0 && (!S_lists || !I_lists || !D || !I)) return fail(TRX_EINVAL, "null pointer");
+    HIPCHK(launch_merge(metric, nlists, nq, k, S_lists, I_lists, D, I, (hipStream_t)stream));
+    return TRX_OK;
+}
+
+}  // extern "C"

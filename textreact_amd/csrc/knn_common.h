@@ -1,0 +1,154 @@
+// knn_common.h -- shared definitions of the gfx950 flat k-NN kernels (internal; the public
+// boundary is include/trx_knn.h).  Wave = 64 lanes everywhere; no other target is supported.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace trx {
+
+typedef unsigned short bf16_t;  // raw bf16 bits
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+// ---- geometry of the scan kernel ---------------------------------------------------------
+constexpr int TILE_M = 256;     // corpus rows per tile (MFMA M side)
+constexpr int TILE_N = 256;     // queries per workgroup (MFMA N side)
+constexpr int BK = 64;          // K-step staged through LDS
+constexpr int SCAN_THREADS = 512;
+constexpr int CAP = 64;         // candidate slots per (query, split): one per lane of a wave
+constexpr int KEEP = 32;        // entries the select kernel re-scores exactly (>= TRX_FAST_MAX_K)
+
+// ---- bf16 helpers ------------------------------------------------------------------------
+__device__ __forceinline__ float bf16_to_f32(bf16_t h) { return __uint_as_float(((u32)h) << 16); }
+// round-to-nearest-even; NaN stays NaN (quiet), inputs are finite in every caller that matters
+__device__ __forceinline__ bf16_t f32_to_bf16_rn(float f) {
+    u32 u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    return (bf16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+// ---- order-preserving packing of (key, id) -------------------------------------------------
+// comp = ordkey(key) << 32 | ~id : larger comp == ranked earlier (key descending, id ascending).
+// comp == 0 is the "empty" sentinel (ordkey never produces 0 for a non-NaN key with ~id == 0
+// only when id == 0xFFFFFFFF, which is never a valid row).
+__device__ __forceinline__ u32 ordkey(float f) {
+    u32 u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ordkey_inv(u32 o) {
+    u32 u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+    return __uint_as_float(u);
+}
+__device__ __forceinline__ u64 make_comp(float key, u32 id) {
+    return ((u64)ordkey(key) << 32) | (u64)(~id);
+}
+__device__ __forceinline__ float comp_key(u64 c) { return ordkey_inv((u32)(c >> 32)); }
+__device__ __forceinline__ u32 comp_id(u64 c) { return ~(u32)c; }
+
+// order-preserving map of a finite-or-inf double to u64 (larger == larger value)
+__device__ __forceinline__ u64 orddbl(double d) {
+    u64 u = (u64)__double_as_longlong(d);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+
+// ---- wave-wide bitonic sorts (64 lanes, one element per lane) -------------------------------
+__device__ __forceinline__ u64 shfl_xor_u64(u64 v, int m) {
+    u32 lo = (u32)v, hi = (u32)(v >> 32);
+    lo = __shfl_xor(lo, m, 64);
+    hi = __shfl_xor(hi, m, 64);
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ u64 shfl_u64(u64 v, int src) {
+    u32 lo = (u32)v, hi = (u32)(v >> 32);
+    lo = __shfl(lo, src, 64);
+    hi = __shfl(hi, src, 64);
+    return ((u64)hi << 32) | lo;
+}
+
+// After the call lane 0 holds the largest value, lane 63 the smallest.
+__device__ __forceinline__ u64 wave_sort_desc(u64 v, int lane) {
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            u64 o = shfl_xor_u64(v, j);
+            bool lower = (lane & j) == 0;
+            bool desc = (lane & k) == 0;          // k == 64: always true -> final order descending
+            bool keep_max = (lower == desc);
+            u64 mx = v > o ? v : o, mn = v > o ? o : v;
+            v = keep_max ? mx : mn;
+        }
+    }
+    return v;
+}
+
+// Sort (score key, id) pairs: lane 0 = largest skey, ties -> smallest id.  skey is an orddbl()
+// style key where LARGER means ranked earlier (callers negate for L2).
+__device__ __forceinline__ void wave_sort_pairs(u64& skey, u32& id, int lane) {
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            u64 ok = shfl_xor_u64(skey, j);
+            u32 oi = __shfl_xor(id, j, 64);
+            bool lower = (lane & j) == 0;
+            bool desc = (lane & k) == 0;
+            bool keep_first = (lower == desc);
+            bool mine_first = (skey > ok) || (skey == ok && id < oi);
+            bool take_mine = (keep_first == mine_first);
+            skey = take_mine ? skey : ok;
+            id = take_mine ? id : oi;
+        }
+    }
+}
+
+// ---- parameters ----------------------------------------------------------------------------
+struct ScanParams {
+    const bf16_t* corpus;    // [n_pad][Kp] bf16, n_pad multiple of TILE_M, pad rows zero
+    const bf16_t* queries;   // [q_pad][Kp] bf16, q_pad multiple of TILE_N, pad rows zero
+    const float* cbias;      // L2: -|y|^2 per corpus row (pad rows -inf); IP: unused
+    int Kp;                  // padded contraction length, multiple of BK
+    int n_valid;             // corpus rows that exist
+    int ntiles;              // n_pad / TILE_M
+    int tiles_per_split;
+    int nsplits;
+    int nqtiles;             // q_pad / TILE_N
+    int kprime;              // entries kept per (query, split) at a compaction (<= KEEP)
+    int csoft;               // compaction trigger: count above this after a tile
+    u64* cand;               // [q_pad][nsplits][CAP] packed (key,id)
+    u32* cand_cnt;           // [q_pad][nsplits]
+    u64* cand_thr;           // [q_pad][nsplits] every unlisted row of the split has comp <= this
+    float* scratch;          // [gridDim.x][TILE_N * TILE_M] dense-tile dump (rare path)
+};
+
+struct SelectParams {
+    const u64* cand;
+    const u32* cand_cnt;
+    const u64* cand_thr;
+    int nsplits;
+    const void* corpus_orig;  // exact values: bf16 [.. ][ld_c] or f32 [..][ld_c]
+    int64_t ld_c;             // row stride in elements
+    const void* query_orig;   // exact query values, bf16 or f32, row stride ld_q
+    int64_t ld_q;
+    int corpus_is_bf16;
+    int query_is_bf16;
+    int d;
+    int metric;
+    int k;
+    int nq;
+    int exact_class;          // 1: no certificate needed
+    float eps_rel;            // certificate slack, relative to bound_q
+    const float* qnorm2;      // fp32 |x_q|^2 (upper-bound use only)
+    float ymax_norm2;         // max |y|^2 over the corpus
+    float* D;
+    int64_t* I;
+    double* S64;              // optional fp64 scores [nq][k] (sharded merge), may be null
+    int* flagged;             // queries that could not be certified
+    int* nflagged;
+};
+
+// launchers implemented in the .hip files
+hipError_t launch_scan(const ScanParams& p, int metric, hipStream_t st);
+hipError_t launch_select(const SelectParams& p, hipStream_t st);
+
+}  // namespace trx

@@ -1,0 +1,175 @@
+// knn_prep.hip -- layout kernels around the scan: classify input rows, build the bf16 GEMM
+// operand (plain or 3-term split), norms / L2 bias.  All HBM-streaming, 16 bytes per lane.
+//
+// Replaces faiss IndexFlat::add (retrieve/retrieve_faiss.py:66: memcpy of N x d fp32 into the
+// index) and the fvec_norms_L2sqr pre-pass of exhaustive_L2sqr_blas.
+//
+// Operand layouts, row stride Kp = round_up(K, 64), pad columns zero:
+//   plain (every value representable in bf16):         [ v(d) ]                     K = d
+//   split (fp32 inputs):  corpus row  [ hi(d) | lo(d) | hi(d) ]                     K = 3d
+//                         query row   [ hi(d) | hi(d) | lo(d) ]
+//     hi = bf16(v), lo = bf16(v - hi):  x.y ~= xh.yh + xh.yl + xl.yh, dropped terms <= 3.1 * 2^-18
+//     per component (DESIGN.md "Exactness"); the MFMA sees one contraction of length 3d.
+#include "knn_common.h"
+
+namespace trx {
+
+struct RowStats {          // device-side accumulators (zeroed before each pass)
+    u32 inexact_any;       // some value is not representable in bf16
+    u32 nonint_any;        // some value is not an integer
+    u32 maxabs_bits;       // max |v| as float bits (non-negative floats order like uints)
+    u32 maxnorm2_bits;     // max over rows of |row|^2
+};
+
+template <bool BF>
+__device__ __forceinline__ float load_val(const void* p, int64_t i) {
+    if (BF) return bf16_to_f32(reinterpret_cast<const bf16_t*>(p)[i]);
+    return reinterpret_cast<const float*>(p)[i];
+}
+
+// one wave per row (grid-stride): stats + fp32 |row|^2
+template <bool BF>
+__global__ __launch_bounds__(256) void row_stats_kernel(const void* x, int64_t n, int d, int64_t ld,
+                                                        RowStats* st, float* norm2) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    u32 inexact = 0, nonint = 0;
+    float maxabs = 0.f, maxn2 = 0.f;
+    for (int64_t r = wave0; r < n; r += nwaves) {
+        const char* row = reinterpret_cast<const char*>(x) + r * ld * (BF ? 2 : 4);
+        float s = 0.f;
+        for (int i = lane; i < d; i += 64) {
+            const float v = load_val<BF>(row, i);
+            s = __builtin_fmaf(v, v, s);
+            const float a = fabsf(v);
+            maxabs = fmaxf(maxabs, a);
+            if (!BF) inexact |= (bf16_to_f32(f32_to_bf16_rn(v)) != v) ? 1u : 0u;
+            nonint |= (rintf(v) != v) ? 1u : 0u;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (lane == 0 && norm2) norm2[r] = s;
+        maxn2 = fmaxf(maxn2, s);
+    }
+    // wave-reduce then one atomic per wave
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        maxabs = fmaxf(maxabs, __shfl_xor(maxabs, o, 64));
+        inexact |= __shfl_xor(inexact, o, 64);
+        nonint |= __shfl_xor(nonint, o, 64);
+    }
+    if (lane == 0) {
+        if (inexact) atomicOr(&st->inexact_any, 1u);
+        if (nonint) atomicOr(&st->nonint_any, 1u);
+        atomicMax(&st->maxabs_bits, __float_as_uint(maxabs));
+        atomicMax(&st->maxnorm2_bits, __float_as_uint(maxn2));
+    }
+}
+
+// Build GEMM operand rows.  One thread per (row, 8-component group).
+// SPLIT: 0 plain, 1 split-corpus [hi|lo|hi], 2 split-query [hi|hi|lo]
+template <bool BF, int SPLIT>
+__global__ __launch_bounds__(256) void build_operand_kernel(const void* x, int64_t n, int d, int64_t ld,
+                                                            bf16_t* out, int Kp) {
+    const int groups = (d + 7) / 8;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n * groups) return;
+    const int64_t r = t / groups;
+    const int g = (int)(t - r * groups);
+    const char* row = reinterpret_cast<const char*>(x) + r * ld * (BF ? 2 : 4);
+    bf16_t* o = out + r * Kp;
+    bf16_t hi[8], lo[8];
+    const int c0 = g * 8;
+    const int cnt = (d - c0) < 8 ? (d - c0) : 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float v = i < cnt ? load_val<BF>(row, c0 + i) : 0.f;
+        hi[i] = f32_to_bf16_rn(v);
+        lo[i] = f32_to_bf16_rn(v - bf16_to_f32(hi[i]));
+    }
+    if ((d & 7) == 0) {
+        // 16-byte stores: every segment start (0, d, 2d) + c0 is a multiple of 8 elements
+        uint4 H, L;
+        H.x = hi[0] | ((u32)hi[1] << 16); H.y = hi[2] | ((u32)hi[3] << 16);
+        H.z = hi[4] | ((u32)hi[5] << 16); H.w = hi[6] | ((u32)hi[7] << 16);
+        L.x = lo[0] | ((u32)lo[1] << 16); L.y = lo[2] | ((u32)lo[3] << 16);
+        L.z = lo[4] | ((u32)lo[5] << 16); L.w = lo[6] | ((u32)lo[7] << 16);
+        *reinterpret_cast<uint4*>(o + c0) = H;
+        if (SPLIT != 0) {
+            *reinterpret_cast<uint4*>(o + d + c0) = (SPLIT == 1) ? L : H;
+            *reinterpret_cast<uint4*>(o + 2 * d + c0) = (SPLIT == 1) ? H : L;
+        }
+    } else {
+        for (int i = 0; i < cnt; ++i) {
+            o[c0 + i] = hi[i];
+            if (SPLIT != 0) {
+                o[d + c0 + i] = (SPLIT == 1) ? lo[i] : hi[i];
+                o[2 * d + c0 + i] = (SPLIT == 1) ? hi[i] : lo[i];
+            }
+        }
+    }
+}
+
+// bias[j] = -norm2[j] for j < n, -inf for n <= j < n_pad
+__global__ void fill_bias_kernel(const float* norm2, int64_t n, int64_t n_pad, float* bias) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_pad) return;
+    bias[j] = j < n ? -norm2[j] : -__builtin_inff();
+}
+
+// widen bf16 rows to f32 rows (plain -> split transition keeps exact values as f32)
+__global__ void widen_rows_kernel(const bf16_t* in, int64_t n, int d, int64_t ld_in, float* out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * d) return;
+    const int64_t r = t / d;
+    const int c = (int)(t - r * d);
+    out[t] = bf16_to_f32(in[r * ld_in + c]);
+}
+
+hipError_t launch_row_stats(const void* x, int is_bf16, int64_t n, int d, int64_t ld, void* stats_dev,
+                            float* norm2, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    int64_t blocks = (n + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    if (is_bf16)
+        hipLaunchKernelGGL(row_stats_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, x, n, d, ld,
+                           reinterpret_cast<RowStats*>(stats_dev), norm2);
+    else
+        hipLaunchKernelGGL(row_stats_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, x, n, d, ld,
+                           reinterpret_cast<RowStats*>(stats_dev), norm2);
+    return hipGetLastError();
+}
+
+hipError_t launch_build_operand(const void* x, int is_bf16, int split_kind, int64_t n, int d, int64_t ld,
+                                bf16_t* out, int Kp, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    const int groups = (d + 7) / 8;
+    const int64_t total = n * groups;
+    dim3 grid((unsigned)((total + 255) / 256)), block(256);
+#define TRX_BO(a, b) hipLaunchKernelGGL((build_operand_kernel<a, b>), grid, block, 0, st, x, n, d, ld, out, Kp)
+    if (is_bf16) {
+        if (split_kind == 0) TRX_BO(true, 0); else if (split_kind == 1) TRX_BO(true, 1); else TRX_BO(true, 2);
+    } else {
+        if (split_kind == 0) TRX_BO(false, 0); else if (split_kind == 1) TRX_BO(false, 1); else TRX_BO(false, 2);
+    }
+#undef TRX_BO
+    return hipGetLastError();
+}
+
+hipError_t launch_fill_bias(const float* norm2, int64_t n, int64_t n_pad, float* bias, hipStream_t st) {
+    if (n_pad <= 0) return hipSuccess;
+    hipLaunchKernelGGL(fill_bias_kernel, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, st, norm2, n,
+                       n_pad, bias);
+    return hipGetLastError();
+}
+
+hipError_t launch_widen_rows(const bf16_t* in, int64_t n, int d, int64_t ld_in, float* out, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    const int64_t total = n * d;
+    hipLaunchKernelGGL(widen_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, in, n, d,
+                       ld_in, out);
+    return hipGetLastError();
+}
+
+}  // namespace trx

@@ -1,0 +1,349 @@
+// knn_scan.hip -- the hot kernel: Q x C^T as a bf16 MFMA GEMM with the top-k selection fused into
+// the epilogue, so the Q x N score matrix never exists.  gfx950 only.
+//
+// Replaces the inside of faiss IndexFlat::search called at retrieve/retrieve_faiss.py:71 (the
+// sgemm blocks + per-query heap of SURVEY.md section 2b rows N2/N3).
+//
+// Shape of the work
+//   workgroup = 512 threads = 8 waves, owns ONE tile of 256 queries and walks a contiguous range
+//   ("split") of 256-row corpus tiles.  Operands are swapped with respect to the usual GEMM
+//   naming: A = corpus rows (MFMA M side), B = queries (MFMA N side), so in the accumulator the
+//   QUERY is on the lane (col = lane & 15) and a lane's registers are consecutive corpus rows:
+//   the per-query running maximum and threshold test are lane-local, no cross-lane traffic.
+//   waves are laid out 2 (M) x 4 (N): each wave owns 128 corpus rows x 64 queries
+//   = 8 x 4 tiles of v_mfma_f32_16x16x32_bf16 = 128 accumulator registers per lane.
+//
+// LDS (one dynamic array, 16-byte aligned carve, 136,208 B -> one workgroup per CU)
+//   A[2][256 rows][128 B] , B[2][256 rows][128 B] : K-step of 64 bf16 per row, double buffered,
+//   16-byte chunk c of row r stored at chunk (c ^ ((r >> 1) & 7)): conflict-free for both the
+//   ds_write_b128 staging pass and the ds_read_b128 fragment reads (bank analysis in DESIGN.md).
+//   thr_comp[256] u64, thr_key[256] f32, cnt[256] u32, ovf[256] u32, flags.
+//
+// Selection (per query, per split), exact with respect to the approximate key:
+//   cand[...][64] is an append buffer.  A row is appended when comp(key, id) > thr_comp, where
+//   thr is the kprime-th best packed (key,id) at the last compaction (0 = none yet).  When a
+//   buffer passes `csoft` entries one wave sorts its 64 slots (bitonic, one slot per lane), keeps
+//   the best kprime and raises thr.  Thresholds only tighten at compactions, so a query compacts
+//   O(log tiles) times.  If a single tile overflows a buffer (always true for the first tile of a
+//   split, rare afterwards) the workgroup dumps the 256 x 256 key tile to an L2-resident scratch
+//   and the affected queries are rebuilt from {older entries} U {all 256 keys of the tile}: no
+//   row is ever lost, whatever the data order.  Result: the list holds the top-kprime of the
+//   split by (key desc, id asc) plus stale extras, and every unlisted row has comp <= thr.
+#include "knn_common.h"
+
+namespace trx {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+constexpr int LDS_A0 = 0;
+constexpr int LDS_B0 = 2 * TILE_M * 128;                  // 65536
+constexpr int LDS_THRC = LDS_B0 + 2 * TILE_N * 128;       // 131072
+constexpr int LDS_THRK = LDS_THRC + TILE_N * 8;
+constexpr int LDS_CNT = LDS_THRK + TILE_N * 4;
+constexpr int LDS_OVF = LDS_CNT + TILE_N * 4;
+constexpr int LDS_FLAGS = LDS_OVF + TILE_N * 4;
+constexpr int LDS_TOTAL = LDS_FLAGS + 16;  // flags[2]: one word per tile parity
+
+constexpr u32 FLAG_COMPACT = 1u;
+constexpr u32 FLAG_DENSE = 2u;
+
+__device__ __forceinline__ u64 ld_u64_l2(const u64* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float ld_f32_l2(const float* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// XCD-contiguous bijective remap of the block id (blocks b and b+8 share an XCD under the
+// observed round-robin placement; speed only, never correctness).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    int base = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    return base + (bid >> 3);
+}
+
+template <bool L2>
+__global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u64* lds_thrc = reinterpret_cast<u64*>(smem + LDS_THRC);
+    float* lds_thrk = reinterpret_cast<float*>(smem + LDS_THRK);
+    u32* lds_cnt = reinterpret_cast<u32*>(smem + LDS_CNT);
+    u32* lds_ovf = reinterpret_cast<u32*>(smem + LDS_OVF);
+    u32* lds_flags = reinterpret_cast<u32*>(smem + LDS_FLAGS);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave >> 2;  // 0..1 : corpus half of the tile
+    const int wave_n = wave & 3;   // 0..3 : 64-query slice
+
+    const int v = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = v % p.nsplits;
+    const int qtile = v / p.nsplits;
+    const int tile0 = split * p.tiles_per_split;
+    int tile1 = tile0 + p.tiles_per_split;
+    if (tile1 > p.ntiles) tile1 = p.ntiles;
+    const int ntl = tile1 > tile0 ? tile1 - tile0 : 0;
+    const int64_t qbase = (int64_t)qtile * TILE_N;
+
+    // ---- init selection state ----
+    if (tid < TILE_N) {
+        lds_thrc[tid] = 0ull;
+        lds_thrk[tid] = -__builtin_inff();
+        lds_cnt[tid] = 0u;
+        lds_ovf[tid] = 0u;
+    }
+    if (tid == 0) { lds_flags[0] = 0u; lds_flags[1] = 0u; }
+
+    const int ksteps = p.Kp / BK;
+    const int total_steps = ntl * ksteps;
+
+    // ---- staging geometry: thread -> (row srow + 64 i, 16-byte chunk schunk) ----
+    const int srow = tid >> 3, schunk = tid & 7;
+    const int w_off = srow * 128 + ((schunk ^ ((srow >> 1) & 7)) << 4);
+    const bf16_t* gA = p.corpus + ((int64_t)tile0 * TILE_M + srow) * p.Kp + schunk * 8;
+    const bf16_t* gB = p.queries + (qbase + srow) * p.Kp + schunk * 8;
+    const int64_t rstride64 = (int64_t)64 * p.Kp;  // 64 rows further down
+
+    // ---- fragment read geometry ----
+    const int frow = lane & 15, fq = lane >> 4;
+    const int swz = frow >> 1;
+    const int r_off0 = frow * 128 + ((fq ^ swz) << 4);
+    const int r_off1 = frow * 128 + (((4 + fq) ^ swz) << 4);
+    const int a_base = wave_m * 128 * 128;  // byte offset of this wave's first A row
+    const int b_base = wave_n * 64 * 128;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // staging registers as named scalars (arrays captured by a lambda ended up in scratch)
+    uint4 stA0, stA1, stA2, stA3, stB0, stB1, stB2, stB3;
+#define TRX_LOAD_STEP(S)                                                                   \
+    {                                                                                      \
+        const int tl_ = (S) / ksteps, ks_ = (S) - tl_ * ksteps;                            \
+        const bf16_t* a_ = gA + (int64_t)tl_ * TILE_M * p.Kp + ks_ * BK;                   \
+        const bf16_t* b_ = gB + ks_ * BK;                                                  \
+        stA0 = *reinterpret_cast<const uint4*>(a_);                                        \
+        stA1 = *reinterpret_cast<const uint4*>(a_ + rstride64);                            \
+        stA2 = *reinterpret_cast<const uint4*>(a_ + 2 * rstride64);                        \
+        stA3 = *reinterpret_cast<const uint4*>(a_ + 3 * rstride64);                        \
+        stB0 = *reinterpret_cast<const uint4*>(b_);                                        \
+        stB1 = *reinterpret_cast<const uint4*>(b_ + rstride64);                            \
+        stB2 = *reinterpret_cast<const uint4*>(b_ + 2 * rstride64);                        \
+        stB3 = *reinterpret_cast<const uint4*>(b_ + 3 * rstride64);                        \
+    }
+#define TRX_STORE_STEP(BUF)                                                                \
+    {                                                                                      \
+        char* A_ = smem + LDS_A0 + (BUF) * (TILE_M * 128) + w_off;                         \
+        char* B_ = smem + LDS_B0 + (BUF) * (TILE_N * 128) + w_off;                         \
+        *reinterpret_cast<uint4*>(A_) = stA0;                                              \
+        *reinterpret_cast<uint4*>(A_ + 64 * 128) = stA1;                                   \
+        *reinterpret_cast<uint4*>(A_ + 128 * 128) = stA2;                                  \
+        *reinterpret_cast<uint4*>(A_ + 192 * 128) = stA3;                                  \
+        *reinterpret_cast<uint4*>(B_) = stB0;                                              \
+        *reinterpret_cast<uint4*>(B_ + 64 * 128) = stB1;                                   \
+        *reinterpret_cast<uint4*>(B_ + 128 * 128) = stB2;                                  \
+        *reinterpret_cast<uint4*>(B_ + 192 * 128) = stB3;                                  \
+    }
+
+    if (total_steps > 0) {
+        TRX_LOAD_STEP(0);
+        TRX_STORE_STEP(0);
+    }
+    __syncthreads();
+
+    int cur = 0;
+    int ks_in_tile = 0;
+    int tl = 0;
+    for (int s = 0; s < total_steps; ++s) {
+        const bool has_next = (s + 1 < total_steps);
+        if (has_next) TRX_LOAD_STEP(s + 1);
+
+        // ---- MFMA over this K-step: two 32-deep sub-steps ----
+        const char* Ab = smem + LDS_A0 + cur * (TILE_M * 128) + a_base;
+        const char* Bb = smem + LDS_B0 + cur * (TILE_N * 128) + b_base;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int ro = kk ? r_off1 : r_off0;
+            bf16x8 af[8], bfr[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                bfr[nt] = *reinterpret_cast<const bf16x8*>(Bb + nt * 2048 + ro);
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt)
+                af[mt] = *reinterpret_cast<const bf16x8*>(Ab + mt * 2048 + ro);
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bfr[nt],
+                                                                          acc[mt][nt], 0, 0, 0);
+        }
+
+        const bool tile_done = (++ks_in_tile == ksteps);
+        const int tile_row0 = (tile0 + tl) * TILE_M;
+
+        if (tile_done) {
+            // ---- epilogue part 1: threshold filter + append (per wave, no barrier) ----
+            // flags word alternates with the tile parity so that a fast wave's appends for the
+            // next tile can never be seen by a slow wave still deciding about this one.
+            u32* flagw = lds_flags + (tl & 1);
+            f32x4 bias[8];
+            if (L2) {
+#pragma unroll
+                for (int mt = 0; mt < 8; ++mt)
+                    bias[mt] = *reinterpret_cast<const f32x4*>(
+                        p.cbias + tile_row0 + wave_m * 128 + mt * 16 + fq * 4);
+#pragma unroll
+                for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            acc[mt][nt][r] = __builtin_fmaf(2.0f, acc[mt][nt][r], bias[mt][r]);
+            }
+            if (tl == 0) {
+                // first tile of the split: no threshold yet, every row would pass -- go straight
+                // to the dense rebuild instead of 65,536 contended appends.
+                if (tid < TILE_N) lds_ovf[tid] = 1u;
+                if (tid == 0) atomicOr(flagw, FLAG_DENSE);
+            } else
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int ql = wave_n * 64 + nt * 16 + frow;
+                const float tk = lds_thrk[ql];
+                float m = acc[0][nt][0];
+#pragma unroll
+                for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) m = fmaxf(m, acc[mt][nt][r]);
+                if (__any(m >= tk)) {
+                    const u64 tc = lds_thrc[ql];
+                    u64* cq = p.cand + ((qbase + ql) * p.nsplits + split) * CAP;
+#pragma unroll
+                    for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float key = acc[mt][nt][r] + 0.0f;  // -0 -> +0
+                            if (key >= tk) {
+                                const u32 id = (u32)(tile_row0 + wave_m * 128 + mt * 16 + fq * 4 + r);
+                                const u64 c = make_comp(key, id);
+                                if (id < (u32)p.n_valid && c > tc) {
+                                    const u32 pos = atomicAdd(&lds_cnt[ql], 1u);
+                                    if (pos < (u32)CAP) {
+                                        cq[pos] = c;
+                                        if (pos >= (u32)p.csoft) atomicOr(flagw, FLAG_COMPACT);
+                                    } else {
+                                        lds_ovf[ql] = 1u;
+                                        atomicOr(flagw, FLAG_DENSE);
+                                    }
+                                }
+                            }
+                        }
+                }
+            }
+        }
+
+        if (has_next) TRX_STORE_STEP(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+
+        if (tile_done) {
+            // ---- epilogue part 2: rare compaction / dense rebuild (workgroup-uniform) ----
+            const u32 fl = lds_flags[tl & 1];
+            if (fl) {
+                float* scr = p.scratch + (int64_t)blockIdx.x * (TILE_N * TILE_M);
+                if (fl & FLAG_DENSE) {
+#pragma unroll
+                    for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt) {
+                            const int ql = wave_n * 64 + nt * 16 + frow;
+                            *reinterpret_cast<f32x4*>(scr + ql * TILE_M + wave_m * 128 + mt * 16 + fq * 4) =
+                                acc[mt][nt];
+                        }
+                }
+                __syncthreads();
+                if (tid == 0) lds_flags[tl & 1] = 0u;
+                for (int i = 0; i < 32; ++i) {
+                    const int ql = wave * 32 + i;
+                    const u32 c = lds_cnt[ql];
+                    const bool dense = lds_ovf[ql] != 0u;
+                    if (!dense && c <= (u32)p.csoft) continue;  // wave-uniform
+                    u64* cq = p.cand + ((qbase + ql) * p.nsplits + split) * CAP;
+                    const u32 cc = c < (u32)CAP ? c : (u32)CAP;
+                    u64 val = (u32)lane < cc ? ld_u64_l2(cq + lane) : 0ull;
+                    if (dense) {
+                        // entries of the current tile are re-derived from the dump
+                        if (val != 0ull && comp_id(val) >= (u32)tile_row0) val = 0ull;
+                        val = wave_sort_desc(val, lane);
+                        for (int ch = 0; ch < TILE_M / 32; ++ch) {
+                            if (lane >= 32) {
+                                const int rl = ch * 32 + (lane - 32);
+                                const float key = ld_f32_l2(scr + ql * TILE_M + rl) + 0.0f;
+                                const u32 id = (u32)(tile_row0 + rl);
+                                val = (id < (u32)p.n_valid && key == key) ? make_comp(key, id) : 0ull;
+                            }
+                            val = wave_sort_desc(val, lane);
+                        }
+                    } else {
+                        val = wave_sort_desc(val, lane);
+                    }
+                    if (lane < p.kprime) cq[lane] = val;
+                    const u64 kept = __ballot(lane < p.kprime && val != 0ull);
+                    const u32 ncnt = (u32)__popcll(kept);
+                    const u64 tval = shfl_u64(val, p.kprime - 1);
+                    if (lane == 0) {
+                        lds_cnt[ql] = ncnt;
+                        lds_ovf[ql] = 0u;
+                        if (ncnt == (u32)p.kprime) {
+                            lds_thrc[ql] = tval;
+                            lds_thrk[ql] = comp_key(tval);
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            ks_in_tile = 0;
+            ++tl;
+        }
+    }
+
+    // ---- publish per-(query, split) count and bound ----
+    __syncthreads();
+    if (tid < TILE_N) {
+        const int64_t o = (qbase + tid) * p.nsplits + split;
+        const u32 c = lds_cnt[tid];
+        p.cand_cnt[o] = c < (u32)CAP ? c : (u32)CAP;
+        p.cand_thr[o] = lds_thrc[tid];
+    }
+}
+
+hipError_t launch_scan(const ScanParams& p, int metric, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_scan_kernel<false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_scan_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    dim3 grid(p.nqtiles * p.nsplits), block(SCAN_THREADS);
+    if (metric == 1)
+        hipLaunchKernelGGL(knn_scan_kernel<true>, grid, block, LDS_TOTAL, st, p);
+    else
+        hipLaunchKernelGGL(knn_scan_kernel<false>, grid, block, LDS_TOTAL, st, p);
+    return hipGetLastError();
+}
+
+}  // namespace trx

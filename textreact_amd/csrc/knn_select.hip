@@ -1,0 +1,325 @@
+// knn_select.hip -- everything after the scan kernel: merge the per-split candidate lists of a
+// query, re-score the survivors with the canonical fp64 fma chain, order them by the total order
+// (score best first, id ascending), certify the answer, and the exact fall-back scan for queries
+// that cannot be certified.  Also the cross-shard merge of the row-sharded multi-GPU search.
+//
+// Canonical score = oracle/flat_knn_ref.c:trxo_score_canonical (same operations, same order):
+//   IP: s = fma((double)x[k], (double)y[k], s)      L2: t = (double)x[k]-(double)y[k]; s = fma(t,t,s)
+// for k = 0..d-1.  fp64 fma is IEEE on gfx950 (v_fma_f64), so the bits agree with the host.
+//
+// Replaces: faiss HeapBlockResultHandler::end_multiple / heap_reorder behind
+// retrieve/retrieve_faiss.py:71, and gives the (D, I) it returns.
+#include "knn_common.h"
+#include <float.h>
+
+namespace trx {
+
+template <bool BF>
+__device__ __forceinline__ double load_as_double(const void* base, int64_t off) {
+    if (BF) return (double)bf16_to_f32(reinterpret_cast<const bf16_t*>(base)[off]);
+    return (double)reinterpret_cast<const float*>(base)[off];
+}
+
+// canonical score of (query row q, corpus row c); one thread walks the whole row in k order.
+template <bool L2, bool CBF, bool QBF>
+__device__ __forceinline__ double canonical_score(const void* qrow, const void* crow, int d) {
+    double s = 0.0;
+    // 8 components per step: 16-byte loads for bf16 rows, 2 x 16 bytes for f32 rows
+    int k = 0;
+    for (; k + 8 <= d; k += 8) {
+        double x[8], y[8];
+        if (QBF) {
+            uint4 u = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(qrow) + k);
+            const u32 w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                x[2 * i] = (double)__uint_as_float(w[i] << 16);
+                x[2 * i + 1] = (double)__uint_as_float(w[i] & 0xffff0000u);
+            }
+        } else {
+            const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(qrow) + k);
+            const float4 b = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(qrow) + k + 4);
+            x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+        }
+        if (CBF) {
+            uint4 u = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(crow) + k);
+            const u32 w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                y[2 * i] = (double)__uint_as_float(w[i] << 16);
+                y[2 * i + 1] = (double)__uint_as_float(w[i] & 0xffff0000u);
+            }
+        } else {
+            const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(crow) + k);
+            const float4 b = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(crow) + k + 4);
+            y[0] = a.x; y[1] = a.y; y[2] = a.z; y[3] = a.w; y[4] = b.x; y[5] = b.y; y[6] = b.z; y[7] = b.w;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (L2) { const double t = x[i] - y[i]; s = __builtin_fma(t, t, s); }
+            else s = __builtin_fma(x[i], y[i], s);
+        }
+    }
+    for (; k < d; ++k) {
+        const double x = load_as_double<QBF>(qrow, k), y = load_as_double<CBF>(crow, k);
+        if (L2) { const double t = x - y; s = __builtin_fma(t, t, s); }
+        else s = __builtin_fma(x, y, s);
+    }
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------
+// select: one wave per query.
+template <bool L2, bool CBF, bool QBF>
+__global__ __launch_bounds__(256) void knn_select_kernel(SelectParams p) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= p.nq) return;  // wave-uniform
+
+    // ---- 1. merge the split lists by packed approximate (key,id); keep the best KEEP ----
+    u64 v = 0ull;        // lanes 0..31: running best-32, sorted; lanes 32..63: incoming
+    u64 tau = 0ull;      // best packed key of anything NOT kept (0 = nothing dropped)
+    bool first = true;
+    for (int s = 0; s < p.nsplits; ++s) {
+        const int64_t o = (int64_t)q * p.nsplits + s;
+        const int c = (int)p.cand_cnt[o];
+        const u64 thr = p.cand_thr[o];
+        tau = thr > tau ? thr : tau;
+        const u64* cq = p.cand + o * CAP;
+        for (int base = 0; base < c; base += 32) {
+            if (first) {
+                // first chunk may fill all 64 lanes
+                v = lane < c ? cq[lane] : 0ull;
+                base += 32;
+                first = false;
+            } else {
+                const u64 dropped = shfl_u64(v, 32);  // best of the lanes about to be replaced
+                tau = dropped > tau ? dropped : tau;
+                if (lane >= 32) v = (base + lane - 32) < c ? cq[base + lane - 32] : 0ull;
+            }
+            v = wave_sort_desc(v, lane);
+        }
+    }
+    {
+        const u64 dropped = shfl_u64(v, KEEP);
+        tau = dropped > tau ? dropped : tau;
+    }
+    const bool have = lane < KEEP && v != 0ull;
+    const u32 id = have ? comp_id(v) : 0xffffffffu;
+
+    // ---- 2. canonical fp64 score of each kept candidate (one lane per candidate) ----
+    const char* qrow = reinterpret_cast<const char*>(p.query_orig) + (int64_t)q * p.ld_q * (QBF ? 2 : 4);
+    double sc = 0.0;
+    if (have) {
+        const char* crow = reinterpret_cast<const char*>(p.corpus_orig) + (int64_t)id * p.ld_c * (CBF ? 2 : 4);
+        sc = canonical_score<L2, CBF, QBF>(qrow, crow, p.d);
+    }
+    // NaN scores never rank (oracle: skipped)
+    const bool ranked = have && (sc == sc);
+    // sort key: larger == earlier.  IP: score itself; L2: negated.
+    u64 skey = ranked ? orddbl(L2 ? -sc : sc) : 0ull;
+    u32 sid = ranked ? id : 0xffffffffu;
+    // carry the score along by re-deriving it from skey after the sort (orddbl is a bijection)
+    wave_sort_pairs(skey, sid, lane);
+    const int nranked = __popcll(__ballot(skey != 0ull));
+
+    // decode score
+    double ssc;
+    {
+        const u64 u = (skey >> 63) ? (skey & 0x7fffffffffffffffull) : ~skey;
+        const double dv = __longlong_as_double((long long)u);
+        ssc = L2 ? -dv : dv;
+    }
+
+    // ---- 3. certificate: can any row outside the kept set reach the k-th place? ----
+    bool certified = true;
+    if (!p.exact_class && tau != 0ull) {
+        const int kk = p.k < nranked ? p.k : nranked;
+        if (kk < p.k) {
+            certified = false;  // fewer ranked candidates than k although rows were dropped
+        } else {
+            const double s_k = __shfl(ssc, p.k - 1, 64);  // exact score in k-th place
+            const float tau_key = comp_key(tau);
+            const float xn2 = p.qnorm2[q];
+            const float bq = L2 ? (2.0f * sqrtf(xn2 * p.ymax_norm2) + p.ymax_norm2)
+                                : sqrtf(xn2 * p.ymax_norm2);
+            const double eps = (double)p.eps_rel * (double)bq * 1.0001 + 1e-30;
+            const double bound = (double)tau_key + eps;  // upper bound of an outsider's exact key
+            if (L2) {
+                // key = |x|^2 - dist  (exact |x|^2 in fp64, k-ordered)
+                double xx = 0.0;
+                for (int i = 0; i < p.d; ++i) {
+                    const double t = load_as_double<QBF>(qrow, i);
+                    xx = __builtin_fma(t, t, xx);
+                }
+                certified = (xx - s_k) > bound;
+            } else {
+                certified = s_k > bound;
+            }
+        }
+    }
+
+    // ---- 4. write D, I (and fp64 scores for the sharded merge) ----
+    if (lane < p.k) {
+        const bool ok = lane < nranked;
+        const int64_t o = (int64_t)q * p.k + lane;
+        p.D[o] = ok ? (float)ssc : (L2 ? FLT_MAX : -FLT_MAX);
+        p.I[o] = ok ? (int64_t)sid : (int64_t)-1;
+        if (p.S64) p.S64[o] = ok ? ssc : (L2 ? (double)FLT_MAX : -(double)FLT_MAX);
+    }
+    if (!certified && lane == 0) {
+        const int pos = atomicAdd(p.nflagged, 1);
+        p.flagged[pos] = q;
+    }
+}
+
+hipError_t launch_select(const SelectParams& p, hipStream_t st) {
+    dim3 grid((p.nq + 3) / 4), block(256);
+    if (p.nq <= 0) return hipSuccess;
+    const int sel = (p.metric ? 4 : 0) | (p.corpus_is_bf16 ? 2 : 0) | (p.query_is_bf16 ? 1 : 0);
+    switch (sel) {
+        case 0: hipLaunchKernelGGL((knn_select_kernel<false, false, false>), grid, block, 0, st, p); break;
+        case 1: hipLaunchKernelGGL((knn_select_kernel<false, false, true>), grid, block, 0, st, p); break;
+        case 2: hipLaunchKernelGGL((knn_select_kernel<false, true, false>), grid, block, 0, st, p); break;
+        case 3: hipLaunchKernelGGL((knn_select_kernel<false, true, true>), grid, block, 0, st, p); break;
+        case 4: hipLaunchKernelGGL((knn_select_kernel<true, false, false>), grid, block, 0, st, p); break;
+        case 5: hipLaunchKernelGGL((knn_select_kernel<true, false, true>), grid, block, 0, st, p); break;
+        case 6: hipLaunchKernelGGL((knn_select_kernel<true, true, false>), grid, block, 0, st, p); break;
+        default: hipLaunchKernelGGL((knn_select_kernel<true, true, true>), grid, block, 0, st, p); break;
+    }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// exact scan (fall-back and k > TRX_FAST_MAX_K): canonical scores of `nf` listed queries against
+// every corpus row, then k rounds of "next best after the previous pick" per query.
+template <bool L2, bool CBF, bool QBF>
+__global__ __launch_bounds__(256) void exact_scores_kernel(const int* qlist, int nf, int64_t n,
+                                                           const void* corpus, int64_t ld_c,
+                                                           const void* queries, int64_t ld_q, int d,
+                                                           double* out /* [nf][n] */) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int f = blockIdx.y;
+    if (f >= nf || j >= n) return;
+    const int q = qlist ? qlist[f] : f;
+    const char* qrow = reinterpret_cast<const char*>(queries) + (int64_t)q * ld_q * (QBF ? 2 : 4);
+    const char* crow = reinterpret_cast<const char*>(corpus) + j * ld_c * (CBF ? 2 : 4);
+    out[(int64_t)f * n + j] = canonical_score<L2, CBF, QBF>(qrow, crow, d);
+}
+
+template <bool L2>
+__global__ __launch_bounds__(256) void exact_pick_kernel(const int* qlist, int nf, int64_t n, int k,
+                                                         const double* sc, float* D, int64_t* I,
+                                                         double* S64) {
+    __shared__ u64 red_key[256];
+    __shared__ int64_t red_id[256];
+    const int f = blockIdx.x;
+    if (f >= nf) return;
+    const int q = qlist ? qlist[f] : f;
+    const double* row = sc + (int64_t)f * n;
+    u64 prev_key = ~0ull;      // previous pick (sort key: larger == earlier), start above all
+    int64_t prev_id = -1;
+    for (int t = 0; t < k; ++t) {
+        // best element strictly after (prev_key, prev_id) in the total order
+        u64 bk = 0ull; int64_t bi = -1;
+        for (int64_t j = threadIdx.x; j < n; j += 256) {
+            const double s = row[j];
+            if (!(s == s)) continue;
+            const u64 key = orddbl(L2 ? -s : s);
+            const bool after_prev = (key < prev_key) || (key == prev_key && j > prev_id);
+            if (!after_prev) continue;
+            if (bi < 0 || key > bk || (key == bk && j < bi)) { bk = key; bi = j; }
+        }
+        red_key[threadIdx.x] = bk; red_id[threadIdx.x] = bi;
+        __syncthreads();
+        for (int w = 128; w > 0; w >>= 1) {
+            if (threadIdx.x < w) {
+                const u64 ok = red_key[threadIdx.x + w]; const int64_t oi = red_id[threadIdx.x + w];
+                const u64 mk = red_key[threadIdx.x]; const int64_t mi = red_id[threadIdx.x];
+                const bool take = oi >= 0 && (mi < 0 || ok > mk || (ok == mk && oi < mi));
+                if (take) { red_key[threadIdx.x] = ok; red_id[threadIdx.x] = oi; }
+            }
+            __syncthreads();
+        }
+        const u64 wk = red_key[0]; const int64_t wi = red_id[0];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int64_t o = (int64_t)q * k + t;
+            if (wi >= 0) {
+                const double s = row[wi];
+                D[o] = (float)s; I[o] = wi; if (S64) S64[o] = s;
+            } else {
+                D[o] = L2 ? FLT_MAX : -FLT_MAX; I[o] = -1;
+                if (S64) S64[o] = L2 ? (double)FLT_MAX : -(double)FLT_MAX;
+            }
+        }
+        if (wi < 0) { prev_key = 0ull; prev_id = INT64_MAX; }  // nothing left: keep writing pads
+        else { prev_key = wk; prev_id = wi; }
+    }
+}
+
+hipError_t launch_exact_scan(int metric, int cbf, int qbf, const int* qlist, int nf, int64_t n,
+                             const void* corpus, int64_t ld_c, const void* queries, int64_t ld_q,
+                             int d, int k, double* sc, float* D, int64_t* I, double* S64,
+                             hipStream_t st) {
+    if (nf <= 0) return hipSuccess;
+    if (n > 0) {
+        dim3 grid((unsigned)((n + 255) / 256), nf), block(256);
+        const int sel = (metric ? 4 : 0) | (cbf ? 2 : 0) | (qbf ? 1 : 0);
+#define TRX_ES(a, b, c) hipLaunchKernelGGL((exact_scores_kernel<a, b, c>), grid, block, 0, st, qlist, nf, n, corpus, ld_c, queries, ld_q, d, sc)
+        switch (sel) {
+            case 0: TRX_ES(false, false, false); break;
+            case 1: TRX_ES(false, false, true); break;
+            case 2: TRX_ES(false, true, false); break;
+            case 3: TRX_ES(false, true, true); break;
+            case 4: TRX_ES(true, false, false); break;
+            case 5: TRX_ES(true, false, true); break;
+            case 6: TRX_ES(true, true, false); break;
+            default: TRX_ES(true, true, true); break;
+        }
+#undef TRX_ES
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    if (metric) hipLaunchKernelGGL(exact_pick_kernel<true>, dim3(nf), dim3(256), 0, st, qlist, nf, n, k, sc, D, I, S64);
+    else hipLaunchKernelGGL(exact_pick_kernel<false>, dim3(nf), dim3(256), 0, st, qlist, nf, n, k, sc, D, I, S64);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// cross-shard merge: nlists sorted lists per query (fp64 scores, global ids) -> one list.
+// One thread per query; nlists * k is at most a few hundred.
+template <bool L2>
+__global__ void merge_lists_kernel(int nlists, int64_t nq, int k, const double* S, const int64_t* Il,
+                                   float* D, int64_t* I) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    int pos[16];
+    for (int l = 0; l < nlists; ++l) pos[l] = 0;
+    for (int t = 0; t < k; ++t) {
+        int best = -1; double bs = 0.0; int64_t bi = 0;
+        for (int l = 0; l < nlists; ++l) {
+            if (pos[l] >= k) continue;
+            const int64_t o = ((int64_t)l * nq + q) * k + pos[l];
+            const int64_t id = Il[o];
+            if (id < 0) { pos[l] = k; continue; }
+            const double s = S[o];
+            const bool better = best < 0 || (L2 ? s < bs : s > bs) || (s == bs && id < bi);
+            if (better) { best = l; bs = s; bi = id; }
+        }
+        const int64_t o = q * k + t;
+        if (best < 0) { D[o] = L2 ? FLT_MAX : -FLT_MAX; I[o] = -1; }
+        else { D[o] = (float)bs; I[o] = bi; pos[best]++; }
+    }
+}
+
+hipError_t launch_merge(int metric, int nlists, int64_t nq, int k, const double* S, const int64_t* Il,
+                        float* D, int64_t* I, hipStream_t st) {
+    if (nq <= 0) return hipSuccess;
+    dim3 grid((unsigned)((nq + 127) / 128)), block(128);
+    if (metric) hipLaunchKernelGGL(merge_lists_kernel<true>, grid, block, 0, st, nlists, nq, k, S, Il, D, I);
+    else hipLaunchKernelGGL(merge_lists_kernel<false>, grid, block, 0, st, nlists, nq, k, S, Il, D, I);
+    return hipGetLastError();
+}
+
+}  // namespace trx

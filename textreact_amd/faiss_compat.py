@@ -1,0 +1,182 @@
+"""FAISS-shaped flat indexes backed by the gfx950 kernels.
+
+Mirrors the object protocol the reference binds at retrieve/retrieve_faiss.py:65-71::
+
+    index = faiss.IndexFlatL2(d)          # :65
+    index.add(train_fps)                  # :66
+    distance, rank = index.search(q, k)   # :71
+
+so ``import textreact_amd.faiss_compat as faiss`` is the whole change on the reference side
+(INTEGRATION.md).  Same names, argument meaning and error behaviour as faiss' Python wrapper:
+``add``/``search`` take C-contiguous 2-D arrays of any numeric dtype (converted to float32, as
+faiss.swigfaiss replacement_add does -- the reference passes int64 / int8 fingerprints), a
+dimension mismatch raises AssertionError, ``search`` returns ``(D float32[nq,k], I int64[nq,k])``
+best first with ``I = -1`` / ``D = +-3.4e38`` padding when fewer than k vectors are indexed.
+
+Extension beyond faiss (device-resident data, used by bench.py and the sharded search): ``add`` and
+``search`` also accept a ``torch.Tensor`` living on the index's GPU (float32 or bfloat16); search
+then returns torch tensors on that GPU and nothing crosses PCIe.
+
+There is no CPU implementation behind these classes: without libtrxknn.so and a GPU they raise.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+METRIC_INNER_PRODUCT = 0
+METRIC_L2 = 1
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+class IndexFlat:
+    """Exact (brute-force) index.  metric: METRIC_INNER_PRODUCT or METRIC_L2."""
+
+    def __init__(self, d, metric=METRIC_L2, device=None):
+        self.d = int(d)
+        self.metric_type = int(metric)
+        self.is_trained = True
+        if device is None:
+            device = _default_device()
+        self.device = int(device)
+        self._h = ctypes.c_void_p()
+        _lib.check(_lib.lib().trx_index_create(self.d, self.metric_type, self.device, ctypes.byref(self._h)))
+
+    # -- faiss surface ------------------------------------------------------------------------
+    @property
+    def ntotal(self):
+        return int(_lib.lib().trx_index_ntotal(self._h))
+
+    def add(self, x):
+        if _is_torch(x):
+            return self._add_torch(x)
+        x = self._as_f32(x)
+        _lib.check(_lib.lib().trx_index_add(self._h, x.ctypes.data_as(ctypes.c_void_p), x.shape[0], _lib.DTYPE_F32))
+
+    def search(self, x, k):
+        k = int(k)
+        assert k > 0, "k must be positive"
+        if _is_torch(x):
+            return self._search_torch(x, k)
+        x = self._as_f32(x)
+        nq = x.shape[0]
+        D = np.empty((nq, k), dtype=np.float32)
+        I = np.empty((nq, k), dtype=np.int64)
+        _lib.check(_lib.lib().trx_index_search(self._h, x.ctypes.data_as(ctypes.c_void_p), nq, _lib.DTYPE_F32, k,
+                                               D.ctypes.data_as(ctypes.c_void_p), I.ctypes.data_as(ctypes.c_void_p)))
+        return D, I
+
+    def reset(self):
+        _lib.check(_lib.lib().trx_index_reset(self._h))
+
+    # -- extensions ---------------------------------------------------------------------------
+    def set_timing(self, enabled=True):
+        _lib.check(_lib.lib().trx_index_set_timing(self._h, 1 if enabled else 0))
+
+    def last_stats(self):
+        st = _lib.SearchStats()
+        _lib.check(_lib.lib().trx_index_last_stats(self._h, ctypes.byref(st)))
+        return {f: getattr(st, f) for f, _ in st._fields_}
+
+    def search_s64(self, x, k):
+        """torch-only: (D, I, S) with S the fp64 canonical scores (row-sharded merge input)."""
+        return self._search_torch(x, int(k), want_s64=True)
+
+    # -- internals ----------------------------------------------------------------------------
+    def _as_f32(self, x):
+        x = np.asarray(x)
+        assert x.ndim == 2, "expected a 2-D array"
+        assert x.shape[1] == self.d, "dimension mismatch: got %d, index has d=%d" % (x.shape[1], self.d)
+        return np.ascontiguousarray(x, dtype=np.float32)
+
+    def _torch_arg(self, x):
+        import torch
+        assert x.dim() == 2 and x.shape[1] == self.d, "dimension mismatch: got %r, index has d=%d" % (tuple(x.shape), self.d)
+        assert x.is_cuda and x.device.index == self.device, "tensor must live on cuda:%d" % self.device
+        if x.dtype == torch.bfloat16:
+            dt = _lib.DTYPE_BF16
+        else:
+            if x.dtype != torch.float32:
+                x = x.float()
+            dt = _lib.DTYPE_F32
+        return x.contiguous(), dt
+
+    def _add_torch(self, x):
+        import torch
+        x, dt = self._torch_arg(x)
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(_lib.lib().trx_index_add_device(self._h, ctypes.c_void_p(x.data_ptr()), x.shape[0], dt,
+                                                   ctypes.c_void_p(st)))
+
+    def _search_torch(self, x, k, want_s64=False):
+        import torch
+        x, dt = self._torch_arg(x)
+        nq = x.shape[0]
+        dev = torch.device("cuda", self.device)
+        D = torch.empty((nq, k), dtype=torch.float32, device=dev)
+        I = torch.empty((nq, k), dtype=torch.int64, device=dev)
+        st = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        L = _lib.lib()
+        if want_s64:
+            S = torch.empty((nq, k), dtype=torch.float64, device=dev)
+            _lib.check(L.trx_index_search_device_s64(self._h, ctypes.c_void_p(x.data_ptr()), nq, dt, k,
+                                                     ctypes.c_void_p(D.data_ptr()), ctypes.c_void_p(I.data_ptr()),
+                                                     ctypes.c_void_p(S.data_ptr()), st))
+            return D, I, S
+        _lib.check(L.trx_index_search_device(self._h, ctypes.c_void_p(x.data_ptr()), nq, dt, k,
+                                             ctypes.c_void_p(D.data_ptr()), ctypes.c_void_p(I.data_ptr()), st))
+        return D, I
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            try:
+                _lib.lib().trx_index_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+
+class IndexFlatIP(IndexFlat):
+    def __init__(self, d, device=None):
+        super().__init__(d, METRIC_INNER_PRODUCT, device)
+
+
+class IndexFlatL2(IndexFlat):
+    def __init__(self, d, device=None):
+        super().__init__(d, METRIC_L2, device)
+
+
+def merge_topk(metric, S_lists, I_lists):
+    """Cross-shard merge on the GPU (include/trx_knn.h: trx_merge_topk_device).
+    S_lists float64 [nlists, nq, k], I_lists int64 [nlists, nq, k] (global ids), both on one GPU."""
+    import torch
+    assert S_lists.is_cuda and I_lists.is_cuda and S_lists.shape == I_lists.shape and S_lists.dim() == 3
+    S_lists = S_lists.contiguous().double()
+    I_lists = I_lists.contiguous().long()
+    nl, nq, k = S_lists.shape
+    D = torch.empty((nq, k), dtype=torch.float32, device=S_lists.device)
+    I = torch.empty((nq, k), dtype=torch.int64, device=S_lists.device)
+    st = ctypes.c_void_p(torch.cuda.current_stream(S_lists.device.index).cuda_stream)
+    _lib.check(_lib.lib().trx_merge_topk_device(int(metric), nl, nq, k, ctypes.c_void_p(S_lists.data_ptr()),
+                                                ctypes.c_void_p(I_lists.data_ptr()), ctypes.c_void_p(D.data_ptr()),
+                                                ctypes.c_void_p(I.data_ptr()), st))
+    return D, I
+
+
+def _default_device():
+    import os
+    lr = os.environ.get("LOCAL_RANK")
+    if lr is not None:
+        return int(lr)
+    try:
+        import torch
+        if torch.cuda.is_available():
+            return torch.cuda.current_device()
+    except Exception:
+        pass
+    return 0
