@@ -15,8 +15,9 @@
 //
 // LDS (one dynamic array, 16-byte aligned carve, 136,208 B -> one workgroup per CU)
 //   A[2][256 rows][128 B] , B[2][256 rows][128 B] : K-step of 64 bf16 per row, double buffered,
-//   16-byte chunk c of row r stored at chunk (c ^ ((r >> 1) & 7)): conflict-free for both the
-//   ds_write_b128 staging pass and the ds_read_b128 fragment reads (bank analysis in DESIGN.md).
+//   filled by LDS-DMA (global_load_lds_dwordx4, no staging registers); 16-byte chunk c of row r
+//   sits at slot (c ^ ((r >> 1) & 7)) -- the permutation is applied to the per-lane SOURCE address
+//   -- which makes the ds_read_b128 fragment reads conflict-free (bank analysis in DESIGN.md).
 //   thr_comp[256] u64, thr_key[256] f32, cnt[256] u32, ovf[256] u32, flags.
 //
 // Selection (per query, per split), exact with respect to the approximate key:
@@ -99,12 +100,21 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
     const int ksteps = p.Kp / BK;
     const int total_steps = ntl * ksteps;
 
-    // ---- staging geometry: thread -> (row srow + 64 i, 16-byte chunk schunk) ----
-    const int srow = tid >> 3, schunk = tid & 7;
-    const int w_off = srow * 128 + ((schunk ^ ((srow >> 1) & 7)) << 4);
-    const bf16_t* gA = p.corpus + ((int64_t)tile0 * TILE_M + srow) * p.Kp + schunk * 8;
-    const bf16_t* gB = p.queries + (qbase + srow) * p.Kp + schunk * 8;
-    const int64_t rstride64 = (int64_t)64 * p.Kp;  // 64 rows further down
+    // ---- staging geometry (LDS-DMA): wave w moves pieces p = 4w..4w+3 of each operand; a piece is
+    // one global_load_lds_dwordx4 = 8 rows x 128 B, written lane-linear (row p*8 + lane/8, slot
+    // lane%8).  The swizzle lives on the SOURCE: slot s of row r receives global chunk s ^ f(r),
+    // f(r) = (r >> 1) & 7, which is what the fragment reads below undo.
+    const int prow = lane >> 3, pslot = lane & 7;
+    const int c_even = pslot ^ (prow >> 1);        // pieces with (p & 1) == 0
+    const int c_odd = pslot ^ (4 + (prow >> 1));   // pieces with (p & 1) == 1
+    const int64_t rowKp = (int64_t)p.Kp;
+    int poff[4];                                   // element offset of this lane inside a tile, piece i
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        poff[i] = (int)(((wave * 4 + i) * 8 + prow) * rowKp) + ((i & 1) ? c_odd : c_even) * 8;
+    const bf16_t* gA = p.corpus + (int64_t)tile0 * TILE_M * rowKp;
+    const bf16_t* gB = p.queries + qbase * rowKp;
+    const int lds_piece0 = wave * 4 * 1024;        // byte offset of this wave's first piece in a stage
 
     // ---- fragment read geometry ----
     const int frow = lane & 15, fq = lane >> 4;
@@ -120,39 +130,23 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // staging registers as named scalars (arrays captured by a lambda ended up in scratch)
-    uint4 stA0, stA1, stA2, stA3, stB0, stB1, stB2, stB3;
-#define TRX_LOAD_STEP(S)                                                                   \
-    {                                                                                      \
-        const int tl_ = (S) / ksteps, ks_ = (S) - tl_ * ksteps;                            \
-        const bf16_t* a_ = gA + (int64_t)tl_ * TILE_M * p.Kp + ks_ * BK;                   \
-        const bf16_t* b_ = gB + ks_ * BK;                                                  \
-        stA0 = *reinterpret_cast<const uint4*>(a_);                                        \
-        stA1 = *reinterpret_cast<const uint4*>(a_ + rstride64);                            \
-        stA2 = *reinterpret_cast<const uint4*>(a_ + 2 * rstride64);                        \
-        stA3 = *reinterpret_cast<const uint4*>(a_ + 3 * rstride64);                        \
-        stB0 = *reinterpret_cast<const uint4*>(b_);                                        \
-        stB1 = *reinterpret_cast<const uint4*>(b_ + rstride64);                            \
-        stB2 = *reinterpret_cast<const uint4*>(b_ + 2 * rstride64);                        \
-        stB3 = *reinterpret_cast<const uint4*>(b_ + 3 * rstride64);                        \
-    }
-#define TRX_STORE_STEP(BUF)                                                                \
-    {                                                                                      \
-        char* A_ = smem + LDS_A0 + (BUF) * (TILE_M * 128) + w_off;                         \
-        char* B_ = smem + LDS_B0 + (BUF) * (TILE_N * 128) + w_off;                         \
-        *reinterpret_cast<uint4*>(A_) = stA0;                                              \
-        *reinterpret_cast<uint4*>(A_ + 64 * 128) = stA1;                                   \
-        *reinterpret_cast<uint4*>(A_ + 128 * 128) = stA2;                                  \
-        *reinterpret_cast<uint4*>(A_ + 192 * 128) = stA3;                                  \
-        *reinterpret_cast<uint4*>(B_) = stB0;                                              \
-        *reinterpret_cast<uint4*>(B_ + 64 * 128) = stB1;                                   \
-        *reinterpret_cast<uint4*>(B_ + 128 * 128) = stB2;                                  \
-        *reinterpret_cast<uint4*>(B_ + 192 * 128) = stB3;                                  \
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef __attribute__((address_space(1))) const void gbl_void;
+#define TRX_STAGE(S, BUF)                                                                           \
+    {                                                                                               \
+        const int tl_ = (S) / ksteps, ks_ = (S) - tl_ * ksteps;                                     \
+        const bf16_t* a_ = gA + (int64_t)tl_ * TILE_M * rowKp + ks_ * BK;                           \
+        const bf16_t* b_ = gB + ks_ * BK;                                                           \
+        char* la_ = smem + LDS_A0 + (BUF) * (TILE_M * 128) + lds_piece0;                            \
+        char* lb_ = smem + LDS_B0 + (BUF) * (TILE_N * 128) + lds_piece0;                            \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                          \
+            __builtin_amdgcn_global_load_lds((gbl_void*)(a_ + poff[i_]), (lds_void*)(la_ + i_ * 1024), 16, 0, 0); \
+            __builtin_amdgcn_global_load_lds((gbl_void*)(b_ + poff[i_]), (lds_void*)(lb_ + i_ * 1024), 16, 0, 0); \
+        }                                                                                           \
     }
 
     if (total_steps > 0) {
-        TRX_LOAD_STEP(0);
-        TRX_STORE_STEP(0);
+        TRX_STAGE(0, 0);
     }
     __syncthreads();
 
@@ -161,27 +155,44 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
     int tl = 0;
     for (int s = 0; s < total_steps; ++s) {
         const bool has_next = (s + 1 < total_steps);
-        if (has_next) TRX_LOAD_STEP(s + 1);
+        if (has_next) TRX_STAGE(s + 1, cur ^ 1);
 
         // ---- MFMA over this K-step: two 32-deep sub-steps ----
         const char* Ab = smem + LDS_A0 + cur * (TILE_M * 128) + a_base;
         const char* Bb = smem + LDS_B0 + cur * (TILE_N * 128) + b_base;
+        {
+            // Hand-rotated fragment pipeline: 8 groups of 8 MFMAs (group g = (kk, pair of M tiles));
+            // the LDS reads of group g+1 are issued before the MFMAs of group g, and the
+            // sched_barriers keep hipcc from re-serialising them (it otherwise reads two fragments,
+            // waits lgkmcnt(0), issues 8 MFMAs, and so on: 38 % MFMA utilisation).
+            bf16x8 bq[2][4], ap[2][2];
+#define TRX_LOAD_B(KK)                                                                          \
+    _Pragma("unroll") for (int nt_ = 0; nt_ < 4; ++nt_)                                         \
+        bq[KK][nt_] = *reinterpret_cast<const bf16x8*>(Bb + nt_ * 2048 + ((KK) ? r_off1 : r_off0));
+#define TRX_LOAD_A(SLOT, KK, MP)                                                                \
+    _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                            \
+        ap[SLOT][j_] = *reinterpret_cast<const bf16x8*>(Ab + ((MP) * 2 + j_) * 2048 + ((KK) ? r_off1 : r_off0));
+            TRX_LOAD_B(0);
+            TRX_LOAD_A(0, 0, 0);
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int ro = kk ? r_off1 : r_off0;
-            bf16x8 af[8], bfr[4];
+            for (int g = 0; g < 8; ++g) {
+                const int kk = g >> 2, mp = g & 3;
+                if (g + 1 < 8) {
+                    const int kk2 = (g + 1) >> 2, mp2 = (g + 1) & 3;
+                    TRX_LOAD_A((g + 1) & 1, kk2, mp2);
+                    if (mp2 == 0) TRX_LOAD_B(1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-                bfr[nt] = *reinterpret_cast<const bf16x8*>(Bb + nt * 2048 + ro);
+                for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int mt = 0; mt < 8; ++mt)
-                af[mt] = *reinterpret_cast<const bf16x8*>(Ab + mt * 2048 + ro);
-#pragma unroll
-            for (int mt = 0; mt < 8; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bfr[nt],
-                                                                          acc[mt][nt], 0, 0, 0);
+                    for (int nt = 0; nt < 4; ++nt)
+                        acc[mp * 2 + j][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            ap[g & 1][j], bq[kk][nt], acc[mp * 2 + j][nt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#undef TRX_LOAD_A
+#undef TRX_LOAD_B
         }
 
         const bool tile_done = (++ks_in_tile == ksteps);
@@ -248,7 +259,6 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
             }
         }
 
-        if (has_next) TRX_STORE_STEP(cur ^ 1);
         __syncthreads();
         cur ^= 1;
 
