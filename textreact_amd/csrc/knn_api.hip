@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -67,7 +68,7 @@ struct trx_index {
     float maxabs = 0.f, maxnorm2 = 0.f;
     bool nonint = false;
     // workspaces
-    DevBuf w_stats, w_qg, w_qnorm2, w_cand, w_cnt, w_thr, w_scratch, w_flag, w_exact, w_io, w_tmp;
+    DevBuf w_stats, w_qg, w_qnorm2, w_cand, w_cnt, w_thr, w_scratch, w_flag, w_exact, w_io, w_tmp, w_gthr;
     trx_search_stats stats{};
     bool timing = false;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -148,7 +149,7 @@ void trx_index_destroy(trx_index* idx) {
     if (idx->cnorm2) (void)hipFree(idx->cnorm2);
     if (idx->cbias) (void)hipFree(idx->cbias);
     DevBuf* bufs[] = {&idx->w_stats, &idx->w_qg, &idx->w_qnorm2, &idx->w_cand, &idx->w_cnt, &idx->w_thr,
-                      &idx->w_scratch, &idx->w_flag, &idx->w_exact, &idx->w_io, &idx->w_tmp};
+                      &idx->w_scratch, &idx->w_flag, &idx->w_exact, &idx->w_io, &idx->w_tmp, &idx->w_gthr};
     for (DevBuf* b : bufs) b->release();
     for (auto& e : idx->ev) if (e) (void)hipEventDestroy(e);
     delete idx;
@@ -263,6 +264,7 @@ static int search_batch(trx_index* idx, const void* q, int64_t nq, int is_bf, in
     const int ntiles = (int)(n_pad / TILE_M);
     int nsplits = (2048 + nqt - 1) / nqt;
     nsplits = std::max(1, std::min(nsplits, std::min(ntiles, 256)));
+    { const char* e = getenv("TRX_NSPLITS"); if (e) nsplits = std::max(1, std::min(atoi(e), ntiles)); }
     int tps = (ntiles + nsplits - 1) / nsplits;
     nsplits = (ntiles + tps - 1) / tps;  // drop empty trailing splits
     const int kprime = k <= 12 ? 16 : 32;
@@ -277,6 +279,7 @@ static int search_batch(trx_index* idx, const void* q, int64_t nq, int is_bf, in
     if ((rc = idx->w_thr.reserve((size_t)q_pad * nsplits * sizeof(u64)))) return rc;
     if ((rc = idx->w_scratch.reserve((size_t)nwg * TILE_N * TILE_M * sizeof(float)))) return rc;
     if ((rc = idx->w_flag.reserve((size_t)(nq + 4) * sizeof(int)))) return rc;
+    if ((rc = idx->w_gthr.reserve((size_t)q_pad * sizeof(u32)))) return rc;
 
     // query operand + norms
     HIPCHK(hipMemsetAsync(idx->w_qg.p, 0, (size_t)q_pad * Kp * sizeof(bf16_t), st));
@@ -293,6 +296,16 @@ static int search_batch(trx_index* idx, const void* q, int64_t nq, int is_bf, in
     sp.nqtiles = nqt; sp.kprime = kprime; sp.csoft = csoft;
     sp.cand = (u64*)idx->w_cand.p; sp.cand_cnt = (u32*)idx->w_cnt.p; sp.cand_thr = (u64*)idx->w_thr.p;
     sp.scratch = (float*)idx->w_scratch.p;
+    { const char* dbg = getenv("TRX_SCAN_DEBUG"); sp.debug = dbg ? atoi(dbg) : 0; }
+    sp.g_thr = (u32*)idx->w_gthr.p;
+    HIPCHK(hipMemsetAsync(sp.g_thr, 0, (size_t)q_pad * sizeof(u32), st));
+    const bool boot = !getenv("TRX_NO_BOOT") && ntiles > 1;
+    if (boot) {  // seed the shared thresholds: one tile per query tile
+        ScanParams bp = sp;
+        bp.bootstrap = 1; bp.have_boot = 0; bp.nsplits = 1; bp.tiles_per_split = 1;
+        HIPCHK(launch_scan(bp, idx->metric, st));
+    }
+    sp.bootstrap = 0; sp.have_boot = boot ? 1 : 0;
     if (idx->timing) HIPCHK(hipEventRecord(idx->ev[0], st));
     HIPCHK(launch_scan(sp, idx->metric, st));
     if (idx->timing) HIPCHK(hipEventRecord(idx->ev[1], st));

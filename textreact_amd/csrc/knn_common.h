@@ -119,6 +119,11 @@ struct ScanParams {
     u32* cand_cnt;           // [q_pad][nsplits]
     u64* cand_thr;           // [q_pad][nsplits] every unlisted row of the split has comp <= this
     float* scratch;          // [gridDim.x][TILE_N * TILE_M] dense-tile dump (rare path)
+    u32* g_thr;              // [q_pad] ordkey of a key no top-kprime row can be below; shared by all
+                             // workgroups of a query (atomicMax, monotone; a stale read is only looser)
+    int bootstrap;           // 1: threshold bootstrap launch (one tile per query tile, publish g_thr only)
+    int have_boot;           // 1: g_thr was seeded by a bootstrap launch
+    int debug;               // timing-only diagnostics (TRX_SCAN_DEBUG), 0 in production
 };
 
 struct SelectParams {

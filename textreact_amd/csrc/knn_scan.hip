@@ -30,6 +30,12 @@
 //   and the affected queries are rebuilt from {older entries} U {all 256 keys of the tile}: no
 //   row is ever lost, whatever the data order.  Result: the list holds the top-kprime of the
 //   split by (key desc, id asc) plus stale extras, and every unlisted row has comp <= thr.
+//   Thresholds are shared across the splits of a query through g_thr[q] (atomicMax of the key of
+//   a split's kprime-th best): a row below ANY split's kprime-th best has kprime better rows in
+//   that split's list, so no split needs to keep it.  Reads of g_thr may be stale (cross-XCD L2s
+//   are not coherent): a stale value is only a looser threshold, never a wrong one.  A tiny
+//   bootstrap launch (one tile per query tile, dense rebuild) seeds g_thr so the real scan starts
+//   warm and appends O(kprime log N) rows per query in total instead of per split.
 #include "knn_common.h"
 
 namespace trx {
@@ -82,16 +88,24 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
     const int v = xcd_remap(blockIdx.x, gridDim.x);
     const int split = v % p.nsplits;
     const int qtile = v / p.nsplits;
-    const int tile0 = split * p.tiles_per_split;
+    int tile0 = split * p.tiles_per_split;
     int tile1 = tile0 + p.tiles_per_split;
+    if (p.bootstrap) {  // one full tile, spread over the corpus so query tiles do not collide
+        const int span = p.ntiles > 1 ? p.ntiles - 1 : 1;
+        tile0 = (int)(((long long)qtile * 97) % span);
+        tile1 = tile0 + 1;
+    }
     if (tile1 > p.ntiles) tile1 = p.ntiles;
     const int ntl = tile1 > tile0 ? tile1 - tile0 : 0;
     const int64_t qbase = (int64_t)qtile * TILE_N;
 
     // ---- init selection state ----
     if (tid < TILE_N) {
-        lds_thrc[tid] = 0ull;
-        lds_thrk[tid] = -__builtin_inff();
+        const u32 g = (p.have_boot && !p.bootstrap)
+                          ? __hip_atomic_load(p.g_thr + qbase + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                          : 0u;
+        lds_thrc[tid] = (u64)g << 32;  // id part 0 == worst id: ties with the shared key still pass
+        lds_thrk[tid] = g ? ordkey_inv(g) : -__builtin_inff();
         lds_cnt[tid] = 0u;
         lds_ovf[tid] = 0u;
     }
@@ -135,7 +149,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
 #define TRX_STAGE(S, BUF)                                                                           \
     {                                                                                               \
         const int tl_ = (S) / ksteps, ks_ = (S) - tl_ * ksteps;                                     \
-        const bf16_t* a_ = gA + (int64_t)tl_ * TILE_M * rowKp + ks_ * BK;                           \
+        const bf16_t* a_ = gA + (int64_t)((p.debug & 1) ? 0 : tl_) * TILE_M * rowKp + ks_ * BK;                           \
         const bf16_t* b_ = gB + ks_ * BK;                                                           \
         char* la_ = smem + LDS_A0 + (BUF) * (TILE_M * 128) + lds_piece0;                            \
         char* lb_ = smem + LDS_B0 + (BUF) * (TILE_N * 128) + lds_piece0;                            \
@@ -151,16 +165,17 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
     __syncthreads();
 
     int cur = 0;
+    u32 gnext = 0u;
     int ks_in_tile = 0;
     int tl = 0;
     for (int s = 0; s < total_steps; ++s) {
         const bool has_next = (s + 1 < total_steps);
-        if (has_next) TRX_STAGE(s + 1, cur ^ 1);
+        if (has_next && !((p.debug & 4) && s > 2)) TRX_STAGE(s + 1, cur ^ 1);
 
         // ---- MFMA over this K-step: two 32-deep sub-steps ----
         const char* Ab = smem + LDS_A0 + cur * (TILE_M * 128) + a_base;
         const char* Bb = smem + LDS_B0 + cur * (TILE_N * 128) + b_base;
-        {
+        if (!(p.debug & 8)) {
             // Hand-rotated fragment pipeline: 8 groups of 8 MFMAs (group g = (kk, pair of M tiles));
             // the LDS reads of group g+1 are issued before the MFMAs of group g, and the
             // sched_barriers keep hipcc from re-serialising them (it otherwise reads two fragments,
@@ -195,10 +210,12 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
 #undef TRX_LOAD_B
         }
 
+        if (ks_in_tile == 0 && tid < TILE_N)  // latency hidden under the tile's K loop
+            gnext = __hip_atomic_load(p.g_thr + qbase + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const bool tile_done = (++ks_in_tile == ksteps);
         const int tile_row0 = (tile0 + tl) * TILE_M;
 
-        if (tile_done) {
+        if (tile_done && !(p.debug & 2)) {
             // ---- epilogue part 1: threshold filter + append (per wave, no barrier) ----
             // flags word alternates with the tile parity so that a fast wave's appends for the
             // next tile can never be seen by a slow wave still deciding about this one.
@@ -217,8 +234,8 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
                         for (int r = 0; r < 4; ++r)
                             acc[mt][nt][r] = __builtin_fmaf(2.0f, acc[mt][nt][r], bias[mt][r]);
             }
-            if (tl == 0) {
-                // first tile of the split: no threshold yet, every row would pass -- go straight
+            if (tl == 0 && (p.bootstrap || !p.have_boot)) {
+                // cold start: no threshold yet, every row would pass -- go straight
                 // to the dense rebuild instead of 65,536 contended appends.
                 if (tid < TILE_N) lds_ovf[tid] = 1u;
                 if (tid == 0) atomicOr(flagw, FLAG_DENSE);
@@ -227,16 +244,22 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
             for (int nt = 0; nt < 4; ++nt) {
                 const int ql = wave_n * 64 + nt * 16 + frow;
                 const float tk = lds_thrk[ql];
-                float m = acc[0][nt][0];
+                // two-level filter: per-lane maximum of each 4-row group, then of all 32 rows.
+                // Most (wave, nt) pairs have some passing lane on most tiles, so the work after
+                // the first ballot must stay cheap: 8 wave-uniform group tests, and only the
+                // groups that really hold a passing row look at their 4 elements.
+                float gm[8];
 #pragma unroll
                 for (int mt = 0; mt < 8; ++mt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) m = fmaxf(m, acc[mt][nt][r]);
+                    gm[mt] = fmaxf(fmaxf(acc[mt][nt][0], acc[mt][nt][1]), fmaxf(acc[mt][nt][2], acc[mt][nt][3]));
+                const float m = fmaxf(fmaxf(fmaxf(gm[0], gm[1]), fmaxf(gm[2], gm[3])),
+                                      fmaxf(fmaxf(gm[4], gm[5]), fmaxf(gm[6], gm[7])));
                 if (__any(m >= tk)) {
                     const u64 tc = lds_thrc[ql];
                     u64* cq = p.cand + ((qbase + ql) * p.nsplits + split) * CAP;
 #pragma unroll
-                    for (int mt = 0; mt < 8; ++mt)
+                    for (int mt = 0; mt < 8; ++mt) {
+                        if (!__any(gm[mt] >= tk)) continue;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const float key = acc[mt][nt][r] + 0.0f;  // -0 -> +0
@@ -255,6 +278,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
                                 }
                             }
                         }
+                    }
                 }
             }
         }
@@ -310,9 +334,10 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
                     if (lane == 0) {
                         lds_cnt[ql] = ncnt;
                         lds_ovf[ql] = 0u;
-                        if (ncnt == (u32)p.kprime) {
+                        if (ncnt == (u32)p.kprime && tval > lds_thrc[ql]) {
                             lds_thrc[ql] = tval;
                             lds_thrk[ql] = comp_key(tval);
+                            atomicMax(p.g_thr + qbase + ql, (u32)(tval >> 32));
                         }
                     }
                 }
@@ -322,6 +347,12 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
             for (int mt = 0; mt < 8; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            // pick up thresholds other splits have published meanwhile (read by the next filter a
+            // whole tile of barriers later)
+            if (tid < TILE_N && gnext > (u32)(lds_thrc[tid] >> 32)) {
+                lds_thrc[tid] = (u64)gnext << 32;
+                lds_thrk[tid] = ordkey_inv(gnext);
+            }
             ks_in_tile = 0;
             ++tl;
         }
@@ -329,7 +360,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
 
     // ---- publish per-(query, split) count and bound ----
     __syncthreads();
-    if (tid < TILE_N) {
+    if (tid < TILE_N && !p.bootstrap) {
         const int64_t o = (qbase + tid) * p.nsplits + split;
         const u32 c = lds_cnt[tid];
         p.cand_cnt[o] = c < (u32)CAP ? c : (u32)CAP;
@@ -348,7 +379,7 @@ hipError_t launch_scan(const ScanParams& p, int metric, hipStream_t st) {
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    dim3 grid(p.nqtiles * p.nsplits), block(SCAN_THREADS);
+    dim3 grid(p.bootstrap ? p.nqtiles : p.nqtiles * p.nsplits), block(SCAN_THREADS);
     if (metric == 1)
         hipLaunchKernelGGL(knn_scan_kernel<true>, grid, block, LDS_TOTAL, st, p);
     else
