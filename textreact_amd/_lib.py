@@ -6,7 +6,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
-_SO = os.path.join(_CSRC, "libtrxknn.so")
+_SO = os.path.join(_CSRC, os.environ.get("TRX_LIB", "libtrxknn.so"))  # TRX_LIB: diagnostic builds
 
 METRIC_IP, METRIC_L2 = 0, 1
 DTYPE_F32, DTYPE_BF16 = 0, 1

@@ -68,12 +68,13 @@ struct trx_index {
     float maxabs = 0.f, maxnorm2 = 0.f;
     bool nonint = false;
     // workspaces
-    DevBuf w_stats, w_qg, w_qnorm2, w_cand, w_cnt, w_thr, w_scratch, w_flag, w_exact, w_io, w_tmp, w_gthr;
+    DevBuf w_stamp, w_stats, w_qg, w_qnorm2, w_cand, w_cnt, w_thr, w_scratch, w_flag, w_exact, w_io, w_tmp, w_gthr;
     trx_search_stats stats{};
     bool timing = false;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 
-    int Kp_for(int mode_) const { return round_up(mode_ == MODE_SPLIT ? 3 * (int64_t)d : d, BK); }
+    // at least two K-steps: the scan pipeline's prefetch distance is two steps
+    int Kp_for(int mode_) const { return std::max(2 * BK, round_up(mode_ == MODE_SPLIT ? 3 * (int64_t)d : d, BK)); }
 };
 
 static int set_device(const trx_index* idx) { HIPCHK(hipSetDevice(idx->device)); return TRX_OK; }
@@ -88,11 +89,13 @@ static int read_stats(trx_index* idx, hipStream_t st, HostStats* out) {
 static int restructure(trx_index* idx, int64_t newcap, int newmode, hipStream_t st) {
     const int newKp = idx->Kp_for(newmode);
     bf16_t* nCg = nullptr; float* nCo = nullptr; float* nn2 = nullptr; float* nb = nullptr;
-    HIPCHK(hipMalloc((void**)&nCg, (size_t)newcap * newKp * sizeof(bf16_t)));
-    HIPCHK(hipMemsetAsync(nCg, 0, (size_t)newcap * newKp * sizeof(bf16_t), st));
+    // one spare tile behind the last row: the scan's DMA cursors run up to two K-steps past the end
+    const size_t rows_alloc = (size_t)newcap + TILE_M;
+    HIPCHK(hipMalloc((void**)&nCg, rows_alloc * newKp * sizeof(bf16_t)));
+    HIPCHK(hipMemsetAsync(nCg, 0, rows_alloc * newKp * sizeof(bf16_t), st));
     HIPCHK(hipMalloc((void**)&nn2, (size_t)newcap * sizeof(float)));
     HIPCHK(hipMemsetAsync(nn2, 0, (size_t)newcap * sizeof(float), st));
-    HIPCHK(hipMalloc((void**)&nb, (size_t)newcap * sizeof(float)));
+    HIPCHK(hipMalloc((void**)&nb, rows_alloc * sizeof(float)));
     if (newmode == MODE_SPLIT) {
         HIPCHK(hipMalloc((void**)&nCo, (size_t)newcap * idx->d * sizeof(float)));
     }
@@ -222,7 +225,7 @@ int trx_index_add_device(trx_index* idx, const void* x, int64_t n, int dtype, vo
     }
     HIPCHK(hipMemcpyAsync(idx->cnorm2 + idx->n, idx->w_tmp.p, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, st));
     idx->n += n;
-    HIPCHK(launch_fill_bias(idx->cnorm2, idx->n, idx->cap, idx->cbias, st));
+    HIPCHK(launch_fill_bias(idx->cnorm2, idx->n, idx->cap + TILE_M, idx->cbias, st));
     idx->maxabs = std::max(idx->maxabs, bits2f(hs.maxabs_bits));
     idx->maxnorm2 = std::max(idx->maxnorm2, bits2f(hs.maxnorm2_bits));
     idx->nonint = idx->nonint || hs.nonint_any;
@@ -262,7 +265,9 @@ static int search_batch(trx_index* idx, const void* q, int64_t nq, int is_bf, in
     const int nqt = (int)(q_pad / TILE_N);
     const int64_t n_pad = round_up64(idx->n, TILE_M);
     const int ntiles = (int)(n_pad / TILE_M);
-    int nsplits = (2048 + nqt - 1) / nqt;
+    // one workgroup per CU when the query tiles alone fill the chip (measured best on C1: fewer
+    // lists, one cold start per query tile); otherwise split the corpus to reach ~256 workgroups
+    int nsplits = (256 + nqt - 1) / nqt;
     nsplits = std::max(1, std::min(nsplits, std::min(ntiles, 256)));
     { const char* e = getenv("TRX_NSPLITS"); if (e) nsplits = std::max(1, std::min(atoi(e), ntiles)); }
     int tps = (ntiles + nsplits - 1) / nsplits;
@@ -277,7 +282,7 @@ static int search_batch(trx_index* idx, const void* q, int64_t nq, int is_bf, in
     if ((rc = idx->w_cand.reserve((size_t)q_pad * nsplits * CAP * sizeof(u64)))) return rc;
     if ((rc = idx->w_cnt.reserve((size_t)q_pad * nsplits * sizeof(u32)))) return rc;
     if ((rc = idx->w_thr.reserve((size_t)q_pad * nsplits * sizeof(u64)))) return rc;
-    if ((rc = idx->w_scratch.reserve((size_t)nwg * TILE_N * TILE_M * sizeof(float)))) return rc;
+    if ((rc = idx->w_scratch.reserve((size_t)std::max(nwg, nqt) * TILE_N * SPILL * sizeof(u64)))) return rc;
     if ((rc = idx->w_flag.reserve((size_t)(nq + 4) * sizeof(int)))) return rc;
     if ((rc = idx->w_gthr.reserve((size_t)q_pad * sizeof(u32)))) return rc;
 
@@ -295,8 +300,14 @@ static int search_batch(trx_index* idx, const void* q, int64_t nq, int is_bf, in
     sp.Kp = Kp; sp.n_valid = (int)idx->n; sp.ntiles = ntiles; sp.tiles_per_split = tps; sp.nsplits = nsplits;
     sp.nqtiles = nqt; sp.kprime = kprime; sp.csoft = csoft;
     sp.cand = (u64*)idx->w_cand.p; sp.cand_cnt = (u32*)idx->w_cnt.p; sp.cand_thr = (u64*)idx->w_thr.p;
-    sp.scratch = (float*)idx->w_scratch.p;
+    sp.scratch = idx->w_scratch.p;
     { const char* dbg = getenv("TRX_SCAN_DEBUG"); sp.debug = dbg ? atoi(dbg) : 0; }
+    { const char* e = getenv("TRX_POLICY"); sp.policy = e ? atoi(e) : 0; }
+    sp.stamp_out = nullptr;
+#ifdef TRX_STAMP_BUILD
+    if ((rc = idx->w_stamp.reserve((size_t)nwg * 8 * 4 * sizeof(unsigned long long)))) return rc;
+    sp.stamp_out = (unsigned long long*)idx->w_stamp.p;
+#endif
     sp.g_thr = (u32*)idx->w_gthr.p;
     HIPCHK(hipMemsetAsync(sp.g_thr, 0, (size_t)q_pad * sizeof(u32), st));
     const bool boot = !getenv("TRX_NO_BOOT") && ntiles > 1;
@@ -309,6 +320,19 @@ static int search_batch(trx_index* idx, const void* q, int64_t nq, int is_bf, in
     if (idx->timing) HIPCHK(hipEventRecord(idx->ev[0], st));
     HIPCHK(launch_scan(sp, idx->metric, st));
     if (idx->timing) HIPCHK(hipEventRecord(idx->ev[1], st));
+#ifdef TRX_STAMP_BUILD
+    {
+        std::vector<unsigned long long> h((size_t)nwg * 32);
+        HIPCHK(hipMemcpyAsync(h.data(), sp.stamp_out, h.size() * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        double sum[2][4] = {{0}};
+        for (int w = 0; w < nwg; ++w) for (int v = 0; v < 8; ++v) for (int i = 0; i < 4; ++i) sum[v >> 2][i] += (double)h[((size_t)w * 8 + v) * 4 + i];
+        const double nphase = (double)nwg * 4 * 4.0 * tps * (Kp / BK);  // waves per group x phases
+        for (int g = 0; g < 2; ++g)
+            fprintf(stderr, "[stamp] group %d per phase: load-work %.0f  load-barrier %.0f  mfma-issue %.0f  mfma-barrier %.0f cycles\n",
+                    g, sum[g][0] / nphase, sum[g][1] / nphase, sum[g][2] / nphase, sum[g][3] / nphase);
+    }
+#endif
 
     SelectParams se{};
     se.cand = sp.cand; se.cand_cnt = sp.cand_cnt; se.cand_thr = sp.cand_thr; se.nsplits = nsplits;
@@ -385,7 +409,7 @@ static int search_device_impl(trx_index* idx, const void* q, int64_t nq, int dty
     HostStats hs; rc = read_stats(idx, st, &hs); if (rc) return rc;
     if (hs.inexact_any && idx->mode == MODE_PLAIN) {
         rc = restructure(idx, idx->cap, MODE_SPLIT, st); if (rc) return rc;
-        HIPCHK(launch_fill_bias(idx->cnorm2, idx->n, idx->cap, idx->cbias, st));
+        HIPCHK(launch_fill_bias(idx->cnorm2, idx->n, idx->cap + TILE_M, idx->cbias, st));
     }
     const int q_split = idx->mode == MODE_SPLIT;
     const float qmax = bits2f(hs.maxabs_bits);

@@ -17,6 +17,7 @@ constexpr int BK = 64;          // K-step staged through LDS
 constexpr int SCAN_THREADS = 512;
 constexpr int CAP = 64;         // candidate slots per (query, split): one per lane of a wave
 constexpr int KEEP = 32;        // entries the select kernel re-scores exactly (>= TRX_FAST_MAX_K)
+constexpr int SPILL = TILE_M;   // spill slots per query per workgroup (a tile adds at most TILE_M rows)
 
 // ---- bf16 helpers ------------------------------------------------------------------------
 __device__ __forceinline__ float bf16_to_f32(bf16_t h) { return __uint_as_float(((u32)h) << 16); }
@@ -118,12 +119,14 @@ struct ScanParams {
     u64* cand;               // [q_pad][nsplits][CAP] packed (key,id)
     u32* cand_cnt;           // [q_pad][nsplits]
     u64* cand_thr;           // [q_pad][nsplits] every unlisted row of the split has comp <= this
-    float* scratch;          // [gridDim.x][TILE_N * TILE_M] dense-tile dump (rare path)
+    void* scratch;           // [gridDim.x][TILE_N][SPILL] u64 spill slots (rows that do not fit a list)
     u32* g_thr;              // [q_pad] ordkey of a key no top-kprime row can be below; shared by all
                              // workgroups of a query (atomicMax, monotone; a stale read is only looser)
     int bootstrap;           // 1: threshold bootstrap launch (one tile per query tile, publish g_thr only)
     int have_boot;           // 1: g_thr was seeded by a bootstrap launch
+    int policy;              // cache policy of the DMA streams: bit 0 = queries nt, bit 1 = corpus nt
     int debug;               // timing-only diagnostics (TRX_SCAN_DEBUG), 0 in production
+    unsigned long long* stamp_out;  // diagnostic build (-DTRX_STAMP_BUILD) only: [grid][8 waves][4] cycle sums
 };
 
 struct SelectParams {

@@ -70,7 +70,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + (bid >> 3);
 }
 
-template <bool L2>
+template <bool L2, int AUXA, int AUXB>
 __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     u64* lds_thrc = reinterpret_cast<u64*>(smem + LDS_THRC);
@@ -154,8 +154,8 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
         char* la_ = smem + LDS_A0 + (BUF) * (TILE_M * 128) + lds_piece0;                            \
         char* lb_ = smem + LDS_B0 + (BUF) * (TILE_N * 128) + lds_piece0;                            \
         _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                          \
-            __builtin_amdgcn_global_load_lds((gbl_void*)(a_ + poff[i_]), (lds_void*)(la_ + i_ * 1024), 16, 0, 0); \
-            __builtin_amdgcn_global_load_lds((gbl_void*)(b_ + poff[i_]), (lds_void*)(lb_ + i_ * 1024), 16, 0, 0); \
+            __builtin_amdgcn_global_load_lds((gbl_void*)(a_ + poff[i_]), (lds_void*)(la_ + i_ * 1024), 16, 0, AUXA); \
+            __builtin_amdgcn_global_load_lds((gbl_void*)(b_ + poff[i_]), (lds_void*)(lb_ + i_ * 1024), 16, 0, AUXB); \
         }                                                                                           \
     }
 
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
             // ---- epilogue part 2: rare compaction / dense rebuild (workgroup-uniform) ----
             const u32 fl = lds_flags[tl & 1];
             if (fl) {
-                float* scr = p.scratch + (int64_t)blockIdx.x * (TILE_N * TILE_M);
+                float* scr = reinterpret_cast<float*>(p.scratch) + (int64_t)blockIdx.x * (TILE_N * TILE_M);
                 if (fl & FLAG_DENSE) {
 #pragma unroll
                     for (int mt = 0; mt < 8; ++mt)
@@ -368,23 +368,29 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
     }
 }
 
-hipError_t launch_scan(const ScanParams& p, int metric, hipStream_t st) {
+template <bool L2, int AUXA, int AUXB>
+static hipError_t launch_one(const ScanParams& p, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_scan_kernel<false>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_scan_kernel<L2, AUXA, AUXB>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_scan_kernel<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     dim3 grid(p.bootstrap ? p.nqtiles : p.nqtiles * p.nsplits), block(SCAN_THREADS);
-    if (metric == 1)
-        hipLaunchKernelGGL(knn_scan_kernel<true>, grid, block, LDS_TOTAL, st, p);
-    else
-        hipLaunchKernelGGL(knn_scan_kernel<false>, grid, block, LDS_TOTAL, st, p);
+    hipLaunchKernelGGL((knn_scan_kernel<L2, AUXA, AUXB>), grid, block, LDS_TOTAL, st, p);
     return hipGetLastError();
+}
+
+hipError_t launch_scan(const ScanParams& p, int metric, hipStream_t st) {
+    // cache policy of the two LDS-DMA streams: 0 = default, 2 = nt (non-temporal)
+    const int pol = p.policy;
+    if (metric == 1) {
+        switch (pol) { case 1: return launch_one<true, 0, 2>(p, st); case 2: return launch_one<true, 2, 0>(p, st);
+                       case 3: return launch_one<true, 2, 2>(p, st); default: return launch_one<true, 0, 0>(p, st); }
+    }
+    switch (pol) { case 1: return launch_one<false, 0, 2>(p, st); case 2: return launch_one<false, 2, 0>(p, st);
+                   case 3: return launch_one<false, 2, 2>(p, st); default: return launch_one<false, 0, 0>(p, st); }
 }
 
 }  // namespace trx
