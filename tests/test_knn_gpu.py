@@ -167,3 +167,107 @@ def test_int_inputs_like_reference():
     Dr, Ir = oracle.knn_faiss(L2, y[:50].astype(np.float32), y.astype(np.float32), 20)
     assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
     assert (I[:, 0] == np.arange(50)).all() or (D[:, 0] == 0).all()  # self is a distance-0 neighbour
+
+
+# ---- committed golden vectors through the C ABI -----------------------------------------------
+import glob as _glob
+import os as _os
+
+_G = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("path", sorted(_glob.glob(_os.path.join(_G, "knn_*.npz"))))
+def test_golden_vectors_on_gpu(path):
+    z = np.load(path)
+    m, k = int(z["metric"]), int(z["k"])
+    idx = _index(m, z["y"].shape[1])
+    idx.add(z["y"])
+    D, I = idx.search(z["x"], k)
+    assert np.array_equal(I, z["I_canonical"])
+    assert np.array_equal(D.view(np.uint32), z["D_canonical"].view(np.uint32))
+
+
+def test_merge_kernel_equals_oracle_merge():
+    import torch
+    import textreact_amd.faiss_compat as faiss
+    from oracle import flat_knn as oracle
+    y = grid(3000, 64, 3); x = grid(500, 64, 4)
+    for metric in (IP, L2):
+        parts = np.array_split(y, 5)
+        offs = np.cumsum([0] + [len(p) for p in parts[:-1]])
+        Sl, Il, Dl = [], [], []
+        for part, off in zip(parts, offs):
+            idx = _index(metric, 64)
+            idx.add(torch.from_numpy(part).cuda())
+            D, I, S = idx.search_s64(torch.from_numpy(x).cuda(), 10)
+            Sl.append(S); Il.append(torch.where(I >= 0, I + int(off), I)); Dl.append(D)
+        D, I = faiss.merge_topk(metric, torch.stack(Sl), torch.stack(Il))
+        Dr, Ir = oracle.knn_canonical(metric, x, y, 10)
+        assert np.array_equal(I.cpu().numpy(), Ir) and np.array_equal(D.cpu().numpy(), Dr)
+        Dm, Im = oracle.merge_lists(metric, torch.stack(Dl).cpu().numpy(), torch.stack(Il).cpu().numpy())
+        assert np.array_equal(Im, Ir)
+
+
+def test_single_rank_sharded_wrapper():
+    import torch
+    from textreact_amd.sharded import ShardedFlatIndex
+    from oracle import flat_knn as oracle
+    y = gaussian(5000, 64, 1); x = gaussian(64, 64, 2)
+    idx = ShardedFlatIndex(64, IP)
+    idx.add_shard(torch.from_numpy(y).cuda(), 100, 5100)     # offset is applied to the ids
+    D, I = idx.search(torch.from_numpy(x).cuda(), 10)
+    Dr, Ir = oracle.knn_canonical(IP, x, y, 10)
+    assert np.array_equal(I.cpu().numpy(), Ir + 100) and np.array_equal(D.cpu().numpy(), Dr)
+
+
+def test_cli_on_the_real_index(tmp_path):
+    import json
+    import pandas as pd
+    import textreact_amd.retrieve_faiss as rf
+    from oracle import flat_knn as oracle
+    fps = reaction_fp_like(400, 2048, 3)
+    pd.DataFrame({"id": np.arange(300), "canonical_rxn": ["C>>C"] * 300}).to_csv(tmp_path / "train.csv", index=False)
+    pd.DataFrame({"id": np.arange(50) + 1000, "canonical_rxn": ["C>>C"] * 50}).to_csv(tmp_path / "val.csv", index=False)
+    pd.DataFrame({"id": np.arange(50) + 2000, "canonical_rxn": ["C>>C"] * 50}).to_csv(tmp_path / "test.csv", index=False)
+    for name, sl in (("train", slice(0, 300)), ("val", slice(300, 350)), ("test", slice(350, 400))):
+        np.save(tmp_path / (name + ".npy"), fps[sl].astype(np.int64))     # int64 like the reference's arrays
+    rf.main(["--data_path", str(tmp_path), "--train_file", "train.csv", "--valid_file", "val.csv", "--test_file",
+             "test.csv", "--output_path", str(tmp_path / "out"), "--train_vectors", str(tmp_path / "train.npy"),
+             "--valid_vectors", str(tmp_path / "val.npy"), "--test_vectors", str(tmp_path / "test.npy")])
+    got = json.loads((tmp_path / "out" / "test.json").read_text())
+    _, I = oracle.knn_faiss(L2, fps[350:], fps[:300], 20)           # the literal FAISS restatement
+    assert [e["nn"] for e in got] == I.tolist() and [e["id"] for e in got] == list(range(2000, 2050))
+
+
+# ---- BASELINE.json configs[1] at full size: size-independent properties + a sampled oracle check
+def test_c1_full_size_properties():
+    import torch
+    import textreact_amd.faiss_compat as faiss
+    from oracle import flat_knn as oracle
+    n, d, nq, k = 1_000_000, 768, 65_536, 10
+    g = torch.Generator(device="cuda"); g.manual_seed(7)
+    y = torch.randn((n, d), generator=g, device="cuda").bfloat16()
+    x = torch.randn((nq, d), generator=g, device="cuda").bfloat16()
+    x[:4096] = y[::244][:4096]                       # queries that ARE corpus rows
+    for metric, cls in ((IP, faiss.IndexFlatIP), (L2, faiss.IndexFlatL2)):
+        idx = cls(d)
+        idx.add(y)
+        D, I = idx.search(x, k)
+        st = idx.last_stats()
+        assert st["n_uncertified"] < nq // 100
+        Dh, Ih = D.cpu().numpy(), I.cpu().numpy()
+        assert (Ih >= 0).all() and (Ih < n).all()
+        assert all(len(set(r)) == k for r in Ih[:2000].tolist())                       # no duplicates
+        dd = np.diff(Dh, axis=1)
+        assert (dd >= 0).all() if metric == L2 else (dd <= 0).all()                    # best first
+        if metric == L2:
+            assert (Dh[:4096, 0] == 0).all() and (Ih[:4096, 0] == np.arange(4096) * 244).all()   # self at distance 0
+        # idempotence: the same search again returns the same bits
+        D2, I2 = idx.search(x, k)
+        assert torch.equal(I, I2) and torch.equal(D, D2)
+        # sampled exact check against the oracle (64 queries x the full corpus)
+        sel = np.r_[0:8, 4096:4104, np.random.default_rng(0).integers(0, nq, 48)]
+        xs = x[torch.from_numpy(sel).cuda()].float().cpu().numpy()
+        Dr, Ir = oracle.knn_canonical(metric, xs, y.float().cpu().numpy(), k)
+        assert np.array_equal(Ih[sel], Ir) and np.array_equal(Dh[sel].view(np.uint32), Dr.view(np.uint32))
+        del idx

@@ -1,0 +1,60 @@
+"""Neighbor-file contract against goldens produced by the reference's own Python
+(tests/golden/make_golden.py imports /root/reference/textreact/dataset.py)."""
+import json
+import os
+import random
+
+import pytest
+
+from textreact_amd import neighbors as nb
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def golden():
+    with open(os.path.join(G, "neighbors_expected.json")) as f:
+        return json.load(f)
+
+
+def test_reader_matches_reference_load_corpus(golden):
+    got = nb.read_neighbors(os.path.join(G, "neighbors_input.json"))
+    for case in golden["cases"]:
+        assert got == case["neighbors"]
+
+
+def test_get_neighbor_text_matches_reference(golden):
+    with open(os.path.join(G, "neighbors_input.json")) as f:
+        ids = [e["id"] for e in json.load(f)]
+    for case in golden["cases"]:
+        st = nb.NeighborStore(ids, split=case["split"], rng=random, **case["args"])
+        st.skip_gold_neighbor = case["skip_gold"]
+        st.load_corpus(golden["corpus"], os.path.join(G, "neighbors_input.json"))
+        random.seed(1234)
+        lists = [st.get_neighbor_text(i, return_list=True) for i in range(len(ids))]
+        random.seed(1234)
+        texts = [st.get_neighbor_text(i) for i in range(len(ids))]
+        assert lists == case["lists"], case
+        assert texts == case["texts"], case
+
+
+def test_writer_is_byte_identical_to_json_dump(tmp_path):
+    import numpy as np
+    rank = np.array([[2, 0, 1], [1, 2, -1]])
+    res = nb.build_result(np.array([10, 11]), rank, ["a", "b", "c"])
+    assert res == [{"id": 10, "nn": ["c", "a", "b"]}, {"id": 11, "nn": ["b", "c"]}]
+    p = tmp_path / "train.json"
+    nb.write_neighbors(str(p), res)
+    assert p.read_text() == json.dumps(res)  # default separators, as retrieve_faiss.py:117-118
+    assert nb.read_neighbors(str(p)) == {10: ["c", "a", "b"], 11: ["b", "c"]}
+
+
+def test_convert_tevatron(tmp_path):
+    # retrieve/convert_format.py:6-16
+    lines = [json.dumps({"query_id": "q%d" % i, "negative_passages": [{"docid": "d%d" % j, "text": "x"} for j in range(3)]})
+             for i in range(4)]
+    src = tmp_path / "test.jsonl"
+    src.write_text("\n".join(lines) + "\n")
+    dst = tmp_path / "test.json"
+    assert nb.convert_tevatron_file(str(src), str(dst)) == 4
+    assert json.loads(dst.read_text())[2] == {"id": "q2", "nn": ["d0", "d1", "d2"]}
