@@ -1,0 +1,53 @@
+/*
+ * trx_nn.h -- C ABI of libtrxnn.so: the two memory-/latency-bound hot spots of the TextReact
+ * predictor as hand-written gfx950 kernels.
+ *
+ * The reference builds its encoder-decoder from Hugging Face modules (textreact/model.py:21-31:
+ * EncoderDecoderModel = BertModel encoder + RobertaForCausalLM decoder, decoder shape from
+ * textreact/configs/bert_l6.json); the ops below replace, inside those modules,
+ *   - BertSelfAttention / RobertaSelfAttention forward (self-, cross- and causal attention):
+ *       softmax(q k^T * scale + mask) v, heads of 64, output already merged to [B, Lq, H*64]
+ *   - BertSelfOutput / BertOutput / embeddings / lm_head:  LayerNorm(dense_out + residual)
+ * Plain device pointers + sizes + a hipStream_t passed as void*; 0 or a negative TRX_NN_E* code;
+ * never throws; trx_nn_last_error() gives the message.  No CPU path: without a device the calls
+ * fail.  dtype selects the storage type of activations (math is always fp32).
+ */
+#ifndef TRX_NN_H
+#define TRX_NN_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { TRX_NN_F32 = 0, TRX_NN_BF16 = 1 };
+enum { TRX_NN_OK = 0, TRX_NN_EINVAL = -1, TRX_NN_EHIP = -3 };
+enum { TRX_NN_MASK_NONE = 0, TRX_NN_MASK_KEY = 1 /* float [B, Lk] */, TRX_NN_MASK_FULL = 2 /* float [B, Lq, Lk] */ };
+
+/* y = LayerNorm(x + res) * gamma + beta over the last dimension (biased variance, like
+ * torch.nn.functional.layer_norm).  res may be NULL (plain LayerNorm).  x, res, y: [rows, cols] of
+ * `dtype`; gamma, beta: float[cols]; mean, rstd: float[rows], may be NULL (inference). */
+int trx_add_layernorm_fwd(const void* x, const void* res, const float* gamma, const float* beta, float eps,
+                          int64_t rows, int cols, int dtype, void* y, float* mean, float* rstd, void* stream);
+
+/* Backward of the above.  dz = d(loss)/d(x + res) (it is the gradient of both x and res);
+ * dgamma, dbeta: float[cols] (overwritten).  ws: float[2 * nblk * cols] workspace with
+ * nblk = trx_add_layernorm_bwd_blocks(rows) (deterministic two-stage column reduction). */
+int trx_add_layernorm_bwd(const void* dy, const void* x, const void* res, const float* gamma, const float* mean,
+                          const float* rstd, int64_t rows, int cols, int dtype, void* dz, float* dgamma,
+                          float* dbeta, float* ws, void* stream);
+int trx_add_layernorm_bwd_blocks(int64_t rows);
+
+/* out[b, i, h*64 + :] = sum_j softmax_j(scale * q[b,i,h,:].k[b,j,h,:] + mask[b,(i),j]) v[b,j,h,:]
+ * q: [B, Lq, H, 64], k, v: [B, Lk, H, 64] (the layout a Linear + view gives, no transposes),
+ * out: [B, Lq, H*64], all `dtype`.  mask: additive float, see TRX_NN_MASK_*.  causal != 0: key j is
+ * visible to query i iff j <= i + (Lk - Lq) (decoder self-attention, with or without a KV prefix). */
+int trx_attention_fwd(const void* q, const void* k, const void* v, const float* mask, int mask_mode, int causal,
+                      int B, int H, int Lq, int Lk, float scale, int dtype, void* out, void* stream);
+
+const char* trx_nn_last_error(void);
+const char* trx_nn_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

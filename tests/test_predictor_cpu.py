@@ -1,0 +1,66 @@
+"""Predictor module tree on CPU: parameter names and eval-mode logits against the golden produced
+by the reference's own get_model (tests/golden/make_predictor_golden.py).  Uses the fp32 torch
+statement of the two ops (the HIP kernels are checked against the same statement in
+tests/test_predictor_gpu.py); the product backend must refuse to run without a GPU."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from textreact_amd.predictor import ops
+from textreact_amd.predictor.model import Config, TextReactModel, random_state_dict
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "predictor_small.npz")
+
+
+def _load(backend):
+    z = np.load(G)
+    enc, dec = json.loads(str(z["enc_cfg"])), json.loads(str(z["dec_cfg"]))
+    m = TextReactModel(Config(**enc), Config(is_decoder=True, **dec), backend=backend)
+    m.load_state_dict(random_state_dict(m, int(z["seed"])))
+    m.eval()
+    return z, m
+
+
+def test_state_dict_names_match_the_reference():
+    z, m = _load("torch")
+    assert sorted(m.state_dict().keys()) == json.loads(str(z["state_dict_keys"]))
+    # the names SURVEY.md 5.4 lists for the Lightning checkpoint (prefix `model.` added by the LightningModule)
+    keys = set(m.state_dict().keys())
+    for k in ("encoder.embeddings.word_embeddings.weight", "encoder.encoder.layer.1.attention.self.query.weight",
+              "encoder.encoder.layer.0.attention.output.LayerNorm.bias", "encoder.pooler.dense.weight",
+              "decoder.roberta.encoder.layer.0.crossattention.self.key.bias",
+              "decoder.roberta.encoder.layer.1.output.LayerNorm.weight", "decoder.lm_head.layer_norm.weight",
+              "decoder.lm_head.decoder.weight", "decoder.lm_head.bias"):
+        assert k in keys, k
+
+
+def test_logits_match_reference_golden_fp32():
+    z, m = _load("torch")
+    t = lambda k: torch.from_numpy(z[k])
+    with torch.no_grad():
+        logits, enc = m(t("input_ids"), t("attention_mask"), t("decoder_input_ids"), t("decoder_attention_mask"))
+    assert float((logits - t("logits")).abs().max()) <= 1e-3          # north-star tolerance
+    assert float((enc - t("encoder_last_hidden_state")).abs().max()) <= 1e-3
+
+
+def test_hip_backend_refuses_cpu_tensors():
+    z, m = _load("hip")
+    t = lambda k: torch.from_numpy(z[k])
+    with pytest.raises(ops.TrxNNError):
+        m(t("input_ids"), t("attention_mask"), t("decoder_input_ids"), t("decoder_attention_mask"))
+
+
+def test_nn_library_exports_the_header_symbols():
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = re.sub(r"/\*.*?\*/", "", open(os.path.join(root, "include", "trx_nn.h")).read(), flags=re.S)
+    declared = sorted(set(re.findall(r"\b(trx_[a-z0-9_]+)\s*\(", src)))
+    assert declared == sorted(ops.SYMBOLS)
+    L = ops.lib()
+    for s in declared:
+        assert hasattr(L, s)
+    assert L.trx_attention_fwd(None, None, None, None, 0, 0, 1, 1, 1, 1, 1.0, 0, None, None) == -1
+    assert b"bad argument" in L.trx_nn_last_error()

@@ -1,0 +1,109 @@
+"""GPU numerics of the predictor kernels (through the C ABI) against a plain fp32 PyTorch statement
+of the same op, and the whole model against the golden logits of the reference's get_model.
+Tolerances: fp32 kernels 2e-5 abs (same math, different summation order); bf16 storage 2e-2;
+model logits 1e-3 (BASELINE.json north_star)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from textreact_amd.predictor import ops
+from textreact_amd.predictor.model import Config, TextReactModel, random_state_dict
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "predictor_small.npz")
+
+
+def _rand(*shape, dtype=torch.float32, seed=0):
+    g = torch.Generator(device="cuda"); g.manual_seed(seed)
+    return torch.randn(shape, generator=g, device="cuda", dtype=torch.float32).to(dtype)
+
+
+@pytest.mark.parametrize("rows,cols", [(1, 768), (777, 768), (16384, 768), (33, 600), (5, 31090 // 10), (64, 4096)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize("with_res", [True, False])
+def test_add_layernorm_forward(rows, cols, dtype, tol, with_res):
+    x, r = _rand(rows, cols, dtype=dtype, seed=1), (_rand(rows, cols, dtype=dtype, seed=2) if with_res else None)
+    g, b = _rand(cols, seed=3) * 0.1 + 1, _rand(cols, seed=4) * 0.1
+    for eps in (1e-12, 1e-5):
+        y = ops.add_layernorm(x, r, g, b, eps, backend="hip")
+        ref = ops.add_layernorm(x.float(), None if r is None else r.float(), g, b, eps, backend="torch")
+        assert y.dtype == dtype and float((y.float() - ref).abs().max()) <= tol
+
+
+@pytest.mark.parametrize("rows,cols", [(1000, 768), (37, 130)])
+def test_add_layernorm_backward(rows, cols):
+    x, r = _rand(rows, cols, seed=1), _rand(rows, cols, seed=2)
+    g, b = _rand(cols, seed=3) * 0.1 + 1, _rand(cols, seed=4) * 0.1
+    dy = _rand(rows, cols, seed=5)
+    outs = []
+    for backend in ("hip", "torch"):
+        xs, rs, gs, bs = (t.clone().requires_grad_(True) for t in (x, r, g, b))
+        y = ops.add_layernorm(xs, rs, gs, bs, 1e-5, backend=backend)
+        y.backward(dy)
+        outs.append((xs.grad, rs.grad, gs.grad, bs.grad))
+    for a, c in zip(*outs):
+        assert float((a - c).abs().max()) <= 2e-4 * max(1.0, float(c.abs().max()))
+    # deterministic: two runs give the same bits (two-stage reduction, no float atomics)
+    xs = x.clone().requires_grad_(True); gs = g.clone().requires_grad_(True)
+    ops.add_layernorm(xs, r, gs, b, 1e-5).backward(dy)
+    assert torch.equal(gs.grad, outs[0][2])
+
+
+@pytest.mark.parametrize("B,H,Lq,Lk,mask,causal", [
+    (2, 12, 512, 512, "key", False),      # encoder self-attention at the scripts' length
+    (3, 2, 37, 37, "none", False),
+    (2, 4, 70, 70, "full", False),        # --unattend_nonbonds style 2-D mask
+    (2, 12, 7, 7, "key", True),           # RCR decoder: BOS + 5 + EOS
+    (2, 12, 160, 160, "none", True),      # retro decoder self-attention
+    (2, 12, 160, 512, "key", False),      # cross-attention over the encoder states
+    (4, 2, 1, 129, "none", True),         # one decode step against a KV prefix
+    (1, 1, 65, 200, "key", True),
+])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+def test_attention_forward(B, H, Lq, Lk, mask, causal, dtype, tol):
+    q, k, v = _rand(B, Lq, H, 64, dtype=dtype, seed=1), _rand(B, Lk, H, 64, dtype=dtype, seed=2), _rand(B, Lk, H, 64, dtype=dtype, seed=3)
+    m = None
+    neg = torch.finfo(torch.float32).min
+    if mask == "key":
+        keep = torch.ones(B, Lk, device="cuda"); keep[0, Lk // 2 + 1:] = 0
+        m = (1 - keep) * neg
+    elif mask == "full":
+        keep = (torch.rand(B, Lq, Lk, device="cuda") > 0.3).float(); keep[:, :, 0] = 1
+        m = (1 - keep) * neg
+    out = ops.attention(q, k, v, mask=m, causal=causal, backend="hip")
+    ref = ops.attention(q.float(), k.float(), v.float(), mask=m, causal=causal, backend="torch")
+    assert out.shape == (B, Lq, H * 64) and out.dtype == dtype
+    assert float((out.float() - ref).abs().max()) <= tol
+
+
+def test_model_logits_match_reference_golden_on_gpu():
+    z = np.load(G)
+    enc, dec = json.loads(str(z["enc_cfg"])), json.loads(str(z["dec_cfg"]))
+    m = TextReactModel(Config(**enc), Config(is_decoder=True, **dec), backend="hip")
+    m.load_state_dict(random_state_dict(m, int(z["seed"])))
+    m = m.cuda().eval()
+    t = lambda k_: torch.from_numpy(z[k_]).cuda()
+    with torch.no_grad():
+        logits, encs = m(t("input_ids"), t("attention_mask"), t("decoder_input_ids"), t("decoder_attention_mask"))
+    assert float((logits.cpu() - torch.from_numpy(z["logits"])).abs().max()) <= 1e-3
+    assert float((encs.cpu() - torch.from_numpy(z["encoder_last_hidden_state"])).abs().max()) <= 1e-3
+
+
+def test_full_size_model_hip_vs_torch_reference():
+    # scripts' shapes: BERT-base encoder (SciBERT vocab 31090), bert_l6.json decoder, L = 512, T = 7
+    enc = Config(vocab_size=31090)
+    dec = Config(vocab_size=600, num_hidden_layers=6, type_vocab_size=1, layer_norm_eps=1e-5, is_decoder=True)
+    m = TextReactModel(enc, dec, backend="hip")
+    m.load_state_dict(random_state_dict(m, 7))
+    m = m.cuda().eval()
+    g = torch.Generator().manual_seed(1)
+    ids = torch.randint(1, 31090, (4, 512), generator=g).cuda(); am = torch.ones(4, 512, dtype=torch.long).cuda(); am[1, 300:] = 0
+    dids = torch.randint(14, 600, (4, 7), generator=g).cuda()
+    with torch.no_grad():
+        a, _ = m(ids, am, dids)
+        m.backend = "torch"
+        b, _ = m(ids, am, dids)
+    assert float((a - b).abs().max()) <= 1e-3

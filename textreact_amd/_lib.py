@@ -39,7 +39,9 @@ def build(force=False):
     srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hip", ".h"))]
     srcs.append(os.path.join(_HERE, "..", "include", "trx_knn.h"))
     newest = max(os.path.getmtime(s) for s in srcs)
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < newest:
+    nn = os.path.join(_CSRC, "libtrxnn.so")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < newest or not os.path.exists(nn) \
+            or os.path.getmtime(nn) < newest:
         subprocess.check_call(["make", "-C", _CSRC, "-j4"] + (["-B"] if force else []))
     return _SO
 

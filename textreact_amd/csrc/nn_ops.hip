@@ -1,0 +1,256 @@
+// nn_ops.hip -- predictor hot spots on gfx950: fused residual-add + LayerNorm (forward, backward)
+// and attention forward.  C ABI in include/trx_nn.h.  Wave = 64.
+//
+// Replaces (inside the Hugging Face modules the reference instantiates at textreact/model.py:21-31):
+//   LayerNorm(dense(h) + residual)  -- BertSelfOutput / BertOutput / embeddings / lm_head
+//   softmax(q k^T / 8 + mask) v      -- Bert/Roberta self-, cross- and causal attention, heads of 64
+#include "../../include/trx_nn.h"
+#include <hip/hip_runtime.h>
+#include <string>
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string& m) { g_err = m; return code; }
+
+typedef unsigned short bf16_t;
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    return (bf16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+template <bool BF> __device__ __forceinline__ float ld(const void* p, int64_t i) {
+    return BF ? bf2f(reinterpret_cast<const bf16_t*>(p)[i]) : reinterpret_cast<const float*>(p)[i];
+}
+template <bool BF> __device__ __forceinline__ void st(void* p, int64_t i, float v) {
+    if (BF) reinterpret_cast<bf16_t*>(p)[i] = f2bf(v); else reinterpret_cast<float*>(p)[i] = v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---- add + LayerNorm forward: one wave per row, the row cached in registers (cols <= 64*CPL) ----
+// HBM-bound: algorithmic bytes = rows * cols * (x + res + y) * sizeof(dtype).
+constexpr int CPL = 32;  // cached values per lane -> cols <= 2048 in registers; larger rows re-read
+template <bool BF>
+__global__ __launch_bounds__(256) void add_ln_fwd_kernel(const void* x, const void* res, const float* gamma,
+                                                         const float* beta, float eps, int64_t rows, int cols,
+                                                         void* y, float* mean, float* rstd) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int64_t base = row * cols;
+    float v[CPL];
+    const bool cached = cols <= 64 * CPL;
+    float s = 0.f;
+    if (cached) {
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            const int c = lane + 64 * i;
+            v[i] = c < cols ? ld<BF>(x, base + c) + (res ? ld<BF>(res, base + c) : 0.f) : 0.f;
+            s += v[i];
+        }
+    } else {
+        for (int c = lane; c < cols; c += 64) s += ld<BF>(x, base + c) + (res ? ld<BF>(res, base + c) : 0.f);
+    }
+    const float mu = wave_sum(s) / (float)cols;
+    float q = 0.f;
+    if (cached) {
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) { const int c = lane + 64 * i; const float d = c < cols ? v[i] - mu : 0.f; q += d * d; }
+    } else {
+        for (int c = lane; c < cols; c += 64) { const float d = ld<BF>(x, base + c) + (res ? ld<BF>(res, base + c) : 0.f) - mu; q += d * d; }
+    }
+    const float rs = rsqrtf(wave_sum(q) / (float)cols + eps);
+    if (cached) {
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            const int c = lane + 64 * i;
+            if (c < cols) st<BF>(y, base + c, (v[i] - mu) * rs * gamma[c] + beta[c]);
+        }
+    } else {
+        for (int c = lane; c < cols; c += 64) {
+            const float z = ld<BF>(x, base + c) + (res ? ld<BF>(res, base + c) : 0.f);
+            st<BF>(y, base + c, (z - mu) * rs * gamma[c] + beta[c]);
+        }
+    }
+    if (lane == 0) { if (mean) mean[row] = mu; if (rstd) rstd[row] = rs; }
+}
+
+// ---- backward: dz, and per-block partial column sums of dgamma / dbeta ----
+constexpr int BWD_ROWS_PER_WAVE = 8;
+template <bool BF>
+__global__ __launch_bounds__(256) void add_ln_bwd_kernel(const void* dy, const void* x, const void* res,
+                                                         const float* gamma, const float* mean, const float* rstd,
+                                                         int64_t rows, int cols, void* dz, float* ws, int nblk) {
+    extern __shared__ float sm[];  // [4 waves][2][cols]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* pg = sm + (wave * 2) * cols;
+    float* pb = pg + cols;
+    for (int c = lane; c < cols; c += 64) { pg[c] = 0.f; pb[c] = 0.f; }
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * BWD_ROWS_PER_WAVE;
+    for (int r = 0; r < BWD_ROWS_PER_WAVE; ++r) {
+        const int64_t row = row0 + r;
+        if (row >= rows) break;
+        const int64_t base = row * cols;
+        const float mu = mean[row], rs = rstd[row];
+        float s1 = 0.f, s2 = 0.f;
+        for (int c = lane; c < cols; c += 64) {
+            const float z = ld<BF>(x, base + c) + (res ? ld<BF>(res, base + c) : 0.f);
+            const float xh = (z - mu) * rs, g = ld<BF>(dy, base + c) * gamma[c];
+            s1 += g; s2 += g * xh;
+        }
+        s1 = wave_sum(s1) / (float)cols; s2 = wave_sum(s2) / (float)cols;
+        for (int c = lane; c < cols; c += 64) {
+            const float z = ld<BF>(x, base + c) + (res ? ld<BF>(res, base + c) : 0.f);
+            const float xh = (z - mu) * rs, d = ld<BF>(dy, base + c);
+            st<BF>(dz, base + c, rs * (d * gamma[c] - s1 - xh * s2));
+            pg[c] += d * xh; pb[c] += d;
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < cols; c += 256) {
+        float a = 0.f, b = 0.f;
+        for (int w = 0; w < 4; ++w) { a += sm[(w * 2) * cols + c]; b += sm[(w * 2 + 1) * cols + c]; }
+        ws[(int64_t)blockIdx.x * cols + c] = a;
+        ws[((int64_t)nblk + blockIdx.x) * cols + c] = b;
+    }
+}
+__global__ void add_ln_bwd_reduce_kernel(const float* ws, int nblk, int cols, float* dgamma, float* dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    float a = 0.f, b = 0.f;
+    for (int i = 0; i < nblk; ++i) { a += ws[(int64_t)i * cols + c]; b += ws[((int64_t)nblk + i) * cols + c]; }
+    dgamma[c] = a; dbeta[c] = b;
+}
+
+// ---- attention forward, fp32 math, one lane per query row --------------------------------------
+// A wave owns 64 consecutive queries of one (batch, head); K and V rows are the same for every lane,
+// so hipcc fetches them through the scalar cache (s_load) and the products are v_fmac with an SGPR
+// operand: no LDS, no barriers.  q and the running output stay in registers (2 x 64 VGPRs), keys are
+// consumed in chunks of 8 with an online softmax.  FLOPs = 4 * B * H * Lq * Lk * 64.
+constexpr int DH = 64, KC = 8;
+template <bool BF>
+__global__ __launch_bounds__(64) void attention_fwd_kernel(const void* __restrict__ q, const void* __restrict__ k,
+                                                           const void* __restrict__ v, const float* __restrict__ mask,
+                                                           int mask_mode, int causal, int B, int H, int Lq, int Lk,
+                                                           float scale, void* __restrict__ out) {
+    const int qblocks = (Lq + 63) / 64;
+    const int bid = blockIdx.x;
+    const int qb = bid % qblocks, h = (bid / qblocks) % H, b = bid / (qblocks * H);
+    const int i = qb * 64 + threadIdx.x;
+    const bool live = i < Lq;
+    const int ii = live ? i : Lq - 1;
+    float qr[DH], o[DH];
+    const int64_t qoff = (((int64_t)b * Lq + ii) * H + h) * DH;
+#pragma unroll
+    for (int d = 0; d < DH; ++d) { qr[d] = ld<BF>(q, qoff + d) * scale; o[d] = 0.f; }
+    float m = -3.0e38f, l = 0.f;
+    const int jmax_row = causal ? ii + (Lk - Lq) : Lk - 1;            // last visible key of this row
+    const int jend = causal ? min(Lk, qb * 64 + 63 + (Lk - Lq) + 1) : Lk;  // wave-uniform bound
+    for (int j0 = 0; j0 < jend; j0 += KC) {
+        float s[KC];
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            const int j = j0 + c;
+            const int jj = j < Lk ? j : Lk - 1;
+            const int64_t koff = (((int64_t)b * Lk + jj) * H + h) * DH;   // wave-uniform
+            float a = 0.f;
+#pragma unroll
+            for (int d = 0; d < DH; ++d) a = __builtin_fmaf(qr[d], ld<BF>(k, koff + d), a);
+            if (mask_mode == TRX_NN_MASK_KEY) a += mask[(int64_t)b * Lk + jj];
+            else if (mask_mode == TRX_NN_MASK_FULL) a += mask[((int64_t)b * Lq + ii) * Lk + jj];
+            s[c] = (j < Lk && j <= jmax_row) ? a : -3.0e38f;
+        }
+        float cm = s[0];
+#pragma unroll
+        for (int c = 1; c < KC; ++c) cm = fmaxf(cm, s[c]);
+        const float mn = fmaxf(m, cm);
+        const float alpha = __expf(m - mn);
+        l *= alpha;
+#pragma unroll
+        for (int d = 0; d < DH; ++d) o[d] *= alpha;
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            const int j = j0 + c;
+            const int jj = j < Lk ? j : Lk - 1;
+            // rows hidden by the causal / length bound contribute exactly 0 (additive masks with a
+            // finite large negative value behave like the reference: exp underflows to 0)
+            const float pj = (j < Lk && j <= jmax_row) ? __expf(s[c] - mn) : 0.f;
+            l += pj;
+            const int64_t voff = (((int64_t)b * Lk + jj) * H + h) * DH;
+#pragma unroll
+            for (int d = 0; d < DH; ++d) o[d] = __builtin_fmaf(pj, ld<BF>(v, voff + d), o[d]);
+        }
+        m = mn;
+    }
+    if (live) {
+        const float inv = 1.0f / l;
+        const int64_t ooff = ((int64_t)b * Lq + i) * H * DH + (int64_t)h * DH;
+#pragma unroll
+        for (int d = 0; d < DH; ++d) st<BF>(out, ooff + d, o[d] * inv);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* trx_nn_last_error(void) { return g_err.c_str(); }
+const char* trx_nn_version(void) { return "trxnn 0.1 (gfx950)"; }
+int trx_add_layernorm_bwd_blocks(int64_t rows) { return (int)((rows + 4 * BWD_ROWS_PER_WAVE - 1) / (4 * BWD_ROWS_PER_WAVE)); }
+
+int trx_add_layernorm_fwd(const void* x, const void* res, const float* gamma, const float* beta, float eps,
+                          int64_t rows, int cols, int dtype, void* y, float* mean, float* rstd, void* stream) {
+    if (!x || !gamma || !beta || !y || rows < 0 || cols <= 0) return fail(TRX_NN_EINVAL, "add_layernorm_fwd: bad argument");
+    if (dtype != TRX_NN_F32 && dtype != TRX_NN_BF16) return fail(TRX_NN_EINVAL, "unknown dtype");
+    if (rows == 0) return TRX_NN_OK;
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == TRX_NN_BF16) hipLaunchKernelGGL(add_ln_fwd_kernel<true>, grid, block, 0, st, x, res, gamma, beta, eps, rows, cols, y, mean, rstd);
+    else hipLaunchKernelGGL(add_ln_fwd_kernel<false>, grid, block, 0, st, x, res, gamma, beta, eps, rows, cols, y, mean, rstd);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? TRX_NN_OK : fail(TRX_NN_EHIP, hipGetErrorString(e));
+}
+
+int trx_add_layernorm_bwd(const void* dy, const void* x, const void* res, const float* gamma, const float* mean,
+                          const float* rstd, int64_t rows, int cols, int dtype, void* dz, float* dgamma,
+                          float* dbeta, float* ws, void* stream) {
+    if (!dy || !x || !gamma || !mean || !rstd || !dz || !dgamma || !dbeta || !ws || rows <= 0 || cols <= 0)
+        return fail(TRX_NN_EINVAL, "add_layernorm_bwd: bad argument");
+    if (dtype != TRX_NN_F32 && dtype != TRX_NN_BF16) return fail(TRX_NN_EINVAL, "unknown dtype");
+    if ((size_t)cols * 8 * sizeof(float) > 160 * 1024) return fail(TRX_NN_EINVAL, "cols too large for the LDS partials");
+    const int nblk = trx_add_layernorm_bwd_blocks(rows);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = (size_t)cols * 8 * sizeof(float);
+    if (dtype == TRX_NN_BF16) {
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)add_ln_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(add_ln_bwd_kernel<true>, dim3(nblk), dim3(256), lds, st, dy, x, res, gamma, mean, rstd, rows, cols, dz, ws, nblk);
+    } else {
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)add_ln_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(add_ln_bwd_kernel<false>, dim3(nblk), dim3(256), lds, st, dy, x, res, gamma, mean, rstd, rows, cols, dz, ws, nblk);
+    }
+    hipLaunchKernelGGL(add_ln_bwd_reduce_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, ws, nblk, cols, dgamma, dbeta);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? TRX_NN_OK : fail(TRX_NN_EHIP, hipGetErrorString(e));
+}
+
+int trx_attention_fwd(const void* q, const void* k, const void* v, const float* mask, int mask_mode, int causal,
+                      int B, int H, int Lq, int Lk, float scale, int dtype, void* out, void* stream) {
+    if (!q || !k || !v || !out || B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return fail(TRX_NN_EINVAL, "attention_fwd: bad argument");
+    if (mask_mode != TRX_NN_MASK_NONE && !mask) return fail(TRX_NN_EINVAL, "attention_fwd: mask is null");
+    if (mask_mode < 0 || mask_mode > 2) return fail(TRX_NN_EINVAL, "attention_fwd: unknown mask mode");
+    if (dtype != TRX_NN_F32 && dtype != TRX_NN_BF16) return fail(TRX_NN_EINVAL, "unknown dtype");
+    const int qblocks = (Lq + 63) / 64;
+    dim3 grid((unsigned)((int64_t)B * H * qblocks)), block(64);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == TRX_NN_BF16) hipLaunchKernelGGL(attention_fwd_kernel<true>, grid, block, 0, st, q, k, v, mask, mask_mode, causal, B, H, Lq, Lk, scale, out);
+    else hipLaunchKernelGGL(attention_fwd_kernel<false>, grid, block, 0, st, q, k, v, mask, mask_mode, causal, B, H, Lq, Lk, scale, out);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? TRX_NN_OK : fail(TRX_NN_EHIP, hipGetErrorString(e));
+}
+
+}  // extern "C"

@@ -1,0 +1,236 @@
+"""The text-augmented encoder-decoder of TextReact with the reference's parameter names.
+
+Reference: textreact/model.py:21-31 builds `EncoderDecoderModel(BertModel, RobertaForCausalLM)`;
+the decoder shape is textreact/configs/bert_l6.json.  This module tree owns its layers (the pinned
+transformers 4.27.3 inlines attention in BertSelfAttention.forward, there is no hook to replace),
+keeps every parameter name of the Hugging Face state dict -- `encoder.embeddings.*`,
+`encoder.encoder.layer.N.attention.self.{query,key,value}`, `...attention.output.{dense,LayerNorm}`,
+`...intermediate.dense`, `...output.{dense,LayerNorm}`, `decoder.roberta.*` with `crossattention`,
+`decoder.lm_head.{bias,dense,layer_norm,decoder}` -- so a Lightning
+checkpoint's `state_dict` (prefix `model.`) loads unchanged, and routes the two hot spots through
+textreact_amd.predictor.ops: attention (self / cross / causal) and LayerNorm(dense(h) + residual).
+Linear layers stay rocBLAS GEMMs (torch.nn.Linear); GELU is the exact erf form, as in BERT.
+
+Eval-mode math only in round 1 (dropout is identity; parity is defined in eval mode).
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+class Config:
+    """subset of the HF config fields that shape the network"""
+
+    def __init__(self, vocab_size, hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
+                 intermediate_size=3072, max_position_embeddings=512, type_vocab_size=2, layer_norm_eps=1e-12,
+                 pad_token_id=0, is_decoder=False, **_):
+        self.vocab_size, self.hidden_size, self.num_hidden_layers = vocab_size, hidden_size, num_hidden_layers
+        self.num_attention_heads, self.intermediate_size = num_attention_heads, intermediate_size
+        self.max_position_embeddings, self.type_vocab_size = max_position_embeddings, type_vocab_size
+        self.layer_norm_eps, self.pad_token_id, self.is_decoder = layer_norm_eps, pad_token_id, is_decoder
+        assert hidden_size == num_attention_heads * 64, "the attention kernel is specialised for heads of 64"
+
+
+class LayerNormParams(nn.Module):
+    """holds `weight` / `bias` under the HF name; the math happens fused with the residual add"""
+
+    def __init__(self, n):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(n))
+        self.bias = nn.Parameter(torch.zeros(n))
+
+
+class SelfAttentionProj(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.query = nn.Linear(cfg.hidden_size, cfg.hidden_size)
+        self.key = nn.Linear(cfg.hidden_size, cfg.hidden_size)
+        self.value = nn.Linear(cfg.hidden_size, cfg.hidden_size)
+
+
+class AttnOutput(nn.Module):
+    def __init__(self, cfg, in_features=None):
+        super().__init__()
+        self.dense = nn.Linear(in_features or cfg.hidden_size, cfg.hidden_size)
+        self.LayerNorm = LayerNormParams(cfg.hidden_size)
+
+
+class Attention(nn.Module):
+    """`attention` / `crossattention` of a layer: self.{query,key,value} + output.{dense,LayerNorm}"""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.self = SelfAttentionProj(cfg)
+        self.output = AttnOutput(cfg)
+        self.heads, self.eps = cfg.num_attention_heads, cfg.layer_norm_eps
+
+    def forward(self, h, kv, mask, causal, backend):
+        B, Lq, Hd = h.shape
+        Lk = kv.shape[1]
+        q = self.self.query(h).view(B, Lq, self.heads, 64)
+        k = self.self.key(kv).view(B, Lk, self.heads, 64)
+        v = self.self.value(kv).view(B, Lk, self.heads, 64)
+        ctx = ops.attention(q, k, v, mask=mask, causal=causal, backend=backend)
+        return ops.add_layernorm(self.output.dense(ctx), h, self.output.LayerNorm.weight, self.output.LayerNorm.bias,
+                                 self.eps, backend=backend)
+
+
+class Intermediate(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.dense = nn.Linear(cfg.hidden_size, cfg.intermediate_size)
+
+
+class Layer(nn.Module):
+    def __init__(self, cfg, cross=False):
+        super().__init__()
+        self.attention = Attention(cfg)
+        if cross:
+            self.crossattention = Attention(cfg)
+        self.intermediate = Intermediate(cfg)
+        self.output = AttnOutput(cfg, in_features=cfg.intermediate_size)
+        self.eps, self.cross = cfg.layer_norm_eps, cross
+
+    def forward(self, h, self_mask, causal, enc, enc_mask, backend):
+        h = self.attention(h, h, self_mask, causal, backend)
+        if self.cross:
+            h = self.crossattention(h, enc, enc_mask, False, backend)
+        f = torch.nn.functional.gelu(self.intermediate.dense(h))
+        return ops.add_layernorm(self.output.dense(f), h, self.output.LayerNorm.weight, self.output.LayerNorm.bias,
+                                 self.eps, backend=backend)
+
+
+class LayerStack(nn.Module):
+    def __init__(self, cfg, cross=False):
+        super().__init__()
+        self.layer = nn.ModuleList([Layer(cfg, cross) for _ in range(cfg.num_hidden_layers)])
+
+
+class Embeddings(nn.Module):
+    def __init__(self, cfg, roberta=False):
+        super().__init__()
+        self.word_embeddings = nn.Embedding(cfg.vocab_size, cfg.hidden_size, padding_idx=cfg.pad_token_id)
+        self.position_embeddings = nn.Embedding(cfg.max_position_embeddings, cfg.hidden_size,
+                                                padding_idx=cfg.pad_token_id if roberta else None)
+        self.token_type_embeddings = nn.Embedding(cfg.type_vocab_size, cfg.hidden_size)
+        self.LayerNorm = LayerNormParams(cfg.hidden_size)
+        self.eps, self.roberta, self.pad = cfg.layer_norm_eps, roberta, cfg.pad_token_id
+
+    def forward(self, input_ids, position_ids, token_type_ids, backend):
+        if position_ids is None:
+            if self.roberta:   # RoBERTa: positions count non-pad tokens, starting at pad + 1
+                nz = input_ids.ne(self.pad).int()
+                position_ids = (torch.cumsum(nz, dim=1) * nz).long() + self.pad
+            else:
+                position_ids = torch.arange(input_ids.shape[1], device=input_ids.device)[None].expand_as(input_ids)
+        if token_type_ids is None:
+            token_type_ids = torch.zeros_like(input_ids)
+        e = self.word_embeddings(input_ids) + self.token_type_embeddings(token_type_ids)
+        return ops.add_layernorm(e, self.position_embeddings(position_ids), self.LayerNorm.weight,
+                                 self.LayerNorm.bias, self.eps, backend=backend)
+
+
+class Pooler(nn.Module):
+    """present in the checkpoint (encoder.pooler.dense.*); unused by the predictor's forward"""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.dense = nn.Linear(cfg.hidden_size, cfg.hidden_size)
+
+
+class BertEncoder(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.embeddings = Embeddings(cfg)
+        self.encoder = LayerStack(cfg)
+        self.pooler = Pooler(cfg)
+
+    def forward(self, input_ids, key_mask, position_ids, token_type_ids, full_mask, backend):
+        h = self.embeddings(input_ids, position_ids, token_type_ids, backend)
+        m = full_mask if full_mask is not None else key_mask
+        for layer in self.encoder.layer:
+            h = layer(h, m, False, None, None, backend)
+        return h
+
+
+class RobertaBody(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.embeddings = Embeddings(cfg, roberta=True)
+        self.encoder = LayerStack(cfg, cross=True)
+
+
+class LMHead(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.dense = nn.Linear(cfg.hidden_size, cfg.hidden_size)
+        self.layer_norm = LayerNormParams(cfg.hidden_size)
+        self.decoder = nn.Linear(cfg.hidden_size, cfg.vocab_size)
+        self.bias = nn.Parameter(torch.zeros(cfg.vocab_size))
+        self.decoder.bias = self.bias      # tied, as in RobertaLMHead
+        self.eps = cfg.layer_norm_eps
+
+    def forward(self, h, backend):
+        x = torch.nn.functional.gelu(self.dense(h))
+        x = ops.add_layernorm(x, None, self.layer_norm.weight, self.layer_norm.bias, self.eps, backend=backend)
+        return self.decoder(x)
+
+
+class RobertaCausalLM(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.roberta = RobertaBody(cfg)
+        self.lm_head = LMHead(cfg)
+        self.lm_head.decoder.weight = self.roberta.embeddings.word_embeddings.weight   # tie_word_embeddings
+
+
+def additive_key_mask(attention_mask, dtype=torch.float32):
+    """HF convention: (1 - mask) * finfo.min, one value per key"""
+    return (1.0 - attention_mask.to(dtype)) * torch.finfo(dtype).min
+
+
+class TextReactModel(nn.Module):
+    """forward(input_ids, attention_mask, decoder_input_ids, ...) -> (logits, encoder_last_hidden_state)"""
+
+    def __init__(self, enc_cfg, dec_cfg, backend="hip"):
+        super().__init__()
+        self.encoder = BertEncoder(enc_cfg)
+        self.decoder = RobertaCausalLM(dec_cfg)
+        self.backend = backend
+
+    def forward(self, input_ids, attention_mask=None, decoder_input_ids=None, decoder_attention_mask=None,
+                position_ids=None, token_type_ids=None):
+        be = self.backend
+        if attention_mask is None:
+            attention_mask = torch.ones_like(input_ids)
+        full = None
+        if attention_mask.dim() == 3:      # --unattend_nonbonds: [B, L, L] mask (dataset.py:247-254)
+            full = additive_key_mask(attention_mask)
+            key = additive_key_mask(attention_mask.amax(dim=1))
+        else:
+            key = additive_key_mask(attention_mask)
+        enc = self.encoder(input_ids, key, position_ids, token_type_ids, full, be)
+        dmask = additive_key_mask(decoder_attention_mask) if decoder_attention_mask is not None else None
+        h = self.decoder.roberta.embeddings(decoder_input_ids, None, None, be)
+        for layer in self.decoder.roberta.encoder.layer:
+            h = layer(h, dmask, True, enc, key, be)
+        return self.decoder.lm_head(h, be), enc
+
+
+def random_state_dict(model, seed):
+    """Deterministic fp32 weights for parity tests: every tensor drawn from a seeded CPU generator in
+    state-dict order (N(0, 0.05); LayerNorm weights around 1).  Identical on every machine with this
+    torch build, so a fixture needs to carry only the seed, not the weights."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    sd = {}
+    for name, t in model.state_dict().items():
+        w = torch.randn(t.shape, generator=g, dtype=torch.float32) * 0.05
+        if name.endswith("LayerNorm.weight") or name.endswith("layer_norm.weight"):
+            w = w + 1.0
+        sd[name] = w
+    # tied tensors share one value
+    sd["decoder.lm_head.decoder.weight"] = sd["decoder.roberta.embeddings.word_embeddings.weight"]
+    sd["decoder.lm_head.decoder.bias"] = sd["decoder.lm_head.bias"]
+    return sd

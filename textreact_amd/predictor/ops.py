@@ -1,0 +1,151 @@
+"""Attention and residual-add + LayerNorm as torch ops backed by libtrxnn.so (include/trx_nn.h).
+
+backend 'hip'  : the product path -- raw device pointers into the C ABI on torch's current stream.
+                 Raises if the library or a GPU is missing (no silent fallback).
+backend 'torch': plain fp32 PyTorch statement of the same two ops.  It exists as the NUMERICS
+                 REFERENCE for the kernels (tests) and so the module tree can be checked on a box
+                 without a GPU; TextReactModel never selects it by itself.
+"""
+import ctypes
+import math
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(os.path.dirname(_HERE), "csrc", "libtrxnn.so")
+_lib = None
+F32, BF16 = 0, 1
+MASK_NONE, MASK_KEY, MASK_FULL = 0, 1, 2
+SYMBOLS = ["trx_add_layernorm_fwd", "trx_add_layernorm_bwd", "trx_add_layernorm_bwd_blocks",
+           "trx_attention_fwd", "trx_nn_last_error", "trx_nn_version"]
+
+
+class TrxNNError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            raise TrxNNError("libtrxnn.so is missing: run `make -C textreact_amd/csrc`")
+        L = ctypes.CDLL(_SO)
+        vp, i32, i64, f32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+        L.trx_add_layernorm_fwd.argtypes = [vp, vp, vp, vp, f32, i64, i32, i32, vp, vp, vp, vp]
+        L.trx_add_layernorm_bwd.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, i32, vp, vp, vp, vp, vp]
+        L.trx_add_layernorm_bwd_blocks.argtypes = [i64]
+        L.trx_attention_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, i32, vp, vp]
+        L.trx_nn_last_error.restype = ctypes.c_char_p
+        L.trx_nn_version.restype = ctypes.c_char_p
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise TrxNNError("trxnn error %d: %s" % (rc, lib().trx_nn_last_error().decode()))
+
+
+def _need_gpu(t):
+    if not t.is_cuda:
+        raise TrxNNError("the HIP ops need tensors on a GPU (there is no CPU implementation behind them)")
+
+
+def _dt(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TrxNNError("unsupported dtype %s (float32 / bfloat16)" % t.dtype)
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+class _AddLayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta, eps):
+        _need_gpu(x)
+        xs = x.contiguous()
+        rs = res.contiguous() if res is not None else None
+        cols = xs.shape[-1]
+        rows = xs.numel() // cols
+        y = torch.empty_like(xs)
+        need = x.requires_grad or (res is not None and res.requires_grad) or gamma.requires_grad
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device) if need else None
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if need else None
+        g, b = gamma.float().contiguous(), beta.float().contiguous()
+        _check(lib().trx_add_layernorm_fwd(_p(xs), _p(rs), _p(g), _p(b), float(eps), rows, cols, _dt(xs),
+                                           _p(y), _p(mean), _p(rstd), _stream(xs)))
+        if need:
+            ctx.save_for_backward(xs, rs if rs is not None else xs.new_empty(0), g, mean, rstd)
+            ctx.has_res = rs is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xs, rs, g, mean, rstd = ctx.saved_tensors
+        rs = rs if ctx.has_res else None
+        dy = dy.contiguous()
+        cols = xs.shape[-1]
+        rows = xs.numel() // cols
+        nblk = lib().trx_add_layernorm_bwd_blocks(rows)
+        ws = torch.empty(2 * nblk * cols, dtype=torch.float32, device=xs.device)
+        dz = torch.empty_like(xs)
+        dg = torch.empty(cols, dtype=torch.float32, device=xs.device)
+        db = torch.empty(cols, dtype=torch.float32, device=xs.device)
+        _check(lib().trx_add_layernorm_bwd(_p(dy), _p(xs), _p(rs), _p(g), _p(mean), _p(rstd), rows, cols, _dt(xs),
+                                           _p(dz), _p(dg), _p(db), _p(ws), _stream(xs)))
+        return dz, (dz if ctx.has_res else None), dg, db, None
+
+
+def add_layernorm(x, res, gamma, beta, eps, backend="hip"):
+    """LayerNorm(x + res) * gamma + beta over the last dimension; res may be None."""
+    if backend == "hip":
+        return _AddLayerNorm.apply(x, res, gamma, beta, eps)
+    z = x if res is None else x + res
+    return torch.nn.functional.layer_norm(z.float(), (z.shape[-1],), gamma.float(), beta.float(), eps).to(x.dtype)
+
+
+def attention(q, k, v, mask=None, causal=False, scale=None, backend="hip"):
+    """q [B, Lq, H, 64], k / v [B, Lk, H, 64] -> [B, Lq, H*64].
+    mask: additive float, [B, Lk] (key padding) or [B, Lq, Lk]; causal: key j visible iff
+    j <= i + (Lk - Lq)."""
+    B, Lq, H, D = q.shape
+    Lk = k.shape[1]
+    if scale is None:
+        scale = 1.0 / math.sqrt(D)
+    if backend == "hip":
+        _need_gpu(q)
+        if D != 64:
+            raise TrxNNError("the attention kernel is specialised for heads of 64 (got %d)" % D)
+        if q.requires_grad or k.requires_grad or v.requires_grad:
+            raise TrxNNError("attention backward is not implemented yet (round 1: inference only)")
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        mode, m = MASK_NONE, None
+        if mask is not None:
+            m = mask.float().contiguous()
+            mode = MASK_KEY if m.dim() == 2 else MASK_FULL
+            assert m.shape == ((B, Lk) if mode == MASK_KEY else (B, Lq, Lk)), m.shape
+        out = torch.empty((B, Lq, H * D), dtype=q.dtype, device=q.device)
+        _check(lib().trx_attention_fwd(_p(q), _p(k), _p(v), _p(m), mode, 1 if causal else 0, B, H, Lq, Lk,
+                                       float(scale), _dt(q), _p(out), _stream(q)))
+        return out
+    # fp32 reference: exactly what BertSelfAttention's eager path computes
+    qf, kf, vf = (t.float().permute(0, 2, 1, 3) for t in (q, k, v))             # [B, H, L, D]
+    s = torch.matmul(qf, kf.transpose(-1, -2)) * scale
+    if mask is not None:
+        mm = mask.float()
+        s = s + (mm[:, None, None, :] if mm.dim() == 2 else mm[:, None, :, :])
+    if causal:
+        i = torch.arange(Lq, device=q.device)[:, None] + (Lk - Lq)
+        j = torch.arange(Lk, device=q.device)[None, :]
+        s = s.masked_fill(j > i, torch.finfo(torch.float32).min)
+    p = torch.softmax(s, dim=-1)
+    return torch.matmul(p, vf).permute(0, 2, 1, 3).reshape(B, Lq, H * D).to(q.dtype)
