@@ -44,6 +44,19 @@ int trx_add_layernorm_bwd_blocks(int64_t rows);
 int trx_attention_fwd(const void* q, const void* k, const void* v, const float* mask, int mask_mode, int causal,
                       int B, int H, int Lq, int Lk, float scale, int dtype, void* out, void* stream);
 
+/* Same, additionally writing lse[B, H, Lq] = log sum_j exp(score_ij) (float), which the backward
+ * pass needs to recompute the probabilities instead of storing the Lq x Lk matrix. */
+int trx_attention_fwd_lse(const void* q, const void* k, const void* v, const float* mask, int mask_mode, int causal,
+                          int B, int H, int Lq, int Lk, float scale, int dtype, void* out, float* lse, void* stream);
+
+/* Backward of trx_attention_fwd: dq [B, Lq, H, 64], dk, dv [B, Lk, H, 64] from dout [B, Lq, H*64],
+ * the forward inputs, the forward output `out` and `lse`.  Probabilities are recomputed (flash
+ * style); the mask gets no gradient.  Deterministic (no atomics): one pass with a lane per query
+ * row for dq, one pass with a lane per key row for dk and dv. */
+int trx_attention_bwd(const void* q, const void* k, const void* v, const float* mask, int mask_mode, int causal,
+                      int B, int H, int Lq, int Lk, float scale, int dtype, const void* out, const void* dout,
+                      const float* lse, void* dq, void* dk, void* dv, void* stream);
+
 const char* trx_nn_last_error(void);
 const char* trx_nn_version(void);
 

@@ -107,3 +107,50 @@ def test_full_size_model_hip_vs_torch_reference():
         m.backend = "torch"
         b, _ = m(ids, am, dids)
     assert float((a - b).abs().max()) <= 1e-3
+
+
+@pytest.mark.parametrize("B,H,Lq,Lk,mask,causal", [
+    (2, 3, 70, 70, "key", False), (2, 2, 33, 33, "none", True), (2, 2, 20, 77, "key", False),
+    (1, 2, 65, 65, "full", False), (1, 1, 5, 37, "none", True),
+])
+def test_attention_backward(B, H, Lq, Lk, mask, causal):
+    q, k, v = _rand(B, Lq, H, 64, seed=1), _rand(B, Lk, H, 64, seed=2), _rand(B, Lk, H, 64, seed=3)
+    dout = _rand(B, Lq, H * 64, seed=4)
+    neg = torch.finfo(torch.float32).min
+    m = None
+    if mask == "key":
+        keep = torch.ones(B, Lk, device="cuda"); keep[0, Lk // 2 + 1:] = 0
+        m = (1 - keep) * neg
+    elif mask == "full":
+        keep = (torch.rand(B, Lq, Lk, device="cuda") > 0.3).float(); keep[:, :, 0] = 1
+        m = (1 - keep) * neg
+    grads = []
+    for backend in ("hip", "torch"):
+        qs, ks, vs = (t.clone().requires_grad_(True) for t in (q, k, v))
+        out = ops.attention(qs, ks, vs, mask=m, causal=causal, backend=backend)
+        out.backward(dout)
+        grads.append((out.detach(), qs.grad, ks.grad, vs.grad))
+    for a, c in zip(*grads):
+        assert float((a - c).abs().max()) <= 5e-5 * max(1.0, float(c.abs().max()))
+
+
+def test_model_backward_hip_vs_torch():
+    # one training-style step on the small config: loss = CE over decoder logits (main.py:129-131)
+    z = np.load(G)
+    enc, dec = json.loads(str(z["enc_cfg"])), json.loads(str(z["dec_cfg"]))
+    t = lambda k_: torch.from_numpy(z[k_]).cuda()
+    grads = {}
+    for backend in ("hip", "torch"):
+        m = TextReactModel(Config(**enc), Config(is_decoder=True, **dec), backend=backend)
+        m.load_state_dict(random_state_dict(m, int(z["seed"])))
+        m = m.cuda().eval()
+        logits, _ = m(t("input_ids"), t("attention_mask"), t("decoder_input_ids"), t("decoder_attention_mask"))
+        labels = t("decoder_input_ids")[:, 1:]
+        loss = torch.nn.functional.cross_entropy(logits[:, :-1].reshape(-1, logits.shape[-1]), labels.reshape(-1), ignore_index=0)
+        loss.backward()
+        grads[backend] = {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+        grads[backend]["__loss__"] = loss.detach()
+    assert set(grads["hip"]) == set(grads["torch"])
+    for n in grads["hip"]:
+        a, c = grads["hip"][n], grads["torch"][n]
+        assert float((a - c).abs().max()) <= 1e-4 * max(1.0, float(c.abs().max())), n

@@ -137,7 +137,7 @@ template <bool BF>
 __global__ __launch_bounds__(64) void attention_fwd_kernel(const void* __restrict__ q, const void* __restrict__ k,
                                                            const void* __restrict__ v, const float* __restrict__ mask,
                                                            int mask_mode, int causal, int B, int H, int Lq, int Lk,
-                                                           float scale, void* __restrict__ out) {
+                                                           float scale, void* __restrict__ out, float* __restrict__ lse) {
     const int qblocks = (Lq + 63) / 64;
     const int bid = blockIdx.x;
     const int qb = bid % qblocks, h = (bid / qblocks) % H, b = bid / (qblocks * H);
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(64) void attention_fwd_kernel(const void* __restric
     const int64_t qoff = (((int64_t)b * Lq + ii) * H + h) * DH;
 #pragma unroll
     for (int d = 0; d < DH; ++d) { qr[d] = ld<BF>(q, qoff + d) * scale; o[d] = 0.f; }
-    float m = -3.0e38f, l = 0.f;
+    float m = -__builtin_inff(), l = 0.f;
     const int jmax_row = causal ? ii + (Lk - Lq) : Lk - 1;            // last visible key of this row
     const int jend = causal ? min(Lk, qb * 64 + 63 + (Lk - Lq) + 1) : Lk;  // wave-uniform bound
     for (int j0 = 0; j0 < jend; j0 += KC) {
@@ -163,13 +163,13 @@ __global__ __launch_bounds__(64) void attention_fwd_kernel(const void* __restric
             for (int d = 0; d < DH; ++d) a = __builtin_fmaf(qr[d], ld<BF>(k, koff + d), a);
             if (mask_mode == TRX_NN_MASK_KEY) a += mask[(int64_t)b * Lk + jj];
             else if (mask_mode == TRX_NN_MASK_FULL) a += mask[((int64_t)b * Lq + ii) * Lk + jj];
-            s[c] = (j < Lk && j <= jmax_row) ? a : -3.0e38f;
+            s[c] = (j < Lk && j <= jmax_row) ? a : -__builtin_inff();   // hidden keys never set the maximum
         }
         float cm = s[0];
 #pragma unroll
         for (int c = 1; c < KC; ++c) cm = fmaxf(cm, s[c]);
         const float mn = fmaxf(m, cm);
-        const float alpha = __expf(m - mn);
+        const float alpha = (m == mn) ? 1.0f : __expf(m - mn);   // also covers m == mn == -inf
         l *= alpha;
 #pragma unroll
         for (int d = 0; d < DH; ++d) o[d] *= alpha;
@@ -187,11 +187,106 @@ __global__ __launch_bounds__(64) void attention_fwd_kernel(const void* __restric
         }
         m = mn;
     }
+    if (live && lse) lse[((int64_t)b * H + h) * Lq + i] = m + __logf(l);
     if (live) {
         const float inv = 1.0f / l;
         const int64_t ooff = ((int64_t)b * Lq + i) * H * DH + (int64_t)h * DH;
 #pragma unroll
         for (int d = 0; d < DH; ++d) st<BF>(out, ooff + d, o[d] * inv);
+    }
+}
+
+// ---- attention backward, fp32 math, probabilities recomputed from lse --------------------------
+// pass 1 (a lane per query row i):  delta_i = dO_i . O_i ;  dS_ij = p_ij (dO_i . V_j - delta_i) ;
+//                                   dQ_i = scale * sum_j dS_ij K_j
+// pass 2 (a lane per key row j):    dV_j = sum_i p_ij dO_i ;  dK_j = scale * sum_i dS_ij Q_i
+// In both passes the "other" operand row (K_j, V_j / Q_i, dO_i) is wave-uniform -> scalar loads.
+template <bool BF>
+__global__ __launch_bounds__(64) void attention_bwd_dq_kernel(const void* __restrict__ q, const void* __restrict__ k,
+                                                              const void* __restrict__ v, const float* __restrict__ mask,
+                                                              int mask_mode, int causal, int B, int H, int Lq, int Lk,
+                                                              float scale, const void* __restrict__ o, const void* __restrict__ dout,
+                                                              const float* __restrict__ lse, void* __restrict__ dq) {
+    const int qblocks = (Lq + 63) / 64;
+    const int bid = blockIdx.x;
+    const int qb = bid % qblocks, h = (bid / qblocks) % H, b = bid / (qblocks * H);
+    const int i = qb * 64 + threadIdx.x;
+    const bool live = i < Lq;
+    const int ii = live ? i : Lq - 1;
+    float qr[DH], dor[DH], acc[DH];
+    const int64_t qoff = (((int64_t)b * Lq + ii) * H + h) * DH;
+    const int64_t ooff = ((int64_t)b * Lq + ii) * H * DH + (int64_t)h * DH;
+    float delta = 0.f;
+#pragma unroll
+    for (int d = 0; d < DH; ++d) {
+        qr[d] = ld<BF>(q, qoff + d) * scale; dor[d] = ld<BF>(dout, ooff + d); acc[d] = 0.f;
+        delta = __builtin_fmaf(dor[d], ld<BF>(o, ooff + d), delta);
+    }
+    const float L = lse[((int64_t)b * H + h) * Lq + ii];
+    const int jmax_row = causal ? ii + (Lk - Lq) : Lk - 1;
+    const int jend = causal ? min(Lk, qb * 64 + 63 + (Lk - Lq) + 1) : Lk;
+    for (int j = 0; j < jend; ++j) {
+        const int64_t koff = (((int64_t)b * Lk + j) * H + h) * DH;   // wave-uniform
+        float s = 0.f, dp = 0.f;
+#pragma unroll
+        for (int d = 0; d < DH; ++d) { s = __builtin_fmaf(qr[d], ld<BF>(k, koff + d), s); dp = __builtin_fmaf(dor[d], ld<BF>(v, koff + d), dp); }
+        if (mask_mode == TRX_NN_MASK_KEY) s += mask[(int64_t)b * Lk + j];
+        else if (mask_mode == TRX_NN_MASK_FULL) s += mask[((int64_t)b * Lq + ii) * Lk + j];
+        const float p = j <= jmax_row ? __expf(s - L) : 0.f;
+        const float ds = p * (dp - delta);
+#pragma unroll
+        for (int d = 0; d < DH; ++d) acc[d] = __builtin_fmaf(ds, ld<BF>(k, koff + d), acc[d]);
+    }
+    if (live) {
+#pragma unroll
+        for (int d = 0; d < DH; ++d) st<BF>(dq, qoff + d, acc[d] * scale);
+    }
+}
+
+template <bool BF>
+__global__ __launch_bounds__(64) void attention_bwd_dkv_kernel(const void* __restrict__ q, const void* __restrict__ k,
+                                                               const void* __restrict__ v, const float* __restrict__ mask,
+                                                               int mask_mode, int causal, int B, int H, int Lq, int Lk,
+                                                               float scale, const void* __restrict__ o, const void* __restrict__ dout,
+                                                               const float* __restrict__ lse, void* __restrict__ dk, void* __restrict__ dv) {
+    const int kblocks = (Lk + 63) / 64;
+    const int bid = blockIdx.x;
+    const int kb = bid % kblocks, h = (bid / kblocks) % H, b = bid / (kblocks * H);
+    const int j = kb * 64 + threadIdx.x;
+    const bool live = j < Lk;
+    const int jj = live ? j : Lk - 1;
+    float kr[DH], vr[DH], ak[DH], av[DH];
+    const int64_t koff = (((int64_t)b * Lk + jj) * H + h) * DH;
+#pragma unroll
+    for (int d = 0; d < DH; ++d) { kr[d] = ld<BF>(k, koff + d); vr[d] = ld<BF>(v, koff + d); ak[d] = 0.f; av[d] = 0.f; }
+    const float mkey = mask_mode == TRX_NN_MASK_KEY ? mask[(int64_t)b * Lk + jj] : 0.f;
+    // first query row that can see any key of this block (causal): i >= j - (Lk - Lq)
+    const int i0 = causal ? max(0, kb * 64 - (Lk - Lq)) : 0;
+    for (int i = i0; i < Lq; ++i) {
+        const int64_t qoff = (((int64_t)b * Lq + i) * H + h) * DH;          // wave-uniform
+        const int64_t ooff = ((int64_t)b * Lq + i) * H * DH + (int64_t)h * DH;
+        float s = 0.f, dp = 0.f, delta = 0.f;
+#pragma unroll
+        for (int d = 0; d < DH; ++d) {
+            const float qd = ld<BF>(q, qoff + d), dod = ld<BF>(dout, ooff + d);
+            s = __builtin_fmaf(qd, kr[d], s); dp = __builtin_fmaf(dod, vr[d], dp);
+            delta = __builtin_fmaf(dod, ld<BF>(o, ooff + d), delta);        // wave-uniform value
+        }
+        s = s * scale + mkey;
+        if (mask_mode == TRX_NN_MASK_FULL) s += mask[((int64_t)b * Lq + i) * Lk + jj];
+        const float L = lse[((int64_t)b * H + h) * Lq + i];
+        const bool vis = !causal || jj <= i + (Lk - Lq);
+        const float p = vis ? __expf(s - L) : 0.f;
+        const float ds = p * (dp - delta);
+#pragma unroll
+        for (int d = 0; d < DH; ++d) {
+            av[d] = __builtin_fmaf(p, ld<BF>(dout, ooff + d), av[d]);
+            ak[d] = __builtin_fmaf(ds, ld<BF>(q, qoff + d), ak[d]);
+        }
+    }
+    if (live) {
+#pragma unroll
+        for (int d = 0; d < DH; ++d) { st<BF>(dk, koff + d, ak[d] * scale); st<BF>(dv, koff + d, av[d]); }
     }
 }
 
@@ -238,8 +333,8 @@ int trx_add_layernorm_bwd(const void* dy, const void* x, const void* res, const 
     return e == hipSuccess ? TRX_NN_OK : fail(TRX_NN_EHIP, hipGetErrorString(e));
 }
 
-int trx_attention_fwd(const void* q, const void* k, const void* v, const float* mask, int mask_mode, int causal,
-                      int B, int H, int Lq, int Lk, float scale, int dtype, void* out, void* stream) {
+int trx_attention_fwd_lse(const void* q, const void* k, const void* v, const float* mask, int mask_mode, int causal,
+                          int B, int H, int Lq, int Lk, float scale, int dtype, void* out, float* lse, void* stream) {
     if (!q || !k || !v || !out || B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return fail(TRX_NN_EINVAL, "attention_fwd: bad argument");
     if (mask_mode != TRX_NN_MASK_NONE && !mask) return fail(TRX_NN_EINVAL, "attention_fwd: mask is null");
     if (mask_mode < 0 || mask_mode > 2) return fail(TRX_NN_EINVAL, "attention_fwd: unknown mask mode");
@@ -247,8 +342,34 @@ int trx_attention_fwd(const void* q, const void* k, const void* v, const float* 
     const int qblocks = (Lq + 63) / 64;
     dim3 grid((unsigned)((int64_t)B * H * qblocks)), block(64);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == TRX_NN_BF16) hipLaunchKernelGGL(attention_fwd_kernel<true>, grid, block, 0, st, q, k, v, mask, mask_mode, causal, B, H, Lq, Lk, scale, out);
-    else hipLaunchKernelGGL(attention_fwd_kernel<false>, grid, block, 0, st, q, k, v, mask, mask_mode, causal, B, H, Lq, Lk, scale, out);
+    if (dtype == TRX_NN_BF16) hipLaunchKernelGGL(attention_fwd_kernel<true>, grid, block, 0, st, q, k, v, mask, mask_mode, causal, B, H, Lq, Lk, scale, out, lse);
+    else hipLaunchKernelGGL(attention_fwd_kernel<false>, grid, block, 0, st, q, k, v, mask, mask_mode, causal, B, H, Lq, Lk, scale, out, lse);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? TRX_NN_OK : fail(TRX_NN_EHIP, hipGetErrorString(e));
+}
+
+int trx_attention_fwd(const void* q, const void* k, const void* v, const float* mask, int mask_mode, int causal,
+                      int B, int H, int Lq, int Lk, float scale, int dtype, void* out, void* stream) {
+    return trx_attention_fwd_lse(q, k, v, mask, mask_mode, causal, B, H, Lq, Lk, scale, dtype, out, nullptr, stream);
+}
+
+int trx_attention_bwd(const void* q, const void* k, const void* v, const float* mask, int mask_mode, int causal,
+                      int B, int H, int Lq, int Lk, float scale, int dtype, const void* out, const void* dout,
+                      const float* lse, void* dq, void* dk, void* dv, void* stream) {
+    if (!q || !k || !v || !out || !dout || !lse || !dq || !dk || !dv || B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0)
+        return fail(TRX_NN_EINVAL, "attention_bwd: bad argument");
+    if (mask_mode != TRX_NN_MASK_NONE && !mask) return fail(TRX_NN_EINVAL, "attention_bwd: mask is null");
+    if (mask_mode < 0 || mask_mode > 2) return fail(TRX_NN_EINVAL, "attention_bwd: unknown mask mode");
+    if (dtype != TRX_NN_F32 && dtype != TRX_NN_BF16) return fail(TRX_NN_EINVAL, "unknown dtype");
+    hipStream_t st = (hipStream_t)stream;
+    dim3 gq((unsigned)((int64_t)B * H * ((Lq + 63) / 64))), gk((unsigned)((int64_t)B * H * ((Lk + 63) / 64))), block(64);
+    if (dtype == TRX_NN_BF16) {
+        hipLaunchKernelGGL(attention_bwd_dq_kernel<true>, gq, block, 0, st, q, k, v, mask, mask_mode, causal, B, H, Lq, Lk, scale, out, dout, lse, dq);
+        hipLaunchKernelGGL(attention_bwd_dkv_kernel<true>, gk, block, 0, st, q, k, v, mask, mask_mode, causal, B, H, Lq, Lk, scale, out, dout, lse, dk, dv);
+    } else {
+        hipLaunchKernelGGL(attention_bwd_dq_kernel<false>, gq, block, 0, st, q, k, v, mask, mask_mode, causal, B, H, Lq, Lk, scale, out, dout, lse, dq);
+        hipLaunchKernelGGL(attention_bwd_dkv_kernel<false>, gk, block, 0, st, q, k, v, mask, mask_mode, causal, B, H, Lq, Lk, scale, out, dout, lse, dk, dv);
+    }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? TRX_NN_OK : fail(TRX_NN_EHIP, hipGetErrorString(e));
 }

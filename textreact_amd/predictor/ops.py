@@ -18,7 +18,7 @@ _lib = None
 F32, BF16 = 0, 1
 MASK_NONE, MASK_KEY, MASK_FULL = 0, 1, 2
 SYMBOLS = ["trx_add_layernorm_fwd", "trx_add_layernorm_bwd", "trx_add_layernorm_bwd_blocks",
-           "trx_attention_fwd", "trx_nn_last_error", "trx_nn_version"]
+           "trx_attention_fwd", "trx_attention_fwd_lse", "trx_attention_bwd", "trx_nn_last_error", "trx_nn_version"]
 
 
 class TrxNNError(RuntimeError):
@@ -36,6 +36,8 @@ def lib():
         L.trx_add_layernorm_bwd.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, i32, vp, vp, vp, vp, vp]
         L.trx_add_layernorm_bwd_blocks.argtypes = [i64]
         L.trx_attention_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, i32, vp, vp]
+        L.trx_attention_fwd_lse.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, i32, vp, vp, vp]
+        L.trx_attention_bwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp]
         L.trx_nn_last_error.restype = ctypes.c_char_p
         L.trx_nn_version.restype = ctypes.c_char_p
         _lib = L
@@ -113,6 +115,41 @@ def add_layernorm(x, res, gamma, beta, eps, backend="hip"):
     return torch.nn.functional.layer_norm(z.float(), (z.shape[-1],), gamma.float(), beta.float(), eps).to(x.dtype)
 
 
+class _Attention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, mask, causal, scale):
+        B, Lq, H, D = q.shape
+        Lk = k.shape[1]
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        mode, m = MASK_NONE, None
+        if mask is not None:
+            m = mask.float().contiguous()
+            mode = MASK_KEY if m.dim() == 2 else MASK_FULL
+            assert m.shape == ((B, Lk) if mode == MASK_KEY else (B, Lq, Lk)), m.shape
+        out = torch.empty((B, Lq, H * D), dtype=q.dtype, device=q.device)
+        need = q.requires_grad or k.requires_grad or v.requires_grad
+        lse = torch.empty((B, H, Lq), dtype=torch.float32, device=q.device) if need else None
+        _check(lib().trx_attention_fwd_lse(_p(q), _p(k), _p(v), _p(m), mode, 1 if causal else 0, B, H, Lq, Lk,
+                                           float(scale), _dt(q), _p(out), _p(lse), _stream(q)))
+        if need:
+            ctx.save_for_backward(q, k, v, m if m is not None else q.new_empty(0), out, lse)
+            ctx.cfg = (mode, causal, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, m, out, lse = ctx.saved_tensors
+        mode, causal, scale = ctx.cfg
+        B, Lq, H, D = q.shape
+        Lk = k.shape[1]
+        dout = dout.contiguous()
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        _check(lib().trx_attention_bwd(_p(q), _p(k), _p(v), _p(m) if mode != MASK_NONE else None, mode,
+                                       1 if causal else 0, B, H, Lq, Lk, float(scale), _dt(q), _p(out), _p(dout),
+                                       _p(lse), _p(dq), _p(dk), _p(dv), _stream(q)))
+        return dq, dk, dv, None, None, None
+
+
 def attention(q, k, v, mask=None, causal=False, scale=None, backend="hip"):
     """q [B, Lq, H, 64], k / v [B, Lk, H, 64] -> [B, Lq, H*64].
     mask: additive float, [B, Lk] (key padding) or [B, Lq, Lk]; causal: key j visible iff
@@ -125,18 +162,7 @@ def attention(q, k, v, mask=None, causal=False, scale=None, backend="hip"):
         _need_gpu(q)
         if D != 64:
             raise TrxNNError("the attention kernel is specialised for heads of 64 (got %d)" % D)
-        if q.requires_grad or k.requires_grad or v.requires_grad:
-            raise TrxNNError("attention backward is not implemented yet (round 1: inference only)")
-        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
-        mode, m = MASK_NONE, None
-        if mask is not None:
-            m = mask.float().contiguous()
-            mode = MASK_KEY if m.dim() == 2 else MASK_FULL
-            assert m.shape == ((B, Lk) if mode == MASK_KEY else (B, Lq, Lk)), m.shape
-        out = torch.empty((B, Lq, H * D), dtype=q.dtype, device=q.device)
-        _check(lib().trx_attention_fwd(_p(q), _p(k), _p(v), _p(m), mode, 1 if causal else 0, B, H, Lq, Lk,
-                                       float(scale), _dt(q), _p(out), _stream(q)))
-        return out
+        return _Attention.apply(q, k, v, mask, causal, scale)
     # fp32 reference: exactly what BertSelfAttention's eager path computes
     qf, kf, vf = (t.float().permute(0, 2, 1, 3) for t in (q, k, v))             # [B, H, L, D]
     s = torch.matmul(qf, kf.transpose(-1, -2)) * scale
