@@ -1,0 +1,162 @@
+"""Training / evaluation step of the predictor and its checkpoint layout (SURVEY.md section 8a rows
+P3, P4; section 5.4).  Mirrors main.py's ReactionConditionRecommender for the template-free
+models: same attribute names (`model`, `mlm_head` -> state-dict prefixes `model.` / `mlm_head.`,
+main.py:106-108), same losses (main.py:112-134, :158-162), same step (:164-175), same gather of
+evaluation outputs (:259-268), same optimiser (:270-276); Lightning itself is not needed.
+
+Data parallelism is plain `torch.nn.parallel.DistributedDataParallel(find_unused_parameters=True)`
+(main.py:372) over `torch.distributed` -- backend "nccl" is RCCL on ROCm -- one process per GPU.
+"""
+import collections
+import os
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .model import Config, LayerNormParams, TextReactModel
+
+
+class MLMTransform(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.dense = nn.Linear(cfg.hidden_size, cfg.hidden_size)
+        self.LayerNorm = LayerNormParams(cfg.hidden_size)
+
+
+class MLMHead(nn.Module):
+    """BertLMPredictionHead (model.py:40-47, --mlm_layer mlp): transform.{dense,LayerNorm} -> decoder"""
+
+    def __init__(self, cfg, backend="hip"):
+        super().__init__()
+        self.transform = MLMTransform(cfg)
+        self.decoder = nn.Linear(cfg.hidden_size, cfg.vocab_size)
+        self.bias = nn.Parameter(torch.zeros(cfg.vocab_size))
+        self.decoder.bias = self.bias
+        self.eps, self.backend = cfg.layer_norm_eps, backend
+
+    def forward(self, h):
+        x = F.gelu(self.transform.dense(h))
+        x = ops.add_layernorm(x, None, self.transform.LayerNorm.weight, self.transform.LayerNorm.bias, self.eps,
+                              backend=self.backend)
+        return self.decoder(x)
+
+
+class Predictor(nn.Module):
+    """the LightningModule's parameter tree without Lightning"""
+
+    def __init__(self, enc_cfg, dec_cfg, mlm=False, mlm_layer="mlp", mlm_lambda=1.0, pad_token_id=0, backend="hip"):
+        super().__init__()
+        self.model = TextReactModel(enc_cfg, dec_cfg, backend=backend)
+        if mlm:
+            self.mlm_head = MLMHead(enc_cfg, backend) if mlm_layer == "mlp" else nn.Linear(enc_cfg.hidden_size, enc_cfg.vocab_size)
+        self.mlm, self.mlm_lambda, self.pad = mlm, mlm_lambda, pad_token_id
+
+    # main.py:129-134
+    def compute_loss(self, logits, batch_in, reduction="mean"):
+        b, _, vocab = logits.shape
+        labels = batch_in["decoder_input_ids"][:, 1:]
+        loss = F.cross_entropy(logits[:, :-1].reshape(-1, vocab), labels.reshape(-1), ignore_index=self.pad,
+                               reduction=reduction)
+        return loss.view(b, -1).mean(dim=1) if reduction == "none" else loss
+
+    # main.py:151-156: greedy-search accuracy
+    def compute_acc(self, logits, batch_in):
+        preds = logits.argmax(dim=-1)[:, :-1]
+        labels = batch_in["decoder_input_ids"][:, 1:]
+        return torch.logical_or(preds.eq(labels), labels.eq(self.pad)).all(dim=-1).float().mean()
+
+    # main.py:158-162: masked tokens were moved to the front, so only the first trunc_len positions count
+    def compute_mlm_loss(self, encoder_last_hidden_state, labels):
+        b, trunc = labels.shape
+        logits = self.mlm_head(encoder_last_hidden_state[:, :trunc].contiguous())
+        return F.cross_entropy(logits.view(b * trunc, -1), labels.reshape(-1))
+
+    # main.py:164-175
+    def training_step(self, batch_in, batch_out=None):
+        logits, enc = self.model(**batch_in)
+        loss = self.compute_loss(logits, batch_in)
+        logs = {"train_loss": loss.detach()}
+        total = loss
+        if self.mlm:
+            mlm_loss = self.compute_mlm_loss(enc, batch_out["mlm_labels"])
+            total = total + mlm_loss * self.mlm_lambda
+            logs.update(mlm_loss=mlm_loss.detach(), total_loss=total.detach())
+        return total, logs
+
+    # main.py:177-188: per-sample scores of the validation step
+    @torch.no_grad()
+    def validation_step(self, indices, batch_in):
+        logits, _ = self.model(**batch_in)
+        scores = self.compute_loss(logits, batch_in, reduction="none")
+        return {int(i): float(s) for i, s in zip(indices, scores)}
+
+
+def gather_outputs(outputs, group=None):
+    """main.py:259-268: merge the per-rank {idx: value} dicts on every rank"""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return outputs
+    gathered = [None] * dist.get_world_size(group)
+    dist.all_gather_object(gathered, outputs, group=group)
+    merged = {}
+    for o in gathered:
+        merged.update(o)
+    return merged
+
+
+def configure_optimizer(module, lr, weight_decay, num_training_steps, warmup_ratio, scheduler="linear"):
+    """main.py:270-276: AdamW + warm-up/decay schedule stepped per optimiser step"""
+    opt = torch.optim.AdamW(module.parameters(), lr=lr, weight_decay=weight_decay)
+    warm = int(num_training_steps * warmup_ratio)
+
+    def lr_lambda(step):
+        if step < warm:
+            return float(step) / float(max(1, warm))
+        if scheduler == "constant":
+            return 1.0
+        return max(0.0, float(num_training_steps - step) / float(max(1, num_training_steps - warm)))
+    return opt, torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda)
+
+
+# ---- checkpoint layout of pytorch-lightning 2.0 (main.py:358-360, :390-405) --------
+CKPT_KEYS = ("epoch", "global_step", "pytorch-lightning_version", "state_dict", "loops", "callbacks",
+             "optimizer_states", "lr_schedulers")
+
+
+def save_checkpoint(path, module, optimizer=None, lr_scheduler=None, epoch=0, global_step=0, monitor=None):
+    """`best.ckpt` / `last.ckpt`: a torch.save dict with Lightning's keys; `state_dict` carries the
+    module's own names (`model.…`, `mlm_head.…`), so the reference's
+    `load_from_checkpoint(best, strict=False, args=args)` (main.py:404) reads it."""
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    ckpt = collections.OrderedDict()
+    ckpt["epoch"] = int(epoch)
+    ckpt["global_step"] = int(global_step)
+    ckpt["pytorch-lightning_version"] = "2.0.0"
+    ckpt["state_dict"] = collections.OrderedDict((k, v.detach().cpu()) for k, v in module.state_dict().items())
+    ckpt["loops"] = {}
+    ckpt["callbacks"] = {"ModelCheckpoint": {"monitor": monitor, "best_model_path": os.path.abspath(path)}}
+    ckpt["optimizer_states"] = [optimizer.state_dict()] if optimizer is not None else []
+    ckpt["lr_schedulers"] = [lr_scheduler.state_dict()] if lr_scheduler is not None else []
+    torch.save(ckpt, path)
+    return path
+
+
+def load_checkpoint(path, module, optimizer=None, lr_scheduler=None, strict=False):
+    ckpt = torch.load(path, map_location="cpu", weights_only=False)
+    sd = {k: v for k, v in ckpt["state_dict"].items() if not k.endswith("position_ids")}   # 4.27.3 buffer
+    missing, unexpected = module.load_state_dict(sd, strict=strict)
+    if optimizer is not None and ckpt.get("optimizer_states"):
+        optimizer.load_state_dict(ckpt["optimizer_states"][0])
+    if lr_scheduler is not None and ckpt.get("lr_schedulers"):
+        lr_scheduler.load_state_dict(ckpt["lr_schedulers"][0])
+    return ckpt, missing, unexpected
+
+
+def clear_checkpoints(save_path):
+    """--overwrite: delete every *.ckpt first (textreact/utils.py:47-52)"""
+    if os.path.isdir(save_path):
+        for f in os.listdir(save_path):
+            if f.endswith(".ckpt"):
+                os.remove(os.path.join(save_path, f))
