@@ -32,9 +32,87 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// ---- add + LayerNorm forward: one wave per row, the row cached in registers (cols <= 64*CPL) ----
+// ---- add + LayerNorm forward: one wave per row, the row cached in registers -----------------------
 // HBM-bound: algorithmic bytes = rows * cols * (x + res + y) * sizeof(dtype).
-constexpr int CPL = 32;  // cached values per lane -> cols <= 2048 in registers; larger rows re-read
+// Fast path: 16 bytes per lane per access (8 bf16 / 4 f32), up to NCH chunks per lane in registers
+// (cols <= 2048 bf16 / 1024 f32; 768 = 1.5 / 3 chunks per lane).  Other shapes: scalar fallback.
+constexpr int CPL = 32;  // scalar fallback: cached values per lane
+constexpr int NCH = 4;
+template <bool BF> struct Vec16 { static constexpr int N = BF ? 8 : 4; };
+template <bool BF> __device__ __forceinline__ void unpack16(const uint4& u, float* f) {
+    const unsigned w[4] = {u.x, u.y, u.z, u.w};
+    if (BF) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { f[2 * i] = __uint_as_float(w[i] << 16); f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f[i] = __uint_as_float(w[i]);
+    }
+}
+template <bool BF> __device__ __forceinline__ uint4 pack16(const float* f) {
+    unsigned w[4];
+    if (BF) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = (unsigned)f2bf(f[2 * i]) | ((unsigned)f2bf(f[2 * i + 1]) << 16);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = __float_as_uint(f[i]);
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+template <bool BF>
+__global__ __launch_bounds__(256) void add_ln_fwd_vec_kernel(const void* x, const void* res, const float* gamma,
+                                                             const float* beta, float eps, int64_t rows, int cols,
+                                                             void* y, float* mean, float* rstd) {
+    constexpr int V = Vec16<BF>::N;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nchunk = cols / V;
+    const char* xr = reinterpret_cast<const char*>(x) + row * cols * (BF ? 2 : 4);
+    const char* rr = res ? reinterpret_cast<const char*>(res) + row * cols * (BF ? 2 : 4) : nullptr;
+    char* yr = reinterpret_cast<char*>(y) + row * cols * (BF ? 2 : 4);
+    float v[NCH][V];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nchunk) {
+            unpack16<BF>(*reinterpret_cast<const uint4*>(xr + (size_t)c * 16), v[i]);
+            if (rr) {
+                float r[V];
+                unpack16<BF>(*reinterpret_cast<const uint4*>(rr + (size_t)c * 16), r);
+#pragma unroll
+                for (int j = 0; j < V; ++j) v[i][j] += r[j];
+            }
+#pragma unroll
+            for (int j = 0; j < V; ++j) s += v[i][j];
+        }
+    }
+    const float mu = wave_sum(s) / (float)cols;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+        if (lane + 64 * i < nchunk) {
+#pragma unroll
+            for (int j = 0; j < V; ++j) { const float d = v[i][j] - mu; q += d * d; }
+        }
+    const float rs = rsqrtf(wave_sum(q) / (float)cols + eps);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nchunk) {
+            float o[V];
+#pragma unroll
+            for (int j = 0; j < V; ++j) o[j] = (v[i][j] - mu) * rs * gamma[c * V + j] + beta[c * V + j];
+            *reinterpret_cast<uint4*>(yr + (size_t)c * 16) = pack16<BF>(o);
+        }
+    }
+    if (lane == 0) { if (mean) mean[row] = mu; if (rstd) rstd[row] = rs; }
+}
+
+// scalar fallback (any cols)
 template <bool BF>
 __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const void* x, const void* res, const float* gamma,
                                                          const float* beta, float eps, int64_t rows, int cols,
@@ -305,8 +383,16 @@ int trx_add_layernorm_fwd(const void* x, const void* res, const float* gamma, co
     if (rows == 0) return TRX_NN_OK;
     dim3 grid((unsigned)((rows + 3) / 4)), block(256);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == TRX_NN_BF16) hipLaunchKernelGGL(add_ln_fwd_kernel<true>, grid, block, 0, st, x, res, gamma, beta, eps, rows, cols, y, mean, rstd);
-    else hipLaunchKernelGGL(add_ln_fwd_kernel<false>, grid, block, 0, st, x, res, gamma, beta, eps, rows, cols, y, mean, rstd);
+    const int V = dtype == TRX_NN_BF16 ? 8 : 4;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(res)) & 15) == 0;
+    const bool vec = aligned && cols % V == 0 && cols <= 64 * NCH * V;
+    if (vec) {
+        if (dtype == TRX_NN_BF16) hipLaunchKernelGGL(add_ln_fwd_vec_kernel<true>, grid, block, 0, st, x, res, gamma, beta, eps, rows, cols, y, mean, rstd);
+        else hipLaunchKernelGGL(add_ln_fwd_vec_kernel<false>, grid, block, 0, st, x, res, gamma, beta, eps, rows, cols, y, mean, rstd);
+    } else {
+        if (dtype == TRX_NN_BF16) hipLaunchKernelGGL(add_ln_fwd_kernel<true>, grid, block, 0, st, x, res, gamma, beta, eps, rows, cols, y, mean, rstd);
+        else hipLaunchKernelGGL(add_ln_fwd_kernel<false>, grid, block, 0, st, x, res, gamma, beta, eps, rows, cols, y, mean, rstd);
+    }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? TRX_NN_OK : fail(TRX_NN_EHIP, hipGetErrorString(e));
 }
