@@ -3,7 +3,8 @@
 scripts/train_RCR.sh (per-GPU batch 32, L = 512, hidden 768, 12 heads) against their rooflines.
 
   add+LayerNorm : HBM-bound, algorithmic bytes = rows*cols*(x + res + y)*sizeof(dtype)
-  attention     : FLOPs = 4*B*H*Lq*Lk*64 (fp32 VALU kernel: peak 157.3 TFLOP/s vector fp32)
+  attention     : FLOPs = 4*B*H*Lq*Lk*64 (bf16: MFMA flash kernel, peak 2.5 PFLOP/s dense;
+                  fp32: VALU kernel, the accuracy path, peak 157.3 TFLOP/s vector fp32)
 Prints one JSON line per kernel; timing = torch.cuda.Event on torch's current stream, which is the
 stream the kernels are launched on (ops.py passes it through the C ABI)."""
 import json
@@ -52,7 +53,9 @@ def main():
             ref = timeit(lambda: ops.attention(q, k, v, mask=m, causal=causal, backend="torch"), iters=10)
             out.append({"kernel": "attention_fwd", "what": name, "dtype": str(dtype), "B": B, "H": H, "Lq": Lq, "Lk": Lk,
                         "ms": ms, "torch_eager_fp32_ms": ref,
-                        "roofline": {"bound": "valu-fp32", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3}})
+                        "roofline": ({"bound": "mfma", "achieved": tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": tf / 2500.0}
+                                     if dtype == torch.bfloat16 else
+                                     {"bound": "valu-fp32", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3})})
     for o in out:
         print(json.dumps(o))
 

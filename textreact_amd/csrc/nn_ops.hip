@@ -7,6 +7,7 @@
 #include "../../include/trx_nn.h"
 #include <hip/hip_runtime.h>
 #include <string>
+#include <cstdlib>
 
 namespace {
 
@@ -274,6 +275,144 @@ __global__ __launch_bounds__(64) void attention_fwd_kernel(const void* __restric
     }
 }
 
+// ---- attention forward on the matrix cores (bf16 storage, fp32 accumulate) -----------------------
+// Workgroup = 4 waves = 128 queries of one (batch, head); a wave owns 32 queries and walks the keys in
+// tiles of 32.  The score tile is computed TRANSPOSED, S^T = K Q^T with v_mfma_f32_32x32x16_bf16
+// (A = K rows from LDS, B = Q fragments held in registers), so a lane owns ONE query (col = lane & 31)
+// and its 16 accumulator registers are 16 of the tile's 32 keys: the softmax row statistics are
+// lane-local plus one exchange with lane ^ 32.  The probabilities then feed the second product
+// without leaving registers: O^T += V^T P^T, where registers 8s..8s+7 of the S^T accumulator,
+// converted to bf16, ARE the B fragment of k-step s (cdna guide section 3, "an accumulator tile as
+// the next MFMA's operand"), and the matching V^T fragments -- keys 16s + 8(j>>2) + 4h + (j&3) for
+// element j of lane half h -- are read column-major from the row-major V tile with
+// ds_read_b64_tr_b16.  FLOPs = 4 B H Lq Lk 64; K/V tiles are staged through LDS by all 256 threads.
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+__device__ __forceinline__ unsigned pack2bf(float a, float b) { return (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16); }
+
+__global__ __launch_bounds__(256) void attention_fwd_mfma_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                                 const bf16_t* __restrict__ v, const float* __restrict__ mask,
+                                                                 int mask_mode, int causal, int B, int H, int Lq, int Lk,
+                                                                 float scale, bf16_t* __restrict__ out, float* __restrict__ lse) {
+    __shared__ __attribute__((aligned(16))) char lds[4096 + 4096 + 128];
+    char* ldsK = lds; char* ldsV = lds + 4096; float* ldsM = reinterpret_cast<float*>(lds + 8192);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int nqb = (Lq + 127) / 128;
+    const int qb = blockIdx.x % nqb, h = (blockIdx.x / nqb) % H, b = blockIdx.x / (nqb * H);
+    const int qidx = qb * 128 + wave * 32 + r;              // this lane's query
+    const int qc = qidx < Lq ? qidx : Lq - 1;
+    // Q fragments: B operand, B[k = 8hh + j][col r] = Q[query r][d = 16 s + 8 hh + j]
+    bf16x8 qf[4];
+    {
+        const bf16_t* qp = q + (((int64_t)b * Lq + qc) * H + h) * 64 + 8 * hh;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+    }
+    f32x16 o0, o1;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) { o0[t] = 0.f; o1[t] = 0.f; }
+    float m = -__builtin_inff(), lsum = 0.f;
+    const int off = Lk - Lq;
+    int nkb = (Lk + 31) / 32;
+    if (causal) {  // last key any query of this workgroup can see
+        const int lastq = min(Lq - 1, qb * 128 + 127);
+        nkb = min(nkb, (lastq + off) / 32 + 1);
+    }
+    const int srow = tid >> 3, schunk = tid & 7;
+    // transposed-read addressing of the V tile (see header): 16-lane group g, lane 4qq+pp of the group
+    const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
+    const unsigned ldsbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;  // LDS offset of the tile buffers
+    const unsigned vtr = ldsbase + (unsigned)(4096 + (4 * (g >> 1) + qq) * 128 + (16 * (g & 1) + 4 * pp) * 2);
+    const unsigned ka = (unsigned)(r * 128);
+    const int kswz = (r >> 1) & 7;
+
+    for (int kb = 0; kb < nkb; ++kb) {
+        __syncthreads();
+        {
+            const int key = min(kb * 32 + srow, Lk - 1);
+            const int64_t go = (((int64_t)b * Lk + key) * H + h) * 64 + schunk * 8;
+            const uint4 kr = *reinterpret_cast<const uint4*>(k + go);
+            const uint4 vr = *reinterpret_cast<const uint4*>(v + go);
+            *reinterpret_cast<uint4*>(ldsK + srow * 128 + ((schunk ^ ((srow >> 1) & 7)) << 4)) = kr;
+            *reinterpret_cast<uint4*>(ldsV + srow * 128 + schunk * 16) = vr;
+            if (mask_mode == TRX_NN_MASK_KEY && tid < 32) ldsM[tid] = (kb * 32 + tid < Lk) ? mask[(int64_t)b * Lk + kb * 32 + tid] : 0.f;
+        }
+        __syncthreads();
+        // ---- S^T = K Q^T ----
+        f32x16 st;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) st[t] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(ldsK + ka + (((2 * s + hh) ^ kswz) << 4));
+            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[s], st, 0, 0, 0);
+        }
+        // ---- scale, mask, visibility; lane-local row maximum ----
+        float p[16];
+        float mb = -__builtin_inff();
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int kr_ = (t & 3) + 8 * (t >> 2) + 4 * hh;      // key row inside the tile
+            const int key = kb * 32 + kr_;
+            float val = st[t] * scale;
+            if (mask_mode == TRX_NN_MASK_KEY) val += ldsM[kr_];
+            else if (mask_mode == TRX_NN_MASK_FULL) val += mask[((int64_t)b * Lq + qc) * Lk + min(key, Lk - 1)];
+            const bool hidden = key >= Lk || (causal && key > qidx + off);
+            p[t] = hidden ? -__builtin_inff() : val;
+            mb = fmaxf(mb, p[t]);
+        }
+        mb = fmaxf(mb, __shfl_xor(mb, 32, 64));
+        const float mn = fmaxf(m, mb);
+        const float alpha = (m == mn) ? 1.0f : __expf(m - mn);
+        float ps = 0.f;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            p[t] = (p[t] == -__builtin_inff()) ? 0.f : __expf(p[t] - mn);
+            ps += p[t];
+        }
+        lsum = lsum * alpha + ps;
+        m = mn;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) { o0[t] *= alpha; o1[t] *= alpha; }
+        // ---- O^T += V^T P^T ----
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            uint4 pw;
+            pw.x = pack2bf(p[8 * s + 0], p[8 * s + 1]); pw.y = pack2bf(p[8 * s + 2], p[8 * s + 3]);
+            pw.z = pack2bf(p[8 * s + 4], p[8 * s + 5]); pw.w = pack2bf(p[8 * s + 6], p[8 * s + 7]);
+            const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                uint2 lo, hi;   // keys 16s + 4hh + 0..3 and 16s + 8 + 4hh + 0..3, column d = 32 db + r
+                const unsigned a0 = vtr + (unsigned)(16 * s * 128 + 64 * db);
+                asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(lo), "=&v"(hi) : "v"(a0) : "memory");
+                uint4 vw; vw.x = lo.x; vw.y = lo.y; vw.z = hi.x; vw.w = hi.y;
+                const bf16x8 vf = __builtin_bit_cast(bf16x8, vw);
+                if (db == 0) o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o0, 0, 0, 0);
+                else o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o1, 0, 0, 0);
+            }
+        }
+    }
+    const float ltot = lsum + __shfl_xor(lsum, 32, 64);
+    if (qidx < Lq) {
+        const float inv = 1.0f / ltot;
+        if (lse && hh == 0) lse[((int64_t)b * H + h) * Lq + qidx] = m + __logf(ltot);
+        bf16_t* op = out + ((int64_t)b * Lq + qidx) * H * 64 + (int64_t)h * 64;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {   // registers 4gq..4gq+3 = d rows 8gq + 4hh + 0..3
+            uint2 w0, w1;
+            w0.x = pack2bf(o0[4 * gq] * inv, o0[4 * gq + 1] * inv); w0.y = pack2bf(o0[4 * gq + 2] * inv, o0[4 * gq + 3] * inv);
+            w1.x = pack2bf(o1[4 * gq] * inv, o1[4 * gq + 1] * inv); w1.y = pack2bf(o1[4 * gq + 2] * inv, o1[4 * gq + 3] * inv);
+            *reinterpret_cast<uint2*>(op + 8 * gq + 4 * hh) = w0;
+            *reinterpret_cast<uint2*>(op + 32 + 8 * gq + 4 * hh) = w1;
+        }
+    }
+}
+
 // ---- attention backward, fp32 math, probabilities recomputed from lse --------------------------
 // pass 1 (a lane per query row i):  delta_i = dO_i . O_i ;  dS_ij = p_ij (dO_i . V_j - delta_i) ;
 //                                   dQ_i = scale * sum_j dS_ij K_j
@@ -428,7 +567,12 @@ int trx_attention_fwd_lse(const void* q, const void* k, const void* v, const flo
     const int qblocks = (Lq + 63) / 64;
     dim3 grid((unsigned)((int64_t)B * H * qblocks)), block(64);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == TRX_NN_BF16) hipLaunchKernelGGL(attention_fwd_kernel<true>, grid, block, 0, st, q, k, v, mask, mask_mode, causal, B, H, Lq, Lk, scale, out, lse);
+    static const bool force_valu = getenv("TRX_NN_ATTN_VALU") != nullptr;
+    if (dtype == TRX_NN_BF16 && !force_valu) {
+        dim3 g2((unsigned)((int64_t)B * H * ((Lq + 127) / 128))), b2(256);
+        hipLaunchKernelGGL(attention_fwd_mfma_kernel, g2, b2, 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, mask,
+                           mask_mode, causal, B, H, Lq, Lk, scale, (bf16_t*)out, lse);
+    } else if (dtype == TRX_NN_BF16) hipLaunchKernelGGL(attention_fwd_kernel<true>, grid, block, 0, st, q, k, v, mask, mask_mode, causal, B, H, Lq, Lk, scale, out, lse);
     else hipLaunchKernelGGL(attention_fwd_kernel<false>, grid, block, 0, st, q, k, v, mask, mask_mode, causal, B, H, Lq, Lk, scale, out, lse);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? TRX_NN_OK : fail(TRX_NN_EHIP, hipGetErrorString(e));
