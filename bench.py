@@ -72,6 +72,33 @@ def cpu_baseline(corpus_dev, queries_dev, k, target_seconds=15.0):
                       % (nq, queries_dev.shape[0], y.shape[0], y.shape[1])}, I
 
 
+def fingerprint_workload(args, dev, local_rank):
+    """retrieve/retrieve_faiss.py:62-74 as the reference runs it: L2, k = 20, d = 2048 sparse signed counts,
+    the training set searching itself (:114-115).  Secondary line, printed for DESIGN.md."""
+    import torch
+    import textreact_amd.faiss_compat as faiss
+    n = args.n_corpus if args.n_corpus != N_CORPUS else 680_000     # ~ USPTO-condition train size
+    g = torch.Generator(device=dev); g.manual_seed(1)
+    mask = torch.rand((n, 2048), generator=g, device=dev) < 0.02
+    vals = torch.randint(-10, 11, (n, 2048), generator=g, device=dev)
+    y = (mask * vals).to(torch.bfloat16)
+    del mask, vals
+    idx = faiss.IndexFlatL2(2048, device=local_rank)
+    idx.set_timing(True)
+    idx.add(y)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    D, I = idx.search(y, 20)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    st = idx.last_stats()
+    ok = bool((I[:, 0] == torch.arange(n, device=dev)).float().mean() > 0.99) and bool((D[:, 0] == 0).all())
+    print(json.dumps({"metric": "train self-search, IndexFlatL2 k=20 (reference workload)", "value": n / (t1 - t0),
+                      "unit": "queries/s", "seconds": t1 - t0, "n": n, "d": 2048, "k": 20, "scan_ms": st["scan_ms"],
+                      "exact_class": st["exact_class"], "uncertified": st["n_uncertified"], "self_is_first": ok,
+                      "tflops": 2.0 * n * n * 2048 / (st["scan_ms"] * 1e-3) / 1e12 if st["scan_ms"] else None}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -80,6 +107,9 @@ def main():
     ap.add_argument("--n-corpus", type=int, default=N_CORPUS)
     ap.add_argument("--n-queries", type=int, default=N_QUERIES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="dense", choices=["dense", "fingerprint"],
+                    help="dense = the headline (BASELINE.json configs[1]); fingerprint = the reference's own call: "
+                         "IndexFlatL2, k=20, 2048-d integer reaction fingerprints, train set searching itself (not the headline)")
     args = ap.parse_args()
 
     import torch
@@ -101,6 +131,8 @@ def main():
     from textreact_amd.sharded import ShardedFlatIndex, shard_bounds
 
     n, d, nq, k = args.n_corpus, DIM, args.n_queries, TOPK
+    if args.workload == "fingerprint":
+        return fingerprint_workload(args, dev, local_rank)
     lo, hi = shard_bounds(n, world, rank)
     shard = make_rows(hi - lo, d, 1234, dev, row0=lo)
     queries = make_rows(nq, d, 5678, dev)

@@ -271,3 +271,49 @@ def test_c1_full_size_properties():
         Dr, Ir = oracle.knn_canonical(metric, xs, y.float().cpu().numpy(), k)
         assert np.array_equal(Ih[sel], Ir) and np.array_equal(Dh[sel].view(np.uint32), Dr.view(np.uint32))
         del idx
+
+
+def test_more_than_one_query_batch_and_many_splits():
+    # 70,000 queries -> two internal batches (65,536 + 4,464); small corpus -> many corpus splits
+    import torch
+    import textreact_amd.faiss_compat as faiss
+    from oracle import flat_knn as oracle
+    y = gaussian(3000, 64, 1)
+    x = gaussian(70000, 64, 2)
+    idx = faiss.IndexFlatIP(64)
+    idx.add(y)
+    D, I = idx.search(x, 5)
+    sel = np.r_[0:50, 65500:65600, 69950:70000]
+    Dr, Ir = oracle.knn_canonical(IP, x[sel], y, 5)
+    assert np.array_equal(I[sel], Ir) and np.array_equal(D[sel].view(np.uint32), Dr.view(np.uint32))
+    # a few hundred queries against a corpus of 100k rows: nsplits > 1, uneven last split
+    y2 = gaussian(100_003, 96, 3); x2 = gaussian(300, 96, 4)
+    for metric in (IP, L2):
+        st = _check(metric, x2, y2, 10)
+        assert st["n_splits"] > 1
+
+
+def test_device_tensors_fp32_and_reset():
+    import torch
+    import textreact_amd.faiss_compat as faiss
+    from oracle import flat_knn as oracle
+    y = gaussian(4000, 80, 5); x = gaussian(60, 80, 6)
+    idx = faiss.IndexFlatL2(80)
+    idx.add(torch.from_numpy(y).cuda())
+    D, I = idx.search(torch.from_numpy(x).cuda(), 7)
+    Dr, Ir = oracle.knn_canonical(L2, x, y, 7)
+    assert np.array_equal(I.cpu().numpy(), Ir) and np.array_equal(D.cpu().numpy(), Dr)
+    idx.reset()
+    assert idx.ntotal == 0
+    idx.add(y[:10])
+    D, I = idx.search(x[:3], 12)
+    assert (I[:, 10:] == -1).all() and (I[:, :10] >= 0).all()
+
+
+def test_values_outside_bf16_range_and_tiny_values():
+    # large magnitudes and subnormal-ish small values through the split operand
+    rng = np.random.default_rng(9)
+    y = (rng.standard_normal((3000, 48)) * np.exp(rng.uniform(-20, 20, (3000, 1)))).astype(np.float32)
+    x = rng.standard_normal((64, 48)).astype(np.float32)
+    _check(IP, x, y, 10)
+    _check(L2, x, y, 10)
