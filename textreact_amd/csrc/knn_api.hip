@@ -302,7 +302,6 @@ static int search_batch(trx_index* idx, const void* q, int64_t nq, int is_bf, in
     sp.cand = (u64*)idx->w_cand.p; sp.cand_cnt = (u32*)idx->w_cnt.p; sp.cand_thr = (u64*)idx->w_thr.p;
     sp.scratch = idx->w_scratch.p;
     { const char* dbg = getenv("TRX_SCAN_DEBUG"); sp.debug = dbg ? atoi(dbg) : 0; }
-    { const char* e = getenv("TRX_POLICY"); sp.policy = e ? atoi(e) : 0; }
     sp.stamp_out = nullptr;
 #ifdef TRX_STAMP_BUILD
     if ((rc = idx->w_stamp.reserve((size_t)nwg * 8 * 4 * sizeof(unsigned long long)))) return rc;

@@ -124,7 +124,6 @@ struct ScanParams {
                              // workgroups of a query (atomicMax, monotone; a stale read is only looser)
     int bootstrap;           // 1: threshold bootstrap launch (one tile per query tile, publish g_thr only)
     int have_boot;           // 1: g_thr was seeded by a bootstrap launch
-    int policy;              // cache policy of the DMA streams: bit 0 = queries nt, bit 1 = corpus nt
     int debug;               // timing-only diagnostics (TRX_SCAN_DEBUG), 0 in production
     unsigned long long* stamp_out;  // diagnostic build (-DTRX_STAMP_BUILD) only: [grid][8 waves][4] cycle sums
 };

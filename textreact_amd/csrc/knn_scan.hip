@@ -390,14 +390,10 @@ static hipError_t launch_one(const ScanParams& p, hipStream_t st) {
 }
 
 hipError_t launch_scan(const ScanParams& p, int metric, hipStream_t st) {
-    // cache policy of the two LDS-DMA streams: 0 = default, 2 = nt (non-temporal)
-    const int pol = p.policy;
-    if (metric == 1) {
-        switch (pol) { case 1: return launch_one<true, 0, 2>(p, st); case 2: return launch_one<true, 2, 0>(p, st);
-                       case 3: return launch_one<true, 2, 2>(p, st); default: return launch_one<true, 0, 0>(p, st); }
-    }
-    switch (pol) { case 1: return launch_one<false, 0, 2>(p, st); case 2: return launch_one<false, 2, 0>(p, st);
-                   case 3: return launch_one<false, 2, 2>(p, st); default: return launch_one<false, 0, 0>(p, st); }
+    // cache policy of the two LDS-DMA streams is the default one: `nt` on the corpus stream, the
+    // query stream or both measured 107-122 ms against 92 ms, so only <0, 0>
+    // is instantiated.
+    return metric == 1 ? launch_one<true, 0, 0>(p, st) : launch_one<false, 0, 0>(p, st);
 }
 
 }  // namespace trx
