@@ -280,7 +280,8 @@ __global__ __launch_bounds__(64) void attention_fwd_kernel(const void* __restric
 // tiles of 32.  The score tile is computed TRANSPOSED, S^T = K Q^T with v_mfma_f32_32x32x16_bf16
 // (A = K rows from LDS, B = Q fragments held in registers), so a lane owns ONE query (col = lane & 31)
 // and its 16 accumulator registers are 16 of the tile's 32 keys: the softmax row statistics are
-// lane-local plus one exchange with lane ^ 32.  The probabilities then feed the second product
+// lane-local plus one exchange with lane ^ 32.  Key tiles of 64, next tile's global loads in flight
+// under the current tile's math, exponentials as exp2 with the scale folded in.  The probabilities then feed the second product
 // without leaving registers: O^T += V^T P^T, where registers 8s..8s+7 of the S^T accumulator,
 // converted to bf16, ARE the B fragment of k-step s (cdna guide section 3, "an accumulator tile as
 // the next MFMA's operand"), and the matching V^T fragments -- keys 16s + 8(j>>2) + 4h + (j&3) for
@@ -292,20 +293,59 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 __device__ __forceinline__ unsigned pack2bf(float a, float b) { return (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16); }
 
-__global__ __launch_bounds__(256) void attention_fwd_mfma_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+// one 64-key tile of the online softmax, in the transposed accumulator layout: register t of half
+// hb holds key row hb*32 + (t&3) + 8*(t>>2) + 4*hh of the tile for this lane's query.  Scores are
+// moved to base 2 (scale * log2 e folded in).  VIS: the tile has keys that are out of range or
+// hidden by causality (wave-uniform); MM: mask mode.
+template <bool VIS, int MM>
+__device__ __forceinline__ void attn_softmax_tile(f32x16& s0, f32x16& s1, f32x16& o0, f32x16& o1, float& m, float& lsum,
+                                                  float sl2, const float* __restrict__ ldsMt, const float* __restrict__ mrow,
+                                                  int key0, int hh, int Lk, int klim) {
+    constexpr float L2E = 1.44269504088896340736f;
+    float mb = -__builtin_inff();
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int kr_ = hb * 32 + (t & 3) + 8 * (t >> 2) + 4 * hh;
+            float val = (hb ? s1[t] : s0[t]) * sl2;
+            if (MM == TRX_NN_MASK_KEY) val = __builtin_fmaf(ldsMt[kr_], L2E, val);
+            else if (MM == TRX_NN_MASK_FULL) val = __builtin_fmaf(mrow[min(key0 + kr_, Lk - 1)], L2E, val);
+            if (VIS) val = (key0 + kr_ > klim) ? -__builtin_inff() : val;
+            if (hb) s1[t] = val; else s0[t] = val;
+            mb = fmaxf(mb, val);
+        }
+    mb = fmaxf(mb, __shfl_xor(mb, 32, 64));
+    const float mn = fmaxf(m, mb);
+    const float mref = (mn == -__builtin_inff()) ? 0.f : mn;   // all hidden so far: exp2(-inf - 0) = 0, no NaN
+    const float alpha = __builtin_amdgcn_exp2f(m - mref);
+    float ps = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) { s0[t] = __builtin_amdgcn_exp2f(s0[t] - mref); ps += s0[t]; }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) { s1[t] = __builtin_amdgcn_exp2f(s1[t] - mref); ps += s1[t]; }
+    lsum = lsum * alpha + ps;
+    m = mn;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) { o0[t] *= alpha; o1[t] *= alpha; }
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attention_fwd_mfma_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                                  const bf16_t* __restrict__ v, const float* __restrict__ mask,
                                                                  int mask_mode, int causal, int B, int H, int Lq, int Lk,
                                                                  float scale, bf16_t* __restrict__ out, float* __restrict__ lse) {
-    __shared__ __attribute__((aligned(16))) char lds[4096 + 4096 + 128];
-    char* ldsK = lds; char* ldsV = lds + 4096; float* ldsM = reinterpret_cast<float*>(lds + 8192);
+    // key tiles of 64, double buffered, filled by LDS-DMA: [buf][K 8 KiB | V 8 KiB], mask [buf][64]
+    __shared__ __attribute__((aligned(16))) char lds[2 * 16384 + 512];
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef __attribute__((address_space(1))) const void gbl_void;
+    float* ldsM = reinterpret_cast<float*>(lds + 32768);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
     const int nqb = (Lq + 127) / 128;
     const int qb = blockIdx.x % nqb, h = (blockIdx.x / nqb) % H, b = blockIdx.x / (nqb * H);
     const int qidx = qb * 128 + wave * 32 + r;              // this lane's query
     const int qc = qidx < Lq ? qidx : Lq - 1;
-    // Q fragments: B operand, B[k = 8hh + j][col r] = Q[query r][d = 16 s + 8 hh + j]
-    bf16x8 qf[4];
+    bf16x8 qf[4];   // B operand of S^T = K Q^T: B[k = 8hh + j][col r] = Q[query r][d = 16 s + 8 hh + j]
     {
         const bf16_t* qp = q + (((int64_t)b * Lq + qc) * H + h) * 64 + 8 * hh;
 #pragma unroll
@@ -314,93 +354,127 @@ __global__ __launch_bounds__(256) void attention_fwd_mfma_kernel(const bf16_t* _
     f32x16 o0, o1;
 #pragma unroll
     for (int t = 0; t < 16; ++t) { o0[t] = 0.f; o1[t] = 0.f; }
+    const float sl2 = scale * 1.44269504088896340736f;
     float m = -__builtin_inff(), lsum = 0.f;
     const int off = Lk - Lq;
-    int nkb = (Lk + 31) / 32;
+    int nkb = (Lk + 63) / 64;
     if (causal) {  // last key any query of this workgroup can see
         const int lastq = min(Lq - 1, qb * 128 + 127);
-        nkb = min(nkb, (lastq + off) / 32 + 1);
+        nkb = min(nkb, (lastq + off) / 64 + 1);
     }
-    const int srow = tid >> 3, schunk = tid & 7;
-    // transposed-read addressing of the V tile (see header): 16-lane group g, lane 4qq+pp of the group
-    const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
-    const unsigned ldsbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;  // LDS offset of the tile buffers
-    const unsigned vtr = ldsbase + (unsigned)(4096 + (4 * (g >> 1) + qq) * 128 + (16 * (g & 1) + 4 * pp) * 2);
-    const unsigned ka = (unsigned)(r * 128);
-    const int kswz = (r >> 1) & 7;
+    // last visible key of this lane's query (also bounds the tail tile)
+    const int klim = causal ? min(Lk - 1, qidx + off) : Lk - 1;
+    const int klim_wave_min = causal ? min(Lk - 1, qb * 128 + wave * 32 + off) : Lk - 1;   // smallest klim in the wave
+    const float* mrow = (mask_mode == TRX_NN_MASK_FULL) ? mask + ((int64_t)b * Lq + qc) * Lk : nullptr;
 
+    // LDS-DMA geometry: a piece is one global_load_lds_dwordx4 = 8 rows x 128 B written lane-linear
+    // (row 8p + lane/8, slot lane%8); wave w moves pieces 2w, 2w+1 of K and of V.  K's bank swizzle
+    // (slot = chunk ^ ((row >> 1) & 7)) is applied to the SOURCE chunk; V is stored straight.
+    const int prow = lane >> 3, pslot = lane & 7;
+    const int64_t hstride = (int64_t)H * 64;
+    const bf16_t* kbase = k + ((int64_t)b * Lk * H + h) * 64;
+    const bf16_t* vbase = v + ((int64_t)b * Lk * H + h) * 64;
+#define TRX_ATT_STAGE(KB, BUF)                                                                              \
+    {                                                                                                       \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                  \
+            const int p_ = 2 * wave + i_;                                                                   \
+            const int key_ = min((KB) * 64 + 8 * p_ + prow, Lk - 1);                                        \
+            const int kc_ = pslot ^ (4 * i_ + (prow >> 1));                                                 \
+            __builtin_amdgcn_global_load_lds((gbl_void*)(kbase + key_ * hstride + kc_ * 8),                 \
+                                             (lds_void*)(lds + (BUF) * 16384 + p_ * 1024), 16, 0, 0);       \
+            __builtin_amdgcn_global_load_lds((gbl_void*)(vbase + key_ * hstride + pslot * 8),               \
+                                             (lds_void*)(lds + (BUF) * 16384 + 8192 + p_ * 1024), 16, 0, 0); \
+        }                                                                                                   \
+    }
+    const unsigned ldsbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+    const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
+    const unsigned vtr0 = ldsbase + (unsigned)(8192 + (4 * (g >> 1) + qq) * 128 + (16 * (g & 1) + 4 * pp) * 2);
+    const int kswz = (r >> 1) & 7;
+    const bool keymask = mask_mode == TRX_NN_MASK_KEY;
+    const float* mkey = keymask ? mask + (int64_t)b * Lk : nullptr;
+
+    TRX_ATT_STAGE(0, 0);
+    float mnext = 0.f;
+    if (keymask && tid < 64) {
+        ldsM[tid] = mkey[min(tid, Lk - 1)];
+        mnext = mkey[min(64 + tid, Lk - 1)];
+    }
     for (int kb = 0; kb < nkb; ++kb) {
-        __syncthreads();
-        {
-            const int key = min(kb * 32 + srow, Lk - 1);
-            const int64_t go = (((int64_t)b * Lk + key) * H + h) * 64 + schunk * 8;
-            const uint4 kr = *reinterpret_cast<const uint4*>(k + go);
-            const uint4 vr = *reinterpret_cast<const uint4*>(v + go);
-            *reinterpret_cast<uint4*>(ldsK + srow * 128 + ((schunk ^ ((srow >> 1) & 7)) << 4)) = kr;
-            *reinterpret_cast<uint4*>(ldsV + srow * 128 + schunk * 16) = vr;
-            if (mask_mode == TRX_NN_MASK_KEY && tid < 32) ldsM[tid] = (kb * 32 + tid < Lk) ? mask[(int64_t)b * Lk + kb * 32 + tid] : 0.f;
-        }
-        __syncthreads();
-        // ---- S^T = K Q^T ----
-        f32x16 st;
-#pragma unroll
-        for (int t = 0; t < 16; ++t) st[t] = 0.f;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(ldsK + ka + (((2 * s + hh) ^ kswz) << 4));
-            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[s], st, 0, 0, 0);
-        }
-        // ---- scale, mask, visibility; lane-local row maximum ----
-        float p[16];
-        float mb = -__builtin_inff();
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const int kr_ = (t & 3) + 8 * (t >> 2) + 4 * hh;      // key row inside the tile
-            const int key = kb * 32 + kr_;
-            float val = st[t] * scale;
-            if (mask_mode == TRX_NN_MASK_KEY) val += ldsM[kr_];
-            else if (mask_mode == TRX_NN_MASK_FULL) val += mask[((int64_t)b * Lq + qc) * Lk + min(key, Lk - 1)];
-            const bool hidden = key >= Lk || (causal && key > qidx + off);
-            p[t] = hidden ? -__builtin_inff() : val;
-            mb = fmaxf(mb, p[t]);
-        }
-        mb = fmaxf(mb, __shfl_xor(mb, 32, 64));
-        const float mn = fmaxf(m, mb);
-        const float alpha = (m == mn) ? 1.0f : __expf(m - mn);
-        float ps = 0.f;
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            p[t] = (p[t] == -__builtin_inff()) ? 0.f : __expf(p[t] - mn);
-            ps += p[t];
-        }
-        lsum = lsum * alpha + ps;
-        m = mn;
-#pragma unroll
-        for (int t = 0; t < 16; ++t) { o0[t] *= alpha; o1[t] *= alpha; }
-        // ---- O^T += V^T P^T ----
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            uint4 pw;
-            pw.x = pack2bf(p[8 * s + 0], p[8 * s + 1]); pw.y = pack2bf(p[8 * s + 2], p[8 * s + 3]);
-            pw.z = pack2bf(p[8 * s + 4], p[8 * s + 5]); pw.w = pack2bf(p[8 * s + 6], p[8 * s + 7]);
-            const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
-#pragma unroll
-            for (int db = 0; db < 2; ++db) {
-                uint2 lo, hi;   // keys 16s + 4hh + 0..3 and 16s + 8 + 4hh + 0..3, column d = 32 db + r
-                const unsigned a0 = vtr + (unsigned)(16 * s * 128 + 64 * db);
-                asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)"
-                             : "=&v"(lo), "=&v"(hi) : "v"(a0) : "memory");
-                uint4 vw; vw.x = lo.x; vw.y = lo.y; vw.z = hi.x; vw.w = hi.y;
-                const bf16x8 vf = __builtin_bit_cast(bf16x8, vw);
-                if (db == 0) o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o0, 0, 0, 0);
-                else o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o1, 0, 0, 0);
+        const int buf = kb & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my pieces of tile kb (and mnext) have landed
+        __syncthreads();                                    // everyone's have; tile kb-1 is no longer read
+        if (kb + 1 < nkb) {
+            TRX_ATT_STAGE(kb + 1, buf ^ 1);
+            if (keymask && tid < 64) {
+                ldsM[(buf ^ 1) * 64 + tid] = mnext;
+                mnext = mkey[min((kb + 2) * 64 + tid, Lk - 1)];
             }
         }
+        const char* ldsK = lds + buf * 16384;
+        // ---- S^T = K Q^T for both 32-key halves ----
+        f32x16 s0, s1;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) { s0[t] = 0.f; s1[t] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(ldsK + r * 128 + (((2 * s + hh) ^ kswz) << 4));
+            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(ldsK + (32 + r) * 128 + (((2 * s + hh) ^ kswz) << 4));
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qf[s], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qf[s], s1, 0, 0, 0);
+        }
+        // ---- V^T fragments of the whole tile: 16 transposed reads in flight under the softmax ----
+        const unsigned vtr = vtr0 + (unsigned)(buf * 16384);
+        uint2 vt[4][2][2];   // [k-step of 16 keys][d block][low / high 4 keys]
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const unsigned a0 = vtr + (unsigned)(16 * s * 128 + 64 * db);
+                asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:1024"
+                             : "=&v"(vt[s][db][0]), "=&v"(vt[s][db][1]) : "v"(a0) : "memory");
+            }
+        const int key0 = kb * 64;
+        const bool vis = key0 + 63 > klim_wave_min;   // wave-uniform: some key of the tile is hidden for some lane
+        const float* ldsMt = ldsM + buf * 64;
+        if (mask_mode == TRX_NN_MASK_NONE) {
+            if (vis) attn_softmax_tile<true, TRX_NN_MASK_NONE>(s0, s1, o0, o1, m, lsum, sl2, ldsMt, mrow, key0, hh, Lk, klim);
+            else attn_softmax_tile<false, TRX_NN_MASK_NONE>(s0, s1, o0, o1, m, lsum, sl2, ldsMt, mrow, key0, hh, Lk, klim);
+        } else if (keymask) {
+            if (vis) attn_softmax_tile<true, TRX_NN_MASK_KEY>(s0, s1, o0, o1, m, lsum, sl2, ldsMt, mrow, key0, hh, Lk, klim);
+            else attn_softmax_tile<false, TRX_NN_MASK_KEY>(s0, s1, o0, o1, m, lsum, sl2, ldsMt, mrow, key0, hh, Lk, klim);
+        } else {
+            attn_softmax_tile<true, TRX_NN_MASK_FULL>(s0, s1, o0, o1, m, lsum, sl2, ldsMt, mrow, key0, hh, Lk, klim);
+        }
+        // ---- O^T += V^T P^T ----
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(vt[0][0][0]), "+v"(vt[0][0][1]), "+v"(vt[0][1][0]), "+v"(vt[0][1][1]),
+                       "+v"(vt[1][0][0]), "+v"(vt[1][0][1]), "+v"(vt[1][1][0]), "+v"(vt[1][1][1]),
+                       "+v"(vt[2][0][0]), "+v"(vt[2][0][1]), "+v"(vt[2][1][0]), "+v"(vt[2][1][1]),
+                       "+v"(vt[3][0][0]), "+v"(vt[3][0][1]), "+v"(vt[3][1][0]), "+v"(vt[3][1][1]) :: "memory");
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int ss = s & 1;   // k-step s covers keys 16 s .. 16 s + 15 = half s>>1, registers 8 ss .. 8 ss + 7
+            uint4 pw;
+            if (s < 2) {
+                pw.x = pack2bf(s0[8 * ss + 0], s0[8 * ss + 1]); pw.y = pack2bf(s0[8 * ss + 2], s0[8 * ss + 3]);
+                pw.z = pack2bf(s0[8 * ss + 4], s0[8 * ss + 5]); pw.w = pack2bf(s0[8 * ss + 6], s0[8 * ss + 7]);
+            } else {
+                pw.x = pack2bf(s1[8 * ss + 0], s1[8 * ss + 1]); pw.y = pack2bf(s1[8 * ss + 2], s1[8 * ss + 3]);
+                pw.z = pack2bf(s1[8 * ss + 4], s1[8 * ss + 5]); pw.w = pack2bf(s1[8 * ss + 6], s1[8 * ss + 7]);
+            }
+            const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
+            uint4 v0; v0.x = vt[s][0][0].x; v0.y = vt[s][0][0].y; v0.z = vt[s][0][1].x; v0.w = vt[s][0][1].y;
+            uint4 v1; v1.x = vt[s][1][0].x; v1.y = vt[s][1][0].y; v1.z = vt[s][1][1].x; v1.w = vt[s][1][1].y;
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v0), pf, o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v1), pf, o1, 0, 0, 0);
+        }
     }
+#undef TRX_ATT_STAGE
     const float ltot = lsum + __shfl_xor(lsum, 32, 64);
     if (qidx < Lq) {
         const float inv = 1.0f / ltot;
-        if (lse && hh == 0) lse[((int64_t)b * H + h) * Lq + qidx] = m + __logf(ltot);
+        // natural-log LSE of the scaled, masked scores (what the backward pass recomputes against)
+        if (lse && hh == 0) lse[((int64_t)b * H + h) * Lq + qidx] = (m + __builtin_amdgcn_logf(ltot)) * 0.69314718055994530942f;
         bf16_t* op = out + ((int64_t)b * Lq + qidx) * H * 64 + (int64_t)h * 64;
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {   // registers 4gq..4gq+3 = d rows 8gq + 4hh + 0..3
