@@ -16,10 +16,13 @@ int fail(int code, const std::string& m) { g_err = m; return code; }
 
 typedef unsigned short bf16_t;
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    return (bf16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+// round-to-nearest-even, quiet NaN: gfx950's v_cvt_pk_bf16_f32
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+__device__ __forceinline__ unsigned pack2bf(float a, float b) {
+    const f32x2_t v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
 template <bool BF> __device__ __forceinline__ float ld(const void* p, int64_t i) {
     return BF ? bf2f(reinterpret_cast<const bf16_t*>(p)[i]) : reinterpret_cast<const float*>(p)[i];
@@ -54,7 +57,7 @@ template <bool BF> __device__ __forceinline__ uint4 pack16(const float* f) {
     unsigned w[4];
     if (BF) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) w[i] = (unsigned)f2bf(f[2 * i]) | ((unsigned)f2bf(f[2 * i + 1]) << 16);
+        for (int i = 0; i < 4; ++i) w[i] = pack2bf(f[2 * i], f[2 * i + 1]);
     } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) w[i] = __float_as_uint(f[i]);
@@ -291,17 +294,15 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-__device__ __forceinline__ unsigned pack2bf(float a, float b) { return (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16); }
 
 // one 64-key tile of the online softmax, in the transposed accumulator layout: register t of half
-// hb holds key row hb*32 + (t&3) + 8*(t>>2) + 4*hh of the tile for this lane's query.  Scores are
-// moved to base 2 (scale * log2 e folded in).  VIS: the tile has keys that are out of range or
-// hidden by causality (wave-uniform); MM: mask mode.
-template <bool VIS, int MM>
+// hb holds key row hb*32 + (t&3) + 8*(t>>2) + 4*hh of the tile for this lane's query.  The additive
+// mask is already inside the scores (the accumulators start from mask / scale); scores move to
+// base 2 here (scale * log2 e in one multiply).  VIS: the tile has keys that are out of range or
+// hidden by causality for some lane of the wave (wave-uniform).
+template <bool VIS>
 __device__ __forceinline__ void attn_softmax_tile(f32x16& s0, f32x16& s1, f32x16& o0, f32x16& o1, float& m, float& lsum,
-                                                  float sl2, const float* __restrict__ ldsMt, const float* __restrict__ mrow,
-                                                  int key0, int hh, int Lk, int klim) {
-    constexpr float L2E = 1.44269504088896340736f;
+                                                  float sl2, int key0, int hh, int klim) {
     float mb = -__builtin_inff();
 #pragma unroll
     for (int hb = 0; hb < 2; ++hb)
@@ -309,8 +310,6 @@ __device__ __forceinline__ void attn_softmax_tile(f32x16& s0, f32x16& s1, f32x16
         for (int t = 0; t < 16; ++t) {
             const int kr_ = hb * 32 + (t & 3) + 8 * (t >> 2) + 4 * hh;
             float val = (hb ? s1[t] : s0[t]) * sl2;
-            if (MM == TRX_NN_MASK_KEY) val = __builtin_fmaf(ldsMt[kr_], L2E, val);
-            else if (MM == TRX_NN_MASK_FULL) val = __builtin_fmaf(mrow[min(key0 + kr_, Lk - 1)], L2E, val);
             if (VIS) val = (key0 + kr_ > klim) ? -__builtin_inff() : val;
             if (hb) s1[t] = val; else s0[t] = val;
             mb = fmaxf(mb, val);
@@ -330,7 +329,7 @@ __device__ __forceinline__ void attn_softmax_tile(f32x16& s0, f32x16& s1, f32x16
     for (int t = 0; t < 16; ++t) { o0[t] *= alpha; o1[t] *= alpha; }
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attention_fwd_mfma_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attention_fwd_mfma_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                                  const bf16_t* __restrict__ v, const float* __restrict__ mask,
                                                                  int mask_mode, int causal, int B, int H, int Lq, int Lk,
                                                                  float scale, bf16_t* __restrict__ out, float* __restrict__ lse) {
@@ -355,6 +354,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int t = 0; t < 16; ++t) { o0[t] = 0.f; o1[t] = 0.f; }
     const float sl2 = scale * 1.44269504088896340736f;
+    // additive mask enters as the accumulators' starting value, in raw-score units (mask / scale); the
+    // clamp keeps finfo.min-style masks finite, so fully masked rows come out uniform like torch's
+    const float inv_scale = 1.0f / scale;
+#define TRX_MASK_INIT(X) fmaxf((X) * inv_scale, -1e30f)
     float m = -__builtin_inff(), lsum = 0.f;
     const int off = Lk - Lq;
     int nkb = (Lk + 63) / 64;
@@ -396,7 +399,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     TRX_ATT_STAGE(0, 0);
     float mnext = 0.f;
     if (keymask && tid < 64) {
-        ldsM[tid] = mkey[min(tid, Lk - 1)];
+        ldsM[tid] = TRX_MASK_INIT(mkey[min(tid, Lk - 1)]);
         mnext = mkey[min(64 + tid, Lk - 1)];
     }
     for (int kb = 0; kb < nkb; ++kb) {
@@ -406,15 +409,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (kb + 1 < nkb) {
             TRX_ATT_STAGE(kb + 1, buf ^ 1);
             if (keymask && tid < 64) {
-                ldsM[(buf ^ 1) * 64 + tid] = mnext;
+                ldsM[(buf ^ 1) * 64 + tid] = TRX_MASK_INIT(mnext);
                 mnext = mkey[min((kb + 2) * 64 + tid, Lk - 1)];
             }
         }
         const char* ldsK = lds + buf * 16384;
         // ---- S^T = K Q^T for both 32-key halves ----
         f32x16 s0, s1;
+        const int key0 = kb * 64;
+        if (keymask) {
+            const float* mt = ldsM + buf * 64 + 4 * hh;
 #pragma unroll
-        for (int t = 0; t < 16; ++t) { s0[t] = 0.f; s1[t] = 0.f; }
+            for (int t4 = 0; t4 < 4; ++t4) {
+                const float4 a = *reinterpret_cast<const float4*>(mt + 8 * t4);
+                const float4 c = *reinterpret_cast<const float4*>(mt + 32 + 8 * t4);
+                s0[4 * t4] = a.x; s0[4 * t4 + 1] = a.y; s0[4 * t4 + 2] = a.z; s0[4 * t4 + 3] = a.w;
+                s1[4 * t4] = c.x; s1[4 * t4 + 1] = c.y; s1[4 * t4 + 2] = c.z; s1[4 * t4 + 3] = c.w;
+            }
+        } else if (mrow) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int kr_ = (t & 3) + 8 * (t >> 2) + 4 * hh;
+                s0[t] = TRX_MASK_INIT(mrow[min(key0 + kr_, Lk - 1)]);
+                s1[t] = TRX_MASK_INIT(mrow[min(key0 + 32 + kr_, Lk - 1)]);
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) { s0[t] = 0.f; s1[t] = 0.f; }
+        }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(ldsK + r * 128 + (((2 * s + hh) ^ kswz) << 4));
@@ -422,54 +444,47 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qf[s], s0, 0, 0, 0);
             s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qf[s], s1, 0, 0, 0);
         }
-        // ---- V^T fragments of the whole tile: 16 transposed reads in flight under the softmax ----
+        // ---- V^T fragments, first 32 keys: 8 transposed reads in flight under the softmax ----
         const unsigned vtr = vtr0 + (unsigned)(buf * 16384);
         uint2 vt[4][2][2];   // [k-step of 16 keys][d block][low / high 4 keys]
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int db = 0; db < 2; ++db) {
-                const unsigned a0 = vtr + (unsigned)(16 * s * 128 + 64 * db);
-                asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:1024"
-                             : "=&v"(vt[s][db][0]), "=&v"(vt[s][db][1]) : "v"(a0) : "memory");
-            }
-        const int key0 = kb * 64;
-        const bool vis = key0 + 63 > klim_wave_min;   // wave-uniform: some key of the tile is hidden for some lane
-        const float* ldsMt = ldsM + buf * 64;
-        if (mask_mode == TRX_NN_MASK_NONE) {
-            if (vis) attn_softmax_tile<true, TRX_NN_MASK_NONE>(s0, s1, o0, o1, m, lsum, sl2, ldsMt, mrow, key0, hh, Lk, klim);
-            else attn_softmax_tile<false, TRX_NN_MASK_NONE>(s0, s1, o0, o1, m, lsum, sl2, ldsMt, mrow, key0, hh, Lk, klim);
-        } else if (keymask) {
-            if (vis) attn_softmax_tile<true, TRX_NN_MASK_KEY>(s0, s1, o0, o1, m, lsum, sl2, ldsMt, mrow, key0, hh, Lk, klim);
-            else attn_softmax_tile<false, TRX_NN_MASK_KEY>(s0, s1, o0, o1, m, lsum, sl2, ldsMt, mrow, key0, hh, Lk, klim);
-        } else {
-            attn_softmax_tile<true, TRX_NN_MASK_FULL>(s0, s1, o0, o1, m, lsum, sl2, ldsMt, mrow, key0, hh, Lk, klim);
-        }
-        // ---- O^T += V^T P^T ----
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(vt[0][0][0]), "+v"(vt[0][0][1]), "+v"(vt[0][1][0]), "+v"(vt[0][1][1]),
-                       "+v"(vt[1][0][0]), "+v"(vt[1][0][1]), "+v"(vt[1][1][0]), "+v"(vt[1][1][1]),
-                       "+v"(vt[2][0][0]), "+v"(vt[2][0][1]), "+v"(vt[2][1][0]), "+v"(vt[2][1][1]),
-                       "+v"(vt[3][0][0]), "+v"(vt[3][0][1]), "+v"(vt[3][1][0]), "+v"(vt[3][1][1]) :: "memory");
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int ss = s & 1;   // k-step s covers keys 16 s .. 16 s + 15 = half s>>1, registers 8 ss .. 8 ss + 7
-            uint4 pw;
-            if (s < 2) {
-                pw.x = pack2bf(s0[8 * ss + 0], s0[8 * ss + 1]); pw.y = pack2bf(s0[8 * ss + 2], s0[8 * ss + 3]);
-                pw.z = pack2bf(s0[8 * ss + 4], s0[8 * ss + 5]); pw.w = pack2bf(s0[8 * ss + 6], s0[8 * ss + 7]);
-            } else {
-                pw.x = pack2bf(s1[8 * ss + 0], s1[8 * ss + 1]); pw.y = pack2bf(s1[8 * ss + 2], s1[8 * ss + 3]);
-                pw.z = pack2bf(s1[8 * ss + 4], s1[8 * ss + 5]); pw.w = pack2bf(s1[8 * ss + 6], s1[8 * ss + 7]);
-            }
-            const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
-            uint4 v0; v0.x = vt[s][0][0].x; v0.y = vt[s][0][0].y; v0.z = vt[s][0][1].x; v0.w = vt[s][0][1].y;
-            uint4 v1; v1.x = vt[s][1][0].x; v1.y = vt[s][1][0].y; v1.z = vt[s][1][1].x; v1.w = vt[s][1][1].y;
-            o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v0), pf, o0, 0, 0, 0);
-            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v1), pf, o1, 0, 0, 0);
-        }
+#define TRX_VT_READ(S)                                                                                        \
+    _Pragma("unroll") for (int db = 0; db < 2; ++db) {                                                        \
+        const unsigned a0 = vtr + (unsigned)(16 * (S) * 128 + 64 * db);                                       \
+        asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:1024"                    \
+                     : "=&v"(vt[S][db][0]), "=&v"(vt[S][db][1]) : "v"(a0) : "memory");                        \
     }
+#define TRX_VT_WAIT(S0, S1, CNT)                                                                              \
+    asm volatile("s_waitcnt lgkmcnt(" #CNT ")"                                                                \
+                 : "+v"(vt[S0][0][0]), "+v"(vt[S0][0][1]), "+v"(vt[S0][1][0]), "+v"(vt[S0][1][1]),            \
+                   "+v"(vt[S1][0][0]), "+v"(vt[S1][0][1]), "+v"(vt[S1][1][0]), "+v"(vt[S1][1][1]) :: "memory");
+#define TRX_PV_STEP(S, SV)                                                                                    \
+    {                                                                                                         \
+        constexpr int ss = (S) & 1;                                                                           \
+        uint4 pw;                                                                                             \
+        pw.x = pack2bf(SV[8 * ss + 0], SV[8 * ss + 1]); pw.y = pack2bf(SV[8 * ss + 2], SV[8 * ss + 3]);       \
+        pw.z = pack2bf(SV[8 * ss + 4], SV[8 * ss + 5]); pw.w = pack2bf(SV[8 * ss + 6], SV[8 * ss + 7]);       \
+        const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);                                                     \
+        uint4 v0; v0.x = vt[S][0][0].x; v0.y = vt[S][0][0].y; v0.z = vt[S][0][1].x; v0.w = vt[S][0][1].y;     \
+        uint4 v1; v1.x = vt[S][1][0].x; v1.y = vt[S][1][0].y; v1.z = vt[S][1][1].x; v1.w = vt[S][1][1].y;     \
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v0), pf, o0, 0, 0, 0);        \
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v1), pf, o1, 0, 0, 0);        \
+    }
+        TRX_VT_READ(0) TRX_VT_READ(1)
+        const bool vis = key0 + 63 > klim_wave_min;   // wave-uniform: some key of the tile is hidden for some lane
+        if (vis) attn_softmax_tile<true>(s0, s1, o0, o1, m, lsum, sl2, key0, hh, klim);
+        else attn_softmax_tile<false>(s0, s1, o0, o1, m, lsum, sl2, key0, hh, klim);
+        // ---- O^T += V^T P^T: second half's reads fly under the first half's MFMAs ----
+        TRX_VT_READ(2) TRX_VT_READ(3)
+        TRX_VT_WAIT(0, 1, 8)
+        TRX_PV_STEP(0, s0) TRX_PV_STEP(1, s0)
+        TRX_VT_WAIT(2, 3, 0)
+        TRX_PV_STEP(2, s1) TRX_PV_STEP(3, s1)
+    }
+#undef TRX_VT_READ
+#undef TRX_VT_WAIT
+#undef TRX_PV_STEP
 #undef TRX_ATT_STAGE
+#undef TRX_MASK_INIT
     const float ltot = lsum + __shfl_xor(lsum, 32, 64);
     if (qidx < Lq) {
         const float inv = 1.0f / ltot;
