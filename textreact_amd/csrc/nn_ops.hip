@@ -329,19 +329,30 @@ __device__ __forceinline__ void attn_softmax_tile(f32x16& s0, f32x16& s1, f32x16
     for (int t = 0; t < 16; ++t) { o0[t] *= alpha; o1[t] *= alpha; }
 }
 
+template <int MM>   // mask mode: one kernel per mode keeps each one's register footprint to what it needs
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attention_fwd_mfma_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                                  const bf16_t* __restrict__ v, const float* __restrict__ mask,
-                                                                 int mask_mode, int causal, int B, int H, int Lq, int Lk,
+                                                                 int causal, int B, int H, int Lq, int Lk,
                                                                  float scale, bf16_t* __restrict__ out, float* __restrict__ lse) {
-    // key tiles of 64, double buffered, filled by LDS-DMA: [buf][K 8 KiB | V 8 KiB], mask [buf][64]
-    __shared__ __attribute__((aligned(16))) char lds[2 * 16384 + 512];
+    // key tiles of 64 in a ring of 3 (prefetch distance 2), filled by LDS-DMA: [buf][K 8 KiB | V 8 KiB];
+    // then the key mask of 1024 keys (16 tiles), pre-divided by the scale.  52 KiB: 3 workgroups / CU
+    // (its own array: the compiler then knows mask reads cannot alias the LDS-DMA writes and does not
+    // drain vmcnt before them)
+    __shared__ __attribute__((aligned(128))) char lds[3 * 16384];
+    __shared__ __attribute__((aligned(16))) float ldsM[1024];
     typedef __attribute__((address_space(3))) void lds_void;
     typedef __attribute__((address_space(1))) const void gbl_void;
-    float* ldsM = reinterpret_cast<float*>(lds + 32768);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
     const int nqb = (Lq + 127) / 128;
-    const int qb = blockIdx.x % nqb, h = (blockIdx.x / nqb) % H, b = blockIdx.x / (nqb * H);
+    // workgroups are dealt round-robin to the 8 XCDs; renumber so that the query blocks of one
+    // (batch, head) -- which re-read the same K/V -- are neighbours on ONE XCD and share its L2
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, per = nwg >> 3, main_ = per << 3;
+        if (bid < main_) bid = (bid & 7) * per + (bid >> 3);
+    }
+    const int qb = bid % nqb, h = (bid / nqb) % H, b = bid / (nqb * H);
     const int qidx = qb * 128 + wave * 32 + r;              // this lane's query
     const int qc = qidx < Lq ? qidx : Lq - 1;
     bf16x8 qf[4];   // B operand of S^T = K Q^T: B[k = 8hh + j][col r] = Q[query r][d = 16 s + 8 hh + j]
@@ -368,57 +379,94 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     // last visible key of this lane's query (also bounds the tail tile)
     const int klim = causal ? min(Lk - 1, qidx + off) : Lk - 1;
     const int klim_wave_min = causal ? min(Lk - 1, qb * 128 + wave * 32 + off) : Lk - 1;   // smallest klim in the wave
-    const float* mrow = (mask_mode == TRX_NN_MASK_FULL) ? mask + ((int64_t)b * Lq + qc) * Lk : nullptr;
+    const float* mrow = (MM == TRX_NN_MASK_FULL) ? mask + ((int64_t)b * Lq + qc) * Lk : nullptr;
 
     // LDS-DMA geometry: a piece is one global_load_lds_dwordx4 = 8 rows x 128 B written lane-linear
     // (row 8p + lane/8, slot lane%8); wave w moves pieces 2w, 2w+1 of K and of V.  K's bank swizzle
     // (slot = chunk ^ ((row >> 1) & 7)) is applied to the SOURCE chunk; V is stored straight.
+    // Addresses are (uniform base + tile offset) + a per-lane 32-bit byte offset fixed for the kernel.
     const int prow = lane >> 3, pslot = lane & 7;
-    const int64_t hstride = (int64_t)H * 64;
-    const bf16_t* kbase = k + ((int64_t)b * Lk * H + h) * 64;
-    const bf16_t* vbase = v + ((int64_t)b * Lk * H + h) * 64;
+    const unsigned rowbytes = (unsigned)H * 128u;
+    const char* kbase = reinterpret_cast<const char*>(k + ((int64_t)b * Lk * H + h) * 64);
+    const char* vbase = reinterpret_cast<const char*>(v + ((int64_t)b * Lk * H + h) * 64);
+    unsigned kofs[2], vofs[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const unsigned rw = (unsigned)(8 * (2 * wave + i) + prow);
+        kofs[i] = rw * rowbytes + (unsigned)((pslot ^ (4 * i + (prow >> 1))) * 16);
+        vofs[i] = rw * rowbytes + (unsigned)((pslot ^ ((prow & 3) << 1)) * 16);
+    }
 #define TRX_ATT_STAGE(KB, BUF)                                                                              \
     {                                                                                                       \
-        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                  \
-            const int p_ = 2 * wave + i_;                                                                   \
-            const int key_ = min((KB) * 64 + 8 * p_ + prow, Lk - 1);                                        \
-            const int kc_ = pslot ^ (4 * i_ + (prow >> 1));                                                 \
-            __builtin_amdgcn_global_load_lds((gbl_void*)(kbase + key_ * hstride + kc_ * 8),                 \
-                                             (lds_void*)(lds + (BUF) * 16384 + p_ * 1024), 16, 0, 0);       \
-            __builtin_amdgcn_global_load_lds((gbl_void*)(vbase + key_ * hstride + pslot * 8),               \
-                                             (lds_void*)(lds + (BUF) * 16384 + 8192 + p_ * 1024), 16, 0, 0); \
+        const char* kt_ = kbase + (int64_t)(KB) * 64 * rowbytes;                                            \
+        const char* vt_ = vbase + (int64_t)(KB) * 64 * rowbytes;                                            \
+        if ((KB) * 64 + 64 <= Lk) {                                                                         \
+            _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                              \
+                __builtin_amdgcn_global_load_lds((gbl_void*)(kt_ + kofs[i_]),                               \
+                                                 (lds_void*)(lds + (BUF) * 16384 + (2 * wave + i_) * 1024), 16, 0, 0);        \
+                __builtin_amdgcn_global_load_lds((gbl_void*)(vt_ + vofs[i_]),                               \
+                                                 (lds_void*)(lds + (BUF) * 16384 + 8192 + (2 * wave + i_) * 1024), 16, 0, 0); \
+            }                                                                                               \
+        } else { /* tail tile: rows past the last key re-read the last key (they are hidden anyway) */      \
+            _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                              \
+                const int rw_ = min(8 * (2 * wave + i_) + prow, Lk - 1 - (KB) * 64);                        \
+                const unsigned ro_ = (unsigned)rw_ * rowbytes;                                              \
+                __builtin_amdgcn_global_load_lds((gbl_void*)(kt_ + (ro_ + (unsigned)((pslot ^ (4 * i_ + (prow >> 1))) * 16))), \
+                                                 (lds_void*)(lds + (BUF) * 16384 + (2 * wave + i_) * 1024), 16, 0, 0);        \
+                __builtin_amdgcn_global_load_lds((gbl_void*)(vt_ + (ro_ + (unsigned)((pslot ^ ((prow & 3) << 1)) * 16))), \
+                                                 (lds_void*)(lds + (BUF) * 16384 + 8192 + (2 * wave + i_) * 1024), 16, 0, 0); \
+            }                                                                                               \
         }                                                                                                   \
     }
     const unsigned ldsbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
     const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
-    const unsigned vtr0 = ldsbase + (unsigned)(8192 + (4 * (g >> 1) + qq) * 128 + (16 * (g & 1) + 4 * pp) * 2);
+    // V^T read addresses: row 4(g>>1) + qq (+16 per k-step, +8 for the second read), 16-byte chunk
+    // c = 4 db + 2 (g&1) + (pp>>1) stored at slot c ^ ((row & 3) << 1) -- the four rows a 16-lane group
+    // touches then sit in four different 32-byte bank groups.  (row & 3) == qq for every read.
+    const unsigned vtrA0 = ldsbase + (unsigned)(8192 + (4 * (g >> 1) + qq) * 128 + (((2 * (g & 1) + (pp >> 1)) ^ (qq << 1)) << 4) + 8 * (pp & 1));
     const int kswz = (r >> 1) & 7;
-    const bool keymask = mask_mode == TRX_NN_MASK_KEY;
+    unsigned kfa[4];   // K fragment addresses: row r (+32 by offset), chunk (2s + hh) ^ swizzle
+#pragma unroll
+    for (int s = 0; s < 4; ++s) kfa[s] = ldsbase + (unsigned)(r * 128 + (((2 * s + hh) ^ kswz) << 4));
+    constexpr bool keymask = MM == TRX_NN_MASK_KEY;
     const float* mkey = keymask ? mask + (int64_t)b * Lk : nullptr;
 
-    TRX_ATT_STAGE(0, 0);
-    float mnext = 0.f;
-    if (keymask && tid < 64) {
-        ldsM[tid] = TRX_MASK_INIT(mkey[min(tid, Lk - 1)]);
-        mnext = mkey[min(64 + tid, Lk - 1)];
+    // the key mask of tiles 16j .. 16j+15 is (re)loaded when tile 16j starts: 4 keys per thread
+#define TRX_MASK_FILL(KB)                                                                                   \
+    {                                                                                                       \
+        float mv_[4];                                                                                       \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) mv_[i_] = mkey[min((KB) * 64 + 4 * tid + i_, Lk - 1)]; \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) ldsM[4 * tid + i_] = TRX_MASK_INIT(mv_[i_]);       \
     }
-    for (int kb = 0; kb < nkb; ++kb) {
-        const int buf = kb & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my pieces of tile kb (and mnext) have landed
-        __syncthreads();                                    // everyone's have; tile kb-1 is no longer read
-        if (kb + 1 < nkb) {
-            TRX_ATT_STAGE(kb + 1, buf ^ 1);
-            if (keymask && tid < 64) {
-                ldsM[(buf ^ 1) * 64 + tid] = TRX_MASK_INIT(mnext);
-                mnext = mkey[min((kb + 2) * 64 + tid, Lk - 1)];
-            }
-        }
-        const char* ldsK = lds + buf * 16384;
+    // vector-memory order per wave: D(0) D(1) | iteration j: D(j+2).  At the top of iteration j tile j
+    // must have landed while D(j+1)'s four loads may still fly: vmcnt(4).
+    TRX_ATT_STAGE(0, 0);
+    if (nkb > 1) TRX_ATT_STAGE(1, 1);
+    // retire the Q loads HERE: left pending, their first use inside the loop would put an
+    // s_waitcnt vmcnt(0) in front of every tile's first MFMA and drain the prefetch with it
+    asm volatile("" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]));
+    int buf = 0;
+    for (int kc = 0; kc < nkb; kc += 16) {   // chunks of 16 tiles = the 1024 keys whose mask sits in LDS
+    if (keymask) {
+        if (kc > 0) __syncthreads();         // (rare: Lk > 1024) the previous chunk's mask is no longer read
+        TRX_MASK_FILL(kc);
+    }
+    const int kend = min(nkb, kc + 16);
+    for (int kb = kc; kb < kend; ++kb) {
+        if (kb + 1 < nkb) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // tile kb is in LDS for everyone; tile kb-1 is no longer read.  Raw barrier: __syncthreads()
+        // would drain vmcnt to 0 and with it the prefetch distance
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const int buf1 = buf == 2 ? 0 : buf + 1, buf2 = buf == 0 ? 2 : buf - 1;
+        if (kb + 2 < nkb) TRX_ATT_STAGE(kb + 2, buf2);
         // ---- S^T = K Q^T for both 32-key halves ----
         f32x16 s0, s1;
         const int key0 = kb * 64;
         if (keymask) {
-            const float* mt = ldsM + buf * 64 + 4 * hh;
+            const float* mt = ldsM + (kb - kc) * 64 + 4 * hh;
 #pragma unroll
             for (int t4 = 0; t4 < 4; ++t4) {
                 const float4 a = *reinterpret_cast<const float4*>(mt + 8 * t4);
@@ -426,7 +474,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 s0[4 * t4] = a.x; s0[4 * t4 + 1] = a.y; s0[4 * t4 + 2] = a.z; s0[4 * t4 + 3] = a.w;
                 s1[4 * t4] = c.x; s1[4 * t4 + 1] = c.y; s1[4 * t4 + 2] = c.z; s1[4 * t4 + 3] = c.w;
             }
-        } else if (mrow) {
+        } else if (MM == TRX_NN_MASK_FULL) {
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
                 const int kr_ = (t & 3) + 8 * (t >> 2) + 4 * hh;
@@ -437,22 +485,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
             for (int t = 0; t < 16; ++t) { s0[t] = 0.f; s1[t] = 0.f; }
         }
+        // K fragments through inline asm: a C++ read of `lds` would make the compiler drain vmcnt to 0
+        // first (it cannot tell tile kb's buffer from the one tile kb+2 is being DMA'd into)
+        bf16x8 ka[4][2];
+        {
+            const unsigned kb0 = (unsigned)(buf * 16384);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:4096"
+                             : "=&v"(ka[s][0]), "=&v"(ka[s][1]) : "v"(kfa[s] + kb0) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(ka[0][0]), "+v"(ka[0][1]), "+v"(ka[1][0]), "+v"(ka[1][1]),
+                           "+v"(ka[2][0]), "+v"(ka[2][1]), "+v"(ka[3][0]), "+v"(ka[3][1]) :: "memory");
+        }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(ldsK + r * 128 + (((2 * s + hh) ^ kswz) << 4));
-            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(ldsK + (32 + r) * 128 + (((2 * s + hh) ^ kswz) << 4));
-            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qf[s], s0, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qf[s], s1, 0, 0, 0);
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[s][0], qf[s], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[s][1], qf[s], s1, 0, 0, 0);
         }
         // ---- V^T fragments, first 32 keys: 8 transposed reads in flight under the softmax ----
-        const unsigned vtr = vtr0 + (unsigned)(buf * 16384);
+        const unsigned vtrA = vtrA0 + (unsigned)(buf * 16384), vtrB = vtrA ^ 64u;   // d block 0 / 1
         uint2 vt[4][2][2];   // [k-step of 16 keys][d block][low / high 4 keys]
 #define TRX_VT_READ(S)                                                                                        \
-    _Pragma("unroll") for (int db = 0; db < 2; ++db) {                                                        \
-        const unsigned a0 = vtr + (unsigned)(16 * (S) * 128 + 64 * db);                                       \
-        asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:1024"                    \
-                     : "=&v"(vt[S][db][0]), "=&v"(vt[S][db][1]) : "v"(a0) : "memory");                        \
-    }
+    asm volatile("ds_read_b64_tr_b16 %0, %4 offset:%6\n\tds_read_b64_tr_b16 %1, %4 offset:%7\n\t"            \
+                 "ds_read_b64_tr_b16 %2, %5 offset:%6\n\tds_read_b64_tr_b16 %3, %5 offset:%7"                 \
+                 : "=&v"(vt[S][0][0]), "=&v"(vt[S][0][1]), "=&v"(vt[S][1][0]), "=&v"(vt[S][1][1])             \
+                 : "v"(vtrA), "v"(vtrB), "n"((S) * 2048), "n"((S) * 2048 + 1024) : "memory");
 #define TRX_VT_WAIT(S0, S1, CNT)                                                                              \
     asm volatile("s_waitcnt lgkmcnt(" #CNT ")"                                                                \
                  : "+v"(vt[S0][0][0]), "+v"(vt[S0][0][1]), "+v"(vt[S0][1][0]), "+v"(vt[S0][1][1]),            \
@@ -479,11 +537,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         TRX_PV_STEP(0, s0) TRX_PV_STEP(1, s0)
         TRX_VT_WAIT(2, 3, 0)
         TRX_PV_STEP(2, s1) TRX_PV_STEP(3, s1)
+        buf = buf1;
+    }
     }
 #undef TRX_VT_READ
 #undef TRX_VT_WAIT
 #undef TRX_PV_STEP
 #undef TRX_ATT_STAGE
+#undef TRX_MASK_FILL
 #undef TRX_MASK_INIT
     const float ltot = lsum + __shfl_xor(lsum, 32, 64);
     if (qidx < Lq) {
@@ -659,8 +720,13 @@ int trx_attention_fwd_lse(const void* q, const void* k, const void* v, const flo
     static const bool force_valu = getenv("TRX_NN_ATTN_VALU") != nullptr;
     if (dtype == TRX_NN_BF16 && !force_valu) {
         dim3 g2((unsigned)((int64_t)B * H * ((Lq + 127) / 128))), b2(256);
-        hipLaunchKernelGGL(attention_fwd_mfma_kernel, g2, b2, 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, mask,
-                           mask_mode, causal, B, H, Lq, Lk, scale, (bf16_t*)out, lse);
+#define TRX_LAUNCH_MFMA(MM_)                                                                                              \
+    hipLaunchKernelGGL(attention_fwd_mfma_kernel<MM_>, g2, b2, 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, \
+                       mask, causal, B, H, Lq, Lk, scale, (bf16_t*)out, lse)
+        if (mask_mode == TRX_NN_MASK_NONE) TRX_LAUNCH_MFMA(TRX_NN_MASK_NONE);
+        else if (mask_mode == TRX_NN_MASK_KEY) TRX_LAUNCH_MFMA(TRX_NN_MASK_KEY);
+        else TRX_LAUNCH_MFMA(TRX_NN_MASK_FULL);
+#undef TRX_LAUNCH_MFMA
     } else if (dtype == TRX_NN_BF16) hipLaunchKernelGGL(attention_fwd_kernel<true>, grid, block, 0, st, q, k, v, mask, mask_mode, causal, B, H, Lq, Lk, scale, out, lse);
     else hipLaunchKernelGGL(attention_fwd_kernel<false>, grid, block, 0, st, q, k, v, mask, mask_mode, causal, B, H, Lq, Lk, scale, out, lse);
     hipError_t e = hipGetLastError();
