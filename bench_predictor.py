@@ -56,6 +56,25 @@ def main():
                         "roofline": ({"bound": "mfma", "achieved": tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": tf / 2500.0}
                                      if dtype == torch.bfloat16 else
                                      {"bound": "valu-fp32", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3})})
+    # backward (bf16, matrix cores): dq pass + dk/dv pass + the per-query scalar prep; FLOPs counted as the
+    # 5 GEMMs of the textbook backward (the two passes recompute S and dP, 7 GEMMs are executed)
+    for (B, H, Lq, Lk, causal, name) in ((32, 12, 512, 512, False, "encoder self-attention"),
+                                         (32, 12, 160, 512, False, "cross-attention"),
+                                         (32, 12, 160, 160, True, "decoder causal self-attention")):
+        dtype = torch.bfloat16
+        q, k, v = (torch.randn(B, L, H, 64, device=dev).to(dtype).requires_grad_(True) for L in (Lq, Lk, Lk))
+        m = torch.zeros(B, Lk, device=dev)
+        o = ops.attention(q, k, v, mask=m, causal=causal)
+        do = torch.randn_like(o)
+        ms = timeit(lambda: torch.autograd.grad(o, (q, k, v), do, retain_graph=True), iters=10)
+        fl = 10.0 * B * H * Lq * Lk * 64 * (0.5 if causal else 1.0)
+        tf = fl / (ms * 1e-3) / 1e12
+        qr, kr, vr = (t.detach().float().requires_grad_(True) for t in (q, k, v))
+        orf = ops.attention(qr, kr, vr, mask=m, causal=causal, backend="torch")
+        ref = timeit(lambda: torch.autograd.grad(orf, (qr, kr, vr), do.float(), retain_graph=True), iters=5)
+        out.append({"kernel": "attention_bwd", "what": name, "dtype": str(dtype), "B": B, "H": H, "Lq": Lq, "Lk": Lk,
+                    "ms": ms, "torch_eager_fp32_ms": ref,
+                    "roofline": {"bound": "mfma", "achieved": tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": tf / 2500.0}})
     for o in out:
         print(json.dumps(o))
 

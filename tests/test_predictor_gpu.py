@@ -134,6 +134,41 @@ def test_attention_backward(B, H, Lq, Lk, mask, causal):
         assert float((a - c).abs().max()) <= 5e-5 * max(1.0, float(c.abs().max()))
 
 
+@pytest.mark.parametrize("B,H,Lq,Lk,mask,causal", [
+    (2, 3, 70, 70, "key", False), (2, 2, 33, 33, "none", True), (2, 2, 20, 77, "key", False),
+    (1, 2, 65, 65, "full", False), (1, 1, 5, 37, "none", True),
+    (2, 4, 512, 512, "key", False),      # encoder self-attention, several tiles either way
+    (2, 4, 160, 160, "none", True),      # retro decoder self-attention
+    (2, 4, 160, 512, "key", False),      # cross-attention
+    (1, 2, 300, 1100, "key", False),     # key mask spans more than one 1024-key chunk
+    (1, 2, 257, 129, "none", False), (1, 2, 129, 257, "none", True), (1, 1, 200, 200, "full", True),
+])
+def test_attention_backward_bf16_matrix_cores(B, H, Lq, Lk, mask, causal):
+    """bf16 in / bf16 out through the MFMA backward (attn_bwd_mfma.h) against fp32 autograd on the
+    same bf16-rounded inputs; tolerance = bf16 rounding of P, dS and of the outputs"""
+    bf = torch.bfloat16
+    q, k, v = _rand(B, Lq, H, 64, dtype=bf, seed=1), _rand(B, Lk, H, 64, dtype=bf, seed=2), _rand(B, Lk, H, 64, dtype=bf, seed=3)
+    dout = _rand(B, Lq, H * 64, dtype=bf, seed=4)
+    neg = torch.finfo(torch.float32).min
+    m = None
+    if mask == "key":
+        keep = torch.ones(B, Lk, device="cuda"); keep[0, Lk // 2 + 1:] = 0
+        m = (1 - keep) * neg
+    elif mask == "full":
+        keep = (torch.rand(B, Lq, Lk, device="cuda") > 0.3).float(); keep[:, :, 0] = 1
+        m = (1 - keep) * neg
+    qs, ks, vs = (t.clone().requires_grad_(True) for t in (q, k, v))
+    out = ops.attention(qs, ks, vs, mask=m, causal=causal, backend="hip")
+    out.backward(dout)
+    qr, kr, vr = (t.float().clone().requires_grad_(True) for t in (q, k, v))
+    ref = ops.attention(qr, kr, vr, mask=m, causal=causal, backend="torch")
+    ref.backward(dout.float())
+    for name, a, c in (("dq", qs.grad, qr.grad), ("dk", ks.grad, kr.grad), ("dv", vs.grad, vr.grad)):
+        assert a.dtype == bf and a.shape == c.shape
+        err = float((a.float() - c).abs().max())
+        assert err <= 2e-2 * max(1.0, float(c.abs().max())), (name, err, float(c.abs().max()))
+
+
 def test_model_backward_hip_vs_torch():
     # one training-style step on the small config: loss = CE over decoder logits (main.py:129-131)
     z = np.load(G)

@@ -1,0 +1,502 @@
+// Attention backward on the matrix cores (bf16 in, fp32 accumulate).  Included by nn_ops.hip inside
+// its anonymous namespace, after the forward kernel whose fragment conventions it shares:
+//
+//   v_mfma_f32_32x32x16_bf16, lane = (r = lane & 31, hh = lane >> 5)
+//     A operand: A[row r][k = 8 hh .. 8 hh + 7]        B operand: B[k = 8 hh .. 8 hh + 7][col r]
+//     D: register t holds D[row (t & 3) + 8 (t >> 2) + 4 hh][col r]
+//   An accumulator tile can be fed back as a B operand (k = its rows): registers 8 ss .. 8 ss + 7 of
+//   lane (r, hh) are k-slots 8 hh .. 8 hh + 7 of the 16-row k-step ss, in the row order
+//   (j & 3) + 8 (j >> 2) + 4 hh; the matching A operand comes from two ds_read_b64_tr_b16 (rows
+//   4 hh + qq and 8 rows further), which deliver exactly that row order.
+//
+// Everything is deterministic (no atomics): probabilities are recomputed from the forward's
+// log-sum-exp, once per pass.
+//   prep    negl[b,h,i] = -lse_i / scale,  negd[b,h,i] = -(dO_i . O_i)
+//   pass 1  workgroup = 128 queries (a lane per query), streams 64-key tiles of K and V:
+//             S^T = K Q^T (+ mask/scale),  dP^T = V dO^T - delta,  P = exp(scale S - lse),
+//             dS = P (dP - delta),  dQ^T += K^T dS^T                       -> dQ = scale * acc
+//   pass 2  workgroup = 128 keys (a lane per key), streams 64-query tiles of Q and dO:
+//             S = Q K^T - lse/scale,  dP = dO V^T - delta,  P, dS as above,
+//             dV^T += dO^T P,  dK^T += Q^T dS                              -> dK = scale * acc
+// LDS tiles are rows of 128 B (64 bf16); 16-byte chunk c of row `row` sits at slot c ^ bwd_sw(row).
+// bwd_sw is a bijection of (row >> 1) & 7, which keeps the ds_read_b128 row reads conflict-free
+// (16-lane groups see 16 distinct (row parity, slot) pairs), and it moves rows 4a and 4a + 2 four
+// slots apart, which is what the transposed reads need (a 32-lane half reads 4 rows x 64 B).
+
+typedef __attribute__((ext_vector_type(4))) float f32x4v;
+
+__device__ __forceinline__ int bwd_sw(int row) {
+    const int x = (row >> 1) & 7;
+    return ((x & 1) << 2) | (x >> 1);
+}
+
+__global__ __launch_bounds__(256) void attention_bwd_prep_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
+                                                                 const float* __restrict__ lse, int B, int H, int Lq, float scale,
+                                                                 float* __restrict__ negl, float* __restrict__ negd) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;   // (b * Lq + i) * H + h: rows of 64 are contiguous
+    if (idx >= (int64_t)B * Lq * H) return;
+    const int h = (int)(idx % H);
+    const int64_t bi = idx / H;
+    const int i = (int)(bi % Lq), b = (int)(bi / Lq);
+    const uint4* op = reinterpret_cast<const uint4*>(o + idx * 64);
+    const uint4* dp = reinterpret_cast<const uint4*>(dout + idx * 64);
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const uint4 a = op[c], d = dp[c];
+        const unsigned aw[4] = {a.x, a.y, a.z, a.w}, dw[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            acc = __builtin_fmaf(__uint_as_float(aw[w] << 16), __uint_as_float(dw[w] << 16), acc);
+            acc = __builtin_fmaf(__uint_as_float(aw[w] & 0xffff0000u), __uint_as_float(dw[w] & 0xffff0000u), acc);
+        }
+    }
+    const int64_t w = ((int64_t)b * H + h) * Lq + i;
+    negl[w] = -lse[w] / scale;
+    negd[w] = -acc;
+}
+
+// 8 rows x 128 B of a [rows][H][64] bf16 tensor into LDS, one global_load_lds_dwordx4 per wave:
+// lane -> (row base + lane / 8, slot lane % 8), source chunk slot ^ bwd_sw(row)
+#define TRX_BWD_SW_OFS(ROWINTILE, PSLOT) ((unsigned)(((PSLOT) ^ bwd_sw(ROWINTILE)) * 16))
+
+// row-fragment reads (A operand rows r and r + 32 of a tile), k-step s = d 16 s .. 16 s + 15
+#define TRX_BWD_ROWS8(DST, BASE)                                                                            \
+    _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_)                                                        \
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:4096"                               \
+                     : "=&v"(DST[s_][0]), "=&v"(DST[s_][1]) : "v"(rfa[s_] + (BASE)) : "memory");
+#define TRX_BWD_WAIT8(DST)                                                                                  \
+    asm volatile("s_waitcnt lgkmcnt(0)"                                                                     \
+                 : "+v"(DST[0][0]), "+v"(DST[0][1]), "+v"(DST[1][0]), "+v"(DST[1][1]),                      \
+                   "+v"(DST[2][0]), "+v"(DST[2][1]), "+v"(DST[3][0]), "+v"(DST[3][1]) :: "memory");
+// transposed reads of k-step S (16 tile rows) for both d blocks: DST[db][0 / 1] = low / high 4 rows
+#define TRX_BWD_TR(DST, S, A0, A1)                                                                          \
+    asm volatile("ds_read_b64_tr_b16 %0, %4 offset:%8\n\tds_read_b64_tr_b16 %1, %5 offset:%9\n\t"           \
+                 "ds_read_b64_tr_b16 %2, %6 offset:%8\n\tds_read_b64_tr_b16 %3, %7 offset:%9"               \
+                 : "=&v"(DST[0][0]), "=&v"(DST[0][1]), "=&v"(DST[1][0]), "=&v"(DST[1][1])                   \
+                 : "v"(A0), "v"(A1), "v"((A0) ^ 64u), "v"((A1) ^ 64u), "n"((S) * 2048), "n"((S) * 2048 + 1024) : "memory");
+#define TRX_BWD_TRWAIT(DST, CNT)                                                                            \
+    asm volatile("s_waitcnt lgkmcnt(" #CNT ")"                                                              \
+                 : "+v"(DST[0][0]), "+v"(DST[0][1]), "+v"(DST[1][0]), "+v"(DST[1][1]) :: "memory");
+#define TRX_BWD_PACK8(SV, SS)                                                                               \
+    __builtin_bit_cast(bf16x8, uint4{pack2bf(SV[8 * (SS) + 0], SV[8 * (SS) + 1]), pack2bf(SV[8 * (SS) + 2], SV[8 * (SS) + 3]), \
+                                     pack2bf(SV[8 * (SS) + 4], SV[8 * (SS) + 5]), pack2bf(SV[8 * (SS) + 6], SV[8 * (SS) + 7])})
+#define TRX_BWD_TRFRAG(DST, DB)                                                                             \
+    __builtin_bit_cast(bf16x8, uint4{DST[DB][0].x, DST[DB][0].y, DST[DB][1].x, DST[DB][1].y})
+
+// ---- pass 1: dQ ------------------------------------------------------------------------------------
+template <int MM>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attention_bwd_dq_mfma_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, const float* __restrict__ mask,
+    int causal, int B, int H, int Lq, int Lk, float scale, const bf16_t* __restrict__ dout,
+    const float* __restrict__ negl, const float* __restrict__ negd, bf16_t* __restrict__ dq) {
+    __shared__ __attribute__((aligned(128))) char lds[3 * 16384];   // ring of 3: [K 8 KiB | V 8 KiB]
+    __shared__ __attribute__((aligned(16))) float ldsM[1024];       // key mask / scale of 16 tiles
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef __attribute__((address_space(1))) const void gbl_void;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int nqb = (Lq + 127) / 128;
+    int bid = blockIdx.x;
+    {   // query blocks of one (batch, head) next to each other on one XCD (they share K and V)
+        const int nwg = gridDim.x, per = nwg >> 3, main_ = per << 3;
+        if (bid < main_) bid = (bid & 7) * per + (bid >> 3);
+    }
+    const int qb = bid % nqb, h = (bid / nqb) % H, b = bid / (nqb * H);
+    const int qidx = qb * 128 + wave * 32 + r;
+    const int qc = qidx < Lq ? qidx : Lq - 1;
+    bf16x8 qf[4], dof[4];
+    {
+        const int64_t ro = (((int64_t)b * Lq + qc) * H + h) * 64 + 8 * hh;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            qf[s] = *reinterpret_cast<const bf16x8*>(q + ro + 16 * s);
+            dof[s] = *reinterpret_cast<const bf16x8*>(dout + ro + 16 * s);
+        }
+    }
+    const float sl2 = scale * 1.44269504088896340736f;
+    const float inv_scale = 1.0f / scale;
+    const float nlsl2 = negl[((int64_t)b * H + h) * Lq + qc] * sl2;   // -lse * log2 e
+    const float nd = negd[((int64_t)b * H + h) * Lq + qc];            // -delta
+    f32x16 a0, a1;   // dQ^T: d blocks 0..31 / 32..63 x this wave's 32 queries
+#pragma unroll
+    for (int t = 0; t < 16; ++t) { a0[t] = 0.f; a1[t] = 0.f; }
+    const int off = Lk - Lq;
+    int nkb = (Lk + 63) / 64;
+    if (causal) nkb = min(nkb, (min(Lq - 1, qb * 128 + 127) + off) / 64 + 1);
+    const int klim = causal ? min(Lk - 1, qidx + off) : Lk - 1;
+    const int klim_wave_min = causal ? min(Lk - 1, qb * 128 + wave * 32 + off) : Lk - 1;
+    const float* mrow = (MM == TRX_NN_MASK_FULL) ? mask + ((int64_t)b * Lq + qc) * Lk : nullptr;
+    constexpr bool keymask = MM == TRX_NN_MASK_KEY;
+    const float* mkey = keymask ? mask + (int64_t)b * Lk : nullptr;
+
+    const int prow = lane >> 3, pslot = lane & 7;
+    const unsigned rowbytes = (unsigned)H * 128u;
+    const char* kbase = reinterpret_cast<const char*>(k + ((int64_t)b * Lk * H + h) * 64);
+    const char* vbase = reinterpret_cast<const char*>(v + ((int64_t)b * Lk * H + h) * 64);
+    unsigned sofs[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int rw = 8 * (2 * wave + i) + prow;
+        sofs[i] = (unsigned)rw * rowbytes + TRX_BWD_SW_OFS(rw, pslot);
+    }
+#define TRX_BWD1_STAGE(KB, BUF)                                                                             \
+    {                                                                                                       \
+        const char* kt_ = kbase + (int64_t)(KB) * 64 * rowbytes;                                            \
+        const char* vt_ = vbase + (int64_t)(KB) * 64 * rowbytes;                                            \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                  \
+            unsigned so_ = sofs[i_];                                                                        \
+            if ((KB) * 64 + 64 > Lk) { /* tail tile: rows past the last key re-read it (hidden anyway) */   \
+                const int rw_ = 8 * (2 * wave + i_) + prow;                                                 \
+                so_ = (unsigned)min(rw_, Lk - 1 - (KB) * 64) * rowbytes + TRX_BWD_SW_OFS(rw_, pslot);       \
+            }                                                                                               \
+            __builtin_amdgcn_global_load_lds((gbl_void*)(kt_ + so_),                                        \
+                                             (lds_void*)(lds + (BUF) * 16384 + (2 * wave + i_) * 1024), 16, 0, 0);        \
+            __builtin_amdgcn_global_load_lds((gbl_void*)(vt_ + so_),                                        \
+                                             (lds_void*)(lds + (BUF) * 16384 + 8192 + (2 * wave + i_) * 1024), 16, 0, 0); \
+        }                                                                                                   \
+    }
+    const unsigned ldsbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+    unsigned rfa[4];   // row-fragment addresses: row r (+32 by offset), chunk 2 s + hh
+#pragma unroll
+    for (int s = 0; s < 4; ++s) rfa[s] = ldsbase + (unsigned)(r * 128 + (((2 * s + hh) ^ bwd_sw(r)) << 4));
+    const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
+    // transposed reads: rows 4 hh + qq (+ 8), chunk 2 (g & 1) + (pp >> 1) (+ 4 for d block 1 = ^ 64)
+    const int tsw = ((qq >> 1) << 2) | hh;   // bwd_sw(4 hh + qq); 8 rows further it is tsw ^ 2
+    const int tc = 2 * (g & 1) + (pp >> 1);
+    const unsigned tra0 = ldsbase + (unsigned)((4 * hh + qq) * 128 + ((tc ^ tsw) << 4) + 8 * (pp & 1));
+    const unsigned tra1 = ldsbase + (unsigned)((4 * hh + qq) * 128 + ((tc ^ tsw ^ 2) << 4) + 8 * (pp & 1));
+
+    TRX_BWD1_STAGE(0, 0);
+    if (nkb > 1) TRX_BWD1_STAGE(1, 1);
+    asm volatile("" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]));
+    asm volatile("" : "+v"(dof[0]), "+v"(dof[1]), "+v"(dof[2]), "+v"(dof[3]));
+    int buf = 0;
+    for (int kc = 0; kc < nkb; kc += 16) {
+    if (keymask) {
+        if (kc > 0) __syncthreads();
+        float mv_[4];
+#pragma unroll
+        for (int i_ = 0; i_ < 4; ++i_) mv_[i_] = mkey[min(kc * 64 + 4 * tid + i_, Lk - 1)];
+#pragma unroll
+        for (int i_ = 0; i_ < 4; ++i_) ldsM[4 * tid + i_] = fmaxf(mv_[i_] * inv_scale, -1e30f);
+    }
+    const int kend = min(nkb, kc + 16);
+    for (int kb = kc; kb < kend; ++kb) {
+        if (kb + 1 < nkb) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const int buf1 = buf == 2 ? 0 : buf + 1, buf2 = buf == 0 ? 2 : buf - 1;
+        if (kb + 2 < nkb) TRX_BWD1_STAGE(kb + 2, buf2);
+        const unsigned bofs = (unsigned)(buf * 16384);
+        const int key0 = kb * 64;
+        // ---- S^T = K Q^T (+ mask / scale) ----
+        f32x16 s0, s1;
+        if (keymask) {
+            const float* mt = ldsM + (kb - kc) * 64 + 4 * hh;
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4) {
+                const float4 a = *reinterpret_cast<const float4*>(mt + 8 * t4);
+                const float4 c = *reinterpret_cast<const float4*>(mt + 32 + 8 * t4);
+                s0[4 * t4] = a.x; s0[4 * t4 + 1] = a.y; s0[4 * t4 + 2] = a.z; s0[4 * t4 + 3] = a.w;
+                s1[4 * t4] = c.x; s1[4 * t4 + 1] = c.y; s1[4 * t4 + 2] = c.z; s1[4 * t4 + 3] = c.w;
+            }
+        } else if (MM == TRX_NN_MASK_FULL) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int kr_ = (t & 3) + 8 * (t >> 2) + 4 * hh;
+                s0[t] = fmaxf(mrow[min(key0 + kr_, Lk - 1)] * inv_scale, -1e30f);
+                s1[t] = fmaxf(mrow[min(key0 + 32 + kr_, Lk - 1)] * inv_scale, -1e30f);
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) { s0[t] = 0.f; s1[t] = 0.f; }
+        }
+        bf16x8 fr[4][2];
+        TRX_BWD_ROWS8(fr, bofs)
+        TRX_BWD_WAIT8(fr)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[s][0], qf[s], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[s][1], qf[s], s1, 0, 0, 0);
+        }
+        // ---- dP^T - delta = V dO^T - delta ----
+        f32x16 p0, p1;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) { p0[t] = nd; p1[t] = nd; }
+        TRX_BWD_ROWS8(fr, bofs + 8192u)
+        TRX_BWD_WAIT8(fr)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            p0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[s][0], dof[s], p0, 0, 0, 0);
+            p1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[s][1], dof[s], p1, 0, 0, 0);
+        }
+        // K^T fragments of the first 32 keys fly under the elementwise part
+        uint2 kt0[2][2], kt1[2][2];
+        const unsigned ta0 = tra0 + bofs, ta1 = tra1 + bofs;
+        TRX_BWD_TR(kt0, 0, ta0, ta1)
+        TRX_BWD_TR(kt1, 1, ta0, ta1)
+        // ---- dS = P (dP - delta), P = exp2(scale log2e S - lse log2e) ----
+        const bool vis = key0 + 63 > klim_wave_min;
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int kr_ = hb * 32 + (t & 3) + 8 * (t >> 2) + 4 * hh;
+                float pr = __builtin_amdgcn_exp2f(fminf(__builtin_fmaf(hb ? s1[t] : s0[t], sl2, nlsl2), 0.f));   // p <= 1
+                if (vis) pr = (key0 + kr_ > klim) ? 0.f : pr;
+                if (hb) s1[t] = pr * p1[t]; else s0[t] = pr * p0[t];
+            }
+        // ---- dQ^T += K^T dS^T ----
+        TRX_BWD_TRWAIT(kt0, 4)
+        {
+            const bf16x8 ds = TRX_BWD_PACK8(s0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(TRX_BWD_TRFRAG(kt0, 0), ds, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(TRX_BWD_TRFRAG(kt0, 1), ds, a1, 0, 0, 0);
+        }
+        TRX_BWD_TR(kt0, 2, ta0, ta1)
+        TRX_BWD_TRWAIT(kt1, 4)
+        {
+            const bf16x8 ds = TRX_BWD_PACK8(s0, 1);
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(TRX_BWD_TRFRAG(kt1, 0), ds, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(TRX_BWD_TRFRAG(kt1, 1), ds, a1, 0, 0, 0);
+        }
+        TRX_BWD_TR(kt1, 3, ta0, ta1)
+        TRX_BWD_TRWAIT(kt0, 4)
+        {
+            const bf16x8 ds = TRX_BWD_PACK8(s1, 0);
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(TRX_BWD_TRFRAG(kt0, 0), ds, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(TRX_BWD_TRFRAG(kt0, 1), ds, a1, 0, 0, 0);
+        }
+        TRX_BWD_TRWAIT(kt1, 0)
+        {
+            const bf16x8 ds = TRX_BWD_PACK8(s1, 1);
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(TRX_BWD_TRFRAG(kt1, 0), ds, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(TRX_BWD_TRFRAG(kt1, 1), ds, a1, 0, 0, 0);
+        }
+        buf = buf1;
+    }
+    }
+#undef TRX_BWD1_STAGE
+    if (qidx < Lq) {
+        bf16_t* op = dq + (((int64_t)b * Lq + qidx) * H + h) * 64;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {   // registers 4gq..4gq+3 = d rows 8gq + 4hh + 0..3
+            uint2 w0, w1;
+            w0.x = pack2bf(a0[4 * gq] * scale, a0[4 * gq + 1] * scale); w0.y = pack2bf(a0[4 * gq + 2] * scale, a0[4 * gq + 3] * scale);
+            w1.x = pack2bf(a1[4 * gq] * scale, a1[4 * gq + 1] * scale); w1.y = pack2bf(a1[4 * gq + 2] * scale, a1[4 * gq + 3] * scale);
+            *reinterpret_cast<uint2*>(op + 8 * gq + 4 * hh) = w0;
+            *reinterpret_cast<uint2*>(op + 32 + 8 * gq + 4 * hh) = w1;
+        }
+    }
+}
+
+// ---- pass 2: dK, dV --------------------------------------------------------------------------------
+constexpr int BWD2_STAGE = 16384 + 512;   // Q 8 KiB | dO 8 KiB | -lse/scale of 64 queries | -delta of 64 queries
+
+template <int MM>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attention_bwd_dkv_mfma_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, const float* __restrict__ mask,
+    int causal, int B, int H, int Lq, int Lk, float scale, const bf16_t* __restrict__ dout,
+    const float* __restrict__ negl, const float* __restrict__ negd, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv) {
+    __shared__ __attribute__((aligned(128))) char lds[3 * BWD2_STAGE];
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef __attribute__((address_space(1))) const void gbl_void;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int nkblk = (Lk + 127) / 128;
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, per = nwg >> 3, main_ = per << 3;
+        if (bid < main_) bid = (bid & 7) * per + (bid >> 3);
+    }
+    const int kblk = bid % nkblk, h = (bid / nkblk) % H, b = bid / (nkblk * H);
+    const int kidx = kblk * 128 + wave * 32 + r;   // this lane's key
+    const int kc = kidx < Lk ? kidx : Lk - 1;
+    bf16x8 kf[4], vf[4];
+    {
+        const int64_t ro = (((int64_t)b * Lk + kc) * H + h) * 64 + 8 * hh;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            kf[s] = *reinterpret_cast<const bf16x8*>(k + ro + 16 * s);
+            vf[s] = *reinterpret_cast<const bf16x8*>(v + ro + 16 * s);
+        }
+    }
+    constexpr float L2E = 1.44269504088896340736f;
+    const float sl2 = scale * L2E;
+    const float mk2 = (MM == TRX_NN_MASK_KEY) ? fmaxf(mask[(int64_t)b * Lk + kc], -1e30f) * L2E : 0.f;
+    f32x16 ak0, ak1, av0, av1;   // dK^T, dV^T: d blocks x this wave's 32 keys
+#pragma unroll
+    for (int t = 0; t < 16; ++t) { ak0[t] = 0.f; ak1[t] = 0.f; av0[t] = 0.f; av1[t] = 0.f; }
+    const int off = Lk - Lq;
+    const int nqt = (Lq + 63) / 64;
+    // causal: query i sees key j iff j <= i + off; the first query that sees any key of this workgroup
+    const int qt0 = causal ? max(0, kblk * 128 - off) / 64 : 0;
+    const int qmin = causal ? kidx - off : 0;                       // this lane's key is visible to queries >= qmin
+    const int qmin_wave_max = causal ? kblk * 128 + wave * 32 + 31 - off : 0;
+
+    const int prow = lane >> 3, pslot = lane & 7;
+    const unsigned rowbytes = (unsigned)H * 128u;
+    const char* qbase = reinterpret_cast<const char*>(q + ((int64_t)b * Lq * H + h) * 64);
+    const char* dobase = reinterpret_cast<const char*>(dout + ((int64_t)b * Lq * H + h) * 64);
+    const float* nlbase = negl + ((int64_t)b * H + h) * Lq;
+    const float* ndbase = negd + ((int64_t)b * H + h) * Lq;
+    unsigned sofs[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int rw = 8 * (2 * wave + i) + prow;
+        sofs[i] = (unsigned)rw * rowbytes + TRX_BWD_SW_OFS(rw, pslot);
+    }
+    // per stage and wave: 4 tile loads (+ 2 loads of the per-query scalars on wave 0)
+#define TRX_BWD2_STAGE(QT, BUF)                                                                             \
+    {                                                                                                       \
+        const char* qt_ = qbase + (int64_t)(QT) * 64 * rowbytes;                                            \
+        const char* dt_ = dobase + (int64_t)(QT) * 64 * rowbytes;                                           \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                  \
+            unsigned so_ = sofs[i_];                                                                        \
+            if ((QT) * 64 + 64 > Lq) { /* tail tile: rows past the last query re-read it (masked below) */  \
+                const int rw_ = 8 * (2 * wave + i_) + prow;                                                 \
+                so_ = (unsigned)min(rw_, Lq - 1 - (QT) * 64) * rowbytes + TRX_BWD_SW_OFS(rw_, pslot);       \
+            }                                                                                               \
+            __builtin_amdgcn_global_load_lds((gbl_void*)(qt_ + so_),                                        \
+                                             (lds_void*)(lds + (BUF) * BWD2_STAGE + (2 * wave + i_) * 1024), 16, 0, 0);        \
+            __builtin_amdgcn_global_load_lds((gbl_void*)(dt_ + so_),                                        \
+                                             (lds_void*)(lds + (BUF) * BWD2_STAGE + 8192 + (2 * wave + i_) * 1024), 16, 0, 0); \
+        }                                                                                                   \
+        if (wave == 0) {                                                                                    \
+            const int qi_ = min((QT) * 64 + lane, Lq - 1);                                                  \
+            __builtin_amdgcn_global_load_lds((gbl_void*)(nlbase + qi_), (lds_void*)(lds + (BUF) * BWD2_STAGE + 16384), 4, 0, 0);       \
+            __builtin_amdgcn_global_load_lds((gbl_void*)(ndbase + qi_), (lds_void*)(lds + (BUF) * BWD2_STAGE + 16384 + 256), 4, 0, 0); \
+        }                                                                                                   \
+    }
+    const unsigned ldsbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+    unsigned rfa[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) rfa[s] = ldsbase + (unsigned)(r * 128 + (((2 * s + hh) ^ bwd_sw(r)) << 4));
+    const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
+    const int tsw = ((qq >> 1) << 2) | hh;
+    const int tc = 2 * (g & 1) + (pp >> 1);
+    const unsigned tra0 = ldsbase + (unsigned)((4 * hh + qq) * 128 + ((tc ^ tsw) << 4) + 8 * (pp & 1));
+    const unsigned tra1 = ldsbase + (unsigned)((4 * hh + qq) * 128 + ((tc ^ tsw ^ 2) << 4) + 8 * (pp & 1));
+    const unsigned sca = ldsbase + 16384u + (unsigned)(16 * hh);   // per-query scalars: rows 4 hh .. (+8 per float4)
+
+    if (qt0 < nqt) TRX_BWD2_STAGE(qt0, 0);
+    if (qt0 + 1 < nqt) TRX_BWD2_STAGE(qt0 + 1, 1);
+    asm volatile("" : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]));
+    asm volatile("" : "+v"(vf[0]), "+v"(vf[1]), "+v"(vf[2]), "+v"(vf[3]));
+    int buf = 0;
+    for (int qt = qt0; qt < nqt; ++qt) {
+        if (qt + 1 < nqt) {
+            if (wave == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const int buf1 = buf == 2 ? 0 : buf + 1, buf2 = buf == 0 ? 2 : buf - 1;
+        if (qt + 2 < nqt) TRX_BWD2_STAGE(qt + 2, buf2);
+        const unsigned bofs = (unsigned)(buf * BWD2_STAGE);
+        const int q0 = qt * 64;
+        // some query row of the tile is past Lq, or hidden from some key of this wave by causality
+        const bool vis = (q0 + 64 > Lq) || (causal && q0 < qmin_wave_max);
+        const unsigned ta0 = tra0 + bofs, ta1 = tra1 + bofs;
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {   // 32 queries at a time
+            // accumulators start from the per-query scalars: rows (t & 3) + 8 (t >> 2) + 4 hh
+            f32x16 s, p;
+            {
+                f32x4v nl4[4], nd4[4];
+#pragma unroll
+                for (int t4 = 0; t4 < 4; ++t4)
+                    asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"
+                                 : "=&v"(nl4[t4]), "=&v"(nd4[t4]) : "v"(sca + bofs), "n"(hb * 128 + 32 * t4), "n"(256 + hb * 128 + 32 * t4) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(nl4[0]), "+v"(nl4[1]), "+v"(nl4[2]), "+v"(nl4[3]), "+v"(nd4[0]), "+v"(nd4[1]), "+v"(nd4[2]), "+v"(nd4[3]) :: "memory");
+#pragma unroll
+                for (int t4 = 0; t4 < 4; ++t4) {
+                    s[4 * t4] = nl4[t4].x; s[4 * t4 + 1] = nl4[t4].y; s[4 * t4 + 2] = nl4[t4].z; s[4 * t4 + 3] = nl4[t4].w;
+                    p[4 * t4] = nd4[t4].x; p[4 * t4 + 1] = nd4[t4].y; p[4 * t4 + 2] = nd4[t4].z; p[4 * t4 + 3] = nd4[t4].w;
+                }
+            }
+            // ---- S - lse/scale = Q K^T ... ;  dP - delta = dO V^T ... : rows 32 hb + r of the tiles ----
+            bf16x8 fq[4], fd[4];
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_)
+                asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"
+                             : "=&v"(fq[s_]), "=&v"(fd[s_]) : "v"(rfa[s_] + bofs), "n"(hb * 4096), "n"(8192 + hb * 4096) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(fq[0]), "+v"(fq[1]), "+v"(fq[2]), "+v"(fq[3]), "+v"(fd[0]), "+v"(fd[1]), "+v"(fd[2]), "+v"(fd[3]) :: "memory");
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[s_], kf[s_], s, 0, 0, 0);
+                p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fd[s_], vf[s_], p, 0, 0, 0);
+            }
+            // transposed fragments of this half: k-steps 2 hb, 2 hb + 1 of dO (for dV) and of Q (for dK)
+            uint2 td0[2][2], td1[2][2], tq0[2][2], tq1[2][2];
+            if (hb == 0) {
+                TRX_BWD_TR(td0, 0, ta0 + 8192u, ta1 + 8192u) TRX_BWD_TR(td1, 1, ta0 + 8192u, ta1 + 8192u)
+                TRX_BWD_TR(tq0, 0, ta0, ta1) TRX_BWD_TR(tq1, 1, ta0, ta1)
+            } else {
+                TRX_BWD_TR(td0, 2, ta0 + 8192u, ta1 + 8192u) TRX_BWD_TR(td1, 3, ta0 + 8192u, ta1 + 8192u)
+                TRX_BWD_TR(tq0, 2, ta0, ta1) TRX_BWD_TR(tq1, 3, ta0, ta1)
+            }
+            // ---- P = exp2(scale log2e (S - lse/scale) + mask log2e) ; dS = P (dP - delta) ----
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int qr_ = q0 + hb * 32 + (t & 3) + 8 * (t >> 2) + 4 * hh;
+                float val = __builtin_fmaf(s[t], sl2, mk2);
+                if (MM == TRX_NN_MASK_FULL)
+                    val = __builtin_fmaf(fmaxf(mask[((int64_t)b * Lq + min(qr_, Lq - 1)) * Lk + kc], -1e30f), L2E, val);
+                float pr = __builtin_amdgcn_exp2f(fminf(val, 0.f));   // p <= 1
+                if (vis) pr = (qr_ >= Lq || qr_ < qmin) ? 0.f : pr;
+                s[t] = pr;
+                p[t] = pr * p[t];
+            }
+            // ---- dV^T += dO^T P ;  dK^T += Q^T dS ----
+            TRX_BWD_TRWAIT(td0, 12)
+            {
+                const bf16x8 pb = TRX_BWD_PACK8(s, 0);
+                av0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(TRX_BWD_TRFRAG(td0, 0), pb, av0, 0, 0, 0);
+                av1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(TRX_BWD_TRFRAG(td0, 1), pb, av1, 0, 0, 0);
+            }
+            TRX_BWD_TRWAIT(td1, 8)
+            {
+                const bf16x8 pb = TRX_BWD_PACK8(s, 1);
+                av0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(TRX_BWD_TRFRAG(td1, 0), pb, av0, 0, 0, 0);
+                av1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(TRX_BWD_TRFRAG(td1, 1), pb, av1, 0, 0, 0);
+            }
+            TRX_BWD_TRWAIT(tq0, 4)
+            {
+                const bf16x8 db = TRX_BWD_PACK8(p, 0);
+                ak0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(TRX_BWD_TRFRAG(tq0, 0), db, ak0, 0, 0, 0);
+                ak1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(TRX_BWD_TRFRAG(tq0, 1), db, ak1, 0, 0, 0);
+            }
+            TRX_BWD_TRWAIT(tq1, 0)
+            {
+                const bf16x8 db = TRX_BWD_PACK8(p, 1);
+                ak0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(TRX_BWD_TRFRAG(tq1, 0), db, ak0, 0, 0, 0);
+                ak1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(TRX_BWD_TRFRAG(tq1, 1), db, ak1, 0, 0, 0);
+            }
+        }
+        buf = buf1;
+    }
+#undef TRX_BWD2_STAGE
+    if (kidx < Lk) {
+        bf16_t* kp = dk + (((int64_t)b * Lk + kidx) * H + h) * 64;
+        bf16_t* vp = dv + (((int64_t)b * Lk + kidx) * H + h) * 64;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            uint2 w;
+            w.x = pack2bf(ak0[4 * gq] * scale, ak0[4 * gq + 1] * scale); w.y = pack2bf(ak0[4 * gq + 2] * scale, ak0[4 * gq + 3] * scale);
+            *reinterpret_cast<uint2*>(kp + 8 * gq + 4 * hh) = w;
+            w.x = pack2bf(ak1[4 * gq] * scale, ak1[4 * gq + 1] * scale); w.y = pack2bf(ak1[4 * gq + 2] * scale, ak1[4 * gq + 3] * scale);
+            *reinterpret_cast<uint2*>(kp + 32 + 8 * gq + 4 * hh) = w;
+            w.x = pack2bf(av0[4 * gq], av0[4 * gq + 1]); w.y = pack2bf(av0[4 * gq + 2], av0[4 * gq + 3]);
+            *reinterpret_cast<uint2*>(vp + 8 * gq + 4 * hh) = w;
+            w.x = pack2bf(av1[4 * gq], av1[4 * gq + 1]); w.y = pack2bf(av1[4 * gq + 2], av1[4 * gq + 3]);
+            *reinterpret_cast<uint2*>(vp + 32 + 8 * gq + 4 * hh) = w;
+        }
+    }
+}

@@ -563,6 +563,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
 }
 
+#include "attn_bwd_mfma.h"
+
 // ---- attention backward, fp32 math, probabilities recomputed from lse --------------------------
 // pass 1 (a lane per query row i):  delta_i = dO_i . O_i ;  dS_ij = p_ij (dO_i . V_j - delta_i) ;
 //                                   dQ_i = scale * sum_j dS_ij K_j
@@ -748,6 +750,33 @@ int trx_attention_bwd(const void* q, const void* k, const void* v, const float* 
     if (dtype != TRX_NN_F32 && dtype != TRX_NN_BF16) return fail(TRX_NN_EINVAL, "unknown dtype");
     hipStream_t st = (hipStream_t)stream;
     dim3 gq((unsigned)((int64_t)B * H * ((Lq + 63) / 64))), gk((unsigned)((int64_t)B * H * ((Lk + 63) / 64))), block(64);
+    static const bool force_valu = getenv("TRX_NN_ATTN_VALU") != nullptr;
+    if (dtype == TRX_NN_BF16 && !force_valu) {
+        // matrix-core path; its per-query scalars (-lse/scale, -delta) live in a stream-ordered scratch
+        const size_t n = (size_t)B * H * Lq;
+        float* ws = nullptr;
+        if (hipMallocAsync((void**)&ws, 2 * n * sizeof(float), st) != hipSuccess || !ws) {
+            (void)hipGetLastError();
+            return fail(TRX_NN_EHIP, "attention_bwd: scratch allocation failed");
+        }
+        float *negl = ws, *negd = ws + n;
+        hipLaunchKernelGGL(attention_bwd_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const bf16_t*)out,
+                           (const bf16_t*)dout, lse, B, H, Lq, scale, negl, negd);
+        dim3 g1((unsigned)((int64_t)B * H * ((Lq + 127) / 128))), g2((unsigned)((int64_t)B * H * ((Lk + 127) / 128))), b2(256);
+#define TRX_LAUNCH_BWD(MM_)                                                                                                 \
+    hipLaunchKernelGGL(attention_bwd_dq_mfma_kernel<MM_>, g1, b2, 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, \
+                       mask, causal, B, H, Lq, Lk, scale, (const bf16_t*)dout, negl, negd, (bf16_t*)dq);                    \
+    hipLaunchKernelGGL(attention_bwd_dkv_mfma_kernel<MM_>, g2, b2, 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, \
+                       mask, causal, B, H, Lq, Lk, scale, (const bf16_t*)dout, negl, negd, (bf16_t*)dk, (bf16_t*)dv)
+        if (mask_mode == TRX_NN_MASK_NONE) { TRX_LAUNCH_BWD(TRX_NN_MASK_NONE); }
+        else if (mask_mode == TRX_NN_MASK_KEY) { TRX_LAUNCH_BWD(TRX_NN_MASK_KEY); }
+        else { TRX_LAUNCH_BWD(TRX_NN_MASK_FULL); }
+#undef TRX_LAUNCH_BWD
+        hipError_t e1 = hipGetLastError();
+        (void)hipFreeAsync(ws, st);
+        if (e1 != hipSuccess) return fail(TRX_NN_EHIP, hipGetErrorString(e1));
+        return TRX_NN_OK;
+    }
     if (dtype == TRX_NN_BF16) {
         hipLaunchKernelGGL(attention_bwd_dq_kernel<true>, gq, block, 0, st, q, k, v, mask, mask_mode, causal, B, H, Lq, Lk, scale, out, dout, lse, dq);
         hipLaunchKernelGGL(attention_bwd_dkv_kernel<true>, gk, block, 0, st, q, k, v, mask, mask_mode, causal, B, H, Lq, Lk, scale, out, dout, lse, dk, dv);
