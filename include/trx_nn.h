@@ -57,6 +57,32 @@ int trx_attention_bwd(const void* q, const void* k, const void* v, const float* 
                       int B, int H, int Lq, int Lk, float scale, int dtype, const void* out, const void* dout,
                       const float* lse, void* dq, void* dk, void* dv, void* stream);
 
+/* ---- training mode: dropout ------------------------------------------------------------------------
+ * The reference trains with hidden_dropout_prob = attention_probs_dropout_prob = 0.1 (BERT defaults,
+ * textreact/configs/bert_l6.json; [3P] modeling_bert.py: BertSelfAttention.dropout on the
+ * probabilities, BertSelfOutput / BertOutput / BertEmbeddings.dropout before the residual LayerNorm).
+ * Dropout decisions are a pure function of (seed, stream, row, col) -- nothing is stored; every kernel
+ * that needs a decision recomputes it, and trx_dropout_keep_mask materialises the same decisions
+ * (tests, reference backends).  p in [0, 1); kept elements are scaled by 1 / (1 - p).
+ *   LayerNorm ops: y = LayerNorm(dropout(x) + res); index space stream = 0, row, col of x.
+ *   attention    : dropout on the softmax probabilities; stream = b * H + h, row = query, col = key. */
+int trx_add_layernorm_fwd_dropout(const void* x, const void* res, const float* gamma, const float* beta, float eps,
+                                  int64_t rows, int cols, int dtype, float p, uint64_t seed, void* y, float* mean,
+                                  float* rstd, void* stream);
+/* dz = d(loss)/d(dropout(x) + res) (the gradient of res); dx = dz * keep / (1 - p) (the gradient of x);
+ * dx is required when p > 0 and ignored otherwise. */
+int trx_add_layernorm_bwd_dropout(const void* dy, const void* x, const void* res, const float* gamma, const float* mean,
+                                  const float* rstd, int64_t rows, int cols, int dtype, float p, uint64_t seed, void* dz,
+                                  void* dx, float* dgamma, float* dbeta, float* ws, void* stream);
+int trx_attention_fwd_dropout(const void* q, const void* k, const void* v, const float* mask, int mask_mode, int causal,
+                              int B, int H, int Lq, int Lk, float scale, int dtype, float p, uint64_t seed, void* out,
+                              float* lse, void* stream);
+int trx_attention_bwd_dropout(const void* q, const void* k, const void* v, const float* mask, int mask_mode, int causal,
+                              int B, int H, int Lq, int Lk, float scale, int dtype, float p, uint64_t seed, const void* out,
+                              const void* dout, const float* lse, void* dq, void* dk, void* dv, void* stream);
+/* keep[streams][rows][cols] (1 = kept) exactly as the kernels above decide for (seed, p). */
+int trx_dropout_keep_mask(uint64_t seed, float p, int64_t streams, int64_t rows, int64_t cols, unsigned char* keep, void* stream);
+
 const char* trx_nn_last_error(void);
 const char* trx_nn_version(void);
 

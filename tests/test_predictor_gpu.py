@@ -169,6 +169,81 @@ def test_attention_backward_bf16_matrix_cores(B, H, Lq, Lk, mask, causal):
         assert err <= 2e-2 * max(1.0, float(c.abs().max())), (name, err, float(c.abs().max()))
 
 
+# ---- training mode: dropout -------------------------------------------------------------------------
+def test_dropout_decisions_statistics_and_determinism():
+    keep = ops.dropout_keep_mask(1234, 0.1, 6, 300, 257, "cuda")
+    assert keep.shape == (6, 300, 257)
+    frac = float(keep.float().mean())
+    assert abs(frac - 0.9) < 3e-3, frac                        # 462,600 draws: sigma = 4.4e-4
+    assert torch.equal(keep, ops.dropout_keep_mask(1234, 0.1, 6, 300, 257, "cuda"))
+    other = ops.dropout_keep_mask(1235, 0.1, 6, 300, 257, "cuda")
+    assert 0.15 < float((keep != other).float().mean()) < 0.21     # independent: 2 * 0.9 * 0.1 = 0.18
+    # no structure along any axis: neighbouring rows / columns / streams agree as often as chance says
+    for a, b in ((keep[:, 1:], keep[:, :-1]), (keep[:, :, 1:], keep[:, :, :-1]), (keep[1:], keep[:-1])):
+        assert abs(float((a == b).float().mean()) - 0.82) < 6e-3
+    assert bool(ops.dropout_keep_mask(7, 0.0, 1, 4, 64, "cuda").all())
+    assert abs(float(ops.dropout_keep_mask(7, 0.5, 1, 512, 512, "cuda").float().mean()) - 0.5) < 4e-3
+
+
+@pytest.mark.parametrize("rows,cols", [(777, 768), (33, 600), (5, 3109)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 3e-5), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize("with_res", [True, False])
+def test_add_layernorm_dropout_forward_backward(rows, cols, dtype, tol, with_res):
+    x, r = _rand(rows, cols, dtype=dtype, seed=1), (_rand(rows, cols, dtype=dtype, seed=2) if with_res else None)
+    g, b = _rand(cols, seed=3), _rand(cols, seed=4)
+    dy = _rand(rows, cols, dtype=dtype, seed=5)
+    res = []
+    for backend in ("hip", "torch"):
+        xs = x.clone().requires_grad_(True) if backend == "hip" else x.float().clone().requires_grad_(True)
+        rs = None if r is None else (r.clone() if backend == "hip" else r.float().clone()).requires_grad_(True)
+        gs, bs = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        y = ops.add_layernorm(xs, rs, gs, bs, 1e-5, backend=backend, dropout_p=0.1, seed=99)
+        y.backward(dy if backend == "hip" else dy.float())
+        res.append((y.detach().float(), xs.grad.float(), None if rs is None else rs.grad.float(), gs.grad, bs.grad))
+    keep = ops.dropout_keep_mask(99, 0.1, 1, rows, cols, "cuda").view(rows, cols)
+    assert bool((res[0][1][~keep] == 0).all())                 # dropped elements get no gradient
+    for a, c in zip(*res):
+        if a is None:
+            continue
+        assert float((a - c).abs().max()) <= tol * max(1.0, float(c.abs().max()))
+    # p = 0 and eval are the plain op; a different seed drops different elements
+    y0 = ops.add_layernorm(x, r, g, b, 1e-5, dropout_p=0.0)
+    assert torch.equal(y0, ops.add_layernorm(x, r, g, b, 1e-5))
+    assert not torch.equal(ops.add_layernorm(x, r, g, b, 1e-5, dropout_p=0.1, seed=1), ops.add_layernorm(x, r, g, b, 1e-5, dropout_p=0.1, seed=2))
+
+
+@pytest.mark.parametrize("B,H,Lq,Lk,mask,causal", [
+    (2, 3, 70, 70, "key", False), (2, 2, 33, 33, "none", True), (2, 2, 20, 77, "key", False),
+    (1, 2, 65, 65, "full", False), (2, 4, 200, 300, "key", False), (1, 2, 160, 160, "none", True),
+])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 5e-5), (torch.bfloat16, 2e-2)])
+def test_attention_dropout_forward_backward(B, H, Lq, Lk, mask, causal, dtype, tol):
+    """fp32 goes through the VALU kernels, bf16 through the matrix-core kernels; both must take the same
+    decisions as trx_dropout_keep_mask in the forward AND in both backward passes"""
+    q, k, v = _rand(B, Lq, H, 64, dtype=dtype, seed=1), _rand(B, Lk, H, 64, dtype=dtype, seed=2), _rand(B, Lk, H, 64, dtype=dtype, seed=3)
+    dout = _rand(B, Lq, H * 64, dtype=dtype, seed=4)
+    neg = torch.finfo(torch.float32).min
+    m = None
+    if mask == "key":
+        keep = torch.ones(B, Lk, device="cuda"); keep[0, Lk // 2 + 1:] = 0
+        m = (1 - keep) * neg
+    elif mask == "full":
+        keep = (torch.rand(B, Lq, Lk, device="cuda") > 0.3).float(); keep[:, :, 0] = 1
+        m = (1 - keep) * neg
+    res = []
+    for backend in ("hip", "torch"):
+        qs, ks, vs = ((t if backend == "hip" else t.float()).clone().requires_grad_(True) for t in (q, k, v))
+        out = ops.attention(qs, ks, vs, mask=m, causal=causal, backend=backend, dropout_p=0.1, seed=4242)
+        out.backward(dout if backend == "hip" else dout.float())
+        res.append((out.detach().float(), qs.grad.float(), ks.grad.float(), vs.grad.float()))
+    for name, a, c in zip(("out", "dq", "dk", "dv"), *res):
+        err = float((a - c).abs().max())
+        assert err <= tol * max(1.0, float(c.abs().max())), (name, err)
+    plain = ops.attention(q, k, v, mask=m, causal=causal)
+    assert torch.equal(plain, ops.attention(q, k, v, mask=m, causal=causal, dropout_p=0.0))
+    assert not torch.equal(plain.float(), res[0][0])
+
+
 def test_model_backward_hip_vs_torch():
     # one training-style step on the small config: loss = CE over decoder logits (main.py:129-131)
     z = np.load(G)

@@ -85,11 +85,11 @@ __global__ __launch_bounds__(256) void attention_bwd_prep_kernel(const bf16_t* _
     __builtin_bit_cast(bf16x8, uint4{DST[DB][0].x, DST[DB][0].y, DST[DB][1].x, DST[DB][1].y})
 
 // ---- pass 1: dQ ------------------------------------------------------------------------------------
-template <int MM>
+template <int MM, bool DROP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attention_bwd_dq_mfma_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, const float* __restrict__ mask,
     int causal, int B, int H, int Lq, int Lk, float scale, const bf16_t* __restrict__ dout,
-    const float* __restrict__ negl, const float* __restrict__ negd, bf16_t* __restrict__ dq) {
+    const float* __restrict__ negl, const float* __restrict__ negd, bf16_t* __restrict__ dq, DropArgs da) {
     __shared__ __attribute__((aligned(128))) char lds[3 * 16384];   // ring of 3: [K 8 KiB | V 8 KiB]
     __shared__ __attribute__((aligned(16))) float ldsM[1024];       // key mask / scale of 16 tiles
     typedef __attribute__((address_space(3))) void lds_void;
@@ -129,6 +129,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const float* mrow = (MM == TRX_NN_MASK_FULL) ? mask + ((int64_t)b * Lq + qc) * Lk : nullptr;
     constexpr bool keymask = MM == TRX_NN_MASK_KEY;
     const float* mkey = keymask ? mask + (int64_t)b * Lk : nullptr;
+    // dropout hash input of (this lane's query, key pair 0) -- the same function the forward evaluated
+    const unsigned xdrop = DROP ? drop_base(da.seed_lo, da.seed_hi, (unsigned)(b * H + h)) + (unsigned)qidx * DROP_C1 + (unsigned)(2 * hh) * DROP_C2 : 0u;
 
     const int prow = lane >> 3, pslot = lane & 7;
     const unsigned rowbytes = (unsigned)H * 128u;
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // ---- dP^T - delta = V dO^T - delta ----
         f32x16 p0, p1;
 #pragma unroll
-        for (int t = 0; t < 16; ++t) { p0[t] = nd; p1[t] = nd; }
+        for (int t = 0; t < 16; ++t) { p0[t] = DROP ? 0.f : nd; p1[t] = DROP ? 0.f : nd; }   // dropout rescales dP before - delta
         TRX_BWD_ROWS8(fr, bofs + 8192u)
         TRX_BWD_WAIT8(fr)
 #pragma unroll
@@ -240,6 +242,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         TRX_BWD_TR(kt1, 1, ta0, ta1)
         // ---- dS = P (dP - delta), P = exp2(scale log2e S - lse log2e) ----
         const bool vis = key0 + 63 > klim_wave_min;
+        if (DROP) {
+            const unsigned xd = xdrop + (unsigned)(kb * 32) * DROP_C2;
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                for (int t = 0; t < 16; t += 2) {
+                    const unsigned bits = lowbias32(xd + (unsigned)(hb * 16 + ((t & 3) >> 1) + 4 * (t >> 2)) * DROP_C2);
+                    const float k0 = drop_keep(bits, 0, da.thr) ? da.inv_keep : 0.f, k1 = drop_keep(bits, 1, da.thr) ? da.inv_keep : 0.f;
+                    if (hb) { p1[t] = __builtin_fmaf(p1[t], k0, nd); p1[t + 1] = __builtin_fmaf(p1[t + 1], k1, nd); }
+                    else { p0[t] = __builtin_fmaf(p0[t], k0, nd); p0[t + 1] = __builtin_fmaf(p0[t + 1], k1, nd); }
+                }
+        }
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
@@ -296,11 +310,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // ---- pass 2: dK, dV --------------------------------------------------------------------------------
 constexpr int BWD2_STAGE = 16384 + 512;   // Q 8 KiB | dO 8 KiB | -lse/scale of 64 queries | -delta of 64 queries
 
-template <int MM>
+template <int MM, bool DROP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attention_bwd_dkv_mfma_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, const float* __restrict__ mask,
     int causal, int B, int H, int Lq, int Lk, float scale, const bf16_t* __restrict__ dout,
-    const float* __restrict__ negl, const float* __restrict__ negd, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv) {
+    const float* __restrict__ negl, const float* __restrict__ negd, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, DropArgs da) {
     __shared__ __attribute__((aligned(128))) char lds[3 * BWD2_STAGE];
     typedef __attribute__((address_space(3))) void lds_void;
     typedef __attribute__((address_space(1))) const void gbl_void;
@@ -336,6 +350,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int qt0 = causal ? max(0, kblk * 128 - off) / 64 : 0;
     const int qmin = causal ? kidx - off : 0;                       // this lane's key is visible to queries >= qmin
     const int qmin_wave_max = causal ? kblk * 128 + wave * 32 + 31 - off : 0;
+    // dropout hash input of (query 4 hh, this lane's key pair); the key's half of the hash is bit 4 of dshift
+    const unsigned xdrop = DROP ? drop_base(da.seed_lo, da.seed_hi, (unsigned)(b * H + h)) + (unsigned)(4 * hh) * DROP_C1 + ((unsigned)kc >> 1) * DROP_C2 : 0u;
+    const unsigned dshift = ((unsigned)kc & 1u) << 4;
 
     const int prow = lane >> 3, pslot = lane & 7;
     const unsigned rowbytes = (unsigned)H * 128u;
@@ -420,6 +437,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     p[4 * t4] = nd4[t4].x; p[4 * t4 + 1] = nd4[t4].y; p[4 * t4 + 2] = nd4[t4].z; p[4 * t4 + 3] = nd4[t4].w;
                 }
             }
+            f32x16 ndv;   // dropout rescales dP before - delta: keep - delta aside, start dP from 0
+            if (DROP) {
+#pragma unroll
+                for (int t = 0; t < 16; ++t) { ndv[t] = p[t]; p[t] = 0.f; }
+            }
             // ---- S - lse/scale = Q K^T ... ;  dP - delta = dO V^T ... : rows 32 hb + r of the tiles ----
             bf16x8 fq[4], fd[4];
 #pragma unroll
@@ -451,8 +473,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     val = __builtin_fmaf(fmaxf(mask[((int64_t)b * Lq + min(qr_, Lq - 1)) * Lk + kc], -1e30f), L2E, val);
                 float pr = __builtin_amdgcn_exp2f(fminf(val, 0.f));   // p <= 1
                 if (vis) pr = (qr_ >= Lq || qr_ < qmin) ? 0.f : pr;
-                s[t] = pr;
-                p[t] = pr * p[t];
+                if (DROP) {
+                    const unsigned bits = lowbias32(xdrop + (unsigned)(q0 + hb * 32 + (t & 3) + 8 * (t >> 2)) * DROP_C1);
+                    const float km = (((bits >> dshift) & 0xffffu) >= da.thr) ? da.inv_keep : 0.f;
+                    s[t] = pr * km;                                    // what the forward multiplied V with
+                    p[t] = pr * __builtin_fmaf(p[t], km, ndv[t]);
+                } else {
+                    s[t] = pr;
+                    p[t] = pr * p[t];
+                }
             }
             // ---- dV^T += dO^T P ;  dK^T += Q^T dS ----
             TRX_BWD_TRWAIT(td0, 12)

@@ -8,11 +8,58 @@
 #include <hip/hip_runtime.h>
 #include <string>
 #include <cstdlib>
+#include <cmath>
 
 namespace {
 
 thread_local std::string g_err;
 int fail(int code, const std::string& m) { g_err = m; return code; }
+
+// ---- dropout: a counter-based decision per element, recomputed wherever it is needed --------------
+// keep(stream, row, col) depends only on (seed, stream, row, col): the forward kernels, both backward
+// passes and trx_dropout_keep_mask evaluate the same function, nothing is stored.  One 32-bit hash
+// (lowbias32, two multiply-xorshift rounds) serves the two columns 2c, 2c+1 with 16 bits each;
+// an element is dropped when its 16 bits are below thr = round(p * 65536).
+struct Drop { unsigned base, thr; float inv_keep; };   // thr == 0: dropout off
+struct DropArgs { unsigned seed_lo, seed_hi, thr; float inv_keep; };   // attention: the base is per (batch, head)
+__host__ __device__ __forceinline__ unsigned lowbias32(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+__host__ __device__ __forceinline__ unsigned drop_base(unsigned seed_lo, unsigned seed_hi, unsigned stream) {
+    return lowbias32(seed_lo ^ lowbias32(seed_hi + stream * 0x9E3779B9u));
+}
+constexpr unsigned DROP_C1 = 0x9E3779B1u, DROP_C2 = 0x85EBCA77u;
+__device__ __forceinline__ unsigned drop_bits(unsigned base, unsigned row, unsigned colpair) {
+    return lowbias32(base + row * DROP_C1 + colpair * DROP_C2);
+}
+__device__ __forceinline__ bool drop_keep(unsigned bits, unsigned col, unsigned thr) {
+    return ((bits >> ((col & 1u) << 4)) & 0xffffu) >= thr;
+}
+__device__ __forceinline__ float drop_mult(const Drop& d, unsigned row, unsigned col) {   // 0 or 1/(1-p)
+    if (d.thr == 0) return 1.f;
+    return drop_keep(drop_bits(d.base, row, col >> 1), col, d.thr) ? d.inv_keep : 0.f;
+}
+unsigned drop_thr(float p) {
+    const long t = lrintf(p * 65536.0f);
+    return (unsigned)(t < 0 ? 0 : (t > 65535 ? 65535 : t));
+}
+Drop make_drop(float p, uint64_t seed, unsigned stream) {
+    Drop d;
+    d.thr = p > 0.f ? drop_thr(p) : 0u;
+    d.base = drop_base((unsigned)seed, (unsigned)(seed >> 32), stream);
+    d.inv_keep = 1.0f / (1.0f - p);
+    return d;
+}
+__global__ void dropout_keep_mask_kernel(unsigned seed_lo, unsigned seed_hi, unsigned thr, int64_t streams, int64_t rows,
+                                         int64_t cols, unsigned char* __restrict__ keep) {
+    const int64_t n = streams * rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t col = i % cols, sr = i / cols;
+        const unsigned base = drop_base(seed_lo, seed_hi, (unsigned)(sr / rows));
+        keep[i] = drop_keep(drop_bits(base, (unsigned)(sr % rows), (unsigned)(col >> 1)), (unsigned)col, thr) ? 1 : 0;
+    }
+}
 
 typedef unsigned short bf16_t;
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
@@ -68,7 +115,7 @@ template <bool BF> __device__ __forceinline__ uint4 pack16(const float* f) {
 template <bool BF>
 __global__ __launch_bounds__(256) void add_ln_fwd_vec_kernel(const void* x, const void* res, const float* gamma,
                                                              const float* beta, float eps, int64_t rows, int cols,
-                                                             void* y, float* mean, float* rstd) {
+                                                             void* y, float* mean, float* rstd, Drop drop) {
     constexpr int V = Vec16<BF>::N;
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -84,6 +131,14 @@ __global__ __launch_bounds__(256) void add_ln_fwd_vec_kernel(const void* x, cons
         const int c = lane + 64 * i;
         if (c < nchunk) {
             unpack16<BF>(*reinterpret_cast<const uint4*>(xr + (size_t)c * 16), v[i]);
+            if (drop.thr) {   // dropout acts on x only, before the residual is added
+#pragma unroll
+                for (int j = 0; j < V; j += 2) {
+                    const unsigned bits = drop_bits(drop.base, (unsigned)row, (unsigned)(c * V + j) >> 1);
+                    v[i][j] *= drop_keep(bits, 0, drop.thr) ? drop.inv_keep : 0.f;
+                    v[i][j + 1] *= drop_keep(bits, 1, drop.thr) ? drop.inv_keep : 0.f;
+                }
+            }
             if (rr) {
                 float r[V];
                 unpack16<BF>(*reinterpret_cast<const uint4*>(rr + (size_t)c * 16), r);
@@ -120,7 +175,7 @@ __global__ __launch_bounds__(256) void add_ln_fwd_vec_kernel(const void* x, cons
 template <bool BF>
 __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const void* x, const void* res, const float* gamma,
                                                          const float* beta, float eps, int64_t rows, int cols,
-                                                         void* y, float* mean, float* rstd) {
+                                                         void* y, float* mean, float* rstd, Drop drop) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -132,11 +187,11 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const void* x, const vo
 #pragma unroll
         for (int i = 0; i < CPL; ++i) {
             const int c = lane + 64 * i;
-            v[i] = c < cols ? ld<BF>(x, base + c) + (res ? ld<BF>(res, base + c) : 0.f) : 0.f;
+            v[i] = c < cols ? ld<BF>(x, base + c) * drop_mult(drop, (unsigned)row, (unsigned)c) + (res ? ld<BF>(res, base + c) : 0.f) : 0.f;
             s += v[i];
         }
     } else {
-        for (int c = lane; c < cols; c += 64) s += ld<BF>(x, base + c) + (res ? ld<BF>(res, base + c) : 0.f);
+        for (int c = lane; c < cols; c += 64) s += ld<BF>(x, base + c) * drop_mult(drop, (unsigned)row, (unsigned)c) + (res ? ld<BF>(res, base + c) : 0.f);
     }
     const float mu = wave_sum(s) / (float)cols;
     float q = 0.f;
@@ -144,7 +199,7 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const void* x, const vo
 #pragma unroll
         for (int i = 0; i < CPL; ++i) { const int c = lane + 64 * i; const float d = c < cols ? v[i] - mu : 0.f; q += d * d; }
     } else {
-        for (int c = lane; c < cols; c += 64) { const float d = ld<BF>(x, base + c) + (res ? ld<BF>(res, base + c) : 0.f) - mu; q += d * d; }
+        for (int c = lane; c < cols; c += 64) { const float d = ld<BF>(x, base + c) * drop_mult(drop, (unsigned)row, (unsigned)c) + (res ? ld<BF>(res, base + c) : 0.f) - mu; q += d * d; }
     }
     const float rs = rsqrtf(wave_sum(q) / (float)cols + eps);
     if (cached) {
@@ -155,7 +210,7 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const void* x, const vo
         }
     } else {
         for (int c = lane; c < cols; c += 64) {
-            const float z = ld<BF>(x, base + c) + (res ? ld<BF>(res, base + c) : 0.f);
+            const float z = ld<BF>(x, base + c) * drop_mult(drop, (unsigned)row, (unsigned)c) + (res ? ld<BF>(res, base + c) : 0.f);
             st<BF>(y, base + c, (z - mu) * rs * gamma[c] + beta[c]);
         }
     }
@@ -167,7 +222,7 @@ constexpr int BWD_ROWS_PER_WAVE = 8;
 template <bool BF>
 __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const void* dy, const void* x, const void* res,
                                                          const float* gamma, const float* mean, const float* rstd,
-                                                         int64_t rows, int cols, void* dz, float* ws, int nblk) {
+                                                         int64_t rows, int cols, void* dz, void* dx, float* ws, int nblk, Drop drop) {
     extern __shared__ float sm[];  // [4 waves][2][cols]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float* pg = sm + (wave * 2) * cols;
@@ -181,15 +236,19 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const void* dy, const v
         const float mu = mean[row], rs = rstd[row];
         float s1 = 0.f, s2 = 0.f;
         for (int c = lane; c < cols; c += 64) {
-            const float z = ld<BF>(x, base + c) + (res ? ld<BF>(res, base + c) : 0.f);
+            const float km = drop_mult(drop, (unsigned)row, (unsigned)c);
+            const float z = ld<BF>(x, base + c) * km + (res ? ld<BF>(res, base + c) : 0.f);
             const float xh = (z - mu) * rs, g = ld<BF>(dy, base + c) * gamma[c];
             s1 += g; s2 += g * xh;
         }
         s1 = wave_sum(s1) / (float)cols; s2 = wave_sum(s2) / (float)cols;
         for (int c = lane; c < cols; c += 64) {
-            const float z = ld<BF>(x, base + c) + (res ? ld<BF>(res, base + c) : 0.f);
+            const float km = drop_mult(drop, (unsigned)row, (unsigned)c);
+            const float z = ld<BF>(x, base + c) * km + (res ? ld<BF>(res, base + c) : 0.f);
             const float xh = (z - mu) * rs, d = ld<BF>(dy, base + c);
-            st<BF>(dz, base + c, rs * (d * gamma[c] - s1 - xh * s2));
+            const float gz = rs * (d * gamma[c] - s1 - xh * s2);
+            st<BF>(dz, base + c, gz);
+            if (dx) st<BF>(dx, base + c, gz * km);   // gradient of x through its dropout
             pg[c] += d * xh; pb[c] += d;
         }
     }
@@ -219,13 +278,14 @@ template <bool BF>
 __global__ __launch_bounds__(64) void attention_fwd_kernel(const void* __restrict__ q, const void* __restrict__ k,
                                                            const void* __restrict__ v, const float* __restrict__ mask,
                                                            int mask_mode, int causal, int B, int H, int Lq, int Lk,
-                                                           float scale, void* __restrict__ out, float* __restrict__ lse) {
+                                                           float scale, void* __restrict__ out, float* __restrict__ lse, DropArgs da) {
     const int qblocks = (Lq + 63) / 64;
     const int bid = blockIdx.x;
     const int qb = bid % qblocks, h = (bid / qblocks) % H, b = bid / (qblocks * H);
     const int i = qb * 64 + threadIdx.x;
     const bool live = i < Lq;
     const int ii = live ? i : Lq - 1;
+    const unsigned dbase = da.thr ? drop_base(da.seed_lo, da.seed_hi, (unsigned)(b * H + h)) : 0u;
     float qr[DH], o[DH];
     const int64_t qoff = (((int64_t)b * Lq + ii) * H + h) * DH;
 #pragma unroll
@@ -261,8 +321,9 @@ __global__ __launch_bounds__(64) void attention_fwd_kernel(const void* __restric
             const int jj = j < Lk ? j : Lk - 1;
             // rows hidden by the causal / length bound contribute exactly 0 (additive masks with a
             // finite large negative value behave like the reference: exp underflows to 0)
-            const float pj = (j < Lk && j <= jmax_row) ? __expf(s[c] - mn) : 0.f;
+            float pj = (j < Lk && j <= jmax_row) ? __expf(s[c] - mn) : 0.f;
             l += pj;
+            if (da.thr) pj = drop_keep(drop_bits(dbase, (unsigned)ii, (unsigned)j >> 1), (unsigned)j, da.thr) ? pj : 0.f;
             const int64_t voff = (((int64_t)b * Lk + jj) * H + h) * DH;
 #pragma unroll
             for (int d = 0; d < DH; ++d) o[d] = __builtin_fmaf(pj, ld<BF>(v, voff + d), o[d]);
@@ -271,7 +332,7 @@ __global__ __launch_bounds__(64) void attention_fwd_kernel(const void* __restric
     }
     if (live && lse) lse[((int64_t)b * H + h) * Lq + i] = m + __logf(l);
     if (live) {
-        const float inv = 1.0f / l;
+        const float inv = (da.thr ? da.inv_keep : 1.0f) / l;
         const int64_t ooff = ((int64_t)b * Lq + i) * H * DH + (int64_t)h * DH;
 #pragma unroll
         for (int d = 0; d < DH; ++d) st<BF>(out, ooff + d, o[d] * inv);
@@ -300,9 +361,11 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 // mask is already inside the scores (the accumulators start from mask / scale); scores move to
 // base 2 here (scale * log2 e in one multiply).  VIS: the tile has keys that are out of range or
 // hidden by causality for some lane of the wave (wave-uniform).
-template <bool VIS>
+// DROP: after the row sum took the probabilities, the dropped ones are zeroed for the P V product
+// (xd = hash input of this lane's row at the tile's first key pair, see drop_bits).
+template <bool VIS, bool DROP>
 __device__ __forceinline__ void attn_softmax_tile(f32x16& s0, f32x16& s1, f32x16& o0, f32x16& o1, float& m, float& lsum,
-                                                  float sl2, int key0, int hh, int klim) {
+                                                  float sl2, int key0, int hh, int klim, unsigned xd, unsigned thr) {
     float mb = -__builtin_inff();
 #pragma unroll
     for (int hb = 0; hb < 2; ++hb)
@@ -327,13 +390,23 @@ __device__ __forceinline__ void attn_softmax_tile(f32x16& s0, f32x16& s1, f32x16
     m = mn;
 #pragma unroll
     for (int t = 0; t < 16; ++t) { o0[t] *= alpha; o1[t] *= alpha; }
+    if (DROP) {
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+            for (int t = 0; t < 16; t += 2) {   // registers t, t+1 = keys 2c, 2c+1: one hash
+                const unsigned bits = lowbias32(xd + (unsigned)(hb * 16 + ((t & 3) >> 1) + 4 * (t >> 2)) * DROP_C2);
+                if (hb) { s1[t] = drop_keep(bits, 0, thr) ? s1[t] : 0.f; s1[t + 1] = drop_keep(bits, 1, thr) ? s1[t + 1] : 0.f; }
+                else { s0[t] = drop_keep(bits, 0, thr) ? s0[t] : 0.f; s0[t + 1] = drop_keep(bits, 1, thr) ? s0[t + 1] : 0.f; }
+            }
+    }
 }
 
-template <int MM>   // mask mode: one kernel per mode keeps each one's register footprint to what it needs
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attention_fwd_mfma_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+template <int MM, bool DROP>   // mask mode, dropout: one kernel per case keeps each one's register footprint to what it needs
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DROP || MM == TRX_NN_MASK_FULL) ? 2 : 3, (DROP || MM == TRX_NN_MASK_FULL) ? 2 : 3))) void attention_fwd_mfma_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                                  const bf16_t* __restrict__ v, const float* __restrict__ mask,
                                                                  int causal, int B, int H, int Lq, int Lk,
-                                                                 float scale, bf16_t* __restrict__ out, float* __restrict__ lse) {
+                                                                 float scale, bf16_t* __restrict__ out, float* __restrict__ lse, DropArgs da) {
     // key tiles of 64 in a ring of 3 (prefetch distance 2), filled by LDS-DMA: [buf][K 8 KiB | V 8 KiB];
     // then the key mask of 1024 keys (16 tiles), pre-divided by the scale.  52 KiB: 3 workgroups / CU
     // (its own array: the compiler then knows mask reads cannot alias the LDS-DMA writes and does not
@@ -430,6 +503,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     for (int s = 0; s < 4; ++s) kfa[s] = ldsbase + (unsigned)(r * 128 + (((2 * s + hh) ^ kswz) << 4));
     constexpr bool keymask = MM == TRX_NN_MASK_KEY;
     const float* mkey = keymask ? mask + (int64_t)b * Lk : nullptr;
+    // dropout hash input of (this lane's query, key pair 0): + 2 hh because register t's key is ... + 4 hh
+    const unsigned xdrop = DROP ? drop_base(da.seed_lo, da.seed_hi, (unsigned)(b * H + h)) + (unsigned)qidx * DROP_C1 + (unsigned)(2 * hh) * DROP_C2 : 0u;
 
     // the key mask of tiles 16j .. 16j+15 is (re)loaded when tile 16j starts: 4 keys per thread
 #define TRX_MASK_FILL(KB)                                                                                   \
@@ -529,8 +604,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
         TRX_VT_READ(0) TRX_VT_READ(1)
         const bool vis = key0 + 63 > klim_wave_min;   // wave-uniform: some key of the tile is hidden for some lane
-        if (vis) attn_softmax_tile<true>(s0, s1, o0, o1, m, lsum, sl2, key0, hh, klim);
-        else attn_softmax_tile<false>(s0, s1, o0, o1, m, lsum, sl2, key0, hh, klim);
+        const unsigned xd = xdrop + (unsigned)(kb * 32) * DROP_C2;
+        if (vis) attn_softmax_tile<true, DROP>(s0, s1, o0, o1, m, lsum, sl2, key0, hh, klim, xd, da.thr);
+        else attn_softmax_tile<false, DROP>(s0, s1, o0, o1, m, lsum, sl2, key0, hh, klim, xd, da.thr);
         // ---- O^T += V^T P^T: second half's reads fly under the first half's MFMAs ----
         TRX_VT_READ(2) TRX_VT_READ(3)
         TRX_VT_WAIT(0, 1, 8)
@@ -548,7 +624,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #undef TRX_MASK_INIT
     const float ltot = lsum + __shfl_xor(lsum, 32, 64);
     if (qidx < Lq) {
-        const float inv = 1.0f / ltot;
+        const float inv = (DROP ? da.inv_keep : 1.0f) / ltot;
         // natural-log LSE of the scaled, masked scores (what the backward pass recomputes against)
         if (lse && hh == 0) lse[((int64_t)b * H + h) * Lq + qidx] = (m + __builtin_amdgcn_logf(ltot)) * 0.69314718055994530942f;
         bf16_t* op = out + ((int64_t)b * Lq + qidx) * H * 64 + (int64_t)h * 64;
@@ -575,13 +651,14 @@ __global__ __launch_bounds__(64) void attention_bwd_dq_kernel(const void* __rest
                                                               const void* __restrict__ v, const float* __restrict__ mask,
                                                               int mask_mode, int causal, int B, int H, int Lq, int Lk,
                                                               float scale, const void* __restrict__ o, const void* __restrict__ dout,
-                                                              const float* __restrict__ lse, void* __restrict__ dq) {
+                                                              const float* __restrict__ lse, void* __restrict__ dq, DropArgs da) {
     const int qblocks = (Lq + 63) / 64;
     const int bid = blockIdx.x;
     const int qb = bid % qblocks, h = (bid / qblocks) % H, b = bid / (qblocks * H);
     const int i = qb * 64 + threadIdx.x;
     const bool live = i < Lq;
     const int ii = live ? i : Lq - 1;
+    const unsigned dbase = da.thr ? drop_base(da.seed_lo, da.seed_hi, (unsigned)(b * H + h)) : 0u;
     float qr[DH], dor[DH], acc[DH];
     const int64_t qoff = (((int64_t)b * Lq + ii) * H + h) * DH;
     const int64_t ooff = ((int64_t)b * Lq + ii) * H * DH + (int64_t)h * DH;
@@ -602,6 +679,7 @@ __global__ __launch_bounds__(64) void attention_bwd_dq_kernel(const void* __rest
         if (mask_mode == TRX_NN_MASK_KEY) s += mask[(int64_t)b * Lk + j];
         else if (mask_mode == TRX_NN_MASK_FULL) s += mask[((int64_t)b * Lq + ii) * Lk + j];
         const float p = j <= jmax_row ? __expf(s - L) : 0.f;
+        if (da.thr) dp = drop_keep(drop_bits(dbase, (unsigned)ii, (unsigned)j >> 1), (unsigned)j, da.thr) ? dp * da.inv_keep : 0.f;
         const float ds = p * (dp - delta);
 #pragma unroll
         for (int d = 0; d < DH; ++d) acc[d] = __builtin_fmaf(ds, ld<BF>(k, koff + d), acc[d]);
@@ -617,10 +695,11 @@ __global__ __launch_bounds__(64) void attention_bwd_dkv_kernel(const void* __res
                                                                const void* __restrict__ v, const float* __restrict__ mask,
                                                                int mask_mode, int causal, int B, int H, int Lq, int Lk,
                                                                float scale, const void* __restrict__ o, const void* __restrict__ dout,
-                                                               const float* __restrict__ lse, void* __restrict__ dk, void* __restrict__ dv) {
+                                                               const float* __restrict__ lse, void* __restrict__ dk, void* __restrict__ dv, DropArgs da) {
     const int kblocks = (Lk + 63) / 64;
     const int bid = blockIdx.x;
     const int kb = bid % kblocks, h = (bid / kblocks) % H, b = bid / (kblocks * H);
+    const unsigned dbase = da.thr ? drop_base(da.seed_lo, da.seed_hi, (unsigned)(b * H + h)) : 0u;
     const int j = kb * 64 + threadIdx.x;
     const bool live = j < Lk;
     const int jj = live ? j : Lk - 1;
@@ -646,10 +725,15 @@ __global__ __launch_bounds__(64) void attention_bwd_dkv_kernel(const void* __res
         const float L = lse[((int64_t)b * H + h) * Lq + i];
         const bool vis = !causal || jj <= i + (Lk - Lq);
         const float p = vis ? __expf(s - L) : 0.f;
+        float pd = p;   // the probability as the forward used it for the output: dropped and rescaled
+        if (da.thr) {
+            const float km = drop_keep(drop_bits(dbase, (unsigned)i, (unsigned)jj >> 1), (unsigned)jj, da.thr) ? da.inv_keep : 0.f;
+            pd = p * km; dp *= km;
+        }
         const float ds = p * (dp - delta);
 #pragma unroll
         for (int d = 0; d < DH; ++d) {
-            av[d] = __builtin_fmaf(p, ld<BF>(dout, ooff + d), av[d]);
+            av[d] = __builtin_fmaf(pd, ld<BF>(dout, ooff + d), av[d]);
             ak[d] = __builtin_fmaf(ds, ld<BF>(q, qoff + d), ak[d]);
         }
     }
@@ -667,23 +751,56 @@ const char* trx_nn_last_error(void) { return g_err.c_str(); }
 const char* trx_nn_version(void) { return "trxnn 0.1 (gfx950)"; }
 int trx_add_layernorm_bwd_blocks(int64_t rows) { return (int)((rows + 4 * BWD_ROWS_PER_WAVE - 1) / (4 * BWD_ROWS_PER_WAVE)); }
 
-int trx_add_layernorm_fwd(const void* x, const void* res, const float* gamma, const float* beta, float eps,
-                          int64_t rows, int cols, int dtype, void* y, float* mean, float* rstd, void* stream) {
+int trx_add_layernorm_fwd_dropout(const void* x, const void* res, const float* gamma, const float* beta, float eps,
+                                  int64_t rows, int cols, int dtype, float p, uint64_t seed, void* y, float* mean,
+                                  float* rstd, void* stream) {
     if (!x || !gamma || !beta || !y || rows < 0 || cols <= 0) return fail(TRX_NN_EINVAL, "add_layernorm_fwd: bad argument");
     if (dtype != TRX_NN_F32 && dtype != TRX_NN_BF16) return fail(TRX_NN_EINVAL, "unknown dtype");
+    if (!(p >= 0.f && p < 1.f)) return fail(TRX_NN_EINVAL, "dropout probability must be in [0, 1)");
     if (rows == 0) return TRX_NN_OK;
+    const Drop drop = make_drop(p, seed, 0);
     dim3 grid((unsigned)((rows + 3) / 4)), block(256);
     hipStream_t st = (hipStream_t)stream;
     const int V = dtype == TRX_NN_BF16 ? 8 : 4;
     const bool aligned = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(res)) & 15) == 0;
     const bool vec = aligned && cols % V == 0 && cols <= 64 * NCH * V;
     if (vec) {
-        if (dtype == TRX_NN_BF16) hipLaunchKernelGGL(add_ln_fwd_vec_kernel<true>, grid, block, 0, st, x, res, gamma, beta, eps, rows, cols, y, mean, rstd);
-        else hipLaunchKernelGGL(add_ln_fwd_vec_kernel<false>, grid, block, 0, st, x, res, gamma, beta, eps, rows, cols, y, mean, rstd);
+        if (dtype == TRX_NN_BF16) hipLaunchKernelGGL(add_ln_fwd_vec_kernel<true>, grid, block, 0, st, x, res, gamma, beta, eps, rows, cols, y, mean, rstd, drop);
+        else hipLaunchKernelGGL(add_ln_fwd_vec_kernel<false>, grid, block, 0, st, x, res, gamma, beta, eps, rows, cols, y, mean, rstd, drop);
     } else {
-        if (dtype == TRX_NN_BF16) hipLaunchKernelGGL(add_ln_fwd_kernel<true>, grid, block, 0, st, x, res, gamma, beta, eps, rows, cols, y, mean, rstd);
-        else hipLaunchKernelGGL(add_ln_fwd_kernel<false>, grid, block, 0, st, x, res, gamma, beta, eps, rows, cols, y, mean, rstd);
+        if (dtype == TRX_NN_BF16) hipLaunchKernelGGL(add_ln_fwd_kernel<true>, grid, block, 0, st, x, res, gamma, beta, eps, rows, cols, y, mean, rstd, drop);
+        else hipLaunchKernelGGL(add_ln_fwd_kernel<false>, grid, block, 0, st, x, res, gamma, beta, eps, rows, cols, y, mean, rstd, drop);
     }
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? TRX_NN_OK : fail(TRX_NN_EHIP, hipGetErrorString(e));
+}
+
+int trx_add_layernorm_fwd(const void* x, const void* res, const float* gamma, const float* beta, float eps,
+                          int64_t rows, int cols, int dtype, void* y, float* mean, float* rstd, void* stream) {
+    return trx_add_layernorm_fwd_dropout(x, res, gamma, beta, eps, rows, cols, dtype, 0.f, 0, y, mean, rstd, stream);
+}
+
+int trx_add_layernorm_bwd_dropout(const void* dy, const void* x, const void* res, const float* gamma, const float* mean,
+                                  const float* rstd, int64_t rows, int cols, int dtype, float p, uint64_t seed, void* dz,
+                                  void* dx, float* dgamma, float* dbeta, float* ws, void* stream) {
+    if (!dy || !x || !gamma || !mean || !rstd || !dz || !dgamma || !dbeta || !ws || rows <= 0 || cols <= 0)
+        return fail(TRX_NN_EINVAL, "add_layernorm_bwd: bad argument");
+    if (dtype != TRX_NN_F32 && dtype != TRX_NN_BF16) return fail(TRX_NN_EINVAL, "unknown dtype");
+    if (!(p >= 0.f && p < 1.f)) return fail(TRX_NN_EINVAL, "dropout probability must be in [0, 1)");
+    if (p > 0.f && !dx) return fail(TRX_NN_EINVAL, "add_layernorm_bwd: dropout needs the separate dx output");
+    const Drop drop = make_drop(p, seed, 0);
+    if ((size_t)cols * 8 * sizeof(float) > 160 * 1024) return fail(TRX_NN_EINVAL, "cols too large for the LDS partials");
+    const int nblk = trx_add_layernorm_bwd_blocks(rows);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = (size_t)cols * 8 * sizeof(float);
+    if (dtype == TRX_NN_BF16) {
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)add_ln_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(add_ln_bwd_kernel<true>, dim3(nblk), dim3(256), lds, st, dy, x, res, gamma, mean, rstd, rows, cols, dz, p > 0.f ? dx : nullptr, ws, nblk, drop);
+    } else {
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)add_ln_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(add_ln_bwd_kernel<false>, dim3(nblk), dim3(256), lds, st, dy, x, res, gamma, mean, rstd, rows, cols, dz, p > 0.f ? dx : nullptr, ws, nblk, drop);
+    }
+    hipLaunchKernelGGL(add_ln_bwd_reduce_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, ws, nblk, cols, dgamma, dbeta);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? TRX_NN_OK : fail(TRX_NN_EHIP, hipGetErrorString(e));
 }
@@ -691,63 +808,83 @@ int trx_add_layernorm_fwd(const void* x, const void* res, const float* gamma, co
 int trx_add_layernorm_bwd(const void* dy, const void* x, const void* res, const float* gamma, const float* mean,
                           const float* rstd, int64_t rows, int cols, int dtype, void* dz, float* dgamma,
                           float* dbeta, float* ws, void* stream) {
-    if (!dy || !x || !gamma || !mean || !rstd || !dz || !dgamma || !dbeta || !ws || rows <= 0 || cols <= 0)
-        return fail(TRX_NN_EINVAL, "add_layernorm_bwd: bad argument");
-    if (dtype != TRX_NN_F32 && dtype != TRX_NN_BF16) return fail(TRX_NN_EINVAL, "unknown dtype");
-    if ((size_t)cols * 8 * sizeof(float) > 160 * 1024) return fail(TRX_NN_EINVAL, "cols too large for the LDS partials");
-    const int nblk = trx_add_layernorm_bwd_blocks(rows);
-    hipStream_t st = (hipStream_t)stream;
-    const size_t lds = (size_t)cols * 8 * sizeof(float);
-    if (dtype == TRX_NN_BF16) {
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)add_ln_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(add_ln_bwd_kernel<true>, dim3(nblk), dim3(256), lds, st, dy, x, res, gamma, mean, rstd, rows, cols, dz, ws, nblk);
-    } else {
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)add_ln_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(add_ln_bwd_kernel<false>, dim3(nblk), dim3(256), lds, st, dy, x, res, gamma, mean, rstd, rows, cols, dz, ws, nblk);
-    }
-    hipLaunchKernelGGL(add_ln_bwd_reduce_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, ws, nblk, cols, dgamma, dbeta);
+    return trx_add_layernorm_bwd_dropout(dy, x, res, gamma, mean, rstd, rows, cols, dtype, 0.f, 0, dz, nullptr, dgamma, dbeta, ws, stream);
+}
+
+int trx_dropout_keep_mask(uint64_t seed, float p, int64_t streams, int64_t rows, int64_t cols, unsigned char* keep, void* stream) {
+    if (!keep || streams <= 0 || rows <= 0 || cols <= 0 || !(p >= 0.f && p < 1.f)) return fail(TRX_NN_EINVAL, "dropout_keep_mask: bad argument");
+    const int64_t n = streams * rows * cols;
+    const unsigned grid = (unsigned)((n + 255) / 256 > 65536 ? 65536 : (n + 255) / 256);
+    hipLaunchKernelGGL(dropout_keep_mask_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (unsigned)seed, (unsigned)(seed >> 32),
+                       p > 0.f ? drop_thr(p) : 0u, streams, rows, cols, keep);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? TRX_NN_OK : fail(TRX_NN_EHIP, hipGetErrorString(e));
 }
 
-int trx_attention_fwd_lse(const void* q, const void* k, const void* v, const float* mask, int mask_mode, int causal,
-                          int B, int H, int Lq, int Lk, float scale, int dtype, void* out, float* lse, void* stream) {
+static DropArgs make_drop_args(float p, uint64_t seed) {
+    DropArgs a;
+    a.seed_lo = (unsigned)seed; a.seed_hi = (unsigned)(seed >> 32);
+    a.thr = p > 0.f ? drop_thr(p) : 0u;
+    a.inv_keep = 1.0f / (1.0f - p);
+    return a;
+}
+
+int trx_attention_fwd_dropout(const void* q, const void* k, const void* v, const float* mask, int mask_mode, int causal,
+                              int B, int H, int Lq, int Lk, float scale, int dtype, float p, uint64_t seed, void* out,
+                              float* lse, void* stream) {
     if (!q || !k || !v || !out || B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return fail(TRX_NN_EINVAL, "attention_fwd: bad argument");
     if (mask_mode != TRX_NN_MASK_NONE && !mask) return fail(TRX_NN_EINVAL, "attention_fwd: mask is null");
     if (mask_mode < 0 || mask_mode > 2) return fail(TRX_NN_EINVAL, "attention_fwd: unknown mask mode");
     if (dtype != TRX_NN_F32 && dtype != TRX_NN_BF16) return fail(TRX_NN_EINVAL, "unknown dtype");
+    if (!(p >= 0.f && p < 1.f)) return fail(TRX_NN_EINVAL, "dropout probability must be in [0, 1)");
+    if (!(scale > 0.f)) return fail(TRX_NN_EINVAL, "attention_fwd: scale must be positive");
+    const DropArgs da = make_drop_args(p, seed);
     const int qblocks = (Lq + 63) / 64;
     dim3 grid((unsigned)((int64_t)B * H * qblocks)), block(64);
     hipStream_t st = (hipStream_t)stream;
     static const bool force_valu = getenv("TRX_NN_ATTN_VALU") != nullptr;
     if (dtype == TRX_NN_BF16 && !force_valu) {
         dim3 g2((unsigned)((int64_t)B * H * ((Lq + 127) / 128))), b2(256);
-#define TRX_LAUNCH_MFMA(MM_)                                                                                              \
-    hipLaunchKernelGGL(attention_fwd_mfma_kernel<MM_>, g2, b2, 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, \
-                       mask, causal, B, H, Lq, Lk, scale, (bf16_t*)out, lse)
-        if (mask_mode == TRX_NN_MASK_NONE) TRX_LAUNCH_MFMA(TRX_NN_MASK_NONE);
-        else if (mask_mode == TRX_NN_MASK_KEY) TRX_LAUNCH_MFMA(TRX_NN_MASK_KEY);
-        else TRX_LAUNCH_MFMA(TRX_NN_MASK_FULL);
+#define TRX_LAUNCH_MFMA(MM_, DROP_)                                                                                       \
+    hipLaunchKernelGGL((attention_fwd_mfma_kernel<MM_, DROP_>), g2, b2, 0, st, (const bf16_t*)q, (const bf16_t*)k,        \
+                       (const bf16_t*)v, mask, causal, B, H, Lq, Lk, scale, (bf16_t*)out, lse, da)
+        if (da.thr) {
+            if (mask_mode == TRX_NN_MASK_NONE) TRX_LAUNCH_MFMA(TRX_NN_MASK_NONE, true);
+            else if (mask_mode == TRX_NN_MASK_KEY) TRX_LAUNCH_MFMA(TRX_NN_MASK_KEY, true);
+            else TRX_LAUNCH_MFMA(TRX_NN_MASK_FULL, true);
+        } else {
+            if (mask_mode == TRX_NN_MASK_NONE) TRX_LAUNCH_MFMA(TRX_NN_MASK_NONE, false);
+            else if (mask_mode == TRX_NN_MASK_KEY) TRX_LAUNCH_MFMA(TRX_NN_MASK_KEY, false);
+            else TRX_LAUNCH_MFMA(TRX_NN_MASK_FULL, false);
+        }
 #undef TRX_LAUNCH_MFMA
-    } else if (dtype == TRX_NN_BF16) hipLaunchKernelGGL(attention_fwd_kernel<true>, grid, block, 0, st, q, k, v, mask, mask_mode, causal, B, H, Lq, Lk, scale, out, lse);
-    else hipLaunchKernelGGL(attention_fwd_kernel<false>, grid, block, 0, st, q, k, v, mask, mask_mode, causal, B, H, Lq, Lk, scale, out, lse);
+    } else if (dtype == TRX_NN_BF16) hipLaunchKernelGGL(attention_fwd_kernel<true>, grid, block, 0, st, q, k, v, mask, mask_mode, causal, B, H, Lq, Lk, scale, out, lse, da);
+    else hipLaunchKernelGGL(attention_fwd_kernel<false>, grid, block, 0, st, q, k, v, mask, mask_mode, causal, B, H, Lq, Lk, scale, out, lse, da);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? TRX_NN_OK : fail(TRX_NN_EHIP, hipGetErrorString(e));
 }
 
-int trx_attention_fwd(const void* q, const void* k, const void* v, const float* mask, int mask_mode, int causal,
-                      int B, int H, int Lq, int Lk, float scale, int dtype, void* out, void* stream) {
-    return trx_attention_fwd_lse(q, k, v, mask, mask_mode, causal, B, H, Lq, Lk, scale, dtype, out, nullptr, stream);
+int trx_attention_fwd_lse(const void* q, const void* k, const void* v, const float* mask, int mask_mode, int causal,
+                          int B, int H, int Lq, int Lk, float scale, int dtype, void* out, float* lse, void* stream) {
+    return trx_attention_fwd_dropout(q, k, v, mask, mask_mode, causal, B, H, Lq, Lk, scale, dtype, 0.f, 0, out, lse, stream);
 }
 
-int trx_attention_bwd(const void* q, const void* k, const void* v, const float* mask, int mask_mode, int causal,
-                      int B, int H, int Lq, int Lk, float scale, int dtype, const void* out, const void* dout,
-                      const float* lse, void* dq, void* dk, void* dv, void* stream) {
+int trx_attention_fwd(const void* q, const void* k, const void* v, const float* mask, int mask_mode, int causal,
+                      int B, int H, int Lq, int Lk, float scale, int dtype, void* out, void* stream) {
+    return trx_attention_fwd_dropout(q, k, v, mask, mask_mode, causal, B, H, Lq, Lk, scale, dtype, 0.f, 0, out, nullptr, stream);
+}
+
+int trx_attention_bwd_dropout(const void* q, const void* k, const void* v, const float* mask, int mask_mode, int causal,
+                              int B, int H, int Lq, int Lk, float scale, int dtype, float p, uint64_t seed, const void* out,
+                              const void* dout, const float* lse, void* dq, void* dk, void* dv, void* stream) {
     if (!q || !k || !v || !out || !dout || !lse || !dq || !dk || !dv || B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0)
         return fail(TRX_NN_EINVAL, "attention_bwd: bad argument");
     if (mask_mode != TRX_NN_MASK_NONE && !mask) return fail(TRX_NN_EINVAL, "attention_bwd: mask is null");
     if (mask_mode < 0 || mask_mode > 2) return fail(TRX_NN_EINVAL, "attention_bwd: unknown mask mode");
     if (dtype != TRX_NN_F32 && dtype != TRX_NN_BF16) return fail(TRX_NN_EINVAL, "unknown dtype");
+    if (!(p >= 0.f && p < 1.f)) return fail(TRX_NN_EINVAL, "dropout probability must be in [0, 1)");
+    if (!(scale > 0.f)) return fail(TRX_NN_EINVAL, "attention_bwd: scale must be positive");
+    const DropArgs da = make_drop_args(p, seed);
     hipStream_t st = (hipStream_t)stream;
     dim3 gq((unsigned)((int64_t)B * H * ((Lq + 63) / 64))), gk((unsigned)((int64_t)B * H * ((Lk + 63) / 64))), block(64);
     static const bool force_valu = getenv("TRX_NN_ATTN_VALU") != nullptr;
@@ -763,14 +900,20 @@ int trx_attention_bwd(const void* q, const void* k, const void* v, const float* 
         hipLaunchKernelGGL(attention_bwd_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const bf16_t*)out,
                            (const bf16_t*)dout, lse, B, H, Lq, scale, negl, negd);
         dim3 g1((unsigned)((int64_t)B * H * ((Lq + 127) / 128))), g2((unsigned)((int64_t)B * H * ((Lk + 127) / 128))), b2(256);
-#define TRX_LAUNCH_BWD(MM_)                                                                                                 \
-    hipLaunchKernelGGL(attention_bwd_dq_mfma_kernel<MM_>, g1, b2, 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, \
-                       mask, causal, B, H, Lq, Lk, scale, (const bf16_t*)dout, negl, negd, (bf16_t*)dq);                    \
-    hipLaunchKernelGGL(attention_bwd_dkv_mfma_kernel<MM_>, g2, b2, 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, \
-                       mask, causal, B, H, Lq, Lk, scale, (const bf16_t*)dout, negl, negd, (bf16_t*)dk, (bf16_t*)dv)
-        if (mask_mode == TRX_NN_MASK_NONE) { TRX_LAUNCH_BWD(TRX_NN_MASK_NONE); }
-        else if (mask_mode == TRX_NN_MASK_KEY) { TRX_LAUNCH_BWD(TRX_NN_MASK_KEY); }
-        else { TRX_LAUNCH_BWD(TRX_NN_MASK_FULL); }
+#define TRX_LAUNCH_BWD(MM_, DROP_)                                                                                          \
+    hipLaunchKernelGGL((attention_bwd_dq_mfma_kernel<MM_, DROP_>), g1, b2, 0, st, (const bf16_t*)q, (const bf16_t*)k,       \
+                       (const bf16_t*)v, mask, causal, B, H, Lq, Lk, scale, (const bf16_t*)dout, negl, negd, (bf16_t*)dq, da); \
+    hipLaunchKernelGGL((attention_bwd_dkv_mfma_kernel<MM_, DROP_>), g2, b2, 0, st, (const bf16_t*)q, (const bf16_t*)k,      \
+                       (const bf16_t*)v, mask, causal, B, H, Lq, Lk, scale, (const bf16_t*)dout, negl, negd, (bf16_t*)dk, (bf16_t*)dv, da)
+        if (da.thr) {
+            if (mask_mode == TRX_NN_MASK_NONE) { TRX_LAUNCH_BWD(TRX_NN_MASK_NONE, true); }
+            else if (mask_mode == TRX_NN_MASK_KEY) { TRX_LAUNCH_BWD(TRX_NN_MASK_KEY, true); }
+            else { TRX_LAUNCH_BWD(TRX_NN_MASK_FULL, true); }
+        } else {
+            if (mask_mode == TRX_NN_MASK_NONE) { TRX_LAUNCH_BWD(TRX_NN_MASK_NONE, false); }
+            else if (mask_mode == TRX_NN_MASK_KEY) { TRX_LAUNCH_BWD(TRX_NN_MASK_KEY, false); }
+            else { TRX_LAUNCH_BWD(TRX_NN_MASK_FULL, false); }
+        }
 #undef TRX_LAUNCH_BWD
         hipError_t e1 = hipGetLastError();
         (void)hipFreeAsync(ws, st);
@@ -778,14 +921,20 @@ int trx_attention_bwd(const void* q, const void* k, const void* v, const float* 
         return TRX_NN_OK;
     }
     if (dtype == TRX_NN_BF16) {
-        hipLaunchKernelGGL(attention_bwd_dq_kernel<true>, gq, block, 0, st, q, k, v, mask, mask_mode, causal, B, H, Lq, Lk, scale, out, dout, lse, dq);
-        hipLaunchKernelGGL(attention_bwd_dkv_kernel<true>, gk, block, 0, st, q, k, v, mask, mask_mode, causal, B, H, Lq, Lk, scale, out, dout, lse, dk, dv);
+        hipLaunchKernelGGL(attention_bwd_dq_kernel<true>, gq, block, 0, st, q, k, v, mask, mask_mode, causal, B, H, Lq, Lk, scale, out, dout, lse, dq, da);
+        hipLaunchKernelGGL(attention_bwd_dkv_kernel<true>, gk, block, 0, st, q, k, v, mask, mask_mode, causal, B, H, Lq, Lk, scale, out, dout, lse, dk, dv, da);
     } else {
-        hipLaunchKernelGGL(attention_bwd_dq_kernel<false>, gq, block, 0, st, q, k, v, mask, mask_mode, causal, B, H, Lq, Lk, scale, out, dout, lse, dq);
-        hipLaunchKernelGGL(attention_bwd_dkv_kernel<false>, gk, block, 0, st, q, k, v, mask, mask_mode, causal, B, H, Lq, Lk, scale, out, dout, lse, dk, dv);
+        hipLaunchKernelGGL(attention_bwd_dq_kernel<false>, gq, block, 0, st, q, k, v, mask, mask_mode, causal, B, H, Lq, Lk, scale, out, dout, lse, dq, da);
+        hipLaunchKernelGGL(attention_bwd_dkv_kernel<false>, gk, block, 0, st, q, k, v, mask, mask_mode, causal, B, H, Lq, Lk, scale, out, dout, lse, dk, dv, da);
     }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? TRX_NN_OK : fail(TRX_NN_EHIP, hipGetErrorString(e));
+}
+
+int trx_attention_bwd(const void* q, const void* k, const void* v, const float* mask, int mask_mode, int causal,
+                      int B, int H, int Lq, int Lk, float scale, int dtype, const void* out, const void* dout,
+                      const float* lse, void* dq, void* dk, void* dv, void* stream) {
+    return trx_attention_bwd_dropout(q, k, v, mask, mask_mode, causal, B, H, Lq, Lk, scale, dtype, 0.f, 0, out, dout, lse, dq, dk, dv, stream);
 }
 
 }  // extern "C"

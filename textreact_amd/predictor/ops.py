@@ -18,7 +18,9 @@ _lib = None
 F32, BF16 = 0, 1
 MASK_NONE, MASK_KEY, MASK_FULL = 0, 1, 2
 SYMBOLS = ["trx_add_layernorm_fwd", "trx_add_layernorm_bwd", "trx_add_layernorm_bwd_blocks",
-           "trx_attention_fwd", "trx_attention_fwd_lse", "trx_attention_bwd", "trx_nn_last_error", "trx_nn_version"]
+           "trx_attention_fwd", "trx_attention_fwd_lse", "trx_attention_bwd",
+           "trx_add_layernorm_fwd_dropout", "trx_add_layernorm_bwd_dropout", "trx_attention_fwd_dropout",
+           "trx_attention_bwd_dropout", "trx_dropout_keep_mask", "trx_nn_last_error", "trx_nn_version"]
 
 
 class TrxNNError(RuntimeError):
@@ -38,6 +40,13 @@ def lib():
         L.trx_attention_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, i32, vp, vp]
         L.trx_attention_fwd_lse.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, i32, vp, vp, vp]
         L.trx_attention_bwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp]
+        u64 = ctypes.c_uint64
+        L.trx_add_layernorm_fwd_dropout.argtypes = [vp, vp, vp, vp, f32, i64, i32, i32, f32, u64, vp, vp, vp, vp]
+        L.trx_add_layernorm_bwd_dropout.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, i32, f32, u64, vp, vp, vp, vp, vp, vp]
+        L.trx_attention_fwd_dropout.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, i32, f32, u64, vp, vp, vp]
+        L.trx_attention_bwd_dropout.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, i32, f32, u64,
+                                                vp, vp, vp, vp, vp, vp, vp]
+        L.trx_dropout_keep_mask.argtypes = [u64, f32, i64, i64, i64, vp, vp]
         L.trx_nn_last_error.restype = ctypes.c_char_p
         L.trx_nn_version.restype = ctypes.c_char_p
         _lib = L
@@ -70,9 +79,24 @@ def _stream(t):
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
+def new_seed():
+    """a fresh 63-bit dropout seed from torch's CPU generator (so torch.manual_seed makes runs repeatable)"""
+    return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+
+
+def dropout_keep_mask(seed, p, streams, rows, cols, device):
+    """bool [streams, rows, cols]: the decisions the kernels take for (seed, p) -- tests and the
+    'torch' reference backend use it so that both backends drop the same elements"""
+    keep = torch.empty((streams, rows, cols), dtype=torch.uint8, device=device)
+    if not keep.is_cuda:
+        raise TrxNNError("dropout decisions are computed on the GPU (there is no CPU implementation)")
+    _check(lib().trx_dropout_keep_mask(int(seed), float(p), streams, rows, cols, _p(keep), _stream(keep)))
+    return keep.bool()
+
+
 class _AddLayerNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, res, gamma, beta, eps):
+    def forward(ctx, x, res, gamma, beta, eps, p, seed):
         _need_gpu(x)
         xs = x.contiguous()
         rs = res.contiguous() if res is not None else None
@@ -83,41 +107,52 @@ class _AddLayerNorm(torch.autograd.Function):
         mean = torch.empty(rows, dtype=torch.float32, device=x.device) if need else None
         rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if need else None
         g, b = gamma.float().contiguous(), beta.float().contiguous()
-        _check(lib().trx_add_layernorm_fwd(_p(xs), _p(rs), _p(g), _p(b), float(eps), rows, cols, _dt(xs),
-                                           _p(y), _p(mean), _p(rstd), _stream(xs)))
+        _check(lib().trx_add_layernorm_fwd_dropout(_p(xs), _p(rs), _p(g), _p(b), float(eps), rows, cols, _dt(xs),
+                                                   float(p), int(seed), _p(y), _p(mean), _p(rstd), _stream(xs)))
         if need:
             ctx.save_for_backward(xs, rs if rs is not None else xs.new_empty(0), g, mean, rstd)
             ctx.has_res = rs is not None
+            ctx.drop = (float(p), int(seed))
         return y
 
     @staticmethod
     def backward(ctx, dy):
         xs, rs, g, mean, rstd = ctx.saved_tensors
         rs = rs if ctx.has_res else None
+        p, seed = ctx.drop
         dy = dy.contiguous()
         cols = xs.shape[-1]
         rows = xs.numel() // cols
         nblk = lib().trx_add_layernorm_bwd_blocks(rows)
         ws = torch.empty(2 * nblk * cols, dtype=torch.float32, device=xs.device)
         dz = torch.empty_like(xs)
+        dx = torch.empty_like(xs) if p > 0 else None
         dg = torch.empty(cols, dtype=torch.float32, device=xs.device)
         db = torch.empty(cols, dtype=torch.float32, device=xs.device)
-        _check(lib().trx_add_layernorm_bwd(_p(dy), _p(xs), _p(rs), _p(g), _p(mean), _p(rstd), rows, cols, _dt(xs),
-                                           _p(dz), _p(dg), _p(db), _p(ws), _stream(xs)))
-        return dz, (dz if ctx.has_res else None), dg, db, None
+        _check(lib().trx_add_layernorm_bwd_dropout(_p(dy), _p(xs), _p(rs), _p(g), _p(mean), _p(rstd), rows, cols, _dt(xs),
+                                                   p, seed, _p(dz), _p(dx), _p(dg), _p(db), _p(ws), _stream(xs)))
+        return (dx if p > 0 else dz), (dz if ctx.has_res else None), dg, db, None, None, None
 
 
-def add_layernorm(x, res, gamma, beta, eps, backend="hip"):
-    """LayerNorm(x + res) * gamma + beta over the last dimension; res may be None."""
+def add_layernorm(x, res, gamma, beta, eps, backend="hip", dropout_p=0.0, seed=None):
+    """LayerNorm(dropout(x) + res) * gamma + beta over the last dimension; res may be None.
+    dropout_p > 0 (training): x is dropped before the residual is added, as BertSelfOutput /
+    BertOutput / BertEmbeddings do; `seed` picks the decisions (default: a fresh one)."""
+    if dropout_p > 0 and seed is None:
+        seed = new_seed()
     if backend == "hip":
-        return _AddLayerNorm.apply(x, res, gamma, beta, eps)
+        return _AddLayerNorm.apply(x, res, gamma, beta, eps, float(dropout_p), 0 if seed is None else seed)
+    if dropout_p > 0:
+        cols = x.shape[-1]
+        keep = dropout_keep_mask(seed, dropout_p, 1, x.numel() // cols, cols, x.device).view(x.shape)
+        x = x * keep.to(x.dtype) / (1.0 - dropout_p)
     z = x if res is None else x + res
     return torch.nn.functional.layer_norm(z.float(), (z.shape[-1],), gamma.float(), beta.float(), eps).to(x.dtype)
 
 
 class _Attention(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, k, v, mask, causal, scale):
+    def forward(ctx, q, k, v, mask, causal, scale, p, seed):
         B, Lq, H, D = q.shape
         Lk = k.shape[1]
         q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
@@ -129,41 +164,43 @@ class _Attention(torch.autograd.Function):
         out = torch.empty((B, Lq, H * D), dtype=q.dtype, device=q.device)
         need = q.requires_grad or k.requires_grad or v.requires_grad
         lse = torch.empty((B, H, Lq), dtype=torch.float32, device=q.device) if need else None
-        _check(lib().trx_attention_fwd_lse(_p(q), _p(k), _p(v), _p(m), mode, 1 if causal else 0, B, H, Lq, Lk,
-                                           float(scale), _dt(q), _p(out), _p(lse), _stream(q)))
+        _check(lib().trx_attention_fwd_dropout(_p(q), _p(k), _p(v), _p(m), mode, 1 if causal else 0, B, H, Lq, Lk,
+                                               float(scale), _dt(q), float(p), int(seed), _p(out), _p(lse), _stream(q)))
         if need:
             ctx.save_for_backward(q, k, v, m if m is not None else q.new_empty(0), out, lse)
-            ctx.cfg = (mode, causal, scale)
+            ctx.cfg = (mode, causal, scale, float(p), int(seed))
         return out
 
     @staticmethod
     def backward(ctx, dout):
         q, k, v, m, out, lse = ctx.saved_tensors
-        mode, causal, scale = ctx.cfg
+        mode, causal, scale, p, seed = ctx.cfg
         B, Lq, H, D = q.shape
         Lk = k.shape[1]
         dout = dout.contiguous()
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-        _check(lib().trx_attention_bwd(_p(q), _p(k), _p(v), _p(m) if mode != MASK_NONE else None, mode,
-                                       1 if causal else 0, B, H, Lq, Lk, float(scale), _dt(q), _p(out), _p(dout),
-                                       _p(lse), _p(dq), _p(dk), _p(dv), _stream(q)))
-        return dq, dk, dv, None, None, None
+        _check(lib().trx_attention_bwd_dropout(_p(q), _p(k), _p(v), _p(m) if mode != MASK_NONE else None, mode,
+                                               1 if causal else 0, B, H, Lq, Lk, float(scale), _dt(q), p, seed,
+                                               _p(out), _p(dout), _p(lse), _p(dq), _p(dk), _p(dv), _stream(q)))
+        return dq, dk, dv, None, None, None, None, None
 
 
-def attention(q, k, v, mask=None, causal=False, scale=None, backend="hip"):
+def attention(q, k, v, mask=None, causal=False, scale=None, backend="hip", dropout_p=0.0, seed=None):
     """q [B, Lq, H, 64], k / v [B, Lk, H, 64] -> [B, Lq, H*64].
     mask: additive float, [B, Lk] (key padding) or [B, Lq, Lk]; causal: key j visible iff
-    j <= i + (Lk - Lq)."""
+    j <= i + (Lk - Lq).  dropout_p > 0 (training): dropout on the softmax probabilities
+    (BertSelfAttention.dropout); `seed` picks the decisions (default: a fresh one)."""
     B, Lq, H, D = q.shape
     Lk = k.shape[1]
     if scale is None:
         scale = 1.0 / math.sqrt(D)
+    if dropout_p > 0 and seed is None:
+        seed = new_seed()
     if backend == "hip":
         _need_gpu(q)
         if D != 64:
             raise TrxNNError("the attention kernel is specialised for heads of 64 (got %d)" % D)
-        return _Attention.apply(q, k, v, mask, causal, scale)
-    # fp32 reference: exactly what BertSelfAttention's eager path computes
+        return _Attention.apply(q, k, v, mask, causal, scale, float(dropout_p), 0 if seed is None else seed)
     qf, kf, vf = (t.float().permute(0, 2, 1, 3) for t in (q, k, v))             # [B, H, L, D]
     s = torch.matmul(qf, kf.transpose(-1, -2)) * scale
     if mask is not None:
@@ -174,4 +211,7 @@ def attention(q, k, v, mask=None, causal=False, scale=None, backend="hip"):
         j = torch.arange(Lk, device=q.device)[None, :]
         s = s.masked_fill(j > i, torch.finfo(torch.float32).min)
     p = torch.softmax(s, dim=-1)
+    if dropout_p > 0:
+        keep = dropout_keep_mask(seed, dropout_p, B * H, Lq, Lk, q.device).view(B, H, Lq, Lk)
+        p = p * keep.float() / (1.0 - dropout_p)
     return torch.matmul(p, vf).permute(0, 2, 1, 3).reshape(B, Lq, H * D).to(q.dtype)
