@@ -27,6 +27,42 @@ def timeit(fn, iters=20, warm=3):
     return a.elapsed_time(b) / iters
 
 
+def train_step_bench(dev, steps=5):
+    """one optimisation step of the full-size predictor at the scripts' per-GPU shapes
+    (train_RetroSyn_tf.sh: batch 128 over 4 GPUs -> 32, encoder L = 512, decoder T = 160; bf16 autocast
+    like --precision 16-mixed, dropout 0.1, AdamW), forward + backward + optimizer, random-init weights."""
+    from textreact_amd.predictor.model import Config
+    from textreact_amd.predictor import train
+    res = []
+    B, L, T = 32, 512, 160
+    g = torch.Generator().manual_seed(0)
+    batch = {"input_ids": torch.randint(1, 31090, (B, L), generator=g).to(dev),
+             "attention_mask": torch.ones(B, L, dtype=torch.long, device=dev),
+             "decoder_input_ids": torch.randint(14, 600, (B, T), generator=g).to(dev),
+             "decoder_attention_mask": torch.ones(B, T, dtype=torch.long, device=dev)}
+    batch["attention_mask"][::3, 400:] = 0
+    for backend in ("hip", "torch"):
+        enc = Config(vocab_size=31090)
+        dec = Config(vocab_size=600, num_hidden_layers=6, type_vocab_size=1, layer_norm_eps=1e-5, is_decoder=True)
+        torch.manual_seed(0)
+        p = train.Predictor(enc, dec, mlm=False, backend=backend).to(dev).train()
+        opt = torch.optim.AdamW(p.parameters(), lr=1e-4)
+
+        def step():
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                loss, _ = p.training_step(batch)
+            loss.backward()
+            opt.step(); opt.zero_grad(set_to_none=True)
+            return loss
+        ms = timeit(step, iters=steps, warm=2)
+        tokens = B * (L + T)
+        res.append({"kernel": "train_step", "backend": backend, "dtype": "bf16 autocast", "B": B, "L": L, "T": T,
+                    "ms": ms, "tokens_per_s": tokens / (ms * 1e-3)})
+        del p, opt
+        torch.cuda.empty_cache()
+    return res
+
+
 def main():
     dev = "cuda"
     out = []
@@ -75,6 +111,7 @@ def main():
         out.append({"kernel": "attention_bwd", "what": name, "dtype": str(dtype), "B": B, "H": H, "Lq": Lq, "Lk": Lk,
                     "ms": ms, "torch_eager_fp32_ms": ref,
                     "roofline": {"bound": "mfma", "achieved": tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": tf / 2500.0}})
+    out.extend(train_step_bench(dev))
     for o in out:
         print(json.dumps(o))
 

@@ -264,3 +264,30 @@ def test_model_backward_hip_vs_torch():
     for n in grads["hip"]:
         a, c = grads["hip"][n], grads["torch"][n]
         assert float((a - c).abs().max()) <= 1e-4 * max(1.0, float(c.abs().max())), n
+
+
+def test_model_training_mode_dropout_hip_vs_torch():
+    """train(): dropout on, the same seeds on both backends (torch.manual_seed fixes the seed stream the ops
+    draw from) -> the same elements are dropped, so loss and every gradient must agree"""
+    z = np.load(G)
+    enc, dec = json.loads(str(z["enc_cfg"])), json.loads(str(z["dec_cfg"]))
+    t = lambda k_: torch.from_numpy(z[k_]).cuda()
+    grads = {}
+    for backend in ("hip", "torch"):
+        m = TextReactModel(Config(**enc), Config(is_decoder=True, **dec), backend=backend)
+        m.load_state_dict(random_state_dict(m, int(z["seed"])))
+        m = m.cuda().train()
+        torch.manual_seed(11)
+        logits, _ = m(t("input_ids"), t("attention_mask"), t("decoder_input_ids"), t("decoder_attention_mask"))
+        labels = t("decoder_input_ids")[:, 1:]
+        loss = torch.nn.functional.cross_entropy(logits[:, :-1].reshape(-1, logits.shape[-1]), labels.reshape(-1), ignore_index=0)
+        loss.backward()
+        grads[backend] = {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+        grads[backend]["__loss__"] = loss.detach()
+    m.eval()
+    with torch.no_grad():
+        ev, _ = m(t("input_ids"), t("attention_mask"), t("decoder_input_ids"), t("decoder_attention_mask"))
+    assert not torch.allclose(ev, logits.detach(), atol=1e-4)      # dropout did change the forward
+    for n in grads["hip"]:
+        a, c = grads["hip"][n], grads["torch"][n]
+        assert float((a - c).abs().max()) <= 1e-4 * max(1.0, float(c.abs().max())), n

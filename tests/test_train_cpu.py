@@ -18,9 +18,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "tests", "golden", "predictor_small.npz")
 
 
-def _predictor(mlm=True):
+def _predictor(mlm=True, dropout=0.0):
     z = np.load(G)
     enc, dec = json.loads(str(z["enc_cfg"])), json.loads(str(z["dec_cfg"]))
+    for c in (enc, dec):   # these tests compare numbers across runs: dropout off unless asked for
+        c["hidden_dropout_prob"] = c["attention_probs_dropout_prob"] = dropout
     p = train.Predictor(Config(**enc), Config(is_decoder=True, **dec), mlm=mlm, backend="torch")
     g = torch.Generator().manual_seed(5)
     with torch.no_grad():
@@ -121,3 +123,15 @@ def test_two_rank_ddp_gradients_are_the_rank_average():
         local.append({n: t.grad.clone() for n, t in p.named_parameters() if t.grad is not None})
     for n in g0:
         assert torch.allclose(g0[n], (local[0][n] + local[1][n]) / 2, atol=1e-6), n
+
+
+def test_training_mode_applies_dropout_and_eval_mode_does_not():
+    _, p, batch = _predictor(mlm=False, dropout=0.1)
+    p.eval()
+    a = p.model(**batch)[0]
+    assert torch.equal(a, p.model(**batch)[0])
+    p.train()
+    torch.manual_seed(0); b1 = p.model(**batch)[0]
+    torch.manual_seed(0); b2 = p.model(**batch)[0]
+    torch.manual_seed(1); b3 = p.model(**batch)[0]
+    assert torch.equal(b1, b2) and not torch.equal(b1, b3) and not torch.equal(a, b1)

@@ -11,7 +11,10 @@ checkpoint's `state_dict` (prefix `model.`) loads unchanged, and routes the two 
 textreact_amd.predictor.ops: attention (self / cross / causal) and LayerNorm(dense(h) + residual).
 Linear layers stay rocBLAS GEMMs (torch.nn.Linear); GELU is the exact erf form, as in BERT.
 
-Eval-mode math only in round 1 (dropout is identity; parity is defined in eval mode).
+Training mode applies the reference's dropout (BERT defaults 0.1 / 0.1): on the attention
+probabilities and on dense outputs before the residual LayerNorm -- both inside the fused kernels --
+and on the embeddings after their LayerNorm (torch's dropout); eval mode is the identity, and parity
+with the reference's logits is defined in eval mode.
 """
 import torch
 import torch.nn as nn
@@ -24,11 +27,12 @@ class Config:
 
     def __init__(self, vocab_size, hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
                  intermediate_size=3072, max_position_embeddings=512, type_vocab_size=2, layer_norm_eps=1e-12,
-                 pad_token_id=0, is_decoder=False, **_):
+                 pad_token_id=0, is_decoder=False, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1, **_):
         self.vocab_size, self.hidden_size, self.num_hidden_layers = vocab_size, hidden_size, num_hidden_layers
         self.num_attention_heads, self.intermediate_size = num_attention_heads, intermediate_size
         self.max_position_embeddings, self.type_vocab_size = max_position_embeddings, type_vocab_size
         self.layer_norm_eps, self.pad_token_id, self.is_decoder = layer_norm_eps, pad_token_id, is_decoder
+        self.hidden_dropout_prob, self.attention_probs_dropout_prob = hidden_dropout_prob, attention_probs_dropout_prob
         assert hidden_size == num_attention_heads * 64, "the attention kernel is specialised for heads of 64"
 
 
@@ -64,6 +68,7 @@ class Attention(nn.Module):
         self.self = SelfAttentionProj(cfg)
         self.output = AttnOutput(cfg)
         self.heads, self.eps = cfg.num_attention_heads, cfg.layer_norm_eps
+        self.p_attn, self.p_hidden = cfg.attention_probs_dropout_prob, cfg.hidden_dropout_prob
 
     def forward(self, h, kv, mask, causal, backend):
         B, Lq, Hd = h.shape
@@ -71,9 +76,10 @@ class Attention(nn.Module):
         q = self.self.query(h).view(B, Lq, self.heads, 64)
         k = self.self.key(kv).view(B, Lk, self.heads, 64)
         v = self.self.value(kv).view(B, Lk, self.heads, 64)
-        ctx = ops.attention(q, k, v, mask=mask, causal=causal, backend=backend)
+        ctx = ops.attention(q, k, v, mask=mask, causal=causal, backend=backend,
+                            dropout_p=self.p_attn if self.training else 0.0)
         return ops.add_layernorm(self.output.dense(ctx), h, self.output.LayerNorm.weight, self.output.LayerNorm.bias,
-                                 self.eps, backend=backend)
+                                 self.eps, backend=backend, dropout_p=self.p_hidden if self.training else 0.0)
 
 
 class Intermediate(nn.Module):
@@ -90,7 +96,7 @@ class Layer(nn.Module):
             self.crossattention = Attention(cfg)
         self.intermediate = Intermediate(cfg)
         self.output = AttnOutput(cfg, in_features=cfg.intermediate_size)
-        self.eps, self.cross = cfg.layer_norm_eps, cross
+        self.eps, self.cross, self.p_hidden = cfg.layer_norm_eps, cross, cfg.hidden_dropout_prob
 
     def forward(self, h, self_mask, causal, enc, enc_mask, backend):
         h = self.attention(h, h, self_mask, causal, backend)
@@ -98,7 +104,7 @@ class Layer(nn.Module):
             h = self.crossattention(h, enc, enc_mask, False, backend)
         f = torch.nn.functional.gelu(self.intermediate.dense(h))
         return ops.add_layernorm(self.output.dense(f), h, self.output.LayerNorm.weight, self.output.LayerNorm.bias,
-                                 self.eps, backend=backend)
+                                 self.eps, backend=backend, dropout_p=self.p_hidden if self.training else 0.0)
 
 
 class LayerStack(nn.Module):
@@ -116,6 +122,7 @@ class Embeddings(nn.Module):
         self.token_type_embeddings = nn.Embedding(cfg.type_vocab_size, cfg.hidden_size)
         self.LayerNorm = LayerNormParams(cfg.hidden_size)
         self.eps, self.roberta, self.pad = cfg.layer_norm_eps, roberta, cfg.pad_token_id
+        self.p_hidden = cfg.hidden_dropout_prob
 
     def forward(self, input_ids, position_ids, token_type_ids, backend):
         if position_ids is None:
@@ -127,8 +134,9 @@ class Embeddings(nn.Module):
         if token_type_ids is None:
             token_type_ids = torch.zeros_like(input_ids)
         e = self.word_embeddings(input_ids) + self.token_type_embeddings(token_type_ids)
-        return ops.add_layernorm(e, self.position_embeddings(position_ids), self.LayerNorm.weight,
-                                 self.LayerNorm.bias, self.eps, backend=backend)
+        y = ops.add_layernorm(e, self.position_embeddings(position_ids), self.LayerNorm.weight,
+                              self.LayerNorm.bias, self.eps, backend=backend)
+        return torch.nn.functional.dropout(y, self.p_hidden, self.training)   # after the LayerNorm (BertEmbeddings)
 
 
 class Pooler(nn.Module):

@@ -142,7 +142,9 @@ def add_layernorm(x, res, gamma, beta, eps, backend="hip", dropout_p=0.0, seed=N
         seed = new_seed()
     if backend == "hip":
         return _AddLayerNorm.apply(x, res, gamma, beta, eps, float(dropout_p), 0 if seed is None else seed)
-    if dropout_p > 0:
+    if dropout_p > 0 and not x.is_cuda:     # module tree on a box without a GPU: torch's own dropout
+        x = torch.nn.functional.dropout(x, dropout_p, True)
+    elif dropout_p > 0:
         cols = x.shape[-1]
         keep = dropout_keep_mask(seed, dropout_p, 1, x.numel() // cols, cols, x.device).view(x.shape)
         x = x * keep.to(x.dtype) / (1.0 - dropout_p)
@@ -211,7 +213,9 @@ def attention(q, k, v, mask=None, causal=False, scale=None, backend="hip", dropo
         j = torch.arange(Lk, device=q.device)[None, :]
         s = s.masked_fill(j > i, torch.finfo(torch.float32).min)
     p = torch.softmax(s, dim=-1)
-    if dropout_p > 0:
+    if dropout_p > 0 and not q.is_cuda:
+        p = torch.nn.functional.dropout(p, dropout_p, True)
+    elif dropout_p > 0:
         keep = dropout_keep_mask(seed, dropout_p, B * H, Lq, Lk, q.device).view(B, H, Lq, Lk)
         p = p * keep.float() / (1.0 - dropout_p)
     return torch.matmul(p, vf).permute(0, 2, 1, 3).reshape(B, Lq, H * D).to(q.dtype)
