@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const void* x, const vo
 }
 
 // ---- backward: dz, and per-block partial column sums of dgamma / dbeta ----
-constexpr int BWD_ROWS_PER_WAVE = 8;
+constexpr int BWD_MAX_BLOCKS = 512;   // workgroups of 4 waves, rows dealt round-robin to the waves
 template <bool BF>
 __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const void* dy, const void* x, const void* res,
                                                          const float* gamma, const float* mean, const float* rstd,
@@ -228,10 +228,7 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const void* dy, const v
     float* pg = sm + (wave * 2) * cols;
     float* pb = pg + cols;
     for (int c = lane; c < cols; c += 64) { pg[c] = 0.f; pb[c] = 0.f; }
-    const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * BWD_ROWS_PER_WAVE;
-    for (int r = 0; r < BWD_ROWS_PER_WAVE; ++r) {
-        const int64_t row = row0 + r;
-        if (row >= rows) break;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
         const int64_t base = row * cols;
         const float mu = mean[row], rs = rstd[row];
         float s1 = 0.f, s2 = 0.f;
@@ -260,12 +257,119 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const void* dy, const v
         ws[((int64_t)nblk + blockIdx.x) * cols + c] = b;
     }
 }
-__global__ void add_ln_bwd_reduce_kernel(const float* ws, int nblk, int cols, float* dgamma, float* dbeta) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= cols) return;
-    float a = 0.f, b = 0.f;
-    for (int i = 0; i < nblk; ++i) { a += ws[(int64_t)i * cols + c]; b += ws[((int64_t)nblk + i) * cols + c]; }
-    dgamma[c] = a; dbeta[c] = b;
+// Fast path (same conditions as the forward's): a wave per row, the row lives in registers (16-byte
+// accesses, one pass over dy / x / res), and because a lane owns the same columns in every row it also
+// carries the dgamma / dbeta partial sums of its columns in registers over all its rows; the four
+// waves of a workgroup are combined through LDS at the end.
+template <bool BF>
+__global__ __launch_bounds__(256) void add_ln_bwd_vec_kernel(const void* dy, const void* x, const void* res,
+                                                             const float* gamma, const float* mean, const float* rstd,
+                                                             int64_t rows, int cols, void* dz, void* dx, float* ws, int nblk, Drop drop) {
+    extern __shared__ float sm[];  // [4 waves][2][cols]
+    constexpr int V = Vec16<BF>::N;
+    constexpr int ES = BF ? 2 : 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nchunk = cols / V;
+    float ag[NCH][V], ab[NCH][V], gm[NCH][V];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = lane + 64 * i;
+#pragma unroll
+        for (int j = 0; j < V; ++j) { ag[i][j] = 0.f; ab[i][j] = 0.f; gm[i][j] = c < nchunk ? gamma[c * V + j] : 0.f; }
+    }
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+        const size_t rb = (size_t)row * cols * ES;
+        const float mu = mean[row], rs = rstd[row];
+        float g[NCH][V], xh[NCH][V];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nchunk) {
+                float d[V], z[V];
+                unpack16<BF>(*reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(dy) + rb + (size_t)c * 16), d);
+                unpack16<BF>(*reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(x) + rb + (size_t)c * 16), z);
+                if (drop.thr) {
+#pragma unroll
+                    for (int j = 0; j < V; j += 2) {
+                        const unsigned bits = drop_bits(drop.base, (unsigned)row, (unsigned)(c * V + j) >> 1);
+                        z[j] *= drop_keep(bits, 0, drop.thr) ? drop.inv_keep : 0.f;
+                        z[j + 1] *= drop_keep(bits, 1, drop.thr) ? drop.inv_keep : 0.f;
+                    }
+                }
+                if (res) {
+                    float r[V];
+                    unpack16<BF>(*reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(res) + rb + (size_t)c * 16), r);
+#pragma unroll
+                    for (int j = 0; j < V; ++j) z[j] += r[j];
+                }
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    xh[i][j] = (z[j] - mu) * rs;
+                    g[i][j] = d[j] * gm[i][j];
+                    s1 += g[i][j]; s2 += g[i][j] * xh[i][j];
+                    ag[i][j] += d[j] * xh[i][j]; ab[i][j] += d[j];
+                }
+            }
+        }
+        s1 = wave_sum(s1) / (float)cols; s2 = wave_sum(s2) / (float)cols;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nchunk) {
+                float o[V];
+#pragma unroll
+                for (int j = 0; j < V; ++j) o[j] = rs * (g[i][j] - s1 - xh[i][j] * s2);
+                *reinterpret_cast<uint4*>(reinterpret_cast<char*>(dz) + rb + (size_t)c * 16) = pack16<BF>(o);
+                if (dx) {   // gradient of x through its dropout
+#pragma unroll
+                    for (int j = 0; j < V; j += 2) {
+                        const unsigned bits = drop_bits(drop.base, (unsigned)row, (unsigned)(c * V + j) >> 1);
+                        o[j] *= drop_keep(bits, 0, drop.thr) ? drop.inv_keep : 0.f;
+                        o[j + 1] *= drop_keep(bits, 1, drop.thr) ? drop.inv_keep : 0.f;
+                    }
+                    *reinterpret_cast<uint4*>(reinterpret_cast<char*>(dx) + rb + (size_t)c * 16) = pack16<BF>(o);
+                }
+            }
+        }
+    }
+    float* pg = sm + (wave * 2) * cols;
+    float* pb = pg + cols;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nchunk) {
+#pragma unroll
+            for (int j = 0; j < V; ++j) { pg[c * V + j] = ag[i][j]; pb[c * V + j] = ab[i][j]; }
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < cols; c += 256) {
+        float a = 0.f, b = 0.f;
+        for (int w = 0; w < 4; ++w) { a += sm[(w * 2) * cols + c]; b += sm[(w * 2 + 1) * cols + c]; }
+        ws[(int64_t)blockIdx.x * cols + c] = a;
+        ws[((int64_t)nblk + blockIdx.x) * cols + c] = b;
+    }
+}
+
+// second stage: sum the nblk partial rows of ws.  A workgroup owns 16 columns of one of the two
+// arrays (blockIdx.y: 0 dgamma, 1 dbeta); its 16 x 16 threads walk the partial rows 16 at a time.
+__global__ __launch_bounds__(256) void add_ln_bwd_reduce_kernel(const float* ws, int nblk, int cols, float* dgamma, float* dbeta) {
+    __shared__ float part[16][17];
+    const int tc = threadIdx.x & 15, tr = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + tc;
+    const float* src = ws + (int64_t)blockIdx.y * nblk * cols;
+    float a = 0.f;
+    if (c < cols)
+        for (int i = tr; i < nblk; i += 16) a += src[(int64_t)i * cols + c];
+    part[tr][tc] = a;
+    __syncthreads();
+    if (tr == 0 && c < cols) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += part[i][tc];
+        (blockIdx.y ? dbeta : dgamma)[c] = t;
+    }
 }
 
 // ---- attention forward, fp32 math, one lane per query row --------------------------------------
@@ -749,7 +853,7 @@ extern "C" {
 
 const char* trx_nn_last_error(void) { return g_err.c_str(); }
 const char* trx_nn_version(void) { return "trxnn 0.1 (gfx950)"; }
-int trx_add_layernorm_bwd_blocks(int64_t rows) { return (int)((rows + 4 * BWD_ROWS_PER_WAVE - 1) / (4 * BWD_ROWS_PER_WAVE)); }
+int trx_add_layernorm_bwd_blocks(int64_t rows) { const int64_t b = (rows + 3) / 4; return (int)(b < 1 ? 1 : (b > BWD_MAX_BLOCKS ? BWD_MAX_BLOCKS : b)); }
 
 int trx_add_layernorm_fwd_dropout(const void* x, const void* res, const float* gamma, const float* beta, float eps,
                                   int64_t rows, int cols, int dtype, float p, uint64_t seed, void* y, float* mean,
@@ -793,14 +897,20 @@ int trx_add_layernorm_bwd_dropout(const void* dy, const void* x, const void* res
     const int nblk = trx_add_layernorm_bwd_blocks(rows);
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = (size_t)cols * 8 * sizeof(float);
-    if (dtype == TRX_NN_BF16) {
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)add_ln_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(add_ln_bwd_kernel<true>, dim3(nblk), dim3(256), lds, st, dy, x, res, gamma, mean, rstd, rows, cols, dz, p > 0.f ? dx : nullptr, ws, nblk, drop);
-    } else {
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)add_ln_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(add_ln_bwd_kernel<false>, dim3(nblk), dim3(256), lds, st, dy, x, res, gamma, mean, rstd, rows, cols, dz, p > 0.f ? dx : nullptr, ws, nblk, drop);
+    const int V = dtype == TRX_NN_BF16 ? 8 : 4;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(res) |
+                           reinterpret_cast<uintptr_t>(dz) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0;
+    const bool vec = aligned && cols % V == 0 && cols <= 64 * NCH * V;
+#define TRX_LAUNCH_LNB(KERNEL)                                                                                              \
+    {                                                                                                                       \
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(KERNEL, dim3(nblk), dim3(256), lds, st, dy, x, res, gamma, mean, rstd, rows, cols, dz,           \
+                           p > 0.f ? dx : nullptr, ws, nblk, drop);                                                         \
     }
-    hipLaunchKernelGGL(add_ln_bwd_reduce_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, ws, nblk, cols, dgamma, dbeta);
+    if (dtype == TRX_NN_BF16) { if (vec) TRX_LAUNCH_LNB(add_ln_bwd_vec_kernel<true>) else TRX_LAUNCH_LNB(add_ln_bwd_kernel<true>) }
+    else { if (vec) TRX_LAUNCH_LNB(add_ln_bwd_vec_kernel<false>) else TRX_LAUNCH_LNB(add_ln_bwd_kernel<false>) }
+#undef TRX_LAUNCH_LNB
+    hipLaunchKernelGGL(add_ln_bwd_reduce_kernel, dim3((cols + 15) / 16, 2), dim3(256), 0, st, ws, nblk, cols, dgamma, dbeta);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? TRX_NN_OK : fail(TRX_NN_EHIP, hipGetErrorString(e));
 }
