@@ -317,3 +317,48 @@ def test_values_outside_bf16_range_and_tiny_values():
     x = rng.standard_normal((64, 48)).astype(np.float32)
     _check(IP, x, y, 10)
     _check(L2, x, y, 10)
+
+
+# ---- N > 1 on one device: every rank drives the HIP index and the HIP merge kernel on cuda:0; only the
+# transport differs from the real run (gloo instead of RCCL, since two ranks cannot share a GPU in RCCL)
+def _rank_worker(rank, world, port, ret):
+    import os, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+    import torch, torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from textreact_amd.sharded import ShardedFlatIndex, shard_bounds
+    from _data import gaussian as g_
+    n, d, nq = 30011, 96, 300
+    y, x = g_(n, d, 11), g_(nq, d, 12)
+    y[5000:5040] = y[100]                                   # ties that straddle the shard boundaries
+    y[20000:20020] = y[100]
+    out = {}
+    for metric in (0, 1):
+        lo, hi = shard_bounds(n, world, rank)
+        idx = ShardedFlatIndex(d, metric)
+        idx.add_shard(torch.from_numpy(y[lo:hi]).cuda(), lo, n)
+        D, I = idx.search(torch.from_numpy(x).cuda(), 10)
+        out[metric] = (D.cpu().numpy(), I.cpu().numpy())
+    ret[rank] = out
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_multi_rank_sharded_search_on_one_gpu(world):
+    import socket
+    import torch.multiprocessing as mp
+    from oracle import flat_knn as oracle
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mgr = mp.Manager(); ret = mgr.dict()
+    mp.spawn(_rank_worker, args=(world, port, ret), nprocs=world, join=True)
+    n, d, nq = 30011, 96, 300
+    y, x = gaussian(n, d, 11), gaussian(nq, d, 12)
+    y[5000:5040] = y[100]; y[20000:20020] = y[100]
+    for metric in (IP, L2):
+        Dr, Ir = oracle.knn_canonical(metric, x, y, 10)
+        for r in range(world):
+            D, I = ret[r][metric]
+            assert np.array_equal(I, Ir), (metric, r)
+            assert np.array_equal(D.view(np.uint32), Dr.view(np.uint32)), (metric, r)

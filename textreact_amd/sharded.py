@@ -59,10 +59,11 @@ class ShardedFlatIndex:
         nq = S.shape[0]
         pack = torch.stack([S.contiguous().view(torch.int64), I.contiguous()])
         out = torch.empty((self.world_size,) + tuple(pack.shape), dtype=torch.int64, device=pack.device)
-        if dist.get_backend(self.group) == "gloo":  # CPU test path
-            parts = [torch.empty_like(pack) for _ in range(self.world_size)]
-            dist.all_gather(parts, pack, group=self.group)
-            out = torch.stack(parts)
+        if dist.get_backend(self.group) == "gloo":  # test path (gloo gathers host tensors only)
+            host = pack.cpu()
+            parts = [torch.empty_like(host) for _ in range(self.world_size)]
+            dist.all_gather(parts, host, group=self.group)
+            out = torch.stack(parts).to(pack.device)
         else:
             dist.all_gather_into_tensor(out, pack, group=self.group)
         S_all = out[:, 0].contiguous().view(torch.float64)
