@@ -119,11 +119,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the retrieval path has no CPU fallback")
+    # TRX_BENCH_BACKEND=gloo TRX_BENCH_DEVICE=0 lets several ranks share one GPU to rehearse the N > 1 path
+    # (RCCL refuses two ranks on one device); the real run is nccl = RCCL, one GPU per rank
+    backend = os.environ.get("TRX_BENCH_BACKEND", "nccl")
+    local_rank = int(os.environ.get("TRX_BENCH_DEVICE", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     if args.gpus != world and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
 

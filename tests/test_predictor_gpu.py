@@ -61,6 +61,8 @@ def test_add_layernorm_backward(rows, cols):
     (2, 12, 160, 512, "key", False),      # cross-attention over the encoder states
     (4, 2, 1, 129, "none", True),         # one decode step against a KV prefix
     (1, 1, 65, 200, "key", True),
+    (1, 2, 130, 2100, "key", False),      # key mask longer than the 1024 keys the kernel keeps in LDS at a time
+    (1, 2, 300, 1100, "full", True),
 ])
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
 def test_attention_forward(B, H, Lq, Lk, mask, causal, dtype, tol):
