@@ -37,6 +37,7 @@
 //   bootstrap launch (one tile per query tile, dense rebuild) seeds g_thr so the real scan starts
 //   warm and appends O(kprime log N) rows per query in total instead of per split.
 #include "knn_common.h"
+#include <cstdlib>
 
 namespace trx {
 
@@ -393,6 +394,11 @@ hipError_t launch_scan(const ScanParams& p, int metric, hipStream_t st) {
     // cache policy of the two LDS-DMA streams is the default one: `nt` on the corpus stream, the
     // query stream or both measured 107-122 ms against 92 ms, so only <0, 0>
     // is instantiated.
+#ifdef TRX_POLICY_EXPERIMENT
+    static const int pol = getenv("TRX_POLICY") ? atoi(getenv("TRX_POLICY")) : 0;   // 1: nt on queries, 2: nt on corpus
+    if (metric != 1 && pol == 2) return launch_one<false, 2, 0>(p, st);
+    if (metric != 1 && pol == 1) return launch_one<false, 0, 2>(p, st);
+#endif
     return metric == 1 ? launch_one<true, 0, 0>(p, st) : launch_one<false, 0, 0>(p, st);
 }
 
