@@ -80,6 +80,15 @@ int trx_attention_fwd_dropout(const void* q, const void* k, const void* v, const
 int trx_attention_bwd_dropout(const void* q, const void* k, const void* v, const float* mask, int mask_mode, int causal,
                               int B, int H, int Lq, int Lk, float scale, int dtype, float p, uint64_t seed, const void* out,
                               const void* dout, const float* lse, void* dq, void* dk, void* dv, void* stream);
+/* Mixed storage, the autocast case: x is a bf16 dense output, the residual stream (res, y) is fp32 --
+ * torch runs layer_norm in fp32 under autocast and so does the reference's --precision 16-mixed.
+ * cols % 4 == 0, cols <= 1024.  Backward: dy, dz fp32 (dz = gradient of res), dx bf16 (gradient of x,
+ * through the dropout when p > 0), always written. */
+int trx_add_layernorm_fwd_mixed(const void* x_bf16, const void* res_f32, const float* gamma, const float* beta, float eps,
+                                int64_t rows, int cols, float p, uint64_t seed, void* y_f32, float* mean, float* rstd, void* stream);
+int trx_add_layernorm_bwd_mixed(const void* dy_f32, const void* x_bf16, const void* res_f32, const float* gamma, const float* mean,
+                                const float* rstd, int64_t rows, int cols, float p, uint64_t seed, void* dz_f32, void* dx_bf16,
+                                float* dgamma, float* dbeta, float* ws, void* stream);
 /* keep[streams][rows][cols] (1 = kept) exactly as the kernels above decide for (seed, p). */
 int trx_dropout_keep_mask(uint64_t seed, float p, int64_t streams, int64_t rows, int64_t cols, unsigned char* keep, void* stream);
 

@@ -293,3 +293,82 @@ def test_model_training_mode_dropout_hip_vs_torch():
     for n in grads["hip"]:
         a, c = grads["hip"][n], grads["torch"][n]
         assert float((a - c).abs().max()) <= 1e-4 * max(1.0, float(c.abs().max())), n
+
+
+def test_dense_producer_feeds_the_flat_index_on_device(tmp_path):
+    """encoder -> [N, hidden] bf16 embeddings in HBM -> flat index -> neighbor file, nothing through the host;
+    the ids must be what the oracle finds on exactly those embeddings"""
+    from textreact_amd import dense, neighbors
+    from oracle import flat_knn as oracle
+    cfg = Config(vocab_size=500, num_hidden_layers=2, max_position_embeddings=64)
+    torch.manual_seed(0)
+    enc = dense.DenseEncoder(cfg).cuda().eval()
+    g = torch.Generator().manual_seed(3)
+    c_ids = torch.randint(1, 500, (1500, 40), generator=g); c_am = torch.ones_like(c_ids); c_am[::4, 25:] = 0
+    q_ids = torch.randint(1, 500, (70, 33), generator=g); q_am = torch.ones_like(q_ids)
+    corpus = dense.encode(enc, c_ids, c_am, batch_size=512)
+    assert corpus.is_cuda and corpus.dtype == torch.bfloat16 and corpus.shape == (1500, 768)
+    index = dense.build_index(corpus)
+    assert index.ntotal == 1500
+    ckeys = ["c%d" % i for i in range(1500)]; qkeys = ["q%d" % i for i in range(70)]
+    result = dense.retrieve(enc, index, q_ids, q_am, qkeys, ckeys, k=10)
+    q = dense.encode(enc, q_ids, q_am)
+    _, Ir = oracle.knn_canonical(0, q.float().cpu().numpy(), corpus.float().cpu().numpy(), 10)
+    assert [r["id"] for r in result] == qkeys
+    assert [r["nn"] for r in result] == [[ckeys[j] for j in row] for row in Ir]
+    neighbors.write_neighbors(str(tmp_path / "val.json"), result)
+    assert neighbors.read_neighbors(str(tmp_path / "val.json"))["q3"] == result[3]["nn"]
+    # the bf16 autocast path agrees with the fp32 statement of the ops to bf16 accuracy
+    enc.backend = "torch"
+    ref = dense.encode(enc, c_ids[:64], c_am[:64], autocast=False, out_dtype=torch.float32)
+    assert float((corpus[:64].float() - ref).abs().max()) <= 5e-2 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("train_mode", [False, True])
+def test_model_under_bf16_autocast_hip_vs_torch(train_mode):
+    """--precision 16-mixed style: Linear layers emit bf16, the residual stream stays fp32 (mixed operand
+    types reach add_layernorm), attention runs on the matrix cores.  Loss and gradients against the
+    PyTorch statement of the ops under the same autocast (and the same dropout decisions)."""
+    z = np.load(G)
+    enc, dec = json.loads(str(z["enc_cfg"])), json.loads(str(z["dec_cfg"]))
+    t = lambda k_: torch.from_numpy(z[k_]).cuda()
+    res = {}
+    for backend in ("hip", "torch"):
+        m = TextReactModel(Config(**enc), Config(is_decoder=True, **dec), backend=backend)
+        m.load_state_dict(random_state_dict(m, int(z["seed"])))
+        m = m.cuda().train(train_mode)
+        torch.manual_seed(5)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            logits, _ = m(t("input_ids"), t("attention_mask"), t("decoder_input_ids"), t("decoder_attention_mask"))
+            labels = t("decoder_input_ids")[:, 1:]
+            loss = torch.nn.functional.cross_entropy(logits[:, :-1].reshape(-1, logits.shape[-1]).float(), labels.reshape(-1), ignore_index=0)
+        loss.backward()
+        assert bool(torch.isfinite(logits).all()) and bool(torch.isfinite(loss))
+        res[backend] = (logits.detach().float(), loss.detach(), {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
+    assert float((res["hip"][0] - res["torch"][0]).abs().max()) <= 6e-2 * max(1.0, float(res["torch"][0].abs().max()))
+    assert abs(float(res["hip"][1] - res["torch"][1])) <= 3e-2 * max(1.0, abs(float(res["torch"][1])))
+    for n in res["hip"][2]:
+        a, c = res["hip"][2][n], res["torch"][2][n]
+        assert bool(torch.isfinite(a).all()), n
+        assert float((a - c).abs().max()) <= 8e-2 * max(1e-2, float(c.abs().max())), n
+
+
+@pytest.mark.parametrize("rows,cols", [(777, 768), (33, 600), (5000, 1024)])
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_add_layernorm_mixed_storage(rows, cols, p):
+    """x bf16, residual stream fp32 (autocast): forward and backward against the PyTorch statement"""
+    x = _rand(rows, cols, dtype=torch.bfloat16, seed=1); r = _rand(rows, cols, seed=2)
+    g, b = _rand(cols, seed=3), _rand(cols, seed=4)
+    dy = _rand(rows, cols, seed=5)
+    res = []
+    for backend in ("hip", "torch"):
+        xs, rs = x.clone().requires_grad_(True), r.clone().requires_grad_(True)
+        gs, bs = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        y = ops.add_layernorm(xs, rs, gs, bs, 1e-12, backend=backend, dropout_p=p, seed=77)
+        assert y.dtype == torch.float32
+        y.backward(dy)
+        assert xs.grad.dtype == torch.bfloat16 and rs.grad.dtype == torch.float32
+        res.append((y.detach(), xs.grad.float(), rs.grad, gs.grad, bs.grad))
+    tols = (3e-5, 1e-2, 3e-5, 3e-5, 3e-5)     # dx is rounded to bf16 once
+    for a, c, tol in zip(*res, tols):
+        assert float((a - c).abs().max()) <= tol * max(1.0, float(c.abs().max()))

@@ -112,7 +112,15 @@ template <bool BF> __device__ __forceinline__ uint4 pack16(const float* f) {
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-template <bool BF>
+// 4 bf16 (8 bytes) -> 4 floats: the x operand of the mixed case (bf16 dense output, fp32 residual stream)
+__device__ __forceinline__ void unpack8bf(const uint2& u, float* f) {
+    f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
+    f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
+}
+__device__ __forceinline__ uint2 pack8bf(const float* f) { return make_uint2(pack2bf(f[0], f[1]), pack2bf(f[2], f[3])); }
+
+// MIX: x is bf16 while res / y are fp32 (then BF is false and a lane step is 4 elements: 8 bytes of x)
+template <bool BF, bool MIX>
 __global__ __launch_bounds__(256) void add_ln_fwd_vec_kernel(const void* x, const void* res, const float* gamma,
                                                              const float* beta, float eps, int64_t rows, int cols,
                                                              void* y, float* mean, float* rstd, Drop drop) {
@@ -121,7 +129,7 @@ __global__ __launch_bounds__(256) void add_ln_fwd_vec_kernel(const void* x, cons
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int nchunk = cols / V;
-    const char* xr = reinterpret_cast<const char*>(x) + row * cols * (BF ? 2 : 4);
+    const char* xr = reinterpret_cast<const char*>(x) + row * cols * ((BF || MIX) ? 2 : 4);
     const char* rr = res ? reinterpret_cast<const char*>(res) + row * cols * (BF ? 2 : 4) : nullptr;
     char* yr = reinterpret_cast<char*>(y) + row * cols * (BF ? 2 : 4);
     float v[NCH][V];
@@ -130,7 +138,8 @@ __global__ __launch_bounds__(256) void add_ln_fwd_vec_kernel(const void* x, cons
     for (int i = 0; i < NCH; ++i) {
         const int c = lane + 64 * i;
         if (c < nchunk) {
-            unpack16<BF>(*reinterpret_cast<const uint4*>(xr + (size_t)c * 16), v[i]);
+            if (MIX) unpack8bf(*reinterpret_cast<const uint2*>(xr + (size_t)c * 8), v[i]);
+            else unpack16<BF>(*reinterpret_cast<const uint4*>(xr + (size_t)c * 16), v[i]);
             if (drop.thr) {   // dropout acts on x only, before the residual is added
 #pragma unroll
                 for (int j = 0; j < V; j += 2) {
@@ -261,7 +270,7 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const void* dy, const v
 // accesses, one pass over dy / x / res), and because a lane owns the same columns in every row it also
 // carries the dgamma / dbeta partial sums of its columns in registers over all its rows; the four
 // waves of a workgroup are combined through LDS at the end.
-template <bool BF>
+template <bool BF, bool MIX>
 __global__ __launch_bounds__(256) void add_ln_bwd_vec_kernel(const void* dy, const void* x, const void* res,
                                                              const float* gamma, const float* mean, const float* rstd,
                                                              int64_t rows, int cols, void* dz, void* dx, float* ws, int nblk, Drop drop) {
@@ -288,7 +297,8 @@ __global__ __launch_bounds__(256) void add_ln_bwd_vec_kernel(const void* dy, con
             if (c < nchunk) {
                 float d[V], z[V];
                 unpack16<BF>(*reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(dy) + rb + (size_t)c * 16), d);
-                unpack16<BF>(*reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(x) + rb + (size_t)c * 16), z);
+                if (MIX) unpack8bf(*reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(x) + (rb >> 1) + (size_t)c * 8), z);
+                else unpack16<BF>(*reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(x) + rb + (size_t)c * 16), z);
                 if (drop.thr) {
 #pragma unroll
                     for (int j = 0; j < V; j += 2) {
@@ -321,14 +331,17 @@ __global__ __launch_bounds__(256) void add_ln_bwd_vec_kernel(const void* dy, con
 #pragma unroll
                 for (int j = 0; j < V; ++j) o[j] = rs * (g[i][j] - s1 - xh[i][j] * s2);
                 *reinterpret_cast<uint4*>(reinterpret_cast<char*>(dz) + rb + (size_t)c * 16) = pack16<BF>(o);
-                if (dx) {   // gradient of x through its dropout
+                if (dx) {   // gradient of x: through its dropout, and in x's own storage type
+                    if (drop.thr) {
 #pragma unroll
-                    for (int j = 0; j < V; j += 2) {
-                        const unsigned bits = drop_bits(drop.base, (unsigned)row, (unsigned)(c * V + j) >> 1);
-                        o[j] *= drop_keep(bits, 0, drop.thr) ? drop.inv_keep : 0.f;
-                        o[j + 1] *= drop_keep(bits, 1, drop.thr) ? drop.inv_keep : 0.f;
+                        for (int j = 0; j < V; j += 2) {
+                            const unsigned bits = drop_bits(drop.base, (unsigned)row, (unsigned)(c * V + j) >> 1);
+                            o[j] *= drop_keep(bits, 0, drop.thr) ? drop.inv_keep : 0.f;
+                            o[j + 1] *= drop_keep(bits, 1, drop.thr) ? drop.inv_keep : 0.f;
+                        }
                     }
-                    *reinterpret_cast<uint4*>(reinterpret_cast<char*>(dx) + rb + (size_t)c * 16) = pack16<BF>(o);
+                    if (MIX) *reinterpret_cast<uint2*>(reinterpret_cast<char*>(dx) + (rb >> 1) + (size_t)c * 8) = pack8bf(o);
+                    else *reinterpret_cast<uint4*>(reinterpret_cast<char*>(dx) + rb + (size_t)c * 16) = pack16<BF>(o);
                 }
             }
         }
@@ -869,8 +882,8 @@ int trx_add_layernorm_fwd_dropout(const void* x, const void* res, const float* g
     const bool aligned = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(res)) & 15) == 0;
     const bool vec = aligned && cols % V == 0 && cols <= 64 * NCH * V;
     if (vec) {
-        if (dtype == TRX_NN_BF16) hipLaunchKernelGGL(add_ln_fwd_vec_kernel<true>, grid, block, 0, st, x, res, gamma, beta, eps, rows, cols, y, mean, rstd, drop);
-        else hipLaunchKernelGGL(add_ln_fwd_vec_kernel<false>, grid, block, 0, st, x, res, gamma, beta, eps, rows, cols, y, mean, rstd, drop);
+        if (dtype == TRX_NN_BF16) hipLaunchKernelGGL((add_ln_fwd_vec_kernel<true, false>), grid, block, 0, st, x, res, gamma, beta, eps, rows, cols, y, mean, rstd, drop);
+        else hipLaunchKernelGGL((add_ln_fwd_vec_kernel<false, false>), grid, block, 0, st, x, res, gamma, beta, eps, rows, cols, y, mean, rstd, drop);
     } else {
         if (dtype == TRX_NN_BF16) hipLaunchKernelGGL(add_ln_fwd_kernel<true>, grid, block, 0, st, x, res, gamma, beta, eps, rows, cols, y, mean, rstd, drop);
         else hipLaunchKernelGGL(add_ln_fwd_kernel<false>, grid, block, 0, st, x, res, gamma, beta, eps, rows, cols, y, mean, rstd, drop);
@@ -907,8 +920,8 @@ int trx_add_layernorm_bwd_dropout(const void* dy, const void* x, const void* res
         hipLaunchKernelGGL(KERNEL, dim3(nblk), dim3(256), lds, st, dy, x, res, gamma, mean, rstd, rows, cols, dz,           \
                            p > 0.f ? dx : nullptr, ws, nblk, drop);                                                         \
     }
-    if (dtype == TRX_NN_BF16) { if (vec) TRX_LAUNCH_LNB(add_ln_bwd_vec_kernel<true>) else TRX_LAUNCH_LNB(add_ln_bwd_kernel<true>) }
-    else { if (vec) TRX_LAUNCH_LNB(add_ln_bwd_vec_kernel<false>) else TRX_LAUNCH_LNB(add_ln_bwd_kernel<false>) }
+    if (dtype == TRX_NN_BF16) { if (vec) TRX_LAUNCH_LNB((add_ln_bwd_vec_kernel<true, false>)) else TRX_LAUNCH_LNB(add_ln_bwd_kernel<true>) }
+    else { if (vec) TRX_LAUNCH_LNB((add_ln_bwd_vec_kernel<false, false>)) else TRX_LAUNCH_LNB(add_ln_bwd_kernel<false>) }
 #undef TRX_LAUNCH_LNB
     hipLaunchKernelGGL(add_ln_bwd_reduce_kernel, dim3((cols + 15) / 16, 2), dim3(256), 0, st, ws, nblk, cols, dgamma, dbeta);
     hipError_t e = hipGetLastError();
@@ -919,6 +932,42 @@ int trx_add_layernorm_bwd(const void* dy, const void* x, const void* res, const 
                           const float* rstd, int64_t rows, int cols, int dtype, void* dz, float* dgamma,
                           float* dbeta, float* ws, void* stream) {
     return trx_add_layernorm_bwd_dropout(dy, x, res, gamma, mean, rstd, rows, cols, dtype, 0.f, 0, dz, nullptr, dgamma, dbeta, ws, stream);
+}
+
+int trx_add_layernorm_fwd_mixed(const void* x_bf16, const void* res_f32, const float* gamma, const float* beta, float eps,
+                                int64_t rows, int cols, float p, uint64_t seed, void* y_f32, float* mean, float* rstd, void* stream) {
+    if (!x_bf16 || !res_f32 || !gamma || !beta || !y_f32 || rows < 0 || cols <= 0) return fail(TRX_NN_EINVAL, "add_layernorm_fwd_mixed: bad argument");
+    if (!(p >= 0.f && p < 1.f)) return fail(TRX_NN_EINVAL, "dropout probability must be in [0, 1)");
+    if (cols % 4 != 0 || cols > 64 * NCH * 4) return fail(TRX_NN_EINVAL, "add_layernorm_fwd_mixed: cols must be a multiple of 4 and <= 1024");
+    if (((reinterpret_cast<uintptr_t>(res_f32) | reinterpret_cast<uintptr_t>(y_f32)) & 15) || (reinterpret_cast<uintptr_t>(x_bf16) & 7))
+        return fail(TRX_NN_EINVAL, "add_layernorm_fwd_mixed: operands must be 16-byte (x: 8-byte) aligned");
+    if (rows == 0) return TRX_NN_OK;
+    const Drop drop = make_drop(p, seed, 0);
+    hipLaunchKernelGGL((add_ln_fwd_vec_kernel<false, true>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       x_bf16, res_f32, gamma, beta, eps, rows, cols, y_f32, mean, rstd, drop);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? TRX_NN_OK : fail(TRX_NN_EHIP, hipGetErrorString(e));
+}
+
+int trx_add_layernorm_bwd_mixed(const void* dy_f32, const void* x_bf16, const void* res_f32, const float* gamma, const float* mean,
+                                const float* rstd, int64_t rows, int cols, float p, uint64_t seed, void* dz_f32, void* dx_bf16,
+                                float* dgamma, float* dbeta, float* ws, void* stream) {
+    if (!dy_f32 || !x_bf16 || !res_f32 || !gamma || !mean || !rstd || !dz_f32 || !dx_bf16 || !dgamma || !dbeta || !ws || rows <= 0 || cols <= 0)
+        return fail(TRX_NN_EINVAL, "add_layernorm_bwd_mixed: bad argument");
+    if (!(p >= 0.f && p < 1.f)) return fail(TRX_NN_EINVAL, "dropout probability must be in [0, 1)");
+    if (cols % 4 != 0 || cols > 64 * NCH * 4) return fail(TRX_NN_EINVAL, "add_layernorm_bwd_mixed: cols must be a multiple of 4 and <= 1024");
+    if (((reinterpret_cast<uintptr_t>(res_f32) | reinterpret_cast<uintptr_t>(dy_f32) | reinterpret_cast<uintptr_t>(dz_f32)) & 15) ||
+        ((reinterpret_cast<uintptr_t>(x_bf16) | reinterpret_cast<uintptr_t>(dx_bf16)) & 7))
+        return fail(TRX_NN_EINVAL, "add_layernorm_bwd_mixed: operands must be 16-byte (x, dx: 8-byte) aligned");
+    const Drop drop = make_drop(p, seed, 0);
+    const int nblk = trx_add_layernorm_bwd_blocks(rows);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = (size_t)cols * 8 * sizeof(float);
+    hipLaunchKernelGGL((add_ln_bwd_vec_kernel<false, true>), dim3(nblk), dim3(256), lds, st, dy_f32, x_bf16, res_f32, gamma, mean, rstd,
+                       rows, cols, dz_f32, dx_bf16, ws, nblk, drop);
+    hipLaunchKernelGGL(add_ln_bwd_reduce_kernel, dim3((cols + 15) / 16, 2), dim3(256), 0, st, ws, nblk, cols, dgamma, dbeta);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? TRX_NN_OK : fail(TRX_NN_EHIP, hipGetErrorString(e));
 }
 
 int trx_dropout_keep_mask(uint64_t seed, float p, int64_t streams, int64_t rows, int64_t cols, unsigned char* keep, void* stream) {

@@ -1,0 +1,83 @@
+"""Dense embedding producer + on-device retrieval: the step BEFORE the flat index.
+
+The reference obtains its 768-d text / reaction embeddings from an external dense retriever
+(README.md:44-47: a Tevatron bi-encoder -- BERT encoder, the [CLS] hidden state as the embedding,
+dot-product similarity), writes them to disk, searches them with FAISS and converts the ranking with
+retrieve/convert_format.py:6-16.  Here the same three steps stay on the GPU: the BERT encoder of
+`predictor/model.py` (attention and LayerNorm through libtrxnn.so) produces [N, 768] embeddings
+directly in HBM, they are added to the flat index (libtrxknn.so) as bf16 without a host round trip,
+and the neighbours come back as the neighbor-file structure `textreact/dataset.py:40-44` reads.
+Tokenisation stays outside (the reference's tokenizer files are not part of the repo): inputs are
+token ids + attention masks.
+
+    enc = DenseEncoder(Config(vocab_size=31090)).cuda().eval()      # BERT-base shape = SciBERT's
+    enc.load_state_dict(tevatron_state_dict, strict=False)            # HF parameter names
+    corpus = encode(enc, corpus_ids, corpus_mask)                      # [N, 768] bf16 on the GPU
+    index = build_index(corpus)                                        # IndexFlatIP in HBM
+    result = retrieve(enc, index, query_ids, query_mask, query_keys, corpus_keys, k=10)
+    neighbors.write_neighbors("train.json", result)
+"""
+import torch
+import torch.nn as nn
+
+from . import faiss_compat as faiss
+from .neighbors import build_result
+from .predictor.model import BertEncoder, Config, additive_key_mask  # noqa: F401  (Config re-exported)
+
+
+class DenseEncoder(nn.Module):
+    """BERT encoder + [CLS] pooling (Tevatron's DenseModel.encode_passage / encode_query without a
+    projection head).  Parameter names are the Hugging Face ones under `encoder.` exactly as in
+    TextReactModel, so a predictor checkpoint's encoder or a Tevatron `model.lm_q` / `lm_p`
+    state dict loads with the prefix renamed."""
+
+    def __init__(self, cfg, backend="hip", normalize=False):
+        super().__init__()
+        self.encoder = BertEncoder(cfg)
+        self.backend, self.normalize = backend, normalize
+
+    def forward(self, input_ids, attention_mask=None):
+        if attention_mask is None:
+            attention_mask = torch.ones_like(input_ids)
+        h = self.encoder(input_ids, additive_key_mask(attention_mask), None, None, None, self.backend)
+        cls = h[:, 0]
+        return torch.nn.functional.normalize(cls.float(), dim=-1).to(cls.dtype) if self.normalize else cls
+
+
+@torch.no_grad()
+def encode(model, input_ids, attention_mask=None, batch_size=256, out_dtype=torch.bfloat16, autocast=True):
+    """[N, L] token ids -> [N, hidden] embeddings on the model's device, in batches; eval mode, and by
+    default bf16 autocast (the matrix-core attention path).  The ids may live on the host: only one
+    batch at a time is moved."""
+    dev = next(model.parameters()).device
+    was_training = model.training
+    model.eval()
+    out = torch.empty((input_ids.shape[0], model.encoder.embeddings.word_embeddings.embedding_dim), dtype=out_dtype, device=dev)
+    try:
+        for lo in range(0, input_ids.shape[0], batch_size):
+            ids = input_ids[lo:lo + batch_size].to(dev)
+            am = None if attention_mask is None else attention_mask[lo:lo + batch_size].to(dev)
+            if autocast and dev.type == "cuda":
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    e = model(ids, am)
+            else:
+                e = model(ids, am)
+            out[lo:lo + ids.shape[0]] = e.to(out_dtype)
+    finally:
+        model.train(was_training)
+    return out
+
+
+def build_index(embeddings, metric=faiss.METRIC_INNER_PRODUCT):
+    """flat index over embeddings that are already on the GPU (bf16 / fp32): no host copy"""
+    index = faiss.IndexFlat(embeddings.shape[1], metric, device=embeddings.device.index or 0)
+    index.add(embeddings)
+    return index
+
+
+def retrieve(model, index, query_ids, query_mask, query_keys, corpus_keys, k=10, batch_size=256):
+    """encode the queries, search, and return the neighbor-file structure
+    [{'id': query key, 'nn': [corpus key, ...]}] (retrieve_faiss.py:116; convert_format.py:6-16)."""
+    q = encode(model, query_ids, query_mask, batch_size)
+    _, rank = index.search(q, k)
+    return build_result(query_keys, rank.cpu().numpy(), corpus_keys)

@@ -20,7 +20,8 @@ MASK_NONE, MASK_KEY, MASK_FULL = 0, 1, 2
 SYMBOLS = ["trx_add_layernorm_fwd", "trx_add_layernorm_bwd", "trx_add_layernorm_bwd_blocks",
            "trx_attention_fwd", "trx_attention_fwd_lse", "trx_attention_bwd",
            "trx_add_layernorm_fwd_dropout", "trx_add_layernorm_bwd_dropout", "trx_attention_fwd_dropout",
-           "trx_attention_bwd_dropout", "trx_dropout_keep_mask", "trx_nn_last_error", "trx_nn_version"]
+           "trx_attention_bwd_dropout", "trx_dropout_keep_mask", "trx_add_layernorm_fwd_mixed",
+           "trx_add_layernorm_bwd_mixed", "trx_nn_last_error", "trx_nn_version"]
 
 
 class TrxNNError(RuntimeError):
@@ -47,6 +48,8 @@ def lib():
         L.trx_attention_bwd_dropout.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, i32, f32, u64,
                                                 vp, vp, vp, vp, vp, vp, vp]
         L.trx_dropout_keep_mask.argtypes = [u64, f32, i64, i64, i64, vp, vp]
+        L.trx_add_layernorm_fwd_mixed.argtypes = [vp, vp, vp, vp, f32, i64, i32, f32, u64, vp, vp, vp, vp]
+        L.trx_add_layernorm_bwd_mixed.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, f32, u64, vp, vp, vp, vp, vp, vp]
         L.trx_nn_last_error.restype = ctypes.c_char_p
         L.trx_nn_version.restype = ctypes.c_char_p
         _lib = L
@@ -134,12 +137,60 @@ class _AddLayerNorm(torch.autograd.Function):
         return (dx if p > 0 else dz), (dz if ctx.has_res else None), dg, db, None, None, None
 
 
+class _AddLayerNormMixed(torch.autograd.Function):
+    """x bf16 (a dense output under autocast), res / y fp32 (the residual stream)"""
+
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta, eps, p, seed):
+        _need_gpu(x)
+        xs, rs = x.contiguous(), res.contiguous()
+        cols = xs.shape[-1]
+        rows = xs.numel() // cols
+        y = torch.empty_like(rs)
+        need = x.requires_grad or res.requires_grad or gamma.requires_grad
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device) if need else None
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if need else None
+        g, b = gamma.float().contiguous(), beta.float().contiguous()
+        _check(lib().trx_add_layernorm_fwd_mixed(_p(xs), _p(rs), _p(g), _p(b), float(eps), rows, cols, float(p), int(seed),
+                                                 _p(y), _p(mean), _p(rstd), _stream(xs)))
+        if need:
+            ctx.save_for_backward(xs, rs, g, mean, rstd)
+            ctx.drop = (float(p), int(seed))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xs, rs, g, mean, rstd = ctx.saved_tensors
+        p, seed = ctx.drop
+        dy = dy.float().contiguous()
+        cols = xs.shape[-1]
+        rows = xs.numel() // cols
+        nblk = lib().trx_add_layernorm_bwd_blocks(rows)
+        ws = torch.empty(2 * nblk * cols, dtype=torch.float32, device=xs.device)
+        dz, dx = torch.empty_like(rs), torch.empty_like(xs)
+        dg = torch.empty(cols, dtype=torch.float32, device=xs.device)
+        db = torch.empty(cols, dtype=torch.float32, device=xs.device)
+        _check(lib().trx_add_layernorm_bwd_mixed(_p(dy), _p(xs), _p(rs), _p(g), _p(mean), _p(rstd), rows, cols, p, seed,
+                                                 _p(dz), _p(dx), _p(dg), _p(db), _p(ws), _stream(xs)))
+        return dx, dz, dg, db, None, None, None
+
+
 def add_layernorm(x, res, gamma, beta, eps, backend="hip", dropout_p=0.0, seed=None):
     """LayerNorm(dropout(x) + res) * gamma + beta over the last dimension; res may be None.
     dropout_p > 0 (training): x is dropped before the residual is added, as BertSelfOutput /
     BertOutput / BertEmbeddings do; `seed` picks the decisions (default: a fresh one)."""
     if dropout_p > 0 and seed is None:
         seed = new_seed()
+    if res is not None and res.dtype != x.dtype:
+        # autocast: dense outputs are bf16 while the residual stream stays fp32 (torch runs layer_norm in
+        # fp32 under autocast, so does the reference): the mixed kernels read x as bf16 and keep the
+        # stream in fp32; anything else is widened to one storage type first.
+        cols = x.shape[-1]
+        if (backend == "hip" and x.dtype == torch.bfloat16 and res.dtype == torch.float32 and cols % 4 == 0
+                and cols <= 1024 and x.is_cuda):
+            return _AddLayerNormMixed.apply(x, res, gamma, beta, eps, float(dropout_p), 0 if seed is None else seed)
+        wide = torch.promote_types(x.dtype, res.dtype)
+        x, res = x.to(wide), res.to(wide)
     if backend == "hip":
         return _AddLayerNorm.apply(x, res, gamma, beta, eps, float(dropout_p), 0 if seed is None else seed)
     if dropout_p > 0 and not x.is_cuda:     # module tree on a box without a GPU: torch's own dropout
