@@ -372,3 +372,15 @@ def test_add_layernorm_mixed_storage(rows, cols, p):
     tols = (3e-5, 1e-2, 3e-5, 3e-5, 3e-5)     # dx is rounded to bf16 once
     for a, c, tol in zip(*res, tols):
         assert float((a - c).abs().max()) <= tol * max(1.0, float(c.abs().max()))
+
+
+def test_beam_search_on_the_hip_ops_matches_the_huggingface_golden():
+    """the decode loop (KV cache, one-token attention against the cache, cross-attention over the encoder
+    states) through the HIP ops reproduces what `generate` returned for the reference model"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_generate_cpu import check_case, golden_model
+    z, dec, m = golden_model(backend="hip")
+    m = m.cuda()
+    for i, c in enumerate(json.loads(str(z["cases"]))):
+        check_case(z, dec, m, i, c, dev="cuda", tol=1e-3)

@@ -1,0 +1,222 @@
+"""Beam-search decoding for the predictor's test step (textreact/main.py:218-233).
+
+The reference calls Hugging Face `generate` on its EncoderDecoderModel:
+
+    output = self.model.generate(**batch_in, num_beams=num_beams, num_return_sequences=num_beams,
+                                 max_length=self.args.max_dec_length, length_penalty=0,
+                                 bos_token_id=..., eos_token_id=..., pad_token_id=...,
+                                 return_dict_in_generate=True, output_scores=True)
+
+i.e. deterministic beam search (no sampling, no logits processors, `early_stopping=False`), or greedy
+search when num_beams == 1.  This module restates that algorithm -- transformers 4.27.3
+`GenerationMixin.beam_search` + `BeamSearchScorer.process / finalize` + `BeamHypotheses`, the version
+the reference pins -- over TextReactModel with a key/value cache: the encoder runs once, the
+cross-attention keys / values of every decoder layer are projected once, each step feeds one token per
+beam through the decoder (attention and add+LayerNorm through the same ops as training), and the
+self-attention cache is re-ordered by the surviving beams' parents.
+
+Golden: tests/golden/generate_small.npz holds what `generate` itself returns for the reference model
+(tests/golden/make_generate_golden.py); sequences agree up to the padding after the end token (4.27.3
+pads with pad_token_id, the transformers 5.x that produced the golden repeats the end token;
+`batch_decode(skip_special_tokens=True)`, what main.py:227 does next, erases both), scores to 1e-4.
+"""
+import torch
+
+from . import ops
+
+
+class _BeamHypotheses:
+    """n-best list of finished hypotheses of one batch item ([3P] generation/beam_search.py: BeamHypotheses)"""
+
+    def __init__(self, num_beams, length_penalty, early_stopping):
+        self.num_beams, self.length_penalty, self.early_stopping = num_beams, length_penalty, early_stopping
+        self.beams = []
+        self.worst_score = 1e9
+
+    def __len__(self):
+        return len(self.beams)
+
+    def add(self, hyp, sum_logprobs):
+        score = sum_logprobs / (hyp.shape[-1] ** self.length_penalty)
+        if len(self) < self.num_beams or score > self.worst_score:
+            self.beams.append((score, hyp))
+            if len(self) > self.num_beams:
+                ranked = sorted((s, i) for i, (s, _) in enumerate(self.beams))
+                del self.beams[ranked[0][1]]
+                self.worst_score = ranked[1][0]
+            else:
+                self.worst_score = min(score, self.worst_score)
+
+    def is_done(self, best_sum_logprobs, cur_len):
+        if len(self) < self.num_beams:
+            return False
+        if self.early_stopping is True:
+            return True
+        if self.early_stopping is False:
+            return self.worst_score >= best_sum_logprobs / cur_len ** self.length_penalty
+        # "never"
+        if self.length_penalty > 0.0:
+            raise ValueError("early_stopping='never' with a positive length penalty needs max_length here")
+        return self.worst_score >= best_sum_logprobs / cur_len ** self.length_penalty
+
+
+class _DecoderState:
+    """encoder output, per-layer cross-attention K / V (projected once) and the self-attention cache"""
+
+    def __init__(self, model, input_ids, attention_mask, expand, max_length):
+        from .model import additive_key_mask
+        self.model, self.be = model, model.backend
+        dec = model.decoder.roberta
+        if attention_mask is None:
+            attention_mask = torch.ones_like(input_ids)
+        key = additive_key_mask(attention_mask)
+        enc = model.encoder(input_ids, key, None, None, None, self.be)
+        self.enc_states = enc
+        enc = enc.repeat_interleave(expand, dim=0)
+        self.key = key.repeat_interleave(expand, dim=0)
+        n, L, _ = enc.shape
+        self.layers = list(dec.encoder.layer)
+        H = self.layers[0].attention.heads
+        self.H = H
+        self.kx = [ly.crossattention.self.key(enc).view(n, L, H, 64) for ly in self.layers]
+        self.vx = [ly.crossattention.self.value(enc).view(n, L, H, 64) for ly in self.layers]
+        dt, dev = self.kx[0].dtype, enc.device
+        self.kc = [torch.zeros((n, max_length, H, 64), dtype=dt, device=dev) for _ in self.layers]
+        self.vc = [torch.zeros((n, max_length, H, 64), dtype=dt, device=dev) for _ in self.layers]
+        self.pad = dec.embeddings.pad
+
+    def step(self, tokens, t):
+        """tokens [n] = the tokens at position t; returns log-probabilities [n, vocab] of position t + 1"""
+        m, be, H = self.model, self.be, self.H
+        emb = m.decoder.roberta.embeddings
+        ids = tokens[:, None]
+        # RoBERTa positions with a cache: (1 + past length) for real tokens, the padding index for padding
+        pos = torch.where(ids.ne(self.pad), torch.full_like(ids, t + 1 + self.pad), torch.full_like(ids, self.pad))
+        h = emb(ids, pos, None, be)
+        n = h.shape[0]
+        for li, ly in enumerate(self.layers):
+            at = ly.attention
+            q = at.self.query(h).view(n, 1, H, 64)
+            self.kc[li][:, t] = at.self.key(h).view(n, H, 64)
+            self.vc[li][:, t] = at.self.value(h).view(n, H, 64)
+            ctx = ops.attention(q, self.kc[li][:, :t + 1], self.vc[li][:, :t + 1], mask=None, causal=False, backend=be)
+            h = ops.add_layernorm(at.output.dense(ctx), h, at.output.LayerNorm.weight, at.output.LayerNorm.bias, at.eps, backend=be)
+            ca = ly.crossattention
+            q = ca.self.query(h).view(n, 1, H, 64)
+            ctx = ops.attention(q, self.kx[li], self.vx[li], mask=self.key, causal=False, backend=be)
+            h = ops.add_layernorm(ca.output.dense(ctx), h, ca.output.LayerNorm.weight, ca.output.LayerNorm.bias, ca.eps, backend=be)
+            f = torch.nn.functional.gelu(ly.intermediate.dense(h))
+            h = ops.add_layernorm(ly.output.dense(f), h, ly.output.LayerNorm.weight, ly.output.LayerNorm.bias, ly.eps, backend=be)
+        logits = m.decoder.lm_head(h, be)[:, -1]
+        return torch.log_softmax(logits.float(), dim=-1)
+
+    def reorder(self, parents, t):
+        """keep the caches of the surviving beams' parents (positions 0..t are filled)"""
+        for li in range(len(self.layers)):
+            self.kc[li][:, :t + 1] = self.kc[li][:, :t + 1].index_select(0, parents)
+            self.vc[li][:, :t + 1] = self.vc[li][:, :t + 1].index_select(0, parents)
+
+
+@torch.no_grad()
+def generate(model, input_ids, attention_mask=None, num_beams=1, num_return_sequences=None, max_length=20,
+             length_penalty=1.0, early_stopping=False, bos_token_id=None, eos_token_id=None, pad_token_id=0):
+    """-> (sequences [B * num_return_sequences, T] int64, sequences_scores [B * num_return_sequences] or None).
+    Same argument meaning as the `generate` call at main.py:218-226; greedy search for num_beams == 1
+    (sequences_scores is None then, as with Hugging Face, and main.py:228-231 reports zeros)."""
+    was_training = model.training
+    model.eval()
+    try:
+        if num_beams == 1:
+            return _greedy(model, input_ids, attention_mask, max_length, bos_token_id, eos_token_id, pad_token_id), None
+        return _beam_search(model, input_ids, attention_mask, num_beams, num_return_sequences or 1, max_length,
+                            length_penalty, early_stopping, bos_token_id, eos_token_id, pad_token_id)
+    finally:
+        model.train(was_training)
+
+
+def _greedy(model, input_ids, attention_mask, max_length, bos, eos, pad):
+    B, dev = input_ids.shape[0], input_ids.device
+    st = _DecoderState(model, input_ids, attention_mask, 1, max_length)
+    seqs = torch.full((B, 1), bos, dtype=torch.long, device=dev)
+    unfinished = torch.ones(B, dtype=torch.long, device=dev)
+    for t in range(max_length - 1):
+        nxt = st.step(seqs[:, -1], t).argmax(dim=-1)
+        nxt = nxt * unfinished + pad * (1 - unfinished)
+        seqs = torch.cat([seqs, nxt[:, None]], dim=1)
+        if eos is not None:
+            unfinished = unfinished * nxt.ne(eos).long()
+        if int(unfinished.max()) == 0:
+            break
+    return seqs
+
+
+def _beam_search(model, input_ids, attention_mask, nb, keep, max_length, length_penalty, early_stopping, bos, eos, pad):
+    B, dev = input_ids.shape[0], input_ids.device
+    st = _DecoderState(model, input_ids, attention_mask, nb, max_length)
+    seqs = torch.full((B * nb, 1), bos, dtype=torch.long, device=dev)
+    beam_scores = torch.zeros((B, nb), dtype=torch.float32, device=dev)
+    beam_scores[:, 1:] = -1e9                        # all beams start identical: only the first one counts
+    beam_scores = beam_scores.view(-1)
+    hyps = [_BeamHypotheses(nb, length_penalty, early_stopping) for _ in range(B)]
+    done = [False] * B
+    for t in range(max_length - 1):
+        cur_len = seqs.shape[1]
+        logp = st.step(seqs[:, -1], t)
+        vocab = logp.shape[-1]
+        scores = (logp + beam_scores[:, None]).view(B, nb * vocab)
+        top_s, top_i = torch.topk(scores, 2 * nb, dim=1, largest=True, sorted=True)
+        top_beam = torch.div(top_i, vocab, rounding_mode="floor")
+        top_tok = top_i % vocab
+        # BeamSearchScorer.process, on the host like the original (B * 2 * nb scalars per step)
+        s_l, b_l, t_l = top_s.tolist(), top_beam.tolist(), top_tok.tolist()
+        seqs_host = None
+        nscore = torch.zeros((B, nb), dtype=torch.float32)
+        ntok = torch.full((B, nb), pad, dtype=torch.long)
+        nidx = torch.zeros((B, nb), dtype=torch.long)
+        for b in range(B):
+            if done[b]:
+                continue                                       # zeros / pad / beam 0, as initialised
+            slot = 0
+            for rank in range(2 * nb):
+                tok, sc, parent = t_l[b][rank], s_l[b][rank], b * nb + b_l[b][rank]
+                if eos is not None and tok == eos:
+                    if rank >= nb:                             # an end token outside the top num_beams is ignored
+                        continue
+                    if seqs_host is None:
+                        seqs_host = seqs.cpu()
+                    hyps[b].add(seqs_host[parent].clone(), sc)
+                else:
+                    nscore[b, slot], ntok[b, slot], nidx[b, slot] = sc, tok, parent
+                    slot += 1
+                if slot == nb:
+                    break
+            if slot < nb:
+                raise ValueError("fewer than num_beams non-end candidates: increase the vocabulary or lower num_beams")
+            done[b] = done[b] or hyps[b].is_done(max(s_l[b]), cur_len)
+        beam_scores = nscore.view(-1).to(dev)
+        parents = nidx.view(-1).to(dev)
+        st.reorder(parents, t)
+        seqs = torch.cat([seqs.index_select(0, parents), ntok.view(-1, 1).to(dev)], dim=1)
+        if all(done) or seqs.shape[1] >= max_length:
+            break
+    # BeamSearchScorer.finalize
+    seqs_host, final = seqs.cpu(), beam_scores.cpu().tolist()
+    for b in range(B):
+        if done[b]:
+            continue
+        for j in range(nb):
+            hyps[b].add(seqs_host[b * nb + j], final[b * nb + j])
+    best, best_scores = [], []
+    for b in range(B):
+        ranked = sorted(hyps[b].beams, key=lambda x: x[0])
+        for _ in range(keep):
+            sc, hyp = ranked.pop()
+            best.append(hyp); best_scores.append(sc)
+    lengths = [int(h.shape[0]) for h in best]
+    width = min(max(lengths) + 1, max_length)
+    out = torch.full((len(best), width), pad, dtype=torch.long)
+    for i, h in enumerate(best):
+        out[i, :lengths[i]] = h
+        if lengths[i] < width:
+            out[i, lengths[i]] = eos
+    return out.to(dev), torch.tensor(best_scores, dtype=torch.float32, device=dev)

@@ -93,6 +93,27 @@ class Predictor(nn.Module):
         return {int(i): float(s) for i, s in zip(indices, scores)}
 
 
+# main.py:198-233 (template-free branch): beam search, num_return_sequences = num_beams
+def test_step(predictor, indices, batch_in, num_beams, max_dec_length, bos_token_id, eos_token_id, pad_token_id=0,
+              decode=None):
+    """{idx: {'prediction': [...num_beams items...], 'score': [...]}} as test_step stores it.  `decode` maps a
+    [n, T] tensor of token ids to n strings (the reference's dec_tokenizer.batch_decode(...,
+    skip_special_tokens=True)); without it the predictions are the token-id lists with the special tokens
+    removed, which is what that call strips."""
+    from .generate import generate
+    seqs, scores = generate(predictor.model, batch_in["input_ids"], batch_in.get("attention_mask"), num_beams=num_beams,
+                            num_return_sequences=num_beams, max_length=max_dec_length, length_penalty=0,
+                            bos_token_id=bos_token_id, eos_token_id=eos_token_id, pad_token_id=pad_token_id)
+    if decode is not None:
+        preds = decode(seqs)
+    else:
+        special = {bos_token_id, eos_token_id, pad_token_id}
+        preds = [[int(t) for t in row if int(t) not in special] for row in seqs.cpu().numpy()]
+    score_list = scores.tolist() if scores is not None else [0] * len(preds)
+    return {int(idx): {"prediction": preds[i * num_beams:(i + 1) * num_beams],
+                       "score": score_list[i * num_beams:(i + 1) * num_beams]} for i, idx in enumerate(indices)}
+
+
 def gather_outputs(outputs, group=None):
     """main.py:259-268: merge the per-rank {idx: value} dicts on every rank"""
     import torch.distributed as dist
