@@ -384,3 +384,13 @@ def test_beam_search_on_the_hip_ops_matches_the_huggingface_golden():
     m = m.cuda()
     for i, c in enumerate(json.loads(str(z["cases"]))):
         check_case(z, dec, m, i, c, dev="cuda", tol=1e-3)
+
+
+def test_template_based_branch_on_the_hip_ops():
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_template_cpu import check, load
+    z, m, batch = load(backend="hip")
+    m = m.cuda()
+    batch = {k: (v.cuda() if torch.is_tensor(v) else ([t.cuda() for t in v] if k == "atom_indices" else v)) for k, v in batch.items()}
+    check(z, m, batch, 1e-3)
