@@ -64,3 +64,28 @@ def test_nn_library_exports_the_header_symbols():
         assert hasattr(L, s)
     assert L.trx_attention_fwd(None, None, None, None, 0, 0, 1, 1, 1, 1, 1.0, 0, None, None) == -1
     assert b"bad argument" in L.trx_nn_last_error()
+
+
+def test_embedding_tables_grow_and_keep_their_rows():
+    import torch
+    from textreact_amd.predictor.model import (Config, TextReactModel, expand_position_embeddings, expand_word_embeddings,
+                                               gather_prediction_each_neighbor)
+    m = TextReactModel(Config(vocab_size=50, hidden_size=128, num_hidden_layers=1, num_attention_heads=2, intermediate_size=64,
+                              max_position_embeddings=16),
+                       Config(vocab_size=20, hidden_size=128, num_hidden_layers=1, num_attention_heads=2, intermediate_size=64,
+                              max_position_embeddings=16, is_decoder=True), backend="torch").eval()
+    ids = torch.randint(1, 50, (2, 16)); dids = torch.randint(1, 20, (2, 5))
+    with torch.no_grad():
+        a = m(ids, None, dids)[0]
+    pos, word = m.encoder.embeddings.position_embeddings.weight.clone(), m.encoder.embeddings.word_embeddings.weight.clone()
+    expand_position_embeddings(m.encoder, 40); expand_word_embeddings(m.encoder, 70)
+    expand_position_embeddings(m.encoder, 8)                              # never shrinks
+    assert m.encoder.embeddings.position_embeddings.weight.shape[0] == 40 and m.encoder.embeddings.word_embeddings.weight.shape[0] == 70
+    assert torch.equal(m.encoder.embeddings.position_embeddings.weight[:16], pos)
+    assert torch.equal(m.encoder.embeddings.word_embeddings.weight[:50], word)
+    with torch.no_grad():
+        assert torch.equal(a, m(ids, None, dids)[0])                       # old inputs, same outputs
+        m(torch.randint(50, 70, (2, 40)), None, dids)                      # the new rows are usable
+    merged = gather_prediction_each_neighbor({0: {"prediction": ["a"], "score": [1.0]}, 1: {"prediction": ["b"], "score": [.5]},
+                                              2: {"prediction": ["c"], "score": [.2]}}, 2)
+    assert merged == {0: {"prediction": ["a", "b"], "score": [1.0, .5]}, 1: {"prediction": ["c"], "score": [.2]}}

@@ -242,3 +242,39 @@ def random_state_dict(model, seed):
     sd["decoder.lm_head.decoder.weight"] = sd["decoder.roberta.embeddings.word_embeddings.weight"]
     sd["decoder.lm_head.decoder.bias"] = sd["decoder.lm_head.bias"]
     return sd
+
+
+# ---- embedding-table growth (textreact/utils.py:18-44, called from model.py:32-35) -------------------------
+def expand_position_embeddings(encoder, max_length):
+    """grow the encoder's position table to max_length rows, old rows kept (new rows: nn.Embedding's init)"""
+    emb = encoder.embeddings
+    old = emb.position_embeddings.weight.data
+    if max_length <= old.shape[0]:
+        return
+    new = nn.Embedding(max_length, old.shape[1]).to(old.device, old.dtype)
+    new.weight.data[:old.shape[0]] = old
+    emb.position_embeddings = new
+
+
+def expand_word_embeddings(encoder, vocab_size):
+    """grow the encoder's word table to vocab_size rows (--encoder_tokenizer smiles_text), old rows kept"""
+    emb = encoder.embeddings
+    old = emb.word_embeddings.weight.data
+    if vocab_size <= old.shape[0]:
+        return
+    new = nn.Embedding(vocab_size, old.shape[1], padding_idx=emb.word_embeddings.padding_idx).to(old.device, old.dtype)
+    new.weight.data[:old.shape[0]] = old
+    emb.word_embeddings = new
+
+
+def gather_prediction_each_neighbor(prediction, num_neighbors):
+    """--test_each_neighbor: predictions of the num_neighbors copies of one example merged (utils.py:55-64)"""
+    results = {}
+    for i, pred in sorted(prediction.items()):
+        idx = i // num_neighbors
+        if idx not in results:
+            results[idx] = pred
+        else:
+            for key in results[idx]:
+                results[idx][key] += pred[key]
+    return results
