@@ -89,3 +89,16 @@ def test_embedding_tables_grow_and_keep_their_rows():
     merged = gather_prediction_each_neighbor({0: {"prediction": ["a"], "score": [1.0]}, 1: {"prediction": ["b"], "score": [.5]},
                                               2: {"prediction": ["c"], "score": [.2]}}, 2)
     assert merged == {0: {"prediction": ["a", "b"], "score": [1.0, .5]}, 1: {"prediction": ["c"], "score": [.2]}}
+
+
+def test_top_k_accuracies_follow_evaluate_py():
+    import pandas as pd
+    from textreact_amd.predictor.evaluate import CONDITION_COLS, evaluate_reaction_condition, evaluate_retrosynthesis
+    df = pd.DataFrame([["c", "s1", "", "r1", ""], ["", "s2", "s3", "r2", "r3"], ["", "", "", "", ""]], columns=CONDITION_COLS)
+    pred = {0: {"prediction": [["x", "", "", "", ""], ["c", "s1", "", "r1", ""]]},      # hit at rank 2
+            1: {"prediction": [["", "s2", "s3", "r2", "r3"]]}}                           # hit at rank 1; example 2 unpredicted
+    acc = evaluate_reaction_condition(pred, df)
+    assert acc == {1: 1 / 3, 3: 2 / 3, 5: 2 / 3, 10: 2 / 3, 15: 2 / 3}
+    retro = evaluate_retrosynthesis({0: {"prediction": ["CCO", "CC"]}, 1: {"prediction": ["N", "O", "C"]}}, ["CC", "S"],
+                                    canonical=lambda s: s)
+    assert retro == {1: 0.0, 2: 0.5, 3: 0.5, 5: 0.5, 10: 0.5, 20: 0.5}
