@@ -1,0 +1,44 @@
+"""randomised shapes / metrics / input classes through the flat index against the CPU oracle, bit for bit:
+python3 tools/knn_fuzz.py [n_cases] [seed]"""
+import sys, os, random
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import textreact_amd.faiss_compat as faiss
+from oracle import flat_knn as oracle
+from _data import bf16_round, gaussian, grid, morgan_like, reaction_fp_like
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+nfail = 0
+for it in range(n_cases):
+    metric = rng.choice([0, 1])
+    kind = rng.choice(["gauss", "gauss_bf16", "grid", "fp", "dup"])
+    d = rng.choice([1, 3, 17, 64, 65, 100, 128, 200, 256, 300, 768, 1024])
+    n = rng.choice([1, 2, 7, 255, 256, 257, 1000, 5000, 20000, 60000])
+    nq = rng.choice([1, 2, 63, 64, 65, 255, 256, 257, 700])
+    k = rng.choice([1, 2, 10, 20, 24, 25, 64, 100])
+    if kind == "gauss":
+        y, x = gaussian(n, d, 2 * it), gaussian(nq, d, 2 * it + 1)
+    elif kind == "gauss_bf16":
+        y, x = bf16_round(gaussian(n, d, 2 * it)), bf16_round(gaussian(nq, d, 2 * it + 1))
+    elif kind == "grid":
+        y, x = grid(n, d, 2 * it), grid(nq, d, 2 * it + 1)
+    elif kind == "fp":
+        y, x = morgan_like(n, d, 2 * it).astype(np.float32), morgan_like(nq, d, 2 * it + 1).astype(np.float32)
+    else:   # clusters of exact duplicates: ties everywhere
+        base = gaussian(max(1, n // 8), d, 2 * it)
+        y = base[np.random.default_rng(it).integers(0, base.shape[0], n)]
+        x = gaussian(nq, d, 2 * it + 1)
+    idx = faiss.IndexFlat(d, metric)
+    chunks = rng.choice([1, 1, 3])
+    for part in np.array_split(y, chunks):
+        if part.shape[0]:
+            idx.add(part)
+    D, I = idx.search(x, k)
+    Dr, Ir = oracle.knn_canonical(metric, x, y, k)
+    ok = np.array_equal(I, Ir) and np.array_equal(D.view(np.uint32), Dr.view(np.uint32))
+    if not ok:
+        nfail += 1
+        bad = np.argwhere(I != Ir)
+        print("FAIL", it, dict(metric=metric, kind=kind, d=d, n=n, nq=nq, k=k, chunks=chunks), "first bad", bad[:3].tolist(), idx.last_stats())
+print(n_cases, "cases,", nfail, "failures")
