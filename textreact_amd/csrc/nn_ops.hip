@@ -482,40 +482,63 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 // (xd = hash input of this lane's row at the tile's first key pair, see drop_bits).
 template <bool VIS, bool DROP>
 __device__ __forceinline__ void attn_softmax_tile(f32x16& s0, f32x16& s1, f32x16& o0, f32x16& o1, float& m, float& lsum,
-                                                  float sl2, int key0, int hh, int klim, unsigned xd, unsigned thr) {
+                                                  float sl2, int key0, int hh, int klim, unsigned xd, unsigned thr,
+                                                  unsigned (&pk)[2][8]) {
+    // the maximum is taken on the raw scores (scale > 0 commutes with it); the scaling then rides in the
+    // exponent's fma: p = exp2(s * scale log2e - m)
     float mb = -__builtin_inff();
 #pragma unroll
     for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             const int kr_ = hb * 32 + (t & 3) + 8 * (t >> 2) + 4 * hh;
-            float val = (hb ? s1[t] : s0[t]) * sl2;
-            if (VIS) val = (key0 + kr_ > klim) ? -__builtin_inff() : val;
-            if (hb) s1[t] = val; else s0[t] = val;
+            float val = hb ? s1[t] : s0[t];
+            if (VIS) {
+                val = (key0 + kr_ > klim) ? -__builtin_inff() : val;
+                if (hb) s1[t] = val; else s0[t] = val;
+            }
             mb = fmaxf(mb, val);
         }
-    mb = fmaxf(mb, __shfl_xor(mb, 32, 64));
+    mb = fmaxf(mb, __shfl_xor(mb, 32, 64)) * sl2;
     const float mn = fmaxf(m, mb);
     const float mref = (mn == -__builtin_inff()) ? 0.f : mn;   // all hidden so far: exp2(-inf - 0) = 0, no NaN
     const float alpha = __builtin_amdgcn_exp2f(m - mref);
+    const float nref = -mref;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) s0[t] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[t], sl2, nref));
+#pragma unroll
+    for (int t = 0; t < 16; ++t) s1[t] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[t], sl2, nref));
     float ps = 0.f;
-#pragma unroll
-    for (int t = 0; t < 16; ++t) { s0[t] = __builtin_amdgcn_exp2f(s0[t] - mref); ps += s0[t]; }
-#pragma unroll
-    for (int t = 0; t < 16; ++t) { s1[t] = __builtin_amdgcn_exp2f(s1[t] - mref); ps += s1[t]; }
-    lsum = lsum * alpha + ps;
-    m = mn;
-#pragma unroll
-    for (int t = 0; t < 16; ++t) { o0[t] *= alpha; o1[t] *= alpha; }
     if (DROP) {
+        // the row sum takes every probability; the dropped ones are then zeroed for the P V product
+#pragma unroll
+        for (int t = 0; t < 16; ++t) ps += s0[t] + s1[t];
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
             for (int t = 0; t < 16; t += 2) {   // registers t, t+1 = keys 2c, 2c+1: one hash
                 const unsigned bits = lowbias32(xd + (unsigned)(hb * 16 + ((t & 3) >> 1) + 4 * (t >> 2)) * DROP_C2);
-                if (hb) { s1[t] = drop_keep(bits, 0, thr) ? s1[t] : 0.f; s1[t + 1] = drop_keep(bits, 1, thr) ? s1[t + 1] : 0.f; }
-                else { s0[t] = drop_keep(bits, 0, thr) ? s0[t] : 0.f; s0[t + 1] = drop_keep(bits, 1, thr) ? s0[t + 1] : 0.f; }
+                const float e0 = hb ? s1[t] : s0[t], e1 = hb ? s1[t + 1] : s0[t + 1];
+                pk[hb][t >> 1] = pack2bf(drop_keep(bits, 0, thr) ? e0 : 0.f, drop_keep(bits, 1, thr) ? e1 : 0.f);
             }
+    } else {
+        // pack to bf16 for the second product and sum THOSE values (v_dot2c_f32_bf16 with (1, 1)): one
+        // instruction per pair instead of two adds, and the normaliser matches what multiplies V
+        const bf16x2_t ones = __builtin_bit_cast(bf16x2_t, 0x3f803f80u);
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+            for (int t = 0; t < 16; t += 2) {
+                const unsigned w = pack2bf(hb ? s1[t] : s0[t], hb ? s1[t + 1] : s0[t + 1]);
+                pk[hb][t >> 1] = w;
+                ps = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w), ones, ps, false);
+            }
+    }
+    lsum = lsum * alpha + ps;
+    m = mn;
+    if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {   // wave-uniform: the running maximum moved for some lane
+#pragma unroll
+        for (int t = 0; t < 16; ++t) { o0[t] *= alpha; o1[t] *= alpha; }
     }
 }
 
@@ -707,13 +730,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DROP || MM
     asm volatile("s_waitcnt lgkmcnt(" #CNT ")"                                                                \
                  : "+v"(vt[S0][0][0]), "+v"(vt[S0][0][1]), "+v"(vt[S0][1][0]), "+v"(vt[S0][1][1]),            \
                    "+v"(vt[S1][0][0]), "+v"(vt[S1][0][1]), "+v"(vt[S1][1][0]), "+v"(vt[S1][1][1]) :: "memory");
-#define TRX_PV_STEP(S, SV)                                                                                    \
+#define TRX_PV_STEP(S, HB)                                                                                    \
     {                                                                                                         \
-        constexpr int ss = (S) & 1;                                                                           \
-        uint4 pw;                                                                                             \
-        pw.x = pack2bf(SV[8 * ss + 0], SV[8 * ss + 1]); pw.y = pack2bf(SV[8 * ss + 2], SV[8 * ss + 3]);       \
-        pw.z = pack2bf(SV[8 * ss + 4], SV[8 * ss + 5]); pw.w = pack2bf(SV[8 * ss + 6], SV[8 * ss + 7]);       \
-        const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);                                                     \
+        constexpr int ss = (S) & 1;   /* k-step S = keys 16 S .. 16 S + 15 = pairs 4 ss .. 4 ss + 3 of half HB */ \
+        const bf16x8 pf = __builtin_bit_cast(bf16x8, uint4{pk[HB][4 * ss], pk[HB][4 * ss + 1], pk[HB][4 * ss + 2], pk[HB][4 * ss + 3]}); \
         uint4 v0; v0.x = vt[S][0][0].x; v0.y = vt[S][0][0].y; v0.z = vt[S][0][1].x; v0.w = vt[S][0][1].y;     \
         uint4 v1; v1.x = vt[S][1][0].x; v1.y = vt[S][1][0].y; v1.z = vt[S][1][1].x; v1.w = vt[S][1][1].y;     \
         o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v0), pf, o0, 0, 0, 0);        \
@@ -722,14 +742,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DROP || MM
         TRX_VT_READ(0) TRX_VT_READ(1)
         const bool vis = key0 + 63 > klim_wave_min;   // wave-uniform: some key of the tile is hidden for some lane
         const unsigned xd = xdrop + (unsigned)(kb * 32) * DROP_C2;
-        if (vis) attn_softmax_tile<true, DROP>(s0, s1, o0, o1, m, lsum, sl2, key0, hh, klim, xd, da.thr);
-        else attn_softmax_tile<false, DROP>(s0, s1, o0, o1, m, lsum, sl2, key0, hh, klim, xd, da.thr);
+        unsigned pk[2][8];   // the tile's probabilities as bf16 pairs: the B operands of the second product
+        if (vis) attn_softmax_tile<true, DROP>(s0, s1, o0, o1, m, lsum, sl2, key0, hh, klim, xd, da.thr, pk);
+        else attn_softmax_tile<false, DROP>(s0, s1, o0, o1, m, lsum, sl2, key0, hh, klim, xd, da.thr, pk);
         // ---- O^T += V^T P^T: second half's reads fly under the first half's MFMAs ----
         TRX_VT_READ(2) TRX_VT_READ(3)
         TRX_VT_WAIT(0, 1, 8)
-        TRX_PV_STEP(0, s0) TRX_PV_STEP(1, s0)
+        TRX_PV_STEP(0, 0) TRX_PV_STEP(1, 0)
         TRX_VT_WAIT(2, 3, 0)
-        TRX_PV_STEP(2, s1) TRX_PV_STEP(3, s1)
+        TRX_PV_STEP(2, 1) TRX_PV_STEP(3, 1)
         buf = buf1;
     }
     }
