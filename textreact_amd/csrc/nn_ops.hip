@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256) void add_ln_bwd_reduce_kernel(const float* ws,
 // operand: no LDS, no barriers.  q and the running output stay in registers (2 x 64 VGPRs), keys are
 // consumed in chunks of 8 with an online softmax.  FLOPs = 4 * B * H * Lq * Lk * 64.
 constexpr int DH = 64, KC = 8;
-template <bool BF>
+template <bool BF, bool DROP>   // DROP is a template flag: the hash in the key loop costs the plain variant its scalar registers
 __global__ __launch_bounds__(64) void attention_fwd_kernel(const void* __restrict__ q, const void* __restrict__ k,
                                                            const void* __restrict__ v, const float* __restrict__ mask,
                                                            int mask_mode, int causal, int B, int H, int Lq, int Lk,
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(64) void attention_fwd_kernel(const void* __restric
     const int i = qb * 64 + threadIdx.x;
     const bool live = i < Lq;
     const int ii = live ? i : Lq - 1;
-    const unsigned dbase = da.thr ? drop_base(da.seed_lo, da.seed_hi, (unsigned)(b * H + h)) : 0u;
+    const unsigned dbase = DROP ? drop_base(da.seed_lo, da.seed_hi, (unsigned)(b * H + h)) : 0u;
     float qr[DH], o[DH];
     const int64_t qoff = (((int64_t)b * Lq + ii) * H + h) * DH;
 #pragma unroll
@@ -440,7 +440,7 @@ __global__ __launch_bounds__(64) void attention_fwd_kernel(const void* __restric
             // finite large negative value behave like the reference: exp underflows to 0)
             float pj = (j < Lk && j <= jmax_row) ? __expf(s[c] - mn) : 0.f;
             l += pj;
-            if (da.thr) pj = drop_keep(drop_bits(dbase, (unsigned)ii, (unsigned)j >> 1), (unsigned)j, da.thr) ? pj : 0.f;
+            if (DROP) pj = drop_keep(drop_bits(dbase, (unsigned)ii, (unsigned)j >> 1), (unsigned)j, da.thr) ? pj : 0.f;
             const int64_t voff = (((int64_t)b * Lk + jj) * H + h) * DH;
 #pragma unroll
             for (int d = 0; d < DH; ++d) o[d] = __builtin_fmaf(pj, ld<BF>(v, voff + d), o[d]);
@@ -449,7 +449,7 @@ __global__ __launch_bounds__(64) void attention_fwd_kernel(const void* __restric
     }
     if (live && lse) lse[((int64_t)b * H + h) * Lq + i] = m + __logf(l);
     if (live) {
-        const float inv = (da.thr ? da.inv_keep : 1.0f) / l;
+        const float inv = (DROP ? da.inv_keep : 1.0f) / l;
         const int64_t ooff = ((int64_t)b * Lq + i) * H * DH + (int64_t)h * DH;
 #pragma unroll
         for (int d = 0; d < DH; ++d) st<BF>(out, ooff + d, o[d] * inv);
@@ -784,7 +784,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DROP || MM
 //                                   dQ_i = scale * sum_j dS_ij K_j
 // pass 2 (a lane per key row j):    dV_j = sum_i p_ij dO_i ;  dK_j = scale * sum_i dS_ij Q_i
 // In both passes the "other" operand row (K_j, V_j / Q_i, dO_i) is wave-uniform -> scalar loads.
-template <bool BF>
+template <bool BF, bool DROP>
 __global__ __launch_bounds__(64) void attention_bwd_dq_kernel(const void* __restrict__ q, const void* __restrict__ k,
                                                               const void* __restrict__ v, const float* __restrict__ mask,
                                                               int mask_mode, int causal, int B, int H, int Lq, int Lk,
@@ -796,7 +796,7 @@ __global__ __launch_bounds__(64) void attention_bwd_dq_kernel(const void* __rest
     const int i = qb * 64 + threadIdx.x;
     const bool live = i < Lq;
     const int ii = live ? i : Lq - 1;
-    const unsigned dbase = da.thr ? drop_base(da.seed_lo, da.seed_hi, (unsigned)(b * H + h)) : 0u;
+    const unsigned dbase = DROP ? drop_base(da.seed_lo, da.seed_hi, (unsigned)(b * H + h)) : 0u;
     float qr[DH], dor[DH], acc[DH];
     const int64_t qoff = (((int64_t)b * Lq + ii) * H + h) * DH;
     const int64_t ooff = ((int64_t)b * Lq + ii) * H * DH + (int64_t)h * DH;
@@ -817,7 +817,7 @@ __global__ __launch_bounds__(64) void attention_bwd_dq_kernel(const void* __rest
         if (mask_mode == TRX_NN_MASK_KEY) s += mask[(int64_t)b * Lk + j];
         else if (mask_mode == TRX_NN_MASK_FULL) s += mask[((int64_t)b * Lq + ii) * Lk + j];
         const float p = j <= jmax_row ? __expf(s - L) : 0.f;
-        if (da.thr) dp = drop_keep(drop_bits(dbase, (unsigned)ii, (unsigned)j >> 1), (unsigned)j, da.thr) ? dp * da.inv_keep : 0.f;
+        if (DROP) dp = drop_keep(drop_bits(dbase, (unsigned)ii, (unsigned)j >> 1), (unsigned)j, da.thr) ? dp * da.inv_keep : 0.f;
         const float ds = p * (dp - delta);
 #pragma unroll
         for (int d = 0; d < DH; ++d) acc[d] = __builtin_fmaf(ds, ld<BF>(k, koff + d), acc[d]);
@@ -828,7 +828,7 @@ __global__ __launch_bounds__(64) void attention_bwd_dq_kernel(const void* __rest
     }
 }
 
-template <bool BF>
+template <bool BF, bool DROP>
 __global__ __launch_bounds__(64) void attention_bwd_dkv_kernel(const void* __restrict__ q, const void* __restrict__ k,
                                                                const void* __restrict__ v, const float* __restrict__ mask,
                                                                int mask_mode, int causal, int B, int H, int Lq, int Lk,
@@ -837,7 +837,7 @@ __global__ __launch_bounds__(64) void attention_bwd_dkv_kernel(const void* __res
     const int kblocks = (Lk + 63) / 64;
     const int bid = blockIdx.x;
     const int kb = bid % kblocks, h = (bid / kblocks) % H, b = bid / (kblocks * H);
-    const unsigned dbase = da.thr ? drop_base(da.seed_lo, da.seed_hi, (unsigned)(b * H + h)) : 0u;
+    const unsigned dbase = DROP ? drop_base(da.seed_lo, da.seed_hi, (unsigned)(b * H + h)) : 0u;
     const int j = kb * 64 + threadIdx.x;
     const bool live = j < Lk;
     const int jj = live ? j : Lk - 1;
@@ -864,7 +864,7 @@ __global__ __launch_bounds__(64) void attention_bwd_dkv_kernel(const void* __res
         const bool vis = !causal || jj <= i + (Lk - Lq);
         const float p = vis ? __expf(s - L) : 0.f;
         float pd = p;   // the probability as the forward used it for the output: dropped and rescaled
-        if (da.thr) {
+        if (DROP) {
             const float km = drop_keep(drop_bits(dbase, (unsigned)i, (unsigned)jj >> 1), (unsigned)jj, da.thr) ? da.inv_keep : 0.f;
             pd = p * km; dp *= km;
         }
@@ -1038,8 +1038,12 @@ int trx_attention_fwd_dropout(const void* q, const void* k, const void* v, const
             else TRX_LAUNCH_MFMA(TRX_NN_MASK_FULL, false);
         }
 #undef TRX_LAUNCH_MFMA
-    } else if (dtype == TRX_NN_BF16) hipLaunchKernelGGL(attention_fwd_kernel<true>, grid, block, 0, st, q, k, v, mask, mask_mode, causal, B, H, Lq, Lk, scale, out, lse, da);
-    else hipLaunchKernelGGL(attention_fwd_kernel<false>, grid, block, 0, st, q, k, v, mask, mask_mode, causal, B, H, Lq, Lk, scale, out, lse, da);
+    } else {
+#define TRX_LAUNCH_VALU(BF_, DROP_) hipLaunchKernelGGL((attention_fwd_kernel<BF_, DROP_>), grid, block, 0, st, q, k, v, mask, mask_mode, causal, B, H, Lq, Lk, scale, out, lse, da)
+        if (dtype == TRX_NN_BF16) { if (da.thr) TRX_LAUNCH_VALU(true, true); else TRX_LAUNCH_VALU(true, false); }
+        else { if (da.thr) TRX_LAUNCH_VALU(false, true); else TRX_LAUNCH_VALU(false, false); }
+#undef TRX_LAUNCH_VALU
+    }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? TRX_NN_OK : fail(TRX_NN_EHIP, hipGetErrorString(e));
 }
@@ -1100,13 +1104,14 @@ int trx_attention_bwd_dropout(const void* q, const void* k, const void* v, const
         if (e1 != hipSuccess) return fail(TRX_NN_EHIP, hipGetErrorString(e1));
         return TRX_NN_OK;
     }
-    if (dtype == TRX_NN_BF16) {
-        hipLaunchKernelGGL(attention_bwd_dq_kernel<true>, gq, block, 0, st, q, k, v, mask, mask_mode, causal, B, H, Lq, Lk, scale, out, dout, lse, dq, da);
-        hipLaunchKernelGGL(attention_bwd_dkv_kernel<true>, gk, block, 0, st, q, k, v, mask, mask_mode, causal, B, H, Lq, Lk, scale, out, dout, lse, dk, dv, da);
-    } else {
-        hipLaunchKernelGGL(attention_bwd_dq_kernel<false>, gq, block, 0, st, q, k, v, mask, mask_mode, causal, B, H, Lq, Lk, scale, out, dout, lse, dq, da);
-        hipLaunchKernelGGL(attention_bwd_dkv_kernel<false>, gk, block, 0, st, q, k, v, mask, mask_mode, causal, B, H, Lq, Lk, scale, out, dout, lse, dk, dv, da);
-    }
+#define TRX_LAUNCH_VALU_BWD(BF_, DROP_)                                                                                     \
+    hipLaunchKernelGGL((attention_bwd_dq_kernel<BF_, DROP_>), gq, block, 0, st, q, k, v, mask, mask_mode, causal, B, H, Lq, Lk, \
+                       scale, out, dout, lse, dq, da);                                                                      \
+    hipLaunchKernelGGL((attention_bwd_dkv_kernel<BF_, DROP_>), gk, block, 0, st, q, k, v, mask, mask_mode, causal, B, H, Lq, Lk, \
+                       scale, out, dout, lse, dk, dv, da)
+    if (dtype == TRX_NN_BF16) { if (da.thr) { TRX_LAUNCH_VALU_BWD(true, true); } else { TRX_LAUNCH_VALU_BWD(true, false); } }
+    else { if (da.thr) { TRX_LAUNCH_VALU_BWD(false, true); } else { TRX_LAUNCH_VALU_BWD(false, false); } }
+#undef TRX_LAUNCH_VALU_BWD
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? TRX_NN_OK : fail(TRX_NN_EHIP, hipGetErrorString(e));
 }
