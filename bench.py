@@ -107,6 +107,9 @@ def main():
     ap.add_argument("--n-corpus", type=int, default=N_CORPUS)
     ap.add_argument("--n-queries", type=int, default=N_QUERIES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--weak", action="store_true",
+                    help="weak scaling: --n-corpus rows PER GPU (BASELINE.json configs[2]: 8 GPUs x 1M rows = 8M); "
+                         "default is strong scaling, the 1M-row corpus row-sharded over the GPUs")
     ap.add_argument("--workload", default="dense", choices=["dense", "fingerprint"],
                     help="dense = the headline (BASELINE.json configs[1]); fingerprint = the reference's own call: "
                          "IndexFlatL2, k=20, 2048-d integer reaction fingerprints, train set searching itself (not the headline)")
@@ -137,7 +140,7 @@ def main():
     import textreact_amd.faiss_compat as faiss
     from textreact_amd.sharded import ShardedFlatIndex, shard_bounds
 
-    n, d, nq, k = args.n_corpus, DIM, args.n_queries, TOPK
+    n, d, nq, k = args.n_corpus * (world if args.weak else 1), DIM, args.n_queries, TOPK
     if args.workload == "fingerprint":
         return fingerprint_workload(args, dev, local_rank)
     lo, hi = shard_bounds(n, world, rank)
@@ -178,7 +181,7 @@ def main():
         achieved = flops_launch / (mean_launch_ms * 1e-3) / 1e12 if mean_launch_ms > 0 else 0.0
         traffic = None
         tf = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tf) and world == 1 and n == N_CORPUS and nq == N_QUERIES:
+        if os.path.exists(tf) and world == 1 and n == N_CORPUS and nq == N_QUERIES:   # measured for exactly this launch
             try:
                 traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
             except Exception:
@@ -186,7 +189,7 @@ def main():
         line = {
             "metric": "queries/sec top-10 over 1Mx768 corpus", "value": value, "unit": "queries/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16",
+            "higher_is_better": True, "scaling": "weak" if args.weak else "strong", "vs_baseline": None, "dtype": "bf16",
             "data": "synthetic",
             "config": {"workload": "exact IP top-%d, %dx%d bf16 corpus row-sharded %d-way, %d queries per step"
                                    % (k, n, d, world, nq),
