@@ -129,3 +129,28 @@ def test_merge_lists_equals_unsharded():
             Dl.append(d); Il.append(np.where(i >= 0, i + off, i))
         Dm, Im = oracle.merge_lists(metric, np.stack(Dl), np.stack(Il))
         assert np.array_equal(Im, I) and np.array_equal(Dm, D)
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+def test_oracle_agrees_with_an_independent_exact_search(metric):
+    """FAISS is not installed here (the oracle's header says 'parity unpinned'), but scikit-learn is: its
+    brute-force NearestNeighbors is an independent exact k-NN.  On Gaussian data (no exact ties) both of
+    the oracle's statements must return its neighbours, in its order, up to pairs whose scores differ by
+    less than float32 can resolve."""
+    from sklearn.neighbors import NearestNeighbors
+    from _data import gaussian
+    y, x = gaussian(4000, 96, 41), gaussian(150, 96, 42)
+    k = 10
+    if metric == 1:
+        nn = NearestNeighbors(n_neighbors=k, algorithm="brute", metric="euclidean").fit(y.astype(np.float64))
+        _, ids = nn.kneighbors(x.astype(np.float64))
+    else:   # inner product: brute force on float64 scores
+        ids = np.argsort(-(x.astype(np.float64) @ y.astype(np.float64).T), axis=1, kind="stable")[:, :k]
+    s = (x.astype(np.float64) @ y.astype(np.float64).T) if metric == 0 else \
+        -((x.astype(np.float64)[:, None, :] - y.astype(np.float64)[None, :, :]) ** 2).sum(-1)
+    for name in ("knn_canonical", "knn_faiss"):
+        _, I = getattr(oracle, name)(metric, x, y, k)
+        diff = np.argwhere(I != ids)
+        for q, j in diff:   # only near-ties may differ
+            assert abs(s[q, I[q, j]] - s[q, ids[q, j]]) <= 1e-4 * max(1.0, abs(s[q, ids[q, j]])), (name, q, j)
+        assert len(diff) <= 0.01 * ids.size, (name, len(diff))
