@@ -44,6 +44,13 @@ int trx_add_layernorm_bwd_blocks(int64_t rows);
 int trx_attention_fwd(const void* q, const void* k, const void* v, const float* mask, int mask_mode, int causal,
                       int B, int H, int Lq, int Lk, float scale, int dtype, void* out, void* stream);
 
+/* Inference against a key/value cache (beam-search decoding, main.py:218-226): k and v are the first Lk
+ * positions of cache tensors [B, Lmax, H, 64]; kv_batch_stride = Lmax * H * 64 elements between batch items,
+ * so no step has to compact the cache first.  Forward only. */
+int trx_attention_fwd_kvcache(const void* q, const void* k, const void* v, const float* mask, int mask_mode, int causal,
+                              int B, int H, int Lq, int Lk, int64_t kv_batch_stride, float scale, int dtype, void* out,
+                              void* stream);
+
 /* Same, additionally writing lse[B, H, Lq] = log sum_j exp(score_ij) (float), which the backward
  * pass needs to recompute the probabilities instead of storing the Lq x Lk matrix. */
 int trx_attention_fwd_lse(const void* q, const void* k, const void* v, const float* mask, int mask_mode, int causal,

@@ -394,3 +394,19 @@ def test_template_based_branch_on_the_hip_ops():
     m = m.cuda()
     batch = {k: (v.cuda() if torch.is_tensor(v) else ([t.cuda() for t in v] if k == "atom_indices" else v)) for k, v in batch.items()}
     check(z, m, batch, 1e-3)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+def test_attention_reads_a_key_value_cache_in_place(dtype, tol):
+    B, H, Lmax = 5, 12, 40
+    kc, vc = _rand(B, Lmax, H, 64, dtype=dtype, seed=2), _rand(B, Lmax, H, 64, dtype=dtype, seed=3)
+    for Lk in (1, 7, 33, 40):
+        q = _rand(B, 1, H, 64, dtype=dtype, seed=10 + Lk)
+        k, v = kc[:, :Lk], vc[:, :Lk]
+        assert Lk == Lmax or not k.is_contiguous()
+        with torch.no_grad():
+            out = ops.attention(q, k, v)                                   # strided: the kv-cache entry point
+            ref = ops.attention(q.float(), k.float(), v.float(), backend="torch")
+            same = ops.attention(q, k.contiguous(), v.contiguous())        # dense entry point
+        assert float((out.float() - ref).abs().max()) <= tol
+        assert torch.equal(out, same)

@@ -21,7 +21,9 @@ int fail(int code, const std::string& m) { g_err = m; return code; }
 // (lowbias32, two multiply-xorshift rounds) serves the two columns 2c, 2c+1 with 16 bits each;
 // an element is dropped when its 16 bits are below thr = round(p * 65536).
 struct Drop { unsigned base, thr; float inv_keep; };   // thr == 0: dropout off
-struct DropArgs { unsigned seed_lo, seed_hi, thr; float inv_keep; };   // attention: the base is per (batch, head)
+// attention: the dropout base is per (batch, head).  kv_bs: elements between consecutive batch items of k and
+// of v (0 = dense, Lk * H * 64); set by the key/value-cache entry point, forward kernels only
+struct DropArgs { unsigned seed_lo, seed_hi, thr; float inv_keep; long long kv_bs; };
 __host__ __device__ __forceinline__ unsigned lowbias32(unsigned x) {
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
     return x;
@@ -403,6 +405,7 @@ __global__ __launch_bounds__(64) void attention_fwd_kernel(const void* __restric
     const bool live = i < Lq;
     const int ii = live ? i : Lq - 1;
     const unsigned dbase = DROP ? drop_base(da.seed_lo, da.seed_hi, (unsigned)(b * H + h)) : 0u;
+    const int64_t kvbs = da.kv_bs ? da.kv_bs : (int64_t)Lk * H * DH;
     float qr[DH], o[DH];
     const int64_t qoff = (((int64_t)b * Lq + ii) * H + h) * DH;
 #pragma unroll
@@ -416,7 +419,7 @@ __global__ __launch_bounds__(64) void attention_fwd_kernel(const void* __restric
         for (int c = 0; c < KC; ++c) {
             const int j = j0 + c;
             const int jj = j < Lk ? j : Lk - 1;
-            const int64_t koff = (((int64_t)b * Lk + jj) * H + h) * DH;   // wave-uniform
+            const int64_t koff = (int64_t)b * kvbs + ((int64_t)jj * H + h) * DH;   // wave-uniform
             float a = 0.f;
 #pragma unroll
             for (int d = 0; d < DH; ++d) a = __builtin_fmaf(qr[d], ld<BF>(k, koff + d), a);
@@ -441,7 +444,7 @@ __global__ __launch_bounds__(64) void attention_fwd_kernel(const void* __restric
             float pj = (j < Lk && j <= jmax_row) ? __expf(s[c] - mn) : 0.f;
             l += pj;
             if (DROP) pj = drop_keep(drop_bits(dbase, (unsigned)ii, (unsigned)j >> 1), (unsigned)j, da.thr) ? pj : 0.f;
-            const int64_t voff = (((int64_t)b * Lk + jj) * H + h) * DH;
+            const int64_t voff = (int64_t)b * kvbs + ((int64_t)jj * H + h) * DH;
 #pragma unroll
             for (int d = 0; d < DH; ++d) o[d] = __builtin_fmaf(pj, ld<BF>(v, voff + d), o[d]);
         }
@@ -600,8 +603,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DROP || MM
     // Addresses are (uniform base + tile offset) + a per-lane 32-bit byte offset fixed for the kernel.
     const int prow = lane >> 3, pslot = lane & 7;
     const unsigned rowbytes = (unsigned)H * 128u;
-    const char* kbase = reinterpret_cast<const char*>(k + ((int64_t)b * Lk * H + h) * 64);
-    const char* vbase = reinterpret_cast<const char*>(v + ((int64_t)b * Lk * H + h) * 64);
+    const int64_t kvbs = da.kv_bs ? da.kv_bs : (int64_t)Lk * H * 64;
+    const char* kbase = reinterpret_cast<const char*>(k + (int64_t)b * kvbs + h * 64);
+    const char* vbase = reinterpret_cast<const char*>(v + (int64_t)b * kvbs + h * 64);
     unsigned kofs[2], vofs[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -1006,19 +1010,22 @@ static DropArgs make_drop_args(float p, uint64_t seed) {
     a.seed_lo = (unsigned)seed; a.seed_hi = (unsigned)(seed >> 32);
     a.thr = p > 0.f ? drop_thr(p) : 0u;
     a.inv_keep = 1.0f / (1.0f - p);
+    a.kv_bs = 0;
     return a;
 }
 
-int trx_attention_fwd_dropout(const void* q, const void* k, const void* v, const float* mask, int mask_mode, int causal,
-                              int B, int H, int Lq, int Lk, float scale, int dtype, float p, uint64_t seed, void* out,
-                              float* lse, void* stream) {
+static int attention_fwd_impl(const void* q, const void* k, const void* v, const float* mask, int mask_mode, int causal,
+                              int B, int H, int Lq, int Lk, int64_t kv_bs, float scale, int dtype, float p, uint64_t seed,
+                              void* out, float* lse, void* stream) {
     if (!q || !k || !v || !out || B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return fail(TRX_NN_EINVAL, "attention_fwd: bad argument");
+    if (kv_bs != 0 && kv_bs < (int64_t)Lk * H * 64) return fail(TRX_NN_EINVAL, "attention_fwd: key/value batch stride smaller than one batch item");
     if (mask_mode != TRX_NN_MASK_NONE && !mask) return fail(TRX_NN_EINVAL, "attention_fwd: mask is null");
     if (mask_mode < 0 || mask_mode > 2) return fail(TRX_NN_EINVAL, "attention_fwd: unknown mask mode");
     if (dtype != TRX_NN_F32 && dtype != TRX_NN_BF16) return fail(TRX_NN_EINVAL, "unknown dtype");
     if (!(p >= 0.f && p < 1.f)) return fail(TRX_NN_EINVAL, "dropout probability must be in [0, 1)");
     if (!(scale > 0.f)) return fail(TRX_NN_EINVAL, "attention_fwd: scale must be positive");
-    const DropArgs da = make_drop_args(p, seed);
+    DropArgs da = make_drop_args(p, seed);
+    da.kv_bs = kv_bs;
     const int qblocks = (Lq + 63) / 64;
     dim3 grid((unsigned)((int64_t)B * H * qblocks)), block(64);
     hipStream_t st = (hipStream_t)stream;
@@ -1046,6 +1053,18 @@ int trx_attention_fwd_dropout(const void* q, const void* k, const void* v, const
     }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? TRX_NN_OK : fail(TRX_NN_EHIP, hipGetErrorString(e));
+}
+
+int trx_attention_fwd_dropout(const void* q, const void* k, const void* v, const float* mask, int mask_mode, int causal,
+                              int B, int H, int Lq, int Lk, float scale, int dtype, float p, uint64_t seed, void* out,
+                              float* lse, void* stream) {
+    return attention_fwd_impl(q, k, v, mask, mask_mode, causal, B, H, Lq, Lk, 0, scale, dtype, p, seed, out, lse, stream);
+}
+
+int trx_attention_fwd_kvcache(const void* q, const void* k, const void* v, const float* mask, int mask_mode, int causal,
+                              int B, int H, int Lq, int Lk, int64_t kv_batch_stride, float scale, int dtype, void* out,
+                              void* stream) {
+    return attention_fwd_impl(q, k, v, mask, mask_mode, causal, B, H, Lq, Lk, kv_batch_stride, scale, dtype, 0.f, 0, out, nullptr, stream);
 }
 
 int trx_attention_fwd_lse(const void* q, const void* k, const void* v, const float* mask, int mask_mode, int causal,

@@ -21,7 +21,7 @@ SYMBOLS = ["trx_add_layernorm_fwd", "trx_add_layernorm_bwd", "trx_add_layernorm_
            "trx_attention_fwd", "trx_attention_fwd_lse", "trx_attention_bwd",
            "trx_add_layernorm_fwd_dropout", "trx_add_layernorm_bwd_dropout", "trx_attention_fwd_dropout",
            "trx_attention_bwd_dropout", "trx_dropout_keep_mask", "trx_add_layernorm_fwd_mixed",
-           "trx_add_layernorm_bwd_mixed", "trx_nn_last_error", "trx_nn_version"]
+           "trx_add_layernorm_bwd_mixed", "trx_attention_fwd_kvcache", "trx_nn_last_error", "trx_nn_version"]
 
 
 class TrxNNError(RuntimeError):
@@ -50,6 +50,7 @@ def lib():
         L.trx_dropout_keep_mask.argtypes = [u64, f32, i64, i64, i64, vp, vp]
         L.trx_add_layernorm_fwd_mixed.argtypes = [vp, vp, vp, vp, f32, i64, i32, f32, u64, vp, vp, vp, vp]
         L.trx_add_layernorm_bwd_mixed.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, f32, u64, vp, vp, vp, vp, vp, vp]
+        L.trx_attention_fwd_kvcache.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i64, f32, i32, vp, vp]
         L.trx_nn_last_error.restype = ctypes.c_char_p
         L.trx_nn_version.restype = ctypes.c_char_p
         _lib = L
@@ -253,6 +254,18 @@ def attention(q, k, v, mask=None, causal=False, scale=None, backend="hip", dropo
         _need_gpu(q)
         if D != 64:
             raise TrxNNError("the attention kernel is specialised for heads of 64 (got %d)" % D)
+        if (not (q.requires_grad or k.requires_grad or v.requires_grad) and dropout_p == 0 and not k.is_contiguous()
+                and k.stride() == v.stride() and k.stride()[1:] == (H * D, D, 1) and k.stride(0) >= Lk * H * D):
+            # the first Lk positions of a key/value cache [B, Lmax, H, 64]: read in place (decoding)
+            qc = q.contiguous()
+            mode, m = MASK_NONE, None
+            if mask is not None:
+                m = mask.float().contiguous()
+                mode = MASK_KEY if m.dim() == 2 else MASK_FULL
+            out = torch.empty((B, Lq, H * D), dtype=q.dtype, device=q.device)
+            _check(lib().trx_attention_fwd_kvcache(_p(qc), _p(k), _p(v), _p(m), mode, 1 if causal else 0, B, H, Lq, Lk,
+                                                   k.stride(0), float(scale), _dt(qc), _p(out), _stream(qc)))
+            return out
         return _Attention.apply(q, k, v, mask, causal, scale, float(dropout_p), 0 if seed is None else seed)
     qf, kf, vf = (t.float().permute(0, 2, 1, 3) for t in (q, k, v))             # [B, H, L, D]
     s = torch.matmul(qf, kf.transpose(-1, -2)) * scale
