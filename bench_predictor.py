@@ -63,6 +63,33 @@ def train_step_bench(dev, steps=5):
     return res
 
 
+def generate_bench(dev):
+    """test step (main.py:218-226): beam search with num_beams = 20 over max_dec_length = 160 (train_RetroSyn_tf.sh:33,43),
+    full-size model, bf16 autocast, random-init weights (no end token wins early: every beam runs the full length)"""
+    from textreact_amd.predictor.model import Config, TextReactModel
+    from textreact_amd.predictor.generate import generate
+    res = []
+    B, L, nb, T = 8, 512, 20, 160
+    g = torch.Generator().manual_seed(0)
+    ids = torch.randint(1, 31090, (B, L), generator=g).to(dev)
+    am = torch.ones(B, L, dtype=torch.long, device=dev)
+    for backend in ("hip", "torch"):
+        torch.manual_seed(0)
+        m = TextReactModel(Config(vocab_size=31090), Config(vocab_size=600, num_hidden_layers=6, type_vocab_size=1,
+                                                            layer_norm_eps=1e-5, is_decoder=True), backend=backend).to(dev).eval()
+
+        def run():
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                return generate(m, ids, am, num_beams=nb, num_return_sequences=nb, max_length=T, length_penalty=0,
+                                bos_token_id=12, eos_token_id=13, pad_token_id=0)
+        ms = timeit(run, iters=2, warm=1)
+        res.append({"kernel": "generate", "backend": backend, "dtype": "bf16 autocast", "B": B, "L": L, "num_beams": nb,
+                    "max_length": T, "ms": ms, "decoded_tokens_per_s": B * nb * (T - 1) / (ms * 1e-3)})
+        del m
+        torch.cuda.empty_cache()
+    return res
+
+
 def main():
     dev = "cuda"
     out = []
@@ -112,6 +139,7 @@ def main():
                     "ms": ms, "torch_eager_fp32_ms": ref,
                     "roofline": {"bound": "mfma", "achieved": tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": tf / 2500.0}})
     out.extend(train_step_bench(dev))
+    out.extend(generate_bench(dev))
     for o in out:
         print(json.dumps(o))
 
