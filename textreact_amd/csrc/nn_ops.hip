@@ -1,9 +1,13 @@
-// nn_ops.hip -- predictor hot spots on gfx950: fused residual-add + LayerNorm (forward, backward)
-// and attention forward.  C ABI in include/trx_nn.h.  Wave = 64.
+// nn_ops.hip -- predictor hot spots on gfx950.  C ABI in include/trx_nn.h.  Wave = 64.
 //
 // Replaces (inside the Hugging Face modules the reference instantiates at textreact/model.py:21-31):
-//   LayerNorm(dense(h) + residual)  -- BertSelfOutput / BertOutput / embeddings / lm_head
-//   softmax(q k^T / 8 + mask) v      -- Bert/Roberta self-, cross- and causal attention, heads of 64
+//   LayerNorm(dropout(dense(h)) + residual)  -- BertSelfOutput / BertOutput / embeddings / lm_head
+//   softmax(q k^T / 8 + mask) v, with dropout on the probabilities in training
+//                                            -- Bert/Roberta self-, cross- and causal attention, heads of 64
+// In this file: the dropout decision function; fused (dropout +) add + LayerNorm forward / backward
+// (vector kernels incl. the bf16-x / fp32-stream case of autocast, scalar fallbacks); attention forward
+// in fp32 (VALU, the <= 1e-3 parity path) and in bf16 on the matrix cores; the fp32 attention backward;
+// the C entry points.  The matrix-core attention backward is attn_bwd_mfma.h (included below).
 #include "../../include/trx_nn.h"
 #include <hip/hip_runtime.h>
 #include <string>
