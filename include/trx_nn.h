@@ -89,13 +89,16 @@ int trx_attention_bwd_dropout(const void* q, const void* k, const void* v, const
                               const void* dout, const float* lse, void* dq, void* dk, void* dv, void* stream);
 /* Mixed storage, the autocast case: x is a bf16 dense output, the residual stream (res, y) is fp32 --
  * torch runs layer_norm in fp32 under autocast and so does the reference's --precision 16-mixed.
- * cols % 4 == 0, cols <= 1024.  Backward: dy, dz fp32 (dz = gradient of res), dx bf16 (gradient of x,
- * through the dropout when p > 0), always written. */
+ * cols % 4 == 0, cols <= 1024.  y_bf16 (may be NULL): a bf16 copy of y for the Linear layers that
+ * consume it next -- the cast autocast would otherwise run per use.  Backward: dy_f32 (gradient that
+ * reached the fp32 y) and dy_bf16 (gradient that reached the bf16 copy), either may be NULL, are summed;
+ * dz fp32 (gradient of res), dx bf16 (gradient of x, through the dropout when p > 0), always written. */
 int trx_add_layernorm_fwd_mixed(const void* x_bf16, const void* res_f32, const float* gamma, const float* beta, float eps,
-                                int64_t rows, int cols, float p, uint64_t seed, void* y_f32, float* mean, float* rstd, void* stream);
-int trx_add_layernorm_bwd_mixed(const void* dy_f32, const void* x_bf16, const void* res_f32, const float* gamma, const float* mean,
-                                const float* rstd, int64_t rows, int cols, float p, uint64_t seed, void* dz_f32, void* dx_bf16,
-                                float* dgamma, float* dbeta, float* ws, void* stream);
+                                int64_t rows, int cols, float p, uint64_t seed, void* y_f32, void* y_bf16, float* mean, float* rstd,
+                                void* stream);
+int trx_add_layernorm_bwd_mixed(const void* dy_f32, const void* dy_bf16, const void* x_bf16, const void* res_f32, const float* gamma,
+                                const float* mean, const float* rstd, int64_t rows, int cols, float p, uint64_t seed, void* dz_f32,
+                                void* dx_bf16, float* dgamma, float* dbeta, float* ws, void* stream);
 /* keep[streams][rows][cols] (1 = kept) exactly as the kernels above decide for (seed, p). */
 int trx_dropout_keep_mask(uint64_t seed, float p, int64_t streams, int64_t rows, int64_t cols, unsigned char* keep, void* stream);
 

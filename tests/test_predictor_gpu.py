@@ -410,3 +410,31 @@ def test_attention_reads_a_key_value_cache_in_place(dtype, tol):
             same = ops.attention(q, k.contiguous(), v.contiguous())        # dense entry point
         assert float((out.float() - ref).abs().max()) <= tol
         assert torch.equal(out, same)
+
+
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_add_layernorm_dual_output_and_two_gradient_paths(p):
+    """autocast shape of the op: x bf16, stream fp32, outputs (y fp32, y bf16 copy); gradients arriving through
+    either output, or both, are summed in the kernel"""
+    rows, cols = 700, 768
+    x = _rand(rows, cols, dtype=torch.bfloat16, seed=1); r = _rand(rows, cols, seed=2)
+    g, b = _rand(cols, seed=3), _rand(cols, seed=4)
+    d32, d16 = _rand(rows, cols, seed=5), _rand(rows, cols, dtype=torch.bfloat16, seed=6)
+    for use32, use16 in ((True, True), (True, False), (False, True)):
+        res = []
+        for backend in ("hip", "torch"):
+            xs, rs = x.clone().requires_grad_(True), r.clone().requires_grad_(True)
+            gs, bs = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+            y, ylow = ops.add_layernorm(xs, rs, gs, bs, 1e-12, backend=backend, dropout_p=p, seed=5, dual=True)
+            if backend == "hip":
+                assert y.dtype == torch.float32 and ylow.dtype == torch.bfloat16
+                assert torch.equal(ylow, y.to(torch.bfloat16))
+            else:
+                ylow = y.to(torch.bfloat16)            # the statement: the low copy is a cast of y
+            loss = (y * d32).sum() * (1.0 if use32 else 0.0) + (ylow.float() * d16.float()).sum() * (1.0 if use16 else 0.0)
+            if backend == "hip":                       # really leave one output out of the graph
+                loss = ((y * d32).sum() if use32 else 0.0) + ((ylow.float() * d16.float()).sum() if use16 else 0.0)
+            loss.backward()
+            res.append((xs.grad.float(), rs.grad, gs.grad, bs.grad))
+        for a, c, tol in zip(*res, (1e-2, 3e-5, 3e-5, 3e-5)):
+            assert float((a - c).abs().max()) <= tol * max(1.0, float(c.abs().max())), (use32, use16)

@@ -129,7 +129,7 @@ __device__ __forceinline__ uint2 pack8bf(const float* f) { return make_uint2(pac
 template <bool BF, bool MIX>
 __global__ __launch_bounds__(256) void add_ln_fwd_vec_kernel(const void* x, const void* res, const float* gamma,
                                                              const float* beta, float eps, int64_t rows, int cols,
-                                                             void* y, float* mean, float* rstd, Drop drop) {
+                                                             void* y, float* mean, float* rstd, Drop drop, void* y16 = nullptr) {
     constexpr int V = Vec16<BF>::N;
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -181,6 +181,8 @@ __global__ __launch_bounds__(256) void add_ln_fwd_vec_kernel(const void* x, cons
 #pragma unroll
             for (int j = 0; j < V; ++j) o[j] = (v[i][j] - mu) * rs * gamma[c * V + j] + beta[c * V + j];
             *reinterpret_cast<uint4*>(yr + (size_t)c * 16) = pack16<BF>(o);
+            // MIX: a bf16 copy of the fp32 stream for the next Linear (what autocast would cast per use)
+            if (MIX && y16) *reinterpret_cast<uint2*>(reinterpret_cast<char*>(y16) + (size_t)row * cols * 2 + (size_t)c * 8) = pack8bf(o);
         }
     }
     if (lane == 0) { if (mean) mean[row] = mu; if (rstd) rstd[row] = rs; }
@@ -279,7 +281,8 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const void* dy, const v
 template <bool BF, bool MIX>
 __global__ __launch_bounds__(256) void add_ln_bwd_vec_kernel(const void* dy, const void* x, const void* res,
                                                              const float* gamma, const float* mean, const float* rstd,
-                                                             int64_t rows, int cols, void* dz, void* dx, float* ws, int nblk, Drop drop) {
+                                                             int64_t rows, int cols, void* dz, void* dx, float* ws, int nblk, Drop drop,
+                                                             const void* dy16 = nullptr) {
     extern __shared__ float sm[];  // [4 waves][2][cols]
     constexpr int V = Vec16<BF>::N;
     constexpr int ES = BF ? 2 : 4;
@@ -302,7 +305,14 @@ __global__ __launch_bounds__(256) void add_ln_bwd_vec_kernel(const void* dy, con
             const int c = lane + 64 * i;
             if (c < nchunk) {
                 float d[V], z[V];
-                unpack16<BF>(*reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(dy) + rb + (size_t)c * 16), d);
+                if (!MIX || dy) unpack16<BF>(*reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(dy) + rb + (size_t)c * 16), d);
+                else { _Pragma("unroll") for (int j = 0; j < V; ++j) d[j] = 0.f; }
+                if (MIX && dy16) {   // gradient that arrived through the bf16 copy of y
+                    float e[4];
+                    unpack8bf(*reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(dy16) + (rb >> 1) + (size_t)c * 8), e);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) d[j] += e[j];
+                }
                 if (MIX) unpack8bf(*reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(x) + (rb >> 1) + (size_t)c * 8), z);
                 else unpack16<BF>(*reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(x) + rb + (size_t)c * 16), z);
                 if (drop.thr) {
@@ -964,36 +974,38 @@ int trx_add_layernorm_bwd(const void* dy, const void* x, const void* res, const 
 }
 
 int trx_add_layernorm_fwd_mixed(const void* x_bf16, const void* res_f32, const float* gamma, const float* beta, float eps,
-                                int64_t rows, int cols, float p, uint64_t seed, void* y_f32, float* mean, float* rstd, void* stream) {
+                                int64_t rows, int cols, float p, uint64_t seed, void* y_f32, void* y_bf16, float* mean, float* rstd,
+                                void* stream) {
     if (!x_bf16 || !res_f32 || !gamma || !beta || !y_f32 || rows < 0 || cols <= 0) return fail(TRX_NN_EINVAL, "add_layernorm_fwd_mixed: bad argument");
     if (!(p >= 0.f && p < 1.f)) return fail(TRX_NN_EINVAL, "dropout probability must be in [0, 1)");
     if (cols % 4 != 0 || cols > 64 * NCH * 4) return fail(TRX_NN_EINVAL, "add_layernorm_fwd_mixed: cols must be a multiple of 4 and <= 1024");
-    if (((reinterpret_cast<uintptr_t>(res_f32) | reinterpret_cast<uintptr_t>(y_f32)) & 15) || (reinterpret_cast<uintptr_t>(x_bf16) & 7))
-        return fail(TRX_NN_EINVAL, "add_layernorm_fwd_mixed: operands must be 16-byte (x: 8-byte) aligned");
+    if (((reinterpret_cast<uintptr_t>(res_f32) | reinterpret_cast<uintptr_t>(y_f32)) & 15) ||
+        ((reinterpret_cast<uintptr_t>(x_bf16) | reinterpret_cast<uintptr_t>(y_bf16)) & 7))
+        return fail(TRX_NN_EINVAL, "add_layernorm_fwd_mixed: operands must be 16-byte (bf16 ones: 8-byte) aligned");
     if (rows == 0) return TRX_NN_OK;
     const Drop drop = make_drop(p, seed, 0);
     hipLaunchKernelGGL((add_ln_fwd_vec_kernel<false, true>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                       x_bf16, res_f32, gamma, beta, eps, rows, cols, y_f32, mean, rstd, drop);
+                       x_bf16, res_f32, gamma, beta, eps, rows, cols, y_f32, mean, rstd, drop, y_bf16);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? TRX_NN_OK : fail(TRX_NN_EHIP, hipGetErrorString(e));
 }
 
-int trx_add_layernorm_bwd_mixed(const void* dy_f32, const void* x_bf16, const void* res_f32, const float* gamma, const float* mean,
-                                const float* rstd, int64_t rows, int cols, float p, uint64_t seed, void* dz_f32, void* dx_bf16,
-                                float* dgamma, float* dbeta, float* ws, void* stream) {
-    if (!dy_f32 || !x_bf16 || !res_f32 || !gamma || !mean || !rstd || !dz_f32 || !dx_bf16 || !dgamma || !dbeta || !ws || rows <= 0 || cols <= 0)
+int trx_add_layernorm_bwd_mixed(const void* dy_f32, const void* dy_bf16, const void* x_bf16, const void* res_f32, const float* gamma,
+                                const float* mean, const float* rstd, int64_t rows, int cols, float p, uint64_t seed, void* dz_f32,
+                                void* dx_bf16, float* dgamma, float* dbeta, float* ws, void* stream) {
+    if ((!dy_f32 && !dy_bf16) || !x_bf16 || !res_f32 || !gamma || !mean || !rstd || !dz_f32 || !dx_bf16 || !dgamma || !dbeta || !ws || rows <= 0 || cols <= 0)
         return fail(TRX_NN_EINVAL, "add_layernorm_bwd_mixed: bad argument");
     if (!(p >= 0.f && p < 1.f)) return fail(TRX_NN_EINVAL, "dropout probability must be in [0, 1)");
     if (cols % 4 != 0 || cols > 64 * NCH * 4) return fail(TRX_NN_EINVAL, "add_layernorm_bwd_mixed: cols must be a multiple of 4 and <= 1024");
     if (((reinterpret_cast<uintptr_t>(res_f32) | reinterpret_cast<uintptr_t>(dy_f32) | reinterpret_cast<uintptr_t>(dz_f32)) & 15) ||
-        ((reinterpret_cast<uintptr_t>(x_bf16) | reinterpret_cast<uintptr_t>(dx_bf16)) & 7))
+        ((reinterpret_cast<uintptr_t>(x_bf16) | reinterpret_cast<uintptr_t>(dx_bf16) | reinterpret_cast<uintptr_t>(dy_bf16)) & 7))
         return fail(TRX_NN_EINVAL, "add_layernorm_bwd_mixed: operands must be 16-byte (x, dx: 8-byte) aligned");
     const Drop drop = make_drop(p, seed, 0);
     const int nblk = trx_add_layernorm_bwd_blocks(rows);
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = (size_t)cols * 8 * sizeof(float);
     hipLaunchKernelGGL((add_ln_bwd_vec_kernel<false, true>), dim3(nblk), dim3(256), lds, st, dy_f32, x_bf16, res_f32, gamma, mean, rstd,
-                       rows, cols, dz_f32, dx_bf16, ws, nblk, drop);
+                       rows, cols, dz_f32, dx_bf16, ws, nblk, drop, dy_bf16);
     hipLaunchKernelGGL(add_ln_bwd_reduce_kernel, dim3((cols + 15) / 16, 2), dim3(256), 0, st, ws, nblk, cols, dgamma, dbeta);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? TRX_NN_OK : fail(TRX_NN_EHIP, hipGetErrorString(e));

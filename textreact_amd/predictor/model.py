@@ -70,16 +70,18 @@ class Attention(nn.Module):
         self.heads, self.eps = cfg.num_attention_heads, cfg.layer_norm_eps
         self.p_attn, self.p_hidden = cfg.attention_probs_dropout_prob, cfg.hidden_dropout_prob
 
-    def forward(self, h, kv, mask, causal, backend):
+    def forward(self, h, h_low, kv_low, mask, causal, backend):
+        """h: the residual stream; h_low / kv_low: what the projections read (a bf16 copy of the stream under
+        autocast, the stream itself otherwise).  Returns the new (stream, low) pair."""
         B, Lq, Hd = h.shape
-        Lk = kv.shape[1]
-        q = self.self.query(h).view(B, Lq, self.heads, 64)
-        k = self.self.key(kv).view(B, Lk, self.heads, 64)
-        v = self.self.value(kv).view(B, Lk, self.heads, 64)
+        Lk = kv_low.shape[1]
+        q = self.self.query(h_low).view(B, Lq, self.heads, 64)
+        k = self.self.key(kv_low).view(B, Lk, self.heads, 64)
+        v = self.self.value(kv_low).view(B, Lk, self.heads, 64)
         ctx = ops.attention(q, k, v, mask=mask, causal=causal, backend=backend,
                             dropout_p=self.p_attn if self.training else 0.0)
         return ops.add_layernorm(self.output.dense(ctx), h, self.output.LayerNorm.weight, self.output.LayerNorm.bias,
-                                 self.eps, backend=backend, dropout_p=self.p_hidden if self.training else 0.0)
+                                 self.eps, backend=backend, dropout_p=self.p_hidden if self.training else 0.0, dual=True)
 
 
 class Intermediate(nn.Module):
@@ -98,13 +100,13 @@ class Layer(nn.Module):
         self.output = AttnOutput(cfg, in_features=cfg.intermediate_size)
         self.eps, self.cross, self.p_hidden = cfg.layer_norm_eps, cross, cfg.hidden_dropout_prob
 
-    def forward(self, h, self_mask, causal, enc, enc_mask, backend):
-        h = self.attention(h, h, self_mask, causal, backend)
+    def forward(self, h, h_low, self_mask, causal, enc_low, enc_mask, backend):
+        h, h_low = self.attention(h, h_low, h_low, self_mask, causal, backend)
         if self.cross:
-            h = self.crossattention(h, enc, enc_mask, False, backend)
-        f = torch.nn.functional.gelu(self.intermediate.dense(h))
+            h, h_low = self.crossattention(h, h_low, enc_low, enc_mask, False, backend)
+        f = torch.nn.functional.gelu(self.intermediate.dense(h_low))
         return ops.add_layernorm(self.output.dense(f), h, self.output.LayerNorm.weight, self.output.LayerNorm.bias,
-                                 self.eps, backend=backend, dropout_p=self.p_hidden if self.training else 0.0)
+                                 self.eps, backend=backend, dropout_p=self.p_hidden if self.training else 0.0, dual=True)
 
 
 class LayerStack(nn.Module):
@@ -157,8 +159,10 @@ class BertEncoder(nn.Module):
     def forward(self, input_ids, key_mask, position_ids, token_type_ids, full_mask, backend):
         h = self.embeddings(input_ids, position_ids, token_type_ids, backend)
         m = full_mask if full_mask is not None else key_mask
+        h_low = h
         for layer in self.encoder.layer:
-            h = layer(h, m, False, None, None, backend)
+            h, h_low = layer(h, h_low, m, False, None, None, backend)
+        self.last_low = h_low      # bf16 copy of the output under autocast (cross-attention reads it)
         return h
 
 
@@ -220,10 +224,12 @@ class TextReactModel(nn.Module):
             key = additive_key_mask(attention_mask)
         enc = self.encoder(input_ids, key, position_ids, token_type_ids, full, be)
         dmask = additive_key_mask(decoder_attention_mask) if decoder_attention_mask is not None else None
+        enc_low = self.encoder.last_low
         h = self.decoder.roberta.embeddings(decoder_input_ids, None, None, be)
+        h_low = h
         for layer in self.decoder.roberta.encoder.layer:
-            h = layer(h, dmask, True, enc, key, be)
-        return self.decoder.lm_head(h, be), enc
+            h, h_low = layer(h, h_low, dmask, True, enc_low, key, be)
+        return self.decoder.lm_head(h_low, be), enc
 
 
 def random_state_dict(model, seed):

@@ -48,8 +48,8 @@ def lib():
         L.trx_attention_bwd_dropout.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, i32, f32, u64,
                                                 vp, vp, vp, vp, vp, vp, vp]
         L.trx_dropout_keep_mask.argtypes = [u64, f32, i64, i64, i64, vp, vp]
-        L.trx_add_layernorm_fwd_mixed.argtypes = [vp, vp, vp, vp, f32, i64, i32, f32, u64, vp, vp, vp, vp]
-        L.trx_add_layernorm_bwd_mixed.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, f32, u64, vp, vp, vp, vp, vp, vp]
+        L.trx_add_layernorm_fwd_mixed.argtypes = [vp, vp, vp, vp, f32, i64, i32, f32, u64, vp, vp, vp, vp, vp]
+        L.trx_add_layernorm_bwd_mixed.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, u64, vp, vp, vp, vp, vp, vp]
         L.trx_attention_fwd_kvcache.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i64, f32, i32, vp, vp]
         L.trx_nn_last_error.restype = ctypes.c_char_p
         L.trx_nn_version.restype = ctypes.c_char_p
@@ -139,47 +139,65 @@ class _AddLayerNorm(torch.autograd.Function):
 
 
 class _AddLayerNormMixed(torch.autograd.Function):
-    """x bf16 (a dense output under autocast), res / y fp32 (the residual stream)"""
+    """x bf16 (a dense output under autocast), res / y fp32 (the residual stream); with `dual` also a bf16
+    copy of y for the Linear layers that read it next (the cast autocast would run per use), whose gradient
+    comes back as a second argument of backward and is summed inside the kernel"""
 
     @staticmethod
-    def forward(ctx, x, res, gamma, beta, eps, p, seed):
+    def forward(ctx, x, res, gamma, beta, eps, p, seed, dual):
         _need_gpu(x)
         xs, rs = x.contiguous(), res.contiguous()
         cols = xs.shape[-1]
         rows = xs.numel() // cols
         y = torch.empty_like(rs)
+        y16 = torch.empty_like(xs) if dual else None
         need = x.requires_grad or res.requires_grad or gamma.requires_grad
         mean = torch.empty(rows, dtype=torch.float32, device=x.device) if need else None
         rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if need else None
         g, b = gamma.float().contiguous(), beta.float().contiguous()
         _check(lib().trx_add_layernorm_fwd_mixed(_p(xs), _p(rs), _p(g), _p(b), float(eps), rows, cols, float(p), int(seed),
-                                                 _p(y), _p(mean), _p(rstd), _stream(xs)))
+                                                 _p(y), _p(y16), _p(mean), _p(rstd), _stream(xs)))
+        ctx.set_materialize_grads(False)
         if need:
             ctx.save_for_backward(xs, rs, g, mean, rstd)
             ctx.drop = (float(p), int(seed))
-        return y
+        return (y, y16) if dual else y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dy16=None):
         xs, rs, g, mean, rstd = ctx.saved_tensors
         p, seed = ctx.drop
-        dy = dy.float().contiguous()
         cols = xs.shape[-1]
         rows = xs.numel() // cols
+        if dy is None and dy16 is None:
+            return None, None, None, None, None, None, None, None
+        dy = dy.float().contiguous() if dy is not None else None
+        dy16 = dy16.to(torch.bfloat16).contiguous() if dy16 is not None else None
         nblk = lib().trx_add_layernorm_bwd_blocks(rows)
         ws = torch.empty(2 * nblk * cols, dtype=torch.float32, device=xs.device)
         dz, dx = torch.empty_like(rs), torch.empty_like(xs)
         dg = torch.empty(cols, dtype=torch.float32, device=xs.device)
         db = torch.empty(cols, dtype=torch.float32, device=xs.device)
-        _check(lib().trx_add_layernorm_bwd_mixed(_p(dy), _p(xs), _p(rs), _p(g), _p(mean), _p(rstd), rows, cols, p, seed,
+        _check(lib().trx_add_layernorm_bwd_mixed(_p(dy), _p(dy16), _p(xs), _p(rs), _p(g), _p(mean), _p(rstd), rows, cols, p, seed,
                                                  _p(dz), _p(dx), _p(dg), _p(db), _p(ws), _stream(xs)))
-        return dx, dz, dg, db, None, None, None
+        return dx, dz, dg, db, None, None, None, None
 
 
-def add_layernorm(x, res, gamma, beta, eps, backend="hip", dropout_p=0.0, seed=None):
+def add_layernorm(x, res, gamma, beta, eps, backend="hip", dropout_p=0.0, seed=None, dual=False):
     """LayerNorm(dropout(x) + res) * gamma + beta over the last dimension; res may be None.
     dropout_p > 0 (training): x is dropped before the residual is added, as BertSelfOutput /
-    BertOutput / BertEmbeddings do; `seed` picks the decisions (default: a fresh one)."""
+    BertOutput / BertEmbeddings do; `seed` picks the decisions (default: a fresh one).
+    dual=True returns (y, y_low): y_low is a bf16 copy of y written by the same kernel when x is bf16 and the
+    residual stream fp32 (autocast) -- for the Linear layers that read y next -- and y itself otherwise."""
+    if dual:
+        cols = x.shape[-1]
+        if (backend == "hip" and res is not None and x.dtype == torch.bfloat16 and res.dtype == torch.float32
+                and cols % 4 == 0 and cols <= 1024 and x.is_cuda):
+            if dropout_p > 0 and seed is None:
+                seed = new_seed()
+            return _AddLayerNormMixed.apply(x, res, gamma, beta, eps, float(dropout_p), 0 if seed is None else seed, True)
+        y = add_layernorm(x, res, gamma, beta, eps, backend=backend, dropout_p=dropout_p, seed=seed)
+        return y, y
     if dropout_p > 0 and seed is None:
         seed = new_seed()
     if res is not None and res.dtype != x.dtype:
@@ -189,7 +207,7 @@ def add_layernorm(x, res, gamma, beta, eps, backend="hip", dropout_p=0.0, seed=N
         cols = x.shape[-1]
         if (backend == "hip" and x.dtype == torch.bfloat16 and res.dtype == torch.float32 and cols % 4 == 0
                 and cols <= 1024 and x.is_cuda):
-            return _AddLayerNormMixed.apply(x, res, gamma, beta, eps, float(dropout_p), 0 if seed is None else seed)
+            return _AddLayerNormMixed.apply(x, res, gamma, beta, eps, float(dropout_p), 0 if seed is None else seed, False)
         wide = torch.promote_types(x.dtype, res.dtype)
         x, res = x.to(wide), res.to(wide)
     if backend == "hip":
