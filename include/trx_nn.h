@@ -99,6 +99,15 @@ int trx_add_layernorm_fwd_mixed(const void* x_bf16, const void* res_f32, const f
 int trx_add_layernorm_bwd_mixed(const void* dy_f32, const void* dy_bf16, const void* x_bf16, const void* res_f32, const float* gamma,
                                 const float* mean, const float* rstd, int64_t rows, int cols, float p, uint64_t seed, void* dz_f32,
                                 void* dx_bf16, float* dgamma, float* dbeta, float* ws, void* stream);
+/* Packed projections (bf16, matrix-core kernels): q, k, v (and dq, dk, dv) are slices of one projection
+ * output, e.g. [B, L, 3 * H * 64] from a single QKV GEMM.  ldq / ldkv = elements between consecutive
+ * tokens of q (dq) and of k, v (dk, dv); out, dout, lse are dense as above. */
+int trx_attention_fwd_strided(const void* q, const void* k, const void* v, const float* mask, int mask_mode, int causal,
+                              int B, int H, int Lq, int Lk, int ldq, int ldkv, float scale, float p, uint64_t seed, void* out,
+                              float* lse, void* stream);
+int trx_attention_bwd_strided(const void* q, const void* k, const void* v, const float* mask, int mask_mode, int causal,
+                              int B, int H, int Lq, int Lk, int ldq, int ldkv, float scale, float p, uint64_t seed, const void* out,
+                              const void* dout, const float* lse, void* dq, void* dk, void* dv, void* stream);
 /* keep[streams][rows][cols] (1 = kept) exactly as the kernels above decide for (seed, p). */
 int trx_dropout_keep_mask(uint64_t seed, float p, int64_t streams, int64_t rows, int64_t cols, unsigned char* keep, void* stream);
 

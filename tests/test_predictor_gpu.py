@@ -438,3 +438,43 @@ def test_add_layernorm_dual_output_and_two_gradient_paths(p):
             res.append((xs.grad.float(), rs.grad, gs.grad, bs.grad))
         for a, c, tol in zip(*res, (1e-2, 3e-5, 3e-5, 3e-5)):
             assert float((a - c).abs().max()) <= tol * max(1.0, float(c.abs().max())), (use32, use16)
+
+
+@pytest.mark.parametrize("B,H,L,Lk,mask,causal,p", [
+    (2, 12, 512, 512, "key", False, 0.0), (2, 3, 70, 70, "key", False, 0.1), (2, 4, 160, 160, "none", True, 0.1),
+    (1, 2, 129, 129, "full", False, 0.0), (2, 12, 160, 512, "key", False, 0.1), (1, 2, 33, 300, "none", False, 0.0),
+])
+def test_packed_projection_operands_equal_separate_tensors(B, H, L, Lk, mask, causal, p):
+    """q, k, v read as slices of one packed GEMM output (row strides), gradients written into the packed shape:
+    bit-identical to the kernels run on separate contiguous tensors"""
+    bf = torch.bfloat16
+    neg = torch.finfo(torch.float32).min
+    m = None
+    if mask == "key":
+        keep = torch.ones(B, Lk, device="cuda"); keep[0, Lk // 2 + 1:] = 0
+        m = (1 - keep) * neg
+    elif mask == "full":
+        keep = (torch.rand(B, L, Lk, device="cuda") > 0.3).float(); keep[:, :, 0] = 1
+        m = (1 - keep) * neg
+    dout = _rand(B, L, H * 64, dtype=bf, seed=4)
+    if L == Lk:   # self-attention: [B, L, 3, H, 64]
+        qkv = _rand(B, L, 3, H, 64, dtype=bf, seed=1)
+        a = qkv.clone().requires_grad_(True)
+        out = ops.attention_qkv(a, mask=m, causal=causal, dropout_p=p, seed=9)
+        out.backward(dout)
+        q, k, v = (t.contiguous().clone().requires_grad_(True) for t in qkv.unbind(dim=2))
+        ref = ops.attention(q, k, v, mask=m, causal=causal, dropout_p=p, seed=9)
+        ref.backward(dout)
+        assert torch.equal(out, ref)
+        for i, g in enumerate((q.grad, k.grad, v.grad)):
+            assert torch.equal(a.grad[:, :, i], g), i
+    else:         # cross-attention: q dense, [B, Lk, 2, H, 64] packed keys / values
+        q0, kv0 = _rand(B, L, H, 64, dtype=bf, seed=1), _rand(B, Lk, 2, H, 64, dtype=bf, seed=2)
+        q1, kv1 = q0.clone().requires_grad_(True), kv0.clone().requires_grad_(True)
+        out = ops.attention_q_kv(q1, kv1, mask=m, causal=causal, dropout_p=p, seed=9)
+        out.backward(dout)
+        q, k, v = q0.clone().requires_grad_(True), *(t.contiguous().clone().requires_grad_(True) for t in kv0.unbind(dim=2))
+        ref = ops.attention(q, k, v, mask=m, causal=causal, dropout_p=p, seed=9)
+        ref.backward(dout)
+        assert torch.equal(out, ref) and torch.equal(q1.grad, q.grad)
+        assert torch.equal(kv1.grad[:, :, 0], k.grad) and torch.equal(kv1.grad[:, :, 1], v.grad)

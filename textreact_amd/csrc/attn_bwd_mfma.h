@@ -105,13 +105,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int qb = bid % nqb, h = (bid / nqb) % H, b = bid / (nqb * H);
     const int qidx = qb * 128 + wave * 32 + r;
     const int qc = qidx < Lq ? qidx : Lq - 1;
+    const int ldq = da.ldq ? da.ldq : H * 64, ldk = da.ldk ? da.ldk : H * 64;
     bf16x8 qf[4], dof[4];
     {
-        const int64_t ro = (((int64_t)b * Lq + qc) * H + h) * 64 + 8 * hh;
+        const int64_t roq = ((int64_t)b * Lq + qc) * ldq + h * 64 + 8 * hh;      // q may be a slice of a packed projection
+        const int64_t rod = (((int64_t)b * Lq + qc) * H + h) * 64 + 8 * hh;      // dout is dense
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            qf[s] = *reinterpret_cast<const bf16x8*>(q + ro + 16 * s);
-            dof[s] = *reinterpret_cast<const bf16x8*>(dout + ro + 16 * s);
+            qf[s] = *reinterpret_cast<const bf16x8*>(q + roq + 16 * s);
+            dof[s] = *reinterpret_cast<const bf16x8*>(dout + rod + 16 * s);
         }
     }
     const float sl2 = scale * 1.44269504088896340736f;
@@ -133,9 +135,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const unsigned xdrop = DROP ? drop_base(da.seed_lo, da.seed_hi, (unsigned)(b * H + h)) + (unsigned)qidx * DROP_C1 + (unsigned)(2 * hh) * DROP_C2 : 0u;
 
     const int prow = lane >> 3, pslot = lane & 7;
-    const unsigned rowbytes = (unsigned)H * 128u;
-    const char* kbase = reinterpret_cast<const char*>(k + ((int64_t)b * Lk * H + h) * 64);
-    const char* vbase = reinterpret_cast<const char*>(v + ((int64_t)b * Lk * H + h) * 64);
+    const unsigned rowbytes = (unsigned)ldk * 2u;
+    const char* kbase = reinterpret_cast<const char*>(k + (int64_t)b * Lk * ldk + h * 64);
+    const char* vbase = reinterpret_cast<const char*>(v + (int64_t)b * Lk * ldk + h * 64);
     unsigned sofs[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -295,7 +297,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 #undef TRX_BWD1_STAGE
     if (qidx < Lq) {
-        bf16_t* op = dq + (((int64_t)b * Lq + qidx) * H + h) * 64;
+        bf16_t* op = dq + ((int64_t)b * Lq + qidx) * ldq + h * 64;
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {   // registers 4gq..4gq+3 = d rows 8gq + 4hh + 0..3
             uint2 w0, w1;
@@ -329,9 +331,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int kblk = bid % nkblk, h = (bid / nkblk) % H, b = bid / (nkblk * H);
     const int kidx = kblk * 128 + wave * 32 + r;   // this lane's key
     const int kc = kidx < Lk ? kidx : Lk - 1;
+    const int ldq = da.ldq ? da.ldq : H * 64, ldk = da.ldk ? da.ldk : H * 64;
     bf16x8 kf[4], vf[4];
     {
-        const int64_t ro = (((int64_t)b * Lk + kc) * H + h) * 64 + 8 * hh;
+        const int64_t ro = ((int64_t)b * Lk + kc) * ldk + h * 64 + 8 * hh;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             kf[s] = *reinterpret_cast<const bf16x8*>(k + ro + 16 * s);
@@ -355,31 +358,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const unsigned dshift = ((unsigned)kc & 1u) << 4;
 
     const int prow = lane >> 3, pslot = lane & 7;
-    const unsigned rowbytes = (unsigned)H * 128u;
-    const char* qbase = reinterpret_cast<const char*>(q + ((int64_t)b * Lq * H + h) * 64);
+    const unsigned rowbytes = (unsigned)ldq * 2u, rowbytes_d = (unsigned)H * 128u;   // q rows (maybe packed) / dout rows (dense)
+    const char* qbase = reinterpret_cast<const char*>(q + (int64_t)b * Lq * ldq + h * 64);
     const char* dobase = reinterpret_cast<const char*>(dout + ((int64_t)b * Lq * H + h) * 64);
     const float* nlbase = negl + ((int64_t)b * H + h) * Lq;
     const float* ndbase = negd + ((int64_t)b * H + h) * Lq;
-    unsigned sofs[2];
+    unsigned sofs[2], sofd[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int rw = 8 * (2 * wave + i) + prow;
         sofs[i] = (unsigned)rw * rowbytes + TRX_BWD_SW_OFS(rw, pslot);
+        sofd[i] = (unsigned)rw * rowbytes_d + TRX_BWD_SW_OFS(rw, pslot);
     }
     // per stage and wave: 4 tile loads (+ 2 loads of the per-query scalars on wave 0)
 #define TRX_BWD2_STAGE(QT, BUF)                                                                             \
     {                                                                                                       \
         const char* qt_ = qbase + (int64_t)(QT) * 64 * rowbytes;                                            \
-        const char* dt_ = dobase + (int64_t)(QT) * 64 * rowbytes;                                           \
+        const char* dt_ = dobase + (int64_t)(QT) * 64 * rowbytes_d;                                         \
         _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                  \
-            unsigned so_ = sofs[i_];                                                                        \
+            unsigned so_ = sofs[i_], sd_ = sofd[i_];                                                        \
             if ((QT) * 64 + 64 > Lq) { /* tail tile: rows past the last query re-read it (masked below) */  \
                 const int rw_ = 8 * (2 * wave + i_) + prow;                                                 \
                 so_ = (unsigned)min(rw_, Lq - 1 - (QT) * 64) * rowbytes + TRX_BWD_SW_OFS(rw_, pslot);       \
+                sd_ = (unsigned)min(rw_, Lq - 1 - (QT) * 64) * rowbytes_d + TRX_BWD_SW_OFS(rw_, pslot);     \
             }                                                                                               \
             __builtin_amdgcn_global_load_lds((gbl_void*)(qt_ + so_),                                        \
                                              (lds_void*)(lds + (BUF) * BWD2_STAGE + (2 * wave + i_) * 1024), 16, 0, 0);        \
-            __builtin_amdgcn_global_load_lds((gbl_void*)(dt_ + so_),                                        \
+            __builtin_amdgcn_global_load_lds((gbl_void*)(dt_ + sd_),                                        \
                                              (lds_void*)(lds + (BUF) * BWD2_STAGE + 8192 + (2 * wave + i_) * 1024), 16, 0, 0); \
         }                                                                                                   \
         if (wave == 0) {                                                                                    \
@@ -513,8 +518,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 #undef TRX_BWD2_STAGE
     if (kidx < Lk) {
-        bf16_t* kp = dk + (((int64_t)b * Lk + kidx) * H + h) * 64;
-        bf16_t* vp = dv + (((int64_t)b * Lk + kidx) * H + h) * 64;
+        bf16_t* kp = dk + ((int64_t)b * Lk + kidx) * ldk + h * 64;
+        bf16_t* vp = dv + ((int64_t)b * Lk + kidx) * ldk + h * 64;
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
             uint2 w;

@@ -27,7 +27,9 @@ int fail(int code, const std::string& m) { g_err = m; return code; }
 struct Drop { unsigned base, thr; float inv_keep; };   // thr == 0: dropout off
 // attention: the dropout base is per (batch, head).  kv_bs: elements between consecutive batch items of k and
 // of v (0 = dense, Lk * H * 64); set by the key/value-cache entry point, forward kernels only
-struct DropArgs { unsigned seed_lo, seed_hi, thr; float inv_keep; long long kv_bs; };
+// ldq / ldk: elements between consecutive rows (tokens) of q and of k / v (0 = dense, H * 64): operands that are
+// slices of one packed projection output [B, L, 3 * H * 64]; matrix-core kernels only
+struct DropArgs { unsigned seed_lo, seed_hi, thr; float inv_keep; long long kv_bs; int ldq, ldk; };
 __host__ __device__ __forceinline__ unsigned lowbias32(unsigned x) {
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
     return x;
@@ -587,7 +589,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DROP || MM
     const int qc = qidx < Lq ? qidx : Lq - 1;
     bf16x8 qf[4];   // B operand of S^T = K Q^T: B[k = 8hh + j][col r] = Q[query r][d = 16 s + 8 hh + j]
     {
-        const bf16_t* qp = q + (((int64_t)b * Lq + qc) * H + h) * 64 + 8 * hh;
+        const bf16_t* qp = q + ((int64_t)b * Lq + qc) * (da.ldq ? da.ldq : H * 64) + h * 64 + 8 * hh;
 #pragma unroll
         for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
     }
@@ -616,8 +618,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DROP || MM
     // (slot = chunk ^ ((row >> 1) & 7)) is applied to the SOURCE chunk; V is stored straight.
     // Addresses are (uniform base + tile offset) + a per-lane 32-bit byte offset fixed for the kernel.
     const int prow = lane >> 3, pslot = lane & 7;
-    const unsigned rowbytes = (unsigned)H * 128u;
-    const int64_t kvbs = da.kv_bs ? da.kv_bs : (int64_t)Lk * H * 64;
+    const unsigned rowbytes = (unsigned)(da.ldk ? da.ldk : H * 64) * 2u;
+    const int64_t kvbs = da.kv_bs ? da.kv_bs : (int64_t)Lk * (da.ldk ? da.ldk : H * 64);
     const char* kbase = reinterpret_cast<const char*>(k + (int64_t)b * kvbs + h * 64);
     const char* vbase = reinterpret_cast<const char*>(v + (int64_t)b * kvbs + h * 64);
     unsigned kofs[2], vofs[2];
@@ -1027,12 +1029,17 @@ static DropArgs make_drop_args(float p, uint64_t seed) {
     a.thr = p > 0.f ? drop_thr(p) : 0u;
     a.inv_keep = 1.0f / (1.0f - p);
     a.kv_bs = 0;
+    a.ldq = 0; a.ldk = 0;
     return a;
 }
 
 static int attention_fwd_impl(const void* q, const void* k, const void* v, const float* mask, int mask_mode, int causal,
                               int B, int H, int Lq, int Lk, int64_t kv_bs, float scale, int dtype, float p, uint64_t seed,
-                              void* out, float* lse, void* stream) {
+                              void* out, float* lse, void* stream, int ldq = 0, int ldk = 0) {
+    if ((ldq || ldk) && (dtype != TRX_NN_BF16 || getenv("TRX_NN_ATTN_VALU")))
+        return fail(TRX_NN_EINVAL, "attention_fwd: strided operands are supported by the bf16 matrix-core path only");
+    if ((ldq && ldq < H * 64) || (ldk && ldk < H * 64) || ((ldq | ldk) & 7))
+        return fail(TRX_NN_EINVAL, "attention_fwd: row strides must be >= H * 64 and multiples of 8 elements");
     if (!q || !k || !v || !out || B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return fail(TRX_NN_EINVAL, "attention_fwd: bad argument");
     if (kv_bs != 0 && kv_bs < (int64_t)Lk * H * 64) return fail(TRX_NN_EINVAL, "attention_fwd: key/value batch stride smaller than one batch item");
     if (mask_mode != TRX_NN_MASK_NONE && !mask) return fail(TRX_NN_EINVAL, "attention_fwd: mask is null");
@@ -1041,7 +1048,7 @@ static int attention_fwd_impl(const void* q, const void* k, const void* v, const
     if (!(p >= 0.f && p < 1.f)) return fail(TRX_NN_EINVAL, "dropout probability must be in [0, 1)");
     if (!(scale > 0.f)) return fail(TRX_NN_EINVAL, "attention_fwd: scale must be positive");
     DropArgs da = make_drop_args(p, seed);
-    da.kv_bs = kv_bs;
+    da.kv_bs = kv_bs; da.ldq = ldq; da.ldk = ldk;
     const int qblocks = (Lq + 63) / 64;
     dim3 grid((unsigned)((int64_t)B * H * qblocks)), block(64);
     hipStream_t st = (hipStream_t)stream;
@@ -1093,9 +1100,13 @@ int trx_attention_fwd(const void* q, const void* k, const void* v, const float* 
     return trx_attention_fwd_dropout(q, k, v, mask, mask_mode, causal, B, H, Lq, Lk, scale, dtype, 0.f, 0, out, nullptr, stream);
 }
 
-int trx_attention_bwd_dropout(const void* q, const void* k, const void* v, const float* mask, int mask_mode, int causal,
+static int attention_bwd_impl(const void* q, const void* k, const void* v, const float* mask, int mask_mode, int causal,
                               int B, int H, int Lq, int Lk, float scale, int dtype, float p, uint64_t seed, const void* out,
-                              const void* dout, const float* lse, void* dq, void* dk, void* dv, void* stream) {
+                              const void* dout, const float* lse, void* dq, void* dk, void* dv, void* stream, int ldq, int ldk) {
+    if ((ldq || ldk) && (dtype != TRX_NN_BF16 || getenv("TRX_NN_ATTN_VALU")))
+        return fail(TRX_NN_EINVAL, "attention_bwd: strided operands are supported by the bf16 matrix-core path only");
+    if ((ldq && ldq < H * 64) || (ldk && ldk < H * 64) || ((ldq | ldk) & 7))
+        return fail(TRX_NN_EINVAL, "attention_bwd: row strides must be >= H * 64 and multiples of 8 elements");
     if (!q || !k || !v || !out || !dout || !lse || !dq || !dk || !dv || B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0)
         return fail(TRX_NN_EINVAL, "attention_bwd: bad argument");
     if (mask_mode != TRX_NN_MASK_NONE && !mask) return fail(TRX_NN_EINVAL, "attention_bwd: mask is null");
@@ -1103,7 +1114,8 @@ int trx_attention_bwd_dropout(const void* q, const void* k, const void* v, const
     if (dtype != TRX_NN_F32 && dtype != TRX_NN_BF16) return fail(TRX_NN_EINVAL, "unknown dtype");
     if (!(p >= 0.f && p < 1.f)) return fail(TRX_NN_EINVAL, "dropout probability must be in [0, 1)");
     if (!(scale > 0.f)) return fail(TRX_NN_EINVAL, "attention_bwd: scale must be positive");
-    const DropArgs da = make_drop_args(p, seed);
+    DropArgs da = make_drop_args(p, seed);
+    da.ldq = ldq; da.ldk = ldk;
     hipStream_t st = (hipStream_t)stream;
     dim3 gq((unsigned)((int64_t)B * H * ((Lq + 63) / 64))), gk((unsigned)((int64_t)B * H * ((Lk + 63) / 64))), block(64);
     static const bool force_valu = getenv("TRX_NN_ATTN_VALU") != nullptr;
@@ -1149,6 +1161,24 @@ int trx_attention_bwd_dropout(const void* q, const void* k, const void* v, const
 #undef TRX_LAUNCH_VALU_BWD
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? TRX_NN_OK : fail(TRX_NN_EHIP, hipGetErrorString(e));
+}
+
+int trx_attention_bwd_dropout(const void* q, const void* k, const void* v, const float* mask, int mask_mode, int causal,
+                              int B, int H, int Lq, int Lk, float scale, int dtype, float p, uint64_t seed, const void* out,
+                              const void* dout, const float* lse, void* dq, void* dk, void* dv, void* stream) {
+    return attention_bwd_impl(q, k, v, mask, mask_mode, causal, B, H, Lq, Lk, scale, dtype, p, seed, out, dout, lse, dq, dk, dv, stream, 0, 0);
+}
+
+int trx_attention_fwd_strided(const void* q, const void* k, const void* v, const float* mask, int mask_mode, int causal,
+                              int B, int H, int Lq, int Lk, int ldq, int ldkv, float scale, float p, uint64_t seed, void* out,
+                              float* lse, void* stream) {
+    return attention_fwd_impl(q, k, v, mask, mask_mode, causal, B, H, Lq, Lk, 0, scale, TRX_NN_BF16, p, seed, out, lse, stream, ldq, ldkv);
+}
+
+int trx_attention_bwd_strided(const void* q, const void* k, const void* v, const float* mask, int mask_mode, int causal,
+                              int B, int H, int Lq, int Lk, int ldq, int ldkv, float scale, float p, uint64_t seed, const void* out,
+                              const void* dout, const float* lse, void* dq, void* dk, void* dv, void* stream) {
+    return attention_bwd_impl(q, k, v, mask, mask_mode, causal, B, H, Lq, Lk, scale, TRX_NN_BF16, p, seed, out, dout, lse, dq, dk, dv, stream, ldq, ldkv);
 }
 
 int trx_attention_bwd(const void* q, const void* k, const void* v, const float* mask, int mask_mode, int causal,

@@ -75,11 +75,21 @@ class Attention(nn.Module):
         autocast, the stream itself otherwise).  Returns the new (stream, low) pair."""
         B, Lq, Hd = h.shape
         Lk = kv_low.shape[1]
-        q = self.self.query(h_low).view(B, Lq, self.heads, 64)
-        k = self.self.key(kv_low).view(B, Lk, self.heads, 64)
-        v = self.self.value(kv_low).view(B, Lk, self.heads, 64)
-        ctx = ops.attention(q, k, v, mask=mask, causal=causal, backend=backend,
-                            dropout_p=self.p_attn if self.training else 0.0)
+        pa = self.p_attn if self.training else 0.0
+        sa = self.self
+        if kv_low is h_low:
+            # self-attention: ONE [*, 768] x [768, 2304] GEMM for q, k, v (same parameters, concatenated per call);
+            # the attention kernels read the three slices of its output in place
+            w = torch.cat([sa.query.weight, sa.key.weight, sa.value.weight])
+            bias = torch.cat([sa.query.bias, sa.key.bias, sa.value.bias])
+            qkv = torch.nn.functional.linear(h_low, w, bias).view(B, Lq, 3, self.heads, 64)
+            ctx = ops.attention_qkv(qkv, mask=mask, causal=causal, backend=backend, dropout_p=pa)
+        else:
+            q = sa.query(h_low).view(B, Lq, self.heads, 64)
+            w = torch.cat([sa.key.weight, sa.value.weight])
+            bias = torch.cat([sa.key.bias, sa.value.bias])
+            kv = torch.nn.functional.linear(kv_low, w, bias).view(B, Lk, 2, self.heads, 64)
+            ctx = ops.attention_q_kv(q, kv, mask=mask, causal=causal, backend=backend, dropout_p=pa)
         return ops.add_layernorm(self.output.dense(ctx), h, self.output.LayerNorm.weight, self.output.LayerNorm.bias,
                                  self.eps, backend=backend, dropout_p=self.p_hidden if self.training else 0.0, dual=True)
 

@@ -21,7 +21,8 @@ SYMBOLS = ["trx_add_layernorm_fwd", "trx_add_layernorm_bwd", "trx_add_layernorm_
            "trx_attention_fwd", "trx_attention_fwd_lse", "trx_attention_bwd",
            "trx_add_layernorm_fwd_dropout", "trx_add_layernorm_bwd_dropout", "trx_attention_fwd_dropout",
            "trx_attention_bwd_dropout", "trx_dropout_keep_mask", "trx_add_layernorm_fwd_mixed",
-           "trx_add_layernorm_bwd_mixed", "trx_attention_fwd_kvcache", "trx_nn_last_error", "trx_nn_version"]
+           "trx_add_layernorm_bwd_mixed", "trx_attention_fwd_kvcache", "trx_attention_fwd_strided",
+           "trx_attention_bwd_strided", "trx_nn_last_error", "trx_nn_version"]
 
 
 class TrxNNError(RuntimeError):
@@ -51,6 +52,9 @@ def lib():
         L.trx_add_layernorm_fwd_mixed.argtypes = [vp, vp, vp, vp, f32, i64, i32, f32, u64, vp, vp, vp, vp, vp]
         L.trx_add_layernorm_bwd_mixed.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, u64, vp, vp, vp, vp, vp, vp]
         L.trx_attention_fwd_kvcache.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i64, f32, i32, vp, vp]
+        L.trx_attention_fwd_strided.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, f32, u64, vp, vp, vp]
+        L.trx_attention_bwd_strided.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, f32, u64,
+                                                vp, vp, vp, vp, vp, vp, vp]
         L.trx_nn_last_error.restype = ctypes.c_char_p
         L.trx_nn_version.restype = ctypes.c_char_p
         _lib = L
@@ -227,6 +231,7 @@ class _Attention(torch.autograd.Function):
     def forward(ctx, q, k, v, mask, causal, scale, p, seed):
         B, Lq, H, D = q.shape
         Lk = k.shape[1]
+        need = q.requires_grad or k.requires_grad or v.requires_grad   # before .contiguous(): a copy made here has no flag
         q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
         mode, m = MASK_NONE, None
         if mask is not None:
@@ -234,7 +239,6 @@ class _Attention(torch.autograd.Function):
             mode = MASK_KEY if m.dim() == 2 else MASK_FULL
             assert m.shape == ((B, Lk) if mode == MASK_KEY else (B, Lq, Lk)), m.shape
         out = torch.empty((B, Lq, H * D), dtype=q.dtype, device=q.device)
-        need = q.requires_grad or k.requires_grad or v.requires_grad
         lse = torch.empty((B, H, Lq), dtype=torch.float32, device=q.device) if need else None
         _check(lib().trx_attention_fwd_dropout(_p(q), _p(k), _p(v), _p(m), mode, 1 if causal else 0, B, H, Lq, Lk,
                                                float(scale), _dt(q), float(p), int(seed), _p(out), _p(lse), _stream(q)))
@@ -301,3 +305,93 @@ def attention(q, k, v, mask=None, causal=False, scale=None, backend="hip", dropo
         keep = dropout_keep_mask(seed, dropout_p, B * H, Lq, Lk, q.device).view(B, H, Lq, Lk)
         p = p * keep.float() / (1.0 - dropout_p)
     return torch.matmul(p, vf).permute(0, 2, 1, 3).reshape(B, Lq, H * D).to(q.dtype)
+
+
+# ---- packed projections: q, k, v as slices of ONE GEMM output (bf16, matrix-core kernels) -------------------
+def _mask_args(mask, B, Lq, Lk):
+    if mask is None:
+        return MASK_NONE, None
+    m = mask.float().contiguous()
+    mode = MASK_KEY if m.dim() == 2 else MASK_FULL
+    assert m.shape == ((B, Lk) if mode == MASK_KEY else (B, Lq, Lk)), m.shape
+    return mode, m
+
+
+class _AttentionPacked(torch.autograd.Function):
+    """`a` holds q (and k, v when `kv` is None): a = [B, L, 3, H, 64] for self-attention; otherwise a = q
+    [B, Lq, H, 64] and kv = [B, Lk, 2, H, 64].  The kernels read the slices in place (row strides) and the
+    backward writes dq, dk, dv straight into gradients of the same packed shapes."""
+
+    @staticmethod
+    def forward(ctx, a, kv, mask, causal, scale, p, seed):
+        need = a.requires_grad or (kv is not None and kv.requires_grad)   # before .contiguous(): a copy has no flag
+        a = a.contiguous()
+        H, D = a.shape[-2], a.shape[-1]
+        es = a.element_size()
+        if kv is None:
+            B, Lq = a.shape[0], a.shape[1]
+            Lk, ldq, ldk = Lq, 3 * H * D, 3 * H * D
+            qp, kp, vp = a.data_ptr(), a.data_ptr() + H * D * es, a.data_ptr() + 2 * H * D * es
+        else:
+            kv = kv.contiguous()
+            B, Lq, Lk = a.shape[0], a.shape[1], kv.shape[1]
+            ldq, ldk = H * D, 2 * H * D
+            qp, kp, vp = a.data_ptr(), kv.data_ptr(), kv.data_ptr() + H * D * es
+        mode, m = _mask_args(mask, B, Lq, Lk)
+        out = torch.empty((B, Lq, H * D), dtype=a.dtype, device=a.device)
+        lse = torch.empty((B, H, Lq), dtype=torch.float32, device=a.device) if need else None
+        c = ctypes.c_void_p
+        _check(lib().trx_attention_fwd_strided(c(qp), c(kp), c(vp), _p(m), mode, 1 if causal else 0, B, H, Lq, Lk, ldq, ldk,
+                                               float(scale), float(p), int(seed), _p(out), _p(lse), _stream(a)))
+        if need:
+            ctx.save_for_backward(a, kv if kv is not None else a.new_empty(0), m if m is not None else a.new_empty(0), out, lse)
+            ctx.cfg = (kv is not None, mode, causal, scale, float(p), int(seed), B, H, D, Lq, Lk, ldq, ldk)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        a, kv, m, out, lse = ctx.saved_tensors
+        has_kv, mode, causal, scale, p, seed, B, H, D, Lq, Lk, ldq, ldk = ctx.cfg
+        es = a.element_size()
+        dout = dout.contiguous()
+        da = torch.empty_like(a)
+        c = ctypes.c_void_p
+        if has_kv:
+            dkv = torch.empty_like(kv)
+            ptrs = (a.data_ptr(), kv.data_ptr(), kv.data_ptr() + H * D * es, da.data_ptr(), dkv.data_ptr(), dkv.data_ptr() + H * D * es)
+        else:
+            dkv = None
+            ptrs = (a.data_ptr(), a.data_ptr() + H * D * es, a.data_ptr() + 2 * H * D * es,
+                    da.data_ptr(), da.data_ptr() + H * D * es, da.data_ptr() + 2 * H * D * es)
+        _check(lib().trx_attention_bwd_strided(c(ptrs[0]), c(ptrs[1]), c(ptrs[2]), _p(m) if mode != MASK_NONE else None, mode,
+                                               1 if causal else 0, B, H, Lq, Lk, ldq, ldk, float(scale), p, seed, _p(out), _p(dout),
+                                               _p(lse), c(ptrs[3]), c(ptrs[4]), c(ptrs[5]), _stream(a)))
+        return da, dkv, None, None, None, None, None
+
+
+def _packed_ok(t, backend):
+    return backend == "hip" and t.is_cuda and t.dtype == torch.bfloat16 and t.shape[-1] == 64 and "TRX_NN_ATTN_VALU" not in os.environ
+
+
+def attention_qkv(qkv, mask=None, causal=False, scale=None, backend="hip", dropout_p=0.0, seed=None):
+    """self-attention on a packed projection qkv [B, L, 3, H, 64] (one GEMM instead of three) -> [B, L, H*64]"""
+    if scale is None:
+        scale = 1.0 / math.sqrt(qkv.shape[-1])
+    if dropout_p > 0 and seed is None:
+        seed = new_seed()
+    if _packed_ok(qkv, backend):
+        return _AttentionPacked.apply(qkv, None, mask, causal, scale, float(dropout_p), 0 if seed is None else seed)
+    q, k, v = qkv.unbind(dim=2)
+    return attention(q, k, v, mask=mask, causal=causal, scale=scale, backend=backend, dropout_p=dropout_p, seed=seed)
+
+
+def attention_q_kv(q, kv, mask=None, causal=False, scale=None, backend="hip", dropout_p=0.0, seed=None):
+    """cross-attention: q [B, Lq, H, 64] and a packed key/value projection kv [B, Lk, 2, H, 64]"""
+    if scale is None:
+        scale = 1.0 / math.sqrt(q.shape[-1])
+    if dropout_p > 0 and seed is None:
+        seed = new_seed()
+    if _packed_ok(q, backend) and kv.dtype == q.dtype:
+        return _AttentionPacked.apply(q, kv, mask, causal, scale, float(dropout_p), 0 if seed is None else seed)
+    k, v = kv.unbind(dim=2)
+    return attention(q, k, v, mask=mask, causal=causal, scale=scale, backend=backend, dropout_p=dropout_p, seed=seed)
