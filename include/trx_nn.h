@@ -95,10 +95,14 @@ int trx_attention_bwd_dropout(const void* q, const void* k, const void* v, const
  * dz fp32 (gradient of res), dx bf16 (gradient of x, through the dropout when p > 0), always written. */
 int trx_add_layernorm_fwd_mixed(const void* x_bf16, const void* res_f32, const float* gamma, const float* beta, float eps,
                                 int64_t rows, int cols, float p, uint64_t seed, void* y_f32, void* y_bf16, float* mean, float* rstd,
-                                void* stream);
+                                const float* x_bias, void* stream);
+/* x_bias (may be NULL): float[cols] added to x before the dropout -- the bias of the Linear that produced x,
+ * kept out of its GEMM so that its gradient (dx_bias = column sums of dx) falls out of this backward instead of
+ * a separate reduction over rows.  ws: float[(x_bias ? 3 : 2) * nblk * cols]. */
 int trx_add_layernorm_bwd_mixed(const void* dy_f32, const void* dy_bf16, const void* x_bf16, const void* res_f32, const float* gamma,
                                 const float* mean, const float* rstd, int64_t rows, int cols, float p, uint64_t seed, void* dz_f32,
-                                void* dx_bf16, float* dgamma, float* dbeta, float* ws, void* stream);
+                                void* dx_bf16, float* dgamma, float* dbeta, const float* x_bias, float* dx_bias, float* ws,
+                                void* stream);
 /* Packed projections (bf16, matrix-core kernels): q, k, v (and dq, dk, dv) are slices of one projection
  * output, e.g. [B, L, 3 * H * 64] from a single QKV GEMM.  ldq / ldkv = elements between consecutive
  * tokens of q (dq) and of k, v (dk, dv); out, dout, lse are dense as above. */

@@ -478,3 +478,25 @@ def test_packed_projection_operands_equal_separate_tensors(B, H, L, Lk, mask, ca
         ref.backward(dout)
         assert torch.equal(out, ref) and torch.equal(q1.grad, q.grad)
         assert torch.equal(kv1.grad[:, :, 0], k.grad) and torch.equal(kv1.grad[:, :, 1], v.grad)
+
+
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_add_layernorm_with_the_producing_linears_bias(p):
+    """x + bias formed inside the mixed-storage kernel, bias gradient = column sums of dx from its backward"""
+    rows, cols = 1500, 768
+    x = _rand(rows, cols, dtype=torch.bfloat16, seed=1); r = _rand(rows, cols, seed=2)
+    g, b, xb = _rand(cols, seed=3), _rand(cols, seed=4), _rand(cols, seed=7)
+    dy = _rand(rows, cols, seed=5)
+    res = []
+    for backend in ("hip", "torch"):
+        xs, rs = x.clone().requires_grad_(True), r.clone().requires_grad_(True)
+        gs, bs, xbs = (t.clone().requires_grad_(True) for t in (g, b, xb))
+        if backend == "hip":
+            y, ylow = ops.add_layernorm(xs, rs, gs, bs, 1e-12, dropout_p=p, seed=3, dual=True, bias=xbs)
+            assert ylow.dtype == torch.bfloat16
+        else:   # the statement: bias added in fp32, then the plain op
+            y = ops.add_layernorm(xs.float() + xbs, rs, gs, bs, 1e-12, backend="torch", dropout_p=p, seed=3)
+        y.backward(dy)
+        res.append((y.detach(), xs.grad.float(), rs.grad, gs.grad, bs.grad, xbs.grad))
+    for a, c, tol in zip(*res, (3e-5, 1e-2, 3e-5, 3e-5, 3e-5, 2e-3)):   # dx (and so its column sums) is rounded to bf16
+        assert float((a - c).abs().max()) <= tol * max(1.0, float(c.abs().max()))

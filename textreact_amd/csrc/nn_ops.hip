@@ -131,7 +131,8 @@ __device__ __forceinline__ uint2 pack8bf(const float* f) { return make_uint2(pac
 template <bool BF, bool MIX>
 __global__ __launch_bounds__(256) void add_ln_fwd_vec_kernel(const void* x, const void* res, const float* gamma,
                                                              const float* beta, float eps, int64_t rows, int cols,
-                                                             void* y, float* mean, float* rstd, Drop drop, void* y16 = nullptr) {
+                                                             void* y, float* mean, float* rstd, Drop drop, void* y16 = nullptr,
+                                                             const float* xbias = nullptr) {
     constexpr int V = Vec16<BF>::N;
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -148,6 +149,10 @@ __global__ __launch_bounds__(256) void add_ln_fwd_vec_kernel(const void* x, cons
         if (c < nchunk) {
             if (MIX) unpack8bf(*reinterpret_cast<const uint2*>(xr + (size_t)c * 8), v[i]);
             else unpack16<BF>(*reinterpret_cast<const uint4*>(xr + (size_t)c * 16), v[i]);
+            if (MIX && xbias) {   // the bias of the Linear that produced x, kept out of its GEMM (see the backward)
+#pragma unroll
+                for (int j = 0; j < V; ++j) v[i][j] += xbias[c * V + j];
+            }
             if (drop.thr) {   // dropout acts on x only, before the residual is added
 #pragma unroll
                 for (int j = 0; j < V; j += 2) {
@@ -284,18 +289,22 @@ template <bool BF, bool MIX>
 __global__ __launch_bounds__(256) void add_ln_bwd_vec_kernel(const void* dy, const void* x, const void* res,
                                                              const float* gamma, const float* mean, const float* rstd,
                                                              int64_t rows, int cols, void* dz, void* dx, float* ws, int nblk, Drop drop,
-                                                             const void* dy16 = nullptr) {
+                                                             const void* dy16 = nullptr, const float* xbias = nullptr) {
     extern __shared__ float sm[];  // [4 waves][2][cols]
     constexpr int V = Vec16<BF>::N;
     constexpr int ES = BF ? 2 : 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nchunk = cols / V;
     float ag[NCH][V], ab[NCH][V], gm[NCH][V];
+    float ax[MIX ? NCH : 1][MIX ? V : 1];   // MIX + xbias: column sums of dx = the gradient of that bias
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int c = lane + 64 * i;
 #pragma unroll
-        for (int j = 0; j < V; ++j) { ag[i][j] = 0.f; ab[i][j] = 0.f; gm[i][j] = c < nchunk ? gamma[c * V + j] : 0.f; }
+        for (int j = 0; j < V; ++j) {
+            ag[i][j] = 0.f; ab[i][j] = 0.f; gm[i][j] = c < nchunk ? gamma[c * V + j] : 0.f;
+            if (MIX) ax[i][j] = 0.f;
+        }
     }
     for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
         const size_t rb = (size_t)row * cols * ES;
@@ -317,6 +326,10 @@ __global__ __launch_bounds__(256) void add_ln_bwd_vec_kernel(const void* dy, con
                 }
                 if (MIX) unpack8bf(*reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(x) + (rb >> 1) + (size_t)c * 8), z);
                 else unpack16<BF>(*reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(x) + rb + (size_t)c * 16), z);
+                if (MIX && xbias) {
+#pragma unroll
+                    for (int j = 0; j < V; ++j) z[j] += xbias[c * V + j];
+                }
                 if (drop.thr) {
 #pragma unroll
                     for (int j = 0; j < V; j += 2) {
@@ -358,8 +371,11 @@ __global__ __launch_bounds__(256) void add_ln_bwd_vec_kernel(const void* dy, con
                             o[j + 1] *= drop_keep(bits, 1, drop.thr) ? drop.inv_keep : 0.f;
                         }
                     }
-                    if (MIX) *reinterpret_cast<uint2*>(reinterpret_cast<char*>(dx) + (rb >> 1) + (size_t)c * 8) = pack8bf(o);
-                    else *reinterpret_cast<uint4*>(reinterpret_cast<char*>(dx) + rb + (size_t)c * 16) = pack16<BF>(o);
+                    if (MIX) {
+                        *reinterpret_cast<uint2*>(reinterpret_cast<char*>(dx) + (rb >> 1) + (size_t)c * 8) = pack8bf(o);
+#pragma unroll
+                        for (int j = 0; j < V; ++j) ax[i][j] += o[j];
+                    } else *reinterpret_cast<uint4*>(reinterpret_cast<char*>(dx) + rb + (size_t)c * 16) = pack16<BF>(o);
                 }
             }
         }
@@ -381,11 +397,29 @@ __global__ __launch_bounds__(256) void add_ln_bwd_vec_kernel(const void* dy, con
         ws[(int64_t)blockIdx.x * cols + c] = a;
         ws[((int64_t)nblk + blockIdx.x) * cols + c] = b;
     }
+    if (MIX && xbias) {   // third partial row: the bias gradient, through the same LDS area
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nchunk) {
+#pragma unroll
+                for (int j = 0; j < V; ++j) pg[c * V + j] = ax[i][j];
+            }
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < cols; c += 256) {
+            float a = 0.f;
+            for (int w = 0; w < 4; ++w) a += sm[(w * 2) * cols + c];
+            ws[((int64_t)2 * nblk + blockIdx.x) * cols + c] = a;
+        }
+    }
 }
 
 // second stage: sum the nblk partial rows of ws.  A workgroup owns 16 columns of one of the two
 // arrays (blockIdx.y: 0 dgamma, 1 dbeta); its 16 x 16 threads walk the partial rows 16 at a time.
-__global__ __launch_bounds__(256) void add_ln_bwd_reduce_kernel(const float* ws, int nblk, int cols, float* dgamma, float* dbeta) {
+__global__ __launch_bounds__(256) void add_ln_bwd_reduce_kernel(const float* ws, int nblk, int cols, float* dgamma, float* dbeta,
+                                                                float* dxbias = nullptr) {
     __shared__ float part[16][17];
     const int tc = threadIdx.x & 15, tr = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + tc;
@@ -399,7 +433,7 @@ __global__ __launch_bounds__(256) void add_ln_bwd_reduce_kernel(const float* ws,
         float t = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) t += part[i][tc];
-        (blockIdx.y ? dbeta : dgamma)[c] = t;
+        (blockIdx.y == 0 ? dgamma : (blockIdx.y == 1 ? dbeta : dxbias))[c] = t;
     }
 }
 
@@ -977,7 +1011,7 @@ int trx_add_layernorm_bwd(const void* dy, const void* x, const void* res, const 
 
 int trx_add_layernorm_fwd_mixed(const void* x_bf16, const void* res_f32, const float* gamma, const float* beta, float eps,
                                 int64_t rows, int cols, float p, uint64_t seed, void* y_f32, void* y_bf16, float* mean, float* rstd,
-                                void* stream) {
+                                const float* x_bias, void* stream) {
     if (!x_bf16 || !res_f32 || !gamma || !beta || !y_f32 || rows < 0 || cols <= 0) return fail(TRX_NN_EINVAL, "add_layernorm_fwd_mixed: bad argument");
     if (!(p >= 0.f && p < 1.f)) return fail(TRX_NN_EINVAL, "dropout probability must be in [0, 1)");
     if (cols % 4 != 0 || cols > 64 * NCH * 4) return fail(TRX_NN_EINVAL, "add_layernorm_fwd_mixed: cols must be a multiple of 4 and <= 1024");
@@ -987,14 +1021,16 @@ int trx_add_layernorm_fwd_mixed(const void* x_bf16, const void* res_f32, const f
     if (rows == 0) return TRX_NN_OK;
     const Drop drop = make_drop(p, seed, 0);
     hipLaunchKernelGGL((add_ln_fwd_vec_kernel<false, true>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                       x_bf16, res_f32, gamma, beta, eps, rows, cols, y_f32, mean, rstd, drop, y_bf16);
+                       x_bf16, res_f32, gamma, beta, eps, rows, cols, y_f32, mean, rstd, drop, y_bf16, x_bias);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? TRX_NN_OK : fail(TRX_NN_EHIP, hipGetErrorString(e));
 }
 
 int trx_add_layernorm_bwd_mixed(const void* dy_f32, const void* dy_bf16, const void* x_bf16, const void* res_f32, const float* gamma,
                                 const float* mean, const float* rstd, int64_t rows, int cols, float p, uint64_t seed, void* dz_f32,
-                                void* dx_bf16, float* dgamma, float* dbeta, float* ws, void* stream) {
+                                void* dx_bf16, float* dgamma, float* dbeta, const float* x_bias, float* dx_bias, float* ws,
+                                void* stream) {
+    if ((x_bias == nullptr) != (dx_bias == nullptr)) return fail(TRX_NN_EINVAL, "add_layernorm_bwd_mixed: x_bias and dx_bias go together");
     if ((!dy_f32 && !dy_bf16) || !x_bf16 || !res_f32 || !gamma || !mean || !rstd || !dz_f32 || !dx_bf16 || !dgamma || !dbeta || !ws || rows <= 0 || cols <= 0)
         return fail(TRX_NN_EINVAL, "add_layernorm_bwd_mixed: bad argument");
     if (!(p >= 0.f && p < 1.f)) return fail(TRX_NN_EINVAL, "dropout probability must be in [0, 1)");
@@ -1007,8 +1043,8 @@ int trx_add_layernorm_bwd_mixed(const void* dy_f32, const void* dy_bf16, const v
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = (size_t)cols * 8 * sizeof(float);
     hipLaunchKernelGGL((add_ln_bwd_vec_kernel<false, true>), dim3(nblk), dim3(256), lds, st, dy_f32, x_bf16, res_f32, gamma, mean, rstd,
-                       rows, cols, dz_f32, dx_bf16, ws, nblk, drop, dy_bf16);
-    hipLaunchKernelGGL(add_ln_bwd_reduce_kernel, dim3((cols + 15) / 16, 2), dim3(256), 0, st, ws, nblk, cols, dgamma, dbeta);
+                       rows, cols, dz_f32, dx_bf16, ws, nblk, drop, dy_bf16, x_bias);
+    hipLaunchKernelGGL(add_ln_bwd_reduce_kernel, dim3((cols + 15) / 16, x_bias ? 3 : 2), dim3(256), 0, st, ws, nblk, cols, dgamma, dbeta, dx_bias);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? TRX_NN_OK : fail(TRX_NN_EHIP, hipGetErrorString(e));
 }

@@ -60,6 +60,16 @@ class AttnOutput(nn.Module):
         self.LayerNorm = LayerNormParams(cfg.hidden_size)
 
 
+def _dense_add_layernorm(dense, x, h, ln, eps, backend, p):
+    """(stream, low) = LayerNorm(dropout(dense(x)) + h).  Under bf16 autocast on the HIP ops (x bf16, stream fp32)
+    the dense layer runs WITHOUT its bias and the fused kernel adds it: the bias gradient then falls out of the
+    LayerNorm backward instead of a separate reduction over all rows."""
+    if backend == "hip" and x.dtype == torch.bfloat16 and h.dtype == torch.float32 and x.is_cuda:
+        return ops.add_layernorm(torch.nn.functional.linear(x, dense.weight), h, ln.weight, ln.bias, eps, backend=backend,
+                                 dropout_p=p, dual=True, bias=dense.bias)
+    return ops.add_layernorm(dense(x), h, ln.weight, ln.bias, eps, backend=backend, dropout_p=p, dual=True)
+
+
 class Attention(nn.Module):
     """`attention` / `crossattention` of a layer: self.{query,key,value} + output.{dense,LayerNorm}"""
 
@@ -90,8 +100,8 @@ class Attention(nn.Module):
             bias = torch.cat([sa.key.bias, sa.value.bias])
             kv = torch.nn.functional.linear(kv_low, w, bias).view(B, Lk, 2, self.heads, 64)
             ctx = ops.attention_q_kv(q, kv, mask=mask, causal=causal, backend=backend, dropout_p=pa)
-        return ops.add_layernorm(self.output.dense(ctx), h, self.output.LayerNorm.weight, self.output.LayerNorm.bias,
-                                 self.eps, backend=backend, dropout_p=self.p_hidden if self.training else 0.0, dual=True)
+        return _dense_add_layernorm(self.output.dense, ctx, h, self.output.LayerNorm, self.eps, backend,
+                                    self.p_hidden if self.training else 0.0)
 
 
 class Intermediate(nn.Module):
@@ -115,8 +125,8 @@ class Layer(nn.Module):
         if self.cross:
             h, h_low = self.crossattention(h, h_low, enc_low, enc_mask, False, backend)
         f = torch.nn.functional.gelu(self.intermediate.dense(h_low))
-        return ops.add_layernorm(self.output.dense(f), h, self.output.LayerNorm.weight, self.output.LayerNorm.bias,
-                                 self.eps, backend=backend, dropout_p=self.p_hidden if self.training else 0.0, dual=True)
+        return _dense_add_layernorm(self.output.dense, f, h, self.output.LayerNorm, self.eps, backend,
+                                    self.p_hidden if self.training else 0.0)
 
 
 class LayerStack(nn.Module):

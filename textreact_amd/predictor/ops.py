@@ -49,8 +49,8 @@ def lib():
         L.trx_attention_bwd_dropout.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, i32, f32, u64,
                                                 vp, vp, vp, vp, vp, vp, vp]
         L.trx_dropout_keep_mask.argtypes = [u64, f32, i64, i64, i64, vp, vp]
-        L.trx_add_layernorm_fwd_mixed.argtypes = [vp, vp, vp, vp, f32, i64, i32, f32, u64, vp, vp, vp, vp, vp]
-        L.trx_add_layernorm_bwd_mixed.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, u64, vp, vp, vp, vp, vp, vp]
+        L.trx_add_layernorm_fwd_mixed.argtypes = [vp, vp, vp, vp, f32, i64, i32, f32, u64, vp, vp, vp, vp, vp, vp]
+        L.trx_add_layernorm_bwd_mixed.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, u64, vp, vp, vp, vp, vp, vp, vp, vp]
         L.trx_attention_fwd_kvcache.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i64, f32, i32, vp, vp]
         L.trx_attention_fwd_strided.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, f32, u64, vp, vp, vp]
         L.trx_attention_bwd_strided.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, f32, u64,
@@ -148,58 +148,69 @@ class _AddLayerNormMixed(torch.autograd.Function):
     comes back as a second argument of backward and is summed inside the kernel"""
 
     @staticmethod
-    def forward(ctx, x, res, gamma, beta, eps, p, seed, dual):
+    def forward(ctx, x, res, gamma, beta, eps, p, seed, dual, bias):
         _need_gpu(x)
         xs, rs = x.contiguous(), res.contiguous()
+        xb = bias.float().contiguous() if bias is not None else None
         cols = xs.shape[-1]
         rows = xs.numel() // cols
         y = torch.empty_like(rs)
         y16 = torch.empty_like(xs) if dual else None
-        need = x.requires_grad or res.requires_grad or gamma.requires_grad
+        need = x.requires_grad or res.requires_grad or gamma.requires_grad or (bias is not None and bias.requires_grad)
         mean = torch.empty(rows, dtype=torch.float32, device=x.device) if need else None
         rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if need else None
         g, b = gamma.float().contiguous(), beta.float().contiguous()
         _check(lib().trx_add_layernorm_fwd_mixed(_p(xs), _p(rs), _p(g), _p(b), float(eps), rows, cols, float(p), int(seed),
-                                                 _p(y), _p(y16), _p(mean), _p(rstd), _stream(xs)))
+                                                 _p(y), _p(y16), _p(mean), _p(rstd), _p(xb), _stream(xs)))
         ctx.set_materialize_grads(False)
         if need:
-            ctx.save_for_backward(xs, rs, g, mean, rstd)
-            ctx.drop = (float(p), int(seed))
+            ctx.save_for_backward(xs, rs, g, mean, rstd, xb if xb is not None else xs.new_empty(0))
+            ctx.drop = (float(p), int(seed), xb is not None)
         return (y, y16) if dual else y
 
     @staticmethod
     def backward(ctx, dy, dy16=None):
-        xs, rs, g, mean, rstd = ctx.saved_tensors
-        p, seed = ctx.drop
+        xs, rs, g, mean, rstd, xb = ctx.saved_tensors
+        p, seed, has_bias = ctx.drop
+        xb = xb if has_bias else None
         cols = xs.shape[-1]
         rows = xs.numel() // cols
         if dy is None and dy16 is None:
-            return None, None, None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None, None
         dy = dy.float().contiguous() if dy is not None else None
         dy16 = dy16.to(torch.bfloat16).contiguous() if dy16 is not None else None
         nblk = lib().trx_add_layernorm_bwd_blocks(rows)
-        ws = torch.empty(2 * nblk * cols, dtype=torch.float32, device=xs.device)
+        ws = torch.empty((3 if has_bias else 2) * nblk * cols, dtype=torch.float32, device=xs.device)
         dz, dx = torch.empty_like(rs), torch.empty_like(xs)
         dg = torch.empty(cols, dtype=torch.float32, device=xs.device)
         db = torch.empty(cols, dtype=torch.float32, device=xs.device)
+        dxb = torch.empty(cols, dtype=torch.float32, device=xs.device) if has_bias else None
         _check(lib().trx_add_layernorm_bwd_mixed(_p(dy), _p(dy16), _p(xs), _p(rs), _p(g), _p(mean), _p(rstd), rows, cols, p, seed,
-                                                 _p(dz), _p(dx), _p(dg), _p(db), _p(ws), _stream(xs)))
-        return dx, dz, dg, db, None, None, None, None
+                                                 _p(dz), _p(dx), _p(dg), _p(db), _p(xb), _p(dxb), _p(ws), _stream(xs)))
+        return dx, dz, dg, db, None, None, None, None, dxb
 
 
-def add_layernorm(x, res, gamma, beta, eps, backend="hip", dropout_p=0.0, seed=None, dual=False):
+def add_layernorm(x, res, gamma, beta, eps, backend="hip", dropout_p=0.0, seed=None, dual=False, bias=None):
     """LayerNorm(dropout(x) + res) * gamma + beta over the last dimension; res may be None.
     dropout_p > 0 (training): x is dropped before the residual is added, as BertSelfOutput /
     BertOutput / BertEmbeddings do; `seed` picks the decisions (default: a fresh one).
     dual=True returns (y, y_low): y_low is a bf16 copy of y written by the same kernel when x is bf16 and the
-    residual stream fp32 (autocast) -- for the Linear layers that read y next -- and y itself otherwise."""
+    residual stream fp32 (autocast) -- for the Linear layers that read y next -- and y itself otherwise.
+    bias: the bias of the Linear that produced x, when the caller ran that Linear WITHOUT it: x + bias is formed
+    here, and in the mixed-storage path inside the kernel, whose backward then yields the bias gradient too."""
+    def _mixed(x, res):
+        cols = x.shape[-1]
+        return (backend == "hip" and res is not None and x.dtype == torch.bfloat16 and res.dtype == torch.float32
+                and cols % 4 == 0 and cols <= 1024 and x.is_cuda)
+    if bias is not None and not _mixed(x, res):
+        x, bias = x + bias.to(x.dtype), None
     if dual:
         cols = x.shape[-1]
         if (backend == "hip" and res is not None and x.dtype == torch.bfloat16 and res.dtype == torch.float32
                 and cols % 4 == 0 and cols <= 1024 and x.is_cuda):
             if dropout_p > 0 and seed is None:
                 seed = new_seed()
-            return _AddLayerNormMixed.apply(x, res, gamma, beta, eps, float(dropout_p), 0 if seed is None else seed, True)
+            return _AddLayerNormMixed.apply(x, res, gamma, beta, eps, float(dropout_p), 0 if seed is None else seed, True, bias)
         y = add_layernorm(x, res, gamma, beta, eps, backend=backend, dropout_p=dropout_p, seed=seed)
         return y, y
     if dropout_p > 0 and seed is None:
@@ -211,7 +222,7 @@ def add_layernorm(x, res, gamma, beta, eps, backend="hip", dropout_p=0.0, seed=N
         cols = x.shape[-1]
         if (backend == "hip" and x.dtype == torch.bfloat16 and res.dtype == torch.float32 and cols % 4 == 0
                 and cols <= 1024 and x.is_cuda):
-            return _AddLayerNormMixed.apply(x, res, gamma, beta, eps, float(dropout_p), 0 if seed is None else seed, False)
+            return _AddLayerNormMixed.apply(x, res, gamma, beta, eps, float(dropout_p), 0 if seed is None else seed, False, bias)
         wide = torch.promote_types(x.dtype, res.dtype)
         x, res = x.to(wide), res.to(wide)
     if backend == "hip":

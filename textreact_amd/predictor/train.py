@@ -129,7 +129,10 @@ def gather_outputs(outputs, group=None):
 
 def configure_optimizer(module, lr, weight_decay, num_training_steps, warmup_ratio, scheduler="linear"):
     """main.py:270-276: AdamW + warm-up/decay schedule stepped per optimiser step"""
-    opt = torch.optim.AdamW(module.parameters(), lr=lr, weight_decay=weight_decay)
+    params = list(module.parameters())
+    # same update rule; `fused` runs it as one multi-tensor kernel when the parameters live on the GPU
+    fused = bool(params) and all(p.is_cuda for p in params)
+    opt = torch.optim.AdamW(params, lr=lr, weight_decay=weight_decay, fused=fused)
     warm = int(num_training_steps * warmup_ratio)
 
     def lr_lambda(step):
