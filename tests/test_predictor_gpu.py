@@ -500,3 +500,44 @@ def test_add_layernorm_with_the_producing_linears_bias(p):
         res.append((y.detach(), xs.grad.float(), rs.grad, gs.grad, bs.grad, xbs.grad))
     for a, c, tol in zip(*res, (3e-5, 1e-2, 3e-5, 3e-5, 3e-5, 2e-3)):   # dx (and so its column sums) is rounded to bf16
         assert float((a - c).abs().max()) <= tol * max(1.0, float(c.abs().max()))
+
+
+def test_ddp_wrapper_single_rank_rccl_on_the_hip_ops():
+    """the predictor under DistributedDataParallel with the RCCL ("nccl") backend, one rank: gradients must equal
+    the unwrapped module's (bucketing, hooks and our autograd Functions get along), bf16 autocast"""
+    import socket
+    import torch.distributed as dist
+    from textreact_amd.predictor import train
+    z = np.load(G)
+    enc, dec = json.loads(str(z["enc_cfg"])), json.loads(str(z["dec_cfg"]))
+    for c in (enc, dec):
+        c["hidden_dropout_prob"] = c["attention_probs_dropout_prob"] = 0.0
+    t = lambda k_: torch.from_numpy(z[k_]).cuda()
+    batch = {k_: t(k_) for k_ in ("input_ids", "attention_mask", "decoder_input_ids", "decoder_attention_mask")}
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        grads = []
+        for wrap in (False, True):
+            p = train.Predictor(Config(**enc), Config(is_decoder=True, **dec), mlm=False, backend="hip").cuda().train()
+            p.model.load_state_dict(random_state_dict(p.model, int(z["seed"])))
+
+            class Step(torch.nn.Module):
+                def __init__(self, pred):
+                    super().__init__(); self.pred = pred
+
+                def forward(self, **b):
+                    return self.pred.training_step(b)[0]
+            mod = Step(p)
+            if wrap:
+                mod = torch.nn.parallel.DistributedDataParallel(mod, device_ids=[0], find_unused_parameters=True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                loss = mod(**batch)
+            loss.backward()
+            grads.append({n: q.grad.detach().clone() for n, q in p.named_parameters() if q.grad is not None})
+        assert set(grads[0]) == set(grads[1])
+        for n in grads[0]:
+            assert torch.equal(grads[0][n], grads[1][n]), n
+    finally:
+        dist.destroy_process_group()
