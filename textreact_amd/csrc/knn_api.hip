@@ -89,6 +89,11 @@ static int read_stats(trx_index* idx, hipStream_t st, HostStats* out) {
 static int restructure(trx_index* idx, int64_t newcap, int newmode, hipStream_t st) {
     const int newKp = idx->Kp_for(newmode);
     bf16_t* nCg = nullptr; float* nCo = nullptr; float* nn2 = nullptr; float* nb = nullptr;
+    // an error return below (HIPCHK) must not leak the arrays allocated so far; `commit` disarms the guard
+    struct Guard {
+        bf16_t*& a; float*& b; float*& c; float*& d; bool commit = false;
+        ~Guard() { if (!commit) { if (a) (void)hipFree(a); if (b) (void)hipFree(b); if (c) (void)hipFree(c); if (d) (void)hipFree(d); } }
+    } guard{nCg, nCo, nn2, nb};
     // one spare tile behind the last row: the scan's DMA cursors run up to two K-steps past the end
     const size_t rows_alloc = (size_t)newcap + TILE_M;
     HIPCHK(hipMalloc((void**)&nCg, rows_alloc * newKp * sizeof(bf16_t)));
@@ -120,6 +125,7 @@ static int restructure(trx_index* idx, int64_t newcap, int newmode, hipStream_t 
     if (idx->cbias) (void)hipFree(idx->cbias);
     idx->Cg = nCg; idx->Co = nCo; idx->cnorm2 = nn2; idx->cbias = nb;
     idx->cap = newcap; idx->mode = newmode; idx->Kp = newKp;
+    guard.commit = true;
     return TRX_OK;
 }
 
@@ -151,7 +157,7 @@ void trx_index_destroy(trx_index* idx) {
     if (idx->Co) (void)hipFree(idx->Co);
     if (idx->cnorm2) (void)hipFree(idx->cnorm2);
     if (idx->cbias) (void)hipFree(idx->cbias);
-    DevBuf* bufs[] = {&idx->w_stats, &idx->w_qg, &idx->w_qnorm2, &idx->w_cand, &idx->w_cnt, &idx->w_thr,
+    DevBuf* bufs[] = {&idx->w_stamp, &idx->w_stats, &idx->w_qg, &idx->w_qnorm2, &idx->w_cand, &idx->w_cnt, &idx->w_thr,
                       &idx->w_scratch, &idx->w_flag, &idx->w_exact, &idx->w_io, &idx->w_tmp, &idx->w_gthr};
     for (DevBuf* b : bufs) b->release();
     for (auto& e : idx->ev) if (e) (void)hipEventDestroy(e);
