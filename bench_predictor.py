@@ -27,7 +27,7 @@ def timeit(fn, iters=20, warm=3):
     return a.elapsed_time(b) / iters
 
 
-def train_step_bench(dev, steps=5):
+def train_step_bench(dev, steps=10):
     """one optimisation step of the full-size predictor at the scripts' per-GPU shapes
     (train_RetroSyn_tf.sh: batch 128 over 4 GPUs -> 32, encoder L = 512, decoder T = 160; bf16 autocast
     like --precision 16-mixed, dropout 0.1, AdamW), forward + backward + optimizer, random-init weights."""
@@ -54,7 +54,7 @@ def train_step_bench(dev, steps=5):
             loss.backward()
             opt.step(); opt.zero_grad(set_to_none=True)
             return loss
-        ms = timeit(step, iters=steps, warm=2)
+        ms = timeit(step, iters=steps, warm=4)   # the caching allocator is still growing during the first steps
         tokens = B * (L + T)
         res.append({"kernel": "train_step", "backend": backend, "dtype": "bf16 autocast", "B": B, "L": L, "T": T,
                     "ms": ms, "tokens_per_s": tokens / (ms * 1e-3)})

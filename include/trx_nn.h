@@ -115,6 +115,15 @@ int trx_attention_bwd_strided(const void* q, const void* k, const void* v, const
 /* keep[streams][rows][cols] (1 = kept) exactly as the kernels above decide for (seed, p). */
 int trx_dropout_keep_mask(uint64_t seed, float p, int64_t streams, int64_t rows, int64_t cols, unsigned char* keep, void* stream);
 
+/* C[N, K] = A[M, N]^T . B[M, K]: bf16 operands and result, fp32 accumulation -- the weight gradient of a Linear
+ * layer, dW = dY^T X, with the contraction over the M token rows split across workgroups (fp32 partial tiles in
+ * ws, summed in a fixed order).  M % 64 == 0, N % 256 == 0, K % 256 == 0, lda / ldb % 8 == 0, ldc % 4 == 0, A, B, ws
+ * 16-byte aligned; anything else returns TRX_NN_EINVAL (-1 from the size query) and the caller keeps its library
+ * GEMM.  ws: trx_gemm_tn_ws_bytes(M, N, K) bytes. */
+int64_t trx_gemm_tn_ws_bytes(int M, int N, int K);
+int trx_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, void* ws, void* C, int ldc, int M, int N, int K,
+                     void* stream);
+
 const char* trx_nn_last_error(void);
 const char* trx_nn_version(void);
 

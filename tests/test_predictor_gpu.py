@@ -541,3 +541,32 @@ def test_ddp_wrapper_single_rank_rccl_on_the_hip_ops():
             assert torch.equal(grads[0][n], grads[1][n]), n
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 256, 256), (448, 512, 256), (5120, 768, 768), (16384, 3072, 768), (16384, 768, 3072), (16384, 2304, 768)])
+def test_split_contraction_weight_gradient_gemm(M, N, K):
+    """trx_gemm_tn_bf16: dW = dY^T X with the token rows split over workgroups, against fp32 matmul"""
+    dy, x = _rand(M, N, dtype=torch.bfloat16, seed=1), _rand(M, K, dtype=torch.bfloat16, seed=2)
+    c = ops.gemm_tn(dy, x)
+    ref = dy.float().t() @ x.float()
+    assert c.dtype == torch.bfloat16 and c.shape == (N, K)
+    assert float((c.float() - ref).abs().max()) <= 6e-3 * max(1.0, float(ref.abs().max()))     # one bf16 rounding of the result
+    assert torch.equal(c, ops.gemm_tn(dy, x))                                                   # fixed summation order
+    big = _rand(M, N + 512, dtype=torch.bfloat16, seed=3)                                       # a slice of a packed gradient
+    sl = big[:, 256:256 + N]
+    assert torch.equal(ops.gemm_tn(sl, x), ops.gemm_tn(sl.contiguous(), x))
+
+
+def test_linear_with_our_weight_gradient_equals_autograd():
+    x = _rand(4, 128, 768, dtype=torch.bfloat16, seed=1); w = _rand(2304, 768, seed=2) * 0.05; b = _rand(2304, seed=3)
+    dy = _rand(4, 128, 2304, dtype=torch.bfloat16, seed=4)
+    res = []
+    for mine in (True, False):
+        xs, ws, bs = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = ops.linear(xs, ws, bs) if mine else torch.nn.functional.linear(xs, ws, bs)
+        y.backward(dy)
+        res.append((y.detach().float(), xs.grad.float(), ws.grad, bs.grad))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    for a, c in zip(res[0][2:], res[1][2:]):
+        assert float((a - c).abs().max()) <= 1e-2 * max(1.0, float(c.abs().max()))

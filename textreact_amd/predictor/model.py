@@ -65,7 +65,7 @@ def _dense_add_layernorm(dense, x, h, ln, eps, backend, p):
     the dense layer runs WITHOUT its bias and the fused kernel adds it: the bias gradient then falls out of the
     LayerNorm backward instead of a separate reduction over all rows."""
     if backend == "hip" and x.dtype == torch.bfloat16 and h.dtype == torch.float32 and x.is_cuda:
-        return ops.add_layernorm(torch.nn.functional.linear(x, dense.weight), h, ln.weight, ln.bias, eps, backend=backend,
+        return ops.add_layernorm(ops.linear(x, dense.weight, None, backend), h, ln.weight, ln.bias, eps, backend=backend,
                                  dropout_p=p, dual=True, bias=dense.bias)
     return ops.add_layernorm(dense(x), h, ln.weight, ln.bias, eps, backend=backend, dropout_p=p, dual=True)
 
@@ -92,13 +92,13 @@ class Attention(nn.Module):
             # the attention kernels read the three slices of its output in place
             w = torch.cat([sa.query.weight, sa.key.weight, sa.value.weight])
             bias = torch.cat([sa.query.bias, sa.key.bias, sa.value.bias])
-            qkv = torch.nn.functional.linear(h_low, w, bias).view(B, Lq, 3, self.heads, 64)
+            qkv = ops.linear(h_low, w, bias, backend).view(B, Lq, 3, self.heads, 64)
             ctx = ops.attention_qkv(qkv, mask=mask, causal=causal, backend=backend, dropout_p=pa)
         else:
-            q = sa.query(h_low).view(B, Lq, self.heads, 64)
+            q = ops.linear(h_low, sa.query.weight, sa.query.bias, backend).view(B, Lq, self.heads, 64)
             w = torch.cat([sa.key.weight, sa.value.weight])
             bias = torch.cat([sa.key.bias, sa.value.bias])
-            kv = torch.nn.functional.linear(kv_low, w, bias).view(B, Lk, 2, self.heads, 64)
+            kv = ops.linear(kv_low, w, bias, backend).view(B, Lk, 2, self.heads, 64)
             ctx = ops.attention_q_kv(q, kv, mask=mask, causal=causal, backend=backend, dropout_p=pa)
         return _dense_add_layernorm(self.output.dense, ctx, h, self.output.LayerNorm, self.eps, backend,
                                     self.p_hidden if self.training else 0.0)
@@ -124,7 +124,7 @@ class Layer(nn.Module):
         h, h_low = self.attention(h, h_low, h_low, self_mask, causal, backend)
         if self.cross:
             h, h_low = self.crossattention(h, h_low, enc_low, enc_mask, False, backend)
-        f = torch.nn.functional.gelu(self.intermediate.dense(h_low))
+        f = torch.nn.functional.gelu(ops.linear(h_low, self.intermediate.dense.weight, self.intermediate.dense.bias, backend))
         return _dense_add_layernorm(self.output.dense, f, h, self.output.LayerNorm, self.eps, backend,
                                     self.p_hidden if self.training else 0.0)
 

@@ -22,7 +22,7 @@ SYMBOLS = ["trx_add_layernorm_fwd", "trx_add_layernorm_bwd", "trx_add_layernorm_
            "trx_add_layernorm_fwd_dropout", "trx_add_layernorm_bwd_dropout", "trx_attention_fwd_dropout",
            "trx_attention_bwd_dropout", "trx_dropout_keep_mask", "trx_add_layernorm_fwd_mixed",
            "trx_add_layernorm_bwd_mixed", "trx_attention_fwd_kvcache", "trx_attention_fwd_strided",
-           "trx_attention_bwd_strided", "trx_nn_last_error", "trx_nn_version"]
+           "trx_attention_bwd_strided", "trx_gemm_tn_bf16", "trx_gemm_tn_ws_bytes", "trx_nn_last_error", "trx_nn_version"]
 
 
 class TrxNNError(RuntimeError):
@@ -55,6 +55,9 @@ def lib():
         L.trx_attention_fwd_strided.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, f32, u64, vp, vp, vp]
         L.trx_attention_bwd_strided.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, f32, u64,
                                                 vp, vp, vp, vp, vp, vp, vp]
+        L.trx_gemm_tn_ws_bytes.argtypes = [i32, i32, i32]
+        L.trx_gemm_tn_ws_bytes.restype = i64
+        L.trx_gemm_tn_bf16.argtypes = [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp]
         L.trx_nn_last_error.restype = ctypes.c_char_p
         L.trx_nn_version.restype = ctypes.c_char_p
         _lib = L
@@ -406,3 +409,60 @@ def attention_q_kv(q, kv, mask=None, causal=False, scale=None, backend="hip", dr
         return _AttentionPacked.apply(q, kv, mask, causal, scale, float(dropout_p), 0 if seed is None else seed)
     k, v = kv.unbind(dim=2)
     return attention(q, k, v, mask=mask, causal=causal, scale=scale, backend=backend, dropout_p=dropout_p, seed=seed)
+
+
+# ---- Linear layers: the weight gradient on a split-contraction TN GEMM ---------------------------------------------
+def gemm_tn_ok(a, b):
+    """can trx_gemm_tn_bf16 take dW = a^T b (a [M, N], b [M, K])?"""
+    M, N = a.shape
+    K = b.shape[1]
+    return (a.is_cuda and a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and b.shape[0] == M and M % 64 == 0
+            and N % 256 == 0 and K % 256 == 0 and a.stride(1) == 1 and b.stride(1) == 1 and a.stride(0) % 8 == 0
+            and b.stride(0) % 8 == 0 and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0 and "TRX_NN_NO_GEMM" not in os.environ)
+
+
+def gemm_tn(a, b):
+    """a [M, N]^T . b [M, K] -> [N, K] (bf16): dW = dY^T X"""
+    M, N = a.shape
+    K = b.shape[1]
+    nbytes = lib().trx_gemm_tn_ws_bytes(M, N, K)
+    if nbytes < 0:
+        raise TrxNNError("trx_gemm_tn_bf16 does not take M %d N %d K %d" % (M, N, K))
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=a.device)
+    out = torch.empty((N, K), dtype=torch.bfloat16, device=a.device)
+    _check(lib().trx_gemm_tn_bf16(_p(a), a.stride(0), _p(b), b.stride(0), _p(ws), _p(out), K, M, N, K, _stream(a)))
+    return out
+
+
+class _LinearWgrad(torch.autograd.Function):
+    """y = x W^T (+ b) with the library GEMM; in the backward the weight gradient dY^T X runs on trx_gemm_tn_bf16
+    (the library contracts the 16,384 token rows inside 9 .. 36 workgroups: 0.48 PFLOP/s), dx and db stay library calls"""
+
+    @staticmethod
+    def forward(ctx, x, w16, b16):
+        ctx.save_for_backward(x, w16)
+        ctx.has_bias = b16 is not None
+        return torch.nn.functional.linear(x, w16, b16)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w16 = ctx.saved_tensors
+        dx = dw = db = None
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        x2 = x.reshape(-1, x.shape[-1])
+        if ctx.needs_input_grad[0]:
+            dx = torch.matmul(dy2, w16).view(x.shape)
+        if ctx.needs_input_grad[1]:
+            dw = gemm_tn(dy2, x2) if gemm_tn_ok(dy2, x2) else torch.matmul(dy2.t(), x2)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy2.sum(dim=0)
+        return dx, dw, db
+
+
+def linear(x, weight, bias=None, backend="hip"):
+    """torch.nn.functional.linear; for bf16 activations on the GPU (autocast training) the weight gradient is routed
+    to the split-contraction TN GEMM when its shape qualifies"""
+    if (backend == "hip" and x.is_cuda and x.dtype == torch.bfloat16 and torch.is_grad_enabled() and weight.requires_grad
+            and weight.shape[0] % 256 == 0 and weight.shape[1] % 256 == 0):
+        return _LinearWgrad.apply(x, weight.to(torch.bfloat16), bias.to(torch.bfloat16) if bias is not None else None)
+    return torch.nn.functional.linear(x, weight, bias)

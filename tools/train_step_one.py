@@ -19,7 +19,7 @@ enc = Config(vocab_size=31090)
 dec = Config(vocab_size=600, num_hidden_layers=6, type_vocab_size=1, layer_norm_eps=1e-5, is_decoder=True)
 torch.manual_seed(0)
 p = train.Predictor(enc, dec, mlm=False, backend=backend).to(dev).train()
-opt = torch.optim.AdamW(p.parameters(), lr=1e-4)
+opt, _ = train.configure_optimizer(p, 1e-4, 0.01, 1000, 0.02)
 for _ in range(steps):
     with torch.autocast("cuda", dtype=torch.bfloat16):
         loss, _ = p.training_step(batch)
