@@ -552,6 +552,9 @@ def test_split_contraction_weight_gradient_gemm(M, N, K):
     assert c.dtype == torch.bfloat16 and c.shape == (N, K)
     assert float((c.float() - ref).abs().max()) <= 6e-3 * max(1.0, float(ref.abs().max()))     # one bf16 rounding of the result
     assert torch.equal(c, ops.gemm_tn(dy, x))                                                   # fixed summation order
+    c2, cs = ops.gemm_tn(dy, x, colsum=True)                                                    # db from the same pass
+    assert torch.equal(c2, c)
+    assert float((cs.float() - dy.float().sum(0)).abs().max()) <= 6e-3 * max(1.0, float(dy.float().sum(0).abs().max()))
     big = _rand(M, N + 512, dtype=torch.bfloat16, seed=3)                                       # a slice of a packed gradient
     sl = big[:, 256:256 + N]
     assert torch.equal(ops.gemm_tn(sl, x), ops.gemm_tn(sl.contiguous(), x))

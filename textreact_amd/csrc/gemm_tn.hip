@@ -24,6 +24,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 constexpr int TILE = 256, BM = 64, THREADS = 512;
 constexpr int STAGE = 2 * BM * 512;           // A rows then B rows, 512 B each: 64 KiB
@@ -31,6 +32,7 @@ constexpr int LDS_TOTAL = 2 * STAGE;
 
 struct Params {
     const bf16_t* A; const bf16_t* B; float* ws;
+    float* ws_colsum;   // [nsplit][N] column sums of A (the bias gradient of the same Linear), or null
     int M, N, K, lda, ldb;
     int tn, tk, nsplit, steps_per_split;
 };
@@ -95,12 +97,26 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_tn_kernel(Params p) {
 #pragma unroll
             for (int t = 0; t < 16; ++t) acc[i][j][t] = 0.f;
 
+    // column sums of A (= db of the Linear whose dW this is) ride along in the workgroups of the first k tile: thread ->
+    // 16-byte chunk tid & 31 of rows (tid >> 5) + 16 j, which all share one swizzle
+    const bool colsum = p.ws_colsum != nullptr && kt == 0;
+    const unsigned csaddr = ldsbase + (unsigned)((tid >> 5) * 512 + (((tid & 31) ^ (4 * ((tid >> 5) & 3))) << 4));
+    float cs[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cs[e] = 0.f;
+
     if (nsteps > 0) TRX_TN_STAGE(0, 0);
     __syncthreads();
     int cur = 0;
     for (int s = 0; s < nsteps; ++s) {
         if (s + 1 < nsteps) TRX_TN_STAGE(s + 1, cur ^ 1);
         const unsigned sb = (unsigned)(cur * STAGE);
+        u32x4 cv[4];
+        if (colsum) {   // older than every fragment read below: the first counted wait retires them
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(cv[j]) : "v"(csaddr + sb), "n"(j * 8192) : "memory");
+        }
         // 4 sub-steps of 16 rows; fragments of sub-step ss+1 are read while the MFMAs of ss run
         uint2 ra[2][4][2], rb[2][2][2];     // [slot][block][low / high 4 rows]
 #define TRX_TN_READ(SLOT, SS)                                                                                    \
@@ -124,6 +140,18 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_tn_kernel(Params p) {
         TRX_TN_READ(1, 1)
         TRX_TN_WAIT(0, 12)
         TRX_TN_MFMA(0)
+        if (colsum) {
+            asm volatile("" : "+v"(cv[0]), "+v"(cv[1]), "+v"(cv[2]), "+v"(cv[3]));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned w[4] = {cv[j][0], cv[j][1], cv[j][2], cv[j][3]};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    cs[2 * e] += __uint_as_float(w[e] << 16);
+                    cs[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u);
+                }
+            }
+        }
         TRX_TN_READ(0, 2)
         TRX_TN_WAIT(1, 12)
         TRX_TN_MFMA(1)
@@ -136,6 +164,18 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_tn_kernel(Params p) {
         cur ^= 1;
     }
 #undef TRX_TN_STAGE
+    if (colsum) {   // 16 row groups -> one value per column, through the (now idle) stage memory
+        float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[(tid >> 5) * 256 + (tid & 31) * 8 + e] = cs[e];
+        __syncthreads();
+        if (tid < 256) {
+            float t = 0.f;
+#pragma unroll
+            for (int g2 = 0; g2 < 16; ++g2) t += red[g2 * 256 + tid];
+            p.ws_colsum[(int64_t)split * p.N + n0 + tid] = t;
+        }
+    }
     // ---- partial tile (fp32): ws[split][n][k]; register t of acc[ib][jb] = C[n = .. + (t&3) + 8(t>>2) + 4hh][k = .. + (lane & 31)]
     float* out = p.ws + (int64_t)split * p.N * p.K;
     const int r = lane & 31;
@@ -153,8 +193,18 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_tn_kernel(Params p) {
 }
 
 __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const float* __restrict__ ws, int nsplit, int64_t nk, int K, int ldc,
-                                                             bf16_t* __restrict__ C) {
+                                                             bf16_t* __restrict__ C, const float* __restrict__ ws_colsum, int N,
+                                                             bf16_t* __restrict__ colsum_out) {
     const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (ws_colsum && i < N) {   // the first N / 4 threads also finish the column sums
+        f32x4 c = *reinterpret_cast<const f32x4*>(ws_colsum + i);
+        for (int j = 1; j < nsplit; ++j) c += *reinterpret_cast<const f32x4*>(ws_colsum + (int64_t)j * N + i);
+        const f32x2 lo = {c[0], c[1]}, hi = {c[2], c[3]};
+        uint2 w;
+        w.x = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2));
+        w.y = __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2));
+        *reinterpret_cast<uint2*>(colsum_out + i) = w;
+    }
     if (i >= nk) return;
     f32x4 s = *reinterpret_cast<const f32x4*>(ws + i);
     for (int j = 1; j < nsplit; ++j) s += *reinterpret_cast<const f32x4*>(ws + (int64_t)j * nk + i);
@@ -184,13 +234,14 @@ extern "C" int64_t trx_gemm_tn_ws_bytes(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0 || M % BM || N % TILE || K % TILE) return -1;
     int tn, tk, ns, sps;
     plan(M, N, K, &tn, &tk, &ns, &sps);
-    return (int64_t)ns * N * K * (int64_t)sizeof(float);
+    return (int64_t)ns * ((int64_t)N * K + N) * (int64_t)sizeof(float);   // partial tiles + partial column sums
 }
 
-extern "C" int trx_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, void* ws, void* C, int ldc, int M, int N, int K,
-                                void* stream) {
+extern "C" int trx_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, void* ws, void* C, int ldc, void* colsum_bf16,
+                                int M, int N, int K, void* stream) {
     using namespace trxtn;
     if (!A || !B || !C || !ws || M <= 0 || N <= 0 || K <= 0) return TRX_NN_EINVAL;
+    if (colsum_bf16 && (reinterpret_cast<uintptr_t>(colsum_bf16) & 7)) return TRX_NN_EINVAL;
     if (M % BM || N % TILE || K % TILE || lda < N || ldb < K || ldc < K || (lda | ldb) % 8 || ldc % 4) return TRX_NN_EINVAL;
     if (((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(ws)) & 15) ||
         (reinterpret_cast<uintptr_t>(C) & 7))
@@ -199,6 +250,7 @@ extern "C" int trx_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, 
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.ws = (float*)ws;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb;
     plan(M, N, K, &p.tn, &p.tk, &p.nsplit, &p.steps_per_split);
+    p.ws_colsum = colsum_bf16 ? p.ws + (int64_t)p.nsplit * N * K : nullptr;
     static bool attr = false;
     if (!attr) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL) != hipSuccess)
@@ -209,6 +261,6 @@ extern "C" int trx_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, 
     hipLaunchKernelGGL(gemm_tn_kernel, dim3(p.tn * p.tk * p.nsplit), dim3(THREADS), LDS_TOTAL, st, p);
     const int64_t nk = (int64_t)N * K;
     hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)((nk / 4 + 255) / 256)), dim3(256), 0, st, (const float*)ws, p.nsplit, nk, K,
-                       ldc, (bf16_t*)C);
+                       ldc, (bf16_t*)C, p.ws_colsum, N, (bf16_t*)colsum_bf16);
     return hipGetLastError() == hipSuccess ? TRX_NN_OK : TRX_NN_EHIP;
 }

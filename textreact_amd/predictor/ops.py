@@ -57,7 +57,7 @@ def lib():
                                                 vp, vp, vp, vp, vp, vp, vp]
         L.trx_gemm_tn_ws_bytes.argtypes = [i32, i32, i32]
         L.trx_gemm_tn_ws_bytes.restype = i64
-        L.trx_gemm_tn_bf16.argtypes = [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp]
+        L.trx_gemm_tn_bf16.argtypes = [vp, i32, vp, i32, vp, vp, i32, vp, i32, i32, i32, vp]
         L.trx_nn_last_error.restype = ctypes.c_char_p
         L.trx_nn_version.restype = ctypes.c_char_p
         _lib = L
@@ -421,8 +421,8 @@ def gemm_tn_ok(a, b):
             and b.stride(0) % 8 == 0 and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0 and "TRX_NN_NO_GEMM" not in os.environ)
 
 
-def gemm_tn(a, b):
-    """a [M, N]^T . b [M, K] -> [N, K] (bf16): dW = dY^T X"""
+def gemm_tn(a, b, colsum=False):
+    """a [M, N]^T . b [M, K] -> [N, K] (bf16): dW = dY^T X; with colsum=True also a.sum(0) (db), from the same pass"""
     M, N = a.shape
     K = b.shape[1]
     nbytes = lib().trx_gemm_tn_ws_bytes(M, N, K)
@@ -430,8 +430,9 @@ def gemm_tn(a, b):
         raise TrxNNError("trx_gemm_tn_bf16 does not take M %d N %d K %d" % (M, N, K))
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=a.device)
     out = torch.empty((N, K), dtype=torch.bfloat16, device=a.device)
-    _check(lib().trx_gemm_tn_bf16(_p(a), a.stride(0), _p(b), b.stride(0), _p(ws), _p(out), K, M, N, K, _stream(a)))
-    return out
+    cs = torch.empty(N, dtype=torch.bfloat16, device=a.device) if colsum else None
+    _check(lib().trx_gemm_tn_bf16(_p(a), a.stride(0), _p(b), b.stride(0), _p(ws), _p(out), K, _p(cs), M, N, K, _stream(a)))
+    return (out, cs) if colsum else out
 
 
 class _LinearWgrad(torch.autograd.Function):
@@ -452,9 +453,16 @@ class _LinearWgrad(torch.autograd.Function):
         x2 = x.reshape(-1, x.shape[-1])
         if ctx.needs_input_grad[0]:
             dx = torch.matmul(dy2, w16).view(x.shape)
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            dw = gemm_tn(dy2, x2) if gemm_tn_ok(dy2, x2) else torch.matmul(dy2.t(), x2)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+            if gemm_tn_ok(dy2, x2):
+                if want_db:
+                    dw, db = gemm_tn(dy2, x2, colsum=True)
+                else:
+                    dw = gemm_tn(dy2, x2)
+            else:
+                dw = torch.matmul(dy2.t(), x2)
+        if want_db and db is None:
             db = dy2.sum(dim=0)
         return dx, dw, db
 
