@@ -330,12 +330,11 @@ static int search_batch(trx_index* idx, const void* q, int64_t nq, int is_bf, in
         std::vector<unsigned long long> h((size_t)nwg * 32);
         HIPCHK(hipMemcpyAsync(h.data(), sp.stamp_out, h.size() * 8, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
-        double sum[2][4] = {{0}};
-        for (int w = 0; w < nwg; ++w) for (int v = 0; v < 8; ++v) for (int i = 0; i < 4; ++i) sum[v >> 2][i] += (double)h[((size_t)w * 8 + v) * 4 + i];
-        const double nphase = (double)nwg * 4 * 4.0 * tps * (Kp / BK);  // waves per group x phases
-        for (int g = 0; g < 2; ++g)
-            fprintf(stderr, "[stamp] group %d per phase: load-work %.0f  load-barrier %.0f  mfma-issue %.0f  mfma-barrier %.0f cycles\n",
-                    g, sum[g][0] / nphase, sum[g][1] / nphase, sum[g][2] / nphase, sum[g][3] / nphase);
+        double sum[4] = {0, 0, 0, 0};
+        for (size_t i = 0; i < h.size(); ++i) sum[i & 3] += (double)h[i];
+        const double nw = (double)nwg * 8, tiles = sum[3] / nw;
+        fprintf(stderr, "[stamp] per wave: %.0f tiles; filter %.0f cycles/tile; compaction section %.0f cycles/tile; %.2f lists compacted per tile\n",
+                tiles, sum[0] / nw / tiles, sum[1] / nw / tiles, sum[2] / nw / tiles);
     }
 #endif
 

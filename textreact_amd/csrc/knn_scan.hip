@@ -51,7 +51,8 @@ constexpr int LDS_THRK = LDS_THRC + TILE_N * 8;
 constexpr int LDS_CNT = LDS_THRK + TILE_N * 4;
 constexpr int LDS_OVF = LDS_CNT + TILE_N * 4;
 constexpr int LDS_FLAGS = LDS_OVF + TILE_N * 4;
-constexpr int LDS_TOTAL = LDS_FLAGS + 16;  // flags[2]: one word per tile parity
+constexpr int LDS_WL = LDS_FLAGS + 16;     // flags[2]: one word per tile parity; then the compaction work list
+constexpr int LDS_TOTAL = LDS_WL + 16 + TILE_N * 4;   // count + up to 256 query numbers
 
 constexpr u32 FLAG_COMPACT = 1u;
 constexpr u32 FLAG_DENSE = 2u;
@@ -81,6 +82,8 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
     u32* lds_cnt = reinterpret_cast<u32*>(smem + LDS_CNT);
     u32* lds_ovf = reinterpret_cast<u32*>(smem + LDS_OVF);
     u32* lds_flags = reinterpret_cast<u32*>(smem + LDS_FLAGS);
+    u32* lds_wlcnt = reinterpret_cast<u32*>(smem + LDS_WL);
+    u32* lds_wl = lds_wlcnt + 4;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -147,6 +150,16 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+#ifdef TRX_STAMP_BUILD
+    // diagnostic build: cycles of this wave in the per-tile filter, in the compaction / dense section (barriers
+    // included), and how many lists it compacted
+    unsigned long long st_filter = 0, st_compact = 0, st_ncomp = 0, st_t0 = 0;
+#define TRX_T0() st_t0 = __builtin_readcyclecounter()
+#define TRX_T1(ACC) ACC += __builtin_readcyclecounter() - st_t0
+#else
+#define TRX_T0()
+#define TRX_T1(ACC)
+#endif
     typedef __attribute__((address_space(3))) void lds_void;
     typedef __attribute__((address_space(1))) const void gbl_void;
 #define TRX_STAGE(S, BUF)                                                                           \
@@ -222,6 +235,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
             // ---- epilogue part 1: threshold filter + append (per wave, no barrier) ----
             // flags word alternates with the tile parity so that a fast wave's appends for the
             // next tile can never be seen by a slow wave still deciding about this one.
+            TRX_T0();
             u32* flagw = lds_flags + (tl & 1);
             f32x4 bias[8];
             if (L2) {
@@ -286,6 +300,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
             }
         }
 
+        if (tile_done && !(p.debug & 2)) { TRX_T1(st_filter); }
         __syncthreads();
         cur ^= 1;
 
@@ -293,6 +308,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
             // ---- epilogue part 2: rare compaction / dense rebuild (workgroup-uniform) ----
             const u32 fl = lds_flags[tl & 1];
             if (fl) {
+                TRX_T0();
                 float* scr = reinterpret_cast<float*>(p.scratch) + (int64_t)blockIdx.x * (TILE_N * TILE_M);
                 if (fl & FLAG_DENSE) {
 #pragma unroll
@@ -304,13 +320,29 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
                                 acc[mt][nt];
                         }
                 }
+                if (tid == 0) *lds_wlcnt = 0u;
                 __syncthreads();
                 if (tid == 0) lds_flags[tl & 1] = 0u;
-                for (int i = 0; i < 32; ++i) {
-                    const int ql = wave * 32 + i;
+                // work list of the queries whose list must be compacted (or rebuilt): built by 256 threads at once and
+                // dealt round-robin to the 8 waves -- a wave used to walk its own 32 queries one after the other, and
+                // the whole workgroup waited at the barrier below for the wave that happened to own most of them
+                if (tid < TILE_N) {
+                    const bool need = lds_ovf[tid] != 0u || lds_cnt[tid] > (u32)p.csoft;
+                    const u64 mk = __ballot(need);
+                    u32 base = 0u;
+                    if (lane == 0 && mk) base = atomicAdd(lds_wlcnt, (u32)__popcll(mk));
+                    base = __shfl(base, 0, 64);
+                    if (need) lds_wl[base + (u32)__popcll(mk & ((1ull << lane) - 1ull))] = (u32)tid;
+                }
+                __syncthreads();
+                const int nwork = (int)*lds_wlcnt;
+                for (int i = wave; i < nwork; i += 8) {
+                    const int ql = (int)lds_wl[i];
                     const u32 c = lds_cnt[ql];
                     const bool dense = lds_ovf[ql] != 0u;
-                    if (!dense && c <= (u32)p.csoft) continue;  // wave-uniform
+#ifdef TRX_STAMP_BUILD
+                    ++st_ncomp;
+#endif
                     u64* cq = p.cand + ((qbase + ql) * p.nsplits + split) * CAP;
                     const u32 cc = c < (u32)CAP ? c : (u32)CAP;
                     u64 val = (u32)lane < cc ? ld_u64_l2(cq + lane) : 0ull;
@@ -345,6 +377,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
                     }
                 }
                 __syncthreads();
+                TRX_T1(st_compact);
             }
 #pragma unroll
             for (int mt = 0; mt < 8; ++mt)
@@ -361,6 +394,12 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
         }
     }
 
+#ifdef TRX_STAMP_BUILD
+    if (p.stamp_out && lane == 0) {
+        unsigned long long* o = p.stamp_out + ((size_t)blockIdx.x * 8 + wave) * 4;
+        o[0] = st_filter; o[1] = st_compact; o[2] = st_ncomp; o[3] = (unsigned long long)ntl;
+    }
+#endif
     // ---- publish per-(query, split) count and bound ----
     __syncthreads();
     if (tid < TILE_N && !p.bootstrap) {
