@@ -121,10 +121,11 @@ int trx_dropout_keep_mask(uint64_t seed, float p, int64_t streams, int64_t rows,
  * 16-byte aligned; anything else returns TRX_NN_EINVAL (-1 from the size query) and the caller keeps its library
  * GEMM.  ws: trx_gemm_tn_ws_bytes(M, N, K) bytes. */
 int64_t trx_gemm_tn_ws_bytes(int M, int N, int K);
-int trx_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, void* ws, void* C, int ldc, void* colsum_bf16,
-                     int M, int N, int K, void* stream);
-/* colsum_bf16 (may be NULL): bf16[N] = column sums of A over its M rows -- the bias gradient db = sum_rows dY of the
- * same Linear, computed from the A tiles while they are in LDS for dW. */
+int trx_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, void* ws, void* C, int ldc, void* colsum,
+                     int out_f32, int M, int N, int K, void* stream);
+/* colsum (may be NULL): [N] column sums of A over its M rows -- the bias gradient db = sum_rows dY of the same
+ * Linear, computed from the A tiles while they are in LDS for dW.  out_f32 != 0: C and colsum are written as fp32
+ * (the gradients of fp32 parameters: no rounding and no cast afterwards; C then 16-byte aligned), else bf16. */
 
 const char* trx_nn_last_error(void);
 const char* trx_nn_version(void);

@@ -192,28 +192,36 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_tn_kernel(Params p) {
         }
 }
 
+// OUT32: the results are written as fp32 (the gradient of an fp32 parameter: no rounding, no cast kernel afterwards)
+template <bool OUT32>
 __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const float* __restrict__ ws, int nsplit, int64_t nk, int K, int ldc,
-                                                             bf16_t* __restrict__ C, const float* __restrict__ ws_colsum, int N,
-                                                             bf16_t* __restrict__ colsum_out) {
+                                                             void* __restrict__ C, const float* __restrict__ ws_colsum, int N,
+                                                             void* __restrict__ colsum_out) {
     const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (ws_colsum && i < N) {   // the first N / 4 threads also finish the column sums
         f32x4 c = *reinterpret_cast<const f32x4*>(ws_colsum + i);
         for (int j = 1; j < nsplit; ++j) c += *reinterpret_cast<const f32x4*>(ws_colsum + (int64_t)j * N + i);
-        const f32x2 lo = {c[0], c[1]}, hi = {c[2], c[3]};
-        uint2 w;
-        w.x = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2));
-        w.y = __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2));
-        *reinterpret_cast<uint2*>(colsum_out + i) = w;
+        if (OUT32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(colsum_out) + i) = c;
+        else {
+            const f32x2 lo = {c[0], c[1]}, hi = {c[2], c[3]};
+            uint2 w;
+            w.x = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2));
+            w.y = __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2));
+            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(colsum_out) + i) = w;
+        }
     }
     if (i >= nk) return;
     f32x4 s = *reinterpret_cast<const f32x4*>(ws + i);
     for (int j = 1; j < nsplit; ++j) s += *reinterpret_cast<const f32x4*>(ws + (int64_t)j * nk + i);
-    const f32x2 lo = {s[0], s[1]}, hi = {s[2], s[3]};
-    uint2 w;
-    w.x = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2));
-    w.y = __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2));
     const int64_t n = i / K, k = i % K;
-    *reinterpret_cast<uint2*>(C + n * ldc + k) = w;
+    if (OUT32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(C) + n * ldc + k) = s;
+    else {
+        const f32x2 lo = {s[0], s[1]}, hi = {s[2], s[3]};
+        uint2 w;
+        w.x = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2));
+        w.y = __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2));
+        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(C) + n * ldc + k) = w;
+    }
 }
 
 static void plan(int M, int N, int K, int* tn, int* tk, int* nsplit, int* sps) {
@@ -238,13 +246,13 @@ extern "C" int64_t trx_gemm_tn_ws_bytes(int M, int N, int K) {
 }
 
 extern "C" int trx_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, void* ws, void* C, int ldc, void* colsum_bf16,
-                                int M, int N, int K, void* stream) {
+                                int out_f32, int M, int N, int K, void* stream) {
     using namespace trxtn;
     if (!A || !B || !C || !ws || M <= 0 || N <= 0 || K <= 0) return TRX_NN_EINVAL;
     if (colsum_bf16 && (reinterpret_cast<uintptr_t>(colsum_bf16) & 7)) return TRX_NN_EINVAL;
     if (M % BM || N % TILE || K % TILE || lda < N || ldb < K || ldc < K || (lda | ldb) % 8 || ldc % 4) return TRX_NN_EINVAL;
     if (((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(ws)) & 15) ||
-        (reinterpret_cast<uintptr_t>(C) & 7))
+        (reinterpret_cast<uintptr_t>(C) & (out_f32 ? 15 : 7)) || (out_f32 && colsum_bf16 && (reinterpret_cast<uintptr_t>(colsum_bf16) & 15)))
         return TRX_NN_EINVAL;
     Params p;
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.ws = (float*)ws;
@@ -260,7 +268,11 @@ extern "C" int trx_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, 
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(gemm_tn_kernel, dim3(p.tn * p.tk * p.nsplit), dim3(THREADS), LDS_TOTAL, st, p);
     const int64_t nk = (int64_t)N * K;
-    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)((nk / 4 + 255) / 256)), dim3(256), 0, st, (const float*)ws, p.nsplit, nk, K,
-                       ldc, (bf16_t*)C, p.ws_colsum, N, (bf16_t*)colsum_bf16);
+    if (out_f32)
+        hipLaunchKernelGGL(gemm_tn_reduce_kernel<true>, dim3((unsigned)((nk / 4 + 255) / 256)), dim3(256), 0, st, (const float*)ws, p.nsplit,
+                           nk, K, ldc, C, p.ws_colsum, N, colsum_bf16);
+    else
+        hipLaunchKernelGGL(gemm_tn_reduce_kernel<false>, dim3((unsigned)((nk / 4 + 255) / 256)), dim3(256), 0, st, (const float*)ws, p.nsplit,
+                           nk, K, ldc, C, p.ws_colsum, N, colsum_bf16);
     return hipGetLastError() == hipSuccess ? TRX_NN_OK : TRX_NN_EHIP;
 }

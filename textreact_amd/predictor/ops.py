@@ -57,7 +57,7 @@ def lib():
                                                 vp, vp, vp, vp, vp, vp, vp]
         L.trx_gemm_tn_ws_bytes.argtypes = [i32, i32, i32]
         L.trx_gemm_tn_ws_bytes.restype = i64
-        L.trx_gemm_tn_bf16.argtypes = [vp, i32, vp, i32, vp, vp, i32, vp, i32, i32, i32, vp]
+        L.trx_gemm_tn_bf16.argtypes = [vp, i32, vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, vp]
         L.trx_nn_last_error.restype = ctypes.c_char_p
         L.trx_nn_version.restype = ctypes.c_char_p
         _lib = L
@@ -421,17 +421,19 @@ def gemm_tn_ok(a, b):
             and b.stride(0) % 8 == 0 and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0 and "TRX_NN_NO_GEMM" not in os.environ)
 
 
-def gemm_tn(a, b, colsum=False):
-    """a [M, N]^T . b [M, K] -> [N, K] (bf16): dW = dY^T X; with colsum=True also a.sum(0) (db), from the same pass"""
+def gemm_tn(a, b, colsum=False, out_dtype=torch.bfloat16):
+    """a [M, N]^T . b [M, K] -> [N, K]: dW = dY^T X; with colsum=True also a.sum(0) (db), from the same pass.
+    out_dtype float32: the fp32 sums are returned as they are (gradients of fp32 parameters)"""
     M, N = a.shape
     K = b.shape[1]
     nbytes = lib().trx_gemm_tn_ws_bytes(M, N, K)
     if nbytes < 0:
         raise TrxNNError("trx_gemm_tn_bf16 does not take M %d N %d K %d" % (M, N, K))
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=a.device)
-    out = torch.empty((N, K), dtype=torch.bfloat16, device=a.device)
-    cs = torch.empty(N, dtype=torch.bfloat16, device=a.device) if colsum else None
-    _check(lib().trx_gemm_tn_bf16(_p(a), a.stride(0), _p(b), b.stride(0), _p(ws), _p(out), K, _p(cs), M, N, K, _stream(a)))
+    out = torch.empty((N, K), dtype=out_dtype, device=a.device)
+    cs = torch.empty(N, dtype=out_dtype, device=a.device) if colsum else None
+    _check(lib().trx_gemm_tn_bf16(_p(a), a.stride(0), _p(b), b.stride(0), _p(ws), _p(out), K, _p(cs),
+                                  1 if out_dtype == torch.float32 else 0, M, N, K, _stream(a)))
     return (out, cs) if colsum else out
 
 
@@ -440,10 +442,14 @@ class _LinearWgrad(torch.autograd.Function):
     (the library contracts the 16,384 token rows inside 9 .. 36 workgroups: 0.48 PFLOP/s), dx and db stay library calls"""
 
     @staticmethod
-    def forward(ctx, x, w16, b16):
+    def forward(ctx, x, w, b):
+        # the parameters arrive in their own precision (fp32 under autocast) and are cast here, so that the backward
+        # can hand back gradients in that precision straight from the fp32 sums (no bf16 rounding, no cast kernels)
+        w16 = w.to(torch.bfloat16)
         ctx.save_for_backward(x, w16)
-        ctx.has_bias = b16 is not None
-        return torch.nn.functional.linear(x, w16, b16)
+        ctx.has_bias = b is not None
+        ctx.wdtype = w.dtype
+        return torch.nn.functional.linear(x, w16, b.to(torch.bfloat16) if b is not None else None)
 
     @staticmethod
     def backward(ctx, dy):
@@ -455,15 +461,18 @@ class _LinearWgrad(torch.autograd.Function):
             dx = torch.matmul(dy2, w16).view(x.shape)
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
+            od = torch.float32 if ctx.wdtype == torch.float32 else torch.bfloat16
             if gemm_tn_ok(dy2, x2):
                 if want_db:
-                    dw, db = gemm_tn(dy2, x2, colsum=True)
+                    dw, db = gemm_tn(dy2, x2, colsum=True, out_dtype=od)
                 else:
-                    dw = gemm_tn(dy2, x2)
+                    dw = gemm_tn(dy2, x2, out_dtype=od)
             else:
-                dw = torch.matmul(dy2.t(), x2)
+                dw = torch.matmul(dy2.t(), x2).to(ctx.wdtype)
         if want_db and db is None:
             db = dy2.sum(dim=0)
+        if db is not None:
+            db = db.to(ctx.wdtype)
         return dx, dw, db
 
 
@@ -472,5 +481,5 @@ def linear(x, weight, bias=None, backend="hip"):
     to the split-contraction TN GEMM when its shape qualifies"""
     if (backend == "hip" and x.is_cuda and x.dtype == torch.bfloat16 and torch.is_grad_enabled() and weight.requires_grad
             and weight.shape[0] % 256 == 0 and weight.shape[1] % 256 == 0):
-        return _LinearWgrad.apply(x, weight.to(torch.bfloat16), bias.to(torch.bfloat16) if bias is not None else None)
+        return _LinearWgrad.apply(x, weight, bias)
     return torch.nn.functional.linear(x, weight, bias)
