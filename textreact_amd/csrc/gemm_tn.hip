@@ -211,8 +211,18 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const float* __rest
         }
     }
     if (i >= nk) return;
-    f32x4 s = *reinterpret_cast<const f32x4*>(ws + i);
-    for (int j = 1; j < nsplit; ++j) s += *reinterpret_cast<const f32x4*>(ws + (int64_t)j * nk + i);
+    // four partials in flight per thread (a plain loop waits for each one before asking for the next); the order of
+    // the additions is fixed, so the result is reproducible
+    f32x4 s4[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s4[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int j = 0;
+    for (; j + 3 < nsplit; j += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s4[u] += *reinterpret_cast<const f32x4*>(ws + (int64_t)(j + u) * nk + i);
+    }
+    for (; j < nsplit; ++j) s4[0] += *reinterpret_cast<const f32x4*>(ws + (int64_t)j * nk + i);
+    const f32x4 s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
     const int64_t n = i / K, k = i % K;
     if (OUT32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(C) + n * ldc + k) = s;
     else {

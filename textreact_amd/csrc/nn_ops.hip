@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const void* x, const vo
 }
 
 // ---- backward: dz, and per-block partial column sums of dgamma / dbeta ----
-constexpr int BWD_MAX_BLOCKS = 512;   // workgroups of 4 waves, rows dealt round-robin to the waves
+constexpr int BWD_MAX_BLOCKS = 768;   // workgroups of 4 waves, rows dealt round-robin to the waves
 template <bool BF>
 __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const void* dy, const void* x, const void* res,
                                                          const float* gamma, const float* mean, const float* rstd,
@@ -425,8 +425,17 @@ __global__ __launch_bounds__(256) void add_ln_bwd_reduce_kernel(const float* ws,
     const int c = blockIdx.x * 16 + tc;
     const float* src = ws + (int64_t)blockIdx.y * nblk * cols;
     float a = 0.f;
-    if (c < cols)
-        for (int i = tr; i < nblk; i += 16) a += src[(int64_t)i * cols + c];
+    if (c < cols) {
+        // 8 independent loads in flight per thread: a plain loop waited for each partial row before asking for the next
+        float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int i = tr;
+        for (; i + 7 * 16 < nblk; i += 8 * 16) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a8[u] += src[(int64_t)(i + 16 * u) * cols + c];
+        }
+        for (; i < nblk; i += 16) a8[0] += src[(int64_t)i * cols + c];
+        a = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
+    }
     part[tr][tc] = a;
     __syncthreads();
     if (tr == 0 && c < cols) {
