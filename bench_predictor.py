@@ -55,9 +55,18 @@ def train_step_bench(dev, steps=10):
             opt.step(); opt.zero_grad(set_to_none=True)
             return loss
         ms = timeit(step, iters=steps, warm=4)   # the caching allocator is still growing during the first steps
+
+        def fwd():
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+                return p.model(**batch)[0]
+        p.eval()
+        ms_eval = timeit(fwd, iters=steps, warm=2)
+        p.train()
         tokens = B * (L + T)
         res.append({"kernel": "train_step", "backend": backend, "dtype": "bf16 autocast", "B": B, "L": L, "T": T,
                     "ms": ms, "tokens_per_s": tokens / (ms * 1e-3)})
+        res.append({"kernel": "forward_eval", "backend": backend, "dtype": "bf16 autocast", "B": B, "L": L, "T": T,
+                    "ms": ms_eval, "tokens_per_s": tokens / (ms_eval * 1e-3)})
         del p, opt
         torch.cuda.empty_cache()
     return res
