@@ -233,6 +233,12 @@ class TextReactModel(nn.Module):
 
     def forward(self, input_ids, attention_mask=None, decoder_input_ids=None, decoder_attention_mask=None,
                 position_ids=None, token_type_ids=None):
+        if self.training:   # one generator draw for all the dropout sites of this pass
+            with ops.seed_scope():
+                return self._forward(input_ids, attention_mask, decoder_input_ids, decoder_attention_mask, position_ids, token_type_ids)
+        return self._forward(input_ids, attention_mask, decoder_input_ids, decoder_attention_mask, position_ids, token_type_ids)
+
+    def _forward(self, input_ids, attention_mask, decoder_input_ids, decoder_attention_mask, position_ids, token_type_ids):
         be = self.backend
         if attention_mask is None:
             attention_mask = torch.ones_like(input_ids)

@@ -86,13 +86,50 @@ def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream(t):
+    # the training step is host-bound: the raw-stream query is ~10x cheaper than building a Stream
+    if _raw_stream is not None:
+        return ctypes.c_void_p(_raw_stream(t.device.index if t.device.index is not None else torch.cuda.current_device()))
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
-def new_seed():
-    """a fresh 63-bit dropout seed from torch's CPU generator (so torch.manual_seed makes runs repeatable)"""
+_seed_state = {"base": None, "n": 0}
+_M64 = (1 << 64) - 1
+
+
+def _draw_seed():
     return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+
+
+class seed_scope:
+    """`with ops.seed_scope():` around a forward pass: ONE draw from torch's CPU generator, and every dropout site
+    inside takes a seed derived from it by a hashed counter (splitmix64).  torch.manual_seed therefore still makes
+    runs repeatable, at ~1 us per site instead of the ~10 us of a generator draw (a training step has ~70 sites and
+    is host-bound).  Outside a scope every site draws from the generator itself."""
+
+    def __enter__(self):
+        self.prev = (_seed_state["base"], _seed_state["n"])
+        _seed_state["base"], _seed_state["n"] = _draw_seed(), 0
+        return self
+
+    def __exit__(self, *exc):
+        _seed_state["base"], _seed_state["n"] = self.prev
+        return False
+
+
+def new_seed():
+    """a fresh 62-bit dropout seed (see seed_scope)"""
+    st = _seed_state
+    if st["base"] is None:
+        return _draw_seed()
+    st["n"] += 1
+    z = (st["base"] + st["n"] * 0x9E3779B97F4A7C15) & _M64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+    return (z ^ (z >> 31)) >> 2
 
 
 def dropout_keep_mask(seed, p, streams, rows, cols, device):
@@ -421,12 +458,17 @@ def gemm_tn_ok(a, b):
             and b.stride(0) % 8 == 0 and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0 and "TRX_NN_NO_GEMM" not in os.environ)
 
 
+_tn_ws = {}
+
+
 def gemm_tn(a, b, colsum=False, out_dtype=torch.bfloat16):
     """a [M, N]^T . b [M, K] -> [N, K]: dW = dY^T X; with colsum=True also a.sum(0) (db), from the same pass.
     out_dtype float32: the fp32 sums are returned as they are (gradients of fp32 parameters)"""
     M, N = a.shape
     K = b.shape[1]
-    nbytes = lib().trx_gemm_tn_ws_bytes(M, N, K)
+    nbytes = _tn_ws.get((M, N, K))
+    if nbytes is None:
+        nbytes = _tn_ws[(M, N, K)] = lib().trx_gemm_tn_ws_bytes(M, N, K)
     if nbytes < 0:
         raise TrxNNError("trx_gemm_tn_bf16 does not take M %d N %d K %d" % (M, N, K))
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=a.device)
