@@ -604,3 +604,28 @@ def test_short_training_run_learns_and_tracks_the_pytorch_statement():
     for backend, l in curves.items():
         assert np.mean(l[-5:]) < 0.5 * np.mean(l[:3]), (backend, l[:3], l[-5:])
     assert abs(np.mean(curves["hip"][-5:]) - np.mean(curves["torch"][-5:])) < 0.25 * np.mean(curves["torch"][:3])
+
+
+def test_model_under_fp16_autocast_runs_on_the_bf16_kernels():
+    """the reference's --precision 16-mixed is fp16 autocast: the HIP ops take fp16 activations (on their bf16 kernels)
+    and the model agrees with the PyTorch statement under the same autocast to bf16 accuracy"""
+    z = np.load(G)
+    enc, dec = json.loads(str(z["enc_cfg"])), json.loads(str(z["dec_cfg"]))
+    t = lambda k_: torch.from_numpy(z[k_]).cuda()
+    out = {}
+    for backend in ("hip", "torch"):
+        m = TextReactModel(Config(**enc), Config(is_decoder=True, **dec), backend=backend)
+        m.load_state_dict(random_state_dict(m, int(z["seed"])))
+        m = m.cuda().eval()
+        with torch.autocast("cuda", dtype=torch.float16):
+            logits, _ = m(t("input_ids"), t("attention_mask"), t("decoder_input_ids"), t("decoder_attention_mask"))
+            loss = torch.nn.functional.cross_entropy(logits[:, :-1].reshape(-1, logits.shape[-1]).float(),
+                                                     t("decoder_input_ids")[:, 1:].reshape(-1), ignore_index=0)
+        loss.backward()
+        assert bool(torch.isfinite(logits).all())
+        out[backend] = (logits.detach().float(), {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
+    assert float((out["hip"][0] - out["torch"][0]).abs().max()) <= 6e-2 * max(1.0, float(out["torch"][0].abs().max()))
+    for n in out["hip"][1]:
+        a, c = out["hip"][1][n], out["torch"][1][n]
+        assert bool(torch.isfinite(a).all()), n
+        assert float((a - c).abs().max()) <= 8e-2 * max(1e-2, float(c.abs().max())), n

@@ -238,6 +238,15 @@ def add_layernorm(x, res, gamma, beta, eps, backend="hip", dropout_p=0.0, seed=N
     residual stream fp32 (autocast) -- for the Linear layers that read y next -- and y itself otherwise.
     bias: the bias of the Linear that produced x, when the caller ran that Linear WITHOUT it: x + bias is formed
     here, and in the mixed-storage path inside the kernel, whose backward then yields the bias gradient too."""
+    if backend == "hip" and x.dtype == torch.float16:
+        # fp16 autocast (the reference's --precision 16-mixed): the kernels store bf16 or fp32 -- run on bf16, hand fp16 back
+        # where the caller would have got x's type
+        out = add_layernorm(x.to(torch.bfloat16), res.to(torch.bfloat16) if (res is not None and res.dtype == torch.float16) else res,
+                            gamma, beta, eps, backend=backend, dropout_p=dropout_p, seed=seed, dual=dual, bias=bias)
+        if dual:
+            return out[0].to(torch.float16) if out[0].dtype == torch.bfloat16 else out[0], out[1]
+        return out.to(torch.float16) if out.dtype == torch.bfloat16 else out
+
     def _mixed(x, res):
         cols = x.shape[-1]
         return (backend == "hip" and res is not None and x.dtype == torch.bfloat16 and res.dtype == torch.float32
@@ -323,6 +332,10 @@ def attention(q, k, v, mask=None, causal=False, scale=None, backend="hip", dropo
         scale = 1.0 / math.sqrt(D)
     if dropout_p > 0 and seed is None:
         seed = new_seed()
+    if backend == "hip" and q.dtype == torch.float16:   # fp16 autocast: on the bf16 kernels, fp16 handed back
+        bf = torch.bfloat16
+        return attention(q.to(bf), k.to(bf), v.to(bf), mask=mask, causal=causal, scale=scale, backend=backend,
+                         dropout_p=dropout_p, seed=seed).to(torch.float16)
     if backend == "hip":
         _need_gpu(q)
         if D != 64:
@@ -430,6 +443,9 @@ def attention_qkv(qkv, mask=None, causal=False, scale=None, backend="hip", dropo
         scale = 1.0 / math.sqrt(qkv.shape[-1])
     if dropout_p > 0 and seed is None:
         seed = new_seed()
+    if backend == "hip" and qkv.dtype == torch.float16:
+        return attention_qkv(qkv.to(torch.bfloat16), mask=mask, causal=causal, scale=scale, backend=backend,
+                             dropout_p=dropout_p, seed=seed).to(torch.float16)
     if _packed_ok(qkv, backend):
         return _AttentionPacked.apply(qkv, None, mask, causal, scale, float(dropout_p), 0 if seed is None else seed)
     q, k, v = qkv.unbind(dim=2)
@@ -442,6 +458,9 @@ def attention_q_kv(q, kv, mask=None, causal=False, scale=None, backend="hip", dr
         scale = 1.0 / math.sqrt(q.shape[-1])
     if dropout_p > 0 and seed is None:
         seed = new_seed()
+    if backend == "hip" and q.dtype == torch.float16:
+        return attention_q_kv(q.to(torch.bfloat16), kv.to(torch.bfloat16), mask=mask, causal=causal, scale=scale, backend=backend,
+                              dropout_p=dropout_p, seed=seed).to(torch.float16)
     if _packed_ok(q, backend) and kv.dtype == q.dtype:
         return _AttentionPacked.apply(q, kv, mask, causal, scale, float(dropout_p), 0 if seed is None else seed)
     k, v = kv.unbind(dim=2)
