@@ -82,7 +82,7 @@ def generate_bench(dev):
     g = torch.Generator().manual_seed(0)
     ids = torch.randint(1, 31090, (B, L), generator=g).to(dev)
     am = torch.ones(B, L, dtype=torch.long, device=dev)
-    for backend in ("hip", "torch"):
+    for backend, graph in (("hip", True), ("hip", False), ("torch", False)):
         torch.manual_seed(0)
         m = TextReactModel(Config(vocab_size=31090), Config(vocab_size=600, num_hidden_layers=6, type_vocab_size=1,
                                                             layer_norm_eps=1e-5, is_decoder=True), backend=backend).to(dev).eval()
@@ -90,9 +90,10 @@ def generate_bench(dev):
         def run():
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 return generate(m, ids, am, num_beams=nb, num_return_sequences=nb, max_length=T, length_penalty=0,
-                                bos_token_id=12, eos_token_id=13, pad_token_id=0)
+                                bos_token_id=12, eos_token_id=13, pad_token_id=0, graph=graph)
         ms = timeit(run, iters=2, warm=1)
-        res.append({"kernel": "generate", "backend": backend, "dtype": "bf16 autocast", "B": B, "L": L, "num_beams": nb,
+        res.append({"kernel": "generate", "backend": backend, "decode_step": "hip graph replay" if graph else "eager launches",
+                    "dtype": "bf16 autocast", "B": B, "L": L, "num_beams": nb,
                     "max_length": T, "ms": ms, "decoded_tokens_per_s": B * nb * (T - 1) / (ms * 1e-3)})
         del m
         torch.cuda.empty_cache()

@@ -33,11 +33,11 @@ def until_eos(row, eos):
     return row[: row.index(eos) + 1] if eos in row else row
 
 
-def check_case(z, dec, m, i, case, dev="cpu", tol=1e-4):
+def check_case(z, dec, m, i, case, dev="cpu", tol=1e-4, graph=None):
     ids, am = torch.from_numpy(z["input_ids"]).to(dev), torch.from_numpy(z["attention_mask"]).to(dev)
     seq, sc = generate(m, ids, am, num_beams=case["num_beams"], num_return_sequences=case["num_beams"],
                        max_length=case["max_length"], length_penalty=0, bos_token_id=dec["bos_token_id"],
-                       eos_token_id=dec["eos_token_id"], pad_token_id=dec["pad_token_id"])
+                       eos_token_id=dec["eos_token_id"], pad_token_id=dec["pad_token_id"], graph=graph)
     want_seq, want_sc = z["sequences_%d" % i], z["scores_%d" % i]
     assert seq.shape[0] == want_seq.shape[0] == ids.shape[0] * case["num_beams"]
     got = [until_eos(r, dec["eos_token_id"]) for r in seq.cpu().numpy()]

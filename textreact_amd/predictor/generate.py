@@ -20,6 +20,9 @@ Golden: tests/golden/generate_small.npz holds what `generate` itself returns for
 pads with pad_token_id, the transformers 5.x that produced the golden repeats the end token;
 `batch_decode(skip_special_tokens=True)`, what main.py:227 does next, erases both), scores to 1e-4.
 """
+import contextlib
+import os
+
 import torch
 
 from . import ops
@@ -60,10 +63,26 @@ class _BeamHypotheses:
         return self.worst_score >= best_sum_logprobs / cur_len ** self.length_penalty
 
 
-class _DecoderState:
-    """encoder output, per-layer cross-attention K / V (projected once) and the self-attention cache"""
+def _use_graph(model, dev, graph):
+    """decode through one captured HIP graph per generate call?  Default: yes on a GPU with the HIP ops
+    (TRX_DECODE_GRAPH=0 turns it off); the eager loop is what runs on the CPU and for backend 'torch'."""
+    if graph is None:
+        graph = os.environ.get("TRX_DECODE_GRAPH", "1") != "0"
+    return bool(graph) and dev.type == "cuda" and model.backend == "hip"
 
-    def __init__(self, model, input_ids, attention_mask, expand, max_length):
+
+class _DecoderState:
+    """encoder output, per-layer cross-attention K / V (projected once) and the self-attention cache.
+
+    graph=True: one decode step -- re-order the cache by the surviving beams' parents, embed the new tokens,
+    all decoder layers, the LM head and log-softmax, ~150 launches of a few microseconds each and therefore
+    bound by the host -- is captured ONCE into a HIP graph over static buffers and replayed per position.
+    What changes from step to step lives in device tensors the graph reads: the tokens, the parents, and
+    the position t (the cache row written with index_copy_, the position ids, and a key mask over the
+    full-length cache that opens one more column per step, which gives the same softmax as the eager
+    loop's attention over the first t + 1 cache rows: masked keys contribute exactly 0)."""
+
+    def __init__(self, model, input_ids, attention_mask, expand, max_length, graph=False):
         from .model import additive_key_mask
         self.model, self.be = model, model.backend
         dec = model.decoder.roberta
@@ -72,71 +91,134 @@ class _DecoderState:
         key = additive_key_mask(attention_mask)
         enc = model.encoder(input_ids, key, None, None, None, self.be)
         self.enc_states = enc
-        enc = enc.repeat_interleave(expand, dim=0)
-        self.key = key.repeat_interleave(expand, dim=0)
-        n, L, _ = enc.shape
+        # the `expand` beams of one input share its encoder states: they are the QUERY ROWS of one cross-attention
+        # problem per input (q [B, expand, H, 64] against K / V [B, L, H, 64]), not `expand` copies of K / V
+        self.key, self.expand = key, expand
+        B, L, _ = enc.shape
+        n = B * expand
         self.layers = list(dec.encoder.layer)
         H = self.layers[0].attention.heads
         self.H = H
-        self.kx = [ly.crossattention.self.key(enc).view(n, L, H, 64) for ly in self.layers]
-        self.vx = [ly.crossattention.self.value(enc).view(n, L, H, 64) for ly in self.layers]
+        self.kx = [ly.crossattention.self.key(enc).view(B, L, H, 64) for ly in self.layers]
+        self.vx = [ly.crossattention.self.value(enc).view(B, L, H, 64) for ly in self.layers]
         dt, dev = self.kx[0].dtype, enc.device
         self.kc = [torch.zeros((n, max_length, H, 64), dtype=dt, device=dev) for _ in self.layers]
         self.vc = [torch.zeros((n, max_length, H, 64), dtype=dt, device=dev) for _ in self.layers]
         self.pad = dec.embeddings.pad
+        self.graph = None
+        if graph:
+            self._capture(n, max_length, dev, reorder=expand > 1)
 
-    def step(self, tokens, t):
-        """tokens [n] = the tokens at position t; returns log-probabilities [n, vocab] of position t + 1"""
+    # ---- eager step ----------------------------------------------------------------------------------------
+    def _layers(self, h, self_attention):
         m, be, H = self.model, self.be, self.H
-        emb = m.decoder.roberta.embeddings
-        ids = tokens[:, None]
-        # RoBERTa positions with a cache: (1 + past length) for real tokens, the padding index for padding
-        pos = torch.where(ids.ne(self.pad), torch.full_like(ids, t + 1 + self.pad), torch.full_like(ids, self.pad))
-        h = emb(ids, pos, None, be)
         n = h.shape[0]
         for li, ly in enumerate(self.layers):
             at = ly.attention
             q = at.self.query(h).view(n, 1, H, 64)
-            self.kc[li][:, t] = at.self.key(h).view(n, H, 64)
-            self.vc[li][:, t] = at.self.value(h).view(n, H, 64)
-            ctx = ops.attention(q, self.kc[li][:, :t + 1], self.vc[li][:, :t + 1], mask=None, causal=False, backend=be)
+            ctx = self_attention(li, q, at.self.key(h), at.self.value(h))
             h = ops.add_layernorm(at.output.dense(ctx), h, at.output.LayerNorm.weight, at.output.LayerNorm.bias, at.eps, backend=be)
             ca = ly.crossattention
-            q = ca.self.query(h).view(n, 1, H, 64)
-            ctx = ops.attention(q, self.kx[li], self.vx[li], mask=self.key, causal=False, backend=be)
+            q = ca.self.query(h).view(n // self.expand, self.expand, H, 64)
+            ctx = ops.attention(q, self.kx[li], self.vx[li], mask=self.key, causal=False, backend=be).view(n, 1, H * 64)
             h = ops.add_layernorm(ca.output.dense(ctx), h, ca.output.LayerNorm.weight, ca.output.LayerNorm.bias, ca.eps, backend=be)
             f = torch.nn.functional.gelu(ly.intermediate.dense(h))
             h = ops.add_layernorm(ly.output.dense(f), h, ly.output.LayerNorm.weight, ly.output.LayerNorm.bias, ly.eps, backend=be)
         logits = m.decoder.lm_head(h, be)[:, -1]
         return torch.log_softmax(logits.float(), dim=-1)
 
+    def step(self, tokens, t):
+        """tokens [n] = the tokens at position t; returns log-probabilities [n, vocab] of position t + 1"""
+        if self.graph is not None:
+            self.g_tok.copy_(tokens)
+            self.g_t.fill_(t)
+            self.graph.replay()
+            return self.g_logp
+        be, H = self.be, self.H
+        ids = tokens[:, None]
+        # RoBERTa positions with a cache: (1 + past length) for real tokens, the padding index for padding
+        pos = torch.where(ids.ne(self.pad), torch.full_like(ids, t + 1 + self.pad), torch.full_like(ids, self.pad))
+        h = self.model.decoder.roberta.embeddings(ids, pos, None, be)
+        n = h.shape[0]
+
+        def self_attention(li, q, k, v):
+            self.kc[li][:, t] = k.view(n, H, 64)
+            self.vc[li][:, t] = v.view(n, H, 64)
+            return ops.attention(q, self.kc[li][:, :t + 1], self.vc[li][:, :t + 1], mask=None, causal=False, backend=be)
+        return self._layers(h, self_attention)
+
     def reorder(self, parents, t):
         """keep the caches of the surviving beams' parents (positions 0..t are filled)"""
+        if self.graph is not None:
+            self.g_parents.copy_(parents)          # applied at the head of the next replay
+            return
         for li in range(len(self.layers)):
             self.kc[li][:, :t + 1] = self.kc[li][:, :t + 1].index_select(0, parents)
             self.vc[li][:, :t + 1] = self.vc[li][:, :t + 1].index_select(0, parents)
 
+    # ---- captured step ---------------------------------------------------------------------------------------
+    def _graph_step(self, reorder):
+        be, H = self.be, self.H
+        n = self.g_tok.shape[0]
+        if reorder:
+            for li in range(len(self.layers)):
+                self.kc[li].copy_(self.kc[li].index_select(0, self.g_parents))
+                self.vc[li].copy_(self.vc[li].index_select(0, self.g_parents))
+        self.g_mask.index_fill_(1, self.g_t, 0.0)
+        ids = self.g_tok[:, None]
+        pos = torch.where(ids.ne(self.pad), (self.g_t + (1 + self.pad)).expand_as(ids), torch.full_like(ids, self.pad))
+        h = self.model.decoder.roberta.embeddings(ids, pos, None, be)
+
+        def self_attention(li, q, k, v):
+            self.kc[li].index_copy_(1, self.g_t, k.view(n, 1, H, 64).to(self.kc[li].dtype))
+            self.vc[li].index_copy_(1, self.g_t, v.view(n, 1, H, 64).to(self.vc[li].dtype))
+            return ops.attention(q, self.kc[li], self.vc[li], mask=self.g_mask, causal=False, backend=be)
+        return self._layers(h, self_attention)
+
+    def _capture(self, n, max_length, dev, reorder):
+        self.g_tok = torch.zeros(n, dtype=torch.long, device=dev)
+        self.g_t = torch.zeros(1, dtype=torch.long, device=dev)
+        self.g_parents = torch.arange(n, dtype=torch.long, device=dev)
+        self.g_mask = torch.full((n, max_length), torch.finfo(torch.float32).min, dtype=torch.float32, device=dev)
+        # inside a capture autocast must not cache its casts (they would belong to the graph's pool)
+        if torch.is_autocast_enabled("cuda"):
+            ctx = lambda: torch.autocast("cuda", dtype=torch.get_autocast_dtype("cuda"), cache_enabled=False)   # noqa: E731
+        else:
+            ctx = contextlib.nullcontext
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side), ctx():       # warm-up off the capture: library handles, kernel attributes
+            for _ in range(2):
+                self._graph_step(reorder)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g), ctx():
+            self.g_logp = self._graph_step(reorder)
+        self.g_mask.fill_(torch.finfo(torch.float32).min)      # the warm-up opened column 0
+        self.graph = g
+
 
 @torch.no_grad()
 def generate(model, input_ids, attention_mask=None, num_beams=1, num_return_sequences=None, max_length=20,
-             length_penalty=1.0, early_stopping=False, bos_token_id=None, eos_token_id=None, pad_token_id=0):
+             length_penalty=1.0, early_stopping=False, bos_token_id=None, eos_token_id=None, pad_token_id=0, graph=None):
     """-> (sequences [B * num_return_sequences, T] int64, sequences_scores [B * num_return_sequences] or None).
     Same argument meaning as the `generate` call at main.py:218-226; greedy search for num_beams == 1
-    (sequences_scores is None then, as with Hugging Face, and main.py:228-231 reports zeros)."""
+    (sequences_scores is None then, as with Hugging Face, and main.py:228-231 reports zeros).
+    graph: replay the decode step from a captured HIP graph (None = yes on a GPU with the HIP ops)."""
     was_training = model.training
     model.eval()
     try:
         if num_beams == 1:
-            return _greedy(model, input_ids, attention_mask, max_length, bos_token_id, eos_token_id, pad_token_id), None
+            return _greedy(model, input_ids, attention_mask, max_length, bos_token_id, eos_token_id, pad_token_id, graph), None
         return _beam_search(model, input_ids, attention_mask, num_beams, num_return_sequences or 1, max_length,
-                            length_penalty, early_stopping, bos_token_id, eos_token_id, pad_token_id)
+                            length_penalty, early_stopping, bos_token_id, eos_token_id, pad_token_id, graph)
     finally:
         model.train(was_training)
 
 
-def _greedy(model, input_ids, attention_mask, max_length, bos, eos, pad):
+def _greedy(model, input_ids, attention_mask, max_length, bos, eos, pad, graph=None):
     B, dev = input_ids.shape[0], input_ids.device
-    st = _DecoderState(model, input_ids, attention_mask, 1, max_length)
+    st = _DecoderState(model, input_ids, attention_mask, 1, max_length, _use_graph(model, dev, graph))
     seqs = torch.full((B, 1), bos, dtype=torch.long, device=dev)
     unfinished = torch.ones(B, dtype=torch.long, device=dev)
     for t in range(max_length - 1):
@@ -150,9 +232,10 @@ def _greedy(model, input_ids, attention_mask, max_length, bos, eos, pad):
     return seqs
 
 
-def _beam_search(model, input_ids, attention_mask, nb, keep, max_length, length_penalty, early_stopping, bos, eos, pad):
+def _beam_search(model, input_ids, attention_mask, nb, keep, max_length, length_penalty, early_stopping, bos, eos, pad,
+                 graph=None):
     B, dev = input_ids.shape[0], input_ids.device
-    st = _DecoderState(model, input_ids, attention_mask, nb, max_length)
+    st = _DecoderState(model, input_ids, attention_mask, nb, max_length, _use_graph(model, dev, graph))
     seqs = torch.full((B * nb, 1), bos, dtype=torch.long, device=dev)
     beam_scores = torch.zeros((B, nb), dtype=torch.float32, device=dev)
     beam_scores[:, 1:] = -1e9                        # all beams start identical: only the first one counts
@@ -170,33 +253,32 @@ def _beam_search(model, input_ids, attention_mask, nb, keep, max_length, length_
         # BeamSearchScorer.process, on the host like the original (B * 2 * nb scalars per step)
         s_l, b_l, t_l = top_s.tolist(), top_beam.tolist(), top_tok.tolist()
         seqs_host = None
-        nscore = torch.zeros((B, nb), dtype=torch.float32)
-        ntok = torch.full((B, nb), pad, dtype=torch.long)
-        nidx = torch.zeros((B, nb), dtype=torch.long)
+        nscore, ntok, nidx = [0.0] * (B * nb), [pad] * (B * nb), [0] * (B * nb)     # finished items: zeros / pad / beam 0
         for b in range(B):
             if done[b]:
-                continue                                       # zeros / pad / beam 0, as initialised
-            slot = 0
+                continue
+            slot, tb, sb, bb = b * nb, t_l[b], s_l[b], b_l[b]
             for rank in range(2 * nb):
-                tok, sc, parent = t_l[b][rank], s_l[b][rank], b * nb + b_l[b][rank]
+                tok = tb[rank]
                 if eos is not None and tok == eos:
                     if rank >= nb:                             # an end token outside the top num_beams is ignored
                         continue
                     if seqs_host is None:
                         seqs_host = seqs.cpu()
-                    hyps[b].add(seqs_host[parent].clone(), sc)
+                    hyps[b].add(seqs_host[b * nb + bb[rank]].clone(), sb[rank])
                 else:
-                    nscore[b, slot], ntok[b, slot], nidx[b, slot] = sc, tok, parent
+                    nscore[slot], ntok[slot], nidx[slot] = sb[rank], tok, b * nb + bb[rank]
                     slot += 1
-                if slot == nb:
+                if slot == (b + 1) * nb:
                     break
-            if slot < nb:
+            if slot < (b + 1) * nb:
                 raise ValueError("fewer than num_beams non-end candidates: increase the vocabulary or lower num_beams")
-            done[b] = done[b] or hyps[b].is_done(max(s_l[b]), cur_len)
-        beam_scores = nscore.view(-1).to(dev)
-        parents = nidx.view(-1).to(dev)
+            done[b] = done[b] or hyps[b].is_done(max(sb), cur_len)
+        beam_scores = torch.tensor(nscore, dtype=torch.float32).to(dev)
+        tok_par = torch.tensor([ntok, nidx], dtype=torch.long).to(dev)
+        parents = tok_par[1]
         st.reorder(parents, t)
-        seqs = torch.cat([seqs.index_select(0, parents), ntok.view(-1, 1).to(dev)], dim=1)
+        seqs = torch.cat([seqs.index_select(0, parents), tok_par[0][:, None]], dim=1)
         if all(done) or seqs.shape[1] >= max_length:
             break
     # BeamSearchScorer.finalize

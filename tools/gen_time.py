@@ -1,0 +1,10 @@
+"""generate(): the decode step replayed from a HIP graph vs eager launches vs PyTorch ops (bench_predictor.generate_bench alone)"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench_predictor  # noqa: E402
+
+for r in bench_predictor.generate_bench("cuda"):
+    print(json.dumps(r))
