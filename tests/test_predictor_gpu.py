@@ -395,7 +395,9 @@ def test_graph_decode_equals_the_eager_loop(autocast):
     from textreact_amd.predictor.generate import generate
     torch.manual_seed(3)
     m = TextReactModel(Config(vocab_size=300, num_hidden_layers=2), Config(vocab_size=40, num_hidden_layers=2, type_vocab_size=1,
-                       layer_norm_eps=1e-5, is_decoder=True), backend="hip").cuda().eval()
+                       layer_norm_eps=1e-5, is_decoder=True), backend="hip")
+    m.load_state_dict(random_state_dict(m, 5))      # BERT-style init: logits small enough for bf16 to resolve
+    m = m.cuda().eval()
     g = torch.Generator().manual_seed(1)
     ids = torch.randint(1, 300, (3, 70), generator=g).cuda()
     am = torch.ones(3, 70, dtype=torch.long).cuda()
@@ -423,6 +425,39 @@ def test_template_based_branch_on_the_hip_ops():
     m = m.cuda()
     batch = {k: (v.cuda() if torch.is_tensor(v) else ([t.cuda() for t in v] if k == "atom_indices" else v)) for k, v in batch.items()}
     check(z, m, batch, 1e-3)
+
+
+def test_graph_decode_step_on_bf16_weights_is_as_close_to_fp32_as_eager_autocast():
+    """the captured step under bf16 autocast (prepared bf16 weights, packed key/value cache, biases added inside the
+    LayerNorm kernel) against the fp32 step on the same tokens and the same beam re-ordering, position by position:
+    its error is bf16 rounding of the logits, the same size as the eager autocast loop's"""
+    from textreact_amd.predictor.generate import _DecoderState
+    torch.manual_seed(3)
+    m = TextReactModel(Config(vocab_size=300, num_hidden_layers=2), Config(vocab_size=40, num_hidden_layers=2, type_vocab_size=1,
+                       layer_norm_eps=1e-5, is_decoder=True), backend="hip")
+    m.load_state_dict(random_state_dict(m, 5))
+    m = m.cuda().eval()
+    g = torch.Generator().manual_seed(1)
+    ids = torch.randint(1, 300, (3, 70), generator=g).cuda()
+    am = torch.ones(3, 70, dtype=torch.long).cuda()
+    am[1, 50:] = 0
+    nb, T = 5, 12
+    with torch.no_grad():
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            eager = _DecoderState(m, ids, am, nb, T, graph=False)
+            fast = _DecoderState(m, ids, am, nb, T, graph=True)
+        truth = _DecoderState(m, ids, am, nb, T, graph=False)
+        assert fast.fast and fast.graph is not None and truth.graph is None
+        for t in range(T - 1):
+            tok = torch.randint(3, 40, (3 * nb,), generator=g).cuda()
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                le, lf = eager.step(tok, t).clone(), fast.step(tok, t).clone()
+            lt = truth.step(tok, t)
+            par = torch.stack([torch.randint(0, nb, (nb,), generator=g) + b * nb for b in range(3)]).view(-1).cuda()   # shared parents
+            for st in (eager, fast, truth):
+                st.reorder(par, t)
+            ee, ef = float((le - lt).abs().max()), float((lf - lt).abs().max())
+            assert ef < 0.1 and ef < 2 * ee + 0.01, (t, ee, ef)
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])

@@ -99,13 +99,21 @@ class _DecoderState:
         self.layers = list(dec.encoder.layer)
         H = self.layers[0].attention.heads
         self.H = H
-        self.kx = [ly.crossattention.self.key(enc).view(B, L, H, 64) for ly in self.layers]
-        self.vx = [ly.crossattention.self.value(enc).view(B, L, H, 64) for ly in self.layers]
-        dt, dev = self.kx[0].dtype, enc.device
-        self.kc = [torch.zeros((n, max_length, H, 64), dtype=dt, device=dev) for _ in self.layers]
-        self.vc = [torch.zeros((n, max_length, H, 64), dtype=dt, device=dev) for _ in self.layers]
         self.pad = dec.embeddings.pad
         self.graph = None
+        dev = enc.device
+        # bf16 autocast + graph: the step runs on bf16 copies of the decoder weights made once per call (inside a
+        # capture autocast may not cache its casts, so the module path would cast every weight at every replay),
+        # with the key / value projections packed (one GEMM, one cache tensor and one cache write per layer)
+        self.fast = bool(graph and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16)
+        if self.fast:
+            self._prepare_fast(enc, n, max_length)
+        else:
+            self.kx = [ly.crossattention.self.key(enc).view(B, L, H, 64) for ly in self.layers]
+            self.vx = [ly.crossattention.self.value(enc).view(B, L, H, 64) for ly in self.layers]
+            dt = self.kx[0].dtype
+            self.kc = [torch.zeros((n, max_length, H, 64), dtype=dt, device=dev) for _ in self.layers]
+            self.vc = [torch.zeros((n, max_length, H, 64), dtype=dt, device=dev) for _ in self.layers]
         if graph:
             self._capture(n, max_length, dev, reorder=expand > 1)
 
@@ -161,19 +169,64 @@ class _DecoderState:
         be, H = self.be, self.H
         n = self.g_tok.shape[0]
         if reorder:
-            for li in range(len(self.layers)):
-                self.kc[li].copy_(self.kc[li].index_select(0, self.g_parents))
-                self.vc[li].copy_(self.vc[li].index_select(0, self.g_parents))
+            for c in (self.kvc if self.fast else self.kc + self.vc):
+                c.copy_(c.index_select(0, self.g_parents))
         self.g_mask.index_fill_(1, self.g_t, 0.0)
         ids = self.g_tok[:, None]
         pos = torch.where(ids.ne(self.pad), (self.g_t + (1 + self.pad)).expand_as(ids), torch.full_like(ids, self.pad))
         h = self.model.decoder.roberta.embeddings(ids, pos, None, be)
+        if self.fast:
+            return self._fast_layers(h)
 
         def self_attention(li, q, k, v):
             self.kc[li].index_copy_(1, self.g_t, k.view(n, 1, H, 64).to(self.kc[li].dtype))
             self.vc[li].index_copy_(1, self.g_t, v.view(n, 1, H, 64).to(self.vc[li].dtype))
             return ops.attention(q, self.kc[li], self.vc[li], mask=self.g_mask, causal=False, backend=be)
         return self._layers(h, self_attention)
+
+    def _prepare_fast(self, enc, n, max_length):
+        lin, bf = torch.nn.functional.linear, torch.bfloat16
+        B, L, _ = enc.shape
+        H = self.H
+
+        def w(*mods):      # bf16 weight and bias of one Linear, or of several stacked along the outputs
+            return (torch.cat([m.weight.detach() for m in mods]).to(bf), torch.cat([m.bias.detach() for m in mods]).to(bf))
+        self.w, self.kvx, self.kvc = [], [], []
+        enc16 = enc.to(bf)
+        for ly in self.layers:
+            at, ca = ly.attention, ly.crossattention
+            self.w.append({"q": w(at.self.query), "kv": w(at.self.key, at.self.value), "o": at.output.dense.weight.detach().to(bf),
+                           "qx": w(ca.self.query), "ox": ca.output.dense.weight.detach().to(bf), "i": w(ly.intermediate.dense),
+                           "out": ly.output.dense.weight.detach().to(bf)})
+            self.kvx.append(lin(enc16, *w(ca.self.key, ca.self.value)).view(B, L, 2, H, 64))
+            self.kvc.append(torch.zeros((n, max_length, 2, H, 64), dtype=bf, device=enc.device))
+        head = self.model.decoder.lm_head
+        self.w_head = (w(head.dense), w(head.decoder))
+
+    def _fast_layers(self, h):
+        """the decoder layers of `_layers` on the prepared bf16 weights: fp32 residual stream, bf16 copies of it for the
+        GEMMs written by the LayerNorm kernel, dense biases added inside that kernel"""
+        lin, be, H = torch.nn.functional.linear, self.be, self.H
+        n = h.shape[0]
+        h16 = h.to(torch.bfloat16)
+        for li, ly in enumerate(self.layers):
+            w, at, ca = self.w[li], ly.attention, ly.crossattention
+            q = lin(h16, *w["q"]).view(n, 1, H, 64)
+            self.kvc[li].index_copy_(1, self.g_t, lin(h16, *w["kv"]).view(n, 1, 2, H, 64))
+            ctx = ops.attention_q_kv(q, self.kvc[li], mask=self.g_mask, backend=be)
+            h, h16 = ops.add_layernorm(lin(ctx, w["o"]), h, at.output.LayerNorm.weight, at.output.LayerNorm.bias, at.eps, backend=be,
+                                       dual=True, bias=at.output.dense.bias)
+            q = lin(h16, *w["qx"]).view(n // self.expand, self.expand, H, 64)
+            ctx = ops.attention_q_kv(q, self.kvx[li], mask=self.key, backend=be).view(n, 1, H * 64)
+            h, h16 = ops.add_layernorm(lin(ctx, w["ox"]), h, ca.output.LayerNorm.weight, ca.output.LayerNorm.bias, ca.eps, backend=be,
+                                       dual=True, bias=ca.output.dense.bias)
+            f = torch.nn.functional.gelu(lin(h16, *w["i"]))
+            h, h16 = ops.add_layernorm(lin(f, w["out"]), h, ly.output.LayerNorm.weight, ly.output.LayerNorm.bias, ly.eps, backend=be,
+                                       dual=True, bias=ly.output.dense.bias)
+        head = self.model.decoder.lm_head
+        x = torch.nn.functional.gelu(lin(h16, *self.w_head[0]))
+        x = ops.add_layernorm(x, None, head.layer_norm.weight, head.layer_norm.bias, head.eps, backend=be)
+        return torch.log_softmax(lin(x, *self.w_head[1])[:, -1].float(), dim=-1)
 
     def _capture(self, n, max_length, dev, reorder):
         self.g_tok = torch.zeros(n, dtype=torch.long, device=dev)
