@@ -76,7 +76,8 @@ class _DecoderState:
 
     graph=True: one decode step -- re-order the cache by the surviving beams' parents, embed the new tokens,
     all decoder layers, the LM head and log-softmax, ~150 launches of a few microseconds each and therefore
-    bound by the host -- is captured ONCE into a HIP graph over static buffers and replayed per position.
+    bound by the host -- is captured into a HIP graph over static buffers and replayed per position (with beams: two
+    graphs, for even and odd positions, that re-order the cache from one of two cache sets into the other).
     What changes from step to step lives in device tensors the graph reads: the tokens, the parents, and
     the position t (the cache row written with index_copy_, the position ids, and a key mask over the
     full-length cache that opens one more column per step, which gives the same softmax as the eager
@@ -140,8 +141,9 @@ class _DecoderState:
         if self.graph is not None:
             self.g_tok.copy_(tokens)
             self.g_t.fill_(t)
-            self.graph.replay()
-            return self.g_logp
+            which = t % len(self.graph)           # with beams: even / odd positions alternate between two cache sets
+            self.graph[which].replay()
+            return self.g_logp[which]
         be, H = self.be, self.H
         ids = tokens[:, None]
         # RoBERTa positions with a cache: (1 + past length) for real tokens, the padding index for padding
@@ -165,12 +167,23 @@ class _DecoderState:
             self.vc[li][:, :t + 1] = self.vc[li][:, :t + 1].index_select(0, parents)
 
     # ---- captured step ---------------------------------------------------------------------------------------
-    def _graph_step(self, reorder):
+    def _caches(self):
+        return self.kvc if self.fast else self.kc + self.vc
+
+    def _use_caches(self, tensors):
+        if self.fast:
+            self.kvc = list(tensors)
+        else:
+            self.kc, self.vc = list(tensors[:len(tensors) // 2]), list(tensors[len(tensors) // 2:])
+
+    def _graph_step(self, previous):
+        """previous: the cache set the step before wrote (re-ordered by the parents INTO the current set, which
+        halves the traffic of re-ordering in place through a temporary), or None without beams"""
         be, H = self.be, self.H
         n = self.g_tok.shape[0]
-        if reorder:
-            for c in (self.kvc if self.fast else self.kc + self.vc):
-                c.copy_(c.index_select(0, self.g_parents))
+        if previous is not None:
+            for src, dst in zip(previous, self._caches()):
+                torch.index_select(src, 0, self.g_parents, out=dst)
         self.g_mask.index_fill_(1, self.g_t, 0.0)
         ids = self.g_tok[:, None]
         pos = torch.where(ids.ne(self.pad), (self.g_t + (1 + self.pad)).expand_as(ids), torch.full_like(ids, self.pad))
@@ -240,15 +253,22 @@ class _DecoderState:
             ctx = contextlib.nullcontext
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
+        sets = [self._caches()]
+        if reorder:
+            sets.append([torch.zeros_like(c) for c in sets[0]])
         with torch.cuda.stream(side), ctx():       # warm-up off the capture: library handles, kernel attributes
             for _ in range(2):
-                self._graph_step(reorder)
+                self._graph_step(sets[1] if reorder else None)
         torch.cuda.current_stream(dev).wait_stream(side)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g), ctx():
-            self.g_logp = self._graph_step(reorder)
+        graphs, self.g_logp = [], []
+        for which in range(len(sets)):             # position t replays graph t % 2: reads set (t + 1) % 2, writes set t % 2
+            self._use_caches(sets[which])
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=graphs[0].pool() if graphs else None), ctx():
+                self.g_logp.append(self._graph_step(sets[1 - which] if reorder else None))
+            graphs.append(g)
         self.g_mask.fill_(torch.finfo(torch.float32).min)      # the warm-up opened column 0
-        self.graph = g
+        self.graph, self.g_sets = graphs, sets     # both cache sets stay alive as long as the graphs that write them
 
 
 @torch.no_grad()
@@ -299,10 +319,13 @@ def _beam_search(model, input_ids, attention_mask, nb, keep, max_length, length_
         cur_len = seqs.shape[1]
         logp = st.step(seqs[:, -1], t)
         vocab = logp.shape[-1]
-        scores = (logp + beam_scores[:, None]).view(B, nb * vocab)
-        top_s, top_i = torch.topk(scores, 2 * nb, dim=1, largest=True, sorted=True)
-        top_beam = torch.div(top_i, vocab, rounding_mode="floor")
-        top_tok = top_i % vocab
+        # the 2 * num_beams best continuations of each input, in two stages (per beam, then across an input's beams):
+        # one top-k over [B, num_beams * vocab] runs on B workgroups only
+        k1 = min(2 * nb, vocab)
+        s1, i1 = torch.topk(logp + beam_scores[:, None], k1, dim=1, largest=True, sorted=True)
+        top_s, j = torch.topk(s1.view(B, nb * k1), 2 * nb, dim=1, largest=True, sorted=True)
+        top_beam = torch.div(j, k1, rounding_mode="floor")
+        top_tok = i1.view(B, nb * k1).gather(1, j)
         # BeamSearchScorer.process, on the host like the original (B * 2 * nb scalars per step)
         s_l, b_l, t_l = top_s.tolist(), top_beam.tolist(), top_tok.tolist()
         seqs_host = None
