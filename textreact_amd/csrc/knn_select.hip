@@ -104,7 +104,28 @@ __global__ __launch_bounds__(256) void knn_select_kernel(SelectParams p) {
         const u64 dropped = shfl_u64(v, KEEP);
         tau = dropped > tau ? dropped : tau;
     }
-    const bool have = lane < KEEP && v != 0ull;
+    bool have = lane < KEEP && v != 0ull;
+    // error bound of an approximate key (the same one the certificate uses below)
+    const float xn2 = p.qnorm2[q];
+    const float bq = L2 ? (2.0f * sqrtf(xn2 * p.ymax_norm2) + p.ymax_norm2) : sqrtf(xn2 * p.ymax_norm2);
+    const double eps = (double)p.eps_rel * (double)bq * 1.0001 + 1e-30;
+    // ---- 1b. epsilon window: |approximate - exact| <= eps for every row, so the k candidates with the best
+    // approximate keys all have exact keys >= a_k - eps (a_k = the k-th best approximate key); a candidate whose
+    // approximate key is below a_k - 2 eps has an exact key < a_k - eps and cannot reach the top k: it is not
+    // re-scored (its row is never fetched) and counts as dropped.  The lanes are sorted, so the pruned ones
+    // form a suffix; a non-finite eps prunes nothing.
+    int nkeep = KEEP;
+    if (p.k <= KEEP) {
+        const u64 vk = shfl_u64(v, p.k - 1);
+        const bool prune = have && lane >= p.k && vk != 0ull && ((double)comp_key(v) + eps < (double)comp_key(vk) - eps);
+        const u64 pm = __ballot(prune);
+        if (pm) {
+            nkeep = __ffsll((long long)pm) - 1;
+            const u64 dropped = shfl_u64(v, nkeep);
+            tau = dropped > tau ? dropped : tau;
+            if (lane >= nkeep) have = false;
+        }
+    }
     const u32 id = have ? comp_id(v) : 0xffffffffu;
 
     // ---- 2. canonical fp64 score of each kept candidate (one lane per candidate, k ascending) ----
@@ -127,6 +148,7 @@ __global__ __launch_bounds__(256) void knn_select_kernel(SelectParams p) {
         for (int k0 = 0; k0 < p.d; k0 += SLICE) {
 #pragma unroll
             for (int ps = 0; ps < PASSES; ++ps) {
+                if (ps * (64 / LPR) >= nkeep) break;     // wave-uniform: the rows of this pass were all pruned
                 const int row = ps * (64 / LPR) + lane / LPR, part = lane % LPR;
                 const u32 rid = __shfl(id, row, 64);
                 uint4 val = make_uint4(0, 0, 0, 0);
@@ -189,10 +211,6 @@ __global__ __launch_bounds__(256) void knn_select_kernel(SelectParams p) {
         } else {
             const double s_k = __shfl(ssc, p.k - 1, 64);  // exact score in k-th place
             const float tau_key = comp_key(tau);
-            const float xn2 = p.qnorm2[q];
-            const float bq = L2 ? (2.0f * sqrtf(xn2 * p.ymax_norm2) + p.ymax_norm2)
-                                : sqrtf(xn2 * p.ymax_norm2);
-            const double eps = (double)p.eps_rel * (double)bq * 1.0001 + 1e-30;
             const double bound = (double)tau_key + eps;  // upper bound of an outsider's exact key
             if (L2) {
                 // key = |x|^2 - dist  (exact |x|^2 in fp64, k-ordered)
