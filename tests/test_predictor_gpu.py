@@ -427,6 +427,25 @@ def test_template_based_branch_on_the_hip_ops():
     check(z, m, batch, 1e-3)
 
 
+def test_repeated_graph_decodes_release_their_memory():
+    """graphs, cache sets and pools die with the call; the warm-up stream is reused (a fresh stream per call pinned one
+    BLAS workspace of 76 MB each)"""
+    from textreact_amd.predictor.generate import generate
+    torch.manual_seed(0)
+    m = TextReactModel(Config(vocab_size=300, num_hidden_layers=1), Config(vocab_size=40, num_hidden_layers=1, type_vocab_size=1,
+                       layer_norm_eps=1e-5, is_decoder=True), backend="hip").cuda().eval()
+    g = torch.Generator().manual_seed(0)
+    seen = []
+    for it in range(8):
+        ids = torch.randint(1, 300, (4, 64), generator=g).cuda()
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=it % 2 == 0):
+            generate(m, ids, None, num_beams=4, num_return_sequences=4, max_length=16, length_penalty=0, bos_token_id=1,
+                     eos_token_id=2, pad_token_id=0, graph=True)
+        torch.cuda.synchronize()
+        seen.append(torch.cuda.memory_allocated())
+    assert max(seen[2:]) - min(seen[2:]) < (8 << 20), seen
+
+
 def test_graph_decode_step_on_bf16_weights_is_as_close_to_fp32_as_eager_autocast():
     """the captured step under bf16 autocast (prepared bf16 weights, packed key/value cache, biases added inside the
     LayerNorm kernel) against the fp32 step on the same tokens and the same beam re-ordering, position by position:

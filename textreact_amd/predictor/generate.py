@@ -63,6 +63,9 @@ class _BeamHypotheses:
         return self.worst_score >= best_sum_logprobs / cur_len ** self.length_penalty
 
 
+_warmup_streams = {}
+
+
 def _use_graph(model, dev, graph):
     """decode through one captured HIP graph per generate call?  Default: yes on a GPU with the HIP ops
     (TRX_DECODE_GRAPH=0 turns it off); the eager loop is what runs on the CPU and for backend 'torch'."""
@@ -251,7 +254,11 @@ class _DecoderState:
             ctx = lambda: torch.autocast("cuda", dtype=torch.get_autocast_dtype("cuda"), cache_enabled=False)   # noqa: E731
         else:
             ctx = contextlib.nullcontext
-        side = torch.cuda.Stream(device=dev)
+        # ONE warm-up stream per device for the life of the process: the BLAS library keeps a workspace (76 MB here)
+        # per stream it has ever run on, so a fresh stream per call would pin another one each time
+        side = _warmup_streams.get(dev.index)
+        if side is None:
+            side = _warmup_streams[dev.index] = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         sets = [self._caches()]
         if reorder:
