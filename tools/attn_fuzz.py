@@ -43,7 +43,8 @@ for it in range(n):
         worst = max(worst, e) if Lk > 1 else worst
         # Lk == 1: P = 1, the exact gradients of q and k are 0 and what is left is the bf16 rounding of O inside
         # delta = dO . O (every flash-style backward has it); judged on an absolute scale there
-        tol = 0.15 if (Lk == 1 and name in ("dq", "dk")) else 2.5e-2
+        # (the noise of dk adds up over the Lq queries and grows with the 1 / (1 - p) scaling: ~ 0.01 sqrt(Lq) / (1 - p))
+        tol = max(0.15, 0.012 * Lq ** 0.5 / (1 - p)) if (Lk == 1 and name in ("dq", "dk")) else 2.5e-2
         if not (e <= tol) or not bool(torch.isfinite(a.float()).all()):
             print("FAIL", it, dict(B=B, H=H, Lq=Lq, Lk=Lk, causal=causal, mode=mode, p=p), errs)
             nfail += 1
