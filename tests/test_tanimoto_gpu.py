@@ -1,0 +1,79 @@
+"""libtrxtani.so against the oracle (oracle/tanimoto.py): similarities bit-identical doubles, ranks identical including
+the order among equal similarities (retrieve/retrieve.py:34-40,55-62)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import tanimoto as oracle
+from test_tanimoto_cpu import fingerprints
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(corpus, queries, k):
+    from textreact_amd.tanimoto import TanimotoIndex
+    idx = TanimotoIndex(corpus.shape[1])
+    idx.add(corpus)
+    sim, rank = idx.search(queries, k)
+    want_s, want_r = oracle.search(queries, corpus, k)
+    assert np.array_equal(rank.cpu().numpy(), want_r)
+    assert np.array_equal(sim.cpu().numpy().view(np.uint64), want_s.view(np.uint64))
+    return idx
+
+
+@pytest.mark.parametrize("n,d,nq,k", [(1000, 2048, 5, 100), (64, 2048, 1, 100), (130, 1024, 17, 10), (4099, 2048, 70, 100),
+                                      (777, 64, 33, 7), (5, 8, 3, 100), (20000, 2048, 130, 100)])
+def test_search_equals_the_oracle(n, d, nq, k):
+    rng = np.random.default_rng(n + d + nq)
+    corpus = fingerprints(rng, n, d)
+    queries = fingerprints(rng, nq, d)
+    queries[0] = corpus[n // 2]                    # an exact match
+    _check(corpus, queries, k)
+
+
+def test_many_equal_similarities_are_ordered_by_descending_row_number():
+    rng = np.random.default_rng(3)
+    base = fingerprints(rng, 40, 256, density=0.1)
+    corpus = base[rng.integers(0, 40, 3000)]       # 3000 rows, only 40 distinct fingerprints
+    corpus[100:140] = 0                            # empty fingerprints: similarity 0 by the denominator rule
+    queries = np.concatenate([base[:6], np.zeros((1, 256), dtype=np.int64)])
+    _check(corpus, queries, 100)
+
+
+def test_dtypes_device_inputs_and_the_reference_output_structure():
+    from textreact_amd.tanimoto import TanimotoIndex, retrieve
+    rng = np.random.default_rng(5)
+    corpus = fingerprints(rng, 500, 2048)
+    queries = fingerprints(rng, 9, 2048)
+    want_s, want_r = oracle.search(queries, corpus, 100)
+    for conv in (lambda a: a.astype(np.int32), lambda a: a.astype(np.int8), lambda a: torch.from_numpy(a).cuda()):
+        idx = TanimotoIndex(2048)
+        idx.add(conv(corpus))
+        sim, rank = idx.search(conv(queries), 100)
+        assert np.array_equal(rank.cpu().numpy(), want_r) and np.array_equal(sim.cpu().numpy(), want_s)
+    res = retrieve(queries, corpus, k=100, limit=4)            # retrieve.py:55-66
+    assert sorted(res) == [0, 1, 2, 3] and sorted(res[0]) == ["rank", "similarity"]
+    assert res[2]["rank"] == want_r[2].tolist() and res[2]["similarity"] == want_s[2].tolist()
+
+
+def test_batches_of_64_rows_append_and_bad_inputs_fail_loudly():
+    from textreact_amd.tanimoto import TanimotoIndex, TrxTanimotoError
+    rng = np.random.default_rng(6)
+    corpus = fingerprints(rng, 64 * 5 + 9, 512)
+    queries = fingerprints(rng, 4, 512)
+    idx = TanimotoIndex(512)
+    idx.add(corpus[:128]); idx.add(corpus[128:320]); idx.add(corpus[320:])
+    sim, rank = idx.search(queries, 50)
+    want_s, want_r = oracle.search(queries, corpus, 50)
+    assert np.array_equal(rank.cpu().numpy(), want_r) and np.array_equal(sim.cpu().numpy(), want_s)
+    with pytest.raises(TrxTanimotoError):
+        idx.add(corpus[:3])                                     # the last block is partially filled
+    big = corpus[:64].copy(); big[3, 5] = 300
+    with pytest.raises(TrxTanimotoError):
+        TanimotoIndex(512).add(big)
+    with pytest.raises(TrxTanimotoError):
+        TanimotoIndex(512).add(np.full((64, 512), 200, dtype=np.int64))       # sum of magnitudes >= 32768
+    with pytest.raises(TrxTanimotoError):
+        TanimotoIndex(512).add(np.zeros((64, 512), dtype=np.float32))
+    with pytest.raises(TrxTanimotoError):
+        idx.search(big[:4], 5)

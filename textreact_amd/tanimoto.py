@@ -1,0 +1,191 @@
+"""Brute-force Tanimoto retrieval on the GPU: the reference's retrieve/retrieve.py.
+
+retrieve.py:34-40 scores ONE test reaction against every train reaction with RDKit's TanimotoSimilarity in a pool of
+64 processes, :55-62 keeps the 100 best (`rank`, `similarity`) and dumps {row: {...}} to test_nn.json.  Here the
+train fingerprints -- the dense count arrays retrieve_faiss.py:24-27 already builds from the same RDKit difference
+fingerprints -- are packed once into HBM (one byte per count magnitude, 64-row blocks) and libtrxtani.so
+(include/trx_tanimoto.h) scores 64 queries per pass over them with v_sad_u8; the similarities come back as the same
+doubles (integer numerator / integer denominator, one IEEE division) and the ranking is exact.
+
+    index = TanimotoIndex(2048)                      # cuda:0
+    index.add(train_fps)                             # [N, 2048] int (numpy or torch, host or device)
+    sim, rank = index.search(test_fps, k=100)        # float64 [Q, 100], int64 [Q, 100]
+    result = retrieve(test_fps, train_fps)           # {i: {'rank': [...], 'similarity': [...]}} as retrieve.py:60-63
+
+No CPU fallback: without the HIP library or a GPU the calls raise.  Tokenisation of SMILES into fingerprints is RDKit's
+job (absent here) and stays with the reference's own functions.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+_SO = os.path.join(_CSRC, "libtrxtani.so")
+
+# every symbol include/trx_tanimoto.h declares (tests/test_abi.py checks the header against this list)
+SYMBOLS = ["trx_tanimoto_packed_bytes", "trx_tanimoto_pack", "trx_tanimoto_scores", "trx_tanimoto_last_error"]
+I64, I32, I8 = 0, 1, 2
+QUERY_GROUP, KEY_ID_BITS = 16, 27
+MAX_SUM = 32768          # sum |count| per fingerprint must stay below this (exactness of the key order, see the header)
+
+
+class TrxTanimotoError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def build(force=False):
+    src = os.path.join(_CSRC, "tanimoto.hip")
+    hdr = os.path.join(_HERE, "..", "include", "trx_tanimoto.h")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["make", "-C", _CSRC, "libtrxtani.so"] + (["-B"] if force else []))
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            try:
+                build()
+            except Exception as e:
+                raise TrxTanimotoError("libtrxtani.so is missing and could not be built: %s" % e)
+        L = ctypes.CDLL(_SO)
+        vp, i32, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
+        L.trx_tanimoto_packed_bytes.restype = i64
+        L.trx_tanimoto_packed_bytes.argtypes = [i64, i32]
+        L.trx_tanimoto_pack.argtypes = [vp, i32, i64, i32, i64, i64, vp, vp, vp, vp]
+        L.trx_tanimoto_scores.argtypes = [vp, vp, i64, i32, vp, vp, i32, vp, vp, i64, vp]
+        L.trx_tanimoto_last_error.restype = ctypes.c_char_p
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise TrxTanimotoError(lib().trx_tanimoto_last_error().decode() or "libtrxtani error %d" % rc)
+
+
+def _stream(dev):
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+_DT = {torch.int64: I64, torch.int32: I32, torch.int8: I8}
+
+
+class TanimotoIndex:
+    """flat store of count fingerprints in HBM; `search` = retrieve.py:34-40 + :59-62 for a batch of queries"""
+
+    def __init__(self, d=2048, device=0):
+        if d <= 0 or d % 4:
+            raise TrxTanimotoError("the fingerprint length must be a positive multiple of 4 (got %d)" % d)
+        if not torch.cuda.is_available():
+            raise TrxTanimotoError("TanimotoIndex needs a GPU (there is no CPU implementation behind it)")
+        lib()
+        self.d, self.dev = d, torch.device("cuda", device)
+        self.ntotal, self.cap = 0, 0
+        self.packed = None          # uint8 [cap / 64 * d * 64] in the layout of the header
+        self.row_sum = None         # int32 [cap]
+
+    def _as_device_ints(self, x):
+        t = torch.as_tensor(np.ascontiguousarray(x)) if not torch.is_tensor(x) else x
+        if t.dim() != 2 or t.shape[1] != self.d:
+            raise TrxTanimotoError("expected [n, %d] counts, got %s" % (self.d, tuple(t.shape)))
+        if t.dtype == torch.uint8 or t.dtype == torch.bool or t.dtype == torch.int16:
+            t = t.to(torch.int32)
+        if t.dtype not in _DT:
+            raise TrxTanimotoError("fingerprints must be integer counts (got %s)" % t.dtype)
+        return t.to(self.dev).contiguous()
+
+    def _reserve(self, n):
+        if n <= self.cap:
+            return
+        cap = max(((n + 63) // 64) * 64, 2 * self.cap)
+        packed = torch.zeros(cap * self.d, dtype=torch.uint8, device=self.dev)
+        row_sum = torch.zeros(cap, dtype=torch.int32, device=self.dev)
+        if self.ntotal:
+            used = ((self.ntotal + 63) // 64) * 64
+            packed[:used * self.d] = self.packed[:used * self.d]
+            row_sum[:self.ntotal] = self.row_sum[:self.ntotal]
+        self.packed, self.row_sum, self.cap = packed, row_sum, cap
+
+    def add(self, fps):
+        """append [n, d] integer counts (signed: magnitudes are what RDKit's similarity uses)"""
+        t = self._as_device_ints(fps)
+        n = t.shape[0]
+        if n == 0:
+            return
+        if self.ntotal % 64:
+            # a partially filled block: re-pack its rows together with the new ones
+            raise TrxTanimotoError("add() after a batch whose size is not a multiple of 64 is not supported: add everything at once, "
+                                   "or in batches that are multiples of 64 rows")
+        if self.ntotal + n >= (1 << KEY_ID_BITS):
+            raise TrxTanimotoError("at most 2^27 - 1 rows")
+        self._reserve(self.ntotal + n)
+        flags = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        _check(lib().trx_tanimoto_pack(t.data_ptr(), _DT[t.dtype], n, self.d, t.stride(0), self.ntotal, self.packed.data_ptr(),
+                                       self.row_sum.data_ptr(), flags.data_ptr(), _stream(self.dev)))
+        if int(flags.item()) & 1:
+            raise TrxTanimotoError("a count magnitude above 255 does not fit the byte storage")
+        if int(self.row_sum[self.ntotal:self.ntotal + n].max().item()) >= MAX_SUM:
+            raise TrxTanimotoError("sum |count| of a fingerprint must be < %d" % MAX_SUM)
+        self.ntotal += n
+
+    def _pack_queries(self, q):
+        mag = q.abs()
+        if int(mag.max().item()) > 255:
+            raise TrxTanimotoError("a count magnitude above 255 does not fit the byte storage")
+        q_sum = mag.sum(dim=1, dtype=torch.int64)
+        if int(q_sum.max().item()) >= MAX_SUM:
+            raise TrxTanimotoError("sum |count| of a fingerprint must be < %d" % MAX_SUM)
+        nq = q.shape[0]
+        nq_pad = (nq + QUERY_GROUP - 1) // QUERY_GROUP * QUERY_GROUP
+        b = torch.zeros((nq_pad, self.d), dtype=torch.uint8, device=self.dev)
+        b[:nq] = mag.to(torch.uint8)
+        q_t = b.view(torch.int32).t().contiguous()                  # [d / 4, nq_pad] dwords, dword j of query q at [j, q]
+        s = torch.zeros(nq_pad, dtype=torch.int32, device=self.dev)
+        s[:nq] = q_sum.to(torch.int32)
+        return q_t, s
+
+    def search(self, queries, k=100, batch=64):
+        """-> (similarity float64 [Q, k'], rank int64 [Q, k']) on the device, k' = min(k, ntotal); best first, equal
+        similarities ordered by descending row number"""
+        q = self._as_device_ints(queries)
+        nq, n = q.shape[0], self.ntotal
+        kk = min(k, n)
+        sim = torch.zeros((nq, kk), dtype=torch.float64, device=self.dev)
+        rank = torch.zeros((nq, kk), dtype=torch.int64, device=self.dev)
+        if nq == 0 or kk == 0:
+            return sim, rank
+        for lo in range(0, nq, batch):
+            qb = q[lo:lo + batch]
+            m = qb.shape[0]
+            q_t, q_sum = self._pack_queries(qb)
+            both = torch.empty((m, n), dtype=torch.int32, device=self.dev)
+            keys = torch.empty((m, n), dtype=torch.int64, device=self.dev)
+            _check(lib().trx_tanimoto_scores(self.packed.data_ptr(), self.row_sum.data_ptr(), n, self.d, q_t.data_ptr(), q_sum.data_ptr(),
+                                             m, both.data_ptr(), keys.data_ptr(), n, _stream(self.dev)))
+            top = torch.topk(keys, kk, dim=1, largest=True, sorted=True).values
+            r = top & ((1 << KEY_ID_BITS) - 1)
+            a = both.gather(1, r).to(torch.float64)
+            den = self.row_sum[:n].to(torch.float64)[r] + q_sum[:m].to(torch.float64)[:, None] - a
+            sim[lo:lo + m] = torch.where(den.abs() < 1e-6, torch.zeros_like(a), a / den)
+            rank[lo:lo + m] = r
+        return sim, rank
+
+
+def retrieve(test_fps, train_fps, k=100, limit=None, device=0):
+    """the structure retrieve.py:55-66 dumps to test_nn.json: {i: {'rank': [...], 'similarity': [...]}} for the first
+    `limit` queries (the script stops after 100)"""
+    index = TanimotoIndex(np.asarray(train_fps).shape[1] if not torch.is_tensor(train_fps) else train_fps.shape[1], device)
+    index.add(train_fps)
+    q = test_fps if limit is None else test_fps[:limit]
+    sim, rank = index.search(q, k)
+    sim, rank = sim.cpu().numpy(), rank.cpu().numpy()
+    return {i: {"rank": rank[i].tolist(), "similarity": sim[i].tolist()} for i in range(len(rank))}
