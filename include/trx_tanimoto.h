@@ -52,7 +52,16 @@ int trx_tanimoto_pack(const void* fps, int dtype, int64_t n, int d, int64_t ld, 
  *    of a row are the k best matches, ties won by the larger row number (a stable ascending argsort read backwards,
  *    retrieve.py:59).  Requires n < 2^27. */
 int trx_tanimoto_scores(const void* packed, const int32_t* row_sum, int64_t n, int d, const uint32_t* q_t, const int32_t* q_sum,
-                        int nq, uint32_t* and_out, int64_t* key_out, int64_t ld_out, void* stream);
+                        int nq, uint32_t* and_out, int64_t* key_out, int64_t ld_out, int64_t* block_max, void* stream);
+
+/* Selection without sorting every key (retrieve.py:59 argsorts all N similarities).  block_max (above; may be NULL):
+ * block_max[q * ceil(n / 64) + b] = the best key among rows 64 b .. 64 b + 63.  The k-th largest block maximum t is a
+ * lower bound of the k-th largest key (k blocks hold a key >= t), so every one of the k best keys is >= t:
+ * trx_tanimoto_filter appends the keys >= thr[q] of query q to out[q * cap ...] (any order; counts[q], zeroed by the
+ * caller, ends as the number found -- if it exceeds cap the list is incomplete and the caller must select from the
+ * full key row instead) and the k best of that short list are the k best overall. */
+int trx_tanimoto_filter(const int64_t* keys, int64_t n, int64_t ld, int nq, const int64_t* thr, int cap, int64_t* out, int32_t* counts,
+                        void* stream);
 
 const char* trx_tanimoto_last_error(void);
 

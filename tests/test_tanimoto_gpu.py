@@ -22,7 +22,7 @@ def _check(corpus, queries, k):
 
 
 @pytest.mark.parametrize("n,d,nq,k", [(1000, 2048, 5, 100), (64, 2048, 1, 100), (130, 1024, 17, 10), (4099, 2048, 70, 100),
-                                      (777, 64, 33, 7), (5, 8, 3, 100), (20000, 2048, 130, 100)])
+                                      (777, 64, 33, 7), (5, 8, 3, 100), (20000, 2048, 130, 100), (70001, 1024, 40, 100)])
 def test_search_equals_the_oracle(n, d, nq, k):
     rng = np.random.default_rng(n + d + nq)
     corpus = fingerprints(rng, n, d)
@@ -38,6 +38,17 @@ def test_many_equal_similarities_are_ordered_by_descending_row_number():
     corpus[100:140] = 0                            # empty fingerprints: similarity 0 by the denominator rule
     queries = np.concatenate([base[:6], np.zeros((1, 256), dtype=np.int64)])
     _check(corpus, queries, 100)
+
+
+def test_shortlist_selection_with_heavy_ties_falls_back_to_the_full_key_rows():
+    """30,000 rows but 40 distinct fingerprints: far more keys sit above the block-maximum bound than the short list
+    holds, for some queries; the result is still the oracle's, tie order included"""
+    rng = np.random.default_rng(4)
+    base = fingerprints(rng, 40, 512, density=0.08)
+    corpus = base[rng.integers(0, 40, 30001)]
+    queries = np.concatenate([base[:5], fingerprints(rng, 3, 512, density=0.08)])
+    _check(corpus, queries, 100)
+    _check(corpus, queries, 1)
 
 
 def test_dtypes_device_inputs_and_the_reference_output_structure():

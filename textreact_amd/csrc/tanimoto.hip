@@ -68,7 +68,7 @@ template <int NG>
 __global__ __launch_bounds__(256) void scores_kernel(const uint32_t* __restrict__ packed, const int32_t* __restrict__ row_sum, int64_t n,
                                                      int dw, const uint32_t* __restrict__ q_t, const int32_t* __restrict__ q_sum, int q0,
                                                      int nq, int nq_pad, uint32_t* __restrict__ and_out, int64_t* __restrict__ key_out,
-                                                     int64_t ld_out) {
+                                                     int64_t ld_out, int64_t* __restrict__ block_max) {
     constexpr int NQ = NG * QG;
     const int lane = threadIdx.x & 63;
     const int64_t blk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -98,30 +98,63 @@ __global__ __launch_bounds__(256) void scores_kernel(const uint32_t* __restrict_
         for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_sad_u8(v, qq[q], acc[q]);
     }
     const int64_t row = blk * 64 + lane;
-    if (row >= n) return;
-    const int rs = row_sum[row];
+    const bool live = row < n;
+    const int rs = live ? row_sum[row] : 0;
+    const int64_t nblocks = (n + 63) >> 6;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int qi = qbase + q;
-        if (qi < nq) {
+        if (qi < nq) {                                     // wave-uniform
             const int s = rs + q_sum[qi];
             const int a = (s - (int)acc[q]) >> 1;          // sum of minima
             const int dn = s - a;                          // |v1| + |v2| - and
             const double sim = dn > 0 ? (double)a / (double)dn : 0.0;
             const uint64_t fx = (uint64_t)(sim * 68719476735.0);     // 2^36 - 1
-            if (and_out) and_out[(int64_t)qi * ld_out + row] = (uint32_t)a;
-            key_out[(int64_t)qi * ld_out + row] = (int64_t)((fx << TRX_TANI_KEY_ID_BITS) | (uint64_t)row);
+            const int64_t key = live ? (int64_t)((fx << TRX_TANI_KEY_ID_BITS) | (uint64_t)row) : (int64_t)-1;
+            if (live) {
+                if (and_out) and_out[(int64_t)qi * ld_out + row] = (uint32_t)a;
+                key_out[(int64_t)qi * ld_out + row] = key;
+            }
+            if (block_max) {                               // best key of this block of 64 rows (selection threshold, see the header)
+                int64_t m = key;
+#pragma unroll
+                for (int o = 32; o; o >>= 1) {
+                    const int64_t x = __shfl_xor(m, o, 64);
+                    m = x > m ? x : m;
+                }
+                if (lane == 0) block_max[(int64_t)qi * nblocks + blk] = m;
+            }
         }
+    }
+}
+
+// keys >= thr[q] of every query, appended in any order (they are distinct: the row number is part of a key)
+__global__ __launch_bounds__(256) void filter_kernel(const int64_t* __restrict__ keys, int64_t n, int64_t ld, const int64_t* __restrict__ thr,
+                                                     int cap, int64_t* __restrict__ out, int32_t* __restrict__ counts) {
+    const int q = blockIdx.y;
+    const int64_t t = thr[q];
+    const int64_t* kq = keys + (int64_t)q * ld;
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2; i < n; i += (int64_t)gridDim.x * 512) {
+        int64_t a, b = -1;
+        if (i + 1 < n && (((uintptr_t)(kq + i)) & 15) == 0) {
+            const longlong2 v = *reinterpret_cast<const longlong2*>(kq + i);
+            a = v.x; b = v.y;
+        } else {
+            a = kq[i];
+            if (i + 1 < n) b = kq[i + 1];
+        }
+        if (a >= t) { const int pos = atomicAdd(&counts[q], 1); if (pos < cap) out[(int64_t)q * cap + pos] = a; }
+        if (b >= t) { const int pos = atomicAdd(&counts[q], 1); if (pos < cap) out[(int64_t)q * cap + pos] = b; }
     }
 }
 
 template <int NG>
 void launch_scores(const void* packed, const int32_t* row_sum, int64_t n, int d, const uint32_t* q_t, const int32_t* q_sum, int q0, int count,
-                   int nq, int nq_pad, uint32_t* and_out, int64_t* key_out, int64_t ld_out, hipStream_t st) {
+                   int nq, int nq_pad, uint32_t* and_out, int64_t* key_out, int64_t ld_out, int64_t* block_max, hipStream_t st) {
     const int64_t blocks = (n + 63) / 64;
     const dim3 grid((unsigned)((blocks + 3) / 4), (unsigned)count);
     hipLaunchKernelGGL(scores_kernel<NG>, grid, dim3(256), 0, st, (const uint32_t*)packed, row_sum, n, d / 4, q_t, q_sum, q0, nq, nq_pad,
-                       and_out, key_out, ld_out);
+                       and_out, key_out, ld_out, block_max);
 }
 
 }  // namespace
@@ -154,7 +187,7 @@ int trx_tanimoto_pack(const void* fps, int dtype, int64_t n, int d, int64_t ld, 
 }
 
 int trx_tanimoto_scores(const void* packed, const int32_t* row_sum, int64_t n, int d, const uint32_t* q_t, const int32_t* q_sum, int nq,
-                        uint32_t* and_out, int64_t* key_out, int64_t ld_out, void* stream) {
+                        uint32_t* and_out, int64_t* key_out, int64_t ld_out, int64_t* block_max, void* stream) {
     if (n < 0 || nq < 0 || d <= 0 || d % 4 || ld_out < n) return fail(-1, "trx_tanimoto_scores: bad shape");
     if (n >= ((int64_t)1 << TRX_TANI_KEY_ID_BITS)) return fail(-1, "trx_tanimoto_scores: n must be < 2^27 (row numbers ride in the keys)");
     if (n == 0 || nq == 0) return 0;
@@ -162,11 +195,23 @@ int trx_tanimoto_scores(const void* packed, const int32_t* row_sum, int64_t n, i
     const int nq_pad = (nq + QG - 1) / QG * QG;
     hipStream_t st = (hipStream_t)stream;
     const int full = nq_pad / (4 * QG);                   // passes over the corpus with 64 queries per wave
-    if (full) launch_scores<4>(packed, row_sum, n, d, q_t, q_sum, 0, full, nq, nq_pad, and_out, key_out, ld_out, st);
+    if (full) launch_scores<4>(packed, row_sum, n, d, q_t, q_sum, 0, full, nq, nq_pad, and_out, key_out, ld_out, block_max, st);
     const int q0 = full * 4 * QG, rem = (nq_pad - q0) / QG;
-    if (rem == 1) launch_scores<1>(packed, row_sum, n, d, q_t, q_sum, q0, 1, nq, nq_pad, and_out, key_out, ld_out, st);
-    else if (rem == 2) launch_scores<2>(packed, row_sum, n, d, q_t, q_sum, q0, 1, nq, nq_pad, and_out, key_out, ld_out, st);
-    else if (rem == 3) launch_scores<3>(packed, row_sum, n, d, q_t, q_sum, q0, 1, nq, nq_pad, and_out, key_out, ld_out, st);
+    if (rem == 1) launch_scores<1>(packed, row_sum, n, d, q_t, q_sum, q0, 1, nq, nq_pad, and_out, key_out, ld_out, block_max, st);
+    else if (rem == 2) launch_scores<2>(packed, row_sum, n, d, q_t, q_sum, q0, 1, nq, nq_pad, and_out, key_out, ld_out, block_max, st);
+    else if (rem == 3) launch_scores<3>(packed, row_sum, n, d, q_t, q_sum, q0, 1, nq, nq_pad, and_out, key_out, ld_out, block_max, st);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail(-2, hipGetErrorString(e));
+}
+
+int trx_tanimoto_filter(const int64_t* keys, int64_t n, int64_t ld, int nq, const int64_t* thr, int cap, int64_t* out, int32_t* counts,
+                        void* stream) {
+    if (n < 0 || nq < 0 || ld < n || cap <= 0) return fail(-1, "trx_tanimoto_filter: bad shape");
+    if (n == 0 || nq == 0) return 0;
+    if (!keys || !thr || !out || !counts) return fail(-1, "trx_tanimoto_filter: null pointer");
+    const int64_t want = (n + 511) / 512;
+    const dim3 grid((unsigned)(want < 2048 ? want : 2048), (unsigned)nq);
+    hipLaunchKernelGGL(filter_kernel, grid, dim3(256), 0, (hipStream_t)stream, keys, n, ld, thr, cap, out, counts);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail(-2, hipGetErrorString(e));
 }

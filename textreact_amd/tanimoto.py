@@ -27,7 +27,7 @@ _CSRC = os.path.join(_HERE, "csrc")
 _SO = os.path.join(_CSRC, "libtrxtani.so")
 
 # every symbol include/trx_tanimoto.h declares (tests/test_abi.py checks the header against this list)
-SYMBOLS = ["trx_tanimoto_packed_bytes", "trx_tanimoto_pack", "trx_tanimoto_scores", "trx_tanimoto_last_error"]
+SYMBOLS = ["trx_tanimoto_packed_bytes", "trx_tanimoto_pack", "trx_tanimoto_scores", "trx_tanimoto_filter", "trx_tanimoto_last_error"]
 I64, I32, I8 = 0, 1, 2
 QUERY_GROUP, KEY_ID_BITS = 16, 27
 MAX_SUM = 32768          # sum |count| per fingerprint must stay below this (exactness of the key order, see the header)
@@ -61,7 +61,8 @@ def lib():
         L.trx_tanimoto_packed_bytes.restype = i64
         L.trx_tanimoto_packed_bytes.argtypes = [i64, i32]
         L.trx_tanimoto_pack.argtypes = [vp, i32, i64, i32, i64, i64, vp, vp, vp, vp]
-        L.trx_tanimoto_scores.argtypes = [vp, vp, i64, i32, vp, vp, i32, vp, vp, i64, vp]
+        L.trx_tanimoto_scores.argtypes = [vp, vp, i64, i32, vp, vp, i32, vp, vp, i64, vp, vp]
+        L.trx_tanimoto_filter.argtypes = [vp, i64, i64, i32, vp, i32, vp, vp, vp]
         L.trx_tanimoto_last_error.restype = ctypes.c_char_p
         _lib = L
     return _lib
@@ -153,7 +154,7 @@ class TanimotoIndex:
         s[:nq] = q_sum.to(torch.int32)
         return q_t, s
 
-    def search(self, queries, k=100, batch=64):
+    def search(self, queries, k=100, batch=128):
         """-> (similarity float64 [Q, k'], rank int64 [Q, k']) on the device, k' = min(k, ntotal); best first, equal
         similarities ordered by descending row number"""
         q = self._as_device_ints(queries)
@@ -169,9 +170,26 @@ class TanimotoIndex:
             q_t, q_sum = self._pack_queries(qb)
             both = torch.empty((m, n), dtype=torch.int32, device=self.dev)
             keys = torch.empty((m, n), dtype=torch.int64, device=self.dev)
+            nblocks = (n + 63) // 64
+            cap = max(4 * kk, 1024)
+            shortlist = nblocks >= kk and n > 4 * cap       # otherwise the key rows are short enough to select from directly
+            bmax = torch.empty((m, nblocks), dtype=torch.int64, device=self.dev) if shortlist else None
             _check(lib().trx_tanimoto_scores(self.packed.data_ptr(), self.row_sum.data_ptr(), n, self.d, q_t.data_ptr(), q_sum.data_ptr(),
-                                             m, both.data_ptr(), keys.data_ptr(), n, _stream(self.dev)))
-            top = torch.topk(keys, kk, dim=1, largest=True, sorted=True).values
+                                             m, both.data_ptr(), keys.data_ptr(), n, bmax.data_ptr() if shortlist else None,
+                                             _stream(self.dev)))
+            if shortlist:
+                # the k-th best block maximum bounds the k-th best key from below: only keys above it can be among the k best
+                thr = torch.topk(bmax, kk, dim=1, largest=True, sorted=True).values[:, -1].contiguous()
+                cand = torch.full((m, cap), -1, dtype=torch.int64, device=self.dev)
+                counts = torch.zeros(m, dtype=torch.int32, device=self.dev)
+                _check(lib().trx_tanimoto_filter(keys.data_ptr(), n, n, m, thr.data_ptr(), cap, cand.data_ptr(), counts.data_ptr(),
+                                                 _stream(self.dev)))
+                top = torch.topk(cand, kk, dim=1, largest=True, sorted=True).values
+                over = (counts > cap).nonzero().flatten()
+                if over.numel():                            # more keys above the bound than the list holds (heavily tied data)
+                    top[over] = torch.topk(keys[over], kk, dim=1, largest=True, sorted=True).values
+            else:
+                top = torch.topk(keys, kk, dim=1, largest=True, sorted=True).values
             r = top & ((1 << KEY_ID_BITS) - 1)
             a = both.gather(1, r).to(torch.float64)
             den = self.row_sum[:n].to(torch.float64)[r] + q_sum[:m].to(torch.float64)[:, None] - a
