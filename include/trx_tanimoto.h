@@ -46,22 +46,27 @@ int trx_tanimoto_pack(const void* fps, int dtype, int64_t n, int d, int64_t ld, 
 
 /* queries: q_t [d / 4, nq_pad] dwords of packed magnitudes, TRANSPOSED (dword j of query q at q_t[j * nq_pad + q];
  * nq_pad = nq rounded up to a multiple of 16, padding zero) and q_sum[nq_pad].
- * -> and_out[q * ld_out + r] = sum_i min(|q_i|, |row_r,i|)  (uint32; may be NULL) and
- *    key_out[q * ld_out + r] = floor(sim * (2^36 - 1)) << 27 | r   (int64): keys order (similarity, then row number)
- *    exactly -- distinct similarities of vectors with sums < 32768 differ by more than 2^-32 -- so the k largest keys
- *    of a row are the k best matches, ties won by the larger row number (a stable ascending argsort read backwards,
- *    retrieve.py:59).  Requires n < 2^27. */
+ * -> and_out[q * ld_out + r] = sum_i min(|q_i|, |row_r,i|)  (int16: the sums are < 32768), from which
+ *    sim(q, r) = and / (q_sum[q] + row_sum[r] - and), and, if block_max != NULL,
+ *    block_max[q * ceil(n / 64) + b] = the best fp32 APPROXIMATION of sim among rows 64 b .. 64 b + 63
+ *    ((float)and * rcp((float)den): relative error < 2^-21).  Requires n < 2^27. */
 int trx_tanimoto_scores(const void* packed, const int32_t* row_sum, int64_t n, int d, const uint32_t* q_t, const int32_t* q_sum,
-                        int nq, uint32_t* and_out, int64_t* key_out, int64_t ld_out, int64_t* block_max, void* stream);
+                        int nq, int16_t* and_out, int64_t ld_out, float* block_max, void* stream);
 
-/* Selection without sorting every key (retrieve.py:59 argsorts all N similarities).  block_max (above; may be NULL):
- * block_max[q * ceil(n / 64) + b] = the best key among rows 64 b .. 64 b + 63.  The k-th largest block maximum t is a
- * lower bound of the k-th largest key (k blocks hold a key >= t), so every one of the k best keys is >= t:
- * trx_tanimoto_filter appends the keys >= thr[q] of query q to out[q * cap ...] (any order; counts[q], zeroed by the
- * caller, ends as the number found -- if it exceeds cap the list is incomplete and the caller must select from the
- * full key row instead) and the k best of that short list are the k best overall. */
-int trx_tanimoto_filter(const int64_t* keys, int64_t n, int64_t ld, int nq, const int64_t* thr, int cap, int64_t* out, int32_t* counts,
-                        void* stream);
+/* Selection without sorting all N similarities of a query (retrieve.py:59 argsorts them).
+ * Exact order: key = floor(sim * (2^36 - 1)) << 27 | r with sim = (double)and / (double)den (the double the reference's
+ * Python float holds).  Two different similarities of vectors with sums < 32768 differ by more than 2^-32 (> 15 key
+ * units), equal rationals give the same double: comparing keys as integers IS the order (similarity, then row number),
+ * ties won by the larger row number -- a stable ascending argsort read backwards.
+ * Bound: let t = the k-th largest entry of block_max[q] (k blocks each hold a row whose approximate similarity is >= t).
+ * Then the k-th best exact similarity is >= t (1 - 2^-21), and every one of the k best rows has an approximate
+ * similarity >= t (1 - 2^-21)^2 > thr = t (1 - 2^-20).
+ * trx_tanimoto_filter: for slot s = 0 .. nsel-1 and query q = q_ids ? q_ids[s] : s, appends the exact keys of the rows
+ * whose approximate similarity is >= thr[q] (thr == NULL: of every row) to out[s * cap ...] in any order; counts[s]
+ * (zeroed by the caller) ends as the number found -- above cap the list is incomplete and the caller repeats that
+ * query with thr == NULL and cap >= n.  The k largest keys of a complete list are the k best matches, in order. */
+int trx_tanimoto_filter(const int16_t* and_in, int64_t ld, const int32_t* row_sum, const int32_t* q_sum, const int32_t* q_ids, int nsel,
+                        int64_t n, const float* thr, int64_t cap, int64_t* out, int32_t* counts, void* stream);
 
 const char* trx_tanimoto_last_error(void);
 

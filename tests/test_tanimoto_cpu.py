@@ -71,7 +71,7 @@ def test_argument_errors_and_no_cpu_path():
     assert L.trx_tanimoto_packed_bytes(5, 6) == -1
     assert L.trx_tanimoto_pack(None, 0, 5, 6, 6, 0, None, None, None, None) == -1
     assert b"d % 4" in L.trx_tanimoto_last_error()
-    assert L.trx_tanimoto_scores(None, None, 1 << 27, 8, None, None, 1, None, None, 1 << 27, None, None) == -1
+    assert L.trx_tanimoto_scores(None, None, 1 << 27, 8, None, None, 1, None, 1 << 27, None, None) == -1
     assert b"2^27" in L.trx_tanimoto_last_error()
     if not torch.cuda.is_available():
         with pytest.raises(tanimoto.TrxTanimotoError):

@@ -60,15 +60,21 @@ __global__ __launch_bounds__(256) void pack_kernel(const T* __restrict__ fps, in
     if (r0 + lane < n && sum) atomicAdd(&row_sum[first_row + r0 + lane], sum);
 }
 
+// fp32 stand-in of and / den used only to bound the selection: relative error < 2^-21 (v_rcp_f32 is good to 1 ulp, the
+// integers are exact in fp32), the same function in both kernels
+__device__ __forceinline__ float approx_sim(int a, int dn) {
+    return dn > 0 ? (float)a * __builtin_amdgcn_rcpf((float)dn) : 0.0f;
+}
+
 // ---- scores ------------------------------------------------------------------------------------------------------
-constexpr int UNROLL = 4;                    // vector loads in flight per wave
+constexpr int UNROLL = 8;                    // vector loads in flight per wave
 
 // NG groups of 16 queries per wave: 16 * NG accumulators, so the corpus is read once per 64 queries (NG = 4)
 template <int NG>
 __global__ __launch_bounds__(256) void scores_kernel(const uint32_t* __restrict__ packed, const int32_t* __restrict__ row_sum, int64_t n,
                                                      int dw, const uint32_t* __restrict__ q_t, const int32_t* __restrict__ q_sum, int q0,
-                                                     int nq, int nq_pad, uint32_t* __restrict__ and_out, int64_t* __restrict__ key_out,
-                                                     int64_t ld_out, int64_t* __restrict__ block_max) {
+                                                     int nq, int nq_pad, int16_t* __restrict__ and_out, int64_t ld_out,
+                                                     float* __restrict__ block_max) {
     constexpr int NQ = NG * QG;
     const int lane = threadIdx.x & 63;
     const int64_t blk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -106,55 +112,59 @@ __global__ __launch_bounds__(256) void scores_kernel(const uint32_t* __restrict_
         const int qi = qbase + q;
         if (qi < nq) {                                     // wave-uniform
             const int s = rs + q_sum[qi];
-            const int a = (s - (int)acc[q]) >> 1;          // sum of minima
-            const int dn = s - a;                          // |v1| + |v2| - and
-            const double sim = dn > 0 ? (double)a / (double)dn : 0.0;
-            const uint64_t fx = (uint64_t)(sim * 68719476735.0);     // 2^36 - 1
-            const int64_t key = live ? (int64_t)((fx << TRX_TANI_KEY_ID_BITS) | (uint64_t)row) : (int64_t)-1;
-            if (live) {
-                if (and_out) and_out[(int64_t)qi * ld_out + row] = (uint32_t)a;
-                key_out[(int64_t)qi * ld_out + row] = key;
-            }
-            if (block_max) {                               // best key of this block of 64 rows (selection threshold, see the header)
-                int64_t m = key;
-#pragma unroll
-                for (int o = 32; o; o >>= 1) {
-                    const int64_t x = __shfl_xor(m, o, 64);
-                    m = x > m ? x : m;
-                }
-                if (lane == 0) block_max[(int64_t)qi * nblocks + blk] = m;
+            const int a = (s - (int)acc[q]) >> 1;          // sum of minima (< 32768)
+            if (live) and_out[(int64_t)qi * ld_out + row] = (int16_t)a;
+            if (block_max) {                               // best APPROXIMATE similarity of this block (selection bound, see the header)
+                // similarities are >= 0, so their bit patterns order like unsigned integers: a DPP max-reduction
+                // (six VALU instructions, no LDS crossbar) leaves the block maximum in lane 63
+                uint32_t m = live ? __float_as_uint(approx_sim(a, s - a)) : 0u;
+                m = max(m, (uint32_t)__builtin_amdgcn_update_dpp((int)m, (int)m, 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+                m = max(m, (uint32_t)__builtin_amdgcn_update_dpp((int)m, (int)m, 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+                m = max(m, (uint32_t)__builtin_amdgcn_update_dpp((int)m, (int)m, 0x141, 0xf, 0xf, false));   // row_half_mirror
+                m = max(m, (uint32_t)__builtin_amdgcn_update_dpp((int)m, (int)m, 0x140, 0xf, 0xf, false));   // row_mirror
+                m = max(m, (uint32_t)__builtin_amdgcn_update_dpp((int)m, (int)m, 0x142, 0xa, 0xf, false));   // row_bcast:15
+                m = max(m, (uint32_t)__builtin_amdgcn_update_dpp((int)m, (int)m, 0x143, 0xc, 0xf, false));   // row_bcast:31
+                if (lane == 63) block_max[(int64_t)qi * nblocks + blk] = __uint_as_float(m);
             }
         }
     }
 }
 
-// keys >= thr[q] of every query, appended in any order (they are distinct: the row number is part of a key)
-__global__ __launch_bounds__(256) void filter_kernel(const int64_t* __restrict__ keys, int64_t n, int64_t ld, const int64_t* __restrict__ thr,
-                                                     int cap, int64_t* __restrict__ out, int32_t* __restrict__ counts) {
-    const int q = blockIdx.y;
-    const int64_t t = thr[q];
-    const int64_t* kq = keys + (int64_t)q * ld;
-    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2; i < n; i += (int64_t)gridDim.x * 512) {
-        int64_t a, b = -1;
-        if (i + 1 < n && (((uintptr_t)(kq + i)) & 15) == 0) {
-            const longlong2 v = *reinterpret_cast<const longlong2*>(kq + i);
-            a = v.x; b = v.y;
-        } else {
-            a = kq[i];
-            if (i + 1 < n) b = kq[i + 1];
+// exact key of one pair: the double the reference's Python float holds, cut to 36 bits (order-preserving: header)
+__device__ __forceinline__ int64_t exact_key(int a, int dn, int64_t row) {
+    const double sim = dn > 0 ? (double)a / (double)dn : 0.0;
+    const uint64_t fx = (uint64_t)(sim * 68719476735.0);     // 2^36 - 1
+    return (int64_t)((fx << TRX_TANI_KEY_ID_BITS) | (uint64_t)row);
+}
+
+// exact keys of the pairs whose approximate similarity reaches thr[q] (thr == NULL: of every pair), appended in any
+// order (keys are distinct: the row number is part of a key)
+__global__ __launch_bounds__(256) void filter_kernel(const int16_t* __restrict__ and_in, int64_t ld, const int32_t* __restrict__ row_sum,
+                                                     const int32_t* __restrict__ q_sum, const int32_t* __restrict__ q_ids, int64_t n,
+                                                     const float* __restrict__ thr, int64_t cap, int64_t* __restrict__ out,
+                                                     int32_t* __restrict__ counts) {
+    const int slot = blockIdx.y;                           // position in the output; q_ids maps it to a query (or identity)
+    const int q = q_ids ? q_ids[slot] : slot;
+    const float t = thr ? thr[q] : -1.0f;
+    const int qs = q_sum[q];
+    const int16_t* aq = and_in + (int64_t)q * ld;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int a = aq[i];
+        const int dn = row_sum[i] + qs - a;
+        if (approx_sim(a, dn) >= t) {
+            const int pos = atomicAdd(&counts[slot], 1);
+            if (pos < cap) out[(int64_t)slot * cap + pos] = exact_key(a, dn, i);
         }
-        if (a >= t) { const int pos = atomicAdd(&counts[q], 1); if (pos < cap) out[(int64_t)q * cap + pos] = a; }
-        if (b >= t) { const int pos = atomicAdd(&counts[q], 1); if (pos < cap) out[(int64_t)q * cap + pos] = b; }
     }
 }
 
 template <int NG>
 void launch_scores(const void* packed, const int32_t* row_sum, int64_t n, int d, const uint32_t* q_t, const int32_t* q_sum, int q0, int count,
-                   int nq, int nq_pad, uint32_t* and_out, int64_t* key_out, int64_t ld_out, int64_t* block_max, hipStream_t st) {
+                   int nq, int nq_pad, int16_t* and_out, int64_t ld_out, float* block_max, hipStream_t st) {
     const int64_t blocks = (n + 63) / 64;
     const dim3 grid((unsigned)((blocks + 3) / 4), (unsigned)count);
     hipLaunchKernelGGL(scores_kernel<NG>, grid, dim3(256), 0, st, (const uint32_t*)packed, row_sum, n, d / 4, q_t, q_sum, q0, nq, nq_pad,
-                       and_out, key_out, ld_out, block_max);
+                       and_out, ld_out, block_max);
 }
 
 }  // namespace
@@ -187,31 +197,32 @@ int trx_tanimoto_pack(const void* fps, int dtype, int64_t n, int d, int64_t ld, 
 }
 
 int trx_tanimoto_scores(const void* packed, const int32_t* row_sum, int64_t n, int d, const uint32_t* q_t, const int32_t* q_sum, int nq,
-                        uint32_t* and_out, int64_t* key_out, int64_t ld_out, int64_t* block_max, void* stream) {
+                        int16_t* and_out, int64_t ld_out, float* block_max, void* stream) {
     if (n < 0 || nq < 0 || d <= 0 || d % 4 || ld_out < n) return fail(-1, "trx_tanimoto_scores: bad shape");
     if (n >= ((int64_t)1 << TRX_TANI_KEY_ID_BITS)) return fail(-1, "trx_tanimoto_scores: n must be < 2^27 (row numbers ride in the keys)");
     if (n == 0 || nq == 0) return 0;
-    if (!packed || !row_sum || !q_t || !q_sum || !key_out) return fail(-1, "trx_tanimoto_scores: null pointer");
+    if (!packed || !row_sum || !q_t || !q_sum || !and_out) return fail(-1, "trx_tanimoto_scores: null pointer");
     const int nq_pad = (nq + QG - 1) / QG * QG;
     hipStream_t st = (hipStream_t)stream;
     const int full = nq_pad / (4 * QG);                   // passes over the corpus with 64 queries per wave
-    if (full) launch_scores<4>(packed, row_sum, n, d, q_t, q_sum, 0, full, nq, nq_pad, and_out, key_out, ld_out, block_max, st);
+    if (full) launch_scores<4>(packed, row_sum, n, d, q_t, q_sum, 0, full, nq, nq_pad, and_out, ld_out, block_max, st);
     const int q0 = full * 4 * QG, rem = (nq_pad - q0) / QG;
-    if (rem == 1) launch_scores<1>(packed, row_sum, n, d, q_t, q_sum, q0, 1, nq, nq_pad, and_out, key_out, ld_out, block_max, st);
-    else if (rem == 2) launch_scores<2>(packed, row_sum, n, d, q_t, q_sum, q0, 1, nq, nq_pad, and_out, key_out, ld_out, block_max, st);
-    else if (rem == 3) launch_scores<3>(packed, row_sum, n, d, q_t, q_sum, q0, 1, nq, nq_pad, and_out, key_out, ld_out, block_max, st);
+    if (rem == 1) launch_scores<1>(packed, row_sum, n, d, q_t, q_sum, q0, 1, nq, nq_pad, and_out, ld_out, block_max, st);
+    else if (rem == 2) launch_scores<2>(packed, row_sum, n, d, q_t, q_sum, q0, 1, nq, nq_pad, and_out, ld_out, block_max, st);
+    else if (rem == 3) launch_scores<3>(packed, row_sum, n, d, q_t, q_sum, q0, 1, nq, nq_pad, and_out, ld_out, block_max, st);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail(-2, hipGetErrorString(e));
 }
 
-int trx_tanimoto_filter(const int64_t* keys, int64_t n, int64_t ld, int nq, const int64_t* thr, int cap, int64_t* out, int32_t* counts,
-                        void* stream) {
-    if (n < 0 || nq < 0 || ld < n || cap <= 0) return fail(-1, "trx_tanimoto_filter: bad shape");
-    if (n == 0 || nq == 0) return 0;
-    if (!keys || !thr || !out || !counts) return fail(-1, "trx_tanimoto_filter: null pointer");
-    const int64_t want = (n + 511) / 512;
-    const dim3 grid((unsigned)(want < 2048 ? want : 2048), (unsigned)nq);
-    hipLaunchKernelGGL(filter_kernel, grid, dim3(256), 0, (hipStream_t)stream, keys, n, ld, thr, cap, out, counts);
+int trx_tanimoto_filter(const int16_t* and_in, int64_t ld, const int32_t* row_sum, const int32_t* q_sum, const int32_t* q_ids, int nsel,
+                        int64_t n, const float* thr, int64_t cap, int64_t* out, int32_t* counts, void* stream) {
+    if (n < 0 || nsel < 0 || ld < n || cap <= 0) return fail(-1, "trx_tanimoto_filter: bad shape");
+    if (n >= ((int64_t)1 << TRX_TANI_KEY_ID_BITS)) return fail(-1, "trx_tanimoto_filter: n must be < 2^27 (row numbers ride in the keys)");
+    if (n == 0 || nsel == 0) return 0;
+    if (!and_in || !row_sum || !q_sum || !out || !counts) return fail(-1, "trx_tanimoto_filter: null pointer");
+    const int64_t want = (n + 255) / 256;
+    const dim3 grid((unsigned)(want < 1024 ? want : 1024), (unsigned)nsel);
+    hipLaunchKernelGGL(filter_kernel, grid, dim3(256), 0, (hipStream_t)stream, and_in, ld, row_sum, q_sum, q_ids, n, thr, cap, out, counts);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail(-2, hipGetErrorString(e));
 }

@@ -4,8 +4,9 @@ retrieve.py:34-40 scores ONE test reaction against every train reaction with RDK
 64 processes, :55-62 keeps the 100 best (`rank`, `similarity`) and dumps {row: {...}} to test_nn.json.  Here the
 train fingerprints -- the dense count arrays retrieve_faiss.py:24-27 already builds from the same RDKit difference
 fingerprints -- are packed once into HBM (one byte per count magnitude, 64-row blocks) and libtrxtani.so
-(include/trx_tanimoto.h) scores 64 queries per pass over them with v_sad_u8; the similarities come back as the same
-doubles (integer numerator / integer denominator, one IEEE division) and the ranking is exact.
+(include/trx_tanimoto.h) scores 64 queries per pass over them with v_sad_u8; a bound from per-block maxima leaves a short
+list per query for which exact integer keys are formed; the similarities come back as the same doubles (integer
+numerator / integer denominator, one IEEE division) and the ranking is exact.
 
     index = TanimotoIndex(2048)                      # cuda:0
     index.add(train_fps)                             # [N, 2048] int (numpy or torch, host or device)
@@ -61,8 +62,8 @@ def lib():
         L.trx_tanimoto_packed_bytes.restype = i64
         L.trx_tanimoto_packed_bytes.argtypes = [i64, i32]
         L.trx_tanimoto_pack.argtypes = [vp, i32, i64, i32, i64, i64, vp, vp, vp, vp]
-        L.trx_tanimoto_scores.argtypes = [vp, vp, i64, i32, vp, vp, i32, vp, vp, i64, vp, vp]
-        L.trx_tanimoto_filter.argtypes = [vp, i64, i64, i32, vp, i32, vp, vp, vp]
+        L.trx_tanimoto_scores.argtypes = [vp, vp, i64, i32, vp, vp, i32, vp, i64, vp, vp]
+        L.trx_tanimoto_filter.argtypes = [vp, i64, vp, vp, vp, i32, i64, vp, i64, vp, vp, vp]
         L.trx_tanimoto_last_error.restype = ctypes.c_char_p
         _lib = L
     return _lib
@@ -168,28 +169,36 @@ class TanimotoIndex:
             qb = q[lo:lo + batch]
             m = qb.shape[0]
             q_t, q_sum = self._pack_queries(qb)
-            both = torch.empty((m, n), dtype=torch.int32, device=self.dev)
-            keys = torch.empty((m, n), dtype=torch.int64, device=self.dev)
+            both = torch.empty((m, n), dtype=torch.int16, device=self.dev)       # sums of minima (< 32768)
             nblocks = (n + 63) // 64
             cap = max(4 * kk, 1024)
-            shortlist = nblocks >= kk and n > 4 * cap       # otherwise the key rows are short enough to select from directly
-            bmax = torch.empty((m, nblocks), dtype=torch.int64, device=self.dev) if shortlist else None
+            shortlist = nblocks >= kk and n > 4 * cap       # otherwise every key of a row is formed and selected from directly
+            bmax = torch.empty((m, nblocks), dtype=torch.float32, device=self.dev) if shortlist else None
+            st = _stream(self.dev)
             _check(lib().trx_tanimoto_scores(self.packed.data_ptr(), self.row_sum.data_ptr(), n, self.d, q_t.data_ptr(), q_sum.data_ptr(),
-                                             m, both.data_ptr(), keys.data_ptr(), n, bmax.data_ptr() if shortlist else None,
-                                             _stream(self.dev)))
+                                             m, both.data_ptr(), n, bmax.data_ptr() if shortlist else None, st))
+
+            def keys_of(q_ids, thr, width):
+                nsel = m if q_ids is None else q_ids.numel()
+                cand = torch.full((nsel, width), -1, dtype=torch.int64, device=self.dev)
+                counts = torch.zeros(nsel, dtype=torch.int32, device=self.dev)
+                _check(lib().trx_tanimoto_filter(both.data_ptr(), n, self.row_sum.data_ptr(), q_sum.data_ptr(),
+                                                 None if q_ids is None else q_ids.data_ptr(), nsel, n,
+                                                 None if thr is None else thr.data_ptr(), width, cand.data_ptr(), counts.data_ptr(), st))
+                return cand, counts
             if shortlist:
-                # the k-th best block maximum bounds the k-th best key from below: only keys above it can be among the k best
-                thr = torch.topk(bmax, kk, dim=1, largest=True, sorted=True).values[:, -1].contiguous()
-                cand = torch.full((m, cap), -1, dtype=torch.int64, device=self.dev)
-                counts = torch.zeros(m, dtype=torch.int32, device=self.dev)
-                _check(lib().trx_tanimoto_filter(keys.data_ptr(), n, n, m, thr.data_ptr(), cap, cand.data_ptr(), counts.data_ptr(),
-                                                 _stream(self.dev)))
+                # the k-th best block maximum bounds the k-th best similarity from below (header): only rows whose approximate
+                # similarity reaches it (less the rounding margin) can be among the k best; exact keys are formed for those only
+                thr = (torch.topk(bmax, kk, dim=1, largest=True, sorted=True).values[:, -1] * (1.0 - 2.0 ** -19)).contiguous()
+                cand, counts = keys_of(None, thr, cap)
                 top = torch.topk(cand, kk, dim=1, largest=True, sorted=True).values
-                over = (counts > cap).nonzero().flatten()
-                if over.numel():                            # more keys above the bound than the list holds (heavily tied data)
-                    top[over] = torch.topk(keys[over], kk, dim=1, largest=True, sorted=True).values
+                over = (counts > cap).nonzero().flatten().to(torch.int32)
+                if over.numel():                            # more rows above the bound than the list holds (heavily tied data)
+                    full, _ = keys_of(over, None, n)
+                    top[over.long()] = torch.topk(full, kk, dim=1, largest=True, sorted=True).values
             else:
-                top = torch.topk(keys, kk, dim=1, largest=True, sorted=True).values
+                full, _ = keys_of(None, None, n)
+                top = torch.topk(full, kk, dim=1, largest=True, sorted=True).values
             r = top & ((1 << KEY_ID_BITS) - 1)
             a = both.gather(1, r).to(torch.float64)
             den = self.row_sum[:n].to(torch.float64)[r] + q_sum[:m].to(torch.float64)[:, None] - a
