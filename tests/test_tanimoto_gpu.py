@@ -31,6 +31,22 @@ def test_search_equals_the_oracle(n, d, nq, k):
     _check(corpus, queries, k)
 
 
+def test_dense_fingerprints_with_large_sums_and_crowded_similarities():
+    """sums of magnitudes in the ten-thousands and thousands of similarities within 1e-3 of each other: the keys must
+    still order them exactly and the fp32 selection bound must not lose a row"""
+    rng = np.random.default_rng(8)
+    corpus = fingerprints(rng, 20000, 2048, density=0.5, lo=-30, hi=31)
+    queries = fingerprints(rng, 20, 2048, density=0.5, lo=-30, hi=31)
+    assert 10000 < np.abs(corpus).sum(axis=1).max() < 32768
+    _check(corpus, queries, 100)
+    near = np.repeat(corpus[:1], 9000, axis=0)                  # 9000 rows that differ from one fingerprint in a few positions
+    pos = rng.integers(0, 2048, (9000, 3))
+    for i in range(9000):
+        near[i, pos[i]] += rng.integers(-2, 3, 3)
+    near = np.clip(near, -255, 255)
+    _check(near, np.concatenate([corpus[:1], queries[:3]]), 100)
+
+
 def test_many_equal_similarities_are_ordered_by_descending_row_number():
     rng = np.random.default_rng(3)
     base = fingerprints(rng, 40, 256, density=0.1)
