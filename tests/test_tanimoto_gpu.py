@@ -104,3 +104,17 @@ def test_batches_of_64_rows_append_and_bad_inputs_fail_loudly():
         TanimotoIndex(512).add(np.zeros((64, 512), dtype=np.float32))
     with pytest.raises(TrxTanimotoError):
         idx.search(big[:4], 5)
+
+
+def test_command_line_writes_the_reference_json(tmp_path):
+    import json
+    from textreact_amd import tanimoto
+    rng = np.random.default_rng(9)
+    corpus, queries = fingerprints(rng, 300, 2048), fingerprints(rng, 7, 2048)
+    np.save(tmp_path / "train.npy", corpus); np.save(tmp_path / "test.npy", queries)
+    tanimoto.main(["--train_fps", str(tmp_path / "train.npy"), "--test_fps", str(tmp_path / "test.npy"), "--output",
+                   str(tmp_path / "test_nn.json"), "--limit", "5"])
+    got = json.load(open(tmp_path / "test_nn.json"))
+    want_s, want_r = oracle.search(queries[:5], corpus, 100)
+    assert sorted(got) == ["0", "1", "2", "3", "4"]                     # json.dump turns the row numbers into strings
+    assert got["3"]["rank"] == want_r[3].tolist() and got["3"]["similarity"] == want_s[3].tolist()

@@ -216,3 +216,35 @@ def retrieve(test_fps, train_fps, k=100, limit=None, device=0):
     sim, rank = index.search(q, k)
     sim, rank = sim.cpu().numpy(), rank.cpu().numpy()
     return {i: {"rank": rank[i].tolist(), "similarity": sim[i].tolist()} for i in range(len(rank))}
+
+
+def write_results(path, results):
+    """json.dump as retrieve.py:65-66 does (the integer query numbers become JSON strings, as there)"""
+    import json
+    with open(path, "w") as f:
+        json.dump(results, f)
+
+
+def main(argv=None):
+    """retrieve.py's job on fingerprint arrays that already exist (retrieve_faiss.py caches them as train_fp.pkl):
+    python -m textreact_amd.tanimoto --train_fps train_fp.pkl --test_fps test_fp.pkl --output test_nn.json [--limit 100]"""
+    import argparse
+    import pickle
+    ap = argparse.ArgumentParser(description=main.__doc__)
+    ap.add_argument("--train_fps", required=True, help=".npy or pickle of an [N, d] integer array")
+    ap.add_argument("--test_fps", required=True)
+    ap.add_argument("--output", default="test_nn.json")
+    ap.add_argument("--k", type=int, default=100)
+    ap.add_argument("--limit", type=int, default=100, help="number of test rows (retrieve.py stops after 100); -1 = all")
+    a = ap.parse_args(argv)
+
+    def load(p):
+        if p.endswith(".npy"):
+            return np.load(p)
+        with open(p, "rb") as f:
+            return np.asarray(pickle.load(f))
+    write_results(a.output, retrieve(load(a.test_fps), load(a.train_fps), k=a.k, limit=None if a.limit < 0 else a.limit))
+
+
+if __name__ == "__main__":
+    main()
