@@ -148,12 +148,31 @@ __global__ __launch_bounds__(256) void filter_kernel(const int16_t* __restrict__
     const float t = thr ? thr[q] : -1.0f;
     const int qs = q_sum[q];
     const int16_t* aq = and_in + (int64_t)q * ld;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const int a = aq[i];
-        const int dn = row_sum[i] + qs - a;
-        if (approx_sim(a, dn) >= t) {
-            const int pos = atomicAdd(&counts[slot], 1);
-            if (pos < cap) out[(int64_t)slot * cap + pos] = exact_key(a, dn, i);
+    const bool vec = ((reinterpret_cast<uintptr_t>(aq) | reinterpret_cast<uintptr_t>(row_sum)) & 15) == 0;
+    for (int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8; i0 < n; i0 += (int64_t)gridDim.x * 2048) {
+        int a[8], rs[8];
+        if (vec && i0 + 8 <= n) {                          // 8 rows per lane: one 16-byte and two 16-byte loads
+            const uint4 av = *reinterpret_cast<const uint4*>(aq + i0);
+            const int4 r0 = *reinterpret_cast<const int4*>(row_sum + i0), r1 = *reinterpret_cast<const int4*>(row_sum + i0 + 4);
+            const uint32_t aw[4] = {av.x, av.y, av.z, av.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a[2 * e] = (int)(aw[e] & 0xffffu); a[2 * e + 1] = (int)(aw[e] >> 16); }
+            rs[0] = r0.x; rs[1] = r0.y; rs[2] = r0.z; rs[3] = r0.w; rs[4] = r1.x; rs[5] = r1.y; rs[6] = r1.z; rs[7] = r1.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const bool in = i0 + e < n;
+                a[e] = in ? (int)aq[i0 + e] : 0;
+                rs[e] = in ? row_sum[i0 + e] : -qs;        // den 0 -> approximate similarity 0; masked below anyway
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int dn = rs[e] + qs - a[e];
+            if (i0 + e < n && approx_sim(a[e], dn) >= t) {
+                const int pos = atomicAdd(&counts[slot], 1);
+                if (pos < cap) out[(int64_t)slot * cap + pos] = exact_key(a[e], dn, i0 + e);
+            }
         }
     }
 }
@@ -220,7 +239,7 @@ int trx_tanimoto_filter(const int16_t* and_in, int64_t ld, const int32_t* row_su
     if (n >= ((int64_t)1 << TRX_TANI_KEY_ID_BITS)) return fail(-1, "trx_tanimoto_filter: n must be < 2^27 (row numbers ride in the keys)");
     if (n == 0 || nsel == 0) return 0;
     if (!and_in || !row_sum || !q_sum || !out || !counts) return fail(-1, "trx_tanimoto_filter: null pointer");
-    const int64_t want = (n + 255) / 256;
+    const int64_t want = (n + 2047) / 2048;
     const dim3 grid((unsigned)(want < 1024 ? want : 1024), (unsigned)nsel);
     hipLaunchKernelGGL(filter_kernel, grid, dim3(256), 0, (hipStream_t)stream, and_in, ld, row_sum, q_sum, q_ids, n, thr, cap, out, counts);
     const hipError_t e = hipGetLastError();
