@@ -118,3 +118,52 @@ def test_command_line_writes_the_reference_json(tmp_path):
     want_s, want_r = oracle.search(queries[:5], corpus, 100)
     assert sorted(got) == ["0", "1", "2", "3", "4"]                     # json.dump turns the row numbers into strings
     assert got["3"]["rank"] == want_r[3].tolist() and got["3"]["similarity"] == want_s[3].tolist()
+
+
+def test_single_rank_sharded_wrapper_applies_the_row_offset():
+    from textreact_amd.tanimoto import ShardedTanimotoIndex
+    rng = np.random.default_rng(10)
+    corpus, queries = fingerprints(rng, 700, 1024), fingerprints(rng, 6, 1024)
+    idx = ShardedTanimotoIndex(1024)
+    idx.add_shard(corpus, 4096, 4096 + 700)
+    sim, rank = idx.search(queries, 50)
+    want_s, want_r = oracle.search(queries, corpus, 50)
+    assert np.array_equal(rank.cpu().numpy(), want_r + 4096) and np.array_equal(sim.cpu().numpy(), want_s)
+
+
+def _tani_rank_worker(rank, world, port, ret):
+    import os, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from test_tanimoto_cpu import fingerprints as fp_
+    from textreact_amd.sharded import shard_bounds
+    from textreact_amd.tanimoto import ShardedTanimotoIndex
+    rng = np.random.default_rng(11)
+    base = fp_(rng, 50, 2048)
+    corpus = np.concatenate([fp_(rng, 9000, 2048), base[rng.integers(0, 50, 3001)]])     # ties across the shard boundaries
+    corpus = corpus[rng.permutation(len(corpus))]
+    queries = np.concatenate([base[:4], fp_(rng, 5, 2048)])
+    lo, hi = shard_bounds(len(corpus), world, rank)
+    idx = ShardedTanimotoIndex(2048, device=0)
+    idx.add_shard(corpus[lo:hi], lo, len(corpus))
+    sim, rk = idx.search(queries, 100)
+    ret[rank] = (sim.cpu().numpy(), rk.cpu().numpy(), corpus, queries)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_multi_rank_sharded_tanimoto_on_one_gpu(world):
+    """the N > 1 path with the real HIP index on every rank (gloo carries the gather: one GPU here)"""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mgr = mp.Manager(); ret = mgr.dict()
+    mp.spawn(_tani_rank_worker, args=(world, port, ret), nprocs=world, join=True)
+    for r in range(world):
+        sim, rk, corpus, queries = ret[r]
+        want_s, want_r = oracle.search(queries, corpus, 100)
+        assert np.array_equal(rk, want_r), r
+        assert np.array_equal(sim, want_s), r

@@ -158,13 +158,21 @@ class TanimotoIndex:
     def search(self, queries, k=100, batch=128):
         """-> (similarity float64 [Q, k'], rank int64 [Q, k']) on the device, k' = min(k, ntotal); best first, equal
         similarities ordered by descending row number"""
+        keys, a, den = self.search_keys(queries, k, batch)
+        a, den = a.to(torch.float64), den.to(torch.float64)
+        return torch.where(den.abs() < 1e-6, torch.zeros_like(a), a / den), keys & ((1 << KEY_ID_BITS) - 1)
+
+    def search_keys(self, queries, k=100, batch=128):
+        """the k' best of every query as (key, and, den) int64 [Q, k']: key = the exact order key of include/trx_tanimoto.h
+        (row number in the low 27 bits), similarity = and / den.  What a row-sharded search exchanges and merges."""
         q = self._as_device_ints(queries)
         nq, n = q.shape[0], self.ntotal
         kk = min(k, n)
-        sim = torch.zeros((nq, kk), dtype=torch.float64, device=self.dev)
-        rank = torch.zeros((nq, kk), dtype=torch.int64, device=self.dev)
+        keys_out = torch.zeros((nq, kk), dtype=torch.int64, device=self.dev)
+        a_out = torch.zeros((nq, kk), dtype=torch.int64, device=self.dev)
+        den_out = torch.zeros((nq, kk), dtype=torch.int64, device=self.dev)
         if nq == 0 or kk == 0:
-            return sim, rank
+            return keys_out, a_out, den_out
         for lo in range(0, nq, batch):
             qb = q[lo:lo + batch]
             m = qb.shape[0]
@@ -200,11 +208,61 @@ class TanimotoIndex:
                 full, _ = keys_of(None, None, n)
                 top = torch.topk(full, kk, dim=1, largest=True, sorted=True).values
             r = top & ((1 << KEY_ID_BITS) - 1)
-            a = both.gather(1, r).to(torch.float64)
-            den = self.row_sum[:n].to(torch.float64)[r] + q_sum[:m].to(torch.float64)[:, None] - a
-            sim[lo:lo + m] = torch.where(den.abs() < 1e-6, torch.zeros_like(a), a / den)
-            rank[lo:lo + m] = r
-        return sim, rank
+            a = both.gather(1, r).to(torch.int64)
+            keys_out[lo:lo + m] = top
+            a_out[lo:lo + m] = a
+            den_out[lo:lo + m] = self.row_sum[:n].to(torch.int64)[r] + q_sum[:m].to(torch.int64)[:, None] - a
+        return keys_out, a_out, den_out
+
+
+class ShardedTanimotoIndex:
+    """train rows split over the ranks of a process group (one process per GPU, rows [lo, hi) of
+    sharded.shard_bounds on rank r), queries replicated.  A search = local search_keys -> row numbers made global ->
+    ONE all-gather of [3, Q, k] int64 (key, and, den) per rank over RCCL -> the k largest of the G * k gathered keys.
+    Keys are a total order (similarity, then global row number), so the result equals one unsharded index, on every
+    rank.  `local_index` is injectable (anything with add / search_keys / ntotal): the gloo test supplies the oracle."""
+
+    def __init__(self, d=2048, group=None, local_index=None, device=None):
+        import torch.distributed as dist
+        self.group = group
+        self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.local = local_index if local_index is not None else TanimotoIndex(d, torch.cuda.current_device() if device is None else device)
+        self.offset = self.ntotal = 0
+
+    def add_shard(self, fps_local, offset, ntotal):
+        if ntotal >= (1 << KEY_ID_BITS):
+            raise TrxTanimotoError("at most 2^27 - 1 rows over all shards")
+        self.local.add(fps_local)
+        self.offset, self.ntotal = int(offset), int(ntotal)
+
+    def search(self, queries, k=100):
+        import torch.distributed as dist
+        keys, a, den = self.local.search_keys(queries, k)
+        keys = keys + self.offset                                  # the row number sits in the low bits: local -> global
+        kk = min(k, self.ntotal)
+        if keys.shape[1] < kk:                                     # a shard with fewer than k rows: pad with keys that never win
+            pad = (keys.shape[0], kk - keys.shape[1])
+            keys = torch.cat([keys, torch.full(pad, -1, dtype=torch.int64, device=keys.device)], dim=1)
+            a = torch.cat([a, torch.zeros(pad, dtype=torch.int64, device=a.device)], dim=1)
+            den = torch.cat([den, torch.zeros(pad, dtype=torch.int64, device=den.device)], dim=1)
+        keys, a, den = keys[:, :kk], a[:, :kk], den[:, :kk]
+        if self.world_size > 1:
+            pack = torch.stack([keys, a, den]).contiguous()
+            if dist.get_backend(self.group) == "gloo":             # test path (gloo gathers host tensors)
+                parts = [torch.empty_like(pack.cpu()) for _ in range(self.world_size)]
+                dist.all_gather(parts, pack.cpu(), group=self.group)
+                out = torch.stack(parts).to(pack.device)
+            else:
+                out = torch.empty((self.world_size,) + tuple(pack.shape), dtype=torch.int64, device=pack.device)
+                dist.all_gather_into_tensor(out, pack, group=self.group)
+            allk = out[:, 0].permute(1, 0, 2).reshape(keys.shape[0], -1)          # [Q, G * k]
+            top, pos = torch.topk(allk, kk, dim=1, largest=True, sorted=True)
+            keys = top
+            a = out[:, 1].permute(1, 0, 2).reshape(keys.shape[0], -1).gather(1, pos)
+            den = out[:, 2].permute(1, 0, 2).reshape(keys.shape[0], -1).gather(1, pos)
+        a, den = a.to(torch.float64), den.to(torch.float64)
+        return torch.where(den.abs() < 1e-6, torch.zeros_like(a), a / den), keys & ((1 << KEY_ID_BITS) - 1)
 
 
 def retrieve(test_fps, train_fps, k=100, limit=None, device=0):
