@@ -110,6 +110,9 @@ def main():
     ap.add_argument("--weak", action="store_true",
                     help="weak scaling: --n-corpus rows PER GPU (BASELINE.json configs[2]: 8 GPUs x 1M rows = 8M); "
                          "default is strong scaling, the 1M-row corpus row-sharded over the GPUs")
+    ap.add_argument("--replicas", action="store_true",
+                    help="query-sharded replicas (SURVEY 8e, the separate line): every GPU holds the WHOLE corpus and searches "
+                         "its 1/G of the queries, no collective on the data path; not the north-star line (row-sharded)")
     ap.add_argument("--workload", default="dense", choices=["dense", "fingerprint"],
                     help="dense = the headline (BASELINE.json configs[1]); fingerprint = the reference's own call: "
                          "IndexFlatL2, k=20, 2048-d integer reaction fingerprints, train set searching itself (not the headline)")
@@ -143,13 +146,20 @@ def main():
     n, d, nq, k = args.n_corpus * (world if args.weak else 1), DIM, args.n_queries, TOPK
     if args.workload == "fingerprint":
         return fingerprint_workload(args, dev, local_rank)
-    lo, hi = shard_bounds(n, world, rank)
+    lo, hi = (0, n) if args.replicas else shard_bounds(n, world, rank)
     shard = make_rows(hi - lo, d, 1234, dev, row0=lo)
     queries = make_rows(nq, d, 5678, dev)
+    if args.replicas:
+        qlo, qhi = shard_bounds(nq, world, rank)
+        queries = queries[qlo:qhi].contiguous()
     local = faiss.IndexFlatIP(d, device=local_rank)
     local.set_timing(True)
-    index = ShardedFlatIndex(d, faiss.METRIC_INNER_PRODUCT, local_index=local)
-    index.add_shard(shard, lo, n)
+    if args.replicas:
+        index = local                        # a plain flat index per GPU: nothing to exchange
+        index.add(shard)
+    else:
+        index = ShardedFlatIndex(d, faiss.METRIC_INNER_PRODUCT, local_index=local)
+        index.add_shard(shard, lo, n)
     torch.cuda.synchronize()
 
     def sync():
@@ -176,7 +186,7 @@ def main():
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
         value = nq * args.steps / elapsed
-        flops_launch = 2.0 * nq * (hi - lo) * d        # algorithmic: 2*Q*N_local*d per scan launch
+        flops_launch = 2.0 * queries.shape[0] * (hi - lo) * d        # algorithmic: 2*Q_local*N_local*d per scan launch
         mean_launch_ms = scan_ms / max(launches, 1)
         achieved = flops_launch / (mean_launch_ms * 1e-3) / 1e12 if mean_launch_ms > 0 else 0.0
         traffic = None
@@ -191,10 +201,12 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak" if args.weak else "strong", "vs_baseline": None, "dtype": "bf16",
             "data": "synthetic",
-            "config": {"workload": "exact IP top-%d, %dx%d bf16 corpus row-sharded %d-way, %d queries per step"
-                                   % (k, n, d, world, nq),
+            "config": {"workload": ("exact IP top-%d, %dx%d bf16 corpus replicated on %d GPUs, %d queries per step split over them"
+                                    if args.replicas else
+                                    "exact IP top-%d, %dx%d bf16 corpus row-sharded %d-way, %d queries per step") % (k, n, d, world, nq),
                        "corpus_rows": n, "dim": d, "queries": nq, "k": k,
-                       "parallelism": "corpus row-sharded x%d + RCCL all-gather merge" % world if world > 1 else "single GPU",
+                       "parallelism": ("query-sharded replicas x%d (whole corpus per GPU, no collective)" % world if args.replicas else
+                                       "corpus row-sharded x%d + RCCL all-gather merge" % world) if world > 1 else "single GPU",
                        "uncertified_queries_per_step": uncert / args.steps},
             "roofline": {"bound": "mfma", "kernel": "knn_scan_kernel", "achieved": achieved,
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
