@@ -27,7 +27,7 @@ def timeit(fn, iters=20, warm=3):
     return a.elapsed_time(b) / iters
 
 
-def train_step_bench(dev, steps=10):
+def train_step_bench(dev, steps=10, dtype=torch.bfloat16):
     """one optimisation step of the full-size predictor at the scripts' per-GPU shapes
     (train_RetroSyn_tf.sh: batch 128 over 4 GPUs -> 32, encoder L = 512, decoder T = 160; bf16 autocast
     like --precision 16-mixed, dropout 0.1, AdamW), forward + backward + optimizer, random-init weights."""
@@ -48,24 +48,32 @@ def train_step_bench(dev, steps=10):
         p = train.Predictor(enc, dec, mlm=False, backend=backend).to(dev).train()
         opt, _ = train.configure_optimizer(p, 1e-4, 0.01, 1000, 0.02)
 
+        scaler = torch.amp.GradScaler("cuda") if dtype == torch.float16 else None      # what Lightning's 16-mixed adds
+
         def step():
-            with torch.autocast("cuda", dtype=torch.bfloat16):
+            with torch.autocast("cuda", dtype=dtype):
                 loss, _ = p.training_step(batch)
-            loss.backward()
-            opt.step(); opt.zero_grad(set_to_none=True)
+            if scaler is None:
+                loss.backward()
+                opt.step()
+            else:
+                scaler.scale(loss).backward()
+                scaler.step(opt); scaler.update()
+            opt.zero_grad(set_to_none=True)
             return loss
         ms = timeit(step, iters=steps, warm=4)   # the caching allocator is still growing during the first steps
 
         def fwd():
-            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            with torch.no_grad(), torch.autocast("cuda", dtype=dtype):
                 return p.model(**batch)[0]
         p.eval()
         ms_eval = timeit(fwd, iters=steps, warm=2)
         p.train()
         tokens = B * (L + T)
-        res.append({"kernel": "train_step", "backend": backend, "dtype": "bf16 autocast", "B": B, "L": L, "T": T,
+        name = "bf16 autocast" if dtype == torch.bfloat16 else "fp16 autocast + GradScaler"
+        res.append({"kernel": "train_step", "backend": backend, "dtype": name, "B": B, "L": L, "T": T,
                     "ms": ms, "tokens_per_s": tokens / (ms * 1e-3)})
-        res.append({"kernel": "forward_eval", "backend": backend, "dtype": "bf16 autocast", "B": B, "L": L, "T": T,
+        res.append({"kernel": "forward_eval", "backend": backend, "dtype": name, "B": B, "L": L, "T": T,
                     "ms": ms_eval, "tokens_per_s": tokens / (ms_eval * 1e-3)})
         del p, opt
         torch.cuda.empty_cache()

@@ -712,3 +712,38 @@ def test_model_under_fp16_autocast_runs_on_the_bf16_kernels():
         a, c = out["hip"][1][n], out["torch"][1][n]
         assert bool(torch.isfinite(a).all()), n
         assert float((a - c).abs().max()) <= 8e-2 * max(1e-2, float(c.abs().max())), n
+
+
+def test_fp16_autocast_training_step_through_the_weight_gradient_gemm():
+    """--precision 16-mixed (fp16 autocast + GradScaler) at layer widths that route the Linear layers' weight gradients
+    to trx_gemm_tn_bf16 (multiples of 256): forward, backward and an optimizer step run, the gradients are finite and
+    agree with the PyTorch statement under the same autocast to bf16 / fp16 accuracy"""
+    from textreact_amd.predictor import train
+    torch.manual_seed(0)
+    g = torch.Generator().manual_seed(0)
+    B, L, T = 4, 64, 32
+    batch = {"input_ids": torch.randint(1, 300, (B, L), generator=g).cuda(), "attention_mask": torch.ones(B, L, dtype=torch.long).cuda(),
+             "decoder_input_ids": torch.randint(3, 50, (B, T), generator=g).cuda(),
+             "decoder_attention_mask": torch.ones(B, T, dtype=torch.long).cuda()}
+    grads = {}
+    for backend in ("hip", "torch"):
+        enc = Config(vocab_size=300, hidden_size=256, num_hidden_layers=1, num_attention_heads=4, intermediate_size=512,
+                     hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+        dec = Config(vocab_size=50, hidden_size=256, num_hidden_layers=1, num_attention_heads=4, intermediate_size=512, type_vocab_size=1,
+                     layer_norm_eps=1e-5, is_decoder=True, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+        p = train.Predictor(enc, dec, mlm=False, backend=backend)
+        p.model.load_state_dict(random_state_dict(p.model, 4))
+        p = p.cuda().train()
+        opt, _ = train.configure_optimizer(p, 1e-4, 0.01, 100, 0.02)
+        scaler = torch.amp.GradScaler("cuda", init_scale=1024.0)
+        with torch.autocast("cuda", dtype=torch.float16):
+            loss, _ = p.training_step(batch)
+        scaler.scale(loss).backward()
+        grads[backend] = {n: q.grad.detach().float() / 1024.0 for n, q in p.named_parameters() if q.grad is not None}
+        scaler.step(opt); scaler.update()
+        assert bool(torch.isfinite(loss)) and all(bool(torch.isfinite(q).all()) for q in p.parameters())
+    assert set(grads["hip"]) == set(grads["torch"])
+    for n, a in grads["hip"].items():
+        c = grads["torch"][n]
+        assert bool(torch.isfinite(a).all()), n
+        assert float((a - c).abs().max()) <= 8e-2 * max(1e-3, float(c.abs().max())), n

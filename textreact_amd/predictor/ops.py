@@ -510,13 +510,16 @@ class _LinearWgrad(torch.autograd.Function):
         ctx.save_for_backward(x, w16)
         ctx.has_bias = b is not None
         ctx.wdtype = w.dtype
-        return torch.nn.functional.linear(x, w16, b.to(torch.bfloat16) if b is not None else None)
+        # autocast off: under fp16 autocast (--precision 16-mixed) the library call would be re-cast to fp16 and hand the
+        # backward an fp16 gradient for bf16 operands; x is bf16 here by construction (see `linear`)
+        with torch.autocast("cuda", enabled=False):
+            return torch.nn.functional.linear(x, w16, b.to(torch.bfloat16) if b is not None else None)
 
     @staticmethod
     def backward(ctx, dy):
         x, w16 = ctx.saved_tensors
         dx = dw = db = None
-        dy2 = dy.reshape(-1, dy.shape[-1])
+        dy2 = dy.reshape(-1, dy.shape[-1]).to(torch.bfloat16)      # a no-op except behind an fp16-autocast consumer
         x2 = x.reshape(-1, x.shape[-1])
         if ctx.needs_input_grad[0]:
             dx = torch.matmul(dy2, w16).view(x.shape)

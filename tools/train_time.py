@@ -1,7 +1,8 @@
-"""time the hip-backend train step only (python3 tools/train_time.py)"""
+"""time the train step only, hip and torch backends: python3 tools/train_time.py [bf16|fp16]"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench_predictor as bp
-for r in bp.train_step_bench("cuda", steps=10):
-    print(r["backend"], round(r["ms"], 2), "ms")
+dtype = torch.float16 if (len(sys.argv) > 1 and sys.argv[1] == "fp16") else torch.bfloat16
+for r in bp.train_step_bench("cuda", steps=10, dtype=dtype):
+    print(r["kernel"], r["backend"], r["dtype"], round(r["ms"], 2), "ms")
