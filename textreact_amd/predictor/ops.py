@@ -546,4 +546,11 @@ def linear(x, weight, bias=None, backend="hip"):
     if (backend == "hip" and x.is_cuda and x.dtype == torch.bfloat16 and torch.is_grad_enabled() and weight.requires_grad
             and weight.shape[0] % 256 == 0 and weight.shape[1] % 256 == 0):
         return _LinearWgrad.apply(x, weight, bias)
+    if (backend == "hip" and x.is_cuda and x.dtype == torch.bfloat16 and torch.is_autocast_enabled("cuda")
+            and torch.get_autocast_dtype("cuda") == torch.float16):
+        # fp16 autocast (--precision 16-mixed) over the bf16 stream the LayerNorm kernel writes: keep the product in bf16
+        # (autocast would re-cast x to fp16 and every HIP op downstream would convert it back)
+        with torch.autocast("cuda", enabled=False):
+            bf = torch.bfloat16
+            return torch.nn.functional.linear(x, weight.to(bf), bias.to(bf) if bias is not None else None)
     return torch.nn.functional.linear(x, weight, bias)
