@@ -412,9 +412,11 @@ def test_graph_decode_equals_the_eager_loop(autocast):
         if not autocast:
             assert torch.equal(s0, s1)
             assert nb == 1 or float((c0 - c1).abs().max()) < 1e-4
-        else:       # bf16 rounding may reorder near-ties; the winning hypothesis and the score scale agree
+        else:       # bf16 rounding may reorder near-ties; the score scale agrees (the eager loop rounds its logits to bf16,
+            # ~0.04 per position; the captured step keeps the vocabulary projection in fp32 -- the step-level test below
+            # bounds both against the fp32 step)
             assert s0.shape[0] == s1.shape[0]
-            assert nb == 1 or float((c0 - c1).abs().max()) < 0.1
+            assert nb == 1 or float((c0 - c1).abs().max()) < 0.3
 
 
 def test_template_based_branch_on_the_hip_ops():
@@ -446,7 +448,8 @@ def test_repeated_graph_decodes_release_their_memory():
     assert max(seen[2:]) - min(seen[2:]) < (8 << 20), seen
 
 
-def test_graph_decode_step_on_bf16_weights_is_as_close_to_fp32_as_eager_autocast():
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_graph_decode_step_on_bf16_weights_is_as_close_to_fp32_as_eager_autocast(dtype):
     """the captured step under bf16 autocast (prepared bf16 weights, packed key/value cache, biases added inside the
     LayerNorm kernel) against the fp32 step on the same tokens and the same beam re-ordering, position by position:
     its error is bf16 rounding of the logits, the same size as the eager autocast loop's"""
@@ -462,14 +465,14 @@ def test_graph_decode_step_on_bf16_weights_is_as_close_to_fp32_as_eager_autocast
     am[1, 50:] = 0
     nb, T = 5, 12
     with torch.no_grad():
-        with torch.autocast("cuda", dtype=torch.bfloat16):
+        with torch.autocast("cuda", dtype=dtype):
             eager = _DecoderState(m, ids, am, nb, T, graph=False)
             fast = _DecoderState(m, ids, am, nb, T, graph=True)
         truth = _DecoderState(m, ids, am, nb, T, graph=False)
         assert fast.fast and fast.graph is not None and truth.graph is None
         for t in range(T - 1):
             tok = torch.randint(3, 40, (3 * nb,), generator=g).cuda()
-            with torch.autocast("cuda", dtype=torch.bfloat16):
+            with torch.autocast("cuda", dtype=dtype):
                 le, lf = eager.step(tok, t).clone(), fast.step(tok, t).clone()
             lt = truth.step(tok, t)
             par = torch.stack([torch.randint(0, nb, (nb,), generator=g) + b * nb for b in range(3)]).view(-1).cuda()   # shared parents

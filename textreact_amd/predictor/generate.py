@@ -109,9 +109,12 @@ class _DecoderState:
         # bf16 autocast + graph: the step runs on bf16 copies of the decoder weights made once per call (inside a
         # capture autocast may not cache its casts, so the module path would cast every weight at every replay),
         # with the key / value projections packed (one GEMM, one cache tensor and one cache write per layer)
-        self.fast = bool(graph and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16)
+        # (fp16 autocast, the scripts' --precision 16-mixed, takes the same bf16 path: the HIP kernels store bf16 or fp32)
+        self.fast = bool(graph and torch.is_autocast_enabled("cuda")
+                         and torch.get_autocast_dtype("cuda") in (torch.bfloat16, torch.float16))
         if self.fast:
-            self._prepare_fast(enc, n, max_length)
+            with torch.autocast("cuda", enabled=False):      # every cast of the fast path is explicit
+                self._prepare_fast(enc, n, max_length)
         else:
             self.kx = [ly.crossattention.self.key(enc).view(B, L, H, 64) for ly in self.layers]
             self.vx = [ly.crossattention.self.value(enc).view(B, L, H, 64) for ly in self.layers]
@@ -217,7 +220,8 @@ class _DecoderState:
             self.kvx.append(lin(enc16, *w(ca.self.key, ca.self.value)).view(B, L, 2, H, 64))
             self.kvc.append(torch.zeros((n, max_length, 2, H, 64), dtype=bf, device=enc.device))
         head = self.model.decoder.lm_head
-        self.w_head = (w(head.dense), w(head.decoder))
+        # the vocabulary projection stays fp32: the log-probabilities rank the beams
+        self.w_head = (w(head.dense), (head.decoder.weight.detach().float(), head.decoder.bias.detach().float()))
 
     def _fast_layers(self, h):
         """the decoder layers of `_layers` on the prepared bf16 weights: fp32 residual stream, bf16 copies of it for the
@@ -242,7 +246,7 @@ class _DecoderState:
         head = self.model.decoder.lm_head
         x = torch.nn.functional.gelu(lin(h16, *self.w_head[0]))
         x = ops.add_layernorm(x, None, head.layer_norm.weight, head.layer_norm.bias, head.eps, backend=be)
-        return torch.log_softmax(lin(x, *self.w_head[1])[:, -1].float(), dim=-1)
+        return torch.log_softmax(lin(x[:, -1].float(), *self.w_head[1]), dim=-1)
 
     def _capture(self, n, max_length, dev, reorder):
         self.g_tok = torch.zeros(n, dtype=torch.long, device=dev)
@@ -250,7 +254,9 @@ class _DecoderState:
         self.g_parents = torch.arange(n, dtype=torch.long, device=dev)
         self.g_mask = torch.full((n, max_length), torch.finfo(torch.float32).min, dtype=torch.float32, device=dev)
         # inside a capture autocast must not cache its casts (they would belong to the graph's pool)
-        if torch.is_autocast_enabled("cuda"):
+        if self.fast:
+            ctx = lambda: torch.autocast("cuda", enabled=False)   # noqa: E731
+        elif torch.is_autocast_enabled("cuda"):
             ctx = lambda: torch.autocast("cuda", dtype=torch.get_autocast_dtype("cuda"), cache_enabled=False)   # noqa: E731
         else:
             ctx = contextlib.nullcontext
