@@ -27,20 +27,20 @@ def timeit(fn, iters=20, warm=3):
     return a.elapsed_time(b) / iters
 
 
-def train_step_bench(dev, steps=10, dtype=torch.bfloat16):
+def train_step_bench(dev, steps=10, dtype=torch.bfloat16, L=512, T=160):
     """one optimisation step of the full-size predictor at the scripts' per-GPU shapes
     (train_RetroSyn_tf.sh: batch 128 over 4 GPUs -> 32, encoder L = 512, decoder T = 160; bf16 autocast
     like --precision 16-mixed, dropout 0.1, AdamW), forward + backward + optimizer, random-init weights."""
     from textreact_amd.predictor.model import Config
     from textreact_amd.predictor import train
     res = []
-    B, L, T = 32, 512, 160
+    B = 32
     g = torch.Generator().manual_seed(0)
     batch = {"input_ids": torch.randint(1, 31090, (B, L), generator=g).to(dev),
              "attention_mask": torch.ones(B, L, dtype=torch.long, device=dev),
              "decoder_input_ids": torch.randint(14, 600, (B, T), generator=g).to(dev),
              "decoder_attention_mask": torch.ones(B, T, dtype=torch.long, device=dev)}
-    batch["attention_mask"][::3, 400:] = 0
+    batch["attention_mask"][::3, L * 4 // 5:] = 0
     for backend in ("hip", "torch"):
         enc = Config(vocab_size=31090)
         dec = Config(vocab_size=600, num_hidden_layers=6, type_vocab_size=1, layer_norm_eps=1e-5, is_decoder=True)

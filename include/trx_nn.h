@@ -117,7 +117,7 @@ int trx_dropout_keep_mask(uint64_t seed, float p, int64_t streams, int64_t rows,
 
 /* C[N, K] = A[M, N]^T . B[M, K]: bf16 operands and result, fp32 accumulation -- the weight gradient of a Linear
  * layer, dW = dY^T X, with the contraction over the M token rows split across workgroups (fp32 partial tiles in
- * ws, summed in a fixed order).  M % 64 == 0, N % 256 == 0, K % 256 == 0, lda / ldb % 8 == 0, ldc % 4 == 0, A, B, ws
+ * ws, summed in a fixed order).  Any M >= 1 (the rows past M of the last 64-row step read as zeros), N % 256 == 0, K % 256 == 0, lda / ldb % 8 == 0, ldc % 4 == 0, A, B, ws
  * 16-byte aligned; anything else returns TRX_NN_EINVAL (-1 from the size query) and the caller keeps its library
  * GEMM.  ws: trx_gemm_tn_ws_bytes(M, N, K) bytes. */
 int64_t trx_gemm_tn_ws_bytes(int M, int N, int K);

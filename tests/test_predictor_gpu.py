@@ -629,9 +629,11 @@ def test_ddp_wrapper_single_rank_rccl_on_the_hip_ops():
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("M,N,K", [(64, 256, 256), (448, 512, 256), (5120, 768, 768), (16384, 3072, 768), (16384, 768, 3072), (16384, 2304, 768)])
+@pytest.mark.parametrize("M,N,K", [(64, 256, 256), (448, 512, 256), (5120, 768, 768), (16384, 3072, 768), (16384, 768, 3072), (16384, 2304, 768),
+                                   (65, 256, 256), (127, 256, 512), (1000, 768, 768), (13984, 768, 3072), (4256, 2304, 768), (1, 256, 256)])
 def test_split_contraction_weight_gradient_gemm(M, N, K):
-    """trx_gemm_tn_bf16: dW = dY^T X with the token rows split over workgroups, against fp32 matmul"""
+    """trx_gemm_tn_bf16: dW = dY^T X with the token rows split over workgroups, against fp32 matmul; token counts that are
+    not multiples of the 64-row step included (the rows past the end of the last step are read as zeros)"""
     dy, x = _rand(M, N, dtype=torch.bfloat16, seed=1), _rand(M, K, dtype=torch.bfloat16, seed=2)
     c = ops.gemm_tn(dy, x)
     ref = dy.float().t() @ x.float()
@@ -646,9 +648,12 @@ def test_split_contraction_weight_gradient_gemm(M, N, K):
     assert torch.equal(ops.gemm_tn(sl, x), ops.gemm_tn(sl.contiguous(), x))
 
 
-def test_linear_with_our_weight_gradient_equals_autograd():
-    x = _rand(4, 128, 768, dtype=torch.bfloat16, seed=1); w = _rand(2304, 768, seed=2) * 0.05; b = _rand(2304, seed=3)
-    dy = _rand(4, 128, 2304, dtype=torch.bfloat16, seed=4)
+@pytest.mark.parametrize("B,L", [(4, 128), (4, 131), (3, 437), (1, 63)])
+def test_linear_with_our_weight_gradient_equals_autograd(B, L):
+    """token counts that are not multiples of 64 included (batches padded to their longest sequence); fewer than 64
+    tokens: the library"""
+    x = _rand(B, L, 768, dtype=torch.bfloat16, seed=1); w = _rand(2304, 768, seed=2) * 0.05; b = _rand(2304, seed=3)
+    dy = _rand(B, L, 2304, dtype=torch.bfloat16, seed=4)
     res = []
     for mine in (True, False):
         xs, ws, bs = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)

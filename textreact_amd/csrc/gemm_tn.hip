@@ -18,6 +18,9 @@
 
 namespace trxtn {
 
+__device__ const uint4 g_zero16 = {0u, 0u, 0u, 0u};      // what the rows past M of a ragged last step read as
+
+
 typedef unsigned short bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -48,7 +51,7 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_tn_kernel(Params p) {
     const int split = bid % p.nsplit; bid /= p.nsplit;
     const int kt = bid % p.tk, nt = bid / p.tk;
     const int n0 = nt * TILE, k0 = kt * TILE;
-    const int total_steps = p.M / BM;
+    const int total_steps = (p.M + BM - 1) / BM;          // the last step may be partial: rows >= M read as zeros (A) / row M-1 (B)
     const int step0 = split * p.steps_per_split;
     const int nsteps = max(0, min(p.steps_per_split, total_steps - step0));
 
@@ -64,12 +67,23 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_tn_kernel(Params p) {
     }
 #define TRX_TN_STAGE(S, BUF)                                                                                     \
     {                                                                                                            \
-        const bf16_t* a_ = p.A + (int64_t)(step0 + (S)) * BM * p.lda;                                            \
-        const bf16_t* b_ = p.B + (int64_t)(step0 + (S)) * BM * p.ldb;                                            \
+        const int r0_ = (step0 + (S)) * BM;                                                                      \
+        const bf16_t* a_ = p.A + (int64_t)r0_ * p.lda;                                                           \
+        const bf16_t* b_ = p.B + (int64_t)r0_ * p.ldb;                                                           \
         char* l_ = smem + (BUF) * STAGE + (4 * wave) * 1024;                                                     \
-        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                       \
-            __builtin_amdgcn_global_load_lds((gbl_void*)(a_ + offA[i_]), (lds_void*)(l_ + i_ * 1024), 16, 0, 0); \
-            __builtin_amdgcn_global_load_lds((gbl_void*)(b_ + offB[i_]), (lds_void*)(l_ + BM * 512 + i_ * 1024), 16, 0, 0); \
+        if (r0_ + BM <= p.M) {                                                                                   \
+            _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                   \
+                __builtin_amdgcn_global_load_lds((gbl_void*)(a_ + offA[i_]), (lds_void*)(l_ + i_ * 1024), 16, 0, 0); \
+                __builtin_amdgcn_global_load_lds((gbl_void*)(b_ + offB[i_]), (lds_void*)(l_ + BM * 512 + i_ * 1024), 16, 0, 0); \
+            }                                                                                                    \
+        } else { /* the ragged last step (wave-uniform): a row past M contributes nothing when its A half is zero */ \
+            _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                   \
+                const int over_ = r0_ + 2 * (4 * wave + i_) + prow - (p.M - 1);      /* > 0: rows past the end */ \
+                const bf16_t* pa_ = over_ > 0 ? reinterpret_cast<const bf16_t*>(&g_zero16) : a_ + offA[i_];      \
+                const bf16_t* pb_ = b_ + offB[i_] - (over_ > 0 ? (int64_t)over_ * p.ldb : 0);                    \
+                __builtin_amdgcn_global_load_lds((gbl_void*)pa_, (lds_void*)(l_ + i_ * 1024), 16, 0, 0);         \
+                __builtin_amdgcn_global_load_lds((gbl_void*)pb_, (lds_void*)(l_ + BM * 512 + i_ * 1024), 16, 0, 0); \
+            }                                                                                                    \
         }                                                                                                        \
     }
 
@@ -236,7 +250,7 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const float* __rest
 
 static void plan(int M, int N, int K, int* tn, int* tk, int* nsplit, int* sps) {
     *tn = N / TILE; *tk = K / TILE;
-    const int tiles = *tn * *tk, steps = M / BM;
+    const int tiles = *tn * *tk, steps = (M + BM - 1) / BM;
     int s = 256 / tiles;                        // one wave of workgroups on the 256 CUs (a workgroup takes a whole CU)
     if (s < 1) s = 1;
     if (s > 24) s = 24;
@@ -249,7 +263,7 @@ static void plan(int M, int N, int K, int* tn, int* tk, int* nsplit, int* sps) {
 
 extern "C" int64_t trx_gemm_tn_ws_bytes(int M, int N, int K) {
     using namespace trxtn;
-    if (M <= 0 || N <= 0 || K <= 0 || M % BM || N % TILE || K % TILE) return -1;
+    if (M <= 0 || N <= 0 || K <= 0 || N % TILE || K % TILE) return -1;
     int tn, tk, ns, sps;
     plan(M, N, K, &tn, &tk, &ns, &sps);
     return (int64_t)ns * ((int64_t)N * K + N) * (int64_t)sizeof(float);   // partial tiles + partial column sums
@@ -260,7 +274,7 @@ extern "C" int trx_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, 
     using namespace trxtn;
     if (!A || !B || !C || !ws || M <= 0 || N <= 0 || K <= 0) return TRX_NN_EINVAL;
     if (colsum_bf16 && (reinterpret_cast<uintptr_t>(colsum_bf16) & 7)) return TRX_NN_EINVAL;
-    if (M % BM || N % TILE || K % TILE || lda < N || ldb < K || ldc < K || (lda | ldb) % 8 || ldc % 4) return TRX_NN_EINVAL;
+    if (N % TILE || K % TILE || lda < N || ldb < K || ldc < K || (lda | ldb) % 8 || ldc % 4) return TRX_NN_EINVAL;
     if (((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(ws)) & 15) ||
         (reinterpret_cast<uintptr_t>(C) & (out_f32 ? 15 : 7)) || (out_f32 && colsum_bf16 && (reinterpret_cast<uintptr_t>(colsum_bf16) & 15)))
         return TRX_NN_EINVAL;

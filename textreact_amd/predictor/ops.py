@@ -472,7 +472,7 @@ def gemm_tn_ok(a, b):
     """can trx_gemm_tn_bf16 take dW = a^T b (a [M, N], b [M, K])?"""
     M, N = a.shape
     K = b.shape[1]
-    return (a.is_cuda and a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and b.shape[0] == M and M % 64 == 0
+    return (a.is_cuda and a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and b.shape[0] == M and M >= 64
             and N % 256 == 0 and K % 256 == 0 and a.stride(1) == 1 and b.stride(1) == 1 and a.stride(0) % 8 == 0
             and b.stride(0) % 8 == 0 and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0 and "TRX_NN_NO_GEMM" not in os.environ)
 
@@ -526,7 +526,7 @@ class _LinearWgrad(torch.autograd.Function):
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             od = torch.float32 if ctx.wdtype == torch.float32 else torch.bfloat16
-            if gemm_tn_ok(dy2, x2):
+            if gemm_tn_ok(dy2, x2):        # any token count >= 64: the kernel zero-fills the rows past the end of its last step
                 if want_db:
                     dw, db = gemm_tn(dy2, x2, colsum=True, out_dtype=od)
                 else:
