@@ -80,13 +80,13 @@ def train_step_bench(dev, steps=10, dtype=torch.bfloat16, L=512, T=160):
     return res
 
 
-def generate_bench(dev):
+def generate_bench(dev, B=8):
     """test step (main.py:218-226): beam search with num_beams = 20 over max_dec_length = 160 (train_RetroSyn_tf.sh:33,43),
     full-size model, bf16 autocast, random-init weights (no end token wins early: every beam runs the full length)"""
     from textreact_amd.predictor.model import Config, TextReactModel
     from textreact_amd.predictor.generate import generate
     res = []
-    B, L, nb, T = 8, 512, 20, 160
+    L, nb, T = 512, 20, 160
     g = torch.Generator().manual_seed(0)
     ids = torch.randint(1, 31090, (B, L), generator=g).to(dev)
     am = torch.ones(B, L, dtype=torch.long, device=dev)

@@ -51,6 +51,16 @@ int trx_attention_fwd_kvcache(const void* q, const void* k, const void* v, const
                               int B, int H, int Lq, int Lk, int64_t kv_batch_stride, float scale, int dtype, void* out,
                               void* stream);
 
+/* One-token self-attention of beam-search decoding over a cache that is never re-ordered (generate with num_beams > 1,
+ * main.py:218-226; Hugging Face re-orders the whole cache by the beams' parents at every step).  kv [n, T, 2, H, 64]
+ * bf16: row i holds what beam SLOT i wrote (keys at [.., 0, ..], values at [.., 1, ..]); anc [n, T] int32:
+ * anc[i][s] = the slot whose position-s entry belongs to beam i's history (the caller re-orders this table by the
+ * parents instead of the cache and sets anc[i][t] = i for the position just written).  *t_dev (device int64) = t, the
+ * last filled position: positions 0 .. t are attended.  It is read on the device so that a captured graph can replay
+ * the launch at every step.  q [n, H, 64] bf16 with row stride ldq elements; out [n, H*64] bf16.  T <= 256. */
+int trx_attention_decode_gather(const void* q, int ldq, const void* kv, const int32_t* anc, const int64_t* t_dev, void* out, int n, int H,
+                                int T, float scale, void* stream);
+
 /* Same, additionally writing lse[B, H, Lq] = log sum_j exp(score_ij) (float), which the backward
  * pass needs to recompute the probabilities instead of storing the Lq x Lk matrix. */
 int trx_attention_fwd_lse(const void* q, const void* k, const void* v, const float* mask, int mask_mode, int causal,

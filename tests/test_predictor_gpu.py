@@ -482,6 +482,27 @@ def test_graph_decode_step_on_bf16_weights_is_as_close_to_fp32_as_eager_autocast
             assert ef < 0.1 and ef < 2 * ee + 0.01, (t, ee, ef)
 
 
+@pytest.mark.parametrize("n,T,H", [(12, 40, 12), (7, 160, 2), (33, 256, 3), (2, 1, 12)])
+def test_decode_attention_follows_the_ancestor_table(n, T, H):
+    """trx_attention_decode_gather: keys / values of beam i at position s are read from cache row anc[i][s]; the length
+    comes from a device scalar; q may be a strided slice of a packed projection"""
+    g = torch.Generator().manual_seed(n + T)
+    kv = _rand(n, T, 2, H, 64, dtype=torch.bfloat16, seed=1)
+    anc = torch.randint(0, n, (n, T), generator=g, dtype=torch.int32).cuda()
+    qkv = _rand(n, 1, 3, H, 64, dtype=torch.bfloat16, seed=2)
+    for t in sorted({0, T // 3, T - 1}):
+        t_dev = torch.tensor([t], dtype=torch.int64, device="cuda")
+        for q in (qkv[:, :, 0], qkv[:, :, 0].contiguous()):
+            out = ops.attention_decode_gather(q, kv, anc, t_dev)
+            idx = anc[:, :t + 1].long()                                            # [n, t + 1]
+            pos = torch.arange(t + 1, device="cuda")[None].expand_as(idx)
+            k = kv[idx, pos, 0]                                                    # [n, t + 1, H, 64]: what beam i's history holds
+            v = kv[idx, pos, 1]
+            ref = ops.attention(q.float(), k.float(), v.float(), backend="torch")
+            assert out.shape == (n, 1, H * 64)
+            assert float((out.float() - ref).abs().max()) <= 2e-2
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
 def test_attention_reads_a_key_value_cache_in_place(dtype, tol):
     B, H, Lmax = 5, 12, 40

@@ -841,6 +841,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DROP || MM
 }
 
 #include "attn_bwd_mfma.h"
+#include "attn_decode.h"
 
 // ---- attention backward, fp32 math, probabilities recomputed from lse --------------------------
 // pass 1 (a lane per query row i):  delta_i = dO_i . O_i ;  dS_ij = p_ij (dO_i . V_j - delta_i) ;
@@ -1224,6 +1225,18 @@ int trx_attention_bwd_strided(const void* q, const void* k, const void* v, const
                               int B, int H, int Lq, int Lk, int ldq, int ldkv, float scale, float p, uint64_t seed, const void* out,
                               const void* dout, const float* lse, void* dq, void* dk, void* dv, void* stream) {
     return attention_bwd_impl(q, k, v, mask, mask_mode, causal, B, H, Lq, Lk, scale, TRX_NN_BF16, p, seed, out, dout, lse, dq, dk, dv, stream, ldq, ldkv);
+}
+
+int trx_attention_decode_gather(const void* q, int ldq, const void* kv, const int32_t* anc, const int64_t* t_dev, void* out, int n, int H,
+                                int T, float scale, void* stream) {
+    if (!q || !kv || !anc || !t_dev || !out || n <= 0 || H <= 0 || T <= 0 || ldq < H * 64 || ldq % 8)
+        return fail(TRX_NN_EINVAL, "attention_decode_gather: bad argument");
+    if (T > DEC_MAX_T) return fail(TRX_NN_EINVAL, "attention_decode_gather: at most 256 cache positions");
+    const int waves = n * H;
+    hipLaunchKernelGGL(attention_decode_gather_kernel, dim3((waves + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q, ldq,
+                       (const bf16_t*)kv, anc, (const long long*)t_dev, (bf16_t*)out, n, H, T, scale * 1.4426950408889634f);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? TRX_NN_OK : fail(TRX_NN_EHIP, hipGetErrorString(e));
 }
 
 int trx_attention_bwd(const void* q, const void* k, const void* v, const float* mask, int mask_mode, int causal,

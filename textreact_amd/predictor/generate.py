@@ -80,7 +80,8 @@ class _DecoderState:
     graph=True: one decode step -- re-order the cache by the surviving beams' parents, embed the new tokens,
     all decoder layers, the LM head and log-softmax, ~150 launches of a few microseconds each and therefore
     bound by the host -- is captured into a HIP graph over static buffers and replayed per position (with beams: two
-    graphs, for even and odd positions, that re-order the cache from one of two cache sets into the other).
+    graphs, for even and odd positions, that re-order the cache from one of two cache sets into the other; on the bf16
+    path the cache is not re-ordered at all -- a table of ancestors is, and the attention kernel follows it).
     What changes from step to step lives in device tensors the graph reads: the tokens, the parents, and
     the position t (the cache row written with index_copy_, the position ids, and a key mask over the
     full-length cache that opens one more column per step, which gives the same softmax as the eager
@@ -112,6 +113,9 @@ class _DecoderState:
         # (fp16 autocast, the scripts' --precision 16-mixed, takes the same bf16 path: the HIP kernels store bf16 or fp32)
         self.fast = bool(graph and torch.is_autocast_enabled("cuda")
                          and torch.get_autocast_dtype("cuda") in (torch.bfloat16, torch.float16))
+        # with beams the fast path never re-orders its cache: an ancestor table is re-ordered instead and the attention kernel
+        # follows it (ops.attention_decode_gather; the table holds up to 256 positions)
+        self.gather = self.fast and expand > 1 and max_length <= 256
         if self.fast:
             with torch.autocast("cuda", enabled=False):      # every cast of the fast path is explicit
                 self._prepare_fast(enc, n, max_length)
@@ -190,6 +194,9 @@ class _DecoderState:
         if previous is not None:
             for src, dst in zip(previous, self._caches()):
                 torch.index_select(src, 0, self.g_parents, out=dst)
+        if self.gather:      # beam i now continues the history of beam parents[i]; what it writes at position t lands in row i
+            self.anc.copy_(self.anc.index_select(0, self.g_parents))
+            self.anc.index_copy_(1, self.g_t, self.g_slot)
         self.g_mask.index_fill_(1, self.g_t, 0.0)
         ids = self.g_tok[:, None]
         pos = torch.where(ids.ne(self.pad), (self.g_t + (1 + self.pad)).expand_as(ids), torch.full_like(ids, self.pad))
@@ -214,7 +221,8 @@ class _DecoderState:
         enc16 = enc.to(bf)
         for ly in self.layers:
             at, ca = ly.attention, ly.crossattention
-            self.w.append({"q": w(at.self.query), "kv": w(at.self.key, at.self.value), "o": at.output.dense.weight.detach().to(bf),
+            self.w.append({"q": w(at.self.query), "kv": w(at.self.key, at.self.value), "qkv": w(at.self.query, at.self.key, at.self.value),
+                           "o": at.output.dense.weight.detach().to(bf),
                            "qx": w(ca.self.query), "ox": ca.output.dense.weight.detach().to(bf), "i": w(ly.intermediate.dense),
                            "out": ly.output.dense.weight.detach().to(bf)})
             self.kvx.append(lin(enc16, *w(ca.self.key, ca.self.value)).view(B, L, 2, H, 64))
@@ -231,9 +239,14 @@ class _DecoderState:
         h16 = h.to(torch.bfloat16)
         for li, ly in enumerate(self.layers):
             w, at, ca = self.w[li], ly.attention, ly.crossattention
-            q = lin(h16, *w["q"]).view(n, 1, H, 64)
-            self.kvc[li].index_copy_(1, self.g_t, lin(h16, *w["kv"]).view(n, 1, 2, H, 64))
-            ctx = ops.attention_q_kv(q, self.kvc[li], mask=self.g_mask, backend=be)
+            if self.gather:
+                qkv = lin(h16, *w["qkv"]).view(n, 1, 3, H, 64)                     # one GEMM; q is read in place (strided)
+                self.kvc[li].index_copy_(1, self.g_t, qkv[:, :, 1:])
+                ctx = ops.attention_decode_gather(qkv[:, :, 0], self.kvc[li], self.anc, self.g_t)
+            else:
+                q = lin(h16, *w["q"]).view(n, 1, H, 64)
+                self.kvc[li].index_copy_(1, self.g_t, lin(h16, *w["kv"]).view(n, 1, 2, H, 64))
+                ctx = ops.attention_q_kv(q, self.kvc[li], mask=self.g_mask, backend=be)
             h, h16 = ops.add_layernorm(lin(ctx, w["o"]), h, at.output.LayerNorm.weight, at.output.LayerNorm.bias, at.eps, backend=be,
                                        dual=True, bias=at.output.dense.bias)
             q = lin(h16, *w["qx"]).view(n // self.expand, self.expand, H, 64)
@@ -266,6 +279,10 @@ class _DecoderState:
         if side is None:
             side = _warmup_streams[dev.index] = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
+        if self.gather:
+            self.anc = torch.arange(n, dtype=torch.int32, device=dev)[:, None].repeat(1, max_length)     # anc[i][s]: see _graph_step
+            self.g_slot = torch.arange(n, dtype=torch.int32, device=dev)[:, None]
+            reorder = False
         sets = [self._caches()]
         if reorder:
             sets.append([torch.zeros_like(c) for c in sets[0]])
@@ -281,6 +298,8 @@ class _DecoderState:
                 self.g_logp.append(self._graph_step(sets[1 - which] if reorder else None))
             graphs.append(g)
         self.g_mask.fill_(torch.finfo(torch.float32).min)      # the warm-up opened column 0
+        if self.gather:
+            self.anc.copy_(torch.arange(n, dtype=torch.int32, device=dev)[:, None].expand(n, max_length))
         self.graph, self.g_sets = graphs, sets     # both cache sets stay alive as long as the graphs that write them
 
 

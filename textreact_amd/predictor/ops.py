@@ -22,7 +22,7 @@ SYMBOLS = ["trx_add_layernorm_fwd", "trx_add_layernorm_bwd", "trx_add_layernorm_
            "trx_add_layernorm_fwd_dropout", "trx_add_layernorm_bwd_dropout", "trx_attention_fwd_dropout",
            "trx_attention_bwd_dropout", "trx_dropout_keep_mask", "trx_add_layernorm_fwd_mixed",
            "trx_add_layernorm_bwd_mixed", "trx_attention_fwd_kvcache", "trx_attention_fwd_strided",
-           "trx_attention_bwd_strided", "trx_gemm_tn_bf16", "trx_gemm_tn_ws_bytes", "trx_nn_last_error", "trx_nn_version"]
+           "trx_attention_bwd_strided", "trx_attention_decode_gather", "trx_gemm_tn_bf16", "trx_gemm_tn_ws_bytes", "trx_nn_last_error", "trx_nn_version"]
 
 
 class TrxNNError(RuntimeError):
@@ -55,6 +55,7 @@ def lib():
         L.trx_attention_fwd_strided.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, f32, u64, vp, vp, vp]
         L.trx_attention_bwd_strided.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, f32, u64,
                                                 vp, vp, vp, vp, vp, vp, vp]
+        L.trx_attention_decode_gather.argtypes = [vp, i32, vp, vp, vp, vp, i32, i32, i32, f32, vp]
         L.trx_gemm_tn_ws_bytes.argtypes = [i32, i32, i32]
         L.trx_gemm_tn_ws_bytes.restype = i64
         L.trx_gemm_tn_bf16.argtypes = [vp, i32, vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, vp]
@@ -369,6 +370,23 @@ def attention(q, k, v, mask=None, causal=False, scale=None, backend="hip", dropo
         keep = dropout_keep_mask(seed, dropout_p, B * H, Lq, Lk, q.device).view(B, H, Lq, Lk)
         p = p * keep.float() / (1.0 - dropout_p)
     return torch.matmul(p, vf).permute(0, 2, 1, 3).reshape(B, Lq, H * D).to(q.dtype)
+
+
+def attention_decode_gather(q, kv, anc, t_dev, scale=None):
+    """one-token self-attention of beam search over a cache that is never re-ordered (include/trx_nn.h:
+    trx_attention_decode_gather).  q [n, 1, H, 64] or [n, H, 64] bf16 (rows may be strided), kv [n, T, 2, H, 64] bf16,
+    anc [n, T] int32 ancestor table, t_dev int64 [1] on the device = the last filled position.  -> [n, 1, H*64]"""
+    _need_gpu(q)
+    n, T, _, H, D = kv.shape
+    if D != 64 or q.dtype != torch.bfloat16 or kv.dtype != torch.bfloat16 or anc.dtype != torch.int32 or t_dev.dtype != torch.int64:
+        raise TrxNNError("attention_decode_gather: bf16 q / kv with heads of 64, int32 table, int64 position")
+    q3 = q.reshape(n, H, D) if q.dim() == 4 else q
+    if q3.stride(2) != 1 or q3.stride(1) != D:
+        q3 = q3.contiguous()
+    out = torch.empty((n, 1, H * D), dtype=torch.bfloat16, device=q.device)
+    _check(lib().trx_attention_decode_gather(_p(q3), q3.stride(0), _p(kv.contiguous()), _p(anc.contiguous()), _p(t_dev), _p(out), n, H, T,
+                                             float(scale if scale is not None else 1.0 / math.sqrt(D)), _stream(q)))
+    return out
 
 
 # ---- packed projections: q, k, v as slices of ONE GEMM output (bf16, matrix-core kernels) -------------------
