@@ -205,6 +205,9 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
         ap[SLOT][j_] = *reinterpret_cast<const bf16x8*>(Ab + ((MP) * 2 + j_) * 2048 + ((KK) ? r_off1 : r_off0));
             TRX_LOAD_B(0);
             TRX_LOAD_A(0, 0, 0);
+#ifdef TRX_PRIO_EXPERIMENT
+            __builtin_amdgcn_s_setprio(TRX_PRIO_EXPERIMENT);
+#endif
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
                 const int kk = g >> 2, mp = g & 3;
@@ -222,6 +225,9 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
                             ap[g & 1][j], bq[kk][nt], acc[mp * 2 + j][nt], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
+#ifdef TRX_PRIO_EXPERIMENT
+            __builtin_amdgcn_s_setprio(0);
+#endif
 #undef TRX_LOAD_A
 #undef TRX_LOAD_B
         }
