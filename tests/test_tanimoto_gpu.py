@@ -83,7 +83,7 @@ def test_dtypes_device_inputs_and_the_reference_output_structure():
     assert res[2]["rank"] == want_r[2].tolist() and res[2]["similarity"] == want_s[2].tolist()
 
 
-def test_batches_of_64_rows_append_and_bad_inputs_fail_loudly():
+def test_batches_of_any_size_append_and_bad_inputs_fail_loudly():
     from textreact_amd.tanimoto import TanimotoIndex, TrxTanimotoError
     rng = np.random.default_rng(6)
     corpus = fingerprints(rng, 64 * 5 + 9, 512)
@@ -93,9 +93,17 @@ def test_batches_of_64_rows_append_and_bad_inputs_fail_loudly():
     sim, rank = idx.search(queries, 50)
     want_s, want_r = oracle.search(queries, corpus, 50)
     assert np.array_equal(rank.cpu().numpy(), want_r) and np.array_equal(sim.cpu().numpy(), want_s)
-    with pytest.raises(TrxTanimotoError):
-        idx.add(corpus[:3])                                     # the last block is partially filled
+    idx.add(corpus[:3])                                         # the last block is partially filled: it is packed again
+    idx.add(corpus[3:70].astype(np.int32)); idx.add(corpus[70:71])
+    grown = np.concatenate([corpus, corpus[:71]])
+    sim, rank = idx.search(queries, 50)
+    want_s, want_r = oracle.search(queries, grown, 50)
+    assert idx.ntotal == len(grown) and np.array_equal(rank.cpu().numpy(), want_r) and np.array_equal(sim.cpu().numpy(), want_s)
     big = corpus[:64].copy(); big[3, 5] = 300
+    with pytest.raises(TrxTanimotoError):
+        idx.add(big)                                            # rejected, and the index is left as it was
+    sim, rank = idx.search(queries, 50)
+    assert idx.ntotal == len(grown) and np.array_equal(rank.cpu().numpy(), want_r) and np.array_equal(sim.cpu().numpy(), want_s)
     with pytest.raises(TrxTanimotoError):
         TanimotoIndex(512).add(big)
     with pytest.raises(TrxTanimotoError):

@@ -93,6 +93,7 @@ class TanimotoIndex:
         self.d, self.dev = d, torch.device("cuda", device)
         self.ntotal, self.cap = 0, 0
         self.packed = None          # uint8 [cap / 64 * d * 64] in the layout of the header
+        self._tail = None           # the rows of a partially filled last block, as they were handed in
         self.row_sum = None         # int32 [cap]
 
     def _as_device_ints(self, x):
@@ -120,24 +121,36 @@ class TanimotoIndex:
     def add(self, fps):
         """append [n, d] integer counts (signed: magnitudes are what RDKit's similarity uses)"""
         t = self._as_device_ints(fps)
-        n = t.shape[0]
-        if n == 0:
+        if t.shape[0] == 0:
             return
-        if self.ntotal % 64:
-            # a partially filled block: re-pack its rows together with the new ones
-            raise TrxTanimotoError("add() after a batch whose size is not a multiple of 64 is not supported: add everything at once, "
-                                   "or in batches that are multiples of 64 rows")
-        if self.ntotal + n >= (1 << KEY_ID_BITS):
+        if self.ntotal + t.shape[0] >= (1 << KEY_ID_BITS):
             raise TrxTanimotoError("at most 2^27 - 1 rows")
-        self._reserve(self.ntotal + n)
+        first = self.ntotal
+        if self._tail is not None:
+            # the last block of 64 rows is partially filled: it is packed again, its old rows in front of the new ones
+            first = self.ntotal - self._tail.shape[0]
+            t = torch.cat([self._tail.to(t.dtype), t])
+        n = t.shape[0]
+        self._reserve(first + n)
+        self.row_sum[first:self.ntotal] = 0
         flags = torch.zeros(1, dtype=torch.int32, device=self.dev)
-        _check(lib().trx_tanimoto_pack(t.data_ptr(), _DT[t.dtype], n, self.d, t.stride(0), self.ntotal, self.packed.data_ptr(),
+        _check(lib().trx_tanimoto_pack(t.data_ptr(), _DT[t.dtype], n, self.d, t.stride(0), first, self.packed.data_ptr(),
                                        self.row_sum.data_ptr(), flags.data_ptr(), _stream(self.dev)))
+        bad = None
         if int(flags.item()) & 1:
-            raise TrxTanimotoError("a count magnitude above 255 does not fit the byte storage")
-        if int(self.row_sum[self.ntotal:self.ntotal + n].max().item()) >= MAX_SUM:
-            raise TrxTanimotoError("sum |count| of a fingerprint must be < %d" % MAX_SUM)
-        self.ntotal += n
+            bad = "a count magnitude above 255 does not fit the byte storage"
+        elif int(self.row_sum[first:first + n].max().item()) >= MAX_SUM:
+            bad = "sum |count| of a fingerprint must be < %d" % MAX_SUM
+        if bad:        # leave the index as it was: the rows that were there are packed back
+            self.row_sum[first:first + n] = 0
+            if self._tail is not None:
+                keep = self._tail
+                _check(lib().trx_tanimoto_pack(keep.data_ptr(), _DT[keep.dtype], keep.shape[0], self.d, keep.stride(0), first,
+                                               self.packed.data_ptr(), self.row_sum.data_ptr(), flags.data_ptr(), _stream(self.dev)))
+            raise TrxTanimotoError(bad)
+        self.ntotal = first + n
+        rem = self.ntotal % 64
+        self._tail = t[n - rem:].clone() if rem else None
 
     def _pack_queries(self, q):
         mag = q.abs()
