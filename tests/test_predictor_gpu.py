@@ -776,3 +776,70 @@ def test_fp16_autocast_training_step_through_the_weight_gradient_gemm():
         c = grads["torch"][n]
         assert bool(torch.isfinite(a).all()), n
         assert float((a - c).abs().max()) <= 8e-2 * max(1e-3, float(c.abs().max())), n
+
+
+def test_packed_projection_without_concatenation_equals_autograd():
+    """ops.linear_multi: query / key / value as ONE product whose weight gradient comes back as row blocks, with and
+    without a WeightShadows registry installed"""
+    x = _rand(3, 131, 768, dtype=torch.bfloat16, seed=1)
+    ws = [(_rand(768, 768, seed=10 + i) * 0.05) for i in range(3)]
+    bs = [_rand(768, seed=20 + i) for i in range(3)]
+    dy = _rand(3, 131, 2304, dtype=torch.bfloat16, seed=4)
+    res = []
+    for mode in ("shadows", "casts", "autograd"):
+        xs = x.clone().requires_grad_(True)
+        w_ = [w.clone().requires_grad_(True) for w in ws]
+        b_ = [b.clone().requires_grad_(True) for b in bs]
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            if mode == "autograd":
+                y = torch.nn.functional.linear(xs, torch.cat(w_), torch.cat(b_))
+            else:
+                with ops.use_shadows(ops.WeightShadows() if mode == "shadows" else None):
+                    y = ops.linear_multi(xs, tuple(w_), tuple(b_))
+        y.backward(dy)
+        res.append((y.detach().float(), xs.grad.float(), torch.cat([w.grad for w in w_]), torch.cat([b.grad for b in b_])))
+    for r in res[:2]:
+        assert torch.equal(r[0], res[2][0]) and torch.equal(r[1], res[2][1])
+        for a, c in zip(r[2:], res[2][2:]):
+            assert float((a - c).abs().max()) <= 1e-2 * max(1.0, float(c.abs().max()))
+    assert torch.equal(res[0][2], res[1][2]) and torch.equal(res[0][3], res[1][3])
+
+
+def test_weight_shadows_follow_the_optimizer_and_allow_two_forwards_before_one_backward():
+    from textreact_amd.predictor import train
+    enc = Config(vocab_size=300, hidden_size=256, num_hidden_layers=1, num_attention_heads=4, intermediate_size=512,
+                 hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    dec = Config(vocab_size=50, hidden_size=256, num_hidden_layers=1, num_attention_heads=4, intermediate_size=512, type_vocab_size=1,
+                 layer_norm_eps=1e-5, is_decoder=True, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    g = torch.Generator().manual_seed(0)
+    mk = lambda B: {"input_ids": torch.randint(1, 300, (B, 70), generator=g).cuda(), "attention_mask": torch.ones(B, 70, dtype=torch.long).cuda(),
+                    "decoder_input_ids": torch.randint(3, 50, (B, 33), generator=g).cuda(),
+                    "decoder_attention_mask": torch.ones(B, 33, dtype=torch.long).cuda()}
+    b1, b2 = mk(4), mk(3)
+    out = {}
+    for backend in ("hip", "torch"):
+        p = train.Predictor(enc, dec, mlm=False, backend=backend)
+        p.model.load_state_dict(random_state_dict(p.model, 4))
+        p = p.cuda().train()
+        opt = torch.optim.AdamW(p.parameters(), lr=2e-3, fused=True)      # fused: updates parameters without moving their autograd version
+        losses = []
+        for _ in range(3):
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                l1, _ = p.training_step(b1)
+                l2, _ = p.training_step(b2)          # a second forward before the backward: the shadows must not be rewritten
+            (l1 + l2).backward()
+            opt.step(); opt.zero_grad(set_to_none=True)
+            losses.append(float(l1) + float(l2))
+        out[backend] = losses
+        if backend == "hip":
+            reg = p.model.__dict__["_weight_shadows"]
+            assert len(reg.groups) >= 8
+            for ws_, bs_, w16, b16 in reg.groups.values():           # after the last step the NEXT forward refreshes them
+                pass
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                p.training_step(b1)
+            for ws_, bs_, w16, b16 in reg.groups.values():
+                assert torch.equal(w16, torch.cat([w.detach() for w in ws_]).to(torch.bfloat16))
+    assert out["hip"][-1] < out["hip"][0] - 0.05                      # the optimizer moves the weights: stale shadows would not learn
+    for a, c in zip(out["hip"], out["torch"]):
+        assert abs(a - c) <= 3e-2 * max(1.0, abs(c)), (out["hip"], out["torch"])

@@ -90,15 +90,12 @@ class Attention(nn.Module):
         if kv_low is h_low:
             # self-attention: ONE [*, 768] x [768, 2304] GEMM for q, k, v (same parameters, concatenated per call);
             # the attention kernels read the three slices of its output in place
-            w = torch.cat([sa.query.weight, sa.key.weight, sa.value.weight])
-            bias = torch.cat([sa.query.bias, sa.key.bias, sa.value.bias])
-            qkv = ops.linear(h_low, w, bias, backend).view(B, Lq, 3, self.heads, 64)
+            qkv = ops.linear_multi(h_low, (sa.query.weight, sa.key.weight, sa.value.weight),
+                                   (sa.query.bias, sa.key.bias, sa.value.bias), backend).view(B, Lq, 3, self.heads, 64)
             ctx = ops.attention_qkv(qkv, mask=mask, causal=causal, backend=backend, dropout_p=pa)
         else:
             q = ops.linear(h_low, sa.query.weight, sa.query.bias, backend).view(B, Lq, self.heads, 64)
-            w = torch.cat([sa.key.weight, sa.value.weight])
-            bias = torch.cat([sa.key.bias, sa.value.bias])
-            kv = ops.linear(kv_low, w, bias, backend).view(B, Lk, 2, self.heads, 64)
+            kv = ops.linear_multi(kv_low, (sa.key.weight, sa.value.weight), (sa.key.bias, sa.value.bias), backend).view(B, Lk, 2, self.heads, 64)
             ctx = ops.attention_q_kv(q, kv, mask=mask, causal=causal, backend=backend, dropout_p=pa)
         return _dense_add_layernorm(self.output.dense, ctx, h, self.output.LayerNorm, self.eps, backend,
                                     self.p_hidden if self.training else 0.0)
@@ -222,6 +219,17 @@ def additive_key_mask(attention_mask, dtype=torch.float32):
     return (1.0 - attention_mask.to(dtype)) * torch.finfo(dtype).min
 
 
+def weight_shadows(model, like):
+    """the model's ops.WeightShadows registry (created on first use) when a training forward under autocast on the GPU can
+    use it, else None"""
+    if not (model.backend == "hip" and like.is_cuda and torch.is_autocast_enabled("cuda") and torch.is_grad_enabled()):
+        return None
+    reg = model.__dict__.get("_weight_shadows")
+    if reg is None:
+        reg = model.__dict__["_weight_shadows"] = ops.WeightShadows()
+    return reg
+
+
 class TextReactModel(nn.Module):
     """forward(input_ids, attention_mask, decoder_input_ids, ...) -> (logits, encoder_last_hidden_state)"""
 
@@ -233,8 +241,8 @@ class TextReactModel(nn.Module):
 
     def forward(self, input_ids, attention_mask=None, decoder_input_ids=None, decoder_attention_mask=None,
                 position_ids=None, token_type_ids=None):
-        if self.training:   # one generator draw for all the dropout sites of this pass
-            with ops.seed_scope():
+        if self.training:   # one generator draw for all the dropout sites of this pass, one multi-tensor cast of the Linear weights
+            with ops.seed_scope(), ops.use_shadows(weight_shadows(self, input_ids)):
                 return self._forward(input_ids, attention_mask, decoder_input_ids, decoder_attention_mask, position_ids, token_type_ids)
         return self._forward(input_ids, attention_mask, decoder_input_ids, decoder_attention_mask, position_ids, token_type_ids)
 

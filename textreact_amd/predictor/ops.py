@@ -516,33 +516,120 @@ def gemm_tn(a, b, colsum=False, out_dtype=torch.bfloat16):
     return (out, cs) if colsum else out
 
 
+class WeightShadows:
+    """bf16 copies of the Linear parameters a model feeds to `linear`, refreshed by ONE multi-tensor copy per forward.
+
+    Autocast casts every fp32 weight and bias with its own kernel at every step (~200 launches of a few microseconds,
+    and as many on the host, which bounds the step on real, ragged batches: DESIGN.md section 8).  A group = the weights
+    (and biases) one `linear` call concatenates along the outputs -- (query, key, value) of a self-attention, (key, value)
+    of a cross-attention, or a single Linear -- stored back to back in one bf16 buffer, so that the packed projection
+    needs no torch.cat either.  Groups are registered the first time a forward uses them; `refresh()` at the start of
+    every forward re-copies all of them (parameters change between forwards, not inside one)."""
+
+    def __init__(self):
+        self.groups = {}          # tuple(id(weight) ...) -> (weights, biases, w16, b16)
+        self._dst, self._src = [], []
+
+    def refresh(self):
+        """re-copy every group.  (Skipping the copy when no parameter's autograd version moved would be cheaper, but fused
+        optimizers -- AdamW(fused=True), what the trainer uses -- update parameters without moving it.)"""
+        if not self.groups:
+            return
+        dev = self._dst[0].device
+        if any(p.device != dev for p in self._src):       # the model moved: rebuild lazily
+            self.groups, self._dst, self._src = {}, [], []
+            return
+        with torch.no_grad():
+            torch._foreach_copy_(self._dst, [p.detach() for p in self._src])
+
+    def lookup(self, weights, biases):
+        key = tuple(id(w) for w in weights)
+        g = self.groups.get(key)
+        if g is None:
+            with torch.no_grad():
+                outs = [w.shape[0] for w in weights]
+                w16 = torch.empty((sum(outs), weights[0].shape[1]), dtype=torch.bfloat16, device=weights[0].device)
+                b16 = torch.empty(sum(outs), dtype=torch.bfloat16, device=weights[0].device) if biases is not None else None
+                lo = 0
+                for i, w in enumerate(weights):
+                    wv = w16[lo:lo + outs[i]]
+                    wv.copy_(w.detach())
+                    self._dst.append(wv); self._src.append(w)
+                    if biases is not None:
+                        bv = b16[lo:lo + outs[i]]
+                        bv.copy_(biases[i].detach())
+                        self._dst.append(bv); self._src.append(biases[i])
+                    lo += outs[i]
+            g = self.groups[key] = (tuple(weights), None if biases is None else tuple(biases), w16, b16)
+        return g[2], g[3]
+
+
+_shadows = None
+
+
+class use_shadows:
+    """`with ops.use_shadows(registry):` around a forward pass: `linear` takes its bf16 operands from the registry"""
+
+    def __init__(self, registry):
+        self.registry = registry
+
+    def __enter__(self):
+        global _shadows
+        self.prev, _shadows = _shadows, self.registry
+        if self.registry is not None:
+            self.registry.refresh()
+        return self.registry
+
+    def __exit__(self, *exc):
+        global _shadows
+        _shadows = self.prev
+        return False
+
+
 class _LinearWgrad(torch.autograd.Function):
-    """y = x W^T (+ b) with the library GEMM; in the backward the weight gradient dY^T X runs on trx_gemm_tn_bf16
-    (the library contracts the 16,384 token rows inside 9 .. 36 workgroups: 0.48 PFLOP/s), dx and db stay library calls"""
+    """y = x [W_1; W_2; ...]^T (+ [b_1; b_2; ...]) with the library GEMM; in the backward the weight gradient dY^T X runs on
+    trx_gemm_tn_bf16 (the library contracts the 16,384 token rows inside 9 .. 36 workgroups: 0.48 PFLOP/s), dx stays a
+    library call.  apply(x, n, W_1 .. W_n[, b_1 .. b_n]): several Linear layers over the same input (the query / key /
+    value projections) are ONE product; their gradients are row blocks of the one dW."""
 
     @staticmethod
-    def forward(ctx, x, w, b):
-        # the parameters arrive in their own precision (fp32 under autocast) and are cast here, so that the backward
-        # can hand back gradients in that precision straight from the fp32 sums (no bf16 rounding, no cast kernels)
-        w16 = w.to(torch.bfloat16)
-        ctx.save_for_backward(x, w16)
-        ctx.has_bias = b is not None
-        ctx.wdtype = w.dtype
+    def forward(ctx, x, n, *params):
+        weights = params[:n]
+        biases = params[n:] if len(params) > n else None
+        # the parameters arrive in their own precision (fp32 under autocast): the bf16 operands come from the model's
+        # WeightShadows when a forward has installed them, from casts otherwise; the backward hands back gradients in the
+        # parameters' precision straight from the fp32 sums (no bf16 rounding, no cast kernels)
+        bf = torch.bfloat16
+        if _shadows is not None and weights[0].dtype == torch.float32:
+            w16, b16 = _shadows.lookup(weights, biases)
+        else:
+            w16 = weights[0].to(bf) if n == 1 else torch.cat([w.to(bf) for w in weights])
+            b16 = None if biases is None else (biases[0].to(bf) if n == 1 else torch.cat([b.to(bf) for b in biases]))
+        # w16 rides on ctx, not in save_for_backward: a shadow is re-copied (with the same values) by the next forward, and
+        # two forwards before one backward must not trip autograd's in-place check -- the semantics autocast's own cached
+        # casts have (a parameter changed between a forward and its backward goes unnoticed there as well)
+        ctx.save_for_backward(x)
+        ctx.w16 = w16
+        ctx.n, ctx.has_bias = n, biases is not None
+        ctx.outs = [w.shape[0] for w in weights]
+        ctx.wdtype = weights[0].dtype
         # autocast off: under fp16 autocast (--precision 16-mixed) the library call would be re-cast to fp16 and hand the
         # backward an fp16 gradient for bf16 operands; x is bf16 here by construction (see `linear`)
         with torch.autocast("cuda", enabled=False):
-            return torch.nn.functional.linear(x, w16, b.to(torch.bfloat16) if b is not None else None)
+            return torch.nn.functional.linear(x, w16, b16)
 
     @staticmethod
     def backward(ctx, dy):
-        x, w16 = ctx.saved_tensors
+        (x,), w16 = ctx.saved_tensors, ctx.w16
+        n = ctx.n
         dx = dw = db = None
         dy2 = dy.reshape(-1, dy.shape[-1]).to(torch.bfloat16)      # a no-op except behind an fp16-autocast consumer
         x2 = x.reshape(-1, x.shape[-1])
         if ctx.needs_input_grad[0]:
             dx = torch.matmul(dy2, w16).view(x.shape)
-        want_db = ctx.has_bias and ctx.needs_input_grad[2]
-        if ctx.needs_input_grad[1]:
+        need_w = any(ctx.needs_input_grad[2:2 + n])
+        want_db = ctx.has_bias and any(ctx.needs_input_grad[2 + n:])
+        if need_w:
             od = torch.float32 if ctx.wdtype == torch.float32 else torch.bfloat16
             if gemm_tn_ok(dy2, x2):        # any token count >= 64: the kernel zero-fills the rows past the end of its last step
                 if want_db:
@@ -555,7 +642,28 @@ class _LinearWgrad(torch.autograd.Function):
             db = dy2.sum(dim=0)
         if db is not None:
             db = db.to(ctx.wdtype)
-        return dx, dw, db
+        grads, lo = [], 0
+        for o in ctx.outs:                                         # row blocks of the one dW / db
+            grads.append(dw[lo:lo + o] if dw is not None else None)
+            lo += o
+        if ctx.has_bias:
+            lo = 0
+            for o in ctx.outs:
+                grads.append(db[lo:lo + o] if db is not None else None)
+                lo += o
+        return (dx, None, *grads)
+
+
+def linear_multi(x, weights, biases=None, backend="hip"):
+    """F.linear(x, cat(weights), cat(biases)) for Linear layers that read the same input (query / key / value): one
+    product, no concatenation of the fp32 parameters (see _LinearWgrad); falls back to the concatenation otherwise"""
+    w0 = weights[0]
+    if (backend == "hip" and x.is_cuda and x.dtype == torch.bfloat16 and torch.is_grad_enabled() and w0.requires_grad
+            and sum(w.shape[0] for w in weights) % 256 == 0 and w0.shape[1] % 256 == 0):
+        return _LinearWgrad.apply(x, len(weights), *weights, *(biases if biases is not None else ()))
+    w = w0 if len(weights) == 1 else torch.cat(list(weights))
+    b = None if biases is None else (biases[0] if len(biases) == 1 else torch.cat(list(biases)))
+    return linear(x, w, b, backend)
 
 
 def linear(x, weight, bias=None, backend="hip"):
@@ -563,7 +671,7 @@ def linear(x, weight, bias=None, backend="hip"):
     to the split-contraction TN GEMM when its shape qualifies"""
     if (backend == "hip" and x.is_cuda and x.dtype == torch.bfloat16 and torch.is_grad_enabled() and weight.requires_grad
             and weight.shape[0] % 256 == 0 and weight.shape[1] % 256 == 0):
-        return _LinearWgrad.apply(x, weight, bias)
+        return _LinearWgrad.apply(x, 1, weight, *((bias,) if bias is not None else ()))
     if (backend == "hip" and x.is_cuda and x.dtype == torch.bfloat16 and torch.is_autocast_enabled("cuda")
             and torch.get_autocast_dtype("cuda") == torch.float16):
         # fp16 autocast (--precision 16-mixed) over the bf16 stream the LayerNorm kernel writes: keep the product in bf16

@@ -18,7 +18,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch.nn.utils.rnn import pad_sequence
 
-from .model import BertEncoder, additive_key_mask
+from . import ops
+from .model import BertEncoder, additive_key_mask, weight_shadows
 
 
 class BondTemplatePredictor(nn.Module):
@@ -59,7 +60,11 @@ class TemplateBasedModel(nn.Module):
     def forward(self, input_ids, attention_mask=None, atom_indices=None, position_ids=None, token_type_ids=None, **_):
         if attention_mask is None:
             attention_mask = torch.ones_like(input_ids)
-        enc = self.encoder(input_ids, additive_key_mask(attention_mask), position_ids, token_type_ids, None, self.backend)
+        if self.training:
+            with ops.seed_scope(), ops.use_shadows(weight_shadows(self, input_ids)):
+                enc = self.encoder(input_ids, additive_key_mask(attention_mask), position_ids, token_type_ids, None, self.backend)
+        else:
+            enc = self.encoder(input_ids, additive_key_mask(attention_mask), position_ids, token_type_ids, None, self.backend)
         atoms = pad_sequence([h[idx] for h, idx in zip(enc, atom_indices)], batch_first=True)
         return self.template_head(atoms), enc
 

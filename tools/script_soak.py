@@ -32,6 +32,8 @@ def run(name, make, step_fn, steps=3):
         assert all(l == l and abs(l) < 1e4 for l in losses), (name, backend, losses)
         out[backend] = (losses, p)
     print(name, "hip", [round(l, 4) for l in out["hip"][0]], "torch", [round(l, 4) for l in out["torch"][0]], flush=True)
+    for a, c in zip(out["hip"][0], out["torch"][0]):      # the trajectories must agree step by step (stale weights, a wrong gradient ... show here)
+        assert abs(a - c) <= 5e-3 * max(1.0, abs(c)), (name, out["hip"][0], out["torch"][0])
     return out
 
 
