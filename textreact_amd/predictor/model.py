@@ -16,6 +16,8 @@ probabilities and on dense outputs before the residual LayerNorm -- both inside 
 and on the embeddings after their LayerNorm (torch's dropout); eval mode is the identity, and parity
 with the reference's logits is defined in eval mode.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -222,7 +224,8 @@ def additive_key_mask(attention_mask, dtype=torch.float32):
 def weight_shadows(model, like):
     """the model's ops.WeightShadows registry (created on first use) when a training forward under autocast on the GPU can
     use it, else None"""
-    if not (model.backend == "hip" and like.is_cuda and torch.is_autocast_enabled("cuda") and torch.is_grad_enabled()):
+    if not (model.backend == "hip" and like.is_cuda and torch.is_autocast_enabled("cuda") and torch.is_grad_enabled()) \
+            or "TRX_NN_NO_SHADOWS" in os.environ:      # (the knob is for A/B timing)
         return None
     reg = model.__dict__.get("_weight_shadows")
     if reg is None:
