@@ -530,6 +530,13 @@ class WeightShadows:
         self.groups = {}          # tuple(id(weight) ...) -> (weights, biases, w16, b16)
         self._dst, self._src = [], []
 
+    # a copy or a pickle of the model starts with an empty registry (views into packed buffers do not survive either)
+    def __deepcopy__(self, memo):
+        return WeightShadows()
+
+    def __reduce__(self):
+        return (WeightShadows, ())
+
     def refresh(self):
         """re-copy every group.  (Skipping the copy when no parameter's autograd version moved would be cheaper, but fused
         optimizers -- AdamW(fused=True), what the trainer uses -- update parameters without moving it.)"""
