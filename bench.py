@@ -50,53 +50,104 @@ def make_rows(n, d, seed, device, row0=0):
     return out
 
 
-def cpu_baseline(corpus_dev, queries_dev, k, target_seconds=15.0):
-    """FAISS-structured CPU search (oracle, 'port') on a bounded sample of the same workload."""
+def try_faiss():
+    """The reference's own library (retrieve/retrieve_faiss.py:14).  It is not in the build image; a box that has it
+    makes it the CPU baseline and the parity reference."""
+    try:
+        import faiss
+        return faiss, str(getattr(faiss, "__version__", "unknown"))
+    except Exception:
+        return None, "unavailable"
+
+
+def cpu_baseline(corpus_dev, queries_dev, k, target_seconds=15.0, metric=0):
+    """CPU search on a bounded sample of the same workload: real FAISS when importable ('reference'), otherwise the
+    oracle's FAISS-structured restatement with the host BLAS doing the 4096 x 1024 sgemm blocks ('port')."""
     import numpy as np
     from oracle import flat_knn as oracle
     cores = len(os.sched_getaffinity(0))
     y = corpus_dev.float().cpu().numpy()
+    faiss, faiss_version = try_faiss()
+    if faiss is not None:
+        ref = (faiss.IndexFlatL2 if metric == 1 else faiss.IndexFlatIP)(y.shape[1])
+        ref.add(y)
+        nq = min(4096, queries_dev.shape[0])
+        x = queries_dev[:nq].float().cpu().numpy()
+        ref.search(x[:64], k)
+        t0 = time.perf_counter(); D, I = ref.search(x, k); t1 = time.perf_counter()
+        return {"value": nq / (t1 - t0), "unit": "queries/s", "cores": cores, "kind": "reference", "faiss": faiss_version,
+                "sample": "%d of %d queries x full %dx%d corpus, faiss.IndexFlat%s %s" % (
+                    nq, queries_dev.shape[0], y.shape[0], y.shape[1], "L2" if metric == 1 else "IP", faiss_version)}, I
     # size the sample from a probe with FAISS's own block shape (4096 queries x 8 corpus blocks) so
     # the leg stays within ~10-40 s on any host; 4096 queries = one full FAISS query block
     nprobe = min(4096, queries_dev.shape[0])
     probe = queries_dev[:nprobe].float().cpu().numpy()
     ysub = y[:8192]
-    oracle.knn_faiss_blas(0, probe[:64], ysub[:1024], k)  # warm BLAS threads
-    t0 = time.perf_counter(); oracle.knn_faiss_blas(0, probe, ysub, k); t1 = time.perf_counter()
+    oracle.knn_faiss_blas(metric, probe[:64], ysub[:1024], k)  # warm BLAS threads
+    t0 = time.perf_counter(); oracle.knn_faiss_blas(metric, probe, ysub, k); t1 = time.perf_counter()
     est_full = (t1 - t0) * (y.shape[0] / float(ysub.shape[0]))
     nq = nprobe if est_full <= 2.5 * target_seconds else max(512, int(nprobe * 2.5 * target_seconds / est_full))
     x = queries_dev[:nq].float().cpu().numpy()
-    t0 = time.perf_counter(); D, I = oracle.knn_faiss_blas(0, x, y, k); t1 = time.perf_counter()
-    return {"value": nq / (t1 - t0), "unit": "queries/s", "cores": cores, "kind": "port",
+    t0 = time.perf_counter(); D, I = oracle.knn_faiss_blas(metric, x, y, k); t1 = time.perf_counter()
+    return {"value": nq / (t1 - t0), "unit": "queries/s", "cores": cores, "kind": "port", "faiss": faiss_version,
             "sample": "%d of %d queries x full %dx%d corpus, fp32 host-BLAS sgemm 4096x1024 blocks + heap"
                       % (nq, queries_dev.shape[0], y.shape[0], y.shape[1])}, I
 
 
 def fingerprint_workload(args, dev, local_rank):
-    """retrieve/retrieve_faiss.py:62-74 as the reference runs it: L2, k = 20, d = 2048 sparse signed counts,
-    the training set searching itself (:114-115).  Secondary line, printed for DESIGN.md."""
+    """retrieve/retrieve_faiss.py:62-74 as the reference runs it: IndexFlatL2, k = 20, d = 2048 sparse signed counts
+    (reaction difference fingerprints, :18-27), the training set searching itself (:114-115).  One step = the whole
+    self-search (680,000 queries in batches of 65,536 = 11 scan launches).  Not the headline metric: a second line with
+    its own roofline (same kernel, K = 2048 -> 32 K-steps per tile) and CPU baseline, recorded under profiles/."""
     import torch
     import textreact_amd.faiss_compat as faiss
     n = args.n_corpus if args.n_corpus != N_CORPUS else 680_000     # ~ USPTO-condition train size
     g = torch.Generator(device=dev); g.manual_seed(1)
-    mask = torch.rand((n, 2048), generator=g, device=dev) < 0.02
-    vals = torch.randint(-10, 11, (n, 2048), generator=g, device=dev)
-    y = (mask * vals).to(torch.bfloat16)
+    y = torch.empty((n, 2048), dtype=torch.bfloat16, device=dev)
+    for r0 in range(0, n, 65536):                                   # blockwise: the int64 temporaries of the whole set are 11 GB
+        m = min(65536, n - r0)
+        mask = torch.rand((m, 2048), generator=g, device=dev) < 0.02
+        vals = torch.randint(-10, 11, (m, 2048), generator=g, device=dev)
+        y[r0:r0 + m] = (mask * vals).to(torch.bfloat16)
     del mask, vals
     idx = faiss.IndexFlatL2(2048, device=local_rank)
     idx.set_timing(True)
     idx.add(y)
+    for _ in range(args.warmup):
+        idx.search(y[:65536], 20)
     torch.cuda.synchronize()
+    scan_ms, launches = 0.0, 0
     t0 = time.perf_counter()
-    D, I = idx.search(y, 20)
+    for _ in range(max(1, min(args.steps, 3))):
+        D, I = idx.search(y, 20)
+        st = idx.last_stats()
+        scan_ms += st["scan_ms"]; launches += st["scan_launches"]
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    st = idx.last_stats()
+    steps = max(1, min(args.steps, 3))
     ok = bool((I[:, 0] == torch.arange(n, device=dev)).float().mean() > 0.99) and bool((D[:, 0] == 0).all())
-    print(json.dumps({"metric": "train self-search, IndexFlatL2 k=20 (reference workload)", "value": n / (t1 - t0),
-                      "unit": "queries/s", "seconds": t1 - t0, "n": n, "d": 2048, "k": 20, "scan_ms": st["scan_ms"],
-                      "exact_class": st["exact_class"], "uncertified": st["n_uncertified"], "self_is_first": ok,
-                      "tflops": 2.0 * n * n * 2048 / (st["scan_ms"] * 1e-3) / 1e12 if st["scan_ms"] else None}))
+    flops_step = 2.0 * n * n * 2048
+    mean_launch_ms = scan_ms / max(launches, 1)
+    achieved = flops_step * steps / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else 0.0
+    line = {"metric": "queries/sec, train self-search IndexFlatL2 k=20 over %dx2048 integer fingerprints (the reference's own workload)" % n,
+            "value": n * steps / (t1 - t0), "unit": "queries/s", "n_gpus": 1, "steps": steps, "warmup": args.warmup,
+            "ms_per_step": (t1 - t0) / steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "exact L2 top-20, %dx2048 sparse signed-count fingerprints (2 %% dense, |v| <= 10), the set searching itself"
+                                   % n, "corpus_rows": n, "dim": 2048, "queries": n, "k": 20, "exact_class": st["exact_class"],
+                       "uncertified_queries_per_step": st["n_uncertified"], "self_is_first": ok,
+                       "scan_launches_per_step": launches // steps},
+            "roofline": {"bound": "mfma", "kernel": "knn_scan_kernel", "achieved": achieved, "peak": PEAK_BF16_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None, "launch_ms": mean_launch_ms,
+                         "flops_per_launch": flops_step * steps / max(launches, 1)}}
+    if not args.no_cpu_baseline:
+        base, I_cpu = cpu_baseline(y, y, 20, metric=1)
+        import numpy as np
+        base["index_agreement_with_gpu"] = float((I[: I_cpu.shape[0]].cpu().numpy() == I_cpu).mean())
+        line["cpu_baseline"] = base
+    else:
+        line["cpu_baseline"] = None
+    print(json.dumps(line))
 
 
 def main():

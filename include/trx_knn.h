@@ -12,9 +12,13 @@
  * (streams travel as void*).  Functions return 0 on success or a negative TRX_E* code and never
  * throw; trx_last_error() gives the message for the calling thread.
  *
- * Threading: thread-compatible -- one index per thread at a time.  Calls block until the result
- * is complete unless a *_device variant is given a stream, in which case work is enqueued on that
- * stream and the outputs are valid once the stream reaches that point.
+ * Threading: thread-compatible -- one index per thread at a time.  EVERY call blocks the host until
+ * its result is complete.  The *_device variants take their inputs and outputs in device memory and
+ * run their kernels on the caller's `stream` (so they order against the caller's other work on that
+ * stream), but they are not asynchronous: trx_index_add_device synchronises the stream before it
+ * returns (the caller may free x), and a search synchronises it once per batch of 65,536 queries to
+ * read back how many queries failed the exactness certificate (csrc/knn_api.hip: search_batch).  On
+ * return the outputs are final; no further stream synchronisation is needed to read them.
  *
  * Results (both metrics): neighbours are the k best by the total order
  *   (score best-first, then id ascending), score = fp64 fma chain over the d components,
@@ -55,7 +59,8 @@ int trx_index_create(int d, int metric, int device, trx_index** out);
  * each) from HOST memory; the caller keeps ownership of x.  Ids are assigned sequentially. */
 int trx_index_add(trx_index* idx, const void* x, int64_t n, int dtype);
 
-/* Same, x already in DEVICE memory of the index's device; enqueued on `stream` (hipStream_t). */
+/* Same, x already in DEVICE memory of the index's device; runs on `stream` (hipStream_t) and
+ * synchronises it before returning. */
 int trx_index_add_device(trx_index* idx, const void* x, int64_t n, int dtype, void* stream);
 
 /* index.ntotal */
@@ -75,8 +80,9 @@ void trx_index_destroy(trx_index* idx);
 int trx_index_search(trx_index* idx, const void* q, int64_t nq, int dtype, int k, float* D,
                      int64_t* I);
 
-/* Same with q, D, I in DEVICE memory; enqueued on `stream`.  This is the form bench.py times
- * (inputs resident in HBM) and the one the row-sharded multi-GPU path uses. */
+/* Same with q, D, I in DEVICE memory; runs on `stream`, blocks until D and I are final (see
+ * Threading above).  This is the form bench.py times (inputs resident in HBM) and the one the
+ * row-sharded multi-GPU path uses. */
 int trx_index_search_device(trx_index* idx, const void* q, int64_t nq, int dtype, int k, float* D,
                             int64_t* I, void* stream);
 

@@ -254,7 +254,7 @@ def test_c1_full_size_properties():
         idx.add(y)
         D, I = idx.search(x, k)
         st = idx.last_stats()
-        assert st["n_uncertified"] < nq // 100
+        assert st["n_uncertified"] == 0, st        # every query certified exact by the fast path on the benchmark inputs
         Dh, Ih = D.cpu().numpy(), I.cpu().numpy()
         assert (Ih >= 0).all() and (Ih < n).all()
         assert all(len(set(r)) == k for r in Ih[:2000].tolist())                       # no duplicates
@@ -362,3 +362,58 @@ def test_multi_rank_sharded_search_on_one_gpu(world):
             D, I = ret[r][metric]
             assert np.array_equal(I, Ir), (metric, r)
             assert np.array_equal(D.view(np.uint32), Dr.view(np.uint32)), (metric, r)
+
+
+# ---- the literal FAISS restatement (and FAISS itself when a box has it) on Gaussian C0 -----------------------------
+def _audit_near_ties(metric, x, y, I_hip, I_ref, what):
+    """Every position where the HIP result and an fp32-accumulating reference differ must be a provable near-tie:
+    the two rows' canonical fp64 scores differ by no more than fp32 rounding of the accumulation can explain
+    (the same relation tests/test_oracle.py::test_gaussian_differences_are_provable_near_ties proves CPU-side)."""
+    from oracle import flat_knn as oracle
+    bad = np.argwhere(I_hip != I_ref)
+    if bad.size:
+        Sh = oracle.scores_at(metric, x, y, I_hip)
+        Sr = oracle.scores_at(metric, x, y, I_ref)
+        for q, t in bad:
+            assert abs(Sh[q, t] - Sr[q, t]) <= 64 * np.finfo(np.float32).eps * max(1.0, abs(Sr[q, t])), (what, q, t)
+        # and the two answers are the same SET except where the k-th and (k+1)-th straddle such a tie
+        assert bad.shape[0] <= I_ref.size // 200, (what, bad.shape[0])
+    return int(bad.shape[0])
+
+
+@pytest.mark.parametrize("metric", [IP, L2])
+def test_c0_gaussian_vs_literal_faiss_restatement(metric):
+    # BASELINE.json configs[0] (10k x 768 fp32, 1k queries, top-10) against the oracle's literal FAISS statement:
+    # 4096 x 1024 fp32 blocks (plain loops and host-BLAS sgemm), strict-admission (value, id) heap, heap_reorder
+    from oracle import flat_knn as oracle
+    x, y, k = gaussian(1000, 768, 5678), gaussian(10000, 768, 1234), 10
+    idx = _index(metric, 768)
+    idx.add(y)
+    D, I = idx.search(x, k)
+    for name, fn in (("knn_faiss", oracle.knn_faiss), ("knn_faiss_blas", oracle.knn_faiss_blas)):
+        Df, If = fn(metric, x, y, k)
+        _audit_near_ties(metric, x, y, I, If, name)
+        assert np.allclose(D, Df, rtol=1e-5, atol=1e-3)
+
+
+@pytest.mark.parametrize("metric", [IP, L2])
+def test_real_faiss_when_the_box_has_it(metric):
+    # SURVEY section 8c: FAISS is absent from the build container; if a GPU box ships it, it IS the reference
+    # (retrieve/retrieve_faiss.py:14,65-71) and this test pins the product to it; otherwise the skip says so.
+    faiss = pytest.importorskip("faiss", reason="faiss: unavailable on this box (parity stays pinned to the restatement only)")
+    print("faiss version", getattr(faiss, "__version__", "?"))
+    x, y, k = gaussian(1000, 768, 5678), gaussian(10000, 768, 1234), 10
+    ref = faiss.IndexFlatIP(768) if metric == IP else faiss.IndexFlatL2(768)
+    ref.add(y)
+    Df, If = ref.search(x, k)
+    idx = _index(metric, 768)
+    idx.add(y)
+    D, I = idx.search(x, k)
+    _audit_near_ties(metric, x, y, I, If, "faiss " + getattr(faiss, "__version__", "?"))
+    # integer fingerprints (the reference's real inputs): exact arithmetic on both sides -> identical, ties included (L2)
+    fy = reaction_fp_like(5000, 2048, 3); fx = fy[:200].copy()
+    ref = faiss.IndexFlatL2(2048); ref.add(fy)
+    Df, If = ref.search(fx, 20)
+    idx = _index(L2, 2048); idx.add(fy)
+    D, I = idx.search(fx, 20)
+    assert np.array_equal(I, If) and np.array_equal(D, Df)

@@ -14,6 +14,7 @@
 // spreads the 4 rows over the 4 quarters of a 256-byte bank row.
 #include "../../include/trx_nn.h"
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdint>
 
 namespace trxtn {
@@ -283,11 +284,15 @@ extern "C" int trx_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, 
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb;
     plan(M, N, K, &p.tn, &p.tk, &p.nsplit, &p.steps_per_split);
     p.ws_colsum = colsum_bf16 ? p.ws + (int64_t)p.nsplit * N * K : nullptr;
-    static bool attr = false;
-    if (!attr) {
+    // the attribute is per device: remember which devices of this process have it (bit per ordinal)
+    static std::atomic<unsigned long long> attr_devs{0ull};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return TRX_NN_EHIP;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(attr_devs.load(std::memory_order_acquire) & bit)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL) != hipSuccess)
             return TRX_NN_EHIP;
-        attr = true;
+        attr_devs.fetch_or(bit, std::memory_order_release);
     }
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(gemm_tn_kernel, dim3(p.tn * p.tk * p.nsplit), dim3(THREADS), LDS_TOTAL, st, p);

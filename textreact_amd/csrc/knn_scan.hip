@@ -37,6 +37,7 @@
 //   bootstrap launch (one tile per query tile, dense rebuild) seeds g_thr so the real scan starts
 //   warm and appends O(kprime log N) rows per query in total instead of per split.
 #include "knn_common.h"
+#include <atomic>
 #include <cstdlib>
 
 namespace trx {
@@ -418,12 +419,17 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
 
 template <bool L2, int AUXA, int AUXB, bool BOOT>
 static hipError_t launch_one_b(const ScanParams& p, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_scan_kernel<L2, AUXA, AUXB, BOOT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+    // the attribute is per device (the ABI takes a device ordinal): one bit per ordinal, per instantiation
+    static std::atomic<unsigned long long> attr_devs{0ull};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(attr_devs.load(std::memory_order_acquire) & bit)) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_scan_kernel<L2, AUXA, AUXB, BOOT>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_devs.fetch_or(bit, std::memory_order_release);
     }
     dim3 grid(p.bootstrap ? p.nqtiles : p.nqtiles * p.nsplits), block(SCAN_THREADS);
     hipLaunchKernelGGL((knn_scan_kernel<L2, AUXA, AUXB, BOOT>), grid, block, LDS_TOTAL, st, p);

@@ -16,6 +16,9 @@ the test supplies the oracle for both; the defaults are the HIP index and the HI
 from typing import Callable, Optional, Tuple
 
 
+MAX_SHARDS = 16   # nlists limit of trx_merge_topk_device (csrc/knn_api.hip)
+
+
 def shard_bounds(n_total: int, world_size: int, rank: int) -> Tuple[int, int]:
     """Contiguous, balanced row ranges: the first n_total % G shards get one extra row."""
     base, rem = divmod(int(n_total), int(world_size))
@@ -30,6 +33,9 @@ class ShardedFlatIndex:
         self.group = group
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        if self.world_size > MAX_SHARDS:
+            raise ValueError("ShardedFlatIndex: %d ranks, but trx_merge_topk_device merges at most %d lists "
+                             "(include/trx_knn.h); shard over the GPUs of one node" % (self.world_size, MAX_SHARDS))
         if local_index is None:
             from . import faiss_compat
             local_index = faiss_compat.IndexFlat(d, metric)
