@@ -68,13 +68,14 @@ struct trx_index {
     float maxabs = 0.f, maxnorm2 = 0.f;
     bool nonint = false;
     // workspaces
-    DevBuf w_stamp, w_stats, w_qg, w_qnorm2, w_cand, w_cnt, w_thr, w_scratch, w_flag, w_exact, w_io, w_tmp, w_gthr;
+    DevBuf w_stamp, w_stats, w_qg, w_qnorm2, w_cand, w_cnt, w_thr, w_flag, w_exact, w_io, w_tmp, w_gthr;
     trx_search_stats stats{};
     bool timing = false;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 
-    // at least two K-steps: the scan pipeline's prefetch distance is two steps
-    int Kp_for(int mode_) const { return std::max(2 * BK, round_up(mode_ == MODE_SPLIT ? 3 * (int64_t)d : d, BK)); }
+    // an even number of K-steps, at least 4: the scan kernel's loop handles two per iteration (LDS stage = K-step
+    // parity) and treats the first and the last pair of a tile differently
+    int Kp_for(int mode_) const { return std::max(4 * BK, round_up(mode_ == MODE_SPLIT ? 3 * (int64_t)d : d, 2 * BK)); }
 };
 
 static int set_device(const trx_index* idx) { HIPCHK(hipSetDevice(idx->device)); return TRX_OK; }
@@ -158,7 +159,7 @@ void trx_index_destroy(trx_index* idx) {
     if (idx->cnorm2) (void)hipFree(idx->cnorm2);
     if (idx->cbias) (void)hipFree(idx->cbias);
     DevBuf* bufs[] = {&idx->w_stamp, &idx->w_stats, &idx->w_qg, &idx->w_qnorm2, &idx->w_cand, &idx->w_cnt, &idx->w_thr,
-                      &idx->w_scratch, &idx->w_flag, &idx->w_exact, &idx->w_io, &idx->w_tmp, &idx->w_gthr};
+                      &idx->w_flag, &idx->w_exact, &idx->w_io, &idx->w_tmp, &idx->w_gthr};
     for (DevBuf* b : bufs) b->release();
     for (auto& e : idx->ev) if (e) (void)hipEventDestroy(e);
     delete idx;
@@ -271,24 +272,24 @@ static int search_batch(trx_index* idx, const void* q, int64_t nq, int is_bf, in
     const int nqt = (int)(q_pad / TILE_N);
     const int64_t n_pad = round_up64(idx->n, TILE_M);
     const int ntiles = (int)(n_pad / TILE_M);
-    // one workgroup per CU when the query tiles alone fill the chip (measured best on C1: fewer
-    // lists, one cold start per query tile); otherwise split the corpus to reach ~256 workgroups
-    int nsplits = (256 + nqt - 1) / nqt;
+    // Corpus splits per query tile.  At least enough workgroups to fill the 256 CUs, and at least 4: with the
+    // XCD-contiguous block order of the scan kernel the 32 workgroups that share an XCD are then 8 query tiles x 4
+    // splits, so the 8 query tiles (3 MB at K = 768) stay resident in the XCD's 4 MiB L2 while 4 corpus streams
+    // pass through it, each read by 8 workgroups (tools/scan_lab.hip: fill path 45 -> 67 GB/s per CU).
+    int nsplits = std::max(4, (256 + nqt - 1) / nqt);
     nsplits = std::max(1, std::min(nsplits, std::min(ntiles, 256)));
     { const char* e = getenv("TRX_NSPLITS"); if (e) nsplits = std::max(1, std::min(atoi(e), ntiles)); }
     int tps = (ntiles + nsplits - 1) / nsplits;
     nsplits = (ntiles + tps - 1) / tps;  // drop empty trailing splits
     const int kprime = k <= 12 ? 16 : 32;
-    const int csoft = kprime + (CAP - kprime) / 2;
-    const int nwg = nqt * nsplits;
+    const int nlists = nsplits * LISTS_PER_SPLIT;
 
     int rc;
     if ((rc = idx->w_qg.reserve((size_t)q_pad * Kp * sizeof(bf16_t)))) return rc;
     if ((rc = idx->w_qnorm2.reserve((size_t)q_pad * sizeof(float)))) return rc;
-    if ((rc = idx->w_cand.reserve((size_t)q_pad * nsplits * CAP * sizeof(u64)))) return rc;
-    if ((rc = idx->w_cnt.reserve((size_t)q_pad * nsplits * sizeof(u32)))) return rc;
-    if ((rc = idx->w_thr.reserve((size_t)q_pad * nsplits * sizeof(u64)))) return rc;
-    if ((rc = idx->w_scratch.reserve((size_t)std::max(nwg, nqt) * TILE_N * SPILL * sizeof(u64)))) return rc;
+    if ((rc = idx->w_cand.reserve((size_t)q_pad * nlists * CAPW * sizeof(u64)))) return rc;
+    if ((rc = idx->w_cnt.reserve((size_t)q_pad * nlists * sizeof(u32)))) return rc;
+    if ((rc = idx->w_thr.reserve((size_t)q_pad * nlists * sizeof(u64)))) return rc;
     if ((rc = idx->w_flag.reserve((size_t)(nq + 4) * sizeof(int)))) return rc;
     if ((rc = idx->w_gthr.reserve((size_t)q_pad * sizeof(u32)))) return rc;
 
@@ -304,42 +305,54 @@ static int search_batch(trx_index* idx, const void* q, int64_t nq, int is_bf, in
     ScanParams sp{};
     sp.corpus = idx->Cg; sp.queries = (const bf16_t*)idx->w_qg.p; sp.cbias = idx->cbias;
     sp.Kp = Kp; sp.n_valid = (int)idx->n; sp.ntiles = ntiles; sp.tiles_per_split = tps; sp.nsplits = nsplits;
-    sp.nqtiles = nqt; sp.kprime = kprime; sp.csoft = csoft;
+    sp.nqtiles = nqt; sp.kprime = kprime;
     sp.cand = (u64*)idx->w_cand.p; sp.cand_cnt = (u32*)idx->w_cnt.p; sp.cand_thr = (u64*)idx->w_thr.p;
-    sp.scratch = idx->w_scratch.p;
     { const char* dbg = getenv("TRX_SCAN_DEBUG"); sp.debug = dbg ? atoi(dbg) : 0; }
     sp.stamp_out = nullptr;
 #ifdef TRX_STAMP_BUILD
-    if ((rc = idx->w_stamp.reserve((size_t)nwg * 8 * 4 * sizeof(unsigned long long)))) return rc;
+    if ((rc = idx->w_stamp.reserve((size_t)nqt * nsplits * 8 * 4 * sizeof(unsigned long long)))) return rc;
     sp.stamp_out = (unsigned long long*)idx->w_stamp.p;
 #endif
     sp.g_thr = (u32*)idx->w_gthr.p;
     HIPCHK(hipMemsetAsync(sp.g_thr, 0, (size_t)q_pad * sizeof(u32), st));
-    const bool boot = !getenv("TRX_NO_BOOT") && ntiles > 1;
-    if (boot) {  // seed the shared thresholds: one tile per query tile
+    // seed the shared thresholds: every query tile scans a few tiles (selection bookkeeping only, no lists)
+    const bool boot = !getenv("TRX_NO_BOOT") && ntiles > 2;
+    if (boot) {
         ScanParams bp = sp;
-        bp.bootstrap = 1; bp.have_boot = 0; bp.nsplits = 1; bp.tiles_per_split = 1;
+        bp.bootstrap = 1; bp.nsplits = 1; bp.tiles_per_split = ntiles;
+        bp.boot_tiles = getenv("TRX_BOOT_TILES") ? std::max(2, atoi(getenv("TRX_BOOT_TILES"))) : 16;
         HIPCHK(launch_scan(bp, idx->metric, st));
     }
-    sp.bootstrap = 0; sp.have_boot = boot ? 1 : 0;
+    sp.bootstrap = 0; sp.boot_tiles = 0;
     if (idx->timing) HIPCHK(hipEventRecord(idx->ev[0], st));
     HIPCHK(launch_scan(sp, idx->metric, st));
     if (idx->timing) HIPCHK(hipEventRecord(idx->ev[1], st));
 #ifdef TRX_STAMP_BUILD
     {
+        const int nwg = nqt * nsplits;
         std::vector<unsigned long long> h((size_t)nwg * 32);
         HIPCHK(hipMemcpyAsync(h.data(), sp.stamp_out, h.size() * 8, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
-        double sum[4] = {0, 0, 0, 0};
-        for (size_t i = 0; i < h.size(); ++i) sum[i & 3] += (double)h[i];
-        const double nw = (double)nwg * 8, tiles = sum[3] / nw;
-        fprintf(stderr, "[stamp] per wave: %.0f tiles; filter %.0f cycles/tile; compaction section %.0f cycles/tile; %.2f lists compacted per tile\n",
-                tiles, sum[0] / nw / tiles, sum[1] / nw / tiles, sum[2] / nw / tiles);
+        double cyc = 0, slow = 0, comp = 0, cols = 0, tiles = 0, sa = 0, sb = 0, sc = 0, sd = 0;
+        for (size_t i = 0; i < h.size(); i += 4) {
+            cyc += (double)(h[i] & 0xfffffffffull); sd += (double)(h[i] >> 36); slow += (double)(h[i + 1] & 0xfffffull); sa += (double)(h[i + 1] >> 20); comp += (double)(h[i + 2] & 0xffffull); cols += (double)((h[i + 2] >> 16) & 0xfffffull); sc += (double)(h[i + 2] >> 36);
+            tiles += (double)(h[i + 3] & 0xfffffull); sb += (double)(h[i + 3] >> 20);
+        }
+        // appended rows: the final list counts (exact when nothing was compacted)
+        std::vector<u32> hc((size_t)q_pad * nlists);
+        HIPCHK(hipMemcpyAsync(hc.data(), sp.cand_cnt, hc.size() * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        double app = 0; u32 mx = 0;
+        for (u32 c : hc) { app += c; mx = std::max(mx, c); }
+        fprintf(stderr, "[stamp] work-mask build %.0f cycles, tracking + refresh %.0f cycles per wave and tile; per group: fetch %.0f, test + append %.0f cycles\n", sa / tiles, sb / tiles, sc / std::max(cols, 1.0), sd / std::max(cols, 1.0));
+        fprintf(stderr, "[stamp] per wave and tile: bookkeeping %.0f cycles, slow path entered %.2f times, %.2f columns, %.4f compactions; "
+                        "listed rows %.2f per wave and tile (%.0f per query, fullest list %u of %d)\n",
+                cyc / tiles, slow / tiles, cols / tiles, comp / tiles, app / tiles, app / (double)q_pad, mx, CAPW);
     }
 #endif
 
     SelectParams se{};
-    se.cand = sp.cand; se.cand_cnt = sp.cand_cnt; se.cand_thr = sp.cand_thr; se.nsplits = nsplits;
+    se.cand = sp.cand; se.cand_cnt = sp.cand_cnt; se.cand_thr = sp.cand_thr; se.nlists = nlists;
     if (idx->mode == MODE_SPLIT) { se.corpus_orig = idx->Co; se.ld_c = d; se.corpus_is_bf16 = 0; }
     else { se.corpus_orig = idx->Cg; se.ld_c = Kp; se.corpus_is_bf16 = 1; }
     se.query_orig = q; se.ld_q = d; se.query_is_bf16 = is_bf;
@@ -360,7 +373,7 @@ static int search_batch(trx_index* idx, const void* q, int64_t nq, int is_bf, in
     idx->stats.scan_launches += 1;
     idx->stats.n_splits = nsplits;
     idx->stats.n_uncertified += nf;
-    if (nf > 0) {
+    if (nf > 0 && sp.debug == 0) {      // (timing-only debug modes of the scan kernel produce wrong lists: no fall-back then)
         const int64_t per = std::max<int64_t>(1, ((int64_t)1 << 29) / std::max<int64_t>(1, idx->n * 8));
         if ((rc = idx->w_exact.reserve((size_t)std::min<int64_t>(per, nf) * idx->n * sizeof(double)))) return rc;
         for (int f0 = 0; f0 < nf; f0 += (int)per) {

@@ -15,9 +15,9 @@ constexpr int TILE_M = 256;     // corpus rows per tile (MFMA M side)
 constexpr int TILE_N = 256;     // queries per workgroup (MFMA N side)
 constexpr int BK = 64;          // K-step staged through LDS
 constexpr int SCAN_THREADS = 512;
-constexpr int CAP = 64;         // candidate slots per (query, split): one per lane of a wave
+constexpr int CAPW = 256;       // candidate slots of one list; a list belongs to one (query, corpus split, wave row)
+constexpr int LISTS_PER_SPLIT = 2;  // the two wave rows of the scan workgroup (corpus rows 0-127 / 128-255 of a tile)
 constexpr int KEEP = 32;        // entries the select kernel re-scores exactly (>= TRX_FAST_MAX_K)
-constexpr int SPILL = TILE_M;   // spill slots per query per workgroup (a tile adds at most TILE_M rows)
 
 // ---- bf16 helpers ------------------------------------------------------------------------
 __device__ __forceinline__ float bf16_to_f32(bf16_t h) { return __uint_as_float(((u32)h) << 16); }
@@ -105,34 +105,32 @@ __device__ __forceinline__ void wave_sort_pairs(u64& skey, u32& id, int lane) {
 
 // ---- parameters ----------------------------------------------------------------------------
 struct ScanParams {
-    const bf16_t* corpus;    // [n_pad][Kp] bf16, n_pad multiple of TILE_M, pad rows zero
+    const bf16_t* corpus;    // [n_pad + TILE_M][Kp] bf16, n_pad multiple of TILE_M, pad rows zero
     const bf16_t* queries;   // [q_pad][Kp] bf16, q_pad multiple of TILE_N, pad rows zero
-    const float* cbias;      // L2: -|y|^2 per corpus row (pad rows -inf); IP: unused
-    int Kp;                  // padded contraction length, multiple of BK
+    const float* cbias;      // L2: -|y|^2 per corpus row (pad rows -inf), [n_pad + TILE_M]; IP: unused
+    int Kp;                  // padded contraction length, multiple of 2 * BK
     int n_valid;             // corpus rows that exist
     int ntiles;              // n_pad / TILE_M
     int tiles_per_split;
     int nsplits;
     int nqtiles;             // q_pad / TILE_N
-    int kprime;              // entries kept per (query, split) at a compaction (<= KEEP)
-    int csoft;               // compaction trigger: count above this after a tile
-    u64* cand;               // [q_pad][nsplits][CAP] packed (key,id)
-    u32* cand_cnt;           // [q_pad][nsplits]
-    u64* cand_thr;           // [q_pad][nsplits] every unlisted row of the split has comp <= this
-    void* scratch;           // [gridDim.x][TILE_N][SPILL] u64 spill slots (rows that do not fit a list)
-    u32* g_thr;              // [q_pad] ordkey of a key no top-kprime row can be below; shared by all
+    int kprime;              // 16 or 32: rows behind a query's threshold (8 per tracked maximum of a lane)
+    u64* cand;               // [q_pad][nsplits][2][CAPW] packed (key,id), append order
+    u32* cand_cnt;           // [q_pad][nsplits][2]
+    u64* cand_thr;           // [q_pad][nsplits][2] every unlisted row of the list's rows has comp <= this
+    u32* g_thr;              // [q_pad] ordkey of a key that at least kprime corpus rows reach; shared by all
                              // workgroups of a query (atomicMax, monotone; a stale read is only looser)
-    int bootstrap;           // 1: threshold bootstrap launch (one tile per query tile, publish g_thr only)
-    int have_boot;           // 1: g_thr was seeded by a bootstrap launch
+    int bootstrap;           // 1: threshold bootstrap launch (boot_tiles tiles per query tile, publish g_thr only)
+    int boot_tiles;
     int debug;               // timing-only diagnostics (TRX_SCAN_DEBUG), 0 in production
-    unsigned long long* stamp_out;  // diagnostic build (-DTRX_STAMP_BUILD) only: [grid][8 waves][4] cycle sums
+    unsigned long long* stamp_out;  // diagnostic build (-DTRX_STAMP_BUILD) only
 };
 
 struct SelectParams {
     const u64* cand;
     const u32* cand_cnt;
     const u64* cand_thr;
-    int nsplits;
+    int nlists;               // lists per query = corpus splits x LISTS_PER_SPLIT, CAPW slots each
     const void* corpus_orig;  // exact values: bf16 [.. ][ld_c] or f32 [..][ld_c]
     int64_t ld_c;             // row stride in elements
     const void* query_orig;   // exact query values, bf16 or f32, row stride ld_q

@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void build_operand_kernel(const void* x, int64
 __global__ void fill_bias_kernel(const float* norm2, int64_t n, int64_t n_pad, float* bias) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_pad) return;
-    bias[j] = j < n ? -norm2[j] : -__builtin_inff();
+    bias[j] = j < n ? -0.5f * norm2[j] : -__builtin_inff();     // accumulator start of the L2 scan: x.y - |y|^2 / 2 = key / 2
 }
 
 // widen bf16 rows to f32 rows (plain -> split transition keeps exact values as f32)

@@ -4,38 +4,55 @@
 // Replaces the inside of faiss IndexFlat::search called at retrieve/retrieve_faiss.py:71 (the
 // sgemm blocks + per-query heap of SURVEY.md section 2b rows N2/N3).
 //
-// Shape of the work
+// Shape of the work (round 2; the structure was chosen in tools/scan_lab.hip)
 //   workgroup = 512 threads = 8 waves, owns ONE tile of 256 queries and walks a contiguous range
-//   ("split") of 256-row corpus tiles.  Operands are swapped with respect to the usual GEMM
-//   naming: A = corpus rows (MFMA M side), B = queries (MFMA N side), so in the accumulator the
-//   QUERY is on the lane (col = lane & 15) and a lane's registers are consecutive corpus rows:
-//   the per-query running maximum and threshold test are lane-local, no cross-lane traffic.
-//   waves are laid out 2 (M) x 4 (N): each wave owns 128 corpus rows x 64 queries
-//   = 8 x 4 tiles of v_mfma_f32_16x16x32_bf16 = 128 accumulator registers per lane.
+//   ("split") of 256-row corpus tiles.  Operands are swapped with respect to the usual GEMM naming:
+//   A = corpus rows (MFMA M side), B = queries (MFMA N side), so in the accumulator the QUERY is on
+//   the lane (col = lane & 15) and a lane's registers are consecutive corpus rows: everything the
+//   selection does per query is lane-local.  Waves are laid out 2 (M) x 4 (N): a wave owns 128 corpus
+//   rows x 64 queries = 8 x 4 tiles of v_mfma_f32_16x16x32_bf16 = 128 accumulator registers.
 //
-// LDS (one dynamic array, 16-byte aligned carve, 136,208 B -> one workgroup per CU)
-//   A[2][256 rows][128 B] , B[2][256 rows][128 B] : K-step of 64 bf16 per row, double buffered,
-//   filled by LDS-DMA (global_load_lds_dwordx4, no staging registers); 16-byte chunk c of row r
-//   sits at slot (c ^ ((r >> 1) & 7)) -- the permutation is applied to the per-lane SOURCE address
-//   -- which makes the ds_read_b128 fragment reads conflict-free (bank analysis in DESIGN.md).
-//   thr_comp[256] u64, thr_key[256] f32, cnt[256] u32, ovf[256] u32, flags.
+// Two-group ping-pong.  Waves 0-3 (group 0, corpus rows 0-127 of every tile) and waves 4-7 (group 1,
+//   rows 128-255) share the four SIMDs pairwise and run one barrier interval apart: while one group
+//   issues the 32 MFMAs of a 32-deep half K-step, the other reads its 12 fragments of the next half
+//   and issues its share of the LDS-DMA.  Phase (K-step u, half kk):
+//     interval 4u   : G0 L(u,0) [DMA B rows 0-127 of K-step u+1]     G1 M(u-1,1)
+//     interval 4u+1 : G0 M(u,0)                                      G1 L(u,0) [DMA B rows 128-255 of u+1]
+//     interval 4u+2 : G0 L(u,1) [DMA A rows 128-255 of u+1]          G1 M(u,0)
+//     interval 4u+3 : G0 M(u,1)                                      G1 L(u,1) [DMA A rows 0-127 of u+2]
+//   K-step u lives in LDS stage u & 1 (A 32 KiB + B 32 KiB per stage).  Write-after-read: every fragment
+//   read is retired (lgkmcnt(0)) before the barrier that ends its interval, and each DMA is issued at
+//   least one barrier after the last read of the half-tile it overwrites (A rows 0-127 are read by group
+//   0 only, last in interval 4u+2; everything else last in interval 4u+3).  Read-after-write: a wave
+//   waits vmcnt(4) at the end of every load phase -- all but the four pieces it has just issued, i.e.
+//   the pieces of its previous load phase, two intervals old -- and every half-tile has a barrier
+//   between that wait and its first read.  The K-step sequence runs on across tiles.
 //
-// Selection (per query, per split), exact with respect to the approximate key:
-//   cand[...][64] is an append buffer.  A row is appended when comp(key, id) > thr_comp, where
-//   thr is the kprime-th best packed (key,id) at the last compaction (0 = none yet).  When a
-//   buffer passes `csoft` entries one wave sorts its 64 slots (bitonic, one slot per lane), keeps
-//   the best kprime and raises thr.  Thresholds only tighten at compactions, so a query compacts
-//   O(log tiles) times.  If a single tile overflows a buffer (always true for the first tile of a
-//   split, rare afterwards) the workgroup dumps the 256 x 256 key tile to an L2-resident scratch
-//   and the affected queries are rebuilt from {older entries} U {all 256 keys of the tile}: no
-//   row is ever lost, whatever the data order.  Result: the list holds the top-kprime of the
-//   split by (key desc, id asc) plus stale extras, and every unlisted row has comp <= thr.
-//   Thresholds are shared across the splits of a query through g_thr[q] (atomicMax of the key of
-//   a split's kprime-th best): a row below ANY split's kprime-th best has kprime better rows in
-//   that split's list, so no split needs to keep it.  Reads of g_thr may be stale (cross-XCD L2s
-//   are not coherent): a stale value is only a looser threshold, never a wrong one.  A tiny
-//   bootstrap launch (one tile per query tile, dense rebuild) seeds g_thr so the real scan starts
-//   warm and appends O(kprime log N) rows per query in total instead of per split.
+// LDS image: 16-byte chunk c of row r sits at slot c ^ ((r >> 1) & 7) (permutation on the per-lane DMA
+//   SOURCE address), which makes the ds_read_b128 fragment reads conflict-free.
+//
+// Selection (exact with respect to the approximate key; nothing in it needs a workgroup barrier):
+//   * filter: a lane's 32 keys of a tile and query are reduced to their maximum by v_max3 issued in
+//     the gaps of the tile's last 32 MFMAs; only if some lane's maximum reaches the query's threshold
+//     does the wave look at individual keys (slow path, in the NEXT load phase, under the partner's
+//     MFMAs): rows with key >= threshold are appended to the list of (query, split, wave row) --
+//     CAPW slots in HBM, slot counter in LDS, nobody else writes that list.
+//   * threshold: each lane keeps the J best tile maxima it has seen for each of its 4 queries
+//     (J = kprime / 8).  They are maxima of J different tiles, and the 8 lanes of a query (4 row
+//     quads x 2 wave rows) see disjoint rows: the minimum over those 8 lanes of the J-th best is a
+//     key that at least 8 J = kprime corpus rows reach, so a row below it is outside the top kprime.
+//     Refreshed once per tile (2 cross-lane steps + the partner wave's value through LDS, which may
+//     be stale: stale = lower = still valid), shared between the splits of a query through g_thr
+//     (atomicMax; a one-piece LDS-DMA brings the other splits' values back every 8 tiles) and seeded
+//     by a bootstrap launch of this kernel over a few tiles.
+//   * a list that fills up (tie-heavy or adversarially ordered corpora only) is compacted by its own
+//     wave to its kprime best (key desc, id asc) and from then on also filters by that packed
+//     (key, id): no row is ever lost, whatever the data order.
+//   L2: the accumulators of a tile start from -|y|^2 / 2 of their corpus rows (C operand of the tile's first MFMAs, read
+//   from a per-tile LDS copy), so an accumulator is h = x.y - |y|^2 / 2 = key / 2 and the kernel filters and tracks in
+//   h; packed values and g_thr carry key = 2 h (exact).
+//   At the end every list publishes its count and the bound "every row of mine that is not listed
+//   has packed (key, id) <= bound"; knn_select.hip merges the lists of a query.
 #include "knn_common.h"
 #include <atomic>
 #include <cstdlib>
@@ -44,26 +61,44 @@ namespace trx {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(3))) char lds_char;
+typedef __attribute__((address_space(1))) const void gbl_void;
 
 constexpr int LDS_A0 = 0;
-constexpr int LDS_B0 = 2 * TILE_M * 128;                  // 65536
-constexpr int LDS_THRC = LDS_B0 + 2 * TILE_N * 128;       // 131072
-constexpr int LDS_THRK = LDS_THRC + TILE_N * 8;
-constexpr int LDS_CNT = LDS_THRK + TILE_N * 4;
-constexpr int LDS_OVF = LDS_CNT + TILE_N * 4;
-constexpr int LDS_FLAGS = LDS_OVF + TILE_N * 4;
-constexpr int LDS_WL = LDS_FLAGS + 16;     // flags[2]: one word per tile parity; then the compaction work list
-constexpr int LDS_TOTAL = LDS_WL + 16 + TILE_N * 4;   // count + up to 256 query numbers
+constexpr int LDS_B0 = 2 * TILE_M * 128;         // 65536
+constexpr int S_THRW = LDS_B0 + 2 * TILE_N * 128;  // 131072: f32 [2 wave rows][256 queries] own threshold of a wave row
+constexpr int S_GTHR = S_THRW + 2 * TILE_N * 4;  // u32 [256] copy of g_thr
+constexpr int S_CNT = S_GTHR + TILE_N * 4;       // u32 [2][256] list slot counters
+constexpr int S_THRC = S_CNT + 2 * TILE_N * 4;   // u64 [2][256] packed (key,id) floor of a compacted list (0 = none)
+constexpr int S_BIAS = S_THRC + 2 * TILE_N * 8;  // f32 [2 tile parities][256 rows]  (L2)
+constexpr int LDS_TOTAL = S_BIAS + 2 * TILE_M * 4;   // 142,336 B -> one workgroup per CU
+// ds instruction offsets are 16-bit: the selection state is addressed relative to S_THRW (4-byte arrays) / S_THRC
+constexpr int R_THRW = 0, R_GTHR = S_GTHR - S_THRW, R_CNT = S_CNT - S_THRW, R_THRC = 0;
 
-constexpr u32 FLAG_COMPACT = 1u;
-constexpr u32 FLAG_DENSE = 2u;
-
-__device__ __forceinline__ u64 ld_u64_l2(const u64* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// LDS accesses of the selection state go through asm: a C++ access to the array the LDS-DMA writes makes
+// hipcc drain vmcnt to 0 (cdna_hip_programming.md section 5, "Three .s-level traps").  Addresses are
+// LDS byte addresses (lds0 + offset).  Each read retires itself.
+// The byte offset is an instruction immediate (OFF < 65536), so a lane needs one base register per array shape,
+// not one address register per access (hipcc hoists those out of the tile loop and spills them).
+template <int OFF> __device__ __forceinline__ u32 lds_ld32(u32 a) {
+    u32 v;
+    asm volatile("ds_read_b32 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(a), "n"(OFF) : "memory");
+    return v;
 }
-__device__ __forceinline__ float ld_f32_l2(const float* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+template <int OFF> __device__ __forceinline__ u64 lds_ld64(u32 a) {
+    u64 v;
+    asm volatile("ds_read_b64 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(a), "n"(OFF) : "memory");
+    return v;
 }
+template <int OFF> __device__ __forceinline__ void lds_st32(u32 a, u32 v) { asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(a), "v"(v), "n"(OFF) : "memory"); }
+template <int OFF> __device__ __forceinline__ void lds_st64(u32 a, u64 v) { asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(a), "v"(v), "n"(OFF) : "memory"); }
+template <int OFF> __device__ __forceinline__ u32 lds_inc(u32 a) {
+    u32 r, one = 1u;
+    asm volatile("ds_add_rtn_u32 %0, %1, %2 offset:%3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r) : "v"(a), "v"(one), "n"(OFF) : "memory");
+    return r;
+}
+__device__ __forceinline__ u64 ld_u64_l2(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // XCD-contiguous bijective remap of the block id (blocks b and b+8 share an XCD under the
 // observed round-robin placement; speed only, never correctness).
@@ -73,352 +108,563 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + (bid >> 3);
 }
 
-// BOOT only gives the threshold-bootstrap launch its own symbol, so that profiles list the two
-// launches separately (the main scan's average duration is the roofline number).
-template <bool L2, int AUXA, int AUXB, bool BOOT>
+template <int N> struct ic { static constexpr int value = N; };
+
+// lane id, recomputed where it is needed (volatile: hipcc would otherwise hoist everything derived from the lane id out
+// of the tile loop, keep it in registers the loop does not have, spill it, and reload it through the VMEM queue)
+__device__ __forceinline__ u32 lane_now() {
+    u32 l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
+__device__ __forceinline__ float max3f(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
+
+// A full list (CAPW entries, all written by this wave) is cut to its kprime best by (key desc, id asc).
+// Wave-wide; rare (see the header).  Returns the packed value in kprime-th place.
+__device__ __forceinline__ u64 compact_list(u64* list, int kprime, int lane) {
+    __builtin_amdgcn_s_waitcnt(0);     // this wave's own stores to the list have left
+    u64 e[CAPW / 64];
+#pragma unroll
+    for (int i = 0; i < CAPW / 64; ++i) e[i] = ld_u64_l2(list + lane + 64 * i);   // L2: never a stale L1 line of this CU
+    u64 out = 0ull, last = 0ull;
+    for (int t = 0; t < kprime; ++t) {
+        u64 m = e[0];
+#pragma unroll
+        for (int i = 1; i < CAPW / 64; ++i) m = e[i] > m ? e[i] : m;
+#pragma unroll
+        for (int s = 1; s < 64; s <<= 1) { const u64 o = shfl_xor_u64(m, s); m = o > m ? o : m; }
+        if (lane == t) out = m;
+        last = m;
+#pragma unroll
+        for (int i = 0; i < CAPW / 64; ++i) if (e[i] == m) e[i] = 0ull;     // packed values are unique (ids are)
+    }
+    if (lane < kprime) list[lane] = out;
+    return last;
+}
+
+// BOOT gives the threshold-bootstrap launch its own symbol, so that profiles list the two launches
+// separately (the main scan's average duration is the roofline number).
+template <bool L2, int J, bool BOOT>
 __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    u64* lds_thrc = reinterpret_cast<u64*>(smem + LDS_THRC);
-    float* lds_thrk = reinterpret_cast<float*>(smem + LDS_THRK);
-    u32* lds_cnt = reinterpret_cast<u32*>(smem + LDS_CNT);
-    u32* lds_ovf = reinterpret_cast<u32*>(smem + LDS_OVF);
-    u32* lds_flags = reinterpret_cast<u32*>(smem + LDS_FLAGS);
-    u32* lds_wlcnt = reinterpret_cast<u32*>(smem + LDS_WL);
-    u32* lds_wl = lds_wlcnt + 4;
+    const u32 lds0 = (u32)(uintptr_t)(lds_char*)smem;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wave_m = wave >> 2;  // 0..1 : corpus half of the tile
+    const int wave_m = wave >> 2;  // 0..1 : group = corpus half of the tile
     const int wave_n = wave & 3;   // 0..3 : 64-query slice
 
     const int v = xcd_remap(blockIdx.x, gridDim.x);
-    const int split = v % p.nsplits;
-    const int qtile = v / p.nsplits;
-    int tile0 = split * p.tiles_per_split;
-    int tile1 = tile0 + p.tiles_per_split;
-    if (p.bootstrap) {  // one full tile, spread over the corpus so query tiles do not collide
-        const int span = p.ntiles > 1 ? p.ntiles - 1 : 1;
+    const int split = BOOT ? 0 : v % p.nsplits;
+    const int qtile = BOOT ? v : v / p.nsplits;
+    int tile0, tile1;
+    if (BOOT) {   // a few tiles, spread over the corpus so that query tiles do not collide
+        const int nb = p.boot_tiles < p.ntiles ? p.boot_tiles : p.ntiles;
+        const int span = p.ntiles - nb + 1;
         tile0 = (int)(((long long)qtile * 97) % span);
-        tile1 = tile0 + 1;
+        tile1 = tile0 + nb;
+    } else {
+        tile0 = split * p.tiles_per_split;
+        tile1 = tile0 + p.tiles_per_split;
+        if (tile1 > p.ntiles) tile1 = p.ntiles;
     }
-    if (tile1 > p.ntiles) tile1 = p.ntiles;
     const int ntl = tile1 > tile0 ? tile1 - tile0 : 0;
     const int64_t qbase = (int64_t)qtile * TILE_N;
+    const int ksteps = p.Kp / BK;   // even, >= 4
+    const int Kp = p.Kp;
 
-    // ---- init selection state ----
-    if (tid < TILE_N) {
-        const u32 g = (p.have_boot && !p.bootstrap)
-                          ? __hip_atomic_load(p.g_thr + qbase + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                          : 0u;
-        lds_thrc[tid] = (u64)g << 32;  // id part 0 == worst id: ties with the shared key still pass
-        lds_thrk[tid] = g ? ordkey_inv(g) : -__builtin_inff();
-        lds_cnt[tid] = 0u;
-        lds_ovf[tid] = 0u;
-    }
-    if (tid == 0) { lds_flags[0] = 0u; lds_flags[1] = 0u; }
-
-    const int ksteps = p.Kp / BK;
-    const int total_steps = ntl * ksteps;
-
-    // ---- staging geometry (LDS-DMA): wave w moves pieces p = 4w..4w+3 of each operand; a piece is
-    // one global_load_lds_dwordx4 = 8 rows x 128 B, written lane-linear (row p*8 + lane/8, slot
-    // lane%8).  The swizzle lives on the SOURCE: slot s of row r receives global chunk s ^ f(r),
-    // f(r) = (r >> 1) & 7, which is what the fragment reads below undo.
+    // ---- staging geometry (LDS-DMA): a piece is one global_load_lds_dwordx4 = 8 rows x 128 B, written
+    // lane-linear (row 8 * piece + lane / 8, slot lane % 8); slot s of row r receives global chunk
+    // s ^ ((r >> 1) & 7).  In a load phase a wave moves pieces 4 wave_n .. 4 wave_n + 3 of one 128-row half.
     const int prow = lane >> 3, pslot = lane & 7;
-    const int c_even = pslot ^ (prow >> 1);        // pieces with (p & 1) == 0
-    const int c_odd = pslot ^ (4 + (prow >> 1));   // pieces with (p & 1) == 1
-    const int64_t rowKp = (int64_t)p.Kp;
-    int poff[4];                                   // element offset of this lane inside a tile, piece i
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-        poff[i] = (int)(((wave * 4 + i) * 8 + prow) * rowKp) + ((i & 1) ? c_odd : c_even) * 8;
-    const bf16_t* gA = p.corpus + (int64_t)tile0 * TILE_M * rowKp;
-    const bf16_t* gB = p.queries + qbase * rowKp;
-    const int lds_piece0 = wave * 4 * 1024;        // byte offset of this wave's first piece in a stage
+    const int c_even = pslot ^ (prow >> 1);        // pieces with (piece & 1) == 0
+    const int c_odd = pslot ^ (4 + (prow >> 1));
+    // per-lane BYTE offsets of this wave's pieces inside a 128-row half: piece i = rows 32 wave_n + 8 i + prow; pieces
+    // i and i + 2 differ by 16 rows (a wave-uniform amount), pieces i and i + 1 by 8 rows and the swizzle phase.
+    // Kept as two unsigned 32-bit offsets against wave-uniform base pointers (global_load_lds saddr + voffset form).
+    const u32 po0 = (u32)(((wave_n * 4 + 0) * 8 + prow) * Kp + c_even * 8) * 2u;
+    const u32 po1 = (u32)(((wave_n * 4 + 1) * 8 + prow) * Kp + c_odd * 8) * 2u;
+    const int pstep = 16 * Kp * 2;      // bytes between pieces i and i + 2
+    const int half_elems = 128 * Kp;
+    const bf16_t* gA = p.corpus + (int64_t)tile0 * TILE_M * Kp;
+    const bf16_t* gB = p.queries + qbase * Kp;
+    const int lds_piece0 = wave_n * 4 * 1024;
 
     // ---- fragment read geometry ----
     const int frow = lane & 15, fq = lane >> 4;
     const int swz = frow >> 1;
     const int r_off0 = frow * 128 + ((fq ^ swz) << 4);
     const int r_off1 = frow * 128 + (((4 + fq) ^ swz) << 4);
-    const int a_base = wave_m * 128 * 128;  // byte offset of this wave's first A row
-    const int b_base = wave_n * 64 * 128;
+    const u32 aA0 = lds0 + LDS_A0 + wave_m * 128 * 128 + r_off0, aA1 = lds0 + LDS_A0 + wave_m * 128 * 128 + r_off1;
+    const u32 aB0 = lds0 + LDS_B0 + wave_n * 64 * 128 + r_off0, aB1 = lds0 + LDS_B0 + wave_n * 64 * 128 + r_off1;
+
+    // ---- selection state ----
+    const int ql0 = wave_n * 64 + frow;           // query (inside the tile) of accumulator column nt: ql0 + 16 nt
+    const float NEG_INF = -__builtin_inff();
+    constexpr float KS = L2 ? 2.0f : 1.0f, KI = L2 ? 0.5f : 1.0f;   // key = KS * accumulator (see the header, L2)
+    // per-lane LDS bases of the selection state: [wave row][query] arrays of 4- and 8-byte entries; own row,
+    // partner's row, row 0 (arrays without a wave-row dimension use b4_0)
+    const u32 b4_0 = lds0 + S_THRW + ql0 * 4;
+    const u32 b4_m = b4_0 + wave_m * 1024, b4_p = b4_0 + (wave_m ^ 1) * 1024;
+    const u32 b8_m = lds0 + S_THRC + wave_m * 2048 + ql0 * 8;
+    if (tid < TILE_N) {
+        const u32 g = BOOT ? 0u : __hip_atomic_load(p.g_thr + qbase + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const u32 t4 = lds0 + S_THRW + tid * 4, t8 = lds0 + S_THRC + tid * 8;
+        lds_st32<R_GTHR>(t4, g);
+        lds_st32<R_THRW>(t4, __float_as_uint(NEG_INF));
+        lds_st32<R_THRW + 1024>(t4, __float_as_uint(NEG_INF));
+        lds_st32<R_CNT>(t4, 0u);
+        lds_st32<R_CNT + 1024>(t4, 0u);
+        lds_st64<R_THRC>(t8, 0ull);
+        lds_st64<R_THRC + 2048>(t8, 0ull);
+    }
 
     f32x4 acc[8][4];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int mt = 0; mt < 8; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-#ifdef TRX_STAMP_BUILD
-    // diagnostic build: cycles of this wave in the per-tile filter, in the compaction / dense section (barriers
-    // included), and how many lists it compacted
-    unsigned long long st_filter = 0, st_compact = 0, st_ncomp = 0, st_t0 = 0;
-#define TRX_T0() st_t0 = __builtin_readcyclecounter()
-#define TRX_T1(ACC) ACC += __builtin_readcyclecounter() - st_t0
-#else
-#define TRX_T0()
-#define TRX_T1(ACC)
-#endif
-    typedef __attribute__((address_space(3))) void lds_void;
-    typedef __attribute__((address_space(1))) const void gbl_void;
-#define TRX_STAGE(S, BUF)                                                                           \
-    {                                                                                               \
-        const int tl_ = (S) / ksteps, ks_ = (S) - tl_ * ksteps;                                     \
-        const bf16_t* a_ = gA + (int64_t)((p.debug & 1) ? 0 : tl_) * TILE_M * rowKp + ks_ * BK;                           \
-        const bf16_t* b_ = gB + ks_ * BK;                                                           \
-        char* la_ = smem + LDS_A0 + (BUF) * (TILE_M * 128) + lds_piece0;                            \
-        char* lb_ = smem + LDS_B0 + (BUF) * (TILE_N * 128) + lds_piece0;                            \
-        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                          \
-            __builtin_amdgcn_global_load_lds((gbl_void*)(a_ + poff[i_]), (lds_void*)(la_ + i_ * 1024), 16, 0, AUXA); \
-            __builtin_amdgcn_global_load_lds((gbl_void*)(b_ + poff[i_]), (lds_void*)(lb_ + i_ * 1024), 16, 0, AUXB); \
-        }                                                                                           \
-    }
-
-    if (total_steps > 0) {
-        TRX_STAGE(0, 0);
-    }
-    __syncthreads();
-
-    int cur = 0;
-    u32 gnext = 0u;
-    int ks_in_tile = 0;
-    int tl = 0;
-    for (int s = 0; s < total_steps; ++s) {
-        const bool has_next = (s + 1 < total_steps);
-        if (has_next && !((p.debug & 4) && s > 2)) TRX_STAGE(s + 1, cur ^ 1);
-
-        // ---- MFMA over this K-step: two 32-deep sub-steps ----
-        const char* Ab = smem + LDS_A0 + cur * (TILE_M * 128) + a_base;
-        const char* Bb = smem + LDS_B0 + cur * (TILE_N * 128) + b_base;
-        if (!(p.debug & 8)) {
-            // Hand-rotated fragment pipeline: 8 groups of 8 MFMAs (group g = (kk, pair of M tiles));
-            // the LDS reads of group g+1 are issued before the MFMAs of group g, and the
-            // sched_barriers keep hipcc from re-serialising them (it otherwise reads two fragments,
-            // waits lgkmcnt(0), issues 8 MFMAs, and so on: 38 % MFMA utilisation).
-            bf16x8 bq[2][4], ap[2][2];
-#define TRX_LOAD_B(KK)                                                                          \
-    _Pragma("unroll") for (int nt_ = 0; nt_ < 4; ++nt_)                                         \
-        bq[KK][nt_] = *reinterpret_cast<const bf16x8*>(Bb + nt_ * 2048 + ((KK) ? r_off1 : r_off0));
-#define TRX_LOAD_A(SLOT, KK, MP)                                                                \
-    _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                            \
-        ap[SLOT][j_] = *reinterpret_cast<const bf16x8*>(Ab + ((MP) * 2 + j_) * 2048 + ((KK) ? r_off1 : r_off0));
-            TRX_LOAD_B(0);
-            TRX_LOAD_A(0, 0, 0);
-#ifdef TRX_PRIO_EXPERIMENT
-            __builtin_amdgcn_s_setprio(TRX_PRIO_EXPERIMENT);
-#endif
-#pragma unroll
-            for (int g = 0; g < 8; ++g) {
-                const int kk = g >> 2, mp = g & 3;
-                if (g + 1 < 8) {
-                    const int kk2 = (g + 1) >> 2, mp2 = (g + 1) & 3;
-                    TRX_LOAD_A((g + 1) & 1, kk2, mp2);
-                    if (mp2 == 0) TRX_LOAD_B(1);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int nt = 0; nt < 4; ++nt)
-                        acc[mp * 2 + j][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            ap[g & 1][j], bq[kk][nt], acc[mp * 2 + j][nt], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#ifdef TRX_PRIO_EXPERIMENT
-            __builtin_amdgcn_s_setprio(0);
-#endif
-#undef TRX_LOAD_A
-#undef TRX_LOAD_B
-        }
-
-        if (ks_in_tile == 0 && tid < TILE_N)  // latency hidden under the tile's K loop
-            gnext = __hip_atomic_load(p.g_thr + qbase + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const bool tile_done = (++ks_in_tile == ksteps);
-        const int tile_row0 = (tile0 + tl) * TILE_M;
-
-        if (tile_done && !(p.debug & 2)) {
-            // ---- epilogue part 1: threshold filter + append (per wave, no barrier) ----
-            // flags word alternates with the tile parity so that a fast wave's appends for the
-            // next tile can never be seen by a slow wave still deciding about this one.
-            TRX_T0();
-            u32* flagw = lds_flags + (tl & 1);
-            f32x4 bias[8];
-            if (L2) {
-#pragma unroll
-                for (int mt = 0; mt < 8; ++mt)
-                    bias[mt] = *reinterpret_cast<const f32x4*>(
-                        p.cbias + tile_row0 + wave_m * 128 + mt * 16 + fq * 4);
-#pragma unroll
-                for (int mt = 0; mt < 8; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            acc[mt][nt][r] = __builtin_fmaf(2.0f, acc[mt][nt][r], bias[mt][r]);
-            }
-            if (tl == 0 && (p.bootstrap || !p.have_boot)) {
-                // cold start: no threshold yet, every row would pass -- go straight
-                // to the dense rebuild instead of 65,536 contended appends.
-                if (tid < TILE_N) lds_ovf[tid] = 1u;
-                if (tid == 0) atomicOr(flagw, FLAG_DENSE);
-            } else
+        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = zero4;
+    if (ntl == 0) {
+        // nothing to scan (only possible for an empty split): publish empty lists
+        if (!BOOT && fq == 0) {
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-                const int ql = wave_n * 64 + nt * 16 + frow;
-                const float tk = lds_thrk[ql];
-                // two-level filter: per-lane maximum of each 4-row group, then of all 32 rows.
-                // Most (wave, nt) pairs have some passing lane on most tiles, so the work after
-                // the first ballot must stay cheap: 8 wave-uniform group tests, and only the
-                // groups that really hold a passing row look at their 4 elements.
-                float gm[8];
+                const int64_t o = ((qbase + ql0 + 16 * nt) * p.nsplits + split) * LISTS_PER_SPLIT + wave_m;
+                p.cand_cnt[o] = 0u; p.cand_thr[o] = 0ull;
+            }
+        }
+        return;
+    }
+
+    // ---- prologue: K-step 0 in full and A rows 0-127 of K-step 1 (all waves), bias of tile 0 ----
+    {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int pc = wave * 4 + i;    // piece 0..31 of a 256-row operand stage
+            const int off = (pc * 8 + prow) * Kp + ((pc & 1) ? c_odd : c_even) * 8;
+            __builtin_amdgcn_global_load_lds((gbl_void*)(gA + off), (lds_void*)(smem + LDS_A0 + pc * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void*)(gB + off), (lds_void*)(smem + LDS_B0 + pc * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int pc = wave * 2 + i;    // piece 0..15: rows 0-127
+            const int off = (pc * 8 + prow) * Kp + ((pc & 1) ? c_odd : c_even) * 8;
+            __builtin_amdgcn_global_load_lds((gbl_void*)(gA + off + BK), (lds_void*)(smem + LDS_A0 + 32768 + pc * 1024), 16, 0, 0);
+        }
+        if (L2 && wave == 2)
+            __builtin_amdgcn_global_load_lds((gbl_void*)(p.cbias + (int64_t)tile0 * TILE_M + lane * 4), (lds_void*)(smem + S_BIAS), 16, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    // thresholds of this lane's four queries (identical in the 4 lanes of a query)
+    float thrk[4], trk[J][4], m[4];
+    u32 bits[4] = {0u, 0u, 0u, 0u};     // per-lane "group mt of column nt holds a key >= threshold" (bit 7 - mt), last tile
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        thrk[nt] = NEG_INF;
+        m[nt] = NEG_INF;
+#pragma unroll
+        for (int j = 0; j < J; ++j) trk[j][nt] = NEG_INF;
+    }
+
+    {
+        auto seed = [&](auto NT) { constexpr int nt = decltype(NT)::value; const u32 g = lds_ld32<R_GTHR + 64 * nt>(b4_0); if (g) thrk[nt] = KI * ordkey_inv(g); };
+        seed(ic<0>{}); seed(ic<1>{}); seed(ic<2>{}); seed(ic<3>{});
+    }
+
+    // DMA cursors (wave-uniform).  B stream: K-steps 1, 2, ... (columns wrap per tile).  A stream: group 0
+    // stages rows 128-255 of K-steps 1, 2, ...; group 1 rows 0-127 of K-steps 2, 3, ...
+    const bf16_t* srcB = gB + (wave_m ? half_elems : 0);
+    int ksB = 1;
+    const bf16_t* srcA = gA + (wave_m ? 0 : half_elems) + (wave_m ? 2 : 1) * BK;
+    int ksA = wave_m ? 2 : 1;
+    if (ksA >= ksteps) { ksA -= ksteps; srcA += 255 * Kp; }     // Kp == 128: K-step 2 is the next tile's K-step 0
+    const int wrapA = 255 * Kp;       // added when a K-step cursor moves on to the next tile
+    const bool dbg_nodma = (p.debug & 1) != 0;
+    const bool dbg_nofilter = (p.debug & 2) != 0;
+    const bool dbg_noslow = (p.debug & 4) != 0, dbg_norefresh = (p.debug & 8) != 0;   // timing-only: results are wrong
+
+    if (wave_m) __builtin_amdgcn_s_barrier();       // group 1 runs one interval late
+
+    bf16x8 fa[8], fb[4];
+    f32x4 biasv[8];     // L2: -|y|^2 / 2 of this lane's rows of the tile that is about to start
+    const u32 a_bias = lds0 + S_BIAS + (wave_m * 128 + fq * 4) * 4;
+#define TRX_READ_BIAS()                                                                                    \
+    if (L2) {                                                                                              \
+        _Pragma("unroll") for (int mt_ = 0; mt_ < 8; ++mt_)                                                \
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(biasv[mt_]) : "v"(a_bias + (tl & 1) * 1024), "n"(mt_ * 64) : "memory"); \
+    }
+#define TRX_READ(KK, STG)                                                                                  \
+    {                                                                                                      \
+        _Pragma("unroll") for (int nt_ = 0; nt_ < 4; ++nt_)                                                \
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[nt_]) : "v"((KK) ? aB1 : aB0), "n"(nt_ * 2048 + (STG) * 32768) : "memory"); \
+        _Pragma("unroll") for (int mt_ = 0; mt_ < 8; ++mt_)                                                \
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[mt_]) : "v"((KK) ? aA1 : aA0), "n"(mt_ * 2048 + (STG) * 32768) : "memory"); \
+    }
+    // end of a load phase; NV = VMEM operations this wave may leave in flight (4, or 5 with an extra piece)
+#define TRX_WAIT_L(NV)                                                                                     \
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(" #NV ")" ::: "memory");                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+    __builtin_amdgcn_s_barrier();                                                                          \
+    __builtin_amdgcn_sched_barrier(0);
+#define TRX_END_M()                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+    __builtin_amdgcn_s_barrier();                                                                          \
+    __builtin_amdgcn_sched_barrier(0);
+#define TRX_MFMA_ACC()                                                                                     \
+    __builtin_amdgcn_s_setprio(1);                                                                         \
+    _Pragma("unroll") for (int mt_ = 0; mt_ < 8; ++mt_)                                                    \
+        _Pragma("unroll") for (int nt_ = 0; nt_ < 4; ++nt_)                                                \
+            acc[mt_][nt_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mt_], fb[nt_], acc[mt_][nt_], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);
+    // first phase of a tile: the accumulators start from zero (IP) or from -|y|^2 / 2 of their rows (L2): no clearing pass
+#define TRX_MFMA_ZERO()                                                                                    \
+    __builtin_amdgcn_s_setprio(1);                                                                         \
+    _Pragma("unroll") for (int mt_ = 0; mt_ < 8; ++mt_)                                                    \
+        _Pragma("unroll") for (int nt_ = 0; nt_ < 4; ++nt_)                                                \
+            acc[mt_][nt_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mt_], fb[nt_], L2 ? biasv[mt_] : zero4, 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);
+    // B pieces of this wave's half for the K-step after the current one -> stage STG
+#define TRX_DMA_B(STG)                                                                                     \
+    if (!dbg_nodma) {                                                                                      \
+        const char* s_ = (const char*)(srcB + ksB * BK);                                                   \
+        char* l_ = smem + LDS_B0 + (STG) * 32768 + wave_m * 16384 + lds_piece0;                            \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                   \
+            __builtin_amdgcn_global_load_lds((gbl_void*)(s_ + (i_ >> 1) * pstep + ((i_ & 1) ? po1 : po0)), (lds_void*)(l_ + i_ * 1024), 16, 0, 0); \
+    }                                                                                                      \
+    ksB = (ksB + 1 == ksteps) ? 0 : ksB + 1;
+    // A pieces: group 0 -> rows 128-255, group 1 -> rows 0-127, of the cursor's K-step -> stage STG
+#define TRX_DMA_A(STG)                                                                                     \
+    if (!dbg_nodma) {                                                                                      \
+        char* l_ = smem + LDS_A0 + (STG) * 32768 + (wave_m ? 0 : 16384) + lds_piece0;                      \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                   \
+            __builtin_amdgcn_global_load_lds((gbl_void*)((const char*)srcA + (i_ >> 1) * pstep + ((i_ & 1) ? po1 : po0)), (lds_void*)(l_ + i_ * 1024), 16, 0, 0); \
+    }                                                                                                      \
+    srcA += BK;                                                                                            \
+    if (++ksA == ksteps) { ksA = 0; srcA += wrapA; }
+
+    // ---- what happens once per finished tile, at the start of the wave's next load phase (its partner is
+    // issuing MFMAs meanwhile): threshold bookkeeping, and the slow path if a maximum reached a threshold.
+    // TL = tile index inside the split whose keys are in `acc` / maxima in `m`.
+#ifdef TRX_STAMP_BUILD
+    unsigned long long st_cyc = 0, st_slow = 0, st_comp = 0, st_cols = 0, st_a = 0, st_b = 0, st_c = 0, st_d = 0;
+#endif
+    auto tile_end = [&](const int TL) __attribute__((always_inline)) {
+#ifdef TRX_STAMP_BUILD
+        const unsigned long long st_t0 = __builtin_readcyclecounter();
+#endif
+        const int tile_row0 = (tile0 + TL) * TILE_M;
+        const bool full_tile = L2 || tile_row0 + TILE_M <= p.n_valid;    // IP pad rows score 0: they are not rows
+        // lane-derived values, recomputed here (see lane_now): they shadow the kernel-scope ones
+        const int lane = (int)lane_now();
+        const int frow = lane & 15, fq = lane >> 4;
+        const int ql0 = wave_n * 64 + frow;
+        const u32 b4_0 = lds0 + S_THRW + ql0 * 4;
+        const u32 b4_m = b4_0 + wave_m * 1024, b4_p = b4_0 + (wave_m ^ 1) * 1024;
+        const u32 b8_m = lds0 + S_THRC + wave_m * 2048 + ql0 * 8;
+        // ---- slow path: some lane's tile maximum reached its query's threshold ----
+        const bool hit = (bits[0] | bits[1] | bits[2] | bits[3]) != 0u;
+        if (!BOOT && !dbg_noslow && __any(hit)) {
+#ifdef TRX_STAMP_BUILD
+            ++st_slow;
+#endif
+            // At 4 splits per query tile a workgroup sees 977 tiles and its waves append ~5 rows per tile on average
+            // (70 at the start): this path runs on most tiles and has to stay cheap -- and small: with 128 accumulator
+            // registers live, anything hipcc spills here is reloaded through the VMEM queue, thousands of cycles each
+            // behind the LDS-DMA traffic.  So: ONE copy of the per-group code in a loop over the groups that hold a hit
+            // (wave-uniform 32-bit work mask, group = 4 rows x one query column), the group's accumulator fetched by a
+            // switch over its 32 possible homes.
+#ifdef TRX_STAMP_BUILD
+            const unsigned long long st_t1 = __builtin_readcyclecounter();
+#endif
+            u32 work = 0u;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                if (!__any(bits[nt] != 0u)) continue;
 #pragma unroll
                 for (int mt = 0; mt < 8; ++mt)
-                    gm[mt] = fmaxf(fmaxf(acc[mt][nt][0], acc[mt][nt][1]), fmaxf(acc[mt][nt][2], acc[mt][nt][3]));
-                const float m = fmaxf(fmaxf(fmaxf(gm[0], gm[1]), fmaxf(gm[2], gm[3])),
-                                      fmaxf(fmaxf(gm[4], gm[5]), fmaxf(gm[6], gm[7])));
-                if (__any(m >= tk)) {
-                    const u64 tc = lds_thrc[ql];
-                    u64* cq = p.cand + ((qbase + ql) * p.nsplits + split) * CAP;
-#pragma unroll
-                    for (int mt = 0; mt < 8; ++mt) {
-                        if (!__any(gm[mt] >= tk)) continue;
+                    if (__any((bits[nt] & (0x80u >> mt)) != 0u)) work |= 1u << (nt * 8 + mt);
+            }
+#ifdef TRX_STAMP_BUILD
+            const unsigned long long st_t2 = __builtin_readcyclecounter();
+            st_a += st_t2 - st_t1;
+#endif
+            while (work) {
+                const int gidx = __builtin_amdgcn_readfirstlane(__builtin_ctz(work));
+                work &= work - 1u;
+                const int nt = gidx >> 3, mt = gidx & 7;
+#ifdef TRX_STAMP_BUILD
+                ++st_cols;
+#endif
+#ifdef TRX_STAMP_BUILD
+                const unsigned long long st_t4 = __builtin_readcyclecounter();
+#endif
+                f32x4 x = zero4;
+                switch (gidx) {
+#define TRX_FETCH(G) case G: x = acc[(G) & 7][(G) >> 3]; break;
+                    TRX_FETCH(0) TRX_FETCH(1) TRX_FETCH(2) TRX_FETCH(3) TRX_FETCH(4) TRX_FETCH(5) TRX_FETCH(6) TRX_FETCH(7)
+                    TRX_FETCH(8) TRX_FETCH(9) TRX_FETCH(10) TRX_FETCH(11) TRX_FETCH(12) TRX_FETCH(13) TRX_FETCH(14) TRX_FETCH(15)
+                    TRX_FETCH(16) TRX_FETCH(17) TRX_FETCH(18) TRX_FETCH(19) TRX_FETCH(20) TRX_FETCH(21) TRX_FETCH(22) TRX_FETCH(23)
+                    TRX_FETCH(24) TRX_FETCH(25) TRX_FETCH(26) TRX_FETCH(27) TRX_FETCH(28) TRX_FETCH(29) TRX_FETCH(30) TRX_FETCH(31)
+#undef TRX_FETCH
+                    default: break;
+                }
+#ifdef TRX_STAMP_BUILD
+                asm volatile("" :: "v"(x));
+                const unsigned long long st_t5 = __builtin_readcyclecounter();
+                st_c += st_t5 - st_t4;
+#endif
+                const float tk = nt == 0 ? thrk[0] : nt == 1 ? thrk[1] : nt == 2 ? thrk[2] : thrk[3];
+                const u32 bb = nt == 0 ? bits[0] : nt == 1 ? bits[1] : nt == 2 ? bits[2] : bits[3];
+                const bool sel = (bb & (0x80u >> mt)) != 0u;
+                const u32 a_cnt = b4_m + R_CNT + 64 * nt, a_thc = b8_m + R_THRC + 128 * nt;
+                u64* cq = p.cand + (((qbase + ql0 + 16 * nt) * p.nsplits + split) * LISTS_PER_SPLIT + wave_m) * CAPW;
+                const u32 id0 = (u32)(tile_row0 + wave_m * 128 + mt * 16 + fq * 4);
+                // pass 0; if a list fills up, its wave cuts it to its kprime best and pass 1 repeats the group under the
+                // new floor (a row stored twice is harmless: knn_select drops equal packed values; after the cut the
+                // list has room for a group, so pass 1 cannot fail)
+                for (int rep = 0; rep < 2; ++rep) {
+                    bool ovf = false;
+                    if (sel) {
+                        const u64 tc = lds_ld64<0>(a_thc);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const float key = acc[mt][nt][r] + 0.0f;  // -0 -> +0
-                            if (key >= tk) {
-                                const u32 id = (u32)(tile_row0 + wave_m * 128 + mt * 16 + fq * 4 + r);
-                                const u64 c = make_comp(key, id);
+                            const float h = x[r];
+                            if (h >= tk) {
+                                const u32 id = id0 + r;
+                                const u64 c = make_comp(KS * h + 0.0f, id);     // key; -0 -> +0
                                 if (id < (u32)p.n_valid && c > tc) {
-                                    const u32 pos = atomicAdd(&lds_cnt[ql], 1u);
-                                    if (pos < (u32)CAP) {
-                                        cq[pos] = c;
-                                        if (pos >= (u32)p.csoft) atomicOr(flagw, FLAG_COMPACT);
-                                    } else {
-                                        lds_ovf[ql] = 1u;
-                                        atomicOr(flagw, FLAG_DENSE);
-                                    }
+                                    const u32 pos = lds_inc<0>(a_cnt);
+                                    if (pos < (u32)CAPW) cq[pos] = c;
+                                    else ovf = true;
                                 }
                             }
                         }
                     }
-                }
-            }
-        }
-
-        if (tile_done && !(p.debug & 2)) { TRX_T1(st_filter); }
-        __syncthreads();
-        cur ^= 1;
-
-        if (tile_done) {
-            // ---- epilogue part 2: rare compaction / dense rebuild (workgroup-uniform) ----
-            const u32 fl = lds_flags[tl & 1];
-            if (fl) {
-                TRX_T0();
-                float* scr = reinterpret_cast<float*>(p.scratch) + (int64_t)blockIdx.x * (TILE_N * TILE_M);
-                if (fl & FLAG_DENSE) {
-#pragma unroll
-                    for (int mt = 0; mt < 8; ++mt)
-#pragma unroll
-                        for (int nt = 0; nt < 4; ++nt) {
-                            const int ql = wave_n * 64 + nt * 16 + frow;
-                            *reinterpret_cast<f32x4*>(scr + ql * TILE_M + wave_m * 128 + mt * 16 + fq * 4) =
-                                acc[mt][nt];
-                        }
-                }
-                if (tid == 0) *lds_wlcnt = 0u;
-                __syncthreads();
-                if (tid == 0) lds_flags[tl & 1] = 0u;
-                // work list of the queries whose list must be compacted (or rebuilt): built by 256 threads at once and
-                // dealt round-robin to the 8 waves -- a wave used to walk its own 32 queries one after the other, and
-                // the whole workgroup waited at the barrier below for the wave that happened to own most of them
-                if (tid < TILE_N) {
-                    const bool need = lds_ovf[tid] != 0u || lds_cnt[tid] > (u32)p.csoft;
-                    const u64 mk = __ballot(need);
-                    u32 base = 0u;
-                    if (lane == 0 && mk) base = atomicAdd(lds_wlcnt, (u32)__popcll(mk));
-                    base = __shfl(base, 0, 64);
-                    if (need) lds_wl[base + (u32)__popcll(mk & ((1ull << lane) - 1ull))] = (u32)tid;
-                }
-                __syncthreads();
-                const int nwork = (int)*lds_wlcnt;
-                for (int i = wave; i < nwork; i += 8) {
-                    const int ql = (int)lds_wl[i];
-                    const u32 c = lds_cnt[ql];
-                    const bool dense = lds_ovf[ql] != 0u;
 #ifdef TRX_STAMP_BUILD
-                    ++st_ncomp;
+                    if (rep == 0) st_d += __builtin_readcyclecounter() - st_t5;
 #endif
-                    u64* cq = p.cand + ((qbase + ql) * p.nsplits + split) * CAP;
-                    const u32 cc = c < (u32)CAP ? c : (u32)CAP;
-                    u64 val = (u32)lane < cc ? ld_u64_l2(cq + lane) : 0ull;
-                    if (dense) {
-                        // entries of the current tile are re-derived from the dump
-                        if (val != 0ull && comp_id(val) >= (u32)tile_row0) val = 0ull;
-                        val = wave_sort_desc(val, lane);
-                        for (int ch = 0; ch < TILE_M / 32; ++ch) {
-                            if (lane >= 32) {
-                                const int rl = ch * 32 + (lane - 32);
-                                const float key = ld_f32_l2(scr + ql * TILE_M + rl) + 0.0f;
-                                const u32 id = (u32)(tile_row0 + rl);
-                                val = (id < (u32)p.n_valid && key == key) ? make_comp(key, id) : 0ull;
-                            }
-                            val = wave_sort_desc(val, lane);
+                    u64 om = __ballot(ovf);
+                    if (!om) break;
+                    while (om) {
+                        const int l = __ffsll((long long)om) - 1;
+                        const int qsel = wave_n * 64 + 16 * nt + (l & 15);
+                        u64* lq = p.cand + (((qbase + qsel) * p.nsplits + split) * LISTS_PER_SPLIT + wave_m) * CAPW;
+                        const u64 floor_c = compact_list(lq, p.kprime, lane);
+#ifdef TRX_STAMP_BUILD
+                        ++st_comp;
+#endif
+                        if (lane == 0) {
+                            lds_st32<R_CNT>(lds0 + S_THRW + wave_m * 1024 + qsel * 4, (u32)p.kprime);
+                            lds_st64<R_THRC>(lds0 + S_THRC + wave_m * 2048 + qsel * 8, floor_c);
                         }
-                    } else {
-                        val = wave_sort_desc(val, lane);
-                    }
-                    if (lane < p.kprime) cq[lane] = val;
-                    const u64 kept = __ballot(lane < p.kprime && val != 0ull);
-                    const u32 ncnt = (u32)__popcll(kept);
-                    const u64 tval = shfl_u64(val, p.kprime - 1);
-                    if (lane == 0) {
-                        lds_cnt[ql] = ncnt;
-                        lds_ovf[ql] = 0u;
-                        if (ncnt == (u32)p.kprime && tval > lds_thrc[ql]) {
-                            lds_thrc[ql] = tval;
-                            lds_thrk[ql] = comp_key(tval);
-                            atomicMax(p.g_thr + qbase + ql, (u32)(tval >> 32));
-                        }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        om &= ~(0x0001000100010001ull << (l & 15));
                     }
                 }
-                __syncthreads();
-                TRX_T1(st_compact);
             }
-#pragma unroll
-            for (int mt = 0; mt < 8; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            // pick up thresholds other splits have published meanwhile (read by the next filter a
-            // whole tile of barriers later)
-            if (tid < TILE_N && gnext > (u32)(lds_thrc[tid] >> 32)) {
-                lds_thrc[tid] = (u64)gnext << 32;
-                lds_thrk[tid] = ordkey_inv(gnext);
-            }
-            ks_in_tile = 0;
-            ++tl;
         }
+#ifdef TRX_STAMP_BUILD
+        const unsigned long long st_t3 = __builtin_readcyclecounter();
+#endif
+        // ---- the J best tile maxima of this lane (pad-row tiles of an inner-product index do not count) ----
+        if (full_tile) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                float a = m[nt];
+#pragma unroll
+                for (int j = 0; j < J; ++j) {
+                    const float hi = __builtin_fmaxf(trk[j][nt], a);
+                    a = __builtin_fminf(trk[j][nt], a);
+                    trk[j][nt] = hi;
+                }
+            }
+        }
+        // ---- threshold refresh (every second tile): min over the query's 4 lanes of this wave, then the partner wave
+        // row's value and the other splits' through LDS.  All LDS traffic of the 4 columns is issued together and
+        // waited for once (one access at a time cost 8 ms per search).
+        if (!dbg_norefresh && (BOOT || (TL & 1))) {
+            float g[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) g[nt] = trk[J - 1][nt];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) g[nt] = __builtin_fminf(g[nt], __shfl_xor(g[nt], 16, 64));
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) g[nt] = __builtin_fminf(g[nt], __shfl_xor(g[nt], 32, 64));
+            if (fq == 0) {
+                lds_st32<R_THRW + 0>(b4_m, __float_as_uint(g[0])); lds_st32<R_THRW + 64>(b4_m, __float_as_uint(g[1]));
+                lds_st32<R_THRW + 128>(b4_m, __float_as_uint(g[2])); lds_st32<R_THRW + 192>(b4_m, __float_as_uint(g[3]));
+            }
+            u32 gp[4], gs[4];
+            asm volatile("ds_read_b32 %0, %8 offset:%10\n\tds_read_b32 %1, %8 offset:%11\n\tds_read_b32 %2, %8 offset:%12\n\tds_read_b32 %3, %8 offset:%13\n\t"
+                         "ds_read_b32 %4, %9 offset:%14\n\tds_read_b32 %5, %9 offset:%15\n\tds_read_b32 %6, %9 offset:%16\n\tds_read_b32 %7, %9 offset:%17\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(gp[0]), "=&v"(gp[1]), "=&v"(gp[2]), "=&v"(gp[3]), "=&v"(gs[0]), "=&v"(gs[1]), "=&v"(gs[2]), "=&v"(gs[3])
+                         : "v"(b4_p), "v"(b4_0), "n"(R_THRW), "n"(R_THRW + 64), "n"(R_THRW + 128), "n"(R_THRW + 192),
+                           "n"(R_GTHR), "n"(R_GTHR + 64), "n"(R_GTHR + 128), "n"(R_GTHR + 192)
+                         : "memory");
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const float both = __builtin_fminf(g[nt], __uint_as_float(gp[nt]));      // 8 J rows reach this key
+                float t = __builtin_fmaxf(thrk[nt], both);
+                if (gs[nt]) t = __builtin_fmaxf(t, KI * ordkey_inv(gs[nt]));               // what the other splits have published
+                thrk[nt] = t;
+                if (!BOOT && (TL & 7) == 3 && wave_m == 0 && fq == 0 && both > NEG_INF)    // tell the other splits, now and then
+                    __hip_atomic_fetch_max(p.g_thr + qbase + ql0 + 16 * nt, ordkey(KS * both), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+#ifdef TRX_STAMP_BUILD
+        st_cyc += __builtin_readcyclecounter() - st_t0;
+        st_b += __builtin_readcyclecounter() - st_t3;
+#endif
+    };
+
+    // One pair of K-steps (stage 0, then stage 1).  FIRST: first pair of a tile -- the previous tile's bookkeeping
+    // rides in its first load phase and its first MFMA phase starts the accumulators from zero.  LAST: last pair of a
+    // tile -- its last MFMA phase takes the per-lane maxima in the MFMA gaps.  The three forms are separate
+    // straight-line blocks (a tile = FIRST, middle pairs, LAST; Kp >= 256 so FIRST != LAST): as branches inside one
+    // block they made hipcc spill half the accumulators.
+    // first load phase of a tile's first pair: previous tile's bookkeeping + extra one-piece DMAs in front of the four
+    // regular pieces (the other splits' thresholds every 8 tiles, wave 1; the next tile's bias, L2, wave 2)
+#define TRX_PAIR_HEAD()                                                                                    \
+    {                                                                                                      \
+        const bool aux_g = !BOOT && wave == 1 && (tl & 7) == 7;                                            \
+        const bool aux_b = L2 && wave == 2;                                                                \
+        if (tl > 0 && !dbg_nofilter) {                                                                     \
+            /* the bookkeeping issues stores / atomics (and whatever hipcc spills), which count in vmcnt like the  \
+               DMA pieces: retire the previous load phase's pieces first (two intervals old), do the bookkeeping    \
+               with no DMA in flight and no fragment live, and wait for nothing at the end; the next load phase's   \
+               vmcnt(4) covers everything issued here */                                                    \
+            if (!(p.debug & 16)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          \
+            /* the partner wave on this SIMD is issuing MFMAs at priority 1 meanwhile: without a higher priority the   \
+               bookkeeping below gets the leftover issue slots and runs 2-3x slower -- and it is the critical path */  \
+            __builtin_amdgcn_s_setprio(3);                                                                 \
+            tile_end(tl - 1);                                                                              \
+            __builtin_amdgcn_s_setprio(0);                                                                 \
+            __builtin_amdgcn_sched_barrier(0);                                                             \
+            TRX_READ(0, 0);                                                                                \
+            TRX_READ_BIAS();                                                                               \
+            if (aux_g) __builtin_amdgcn_global_load_lds((gbl_void*)(p.g_thr + qbase + lane * 4), (lds_void*)(smem + S_GTHR), 16, 0, 0); \
+            if (aux_b) __builtin_amdgcn_global_load_lds((gbl_void*)(p.cbias + (int64_t)(tile0 + tl + 1) * TILE_M + lane * 4), \
+                                                        (lds_void*)(smem + S_BIAS + ((tl + 1) & 1) * 1024), 16, 0, 0); \
+            TRX_DMA_B(1);                                                                                  \
+            if (p.debug & 16) { TRX_WAIT_L(5); } else { TRX_WAIT_L(63); }                                  \
+        } else {                                                                                           \
+            TRX_READ(0, 0);                                                                                \
+            TRX_READ_BIAS();                                                                               \
+            if (aux_b) __builtin_amdgcn_global_load_lds((gbl_void*)(p.cbias + (int64_t)(tile0 + tl + 1) * TILE_M + lane * 4), \
+                                                        (lds_void*)(smem + S_BIAS + ((tl + 1) & 1) * 1024), 16, 0, 0); \
+            TRX_DMA_B(1);                                                                                  \
+            if (aux_b) { TRX_WAIT_L(5); } else { TRX_WAIT_L(4); }                                          \
+        }                                                                                                  \
+    }
+#define TRX_PAIR_HEAD_PLAIN()                                                                              \
+    {                                                                                                      \
+        TRX_READ(0, 0);                                                                                    \
+        TRX_DMA_B(1);                                                                                      \
+        TRX_WAIT_L(4);                                                                                     \
+    }
+#define TRX_PAIR_REST(FIRST, LAST)                                                                         \
+    {                                                                                                      \
+        /* ---- M(u, 0) ---- */                                                                            \
+        if (FIRST) { TRX_MFMA_ZERO(); } else { TRX_MFMA_ACC(); }                                           \
+        TRX_END_M();                                                                                       \
+        /* ---- L(u, 1) ----  G1: A rows 0-127 of u+2 -> stage 0; G0: A rows 128-255 of u+1 -> stage 1 */   \
+        TRX_READ(1, 0);                                                                                    \
+        if (wave_m) { TRX_DMA_A(0); } else { TRX_DMA_A(1); }                                               \
+        TRX_WAIT_L(4);                                                                                     \
+        TRX_MFMA_ACC();                                                                                    \
+        TRX_END_M();                                                                                       \
+        /* ================= K-step u+1 = odd (stage 1) ================= */                                \
+        TRX_READ(0, 1);                                                                                    \
+        TRX_DMA_B(0);                                                                                      \
+        TRX_WAIT_L(4);                                                                                     \
+        TRX_MFMA_ACC();                                                                                    \
+        TRX_END_M();                                                                                       \
+        /* ---- L(u+1, 1) ----  G1: A rows 0-127 of u+3 -> stage 1; G0: A rows 128-255 of u+2 -> stage 0 */ \
+        TRX_READ(1, 1);                                                                                    \
+        if (wave_m) { TRX_DMA_A(1); } else { TRX_DMA_A(0); }                                               \
+        TRX_WAIT_L(4);                                                                                     \
+        if (!(LAST)) {                                                                                     \
+            TRX_MFMA_ACC();                                                                                \
+        } else {                                                                                           \
+            /* last 32 MFMAs of the tile.  In their gaps, for every finished group of 4 accumulator rows (mt, nt): \
+               its maximum g (2 VALU), the lane's tile maximum m (1), and one bit "g reaches the query's threshold"  \
+               shifted into bits[nt] (v_cmp + v_addc: bits = 2 bits + carry; group mt ends up at bit 7 - mt) */     \
+            __builtin_amdgcn_s_setprio(1);                                                                 \
+            _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) { m[nt] = NEG_INF; bits[nt] = 0u; }           \
+            _Pragma("unroll") for (int mt = 0; mt < 9; ++mt) {                                             \
+                _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) {                                         \
+                    if (mt < 8) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mt], fb[nt], acc[mt][nt], 0, 0, 0); \
+                    if (mt >= 1) {                                                                         \
+                        const f32x4 a = acc[mt - 1][nt];                                                   \
+                        const float g = max3f(__builtin_fmaxf(a[0], a[1]), a[2], a[3]);                    \
+                        m[nt] = __builtin_fmaxf(m[nt], g);                                                 \
+                        asm volatile("v_cmp_ge_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits[nt]) : "v"(g), "v"(thrk[nt]) : "vcc"); \
+                    }                                                                                      \
+                    __builtin_amdgcn_sched_barrier(0);                                                     \
+                }                                                                                          \
+            }                                                                                              \
+            __builtin_amdgcn_s_setprio(0);                                                                 \
+        }                                                                                                  \
+        TRX_END_M();                                                                                       \
     }
 
+    // The bookkeeping of tile tl-1 lives in the first load phase of tile tl; after the last tile that phase runs
+    // once more on its own (its reads and pieces are never used: the corpus has a spare tile behind its last row).
+    for (int tl = 0;; ++tl) {
+        TRX_PAIR_HEAD();
+        if (tl == ntl) break;
+        TRX_PAIR_REST(true, false);
+        for (int ks = 2; ks + 2 < ksteps; ks += 2) { TRX_PAIR_HEAD_PLAIN(); TRX_PAIR_REST(false, false); }
+        TRX_PAIR_HEAD_PLAIN();
+        TRX_PAIR_REST(false, true);
+    }
+    if (!wave_m) __builtin_amdgcn_s_barrier();      // group 0 waits for the interval group 1 is behind
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    if (BOOT) {
+        // publish min(own, partner) -- the partner's value must be its final one here
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (wave_m == 0 && fq == 0) {
+            auto pubb = [&](auto NT) {
+                constexpr int nt = decltype(NT)::value;
+                const float a = __uint_as_float(lds_ld32<R_THRW + 64 * nt>(b4_m));
+                const float b = __uint_as_float(lds_ld32<R_THRW + 64 * nt>(b4_p));
+                const float both = __builtin_fminf(a, b);
+                if (both > NEG_INF) __hip_atomic_fetch_max(p.g_thr + qbase + ql0 + 16 * nt, ordkey(KS * both), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            };
+            pubb(ic<0>{}); pubb(ic<1>{}); pubb(ic<2>{}); pubb(ic<3>{});
+        }
+        return;
+    }
 #ifdef TRX_STAMP_BUILD
     if (p.stamp_out && lane == 0) {
         unsigned long long* o = p.stamp_out + ((size_t)blockIdx.x * 8 + wave) * 4;
-        o[0] = st_filter; o[1] = st_compact; o[2] = st_ncomp; o[3] = (unsigned long long)ntl;
+        o[0] = st_cyc | (st_d << 36); o[1] = st_slow | (st_a << 20); o[2] = st_comp | (st_cols << 16) | (st_c << 36); o[3] = (unsigned long long)ntl | (st_b << 20);
     }
 #endif
-    // ---- publish per-(query, split) count and bound ----
-    __syncthreads();
-    if (tid < TILE_N && !p.bootstrap) {
-        const int64_t o = (qbase + tid) * p.nsplits + split;
-        const u32 c = lds_cnt[tid];
-        p.cand_cnt[o] = c < (u32)CAP ? c : (u32)CAP;
-        p.cand_thr[o] = lds_thrc[tid];
+    // ---- publish count and bound of this wave's 64 lists ----
+    if (fq == 0) {
+        auto publ = [&](auto NT) {
+            constexpr int nt = decltype(NT)::value;
+            const int64_t o = ((qbase + ql0 + 16 * nt) * p.nsplits + split) * LISTS_PER_SPLIT + wave_m;
+            const u32 c = lds_ld32<R_CNT + 64 * nt>(b4_m);
+            const u64 tc = lds_ld64<R_THRC + 128 * nt>(b8_m);
+            const u64 tkc = thrk[nt] > NEG_INF ? ((u64)ordkey(KS * thrk[nt]) << 32) : 0ull;   // rows never listed have key < KS thrk
+            p.cand_cnt[o] = c < (u32)CAPW ? c : (u32)CAPW;
+            p.cand_thr[o] = tc > tkc ? tc : tkc;
+        };
+        publ(ic<0>{}); publ(ic<1>{}); publ(ic<2>{}); publ(ic<3>{});
     }
 }
 
-template <bool L2, int AUXA, int AUXB, bool BOOT>
-static hipError_t launch_one_b(const ScanParams& p, hipStream_t st) {
+template <bool L2, int J, bool BOOT>
+static hipError_t launch_one(const ScanParams& p, hipStream_t st) {
     // the attribute is per device (the ABI takes a device ordinal): one bit per ordinal, per instantiation
     static std::atomic<unsigned long long> attr_devs{0ull};
     int dev = 0;
@@ -426,31 +672,24 @@ static hipError_t launch_one_b(const ScanParams& p, hipStream_t st) {
     if (e != hipSuccess) return e;
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(attr_devs.load(std::memory_order_acquire) & bit)) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_scan_kernel<L2, AUXA, AUXB, BOOT>),
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_scan_kernel<L2, J, BOOT>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
         if (e != hipSuccess) return e;
         attr_devs.fetch_or(bit, std::memory_order_release);
     }
-    dim3 grid(p.bootstrap ? p.nqtiles : p.nqtiles * p.nsplits), block(SCAN_THREADS);
-    hipLaunchKernelGGL((knn_scan_kernel<L2, AUXA, AUXB, BOOT>), grid, block, LDS_TOTAL, st, p);
+    dim3 grid(BOOT ? p.nqtiles : p.nqtiles * p.nsplits), block(SCAN_THREADS);
+    hipLaunchKernelGGL((knn_scan_kernel<L2, J, BOOT>), grid, block, LDS_TOTAL, st, p);
     return hipGetLastError();
 }
 
-template <bool L2, int AUXA, int AUXB>
-static hipError_t launch_one(const ScanParams& p, hipStream_t st) {
-    return p.bootstrap ? launch_one_b<L2, AUXA, AUXB, true>(p, st) : launch_one_b<L2, AUXA, AUXB, false>(p, st);
-}
-
 hipError_t launch_scan(const ScanParams& p, int metric, hipStream_t st) {
-    // cache policy of the two LDS-DMA streams is the default one: `nt` on the corpus stream, the
-    // query stream or both measured 107-122 ms against 92 ms, so only <0, 0>
-    // is instantiated.
-#ifdef TRX_POLICY_EXPERIMENT
-    static const int pol = getenv("TRX_POLICY") ? atoi(getenv("TRX_POLICY")) : 0;   // 1: nt on queries, 2: nt on corpus
-    if (metric != 1 && pol == 2) return launch_one<false, 2, 0>(p, st);
-    if (metric != 1 && pol == 1) return launch_one<false, 0, 2>(p, st);
-#endif
-    return metric == 1 ? launch_one<true, 0, 0>(p, st) : launch_one<false, 0, 0>(p, st);
+    const bool l2 = metric == 1, j4 = p.kprime > 16;
+    if (p.bootstrap) {
+        if (l2) return j4 ? launch_one<true, 4, true>(p, st) : launch_one<true, 2, true>(p, st);
+        return j4 ? launch_one<false, 4, true>(p, st) : launch_one<false, 2, true>(p, st);
+    }
+    if (l2) return j4 ? launch_one<true, 4, false>(p, st) : launch_one<true, 2, false>(p, st);
+    return j4 ? launch_one<false, 4, false>(p, st) : launch_one<false, 2, false>(p, st);
 }
 
 }  // namespace trx

@@ -76,34 +76,60 @@ __global__ __launch_bounds__(256) void knn_select_kernel(SelectParams p) {
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= p.nq) return;  // wave-uniform
 
-    // ---- 1. merge the split lists by packed approximate (key,id); keep the best KEEP ----
-    u64 v = 0ull;        // lanes 0..31: running best-32, sorted; lanes 32..63: incoming
-    u64 tau = 0ull;      // best packed key of anything NOT kept (0 = nothing dropped)
-    bool first = true;
-    for (int s = 0; s < p.nsplits; ++s) {
-        const int64_t o = (int64_t)q * p.nsplits + s;
-        const int c = (int)p.cand_cnt[o];
-        const u64 thr = p.cand_thr[o];
-        tau = thr > tau ? thr : tau;
-        const u64* cq = p.cand + o * CAP;
-        for (int base = 0; base < c; base += 32) {
-            if (first) {
-                // first chunk may fill all 64 lanes
-                v = lane < c ? cq[lane] : 0ull;
-                base += 32;
-                first = false;
-            } else {
-                const u64 dropped = shfl_u64(v, 32);  // best of the lanes about to be replaced
-                tau = dropped > tau ? dropped : tau;
-                if (lane >= 32) v = (base + lane - 32) < c ? cq[base + lane - 32] : 0ull;
-            }
+    // ---- 1. merge the lists of the query by packed approximate (key,id); keep the best KEEP ----
+    // A query has nlists lists (corpus splits x wave rows of the scan workgroup), each with its own bound: every row of
+    // the list's rows that is NOT listed has a packed value <= bound.  T = the largest bound: every row with a packed
+    // value > T is listed somewhere, and at least kprime >= k listed entries reach T (the bound is either a key that
+    // kprime rows reach, all of them listed, or the kprime-th entry of a compacted list).  So entries below T are
+    // dropped unread by the sort (the lists are append-only logs: most of their entries date from before the
+    // thresholds tightened), and T is the starting value of tau, the best packed value of anything not kept.
+    u64 tau = 0ull;
+    for (int l = lane; l < p.nlists; l += 64) {
+        const u64 b = p.cand_thr[(int64_t)q * p.nlists + l];
+        tau = b > tau ? b : tau;
+    }
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) { const u64 o = shfl_xor_u64(tau, s); tau = o > tau ? o : tau; }
+    const u64 T = tau;
+    __shared__ u64 sel_queue[4][128];
+    u64* qu = sel_queue[threadIdx.x >> 6];
+    int qn = 0;                        // entries waiting in the queue (wave-uniform)
+    u64 v = 0ull;                      // lanes 0..31: running best-32, sorted; lanes 32..63: incoming
+    auto drain = [&](bool all) {
+        while (qn >= 32 || (all && qn > 0)) {
+            const int take = qn < 32 ? qn : 32;
+            __builtin_amdgcn_wave_barrier();
+            if (lane >= 32) v = (lane - 32) < take ? qu[qn - take + (lane - 32)] : 0ull;
+            qn -= take;
             v = wave_sort_desc(v, lane);
+            // a row may have been listed twice (the scan repeats a column after compacting a full list): equal packed
+            // values are adjacent now; keep the first of each run
+            const u64 prev = shfl_u64(v, lane > 0 ? lane - 1 : 0);
+            const bool dup = lane > 0 && v != 0ull && v == prev;
+            if (__any(dup)) {
+                if (dup) v = 0ull;
+                v = wave_sort_desc(v, lane);
+            }
+            const u64 dropped = shfl_u64(v, KEEP);   // best of the lanes about to be replaced
+            tau = dropped > tau ? dropped : tau;
+        }
+    };
+    for (int l = 0; l < p.nlists; ++l) {
+        const int64_t o = (int64_t)q * p.nlists + l;
+        const int c = (int)p.cand_cnt[o];
+        const u64* cq = p.cand + o * CAPW;
+        for (int base = 0; base < c; base += 64) {
+            const u64 e = (base + lane) < c ? cq[base + lane] : 0ull;
+            const bool keep = e != 0ull && e >= T;
+            const u64 km = __ballot(keep);
+            if (keep) qu[qn + __popcll(km & ((1ull << lane) - 1ull))] = e;
+            qn += __popcll(km);
+            __builtin_amdgcn_wave_barrier();
+            drain(false);
         }
     }
-    {
-        const u64 dropped = shfl_u64(v, KEEP);
-        tau = dropped > tau ? dropped : tau;
-    }
+    drain(true);
+    if (lane >= KEEP) v = 0ull;
     bool have = lane < KEEP && v != 0ull;
     // error bound of an approximate key (the same one the certificate uses below)
     const float xn2 = p.qnorm2[q];

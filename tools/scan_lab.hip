@@ -14,6 +14,7 @@
 //     flags bit0: no DMA after the prologue (MFMA + LDS reads only)
 //           bit1: no MFMA (fill only)
 //           bit2: no per-tile maximum
+//           bit3: (variant 4) fragments read once and reused: no LDS read traffic
 // build: hipcc --offload-arch=gfx950 -O3 tools/scan_lab.hip -o tools/scan_lab
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -251,17 +252,20 @@ __global__ __launch_bounds__(THREADS, 2) void lab_v1(LabParams p) {
 #define V1_MFMA()                                                                                          \
     if (mfma_on) {                                                                                         \
         if (!(OPT & 2)) __builtin_amdgcn_s_setprio(1);                                                     \
-        _Pragma("unroll") for (int mt_ = 0; mt_ < 8; ++mt_)                                                \
+        _Pragma("unroll") for (int mt_ = 0; mt_ < 8; ++mt_) {                                              \
+            if ((OPT & 4) && mt_ == 6) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } \
             _Pragma("unroll") for (int nt_ = 0; nt_ < 4; ++nt_)                                            \
                 acc[mt_][nt_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mt_], fb[nt_], acc[mt_][nt_], 0, 0, 0); \
+        }                                                                                                  \
         if (!(OPT & 2)) __builtin_amdgcn_s_setprio(0);                                                     \
     } else {                                                                                               \
+        if (OPT & 4) __builtin_amdgcn_s_barrier();                                                         \
         _Pragma("unroll") for (int mt_ = 0; mt_ < 8; ++mt_) asm volatile("" :: "v"(fa[mt_]));              \
         _Pragma("unroll") for (int nt_ = 0; nt_ < 4; ++nt_) asm volatile("" :: "v"(fb[nt_]));              \
     }                                                                                                      \
     __builtin_amdgcn_sched_barrier(0);
 #define V1_END_M()                                                                                         \
-    __builtin_amdgcn_s_barrier();                                                                          \
+    if (!(OPT & 4)) __builtin_amdgcn_s_barrier();                                                          \
     __builtin_amdgcn_sched_barrier(0);                                                                     \
     if (OPT & 2) __builtin_amdgcn_s_setprio(1);
     // B pieces of this wave's half for the K-step after the current one -> stage STG
@@ -330,6 +334,7 @@ __global__ __launch_bounds__(THREADS, 2) void lab_v1(LabParams p) {
 //   interval 2u   : G0 L(u) [DMA B, all 256 rows, of K-step u+1]              G1 M(u-1)
 //   interval 2u+1 : G0 M(u)                                                   G1 L(u) [DMA A rows 128-255 of u+1, A rows 0-127 of u+2]
 // ------------------------------------------------------------------------------------------------
+template <int EARLY>   // MFMAs of a phase issued AFTER its closing barrier (0: barrier after the last one)
 __global__ __launch_bounds__(THREADS, 2) void lab_v2(LabParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -386,6 +391,7 @@ __global__ __launch_bounds__(THREADS, 2) void lab_v2(LabParams p) {
     const int wrapA = 255 * Kp;
     const bool dma_on = !(p.flags & 1);
     const bool mfma_on = !(p.flags & 2);
+    const bool rd_on = !(p.flags & 8);     // flags bit3: fragments are read once and reused (no LDS read traffic)
     if (wave_m) __builtin_amdgcn_s_barrier();
     bf16x8 fa[2][8], fb[2][4];
 #define V2_READ(STG)                                                                                       \
@@ -428,19 +434,23 @@ __global__ __launch_bounds__(THREADS, 2) void lab_v2(LabParams p) {
     __builtin_amdgcn_sched_barrier(0);
     // end of an MFMA phase: G0 needs all its B pieces landed (read in the next interval), G1 its A rows
     // 128-255 (the first four of the eight it issued)
-#define V2_END_M()                                                                                         \
+#define V2_BAR_M()                                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
     if (wave_m) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
     __builtin_amdgcn_s_barrier();                                                                          \
     __builtin_amdgcn_sched_barrier(0);
+#define V2_END_M() if (EARLY == 0) { V2_BAR_M(); }
 #define V2_MFMA()                                                                                          \
     if (mfma_on) {                                                                                         \
         __builtin_amdgcn_s_setprio(1);                                                                     \
-        _Pragma("unroll") for (int kk_ = 0; kk_ < 2; ++kk_)                                                \
-            _Pragma("unroll") for (int mt_ = 0; mt_ < 8; ++mt_)                                            \
-                _Pragma("unroll") for (int nt_ = 0; nt_ < 4; ++nt_)                                        \
-                    acc[mt_][nt_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[kk_][mt_], fb[kk_][nt_], acc[mt_][nt_], 0, 0, 0); \
+        _Pragma("unroll") for (int i_ = 0; i_ < 64; ++i_) {                                                \
+            const int kk_ = i_ >> 5, mt_ = (i_ >> 2) & 7, nt_ = i_ & 3;                                    \
+            if (EARLY > 0 && i_ == 64 - EARLY) { V2_BAR_M(); }                                             \
+            acc[mt_][nt_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[kk_][mt_], fb[kk_][nt_], acc[mt_][nt_], 0, 0, 0); \
+        }                                                                                                  \
         __builtin_amdgcn_s_setprio(0);                                                                     \
     } else {                                                                                               \
+        if (EARLY > 0) { V2_BAR_M(); }                                                                     \
         _Pragma("unroll") for (int kk_ = 0; kk_ < 2; ++kk_) {                                              \
             _Pragma("unroll") for (int mt_ = 0; mt_ < 8; ++mt_) asm volatile("" :: "v"(fa[kk_][mt_]));     \
             _Pragma("unroll") for (int nt_ = 0; nt_ < 4; ++nt_) asm volatile("" :: "v"(fb[kk_][nt_]));     \
@@ -451,8 +461,8 @@ __global__ __launch_bounds__(THREADS, 2) void lab_v2(LabParams p) {
     if (p.clk) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
     for (int tl = 0; tl < ntl; ++tl) {
         for (int ks = 0; ks < ksteps; ks += 2) {
-            V2_READ(0); V2_DMA(0); V2_WAIT_L(); V2_MFMA(); V2_END_M();
-            V2_READ(1); V2_DMA(1); V2_WAIT_L(); V2_MFMA();
+            if (rd_on || (tl == 0 && ks == 0)) { V2_READ(0); } V2_DMA(0); V2_WAIT_L(); V2_MFMA(); V2_END_M();
+            if (rd_on) { V2_READ(1); } V2_DMA(1); V2_WAIT_L(); V2_MFMA();
             if (ks + 2 == ksteps) { LAB_MAX_ACC(); }
             V2_END_M();
         }
@@ -506,7 +516,11 @@ int main(int argc, char** argv) {
         else if (var == 1) LAB_GO(lab_v1<0>)
         else if (var == 2) LAB_GO(lab_v1<1>)
         else if (var == 3) LAB_GO(lab_v1<3>)
-        else if (var == 4) LAB_GO(lab_v2)
+        else if (var == 4) LAB_GO(lab_v2<0>)
+        else if (var == 5) LAB_GO(lab_v1<5>)
+        else if (var == 6) LAB_GO(lab_v2<12>)
+        else if (var == 7) LAB_GO(lab_v2<20>)
+        else if (var == 8) LAB_GO(lab_v1<7>)
         else { printf("unknown variant\n"); exit(1); }
     };
     // per-query maximum over the whole corpus, reduced on the host: out[wg][wave][lane][nt]
