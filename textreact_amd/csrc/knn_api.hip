@@ -283,11 +283,14 @@ static int search_batch(trx_index* idx, const void* q, int64_t nq, int is_bf, in
     nsplits = (ntiles + tps - 1) / tps;  // drop empty trailing splits
     const int kprime = k <= 12 ? 16 : 32;
     const int nlists = nsplits * LISTS_PER_SPLIT;
+    // a lane lists ~20 (kprime 16) to ~40 (kprime 32) rows per split on random data; a list that could not take another
+    // tile (32 rows) is compacted by the scan kernel, so leave room: 127 = the most a 7-bit counter counts
+    const int cap = 127, cap_alloc = cap + 1;
 
     int rc;
     if ((rc = idx->w_qg.reserve((size_t)q_pad * Kp * sizeof(bf16_t)))) return rc;
     if ((rc = idx->w_qnorm2.reserve((size_t)q_pad * sizeof(float)))) return rc;
-    if ((rc = idx->w_cand.reserve((size_t)q_pad * nlists * CAPW * sizeof(u64)))) return rc;
+    if ((rc = idx->w_cand.reserve((size_t)q_pad * nlists * cap_alloc * sizeof(u64)))) return rc;
     if ((rc = idx->w_cnt.reserve((size_t)q_pad * nlists * sizeof(u32)))) return rc;
     if ((rc = idx->w_thr.reserve((size_t)q_pad * nlists * sizeof(u64)))) return rc;
     if ((rc = idx->w_flag.reserve((size_t)(nq + 4) * sizeof(int)))) return rc;
@@ -305,7 +308,7 @@ static int search_batch(trx_index* idx, const void* q, int64_t nq, int is_bf, in
     ScanParams sp{};
     sp.corpus = idx->Cg; sp.queries = (const bf16_t*)idx->w_qg.p; sp.cbias = idx->cbias;
     sp.Kp = Kp; sp.n_valid = (int)idx->n; sp.ntiles = ntiles; sp.tiles_per_split = tps; sp.nsplits = nsplits;
-    sp.nqtiles = nqt; sp.kprime = kprime;
+    sp.nqtiles = nqt; sp.kprime = kprime; sp.cap = cap; sp.cap_alloc = cap_alloc;
     sp.cand = (u64*)idx->w_cand.p; sp.cand_cnt = (u32*)idx->w_cnt.p; sp.cand_thr = (u64*)idx->w_thr.p;
     { const char* dbg = getenv("TRX_SCAN_DEBUG"); sp.debug = dbg ? atoi(dbg) : 0; }
     sp.stamp_out = nullptr;
@@ -347,16 +350,16 @@ static int search_batch(trx_index* idx, const void* q, int64_t nq, int is_bf, in
         fprintf(stderr, "[stamp] work-mask build %.0f cycles, tracking + refresh %.0f cycles per wave and tile; per group: fetch %.0f, test + append %.0f cycles\n", sa / tiles, sb / tiles, sc / std::max(cols, 1.0), sd / std::max(cols, 1.0));
         fprintf(stderr, "[stamp] per wave and tile: bookkeeping %.0f cycles, slow path entered %.2f times, %.2f columns, %.4f compactions; "
                         "listed rows %.2f per wave and tile (%.0f per query, fullest list %u of %d)\n",
-                cyc / tiles, slow / tiles, cols / tiles, comp / tiles, app / tiles, app / (double)q_pad, mx, CAPW);
+                cyc / tiles, slow / tiles, cols / tiles, comp / tiles, app / tiles, app / (double)q_pad, mx, cap);
     }
 #endif
 
     SelectParams se{};
-    se.cand = sp.cand; se.cand_cnt = sp.cand_cnt; se.cand_thr = sp.cand_thr; se.nlists = nlists;
+    se.cand = sp.cand; se.cand_cnt = sp.cand_cnt; se.cand_thr = sp.cand_thr; se.nlists = nlists; se.cap_alloc = cap_alloc;
     if (idx->mode == MODE_SPLIT) { se.corpus_orig = idx->Co; se.ld_c = d; se.corpus_is_bf16 = 0; }
     else { se.corpus_orig = idx->Cg; se.ld_c = Kp; se.corpus_is_bf16 = 1; }
     se.query_orig = q; se.ld_q = d; se.query_is_bf16 = is_bf;
-    se.d = d; se.metric = idx->metric; se.k = k; se.nq = (int)nq; se.exact_class = exact_class;
+    se.d = d; se.metric = idx->metric; se.k = k; se.nq = (int)nq; se.n = idx->n; se.exact_class = exact_class;
     se.eps_rel = eps_rel; se.qnorm2 = (const float*)idx->w_qnorm2.p; se.ymax_norm2 = idx->maxnorm2;
     se.D = D; se.I = I; se.S64 = S64; se.flagged = flagged; se.nflagged = nflag;
     HIPCHK(launch_select(se, st));

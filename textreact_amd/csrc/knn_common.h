@@ -15,8 +15,8 @@ constexpr int TILE_M = 256;     // corpus rows per tile (MFMA M side)
 constexpr int TILE_N = 256;     // queries per workgroup (MFMA N side)
 constexpr int BK = 64;          // K-step staged through LDS
 constexpr int SCAN_THREADS = 512;
-constexpr int CAPW = 256;       // candidate slots of one list; a list belongs to one (query, corpus split, wave row)
-constexpr int LISTS_PER_SPLIT = 2;  // the two wave rows of the scan workgroup (corpus rows 0-127 / 128-255 of a tile)
+constexpr int LISTS_PER_SPLIT = 8;  // a list belongs to ONE LANE of the scan kernel: (query, corpus split, wave row 0-1, row quad 0-3);
+                                    // its slot counter lives in a register of that lane, nobody else writes the list
 constexpr int KEEP = 32;        // entries the select kernel re-scores exactly (>= TRX_FAST_MAX_K)
 
 // ---- bf16 helpers ------------------------------------------------------------------------
@@ -115,9 +115,11 @@ struct ScanParams {
     int nsplits;
     int nqtiles;             // q_pad / TILE_N
     int kprime;              // 16 or 32: rows behind a query's threshold (8 per tracked maximum of a lane)
-    u64* cand;               // [q_pad][nsplits][2][CAPW] packed (key,id), append order
-    u32* cand_cnt;           // [q_pad][nsplits][2]
-    u64* cand_thr;           // [q_pad][nsplits][2] every unlisted row of the list's rows has comp <= this
+    int cap;                 // usable slots of a list, 63 or 127 (counter = 7 bits of a packed register)
+    int cap_alloc;           // slots allocated per list (cap + 1)
+    u64* cand;               // [q_pad][nsplits][8][cap_alloc] packed (key,id), append order
+    u32* cand_cnt;           // [q_pad][nsplits][8]
+    u64* cand_thr;           // [q_pad][nsplits][8] every unlisted row of the list's rows has comp <= this
     u32* g_thr;              // [q_pad] ordkey of a key that at least kprime corpus rows reach; shared by all
                              // workgroups of a query (atomicMax, monotone; a stale read is only looser)
     int bootstrap;           // 1: threshold bootstrap launch (boot_tiles tiles per query tile, publish g_thr only)
@@ -130,7 +132,8 @@ struct SelectParams {
     const u64* cand;
     const u32* cand_cnt;
     const u64* cand_thr;
-    int nlists;               // lists per query = corpus splits x LISTS_PER_SPLIT, CAPW slots each
+    int nlists;               // lists per query = corpus splits x LISTS_PER_SPLIT
+    int cap_alloc;            // slots allocated per list
     const void* corpus_orig;  // exact values: bf16 [.. ][ld_c] or f32 [..][ld_c]
     int64_t ld_c;             // row stride in elements
     const void* query_orig;   // exact query values, bf16 or f32, row stride ld_q
@@ -141,6 +144,7 @@ struct SelectParams {
     int metric;
     int k;
     int nq;
+    int64_t n;                // corpus rows: ids >= n are pad rows of the last tile (an inner-product scan may list them)
     int exact_class;          // 1: no certificate needed
     float eps_rel;            // certificate slack, relative to bound_q
     const float* qnorm2;      // fp32 |x_q|^2 (upper-bound use only)

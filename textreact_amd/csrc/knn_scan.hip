@@ -35,8 +35,8 @@
 //   * filter: a lane's 32 keys of a tile and query are reduced to their maximum by v_max3 issued in
 //     the gaps of the tile's last 32 MFMAs; only if some lane's maximum reaches the query's threshold
 //     does the wave look at individual keys (slow path, in the NEXT load phase, under the partner's
-//     MFMAs): rows with key >= threshold are appended to the list of (query, split, wave row) --
-//     CAPW slots in HBM, slot counter in LDS, nobody else writes that list.
+//     MFMAs): rows with key >= threshold are appended to the LANE's own list (query, split, wave row, row quad):
+//     63 or 127 slots in HBM, slot counter in a register of the lane, nobody else writes that list.
 //   * threshold: each lane keeps the J best tile maxima it has seen for each of its 4 queries
 //     (J = kprime / 8).  They are maxima of J different tiles, and the 8 lanes of a query (4 row
 //     quads x 2 wave rows) see disjoint rows: the minimum over those 8 lanes of the J-th best is a
@@ -69,12 +69,11 @@ constexpr int LDS_A0 = 0;
 constexpr int LDS_B0 = 2 * TILE_M * 128;         // 65536
 constexpr int S_THRW = LDS_B0 + 2 * TILE_N * 128;  // 131072: f32 [2 wave rows][256 queries] own threshold of a wave row
 constexpr int S_GTHR = S_THRW + 2 * TILE_N * 4;  // u32 [256] copy of g_thr
-constexpr int S_CNT = S_GTHR + TILE_N * 4;       // u32 [2][256] list slot counters
-constexpr int S_THRC = S_CNT + 2 * TILE_N * 4;   // u64 [2][256] packed (key,id) floor of a compacted list (0 = none)
-constexpr int S_BIAS = S_THRC + 2 * TILE_N * 8;  // f32 [2 tile parities][256 rows]  (L2)
-constexpr int LDS_TOTAL = S_BIAS + 2 * TILE_M * 4;   // 142,336 B -> one workgroup per CU
-// ds instruction offsets are 16-bit: the selection state is addressed relative to S_THRW (4-byte arrays) / S_THRC
-constexpr int R_THRW = 0, R_GTHR = S_GTHR - S_THRW, R_CNT = S_CNT - S_THRW, R_THRC = 0;
+constexpr int S_BIAS = S_GTHR + TILE_N * 4;      // f32 [2 tile parities][256 rows]  (L2)
+constexpr int S_TRK = S_BIAS + 2 * TILE_M * 4;   // u32 [8][512 threads]: every lane's tracked tile maxima (see tile_end)
+constexpr int LDS_TOTAL = S_TRK + 8 * SCAN_THREADS * 4;   // 152,576 B -> one workgroup per CU
+// ds instruction offsets are 16-bit: the selection state is addressed relative to S_THRW
+constexpr int R_THRW = 0, R_GTHR = S_GTHR - S_THRW;
 
 // LDS accesses of the selection state go through asm: a C++ access to the array the LDS-DMA writes makes
 // hipcc drain vmcnt to 0 (cdna_hip_programming.md section 5, "Three .s-level traps").  Addresses are
@@ -108,6 +107,15 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + (bid >> 3);
 }
 
+// diagnostic builds: -DTRX_ABL=1 never lists a row (sites stay), -DTRX_ABL=2 removes the sites too (results wrong)
+#if defined(TRX_ABL) && TRX_ABL == 1
+#define TRX_SITE_COND(M) (__builtin_expect((M) == 0x123456789abcdefull, 0))
+#elif defined(TRX_ABL) && TRX_ABL == 2
+#define TRX_SITE_COND(M) false
+#else
+#define TRX_SITE_COND(M) (__builtin_expect((M) != 0ull, 0))
+#endif
+
 template <int N> struct ic { static constexpr int value = N; };
 
 // lane id, recomputed where it is needed (volatile: hipcc would otherwise hoist everything derived from the lane id out
@@ -119,25 +127,55 @@ __device__ __forceinline__ u32 lane_now() {
 }
 
 __device__ __forceinline__ float max3f(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
+// maximum of 8 accumulator values in 4 instructions (asm: hipcc canonicalises every operand of fmaxf with an extra v_max)
+__device__ __forceinline__ float max8f(const f32x4& a, const f32x4& b) {
+    float g;
+    asm("v_max_f32 %0, %1, %2\n\tv_max3_f32 %0, %0, %3, %4\n\tv_max3_f32 %0, %0, %5, %6\n\tv_max3_f32 %0, %0, %7, %8"
+        : "=&v"(g) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]));
+    return g;
+}
+// maximum of the 4 values of an accumulator tile in 2 instructions
+__device__ __forceinline__ float max4f(const f32x4& a) {
+    float g;
+    asm("v_max_f32 %0, %1, %2\n\tv_max3_f32 %0, %0, %3, %4" : "=&v"(g) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]));
+    return g;
+}
+// f32 -> bf16 bits rounded toward -infinity (a tracked maximum may only get smaller: it stays a valid lower bound)
+__device__ __forceinline__ u32 bf16_floor(float f) {
+    const u32 u = __float_as_uint(f);
+    return (u >> 16) + ((u >> 31) & ((u & 0xffffu) != 0u ? 1u : 0u));
+}
+// lanes with x >= y, straight into a scalar register pair
+__device__ __forceinline__ u64 mask_ge(float x, float y) {
+    u64 mk;
+    asm("v_cmp_ge_f32 %0, %1, %2" : "=s"(mk) : "v"(x), "v"(y));
+    return mk;
+}
 
-// A full list (CAPW entries, all written by this wave) is cut to its kprime best by (key desc, id asc).
+// store v to p in the lanes of `mask`, no branch (a skipped store costs a taken branch otherwise: ~30 cycles, and the
+// slow path below is mostly branches)
+__device__ __forceinline__ void store_masked(u64 mask, u64* p, u64 v) {
+    u64 saved;
+    asm volatile("s_and_saveexec_b64 %0, %1\n\tglobal_store_dwordx2 %2, %3, off\n\ts_mov_b64 exec, %0\n\ts_nop 0"
+                 : "=&s"(saved) : "s"(mask), "v"(p), "v"(v) : "memory");
+}
+
+// A list (`cap` valid entries, all written by ONE lane of this wave) is cut to its kprime best by (key desc, id asc).
 // Wave-wide; rare (see the header).  Returns the packed value in kprime-th place.
-__device__ __forceinline__ u64 compact_list(u64* list, int kprime, int lane) {
+__device__ __forceinline__ u64 compact_list(u64* list, int cap, int kprime, int lane) {
     __builtin_amdgcn_s_waitcnt(0);     // this wave's own stores to the list have left
-    u64 e[CAPW / 64];
+    u64 e[2];
 #pragma unroll
-    for (int i = 0; i < CAPW / 64; ++i) e[i] = ld_u64_l2(list + lane + 64 * i);   // L2: never a stale L1 line of this CU
+    for (int i = 0; i < 2; ++i) e[i] = (lane + 64 * i) < cap ? ld_u64_l2(list + lane + 64 * i) : 0ull;   // L2: never a stale L1 line
     u64 out = 0ull, last = 0ull;
     for (int t = 0; t < kprime; ++t) {
-        u64 m = e[0];
-#pragma unroll
-        for (int i = 1; i < CAPW / 64; ++i) m = e[i] > m ? e[i] : m;
+        u64 m = e[0] > e[1] ? e[0] : e[1];
 #pragma unroll
         for (int s = 1; s < 64; s <<= 1) { const u64 o = shfl_xor_u64(m, s); m = o > m ? o : m; }
         if (lane == t) out = m;
         last = m;
 #pragma unroll
-        for (int i = 0; i < CAPW / 64; ++i) if (e[i] == m) e[i] = 0ull;     // packed values are unique (ids are)
+        for (int i = 0; i < 2; ++i) if (e[i] == m) e[i] = 0ull;     // packed values are unique (ids are); a row listed twice goes once
     }
     if (lane < kprime) list[lane] = out;
     return last;
@@ -208,17 +246,18 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
     // partner's row, row 0 (arrays without a wave-row dimension use b4_0)
     const u32 b4_0 = lds0 + S_THRW + ql0 * 4;
     const u32 b4_m = b4_0 + wave_m * 1024, b4_p = b4_0 + (wave_m ^ 1) * 1024;
-    const u32 b8_m = lds0 + S_THRC + wave_m * 2048 + ql0 * 8;
+    {   // tracked maxima of this thread: -inf (fp32, J = 2) / a pair of bf16 -inf (J = 4)
+        const u32 a_trk = lds0 + S_TRK + tid * 4;
+        const u32 ninf = J == 2 ? 0xff800000u : 0xff80ff80u;
+        lds_st32<0>(a_trk, ninf); lds_st32<2048>(a_trk, ninf); lds_st32<4096>(a_trk, ninf); lds_st32<6144>(a_trk, ninf);
+        lds_st32<8192>(a_trk, ninf); lds_st32<10240>(a_trk, ninf); lds_st32<12288>(a_trk, ninf); lds_st32<14336>(a_trk, ninf);
+    }
     if (tid < TILE_N) {
         const u32 g = BOOT ? 0u : __hip_atomic_load(p.g_thr + qbase + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const u32 t4 = lds0 + S_THRW + tid * 4, t8 = lds0 + S_THRC + tid * 8;
+        const u32 t4 = lds0 + S_THRW + tid * 4;
         lds_st32<R_GTHR>(t4, g);
         lds_st32<R_THRW>(t4, __float_as_uint(NEG_INF));
         lds_st32<R_THRW + 1024>(t4, __float_as_uint(NEG_INF));
-        lds_st32<R_CNT>(t4, 0u);
-        lds_st32<R_CNT + 1024>(t4, 0u);
-        lds_st64<R_THRC>(t8, 0ull);
-        lds_st64<R_THRC + 2048>(t8, 0ull);
     }
 
     f32x4 acc[8][4];
@@ -229,10 +268,10 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
         for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = zero4;
     if (ntl == 0) {
         // nothing to scan (only possible for an empty split): publish empty lists
-        if (!BOOT && fq == 0) {
+        if (!BOOT) {
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-                const int64_t o = ((qbase + ql0 + 16 * nt) * p.nsplits + split) * LISTS_PER_SPLIT + wave_m;
+                const int64_t o = (((qbase + ql0 + 16 * nt) * p.nsplits + split) * 2 + wave_m) * 4 + fq;
                 p.cand_cnt[o] = 0u; p.cand_thr[o] = 0ull;
             }
         }
@@ -260,14 +299,12 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
         __builtin_amdgcn_s_barrier();
     }
     // thresholds of this lane's four queries (identical in the 4 lanes of a query)
-    float thrk[4], trk[J][4], m[4];
-    u32 bits[4] = {0u, 0u, 0u, 0u};     // per-lane "group mt of column nt holds a key >= threshold" (bit 7 - mt), last tile
+    float thrk[4], m[4];
+    u32 cnt4 = 0u;      // this lane's four list counters, one byte each: bits 0-6 count, bit 7 = list was compacted (has a floor)
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
         thrk[nt] = NEG_INF;
         m[nt] = NEG_INF;
-#pragma unroll
-        for (int j = 0; j < J; ++j) trk[j][nt] = NEG_INF;
     }
 
     {
@@ -285,7 +322,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
     const int wrapA = 255 * Kp;       // added when a K-step cursor moves on to the next tile
     const bool dbg_nodma = (p.debug & 1) != 0;
     const bool dbg_nofilter = (p.debug & 2) != 0;
-    const bool dbg_noslow = (p.debug & 4) != 0, dbg_norefresh = (p.debug & 8) != 0;   // timing-only: results are wrong
+    const bool dbg_norefresh = (p.debug & 8) != 0;   // timing-only: results are wrong
 
     if (wave_m) __builtin_amdgcn_s_barrier();       // group 1 runs one interval late
 
@@ -364,129 +401,99 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
         const int ql0 = wave_n * 64 + frow;
         const u32 b4_0 = lds0 + S_THRW + ql0 * 4;
         const u32 b4_m = b4_0 + wave_m * 1024, b4_p = b4_0 + (wave_m ^ 1) * 1024;
-        const u32 b8_m = lds0 + S_THRC + wave_m * 2048 + ql0 * 8;
         // ---- slow path: some lane's tile maximum reached its query's threshold ----
-        const bool hit = (bits[0] | bits[1] | bits[2] | bits[3]) != 0u;
-        if (!BOOT && !dbg_noslow && __any(hit)) {
-#ifdef TRX_STAMP_BUILD
-            ++st_slow;
-#endif
-            // At 4 splits per query tile a workgroup sees 977 tiles and its waves append ~5 rows per tile on average
-            // (70 at the start): this path runs on most tiles and has to stay cheap -- and small: with 128 accumulator
-            // registers live, anything hipcc spills here is reloaded through the VMEM queue, thousands of cycles each
-            // behind the LDS-DMA traffic.  So: ONE copy of the per-group code in a loop over the groups that hold a hit
-            // (wave-uniform 32-bit work mask, group = 4 rows x one query column), the group's accumulator fetched by a
-            // switch over its 32 possible homes.
-#ifdef TRX_STAMP_BUILD
-            const unsigned long long st_t1 = __builtin_readcyclecounter();
-#endif
-            u32 work = 0u;
+        // ---- room for the next tile: a lane lists at most 32 rows of a tile per column.  A list that could overflow is
+        // cut to its kprime best (key desc, id asc) NOW, by the whole wave; its lane's threshold rises to the key in
+        // kprime-th place and the packed value in kprime-th place becomes the list's floor (cand_thr).  Rare: ~20 rows
+        // are listed per list on random data (tie-heavy or adversarially ordered corpora get here, and stay exact).
+        if (!BOOT) {
+            const u32 lim = (u32)(p.cap - 32);
+            bool need = false;
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                if (!__any(bits[nt] != 0u)) continue;
+            for (int nt = 0; nt < 4; ++nt) need = need || (((cnt4 >> (8 * nt)) & 0x7fu) > lim);
+            if (__builtin_expect(__any(need), 0)) {
+                const int64_t li0 = (((qbase + ql0) * p.nsplits + split) * 2 + wave_m) * 4 + fq;
+                const int64_t colstride = (int64_t)16 * p.nsplits * LISTS_PER_SPLIT;
 #pragma unroll
-                for (int mt = 0; mt < 8; ++mt)
-                    if (__any((bits[nt] & (0x80u >> mt)) != 0u)) work |= 1u << (nt * 8 + mt);
-            }
-#ifdef TRX_STAMP_BUILD
-            const unsigned long long st_t2 = __builtin_readcyclecounter();
-            st_a += st_t2 - st_t1;
-#endif
-            while (work) {
-                const int gidx = __builtin_amdgcn_readfirstlane(__builtin_ctz(work));
-                work &= work - 1u;
-                const int nt = gidx >> 3, mt = gidx & 7;
-#ifdef TRX_STAMP_BUILD
-                ++st_cols;
-#endif
-#ifdef TRX_STAMP_BUILD
-                const unsigned long long st_t4 = __builtin_readcyclecounter();
-#endif
-                f32x4 x = zero4;
-                switch (gidx) {
-#define TRX_FETCH(G) case G: x = acc[(G) & 7][(G) >> 3]; break;
-                    TRX_FETCH(0) TRX_FETCH(1) TRX_FETCH(2) TRX_FETCH(3) TRX_FETCH(4) TRX_FETCH(5) TRX_FETCH(6) TRX_FETCH(7)
-                    TRX_FETCH(8) TRX_FETCH(9) TRX_FETCH(10) TRX_FETCH(11) TRX_FETCH(12) TRX_FETCH(13) TRX_FETCH(14) TRX_FETCH(15)
-                    TRX_FETCH(16) TRX_FETCH(17) TRX_FETCH(18) TRX_FETCH(19) TRX_FETCH(20) TRX_FETCH(21) TRX_FETCH(22) TRX_FETCH(23)
-                    TRX_FETCH(24) TRX_FETCH(25) TRX_FETCH(26) TRX_FETCH(27) TRX_FETCH(28) TRX_FETCH(29) TRX_FETCH(30) TRX_FETCH(31)
-#undef TRX_FETCH
-                    default: break;
-                }
-#ifdef TRX_STAMP_BUILD
-                asm volatile("" :: "v"(x));
-                const unsigned long long st_t5 = __builtin_readcyclecounter();
-                st_c += st_t5 - st_t4;
-#endif
-                const float tk = nt == 0 ? thrk[0] : nt == 1 ? thrk[1] : nt == 2 ? thrk[2] : thrk[3];
-                const u32 bb = nt == 0 ? bits[0] : nt == 1 ? bits[1] : nt == 2 ? bits[2] : bits[3];
-                const bool sel = (bb & (0x80u >> mt)) != 0u;
-                const u32 a_cnt = b4_m + R_CNT + 64 * nt, a_thc = b8_m + R_THRC + 128 * nt;
-                u64* cq = p.cand + (((qbase + ql0 + 16 * nt) * p.nsplits + split) * LISTS_PER_SPLIT + wave_m) * CAPW;
-                const u32 id0 = (u32)(tile_row0 + wave_m * 128 + mt * 16 + fq * 4);
-                // pass 0; if a list fills up, its wave cuts it to its kprime best and pass 1 repeats the group under the
-                // new floor (a row stored twice is harmless: knn_select drops equal packed values; after the cut the
-                // list has room for a group, so pass 1 cannot fail)
-                for (int rep = 0; rep < 2; ++rep) {
-                    bool ovf = false;
-                    if (sel) {
-                        const u64 tc = lds_ld64<0>(a_thc);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float h = x[r];
-                            if (h >= tk) {
-                                const u32 id = id0 + r;
-                                const u64 c = make_comp(KS * h + 0.0f, id);     // key; -0 -> +0
-                                if (id < (u32)p.n_valid && c > tc) {
-                                    const u32 pos = lds_inc<0>(a_cnt);
-                                    if (pos < (u32)CAPW) cq[pos] = c;
-                                    else ovf = true;
-                                }
-                            }
-                        }
-                    }
-#ifdef TRX_STAMP_BUILD
-                    if (rep == 0) st_d += __builtin_readcyclecounter() - st_t5;
-#endif
-                    u64 om = __ballot(ovf);
-                    if (!om) break;
+                for (int nt = 0; nt < 4; ++nt) {
+                    u64 om = __ballot(((cnt4 >> (8 * nt)) & 0x7fu) > lim);
                     while (om) {
                         const int l = __ffsll((long long)om) - 1;
-                        const int qsel = wave_n * 64 + 16 * nt + (l & 15);
-                        u64* lq = p.cand + (((qbase + qsel) * p.nsplits + split) * LISTS_PER_SPLIT + wave_m) * CAPW;
-                        const u64 floor_c = compact_list(lq, p.kprime, lane);
+                        om &= om - 1ull;
+                        const int64_t li = li0 + nt * colstride;
+                        const int64_t lsel = (int64_t)shfl_u64((u64)li, l);
+                        const int ncur = (int)__shfl((int)((cnt4 >> (8 * nt)) & 0x7fu), l, 64);
+                        const u64 floor_c = compact_list(p.cand + lsel * p.cap_alloc, ncur, p.kprime, lane);
 #ifdef TRX_STAMP_BUILD
                         ++st_comp;
 #endif
-                        if (lane == 0) {
-                            lds_st32<R_CNT>(lds0 + S_THRW + wave_m * 1024 + qsel * 4, (u32)p.kprime);
-                            lds_st64<R_THRC>(lds0 + S_THRC + wave_m * 2048 + qsel * 8, floor_c);
+                        if (lane == l) {
+                            cnt4 = (cnt4 & ~(0xffu << (8 * nt))) | ((u32)(p.kprime | 0x80) << (8 * nt));
+                            const u64 old = (cnt4 >> (8 * nt)) & 0x80u ? 0ull : 0ull;
+                            (void)old;
+                            p.cand_thr[li] = floor_c;
+                            thrk[nt] = __builtin_fmaxf(thrk[nt], KI * comp_key(floor_c));
                         }
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                        om &= ~(0x0001000100010001ull << (l & 15));
                     }
                 }
+                __builtin_amdgcn_s_waitcnt(0);
             }
         }
 #ifdef TRX_STAMP_BUILD
         const unsigned long long st_t3 = __builtin_readcyclecounter();
 #endif
-        // ---- the J best tile maxima of this lane (pad-row tiles of an inner-product index do not count) ----
-        if (full_tile) {
+        // ---- the J best tile maxima of this lane (pad-row tiles of an inner-product index do not count).  They live in
+        // LDS between tiles (8 dwords per thread; J = 4: sixteen values as bf16 pairs, rounded DOWN, so that they stay
+        // lower bounds): as registers hipcc spilled them, and a spill reload waits out the whole VMEM queue.
+        float trk[J][4];
+        {
+            const u32 a_trk = lds0 + S_TRK + (u32)(wave * 64 + lane) * 4;
+            u32 w[8];
+            asm volatile("ds_read_b32 %0, %8\n\tds_read_b32 %1, %8 offset:2048\n\tds_read_b32 %2, %8 offset:4096\n\tds_read_b32 %3, %8 offset:6144\n\t"
+                         "ds_read_b32 %4, %8 offset:8192\n\tds_read_b32 %5, %8 offset:10240\n\tds_read_b32 %6, %8 offset:12288\n\tds_read_b32 %7, %8 offset:14336\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5]), "=&v"(w[6]), "=&v"(w[7])
+                         : "v"(a_trk) : "memory");
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-                float a = m[nt];
+                if (J == 2) { trk[0][nt] = __uint_as_float(w[nt]); trk[J - 1][nt] = __uint_as_float(w[4 + nt]); }
+                else {
 #pragma unroll
-                for (int j = 0; j < J; ++j) {
-                    const float hi = __builtin_fmaxf(trk[j][nt], a);
-                    a = __builtin_fminf(trk[j][nt], a);
-                    trk[j][nt] = hi;
+                    for (int j = 0; j < J; ++j) trk[j][nt] = __uint_as_float(((j & 1) ? (w[(j >> 1) * 4 + nt] & 0xffff0000u) : (w[(j >> 1) * 4 + nt] << 16)));
                 }
             }
+            if (full_tile) {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    float a = m[nt];
+#pragma unroll
+                    for (int j = 0; j < J; ++j) {
+                        const float hi = __builtin_fmaxf(trk[j][nt], a);
+                        a = __builtin_fminf(trk[j][nt], a);
+                        trk[j][nt] = hi;
+                    }
+                }
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    if (J == 2) { w[nt] = __float_as_uint(trk[0][nt]); w[4 + nt] = __float_as_uint(trk[J - 1][nt]); }
+                    else {
+#pragma unroll
+                        for (int jp = 0; jp < J / 2; ++jp) {
+                            const u32 lo = bf16_floor(trk[2 * jp][nt]), hi = bf16_floor(trk[2 * jp + 1][nt]);
+                            w[jp * 4 + nt] = lo | (hi << 16);
+                            trk[2 * jp][nt] = __uint_as_float(lo << 16); trk[2 * jp + 1][nt] = __uint_as_float(hi << 16);
+                        }
+                    }
+                }
+                lds_st32<0>(a_trk, w[0]); lds_st32<2048>(a_trk, w[1]); lds_st32<4096>(a_trk, w[2]); lds_st32<6144>(a_trk, w[3]);
+                if (J == 2) { lds_st32<8192>(a_trk, w[4]); lds_st32<10240>(a_trk, w[5]); lds_st32<12288>(a_trk, w[6]); lds_st32<14336>(a_trk, w[7]); }
+                else { lds_st32<8192>(a_trk, w[4]); lds_st32<10240>(a_trk, w[5]); lds_st32<12288>(a_trk, w[6]); lds_st32<14336>(a_trk, w[7]); }
+            }
         }
-        // ---- threshold refresh (every second tile): min over the query's 4 lanes of this wave, then the partner wave
+        // ---- threshold refresh (every eighth tile): min over the query's 4 lanes of this wave, then the partner wave
         // row's value and the other splits' through LDS.  All LDS traffic of the 4 columns is issued together and
         // waited for once (one access at a time cost 8 ms per search).
-        if (!dbg_norefresh && (BOOT || (TL & 1))) {
+        if (!dbg_norefresh && (BOOT || (TL & 7) == 7)) {
             float g[4];
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) g[nt] = trk[J - 1][nt];
@@ -512,7 +519,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
                 float t = __builtin_fmaxf(thrk[nt], both);
                 if (gs[nt]) t = __builtin_fmaxf(t, KI * ordkey_inv(gs[nt]));               // what the other splits have published
                 thrk[nt] = t;
-                if (!BOOT && (TL & 7) == 3 && wave_m == 0 && fq == 0 && both > NEG_INF)    // tell the other splits, now and then
+                if (!BOOT && (TL & 31) == 31 && wave_m == 0 && fq == 0 && both > NEG_INF)    // tell the other splits, now and then
                     __hip_atomic_fetch_max(p.g_thr + qbase + ql0 + 16 * nt, ordkey(KS * both), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
@@ -531,35 +538,27 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
     // regular pieces (the other splits' thresholds every 8 tiles, wave 1; the next tile's bias, L2, wave 2)
 #define TRX_PAIR_HEAD()                                                                                    \
     {                                                                                                      \
-        const bool aux_g = !BOOT && wave == 1 && (tl & 7) == 7;                                            \
+        const bool aux_g = !BOOT && wave == 1 && (tl & 31) == 15;                                          \
         const bool aux_b = L2 && wave == 2;                                                                \
-        if (tl > 0 && !dbg_nofilter) {                                                                     \
-            /* the bookkeeping issues stores / atomics (and whatever hipcc spills), which count in vmcnt like the  \
-               DMA pieces: retire the previous load phase's pieces first (two intervals old), do the bookkeeping    \
-               with no DMA in flight and no fragment live, and wait for nothing at the end; the next load phase's   \
-               vmcnt(4) covers everything issued here */                                                    \
-            if (!(p.debug & 16)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          \
-            /* the partner wave on this SIMD is issuing MFMAs at priority 1 meanwhile: without a higher priority the   \
-               bookkeeping below gets the leftover issue slots and runs 2-3x slower -- and it is the critical path */  \
-            __builtin_amdgcn_s_setprio(3);                                                                 \
-            tile_end(tl - 1);                                                                              \
-            __builtin_amdgcn_s_setprio(0);                                                                 \
-            __builtin_amdgcn_sched_barrier(0);                                                             \
-            TRX_READ(0, 0);                                                                                \
-            TRX_READ_BIAS();                                                                               \
-            if (aux_g) __builtin_amdgcn_global_load_lds((gbl_void*)(p.g_thr + qbase + lane * 4), (lds_void*)(smem + S_GTHR), 16, 0, 0); \
-            if (aux_b) __builtin_amdgcn_global_load_lds((gbl_void*)(p.cbias + (int64_t)(tile0 + tl + 1) * TILE_M + lane * 4), \
-                                                        (lds_void*)(smem + S_BIAS + ((tl + 1) & 1) * 1024), 16, 0, 0); \
-            TRX_DMA_B(1);                                                                                  \
-            if (p.debug & 16) { TRX_WAIT_L(5); } else { TRX_WAIT_L(63); }                                  \
-        } else {                                                                                           \
-            TRX_READ(0, 0);                                                                                \
-            TRX_READ_BIAS();                                                                               \
-            if (aux_b) __builtin_amdgcn_global_load_lds((gbl_void*)(p.cbias + (int64_t)(tile0 + tl + 1) * TILE_M + lane * 4), \
-                                                        (lds_void*)(smem + S_BIAS + ((tl + 1) & 1) * 1024), 16, 0, 0); \
-            TRX_DMA_B(1);                                                                                  \
-            if (aux_b) { TRX_WAIT_L(5); } else { TRX_WAIT_L(4); }                                          \
+        const bool strict = tl > 0 && !dbg_nofilter && (BOOT || ((tl - 1) & 31) == 31);                    \
+        if (strict) {                                                                                      \
+            /* bookkeeping that publishes thresholds to g_thr issues atomics, which count in vmcnt like the DMA    \
+               pieces: retire the previous load phase's pieces first (two intervals old) and wait for nothing at   \
+               the end; the next load phase's vmcnt(4) covers everything issued here */                      \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                               \
         }                                                                                                  \
+        if (tl > 0 && !dbg_nofilter) {                                                                     \
+            /* the partner wave on this SIMD is issuing MFMAs meanwhile */                                  \
+            tile_end(tl - 1);                                                                              \
+            __builtin_amdgcn_sched_barrier(0);                                                             \
+        }                                                                                                  \
+        TRX_READ(0, 0);                                                                                    \
+        TRX_READ_BIAS();                                                                                   \
+        if (aux_g) __builtin_amdgcn_global_load_lds((gbl_void*)(p.g_thr + qbase + lane * 4), (lds_void*)(smem + S_GTHR), 16, 0, 0); \
+        if (aux_b) __builtin_amdgcn_global_load_lds((gbl_void*)(p.cbias + (int64_t)(tile0 + tl + 1) * TILE_M + lane * 4), \
+                                                    (lds_void*)(smem + S_BIAS + ((tl + 1) & 1) * 1024), 16, 0, 0); \
+        TRX_DMA_B(1);                                                                                      \
+        if (strict) { TRX_WAIT_L(63); } else if (aux_g || aux_b) { TRX_WAIT_L(5); } else { TRX_WAIT_L(4); } \
     }
 #define TRX_PAIR_HEAD_PLAIN()                                                                              \
     {                                                                                                      \
@@ -592,18 +591,45 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
             TRX_MFMA_ACC();                                                                                \
         } else {                                                                                           \
             /* last 32 MFMAs of the tile.  In their gaps, for every finished group of 4 accumulator rows (mt, nt): \
-               its maximum g (2 VALU), the lane's tile maximum m (1), and one bit "g reaches the query's threshold"  \
-               shifted into bits[nt] (v_cmp + v_addc: bits = 2 bits + carry; group mt ends up at bit 7 - mt) */     \
+               its maximum g (2 VALU) and the lane's tile maximum m (1); if g reaches the query's threshold in ANY   \
+               lane (v_cmp + one scalar branch, rarely taken: ~3 of the 32 groups of a tile once the thresholds are   \
+               warm) the group's rows that pass are listed right here, where the group is a known register: masked   \
+               stores into the lane's own list, counter in a byte of cnt4.  Room for a whole tile (32 rows per list)  \
+               is guaranteed by the check at the end of the previous tile's bookkeeping. */                           \
             __builtin_amdgcn_s_setprio(1);                                                                 \
-            _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) { m[nt] = NEG_INF; bits[nt] = 0u; }           \
-            _Pragma("unroll") for (int mt = 0; mt < 9; ++mt) {                                             \
+            _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) m[nt] = NEG_INF;                              \
+            const u32 lane_l = lane_now();                                                                 \
+            const int tile_row0_l = (tile0 + tl) * TILE_M;                                                 \
+            const u32 id_l = (u32)(tile_row0_l + wave_m * 128) + (lane_l >> 4) * 4u;                       \
+            u64* const lp_l = p.cand + ((((qbase + wave_n * 64 + (lane_l & 15)) * p.nsplits + split) * 2 + wave_m) * 4 + (lane_l >> 4)) * p.cap_alloc; \
+            const int64_t colstride_l = (int64_t)16 * p.nsplits * LISTS_PER_SPLIT * p.cap_alloc;          \
+            /* slot (mt, nt) = the gap behind MFMA (mt, nt).  Group (mt - 1, nt) -- 4 rows, one query column -- is   \
+               reduced in slot (mt, nt), one row of MFMAs after it is complete (no wait for the MFMA result), and    \
+               tested in slot (mt + 1, nt), one row later again (no v_cmp -> s_cmp -> s_cbranch chain inside a       \
+               16-cycle gap; an untaken test costs nothing measurable). */                                           \
+            u64 hA_[4] = {0ull, 0ull, 0ull, 0ull}, hB_[4] = {0ull, 0ull, 0ull, 0ull};                      \
+            _Pragma("unroll") for (int mt = 0; mt < 10; ++mt) {                                            \
                 _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) {                                         \
                     if (mt < 8) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mt], fb[nt], acc[mt][nt], 0, 0, 0); \
-                    if (mt >= 1) {                                                                         \
-                        const f32x4 a = acc[mt - 1][nt];                                                   \
-                        const float g = max3f(__builtin_fmaxf(a[0], a[1]), a[2], a[3]);                    \
+                    hB_[nt] = hA_[nt];                                                                     \
+                    if (mt >= 1 && mt < 9) {                /* reduce group mt - 1 */                        \
+                        const float g = max4f(acc[mt - 1][nt]);                                            \
                         m[nt] = __builtin_fmaxf(m[nt], g);                                                 \
-                        asm volatile("v_cmp_ge_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits[nt]) : "v"(g), "v"(thrk[nt]) : "vcc"); \
+                        hA_[nt] = mask_ge(g, thrk[nt]);                                                    \
+                    }                                                                                      \
+                    if (mt >= 2 && !BOOT && TRX_SITE_COND(hB_[nt])) {       /* list rows of group mt - 2 */   \
+                        const float tk_ = thrk[nt];                                                        \
+                        u64* const lq_ = lp_l + nt * colstride_l + ((cnt4 >> (8 * nt)) & 0x7fu);           \
+                        u32 ns_ = 0u;                                                                      \
+                        _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                    \
+                            const float a_ = acc[mt - 2][nt][r];                                           \
+                            const u64 pk_ = mask_ge(a_, tk_);                                              \
+                            if (pk_) {                                                                     \
+                                store_masked(pk_, lq_ + ns_, make_comp(KS * a_ + 0.0f, id_l + (mt - 2) * 16 + r)); \
+                                asm volatile("v_addc_co_u32 %0, vcc, 0, %0, %1" : "+v"(ns_) : "s"(pk_) : "vcc"); \
+                            }                                                                              \
+                        }                                                                                  \
+                        cnt4 += ns_ << (8 * nt);                                                           \
                     }                                                                                      \
                     __builtin_amdgcn_sched_barrier(0);                                                     \
                 }                                                                                          \
@@ -648,18 +674,19 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
         o[0] = st_cyc | (st_d << 36); o[1] = st_slow | (st_a << 20); o[2] = st_comp | (st_cols << 16) | (st_c << 36); o[3] = (unsigned long long)ntl | (st_b << 20);
     }
 #endif
-    // ---- publish count and bound of this wave's 64 lists ----
-    if (fq == 0) {
-        auto publ = [&](auto NT) {
-            constexpr int nt = decltype(NT)::value;
-            const int64_t o = ((qbase + ql0 + 16 * nt) * p.nsplits + split) * LISTS_PER_SPLIT + wave_m;
-            const u32 c = lds_ld32<R_CNT + 64 * nt>(b4_m);
-            const u64 tc = lds_ld64<R_THRC + 128 * nt>(b8_m);
-            const u64 tkc = thrk[nt] > NEG_INF ? ((u64)ordkey(KS * thrk[nt]) << 32) : 0ull;   // rows never listed have key < KS thrk
-            p.cand_cnt[o] = c < (u32)CAPW ? c : (u32)CAPW;
-            p.cand_thr[o] = tc > tkc ? tc : tkc;
-        };
-        publ(ic<0>{}); publ(ic<1>{}); publ(ic<2>{}); publ(ic<3>{});
+    // ---- publish count and bound of this lane's 4 lists ----
+    {
+        const int lane_ = (int)lane_now();
+        const int fq_ = lane_ >> 4, ql_ = wave_n * 64 + (lane_ & 15);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int64_t li = (((qbase + ql_ + 16 * nt) * p.nsplits + split) * 2 + wave_m) * 4 + fq_;
+            const u32 c4 = (cnt4 >> (8 * nt)) & 0xffu;
+            u64 bound = thrk[nt] > NEG_INF ? ((u64)ordkey(KS * thrk[nt]) << 32) : 0ull;   // rows never listed have key < KS thrk
+            if (c4 & 0x80u) { const u64 fl = ld_u64_l2(p.cand_thr + li); bound = fl > bound ? fl : bound; }
+            p.cand_cnt[li] = c4 & 0x7fu;
+            p.cand_thr[li] = bound;
+        }
     }
 }
 

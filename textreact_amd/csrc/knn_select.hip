@@ -117,10 +117,10 @@ __global__ __launch_bounds__(256) void knn_select_kernel(SelectParams p) {
     for (int l = 0; l < p.nlists; ++l) {
         const int64_t o = (int64_t)q * p.nlists + l;
         const int c = (int)p.cand_cnt[o];
-        const u64* cq = p.cand + o * CAPW;
+        const u64* cq = p.cand + o * p.cap_alloc;
         for (int base = 0; base < c; base += 64) {
             const u64 e = (base + lane) < c ? cq[base + lane] : 0ull;
-            const bool keep = e != 0ull && e >= T;
+            const bool keep = e != 0ull && e >= T && (int64_t)comp_id(e) < p.n;
             const u64 km = __ballot(keep);
             if (keep) qu[qn + __popcll(km & ((1ull << lane) - 1ull))] = e;
             qn += __popcll(km);
