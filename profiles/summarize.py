@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Turn the rocprofv3 output of profiles/run_profile.sh <tag> (gpurun_out/prof_<tag>) into the committed summaries:
+profiles/<tag>_kernel_stats.csv, profiles/<tag>_pmc_summary.json and profiles/traffic.json (what bench.py reports as
+roofline.traffic).  FETCH_SIZE is doubled (gfx950 reads half of a wide coalesced stream, MI355X_MICROARCH.md, HBM);
+Infinity-Cache hits are counted, so the figure is L2-miss traffic, an upper bound of the HBM bytes."""
+import csv, glob, json, os, shutil, sys, collections
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", "prof_" + tag)
+stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
+assert stats, "no kernel_stats.csv under " + src
+shutil.copy(stats[0], os.path.join(root, "profiles", tag + "_kernel_stats.csv"))
+
+
+def counters(sub):
+    agg = collections.defaultdict(list)
+    name = None
+    for f in glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "knn_scan_kernel" in r["Kernel_Name"] and "true>" not in r["Kernel_Name"].split("(")[0][-6:]:
+                agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                name = r["Kernel_Name"]
+    return {k: sum(v) / len(v) for k, v in agg.items()}, name
+
+
+avg_ms = None
+for r in csv.DictReader(open(stats[0])):
+    if "knn_scan_kernel" in r["Name"] and r["Name"].rstrip(")").split("<")[1].split(">")[0].endswith("false"):
+        avg_ms = float(r["AverageNs"]) / 1e6
+        kname = r["Name"]
+fetch, _ = counters("pmc_fetch")
+write, _ = counters("pmc_write")
+sq, _ = counters("pmc_sq")
+fetch_kb, write_kb = fetch.get("FETCH_SIZE"), write.get("WRITE_SIZE")
+out = {
+    "command": "python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline (profiles/run_profile.sh %s: one rocprofv3 pass for "
+               "--kernel-trace --stats, one --pmc pass per counter group)" % tag,
+    "kernel": kname, "avg_launch_ms_kernel_trace": avg_ms, "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb,
+    "correction": "gfx950: FETCH_SIZE reads half of a wide (16 B/lane) coalesced stream -> doubled (MI355X_MICROARCH.md, HBM); "
+                  "WRITE_SIZE exact; Infinity-Cache hits are counted, so this is L2-miss traffic = an upper bound of HBM bytes",
+    "hbm_bytes_per_launch": (2 * fetch_kb + write_kb) * 1024 if fetch_kb is not None and write_kb is not None else None,
+    "algorithmic_bytes_per_launch": 2 * (1000000 * 768 + 65536 * 768) + 65536 * 10 * 8,
+    "sq": sq,
+}
+json.dump(out, open(os.path.join(root, "profiles", "traffic.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(root, "profiles", tag + "_pmc_summary.json"), "w"), indent=1)
+print(json.dumps(out, indent=1))

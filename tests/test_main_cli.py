@@ -1,0 +1,130 @@
+"""`python -m textreact_amd.main`: the reference's flag surface (main.py:26-97) and the train / validate / test /
+resume cycle with its files (best.ckpt, last.ckpt, prediction_{split}_{i}.json), on CPU with toy tensors."""
+import glob
+import json
+import os
+import re
+import shlex
+
+import pytest
+import torch
+
+from textreact_amd import main as M
+
+REF_SCRIPTS = "/root/reference/scripts"
+
+
+def _script_argv(path):
+    """the argument list a scripts/train_*.sh hands to main.py, shell variables expanded the way bash would"""
+    text = open(path).read()
+    env = {}
+    for m in re.finditer(r"^([A-Z_]+)=(.*)$", text, re.M):
+        env[m.group(1)] = m.group(2).strip()
+    cmd = text[text.index("python main.py") + len("python main.py"):]
+    cmd = cmd.replace("\\\n", " ")
+
+    def arith(m):
+        expr = re.sub(r"[A-Z_]+", lambda v: env[v.group(0)], m.group(1))
+        return str(int(eval(expr.replace("/", "//"))))
+    cmd = re.sub(r"\$\(\((.*?)\)\)", arith, cmd)
+    cmd = re.sub(r"\$\{([A-Z_]+)\}", lambda m: env[m.group(1)], cmd)
+    cmd = re.sub(r"\$([A-Z_]+)", lambda m: env[m.group(1)], cmd)
+    return shlex.split(cmd, comments=True)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_SCRIPTS), reason="the reference tree is not on this box")
+def test_every_training_script_parses():
+    scripts = sorted(glob.glob(os.path.join(REF_SCRIPTS, "train_*.sh")))
+    assert len(scripts) == 6
+    parser = M.get_parser()
+    for s in scripts:
+        argv = _script_argv(s)
+        args = parser.parse_args(argv)          # SystemExit on an unknown or ambiguous flag
+        assert args.do_train and args.save_path.startswith("output/")
+        assert args.template_based or args.decoder.endswith(".json")
+        if s.endswith("train_RCR.sh"):          # scripts/train_RCR.sh:37 relies on prefix matching: --warmup -> --warmup_ratio
+            assert args.warmup_ratio == 0.02 and args.num_beams == 15 and args.precision == "16-mixed"
+            assert args.mlm and args.mlm_layer == "mlp" and args.mlm_lambda == 0.1 and args.batch_size == 32
+
+
+def test_flag_surface_is_the_references():
+    # every option string of main.py:26-97; parsed out of the reference when it is here, else the count is pinned
+    ours = {a.option_strings[0] for a in M.get_parser()._actions if a.option_strings and a.option_strings[0] != "-h"}
+    if os.path.isfile("/root/reference/main.py"):
+        ref = set(re.findall(r"add_argument\('(--[a-z_]+)'", open("/root/reference/main.py").read()))
+        assert len(ref) == 62 and ref <= ours, sorted(ref - ours)
+    assert len(ours) >= 62
+
+
+def _toy(tmp_path, n=12, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    enc = dict(vocab_size=60, hidden_size=64, num_hidden_layers=1, num_attention_heads=1, intermediate_size=64,
+               max_position_embeddings=32, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    dec = dict(vocab_size=20, hidden_size=64, num_hidden_layers=1, num_attention_heads=1, intermediate_size=64,
+               max_position_embeddings=32, type_vocab_size=1, layer_norm_eps=1e-5, hidden_dropout_prob=0.0,
+               attention_probs_dropout_prob=0.0)
+    (tmp_path / "enc.json").write_text(json.dumps(enc))
+    (tmp_path / "dec.json").write_text(json.dumps(dec))
+    for name, m in (("train", n), ("val", 5), ("val_nogold", 5), ("test", 4)):
+        ids = torch.randint(3, 60, (m, 9), generator=g)
+        dids = torch.randint(3, 20, (m, 6), generator=g)
+        dids[:, 0] = 1
+        dids[:, -1] = 2
+        torch.save({"indices": list(range(100, 100 + m)), "input_ids": ids, "attention_mask": torch.ones_like(ids),
+                    "decoder_input_ids": dids, "decoder_attention_mask": torch.ones_like(dids),
+                    "mlm_labels": torch.randint(0, 60, (m, 3), generator=g)}, tmp_path / (name + ".pt"))
+    return ["--task", "condition", "--encoder", "allenai/scibert_scivocab_uncased", "--arch_encoder", str(tmp_path / "enc.json"),
+            "--decoder", str(tmp_path / "dec.json"), "--save_path", str(tmp_path / "out"), "--kernel_backend", "torch",
+            "--tensors_train", str(tmp_path / "train.pt"), "--tensors_valid", "%s,%s" % (tmp_path / "val.pt", tmp_path / "val_nogold.pt"),
+            "--tensors_test", str(tmp_path / "test.pt"), "--batch_size", "6", "--lr", "1e-3", "--mlm", "--mlm_layer", "mlp",
+            "--mlm_lambda", "0.1", "--warmup", "0.5", "--num_beams", "3", "--max_dec_length", "8", "--test_batch_size", "2",
+            "--val_metric", "val_loss", "--print_freq", "1"]
+
+
+def test_train_validate_test_resume(tmp_path, capsys):
+    argv = _toy(tmp_path)
+    out = tmp_path / "out"
+    # two optimiser steps (12 samples / batch 6), one epoch, then validate + test from best.ckpt
+    assert M.main(argv + ["--epochs", "1", "--do_train", "--do_valid", "--do_test", "--overwrite"]) == 0
+    assert (out / "best.ckpt").is_file() and (out / "last.ckpt").is_file()
+    ck = torch.load(out / "best.ckpt", weights_only=False)
+    assert ck["global_step"] == 2 and ck["epoch"] == 0 and ck["pytorch-lightning_version"].startswith("2.")
+    assert all(k.startswith("model.") or k.startswith("mlm_head.") for k in ck["state_dict"])
+    assert ck["callbacks"]["ModelCheckpoint"]["monitor"] == "val_loss"
+    pred = json.loads((out / "prediction_test_0.json").read_text())
+    assert sorted(pred) == ["100", "101", "102", "103"] and len(pred["100"]["prediction"]) == 3 and len(pred["100"]["score"]) == 3
+    printed = capsys.readouterr().out
+    assert "Num training steps: 2" in printed and '"val_loss/1"' in printed         # second dataloader = gold-removed set
+    # resume: --load_ckpt last.ckpt without --overwrite continues at epoch 1 (main.py:389-391)
+    assert M.main(argv + ["--epochs", "2", "--do_train", "--load_ckpt", "last.ckpt"]) == 0
+    assert "Resumed from" in capsys.readouterr().out
+    ck2 = torch.load(out / "last.ckpt", weights_only=False)
+    assert ck2["epoch"] == 1 and ck2["global_step"] == 4
+    # the checkpoint reloads into a fresh module
+    from textreact_amd.predictor import train as T
+    args = M.get_args(argv)
+    enc_cfg, dec_cfg = M._configs(args)
+    fresh = T.Predictor(enc_cfg, dec_cfg, mlm=True, mlm_layer="mlp", backend="torch")
+    _, missing, unexpected = T.load_checkpoint(str(out / "last.ckpt"), fresh)
+    assert not missing and not unexpected
+
+
+def _rank_main(rank, world, port, argv):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    assert M.main(argv) == 0
+
+
+def test_two_ranks_gloo(tmp_path):
+    # one process per "GPU" (gloo on CPU): shards of the epoch per rank, gradients averaged, files written by rank 0,
+    # evaluation outputs of both ranks merged (main.py:259-268)
+    import socket
+    import torch.multiprocessing as mp
+    argv = _toy(tmp_path) + ["--epochs", "1", "--do_train", "--do_test", "--overwrite", "--gpus", "2"]
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]
+    mp.spawn(_rank_main, args=(2, port, argv), nprocs=2, join=True)
+    out = tmp_path / "out"
+    ck = torch.load(out / "best.ckpt", weights_only=False)
+    assert ck["global_step"] == 1            # 12 samples / (batch 6 x 2 ranks)
+    pred = json.loads((out / "prediction_test_0.json").read_text())
+    assert sorted(pred) == ["100", "101", "102", "103"]

@@ -336,21 +336,16 @@ static int search_batch(trx_index* idx, const void* q, int64_t nq, int is_bf, in
         std::vector<unsigned long long> h((size_t)nwg * 32);
         HIPCHK(hipMemcpyAsync(h.data(), sp.stamp_out, h.size() * 8, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
-        double cyc = 0, slow = 0, comp = 0, cols = 0, tiles = 0, sa = 0, sb = 0, sc = 0, sd = 0;
-        for (size_t i = 0; i < h.size(); i += 4) {
-            cyc += (double)(h[i] & 0xfffffffffull); sd += (double)(h[i] >> 36); slow += (double)(h[i + 1] & 0xfffffull); sa += (double)(h[i + 1] >> 20); comp += (double)(h[i + 2] & 0xffffull); cols += (double)((h[i + 2] >> 16) & 0xfffffull); sc += (double)(h[i + 2] >> 36);
-            tiles += (double)(h[i + 3] & 0xfffffull); sb += (double)(h[i + 3] >> 20);
-        }
-        // appended rows: the final list counts (exact when nothing was compacted)
+        double cyc = 0, comp = 0, tiles = 0;
+        for (size_t i = 0; i < h.size(); i += 4) { cyc += (double)h[i]; comp += (double)h[i + 1]; tiles += (double)h[i + 3]; }
+        // listed rows: the final list counts (exact when nothing was compacted)
         std::vector<u32> hc((size_t)q_pad * nlists);
         HIPCHK(hipMemcpyAsync(hc.data(), sp.cand_cnt, hc.size() * 4, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         double app = 0; u32 mx = 0;
         for (u32 c : hc) { app += c; mx = std::max(mx, c); }
-        fprintf(stderr, "[stamp] work-mask build %.0f cycles, tracking + refresh %.0f cycles per wave and tile; per group: fetch %.0f, test + append %.0f cycles\n", sa / tiles, sb / tiles, sc / std::max(cols, 1.0), sd / std::max(cols, 1.0));
-        fprintf(stderr, "[stamp] per wave and tile: bookkeeping %.0f cycles, slow path entered %.2f times, %.2f columns, %.4f compactions; "
-                        "listed rows %.2f per wave and tile (%.0f per query, fullest list %u of %d)\n",
-                cyc / tiles, slow / tiles, cols / tiles, comp / tiles, app / tiles, app / (double)q_pad, mx, cap);
+        fprintf(stderr, "[stamp] per wave and tile: bookkeeping %.0f cycles, %.5f lists compacted, %.2f rows listed (%.0f per query; fullest list %u of %d)\n",
+                cyc / tiles, comp / tiles, app / tiles, app / (double)q_pad, mx, cap);
     }
 #endif
 

@@ -31,28 +31,40 @@
 // LDS image: 16-byte chunk c of row r sits at slot c ^ ((r >> 1) & 7) (permutation on the per-lane DMA
 //   SOURCE address), which makes the ds_read_b128 fragment reads conflict-free.
 //
-// Selection (exact with respect to the approximate key; nothing in it needs a workgroup barrier):
-//   * filter: a lane's 32 keys of a tile and query are reduced to their maximum by v_max3 issued in
-//     the gaps of the tile's last 32 MFMAs; only if some lane's maximum reaches the query's threshold
-//     does the wave look at individual keys (slow path, in the NEXT load phase, under the partner's
-//     MFMAs): rows with key >= threshold are appended to the LANE's own list (query, split, wave row, row quad):
-//     63 or 127 slots in HBM, slot counter in a register of the lane, nobody else writes that list.
+// Selection (exact with respect to the approximate key; nothing in it needs a workgroup barrier or an atomic):
+//   * filter + listing, inside the gaps of a tile's LAST 32 MFMAs.  Every finished group of 4 accumulator
+//     rows (one v_mfma tile = 4 corpus rows x the lane's query) is reduced to its maximum (v_max + v_max3),
+//     compared with the query's threshold straight into a scalar register pair (v_cmp), and tested one row
+//     of MFMAs later by a scalar branch that is almost never taken (about 3 of the 32 groups of a tile once
+//     the thresholds are warm; the untaken tests cost nothing measurable).  A group with a hit lists its
+//     passing rows right there, where it is a known register: a masked store of the packed (key, id) into
+//     the LANE's own list -- (query, split, wave row, row quad), 127 slots in HBM, slot counter in a byte of
+//     a register of that lane, nobody else writes that list.
 //   * threshold: each lane keeps the J best tile maxima it has seen for each of its 4 queries
-//     (J = kprime / 8).  They are maxima of J different tiles, and the 8 lanes of a query (4 row
-//     quads x 2 wave rows) see disjoint rows: the minimum over those 8 lanes of the J-th best is a
-//     key that at least 8 J = kprime corpus rows reach, so a row below it is outside the top kprime.
-//     Refreshed once per tile (2 cross-lane steps + the partner wave's value through LDS, which may
-//     be stale: stale = lower = still valid), shared between the splits of a query through g_thr
-//     (atomicMax; a one-piece LDS-DMA brings the other splits' values back every 8 tiles) and seeded
-//     by a bootstrap launch of this kernel over a few tiles.
-//   * a list that fills up (tie-heavy or adversarially ordered corpora only) is compacted by its own
-//     wave to its kprime best (key desc, id asc) and from then on also filters by that packed
-//     (key, id): no row is ever lost, whatever the data order.
-//   L2: the accumulators of a tile start from -|y|^2 / 2 of their corpus rows (C operand of the tile's first MFMAs, read
-//   from a per-tile LDS copy), so an accumulator is h = x.y - |y|^2 / 2 = key / 2 and the kernel filters and tracks in
-//   h; packed values and g_thr carry key = 2 h (exact).
-//   At the end every list publishes its count and the bound "every row of mine that is not listed
-//   has packed (key, id) <= bound"; knn_select.hip merges the lists of a query.
+//     (J = kprime / 8; in LDS between tiles).  They are maxima of J different tiles, and the 8 lanes of a
+//     query (4 row quads x 2 wave rows) see disjoint rows: the minimum over those 8 lanes of the J-th best is
+//     a key that at least 8 J = kprime corpus rows reach, so a row below it is outside the top kprime.
+//     Refreshed every 8th tile (2 cross-lane steps + the partner wave's value through LDS, which may be
+//     stale: stale = lower = still valid), shared between the splits of a query through g_thr (atomicMax
+//     every 32nd tile; a one-piece LDS-DMA brings the other splits' values back) and seeded by a bootstrap
+//     launch of this kernel over 16 tiles.
+//   * a list that could not take another tile (32 rows) is cut to its kprime best (key desc, id asc) by
+//     the whole wave at the end of the tile; the packed value in kprime-th place becomes the list's floor
+//     and its key the lane's threshold: tie-heavy or adversarially ordered corpora get here (random data
+//     lists ~20 rows per list), and stay exact -- no row is ever lost, whatever the data order.
+//   Everything else a finished tile needs (tracking, refresh, the room check) runs at the start of the wave's
+//   next load phase, under the partner wave's MFMAs.
+//   L2: the accumulators of a tile start from -|y|^2 / 2 of their corpus rows (C operand of the tile's first
+//   MFMAs, read from a per-tile LDS copy), so an accumulator is h = x.y - |y|^2 / 2 = key / 2 and the kernel
+//   filters and tracks in h; packed values and g_thr carry key = 2 h (exact).
+//   At the end every list publishes its count and the bound "every row of mine that is not listed has
+//   packed (key, id) <= bound"; knn_select.hip merges the lists of a query.
+//
+// What shaped the code (measured): the chip is POWER-limited in this loop (the clock
+//   falls from 2.1 to 1.8 GHz when the LDS-DMA traffic is added to the MFMAs), so wall time follows energy,
+//   not issue slots; with 128 accumulator registers live hipcc spills whatever else it is given, and a
+//   spill reload costs a trip through the VMEM queue behind the DMA pieces (thousands of cycles): all
+//   long-lived per-lane state is either recomputed from the lane id or parked in LDS by hand.
 #include "knn_common.h"
 #include <atomic>
 #include <cstdlib>
@@ -85,18 +97,7 @@ template <int OFF> __device__ __forceinline__ u32 lds_ld32(u32 a) {
     asm volatile("ds_read_b32 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(a), "n"(OFF) : "memory");
     return v;
 }
-template <int OFF> __device__ __forceinline__ u64 lds_ld64(u32 a) {
-    u64 v;
-    asm volatile("ds_read_b64 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(a), "n"(OFF) : "memory");
-    return v;
-}
 template <int OFF> __device__ __forceinline__ void lds_st32(u32 a, u32 v) { asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(a), "v"(v), "n"(OFF) : "memory"); }
-template <int OFF> __device__ __forceinline__ void lds_st64(u32 a, u64 v) { asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(a), "v"(v), "n"(OFF) : "memory"); }
-template <int OFF> __device__ __forceinline__ u32 lds_inc(u32 a) {
-    u32 r, one = 1u;
-    asm volatile("ds_add_rtn_u32 %0, %1, %2 offset:%3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r) : "v"(a), "v"(one), "n"(OFF) : "memory");
-    return r;
-}
 __device__ __forceinline__ u64 ld_u64_l2(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // XCD-contiguous bijective remap of the block id (blocks b and b+8 share an XCD under the
@@ -126,14 +127,6 @@ __device__ __forceinline__ u32 lane_now() {
     return l;
 }
 
-__device__ __forceinline__ float max3f(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
-// maximum of 8 accumulator values in 4 instructions (asm: hipcc canonicalises every operand of fmaxf with an extra v_max)
-__device__ __forceinline__ float max8f(const f32x4& a, const f32x4& b) {
-    float g;
-    asm("v_max_f32 %0, %1, %2\n\tv_max3_f32 %0, %0, %3, %4\n\tv_max3_f32 %0, %0, %5, %6\n\tv_max3_f32 %0, %0, %7, %8"
-        : "=&v"(g) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]));
-    return g;
-}
 // maximum of the 4 values of an accumulator tile in 2 instructions
 __device__ __forceinline__ float max4f(const f32x4& a) {
     float g;
@@ -384,10 +377,10 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
     if (++ksA == ksteps) { ksA = 0; srcA += wrapA; }
 
     // ---- what happens once per finished tile, at the start of the wave's next load phase (its partner is
-    // issuing MFMAs meanwhile): threshold bookkeeping, and the slow path if a maximum reached a threshold.
-    // TL = tile index inside the split whose keys are in `acc` / maxima in `m`.
+    // issuing MFMAs meanwhile): the room check of the lists, the tracked maxima, the threshold refresh.
+    // TL = tile index inside the split whose per-lane maxima are in `m`.
 #ifdef TRX_STAMP_BUILD
-    unsigned long long st_cyc = 0, st_slow = 0, st_comp = 0, st_cols = 0, st_a = 0, st_b = 0, st_c = 0, st_d = 0;
+    unsigned long long st_cyc = 0, st_comp = 0;     // diagnostic build: cycles in here, lists compacted
 #endif
     auto tile_end = [&](const int TL) __attribute__((always_inline)) {
 #ifdef TRX_STAMP_BUILD
@@ -401,7 +394,6 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
         const int ql0 = wave_n * 64 + frow;
         const u32 b4_0 = lds0 + S_THRW + ql0 * 4;
         const u32 b4_m = b4_0 + wave_m * 1024, b4_p = b4_0 + (wave_m ^ 1) * 1024;
-        // ---- slow path: some lane's tile maximum reached its query's threshold ----
         // ---- room for the next tile: a lane lists at most 32 rows of a tile per column.  A list that could overflow is
         // cut to its kprime best (key desc, id asc) NOW, by the whole wave; its lane's threshold rises to the key in
         // kprime-th place and the packed value in kprime-th place becomes the list's floor (cand_thr).  Rare: ~20 rows
@@ -429,8 +421,6 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
 #endif
                         if (lane == l) {
                             cnt4 = (cnt4 & ~(0xffu << (8 * nt))) | ((u32)(p.kprime | 0x80) << (8 * nt));
-                            const u64 old = (cnt4 >> (8 * nt)) & 0x80u ? 0ull : 0ull;
-                            (void)old;
                             p.cand_thr[li] = floor_c;
                             thrk[nt] = __builtin_fmaxf(thrk[nt], KI * comp_key(floor_c));
                         }
@@ -439,9 +429,6 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
                 __builtin_amdgcn_s_waitcnt(0);
             }
         }
-#ifdef TRX_STAMP_BUILD
-        const unsigned long long st_t3 = __builtin_readcyclecounter();
-#endif
         // ---- the J best tile maxima of this lane (pad-row tiles of an inner-product index do not count).  They live in
         // LDS between tiles (8 dwords per thread; J = 4: sixteen values as bf16 pairs, rounded DOWN, so that they stay
         // lower bounds): as registers hipcc spilled them, and a spill reload waits out the whole VMEM queue.
@@ -525,7 +512,6 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
         }
 #ifdef TRX_STAMP_BUILD
         st_cyc += __builtin_readcyclecounter() - st_t0;
-        st_b += __builtin_readcyclecounter() - st_t3;
 #endif
     };
 
@@ -671,7 +657,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
 #ifdef TRX_STAMP_BUILD
     if (p.stamp_out && lane == 0) {
         unsigned long long* o = p.stamp_out + ((size_t)blockIdx.x * 8 + wave) * 4;
-        o[0] = st_cyc | (st_d << 36); o[1] = st_slow | (st_a << 20); o[2] = st_comp | (st_cols << 16) | (st_c << 36); o[3] = (unsigned long long)ntl | (st_b << 20);
+        o[0] = st_cyc; o[1] = st_comp; o[2] = 0ull; o[3] = (unsigned long long)ntl;
     }
 #endif
     // ---- publish count and bound of this lane's 4 lists ----

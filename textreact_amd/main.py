@@ -1,0 +1,360 @@
+"""Trainer entry point: `python -m textreact_amd.main` takes the flags of the reference's main.py
+(/root/reference main.py:26-97, all 62 of them, prefix abbreviations included: scripts/train_RCR.sh:37 passes
+`--warmup 0.02` for `--warmup_ratio`) and drives predictor/train.py -- the step, the losses, AdamW + schedule, DDP,
+`best.ckpt` / `last.ckpt` with the monitor logic of main.py:358-360, resume (:390-397), validate / test with
+`prediction_{split}_{0,1}.json` (:243-245).  SURVEY.md section 8b, "Training CLI + ckpt".
+
+Out of scope: tokenizers and datasets.  The data side of the reference (CSV -> tokenizer ->
+collator, textreact/dataset.py) is replaced by PRE-TOKENISED tensor files, one per split, which is what its collator
+hands the model anyway:
+
+    --tensors_train / --tensors_valid / --tensors_test  FILE[,FILE2]
+        torch.save'd dict: indices [N] (sample ids as they appear in the prediction files), input_ids, attention_mask,
+        decoder_input_ids, decoder_attention_mask [N, L] / [N, T]; optional mlm_labels [N, trunc] (the masked tokens
+        moved to the front, dataset.py:109-122).  A second file of a split is the gold-neighbour-removed variant
+        (dataloader index 1, main.py:336-340).
+    --arch_encoder JSON   encoder architecture when `--encoder` names a hub model (no network here); default: BERT-base
+                            with the SciBERT vocabulary size
+    --tok_vocab_size N, --tok_bos_id / --tok_eos_id / --tok_pad_id   what the decoder tokenizer would have said
+
+The data flags of the reference are accepted and ignored with a note.  One process per GPU: launch with
+`python -m torch.distributed.run --nproc-per-node G -m textreact_amd.main ...` (backend nccl = RCCL); `--gpus` is
+checked against WORLD_SIZE.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+
+import torch
+
+
+def get_parser():
+    p = argparse.ArgumentParser(prog="textreact_amd.main")     # allow_abbrev is argparse's default
+    # ---- main.py:28-36
+    p.add_argument('--task', type=str, default='condition')
+    p.add_argument('--do_train', action='store_true')
+    p.add_argument('--do_valid', action='store_true')
+    p.add_argument('--do_test', action='store_true')
+    p.add_argument('--precision', type=str, default='32')
+    p.add_argument('--seed', type=int, default=42)
+    p.add_argument('--gpus', type=int, default=1)
+    p.add_argument('--print_freq', type=int, default=200)
+    p.add_argument('--debug', action='store_true')
+    # ---- Model, main.py:38-45
+    p.add_argument('--template_based', action='store_true')
+    p.add_argument('--unattend_nonbonds', action='store_true')
+    p.add_argument('--encoder', type=str, default=None)
+    p.add_argument('--decoder', type=str, default=None)
+    p.add_argument('--encoder_pretrained', action='store_true')
+    p.add_argument('--decoder_pretrained', action='store_true')
+    p.add_argument('--share_embedding', action='store_true')
+    p.add_argument('--encoder_tokenizer', type=str, default='text')
+    # ---- Data, main.py:47-72
+    p.add_argument('--data_path', type=str, default=None)
+    p.add_argument('--template_path', type=str, default=None)
+    p.add_argument('--train_file', type=str, default=None)
+    p.add_argument('--valid_file', type=str, default=None)
+    p.add_argument('--test_file', type=str, default=None)
+    p.add_argument('--vocab_file', type=str, default=None)
+    p.add_argument('--corpus_file', type=str, default=None)
+    p.add_argument('--train_label_corpus', action='store_true')
+    p.add_argument('--cache_path', type=str, default=None)
+    p.add_argument('--nn_path', type=str, default=None)
+    p.add_argument('--train_nn_file', type=str, default=None)
+    p.add_argument('--valid_nn_file', type=str, default=None)
+    p.add_argument('--test_nn_file', type=str, default=None)
+    p.add_argument('--max_length', type=int, default=128)
+    p.add_argument('--max_dec_length', type=int, default=128)
+    p.add_argument('--num_workers', type=int, default=8)
+    p.add_argument('--shuffle_smiles', action='store_true')
+    p.add_argument('--no_smiles', action='store_true')
+    p.add_argument('--num_neighbors', type=int, default=-1)
+    p.add_argument('--use_gold_neighbor', action='store_true')
+    p.add_argument('--max_num_neighbors', type=int, default=10)
+    p.add_argument('--random_neighbor_ratio', type=float, default=0.8)
+    p.add_argument('--mlm', action='store_true')
+    p.add_argument('--mlm_ratio', type=float, default=0.15)
+    p.add_argument('--mlm_layer', type=str, default='linear')
+    p.add_argument('--mlm_lambda', type=float, default=1)
+    # ---- Training, main.py:74-89
+    p.add_argument('--epochs', type=int, default=8)
+    p.add_argument('--batch_size', type=int, default=256)
+    p.add_argument('--lr', type=float, default=1e-4)
+    p.add_argument('--weight_decay', type=float, default=0.01)
+    p.add_argument('--max_grad_norm', type=float, default=5.)
+    p.add_argument('--scheduler', type=str, choices=['cosine', 'constant'], default='cosine')
+    p.add_argument('--warmup_ratio', type=float, default=0)
+    p.add_argument('--gradient_accumulation_steps', type=int, default=1)
+    p.add_argument('--load_ckpt', type=str, default='best.ckpt')
+    p.add_argument('--eval_per_epoch', type=int, default=1)
+    p.add_argument('--val_metric', type=str, default='val_acc')
+    p.add_argument('--save_path', type=str, default='output/')
+    p.add_argument('--overwrite', action='store_true')
+    p.add_argument('--num_train_example', type=int, default=None)
+    p.add_argument('--label_smoothing', type=float, default=0.0)
+    # ---- Inference, main.py:91-94
+    p.add_argument('--test_batch_size', type=int, default=64)
+    p.add_argument('--num_beams', type=int, default=1)
+    p.add_argument('--test_each_neighbor', action='store_true')
+    p.add_argument('--test_num_neighbors', type=int, default=1)
+    # ---- this repo: pre-tokenised inputs in place of the dataset / tokenizer stack (see the module docstring).  The
+    # names are chosen so that no prefix that identifies a reference flag uniquely (argparse abbreviations, which the
+    # reference's scripts use) becomes ambiguous: none of them shares its first three letters with a reference flag.
+    p.add_argument('--tensors_train', type=str, default=None)
+    p.add_argument('--tensors_valid', type=str, default=None)
+    p.add_argument('--tensors_test', type=str, default=None)
+    p.add_argument('--arch_encoder', type=str, default=None)
+    p.add_argument('--tok_vocab_size', type=int, default=None, help="decoder vocabulary size (the decoder tokenizer's)")
+    p.add_argument('--tok_bos_id', type=int, default=1)
+    p.add_argument('--tok_eos_id', type=int, default=2)
+    p.add_argument('--tok_pad_id', type=int, default=0)
+    p.add_argument('--kernel_backend', type=str, default=None, choices=['hip', 'torch'],
+                   help="attention / add+LayerNorm backend: hip (libtrxnn.so, default on a GPU) or the PyTorch statement of "
+                        "the same ops (CPU tests)")
+    return p
+
+
+def get_args(argv=None):
+    return get_parser().parse_args(argv)
+
+
+METRIC_TO_MODE = {'val_loss': 'min', 'val_acc': 'max'}      # textreact/utils.py:12-15
+
+
+def _configs(args):
+    from .predictor.model import Config
+    if args.arch_encoder:
+        enc = json.load(open(args.arch_encoder))
+    elif args.encoder and os.path.isfile(args.encoder):
+        enc = json.load(open(args.encoder))
+    else:       # BERT-base with the SciBERT vocabulary (allenai/scibert_scivocab_uncased; the hub is unreachable here)
+        enc = dict(vocab_size=31090)
+    if not args.decoder or not os.path.isfile(args.decoder):
+        raise SystemExit("--decoder must be a decoder config JSON (the reference passes textreact/configs/bert_l6.json)")
+    dec = json.load(open(args.decoder))
+    if args.tok_vocab_size:
+        dec["vocab_size"] = args.tok_vocab_size         # model.py:26: the decoder's vocabulary is the tokenizer's
+    keep = ("vocab_size", "hidden_size", "num_hidden_layers", "num_attention_heads", "intermediate_size",
+            "max_position_embeddings", "type_vocab_size", "layer_norm_eps", "hidden_dropout_prob",
+            "attention_probs_dropout_prob", "pad_token_id")
+    import inspect
+    ok = set(inspect.signature(Config.__init__).parameters)
+    enc = {k: v for k, v in enc.items() if k in keep and k in ok}
+    dec = {k: v for k, v in dec.items() if k in keep and k in ok}
+    return Config(**enc), Config(is_decoder=True, **dec)
+
+
+class TensorSplit:
+    """One pre-tokenised split: what the reference's DataLoader + collator yield, batch by batch
+    (`indices, batch_in, batch_out`, main.py:165)."""
+    IN_KEYS = ("input_ids", "attention_mask", "decoder_input_ids", "decoder_attention_mask")
+
+    def __init__(self, path, name):
+        d = torch.load(path, map_location="cpu", weights_only=False)
+        self.name = name
+        self.indices = [int(i) for i in (d["indices"].tolist() if torch.is_tensor(d["indices"]) else d["indices"])]
+        self.tensors = {k: d[k] for k in self.IN_KEYS if k in d}
+        self.mlm_labels = d.get("mlm_labels")
+        assert "input_ids" in self.tensors and len(self.indices) == self.tensors["input_ids"].shape[0], path
+
+    def __len__(self):
+        return len(self.indices)
+
+    def batches(self, batch_size, rank=0, world=1, device="cpu", limit=None):
+        n = len(self) if limit is None else min(limit, len(self))
+        order = list(range(rank, n, world))             # DistributedSampler(shuffle=False) of Lightning's eval loaders
+        for b0 in range(0, len(order), batch_size):
+            sel = torch.tensor(order[b0:b0 + batch_size], dtype=torch.long)
+            batch_in = {k: v[sel].to(device) for k, v in self.tensors.items()}
+            batch_out = {"mlm_labels": self.mlm_labels[sel].to(device)} if self.mlm_labels is not None else {}
+            yield [self.indices[i] for i in sel.tolist()], batch_in, batch_out
+
+
+def _load_splits(spec, name):
+    return [TensorSplit(f, name) for f in spec.split(",")] if spec else []
+
+
+def _autocast(args, device):
+    prec = str(args.precision)
+    if prec.startswith("16"):
+        return torch.autocast(device_type=device.type, dtype=torch.float16 if device.type == "cuda" else torch.bfloat16)
+    if prec.startswith("bf16"):
+        return torch.autocast(device_type=device.type, dtype=torch.bfloat16)
+    import contextlib
+    return contextlib.nullcontext()
+
+
+def main(argv=None):
+    args = get_args(argv)
+    from .predictor import train as T
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    cuda = torch.cuda.is_available()
+    device = torch.device("cuda", local_rank) if cuda else torch.device("cpu")
+    if cuda:
+        torch.cuda.set_device(local_rank)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl" if cuda else "gloo")
+    if args.gpus != world and rank == 0:
+        print("note: --gpus %d, WORLD_SIZE %d (one process per GPU: launch with torch.distributed.run)" % (args.gpus, world),
+              file=sys.stderr)
+    ignored = [k for k in ("data_path", "train_file", "valid_file", "test_file", "vocab_file", "corpus_file", "nn_path")
+               if getattr(args, k)]
+    if ignored and rank == 0:
+        print("note: dataset / tokenizer flags are accepted and not used here (%s): inputs are the --tensors_* files"
+              % ", ".join("--" + k for k in ignored), file=sys.stderr)
+    if args.template_based:
+        raise SystemExit("--template_based: the template model (predictor/template.py) has its own steps; this entry point "
+                         "drives the template-free encoder-decoder (scripts/train_RCR*.sh, train_RetroSyn_tf*.sh)")
+
+    torch.manual_seed(args.seed)                      # pl.seed_everything (main.py:351)
+    backend = args.kernel_backend or ("hip" if cuda else "torch")
+    enc_cfg, dec_cfg = _configs(args)
+    module = T.Predictor(enc_cfg, dec_cfg, mlm=args.mlm, mlm_layer=args.mlm_layer, mlm_lambda=args.mlm_lambda,
+                         pad_token_id=args.tok_pad_id, backend=backend).to(device)
+    train_sets = _load_splits(args.tensors_train, "train") if args.do_train else []
+    val_sets = _load_splits(args.tensors_valid, "val") if (args.do_train or args.do_valid) else []
+    test_sets = _load_splits(args.tensors_test, "test") if args.do_test else []
+    os.makedirs(args.save_path, exist_ok=True)
+    best_path, last_path = os.path.join(args.save_path, "best.ckpt"), os.path.join(args.save_path, "last.ckpt")
+
+    def validate(mod):
+        """main.py:177-196: per-sample scores of every dataloader, gathered, averaged; the first one is the monitor"""
+        mod.eval()
+        out = {}
+        for di, ds in enumerate(val_sets):
+            scores = {}
+            for indices, batch_in, _ in ds.batches(args.batch_size, rank, world, device):
+                with _autocast(args, device):
+                    scores.update(mod.validation_step(indices, batch_in, args.val_metric))
+            scores = T.gather_outputs(scores)
+            name = args.val_metric if di == 0 else "%s/%d" % (args.val_metric, di)
+            out[name] = float(sum(scores.values()) / max(len(scores), 1))
+        return out
+
+    best_model_path = os.path.join(args.save_path, args.load_ckpt)
+    if args.do_train:
+        assert train_sets, "--do_train needs --tensors_train"
+        train = train_sets[0]
+        n_train = len(train) if args.num_train_example is None else min(args.num_train_example, len(train))
+        steps_per_epoch = math.ceil(n_train / (args.batch_size * world * args.gradient_accumulation_steps))
+        num_training_steps = steps_per_epoch * args.epochs                                  # main.py:383-384
+        if rank == 0:
+            print("Num training steps: %d" % num_training_steps)
+        opt, sched = T.configure_optimizer(module, args.lr, args.weight_decay, num_training_steps, args.warmup_ratio,
+                                           scheduler=args.scheduler)
+        start_epoch, global_step = 0, 0
+        mode = METRIC_TO_MODE[args.val_metric]
+        best = None
+        if args.overwrite:                                                                 # main.py:386-388
+            if rank == 0:
+                T.clear_checkpoints(args.save_path)
+        else:                                                                              # main.py:389-391
+            ckpt_path = os.path.join(args.save_path, args.load_ckpt)
+            if os.path.isfile(ckpt_path):
+                ck, _, _ = T.load_checkpoint(ckpt_path, module, opt, sched)
+                start_epoch, global_step = int(ck["epoch"]) + 1, int(ck["global_step"])
+                best = (ck.get("callbacks") or {}).get("ModelCheckpoint", {}).get("best_model_score")
+                if rank == 0:
+                    print("Resumed from %s (epoch %d, step %d)" % (ckpt_path, start_epoch, global_step))
+        if world > 1:
+            dist.barrier()
+        # data parallelism (main.py:372, DDPStrategy): every rank steps its shard of the shuffled epoch and the gradients
+        # are averaged by ONE flat all-reduce per optimiser step (RCCL over xGMI; a 770 MB fp32 payload is bandwidth-
+        # bound, so one collective instead of DDP's 25 MB buckets costs nothing and needs no forward() wrapper)
+        scaler = torch.amp.GradScaler(enabled=cuda and str(args.precision).startswith("16"))
+        g = torch.Generator().manual_seed(args.seed)
+        for epoch in range(start_epoch, args.epochs):
+            module.train()
+            perm = torch.randperm(n_train, generator=g).tolist()       # one shuffle for all ranks, then rank-strided
+            mine = perm[rank::world]
+            micro = 0
+            opt.zero_grad(set_to_none=True)
+            for b0 in range(0, len(mine), args.batch_size):
+                sel = torch.tensor(mine[b0:b0 + args.batch_size], dtype=torch.long)
+                batch_in = {k: v[sel].to(device) for k, v in train.tensors.items()}
+                batch_out = {"mlm_labels": train.mlm_labels[sel].to(device)} if train.mlm_labels is not None else None
+                with _autocast(args, device):
+                    total, logs = module.training_step(batch_in, batch_out)
+                (scaler.scale(total / args.gradient_accumulation_steps)).backward()
+                micro += 1
+                if micro % args.gradient_accumulation_steps == 0 or b0 + args.batch_size >= len(mine):
+                    if world > 1:
+                        for p_ in module.parameters():      # a parameter unused on this rank still takes part (find_unused_parameters)
+                            if p_.grad is None and p_.requires_grad:
+                                p_.grad = torch.zeros_like(p_)
+                        grads = [p.grad for p in module.parameters() if p.grad is not None]
+                        flat = torch.cat([gr.reshape(-1) for gr in grads])
+                        dist.all_reduce(flat)
+                        flat /= world
+                        off = 0
+                        for gr in grads:
+                            gr.copy_(flat[off:off + gr.numel()].view_as(gr)); off += gr.numel()
+                    scaler.unscale_(opt)
+                    torch.nn.utils.clip_grad_norm_(module.parameters(), args.max_grad_norm)      # gradient_clip_val
+                    scaler.step(opt); scaler.update(); sched.step()
+                    opt.zero_grad(set_to_none=True)
+                    global_step += 1
+                    if rank == 0 and global_step % max(1, args.print_freq) == 0:
+                        print("epoch %d step %d train_loss %.4f lr %.3g" % (epoch, global_step, float(logs["train_loss"]),
+                                                                            sched.get_last_lr()[0]))
+            if (epoch + 1) % args.eval_per_epoch == 0 and val_sets:                       # check_val_every_n_epoch
+                metrics = validate(module)
+                score = metrics[args.val_metric]
+                improved = best is None or (score < best if mode == "min" else score > best)
+                if rank == 0:
+                    print("epoch %d %s" % (epoch, json.dumps(metrics)))
+                    if improved:                                                         # save_top_k=1, filename='best'
+                        T.save_checkpoint(best_path, module, opt, sched, epoch, global_step, monitor=args.val_metric)
+                        _stamp_best(best_path, score)
+                    T.save_checkpoint(last_path, module, opt, sched, epoch, global_step, monitor=args.val_metric)  # save_last
+                    _stamp_best(last_path, score if improved else best)
+                if improved:
+                    best = score
+            elif rank == 0:
+                T.save_checkpoint(last_path, module, opt, sched, epoch, global_step, monitor=args.val_metric)
+            if world > 1:
+                dist.barrier()
+        best_model_path = best_path if os.path.isfile(best_path) else last_path
+
+    if args.do_valid or args.do_test:
+        if rank == 0:
+            print("Load model checkpoint:", best_model_path)
+        T.load_checkpoint(best_model_path, module, strict=False)                          # main.py:404
+    if args.do_valid and val_sets:
+        metrics = validate(module)
+        if rank == 0:
+            print(json.dumps(metrics))
+    if args.do_test:
+        module.eval()
+        for di, ds in enumerate(test_sets):
+            outputs = {}
+            for indices, batch_in, _ in ds.batches(args.test_batch_size, rank, world, device):
+                with _autocast(args, device), torch.no_grad():
+                    outputs.update(T.test_step(module, indices, batch_in, args.num_beams, args.max_dec_length,
+                                               args.tok_bos_id, args.tok_eos_id, args.tok_pad_id))
+            outputs = T.gather_outputs(outputs)
+            if rank == 0:       # main.py:243-245; json keys become strings exactly as json.dump of the reference's dict does
+                with open(os.path.join(args.save_path, "prediction_%s_%d.json" % (ds.name, di)), "w") as f:
+                    json.dump(outputs, f)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+def _stamp_best(path, score):
+    """record the monitored score in the checkpoint's ModelCheckpoint state (what a resume compares against)"""
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    ck["callbacks"]["ModelCheckpoint"]["best_model_score"] = None if score is None else float(score)
+    torch.save(ck, path)
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -24,8 +24,11 @@ def evaluate_reaction_condition(prediction, data_df, cutoffs=(1, 3, 5, 10, 15)):
 
 
 def canonical_smiles(smiles):
+    """RDKit canonical form; an unparsable string stays as it is (the reference's try / except around CanonSmiles).  A
+    MISSING RDKit is an error, as in the reference, whose module fails at import: comparing raw strings instead would
+    report wrong accuracies without a word.  Pass `canonical=` to evaluate_retrosynthesis to use something else."""
+    from rdkit import Chem      # ImportError propagates
     try:
-        from rdkit import Chem
         return Chem.CanonSmiles(smiles)
     except Exception:
         return smiles

@@ -61,11 +61,12 @@ class Predictor(nn.Module):
                                reduction=reduction)
         return loss.view(b, -1).mean(dim=1) if reduction == "none" else loss
 
-    # main.py:151-156: greedy-search accuracy
-    def compute_acc(self, logits, batch_in):
+    # main.py:151-156: greedy-search accuracy (per sample with reduction="none", as validation_step uses it)
+    def compute_acc(self, logits, batch_in, reduction="mean"):
         preds = logits.argmax(dim=-1)[:, :-1]
         labels = batch_in["decoder_input_ids"][:, 1:]
-        return torch.logical_or(preds.eq(labels), labels.eq(self.pad)).all(dim=-1).float().mean()
+        acc = torch.logical_or(preds.eq(labels), labels.eq(self.pad)).all(dim=-1).float()
+        return acc.mean() if reduction == "mean" else acc
 
     # main.py:158-162: masked tokens were moved to the front, so only the first trunc_len positions count
     def compute_mlm_loss(self, encoder_last_hidden_state, labels):
@@ -87,19 +88,28 @@ class Predictor(nn.Module):
 
     # main.py:177-188: per-sample scores of the validation step
     @torch.no_grad()
-    def validation_step(self, indices, batch_in):
+    def validation_step(self, indices, batch_in, val_metric="val_loss"):
         logits, _ = self.model(**batch_in)
-        scores = self.compute_loss(logits, batch_in, reduction="none")
+        if val_metric == "val_loss":
+            scores = self.compute_loss(logits, batch_in, reduction="none")
+        elif val_metric == "val_acc":
+            scores = self.compute_acc(logits, batch_in, reduction="none")
+        else:
+            raise ValueError(val_metric)       # main.py:185
         return {int(i): float(s) for i, s in zip(indices, scores)}
 
 
 # main.py:198-233 (template-free branch): beam search, num_return_sequences = num_beams
 def test_step(predictor, indices, batch_in, num_beams, max_dec_length, bos_token_id, eos_token_id, pad_token_id=0,
-              decode=None):
+              decode=None, reference_scores=False):
     """{idx: {'prediction': [...num_beams items...], 'score': [...]}} as test_step stores it.  `decode` maps a
     [n, T] tensor of token ids to n strings (the reference's dec_tokenizer.batch_decode(...,
     skip_special_tokens=True)); without it the predictions are the token-id lists with the special tokens
-    removed, which is what that call strips."""
+    removed, which is what that call strips.
+
+    `score`: the beam scores (sequences_scores).  The reference means to write them too, but tests
+    `'sequences_scores' in predictions` on the LIST OF DECODED STRINGS (main.py:228-231), which is never true, so its
+    files carry zeros; `reference_scores=True` reproduces that byte for byte."""
     from .generate import generate
     seqs, scores = generate(predictor.model, batch_in["input_ids"], batch_in.get("attention_mask"), num_beams=num_beams,
                             num_return_sequences=num_beams, max_length=max_dec_length, length_penalty=0,
@@ -109,7 +119,7 @@ def test_step(predictor, indices, batch_in, num_beams, max_dec_length, bos_token
     else:
         special = {bos_token_id, eos_token_id, pad_token_id}
         preds = [[int(t) for t in row if int(t) not in special] for row in seqs.cpu().numpy()]
-    score_list = scores.tolist() if scores is not None else [0] * len(preds)
+    score_list = scores.tolist() if (scores is not None and not reference_scores) else [0] * len(preds)
     return {int(idx): {"prediction": preds[i * num_beams:(i + 1) * num_beams],
                        "score": score_list[i * num_beams:(i + 1) * num_beams]} for i, idx in enumerate(indices)}
 
@@ -136,10 +146,16 @@ def configure_optimizer(module, lr, weight_decay, num_training_steps, warmup_rat
     warm = int(num_training_steps * warmup_ratio)
 
     def lr_lambda(step):
+        if scheduler == "constant":     # transformers' "constant" has no warm-up
+            return 1.0
         if step < warm:
             return float(step) / float(max(1, warm))
         if scheduler == "constant":
             return 1.0
+        if scheduler == "cosine":       # transformers get_cosine_schedule_with_warmup, num_cycles = 0.5 (main.py:275)
+            import math
+            progress = float(step - warm) / float(max(1, num_training_steps - warm))
+            return max(0.0, 0.5 * (1.0 + math.cos(math.pi * progress)))
         return max(0.0, float(num_training_steps - step) / float(max(1, num_training_steps - warm)))
     return opt, torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda)
 
@@ -159,7 +175,7 @@ def save_checkpoint(path, module, optimizer=None, lr_scheduler=None, epoch=0, gl
     ckpt["global_step"] = int(global_step)
     ckpt["pytorch-lightning_version"] = "2.0.0"
     ckpt["state_dict"] = collections.OrderedDict((k, v.detach().cpu()) for k, v in module.state_dict().items())
-    ckpt["loops"] = {}
+    ckpt["loops"] = None      # Lightning's restore_loops skips a None entry (an empty dict would KeyError on 'fit_loop')
     ckpt["callbacks"] = {"ModelCheckpoint": {"monitor": monitor, "best_model_path": os.path.abspath(path)}}
     ckpt["optimizer_states"] = [optimizer.state_dict()] if optimizer is not None else []
     ckpt["lr_schedulers"] = [lr_scheduler.state_dict()] if lr_scheduler is not None else []
