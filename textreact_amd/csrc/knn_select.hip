@@ -114,18 +114,36 @@ __global__ __launch_bounds__(256) void knn_select_kernel(SelectParams p) {
             tau = dropped > tau ? dropped : tau;
         }
     };
-    for (int l = 0; l < p.nlists; ++l) {
-        const int64_t o = (int64_t)q * p.nlists + l;
-        const int c = (int)p.cand_cnt[o];
-        const u64* cq = p.cand + o * p.cap_alloc;
-        for (int base = 0; base < c; base += 64) {
-            const u64 e = (base + lane) < c ? cq[base + lane] : 0ull;
-            const bool keep = e != 0ull && e >= T && (int64_t)comp_id(e) < p.n;
-            const u64 km = __ballot(keep);
-            if (keep) qu[qn + __popcll(km & ((1ull << lane) - 1ull))] = e;
-            qn += __popcll(km);
-            __builtin_amdgcn_wave_barrier();
-            drain(false);
+    // The lists are short (a lane of the scan kernel lists ~20 rows per split on random data) and there are many of them
+    // (8 per split): going through them one by one is a chain of dependent global loads, ~1 us each.  So: the counts of 64
+    // lists in one load (a lane per list), then the first 64 entries of 8 lists at a time as 8 independent loads.
+    auto take = [&](u64 e) {
+        const bool keep = e != 0ull && e >= T && (int64_t)comp_id(e) < p.n;
+        const u64 km = __ballot(keep);
+        if (keep) qu[qn + __popcll(km & ((1ull << lane) - 1ull))] = e;
+        qn += __popcll(km);
+        __builtin_amdgcn_wave_barrier();
+        drain(false);
+    };
+    for (int l0 = 0; l0 < p.nlists; l0 += 64) {
+        const int64_t o0 = (int64_t)q * p.nlists + l0;
+        const int mycnt = (l0 + lane) < p.nlists ? (int)p.cand_cnt[o0 + lane] : 0;
+        const int nl = (p.nlists - l0) < 64 ? (p.nlists - l0) : 64;
+        for (int g = 0; g < nl; g += 8) {        // nlists is a multiple of 8
+            u64 e[8];
+            int c[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                c[j] = __shfl(mycnt, g + j, 64);
+                e[j] = lane < c[j] ? p.cand[(o0 + g + j) * p.cap_alloc + lane] : 0ull;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (c[j] == 0) continue;
+                take(e[j]);
+                for (int base = 64; base < c[j]; base += 64)
+                    take((base + lane) < c[j] ? p.cand[(o0 + g + j) * p.cap_alloc + base + lane] : 0ull);
+            }
         }
     }
     drain(true);
