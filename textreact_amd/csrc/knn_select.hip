@@ -189,19 +189,31 @@ __global__ __launch_bounds__(256) void knn_select_kernel(SelectParams p) {
     double sc = 0.0;
     const bool vec_ok = (p.d % SLICE == 0) && ((p.ld_c * CE) % 16 == 0);
     if (vec_ok) {
+        // the loads of slice s + 1 are issued before slice s is scored (registers `nxt`): a wave's chain of dependent
+        // global loads was what the kernel waited for (16 waves per CU, ~1 us per round trip, 12 slices per query)
+        uint4 nxt[PASSES];
+        auto fetch = [&](int k0) {
+#pragma unroll
+            for (int ps = 0; ps < PASSES; ++ps) {
+                nxt[ps] = make_uint4(0, 0, 0, 0);
+                if (ps * (64 / LPR) >= nkeep) continue;     // wave-uniform: the rows of this pass were all pruned
+                const int row = ps * (64 / LPR) + lane / LPR, part = lane % LPR;
+                const u32 rid = __shfl(id, row, 64);
+                if (rid != 0xffffffffu)
+                    nxt[ps] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.corpus_orig) +
+                                                              ((int64_t)rid * p.ld_c + k0) * CE + part * 16);
+            }
+        };
+        fetch(0);
         for (int k0 = 0; k0 < p.d; k0 += SLICE) {
 #pragma unroll
             for (int ps = 0; ps < PASSES; ++ps) {
-                if (ps * (64 / LPR) >= nkeep) break;     // wave-uniform: the rows of this pass were all pruned
+                if (ps * (64 / LPR) >= nkeep) break;
                 const int row = ps * (64 / LPR) + lane / LPR, part = lane % LPR;
-                const u32 rid = __shfl(id, row, 64);
-                uint4 val = make_uint4(0, 0, 0, 0);
-                if (rid != 0xffffffffu)
-                    val = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.corpus_orig) +
-                                                          ((int64_t)rid * p.ld_c + k0) * CE + part * 16);
-                *reinterpret_cast<uint4*>(wl + row * ROWB + part * 16) = val;
+                *reinterpret_cast<uint4*>(wl + row * ROWB + part * 16) = nxt[ps];
             }
             __builtin_amdgcn_wave_barrier();
+            if (k0 + SLICE < p.d) fetch(k0 + SLICE);
             if (have) {
                 const char* rp = wl + lane * ROWB;
 #pragma unroll 2
