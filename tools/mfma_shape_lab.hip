@@ -1,0 +1,96 @@
+// Register-only MFMA loop at the scan kernel's shape (8 waves x 2 workgroups per CU, 128 accumulator registers per
+// wave, random bf16 operands) to compare the energy-limited rate of v_mfma_f32_16x16x32_bf16 (64 per K-step) and
+// v_mfma_f32_32x32x16_bf16 (32 per K-step): same MACs, same operand registers.
+//   mfma_shape_lab <0|1> [iters]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <cstring>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+template <bool M32>
+__global__ __launch_bounds__(512, 2) void mfma_only(const uint4* src, float* out, int iters) {
+    const int tid = threadIdx.x;
+    bf16x8 fa[2][8], fb[2][4];
+    const uint4* s = src + (size_t)(blockIdx.x * 512 + tid) * 24;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { uint4 u = s[i]; fa[i >> 3][i & 7] = *reinterpret_cast<bf16x8*>(&u); }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { uint4 u = s[16 + i]; fb[i >> 2][i & 3] = *reinterpret_cast<bf16x8*>(&u); }
+    float mx = -3e38f;
+    if (M32) {
+        f32x16 acc[4][2];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const int k4 = i >> 3, a = (i >> 1) & 3, b = i & 1;     // 4 K-steps of 16
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[k4 & 1][a * 2 + (k4 >> 1)], fb[k4 & 1][b * 2 + (k4 >> 1)], acc[a][b], 0, 0, 0);
+            }
+            if ((it % 12) == 11) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) { mx = fmaxf(mx, acc[a][b][e]); acc[a][b][e] = 0.f; }
+                    }
+            }
+        }
+    } else {
+        f32x4 acc[8][4];
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 64; ++i) {
+                const int kk = i >> 5, a = (i >> 2) & 7, b = i & 3;
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[kk][a], fb[kk][b], acc[a][b], 0, 0, 0);
+            }
+            if ((it % 12) == 11) {
+#pragma unroll
+                for (int a = 0; a < 8; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { mx = fmaxf(mx, acc[a][b][e]); acc[a][b][e] = 0.f; }
+                    }
+            }
+        }
+    }
+    out[blockIdx.x * 512 + tid] = mx;
+}
+
+int main(int argc, char** argv) {
+    const int m32 = argc > 1 ? atoi(argv[1]) : 0;
+    const int iters = argc > 2 ? atoi(argv[2]) : 977 * 12 * 2;     // two rounds of workgroups' worth in one
+    const int grid = 512;
+    std::vector<unsigned short> h((size_t)grid * 512 * 24 * 8);
+    unsigned s = 12345u;
+    for (auto& x : h) { s = s * 1664525u + 1013904223u; float f = ((s >> 8) & 0xffff) / 32768.0f - 1.0f; unsigned u; memcpy(&u, &f, 4); x = (unsigned short)(u >> 16); }
+    uint4* src; float* out;
+    CK(hipMalloc(&src, h.size() * 2)); CK(hipMemcpy(src, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMalloc(&out, (size_t)grid * 512 * 4));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int rep = 0; rep < 4; ++rep) {
+        CK(hipEventRecord(e0));
+        if (m32) hipLaunchKernelGGL(mfma_only<true>, dim3(grid), dim3(512), 0, 0, src, out, iters);
+        else hipLaunchKernelGGL(mfma_only<false>, dim3(grid), dim3(512), 0, 0, src, out, iters);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipGetLastError());
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        const double flop = (double)grid * 8 * iters * 64.0 * 2 * 16 * 16 * 32;
+        printf("m32 %d: %.2f ms  %.1f TFLOP/s\n", m32, ms, flop / ms / 1e9);
+    }
+    return 0;
+}
