@@ -85,15 +85,16 @@ __device__ __forceinline__ u64 wave_sort_desc(u64 v, int lane) {
 
 // Sort (score key, id) pairs: lane 0 = largest skey, ties -> smallest id.  skey is an orddbl()
 // style key where LARGER means ranked earlier (callers negate for L2).
+template <int W = 64>   // W = 32: the two 32-lane halves of the wave are sorted separately, each best first
 __device__ __forceinline__ void wave_sort_pairs(u64& skey, u32& id, int lane) {
 #pragma unroll
-    for (int k = 2; k <= 64; k <<= 1) {
+    for (int k = 2; k <= W; k <<= 1) {
 #pragma unroll
         for (int j = k >> 1; j > 0; j >>= 1) {
             u64 ok = shfl_xor_u64(skey, j);
             u32 oi = __shfl_xor(id, j, 64);
             bool lower = (lane & j) == 0;
-            bool desc = (lane & k) == 0;
+            bool desc = k == W || (lane & k) == 0;
             bool keep_first = (lower == desc);
             bool mine_first = (skey > ok) || (skey == ok && id < oi);
             bool take_mine = (keep_first == mine_first);

@@ -68,152 +68,206 @@ __device__ __forceinline__ double canonical_score(const void* qrow, const void* 
     return s;
 }
 
+#ifndef TRX_SEL_ABL
+#define TRX_SEL_ABL 0   // diagnostic builds: 1 = candidates are not re-scored, 2 = lists are not read (results are wrong)
+#endif
 // ------------------------------------------------------------------------------------------
-// select: one wave per query.
+// select: one wave per PAIR of queries.  The lists of the two queries are merged one after the other, wave-wide; the
+// survivors of the first move to lanes 32..63, those of the second stay in lanes 0..31, and the re-scoring -- the bulk of
+// the kernel's instructions, one lane per candidate -- runs once for both, as do the final sort (two 32-lane sorts side by
+// side) and the certificate.  (One wave per query left 50+ lanes of every fp64 instruction idle: ~11 candidates survive
+// the epsilon window.  The kernel is VALU-issue bound: 5.4 k vector instructions per query before, profiles/.)
 template <bool L2, bool CBF, bool QBF>
 __global__ __launch_bounds__(256) void knn_select_kernel(SelectParams p) {
-    const int lane = threadIdx.x & 63;
-    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (q >= p.nq) return;  // wave-uniform
-
-    // ---- 1. merge the lists of the query by packed approximate (key,id); keep the best KEEP ----
-    // A query has nlists lists (corpus splits x wave rows of the scan workgroup), each with its own bound: every row of
-    // the list's rows that is NOT listed has a packed value <= bound.  T = the largest bound: every row with a packed
-    // value > T is listed somewhere, and at least kprime >= k listed entries reach T (the bound is either a key that
-    // kprime rows reach, all of them listed, or the kprime-th entry of a compacted list).  So entries below T are
-    // dropped unread by the sort (the lists are append-only logs: most of their entries date from before the
-    // thresholds tightened), and T is the starting value of tau, the best packed value of anything not kept.
-    u64 tau = 0ull;
-    for (int l = lane; l < p.nlists; l += 64) {
-        const u64 b = p.cand_thr[(int64_t)q * p.nlists + l];
-        tau = b > tau ? b : tau;
-    }
-#pragma unroll
-    for (int s = 1; s < 64; s <<= 1) { const u64 o = shfl_xor_u64(tau, s); tau = o > tau ? o : tau; }
-    const u64 T = tau;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, hl = lane & 31, half = lane >> 5;
+    const int q0 = (blockIdx.x * 4 + wv) * 2;       // q0 -> lanes 32..63, q0 + 1 -> lanes 0..31
+    if (q0 >= p.nq) return;                         // wave-uniform; the kernel has no workgroup barrier
     __shared__ u64 sel_queue[4][128];
-    u64* qu = sel_queue[threadIdx.x >> 6];
-    int qn = 0;                        // entries waiting in the queue (wave-uniform)
-    u64 v = 0ull;                      // lanes 0..31: running best-32, sorted; lanes 32..63: incoming
-    auto drain = [&](bool all) {
-        while (qn >= 32 || (all && qn > 0)) {
-            const int take = qn < 32 ? qn : 32;
-            __builtin_amdgcn_wave_barrier();
-            if (lane >= 32) v = (lane - 32) < take ? qu[qn - take + (lane - 32)] : 0ull;
-            qn -= take;
-            v = wave_sort_desc(v, lane);
-            // a row may have been listed twice (the scan repeats a column after compacting a full list): equal packed
-            // values are adjacent now; keep the first of each run
-            const u64 prev = shfl_u64(v, lane > 0 ? lane - 1 : 0);
-            const bool dup = lane > 0 && v != 0ull && v == prev;
-            if (__any(dup)) {
-                if (dup) v = 0ull;
+    __shared__ int sel_lpre[4][64];
+    u64* qu = sel_queue[wv];
+    int* lpre = sel_lpre[wv];
+    u64 vA = 0ull, tauA = 0ull, vB = 0ull, tauB = 0ull;
+    int nkeepA = 0, nkeepB = 0;
+    double epsA = 0.0, epsB = 0.0;
+
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {
+        const int q = q0 + h;
+        if (q >= p.nq) break;
+        // ---- 1. merge the lists of the query by packed approximate (key,id); keep the best KEEP ----
+        // A query has nlists lists (corpus splits x wave rows of the scan workgroup), each with its own bound: every row of
+        // the list's rows that is NOT listed has a packed value <= bound.  T = the largest bound: every row with a packed
+        // value > T is listed somewhere, and at least kprime >= k listed entries reach T (the bound is either a key that
+        // kprime rows reach, all of them listed, or the kprime-th entry of a compacted list).  So entries below T are
+        // dropped unread by the sort (the lists are append-only logs: most of their entries date from before the
+        // thresholds tightened), and T is the starting value of tau, the best packed value of anything not kept.
+        u64 tau = 0ull;
+        for (int l = lane; l < p.nlists; l += 64) {
+            const u64 b = p.cand_thr[(int64_t)q * p.nlists + l];
+            tau = b > tau ? b : tau;
+        }
+#pragma unroll
+        for (int s = 1; s < 64; s <<= 1) { const u64 o = shfl_xor_u64(tau, s); tau = o > tau ? o : tau; }
+        const u64 T = tau;
+        int qn = 0;                        // entries waiting in the queue (wave-uniform), at most 128
+        bool fresh = true;                 // nothing sorted yet: the first sort takes 64 entries, one per lane
+        u64 v = 0ull;                      // lanes 0..31: running best-32, sorted; lanes 32..63: incoming
+        auto drain = [&](bool all) {
+            while (qn > 64 || (all && qn > 0)) {
+                const int room = fresh ? 64 : 32, l0_ = fresh ? 0 : 32;
+                const int take = qn < room ? qn : room;
+                __builtin_amdgcn_wave_barrier();
+                if (lane >= l0_) v = (lane - l0_) < take ? qu[qn - take + (lane - l0_)] : 0ull;
+                fresh = false;
+                qn -= take;
                 v = wave_sort_desc(v, lane);
+                // a row may have been listed twice (the scan repeats a column after compacting a full list): equal packed
+                // values are adjacent now; keep the first of each run
+                const u64 prev = shfl_u64(v, lane > 0 ? lane - 1 : 0);
+                const bool dup = lane > 0 && v != 0ull && v == prev;
+                if (__any(dup)) {
+                    if (dup) v = 0ull;
+                    v = wave_sort_desc(v, lane);
+                }
+                const u64 dropped = shfl_u64(v, KEEP);   // best of the lanes about to be replaced
+                tau = dropped > tau ? dropped : tau;
             }
-            const u64 dropped = shfl_u64(v, KEEP);   // best of the lanes about to be replaced
-            tau = dropped > tau ? dropped : tau;
-        }
-    };
-    // The lists are short (a lane of the scan kernel lists ~20 rows per split on random data) and there are many of them
-    // (8 per split): going through them one by one is a chain of dependent global loads, ~1 us each.  So: the counts of 64
-    // lists in one load (a lane per list), then the first 64 entries of 8 lists at a time as 8 independent loads.
-    auto take = [&](u64 e) {
-        const bool keep = e != 0ull && e >= T && (int64_t)comp_id(e) < p.n;
-        const u64 km = __ballot(keep);
-        if (keep) qu[qn + __popcll(km & ((1ull << lane) - 1ull))] = e;
-        qn += __popcll(km);
-        __builtin_amdgcn_wave_barrier();
-        drain(false);
-    };
-    for (int l0 = 0; l0 < p.nlists; l0 += 64) {
-        const int64_t o0 = (int64_t)q * p.nlists + l0;
-        const int mycnt = (l0 + lane) < p.nlists ? (int)p.cand_cnt[o0 + lane] : 0;
-        const int nl = (p.nlists - l0) < 64 ? (p.nlists - l0) : 64;
-        for (int g = 0; g < nl; g += 8) {        // nlists is a multiple of 8
-            u64 e[8];
-            int c[8];
+        };
+        auto take = [&](u64 e) {
+            const bool keep = e != 0ull && e >= T && (int64_t)comp_id(e) < p.n;
+            const u64 km = __ballot(keep);
+            if (keep) qu[qn + __popcll(km & ((1ull << lane) - 1ull))] = e;
+            qn += __popcll(km);
+            __builtin_amdgcn_wave_barrier();
+            drain(false);
+        };
+        // The lists are short (a lane of the scan kernel lists ~20 rows per split on random data) and there are many of
+        // them (8 per split).  64 lists at a time: their counts in one load (a lane per list), an exclusive prefix sum in
+        // LDS, and then the entries of all of them as ONE flat sequence, 64 per load (a lane finds its list by bisection of
+        // the prefix sums), four loads in flight.  A load per list cost as many vector instructions for 18 entries as this
+        // does for 64.
+#if TRX_SEL_ABL == 2
+        if (0)
+#endif
+        for (int l0 = 0; l0 < p.nlists; l0 += 64) {
+            const int64_t o0 = (int64_t)q * p.nlists + l0;
+            const int mycnt = (l0 + lane) < p.nlists ? (int)p.cand_cnt[o0 + lane] : 0;
+            int pre = mycnt;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                c[j] = __shfl(mycnt, g + j, 64);
-                e[j] = lane < c[j] ? p.cand[(o0 + g + j) * p.cap_alloc + lane] : 0ull;
-            }
+            for (int s_ = 1; s_ < 64; s_ <<= 1) { const int t_ = __shfl_up(pre, s_, 64); if (lane >= s_) pre += t_; }
+            const int total = __shfl(pre, 63, 64);
+            __builtin_amdgcn_wave_barrier();
+            lpre[lane] = pre - mycnt;
+            __builtin_amdgcn_wave_barrier();
+            for (int base = 0; base < total; base += 256) {
+                u64 e[4];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                if (c[j] == 0) continue;
-                take(e[j]);
-                for (int base = 64; base < c[j]; base += 64)
-                    take((base + lane) < c[j] ? p.cand[(o0 + g + j) * p.cap_alloc + base + lane] : 0ull);
+                for (int r_ = 0; r_ < 4; ++r_) {
+                    const int i = base + r_ * 64 + lane;
+                    int l = 0;
+#pragma unroll
+                    for (int step = 32; step; step >>= 1) { if (lpre[l + step] <= i) l += step; }   // last list starting at or before i
+                    e[r_] = i < total ? p.cand[(o0 + l) * p.cap_alloc + (i - lpre[l])] : 0ull;
+                }
+#pragma unroll
+                for (int r_ = 0; r_ < 4; ++r_) { if (base + r_ * 64 < total) take(e[r_]); }
             }
         }
-    }
-    drain(true);
-    if (lane >= KEEP) v = 0ull;
-    bool have = lane < KEEP && v != 0ull;
-    // error bound of an approximate key (the same one the certificate uses below)
-    const float xn2 = p.qnorm2[q];
-    const float bq = L2 ? (2.0f * sqrtf(xn2 * p.ymax_norm2) + p.ymax_norm2) : sqrtf(xn2 * p.ymax_norm2);
-    const double eps = (double)p.eps_rel * (double)bq * 1.0001 + 1e-30;
-    // ---- 1b. epsilon window: |approximate - exact| <= eps for every row, so the k candidates with the best
-    // approximate keys all have exact keys >= a_k - eps (a_k = the k-th best approximate key); a candidate whose
-    // approximate key is below a_k - 2 eps has an exact key < a_k - eps and cannot reach the top k: it is not
-    // re-scored (its row is never fetched) and counts as dropped.  The lanes are sorted, so the pruned ones
-    // form a suffix; a non-finite eps prunes nothing.
-    int nkeep = KEEP;
-    if (p.k <= KEEP) {
-        const u64 vk = shfl_u64(v, p.k - 1);
-        const bool prune = have && lane >= p.k && vk != 0ull && ((double)comp_key(v) + eps < (double)comp_key(vk) - eps);
-        const u64 pm = __ballot(prune);
-        if (pm) {
-            nkeep = __ffsll((long long)pm) - 1;
-            const u64 dropped = shfl_u64(v, nkeep);
-            tau = dropped > tau ? dropped : tau;
-            if (lane >= nkeep) have = false;
+        drain(true);
+        if (lane >= KEEP) v = 0ull;
+        // error bound of an approximate key (the same one the certificate uses below)
+        const float xn2 = p.qnorm2[q];
+        const float bq = L2 ? (2.0f * sqrtf(xn2 * p.ymax_norm2) + p.ymax_norm2) : sqrtf(xn2 * p.ymax_norm2);
+        const double eps = (double)p.eps_rel * (double)bq * 1.0001 + 1e-30;
+        // ---- 1b. epsilon window: |approximate - exact| <= eps for every row, so the k candidates with the best
+        // approximate keys all have exact keys >= a_k - eps (a_k = the k-th best approximate key); a candidate whose
+        // approximate key is below a_k - 2 eps has an exact key < a_k - eps and cannot reach the top k: it is not
+        // re-scored (its row is never fetched) and counts as dropped.  The lanes are sorted, so the pruned ones
+        // form a suffix; a non-finite eps prunes nothing.
+        int nkeep = KEEP;
+        if (p.k <= KEEP) {
+            const u64 vk = shfl_u64(v, p.k - 1);
+            const bool prune = v != 0ull && lane >= p.k && vk != 0ull && ((double)comp_key(v) + eps < (double)comp_key(vk) - eps);
+            const u64 pm = __ballot(prune);
+            if (pm) {
+                nkeep = __ffsll((long long)pm) - 1;
+                const u64 dropped = shfl_u64(v, nkeep);
+                tau = dropped > tau ? dropped : tau;
+                if (lane >= nkeep) v = 0ull;
+            }
         }
+        if (h == 0) { vA = shfl_u64(v, hl); tauA = tau; nkeepA = nkeep; epsA = eps; }
+        else { vB = v; tauB = tau; nkeepB = nkeep; epsB = eps; }
     }
+    // from here on a lane works for the query of its half
+    const int q = half ? q0 : q0 + 1;
+    const bool live = q < p.nq;
+    const u64 v = half ? vA : (lane < KEEP ? vB : 0ull);
+    const u64 tau = half ? tauA : tauB;
+    const double eps = half ? epsA : epsB;
+    const bool have = v != 0ull;
     const u32 id = have ? comp_id(v) : 0xffffffffu;
 
     // ---- 2. canonical fp64 score of each kept candidate (one lane per candidate, k ascending) ----
-    // The 32 candidate rows are brought in 64-component slices by ALL 64 lanes with coalesced
-    // 16-byte loads (8 / 16 lanes per row slice), staged in this wave's LDS region, and each of
-    // the 32 scoring lanes then walks its own row slice out of LDS.  (One lane streaming its own
-    // row from global memory re-fetched every 128-byte line 8 times: 25 GB of L2 traffic and
-    // 1.1 ms per 65,536 queries.)  The summation order is unchanged: k = 0 .. d-1 per candidate.
-    const char* qrow = reinterpret_cast<const char*>(p.query_orig) + (int64_t)q * p.ld_q * (QBF ? 2 : 4);
-    constexpr int CE = CBF ? 2 : 4;                 // corpus element bytes
-    constexpr int SLICE = 64;                       // components per slice
-    constexpr int ROWB = SLICE * CE + 16;           // LDS bytes per row slice (+16: bank spread)
-    constexpr int LPR = SLICE * CE / 16;            // lanes per row slice (8 or 16)
-    constexpr int PASSES = KEEP * LPR / 64;         // 4 or 8 load passes
-    __shared__ __attribute__((aligned(16))) char sel_lds[4][KEEP * (SLICE * 4 + 16)];
-    char* wl = sel_lds[threadIdx.x >> 6];
-    double sc = 0.0;
+    // The candidate rows are brought in slices of 128 bytes by ALL 64 lanes with coalesced 16-byte loads (8 lanes per row
+    // slice), staged in this wave's LDS region, and each scoring lane then walks its own row slice out of LDS.  (One lane
+    // streaming its own row from global memory re-fetched every 128-byte line 8 times.)  The loads of slice s + 1 are
+    // issued before slice s is scored.  The query slices take the same route (a lane per component, read back as LDS
+    // broadcasts of four fp32 values) instead of same-address global loads.  The summation order is unchanged:
+    // k = 0 .. d-1 per candidate.
+    constexpr int QE = QBF ? 2 : 4, CE = CBF ? 2 : 4;   // element bytes
+    const char* qrowA = reinterpret_cast<const char*>(p.query_orig) + (int64_t)q0 * p.ld_q * QE;
+    const char* qrowB = q0 + 1 < p.nq ? qrowA + (int64_t)p.ld_q * QE : qrowA;
+    const char* qrow = half ? qrowA : qrowB;
+    constexpr int SLICE = 128 / CE;                 // components per slice (64 bf16 or 32 f32)
+    constexpr int ROWB = 128 + 16;                  // LDS bytes per row slice (+16: bank spread)
+    constexpr int LPR = 8;                          // lanes per row slice
+    constexpr int PASSES = 8;                       // 64 rows, 8 per pass
+    __shared__ __attribute__((aligned(16))) char sel_lds[4][64 * ROWB];
+    __shared__ __attribute__((aligned(16))) float sel_xq[4][2][64];
+    char* wl = sel_lds[wv];
+    float* xq = sel_xq[wv][half];
+    double sc = 0.0, xx = 0.0;
     const bool vec_ok = (p.d % SLICE == 0) && ((p.ld_c * CE) % 16 == 0);
+#if TRX_SEL_ABL == 1
+    if (0) {
+#else
     if (vec_ok) {
-        // the loads of slice s + 1 are issued before slice s is scored (registers `nxt`): a wave's chain of dependent
-        // global loads was what the kernel waited for (16 waves per CU, ~1 us per round trip, 12 slices per query)
-        uint4 nxt[PASSES];
-        auto fetch = [&](int k0) {
+#endif
+        struct Stage { uint4 r[PASSES]; float x[2]; };
+        Stage st0, st1;
+        const int nsl = p.d / SLICE;
+        u32 rid[PASSES];
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) rid[ps] = __shfl(id, ps * 8 + lane / LPR, 64);
+        const int part = lane % LPR;
+        auto xload = [&](const char* row, int k) {
+            return QBF ? __uint_as_float((u32)reinterpret_cast<const unsigned short*>(row)[k] << 16) : reinterpret_cast<const float*>(row)[k];
+        };
+        auto fetch = [&](Stage& st, int sl) {
+            if (sl >= nsl) return;
+            const int k0 = sl * SLICE;
+            if (SLICE == 64) { st.x[0] = xload(qrowB, k0 + lane); st.x[1] = xload(qrowA, k0 + lane); }
+            else st.x[0] = xload(qrow, k0 + hl);
 #pragma unroll
             for (int ps = 0; ps < PASSES; ++ps) {
-                nxt[ps] = make_uint4(0, 0, 0, 0);
-                if (ps * (64 / LPR) >= nkeep) continue;     // wave-uniform: the rows of this pass were all pruned
-                const int row = ps * (64 / LPR) + lane / LPR, part = lane % LPR;
-                const u32 rid = __shfl(id, row, 64);
-                if (rid != 0xffffffffu)
-                    nxt[ps] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.corpus_orig) +
-                                                              ((int64_t)rid * p.ld_c + k0) * CE + part * 16);
+                st.r[ps] = make_uint4(0, 0, 0, 0);
+                if (rid[ps] != 0xffffffffu)
+                    st.r[ps] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.corpus_orig) +
+                                                               ((int64_t)rid[ps] * p.ld_c + k0) * CE + part * 16);
             }
         };
-        fetch(0);
-        for (int k0 = 0; k0 < p.d; k0 += SLICE) {
+        auto score = [&](Stage& st, int sl) {
+            if (sl >= nsl) return;
 #pragma unroll
             for (int ps = 0; ps < PASSES; ++ps) {
-                if (ps * (64 / LPR) >= nkeep) break;
-                const int row = ps * (64 / LPR) + lane / LPR, part = lane % LPR;
-                *reinterpret_cast<uint4*>(wl + row * ROWB + part * 16) = nxt[ps];
+                if ((ps & 3) * 8 >= ((ps >> 2) ? nkeepA : nkeepB)) continue;   // wave-uniform: rows of this pass all pruned
+                *reinterpret_cast<uint4*>(wl + (ps * 8 + lane / LPR) * ROWB + part * 16) = st.r[ps];
             }
+            if (SLICE == 64) { sel_xq[wv][0][lane] = st.x[0]; sel_xq[wv][1][lane] = st.x[1]; }
+            else sel_xq[wv][half][hl] = st.x[0];
             __builtin_amdgcn_wave_barrier();
-            if (k0 + SLICE < p.d) fetch(k0 + SLICE);
+            fetch(st, sl + 2);
             if (have) {
                 const char* rp = wl + lane * ROWB;
 #pragma unroll 2
@@ -229,17 +283,24 @@ __global__ __launch_bounds__(256) void knn_select_kernel(SelectParams p) {
                     }
 #pragma unroll
                     for (int i = 0; i < NE; ++i) {
-                        const double x = load_as_double<QBF>(qrow, k0 + c * NE + i);
-                        if (L2) { const double t = x - y[i]; sc = __builtin_fma(t, t, sc); }
+                        const double x = (double)xq[c * NE + i];
+                        if (L2) { const double t = x - y[i]; sc = __builtin_fma(t, t, sc); xx = __builtin_fma(x, x, xx); }
                         else sc = __builtin_fma(x, y[i], sc);
                     }
                 }
             }
             __builtin_amdgcn_wave_barrier();
-        }
-    } else if (have) {
+        };
+        fetch(st0, 0); fetch(st1, 1);
+        for (int sl = 0; sl < nsl; sl += 2) { score(st0, sl); score(st1, sl + 1); }
+    } else if (have && TRX_SEL_ABL != 1) {
         const char* crow = reinterpret_cast<const char*>(p.corpus_orig) + (int64_t)id * p.ld_c * CE;
         sc = canonical_score<L2, CBF, QBF>(qrow, crow, p.d);
+        if (L2 && !p.exact_class)
+            for (int i = 0; i < p.d; ++i) {     // |x|^2 in fp64, k-ordered (the certificate's key = |x|^2 - dist)
+                const double t = load_as_double<QBF>(qrow, i);
+                xx = __builtin_fma(t, t, xx);
+            }
     }
     // NaN scores never rank (oracle: skipped)
     const bool ranked = have && (sc == sc);
@@ -247,8 +308,9 @@ __global__ __launch_bounds__(256) void knn_select_kernel(SelectParams p) {
     u64 skey = ranked ? orddbl(L2 ? -sc : sc) : 0ull;
     u32 sid = ranked ? id : 0xffffffffu;
     // carry the score along by re-deriving it from skey after the sort (orddbl is a bijection)
-    wave_sort_pairs(skey, sid, lane);
-    const int nranked = __popcll(__ballot(skey != 0ull));
+    wave_sort_pairs<32>(skey, sid, lane);
+    const u64 rm = __ballot(skey != 0ull);
+    const int nranked = __popc(half ? (u32)(rm >> 32) : (u32)rm);
 
     // decode score
     double ssc;
@@ -260,44 +322,37 @@ __global__ __launch_bounds__(256) void knn_select_kernel(SelectParams p) {
 
     // ---- 3. certificate: can any row outside the kept set reach the k-th place? ----
     bool certified = true;
-    if (!p.exact_class && tau != 0ull) {
-        const int kk = p.k < nranked ? p.k : nranked;
-        if (kk < p.k) {
-            certified = false;  // fewer ranked candidates than k although rows were dropped
-        } else {
-            const double s_k = __shfl(ssc, p.k - 1, 64);  // exact score in k-th place
-            const float tau_key = comp_key(tau);
-            const double bound = (double)tau_key + eps;  // upper bound of an outsider's exact key
-            if (L2) {
-                // key = |x|^2 - dist  (exact |x|^2 in fp64, k-ordered)
-                double xx = 0.0;
-                for (int i = 0; i < p.d; ++i) {
-                    const double t = load_as_double<QBF>(qrow, i);
-                    xx = __builtin_fma(t, t, xx);
-                }
-                certified = (xx - s_k) > bound;
+    {
+        const int ksrc = (lane & 32) + (p.k <= 32 ? p.k - 1 : 31);
+        const double s_k = __shfl(ssc, ksrc, 64);          // exact score in k-th place
+        const double xx0 = __shfl(xx, lane & 32, 64);      // the first candidate's lane has walked the whole query row
+        if (!p.exact_class && tau != 0ull) {
+            if (nranked < p.k) {
+                certified = false;  // fewer ranked candidates than k although rows were dropped
             } else {
-                certified = s_k > bound;
+                const float tau_key = comp_key(tau);
+                const double bound = (double)tau_key + eps;  // upper bound of an outsider's exact key
+                certified = L2 ? (xx0 - s_k) > bound : s_k > bound;   // L2: key = |x|^2 - dist
             }
         }
     }
 
     // ---- 4. write D, I (and fp64 scores for the sharded merge) ----
-    if (lane < p.k) {
-        const bool ok = lane < nranked;
-        const int64_t o = (int64_t)q * p.k + lane;
+    if (hl < p.k && live) {
+        const bool ok = hl < nranked;
+        const int64_t o = (int64_t)q * p.k + hl;
         p.D[o] = ok ? (float)ssc : (L2 ? FLT_MAX : -FLT_MAX);
         p.I[o] = ok ? (int64_t)sid : (int64_t)-1;
         if (p.S64) p.S64[o] = ok ? ssc : (L2 ? (double)FLT_MAX : -(double)FLT_MAX);
     }
-    if (!certified && lane == 0) {
+    if (!certified && hl == 0 && live && TRX_SEL_ABL == 0) {
         const int pos = atomicAdd(p.nflagged, 1);
         p.flagged[pos] = q;
     }
 }
 
 hipError_t launch_select(const SelectParams& p, hipStream_t st) {
-    dim3 grid((p.nq + 3) / 4), block(256);
+    dim3 grid((p.nq + 7) / 8), block(256);
     if (p.nq <= 0) return hipSuccess;
     const int sel = (p.metric ? 4 : 0) | (p.corpus_is_bf16 ? 2 : 0) | (p.query_is_bf16 ? 1 : 0);
     switch (sel) {
