@@ -78,14 +78,15 @@ __device__ __forceinline__ double canonical_score(const void* qrow, const void* 
 // side) and the certificate.  (One wave per query left 50+ lanes of every fp64 instruction idle: ~11 candidates survive
 // the epsilon window.  The kernel is VALU-issue bound: 5.4 k vector instructions per query before, profiles/.)
 template <bool L2, bool CBF, bool QBF>
-__global__ __launch_bounds__(256) void knn_select_kernel(SelectParams p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void knn_select_kernel(SelectParams p) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, hl = lane & 31, half = lane >> 5;
     const int q0 = (blockIdx.x * 4 + wv) * 2;       // q0 -> lanes 32..63, q0 + 1 -> lanes 0..31
     if (q0 >= p.nq) return;                         // wave-uniform; the kernel has no workgroup barrier
-    __shared__ u64 sel_queue[4][128];
-    __shared__ int sel_lpre[4][64];
-    u64* qu = sel_queue[wv];
-    int* lpre = sel_lpre[wv];
+    // LDS per wave: the row slices of the re-scoring (64 rows x 144 bytes); the merge phase, over before the re-scoring
+    // starts, keeps its queue (128 entries) and the lists' prefix sums in the same bytes.  38.9 KB per workgroup: 4 per CU
+    __shared__ __attribute__((aligned(16))) char sel_lds[4][64 * (128 + 16)];
+    u64* qu = reinterpret_cast<u64*>(sel_lds[wv]);
+    int* lpre = reinterpret_cast<int*>(sel_lds[wv] + 128 * 8);
     u64 vA = 0ull, tauA = 0ull, vB = 0ull, tauB = 0ull;
     int nkeepA = 0, nkeepB = 0;
     double epsA = 0.0, epsB = 0.0;
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(256) void knn_select_kernel(SelectParams p) {
     // The candidate rows are brought in slices of 128 bytes by ALL 64 lanes with coalesced 16-byte loads (8 lanes per row
     // slice), staged in this wave's LDS region, and each scoring lane then walks its own row slice out of LDS.  (One lane
     // streaming its own row from global memory re-fetched every 128-byte line 8 times.)  The loads of slice s + 1 are
-    // issued before slice s is scored.  The query slices take the same route (a lane per component, read back as LDS
+    // issued as soon as slice s has left the registers for LDS, before it is scored.  The query slices take the same route (a lane per component, read back as LDS
     // broadcasts of four fp32 values) instead of same-address global loads.  The summation order is unchanged:
     // k = 0 .. d-1 per candidate.
     constexpr int QE = QBF ? 2 : 4, CE = CBF ? 2 : 4;   // element bytes
@@ -223,7 +224,6 @@ __global__ __launch_bounds__(256) void knn_select_kernel(SelectParams p) {
     constexpr int ROWB = 128 + 16;                  // LDS bytes per row slice (+16: bank spread)
     constexpr int LPR = 8;                          // lanes per row slice
     constexpr int PASSES = 8;                       // 64 rows, 8 per pass
-    __shared__ __attribute__((aligned(16))) char sel_lds[4][64 * ROWB];
     __shared__ __attribute__((aligned(16))) float sel_xq[4][2][64];
     char* wl = sel_lds[wv];
     float* xq = sel_xq[wv][half];
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void knn_select_kernel(SelectParams p) {
     if (vec_ok) {
 #endif
         struct Stage { uint4 r[PASSES]; float x[2]; };
-        Stage st0, st1;
+        Stage st0;
         const int nsl = p.d / SLICE;
         u32 rid[PASSES];
 #pragma unroll
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void knn_select_kernel(SelectParams p) {
             if (SLICE == 64) { sel_xq[wv][0][lane] = st.x[0]; sel_xq[wv][1][lane] = st.x[1]; }
             else sel_xq[wv][half][hl] = st.x[0];
             __builtin_amdgcn_wave_barrier();
-            fetch(st, sl + 2);
+            fetch(st, sl + 1);
             if (have) {
                 const char* rp = wl + lane * ROWB;
 #pragma unroll 2
@@ -291,8 +291,9 @@ __global__ __launch_bounds__(256) void knn_select_kernel(SelectParams p) {
             }
             __builtin_amdgcn_wave_barrier();
         };
-        fetch(st0, 0); fetch(st1, 1);
-        for (int sl = 0; sl < nsl; sl += 2) { score(st0, sl); score(st1, sl + 1); }
+        fetch(st0, 0);
+        __builtin_amdgcn_wave_barrier();     // the merge phase's LDS reads are done
+        for (int sl = 0; sl < nsl; ++sl) score(st0, sl);
     } else if (have && TRX_SEL_ABL != 1) {
         const char* crow = reinterpret_cast<const char*>(p.corpus_orig) + (int64_t)id * p.ld_c * CE;
         sc = canonical_score<L2, CBF, QBF>(qrow, crow, p.d);
