@@ -604,6 +604,12 @@ __device__ __forceinline__ void attn_softmax_tile(f32x16& s0, f32x16& s1, f32x16
     }
 }
 
+#ifdef TRX_ATT_STAMP   // tools/attn_lab.hip: per workgroup [0] realtime in, [1] realtime out, [2] cycles in, [3] after the prologue, [4..] after tile j
+__device__ unsigned long long* g_att_stamp;
+#define TRX_STAMP(I, V) if (g_att_stamp && threadIdx.x == 0) g_att_stamp[(size_t)blockIdx.x * 32 + (I)] = (V)
+#else
+#define TRX_STAMP(I, V)
+#endif
 template <int MM, bool DROP>   // mask mode, dropout: one kernel per case keeps each one's register footprint to what it needs
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DROP || MM == TRX_NN_MASK_FULL) ? 2 : 3, (DROP || MM == TRX_NN_MASK_FULL) ? 2 : 3))) void attention_fwd_mfma_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                                  const bf16_t* __restrict__ v, const float* __restrict__ mask,
@@ -618,6 +624,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DROP || MM
     typedef __attribute__((address_space(3))) void lds_void;
     typedef __attribute__((address_space(1))) const void gbl_void;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    TRX_STAMP(0, __builtin_amdgcn_s_memrealtime()); TRX_STAMP(2, __builtin_amdgcn_s_memtime());
     const int r = lane & 31, hh = lane >> 5;
     const int nqb = (Lq + 127) / 128;
     // workgroups are dealt round-robin to the 8 XCDs; renumber so that the query blocks of one
@@ -724,6 +731,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DROP || MM
     // s_waitcnt vmcnt(0) in front of every tile's first MFMA and drain the prefetch with it
     asm volatile("" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]));
     int buf = 0;
+    TRX_STAMP(3, __builtin_amdgcn_s_memtime());
     for (int kc = 0; kc < nkb; kc += 16) {   // chunks of 16 tiles = the 1024 keys whose mask sits in LDS
     if (keymask) {
         if (kc > 0) __syncthreads();         // (rare: Lk > 1024) the previous chunk's mask is no longer read
@@ -815,6 +823,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DROP || MM
         TRX_VT_WAIT(2, 3, 0)
         TRX_PV_STEP(2, 1) TRX_PV_STEP(3, 1)
         buf = buf1;
+        TRX_STAMP(4 + (kb < 26 ? kb : 26), __builtin_amdgcn_s_memtime());
     }
     }
 #undef TRX_VT_READ
@@ -838,6 +847,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DROP || MM
             *reinterpret_cast<uint2*>(op + 32 + 8 * gq + 4 * hh) = w1;
         }
     }
+    TRX_STAMP(31, __builtin_amdgcn_s_memtime()); TRX_STAMP(1, __builtin_amdgcn_s_memrealtime());
 }
 
 #include "attn_bwd_mfma.h"
