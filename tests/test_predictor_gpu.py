@@ -843,3 +843,32 @@ def test_weight_shadows_follow_the_optimizer_and_allow_two_forwards_before_one_b
     assert out["hip"][-1] < out["hip"][0] - 0.05                      # the optimizer moves the weights: stale shadows would not learn
     for a, c in zip(out["hip"], out["torch"]):
         assert abs(a - c) <= 3e-2 * max(1.0, abs(c)), (out["hip"], out["torch"])
+
+
+@pytest.mark.gpu
+def test_a_backward_across_a_parameter_update_is_refused():
+    """the bf16 weight copies `linear` shares between forwards (ops.WeightShadows) carry a generation: two forwards before
+    their backwards are fine, a backward whose forward predates train.mark_parameters_updated raises.  (Widths of 256:
+    `linear` routes only such layers through the shared copies.)"""
+    from textreact_amd.predictor import train
+    enc = dict(vocab_size=40, hidden_size=256, num_hidden_layers=1, num_attention_heads=4, intermediate_size=512,
+               max_position_embeddings=64, type_vocab_size=2, layer_norm_eps=1e-12)
+    dec = dict(vocab_size=40, hidden_size=256, num_hidden_layers=1, num_attention_heads=4, intermediate_size=512,
+               max_position_embeddings=64, type_vocab_size=1, layer_norm_eps=1e-5)
+    g = torch.Generator().manual_seed(0)
+    src = torch.randint(4, 40, (64, 12), generator=g)
+    batch = {"input_ids": src.cuda(), "attention_mask": torch.ones_like(src).cuda(),
+             "decoder_input_ids": torch.cat([torch.full((64, 1), 2), src[:, :8], torch.full((64, 1), 3)], 1).cuda(),
+             "decoder_attention_mask": torch.ones(64, 10, dtype=torch.long).cuda()}
+    torch.manual_seed(1)
+    p = train.Predictor(Config(**enc), Config(is_decoder=True, **dec), mlm=False, backend="hip").cuda().train()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        l1, _ = p.training_step(batch)
+        l2, _ = p.training_step(batch)
+    (l1 + l2).backward()                                   # two forwards, one generation: legal
+    assert all(torch.isfinite(q.grad).all() for q in p.parameters() if q.grad is not None)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        l3, _ = p.training_step(batch)
+    train.mark_parameters_updated(p)
+    with pytest.raises(RuntimeError, match="between this forward and its backward"):
+        l3.backward()

@@ -299,6 +299,7 @@ def main(argv=None):
                     scaler.unscale_(opt)
                     torch.nn.utils.clip_grad_norm_(module.parameters(), args.max_grad_norm)      # gradient_clip_val
                     scaler.step(opt); scaler.update(); sched.step()
+                    T.mark_parameters_updated(module)
                     opt.zero_grad(set_to_none=True)
                     global_step += 1
                     if rank == 0 and global_step % max(1, args.print_freq) == 0:

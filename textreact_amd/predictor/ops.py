@@ -527,8 +527,15 @@ class WeightShadows:
     every forward re-copies all of them (parameters change between forwards, not inside one)."""
 
     def __init__(self):
-        self.groups = {}          # tuple(id(weight) ...) -> (weights, biases, w16, b16)
+        self.groups = {}          # (tuple(id(weight) ...), has biases) -> (weights, biases, w16, b16)
         self._dst, self._src = [], []
+        self.generation = 0       # moves when the parameters behind the shadows are known to have changed (mark_stale)
+
+    def mark_stale(self):
+        """the trainer calls this after an optimizer step / load_state_dict: a backward whose forward ran before it would
+        read the NEXT forward's values out of the shared buffers, and says so instead (`_LinearWgrad.backward`).  Two
+        forwards before their backwards (no step in between) keep one generation and stay legal."""
+        self.generation += 1
 
     # a copy or a pickle of the model starts with an empty registry (views into packed buffers do not survive either)
     def __deepcopy__(self, memo):
@@ -550,7 +557,7 @@ class WeightShadows:
             torch._foreach_copy_(self._dst, [p.detach() for p in self._src])
 
     def lookup(self, weights, biases):
-        key = tuple(id(w) for w in weights)
+        key = (tuple(id(w) for w in weights), biases is not None)
         g = self.groups.get(key)
         if g is None:
             with torch.no_grad():
@@ -609,7 +616,9 @@ class _LinearWgrad(torch.autograd.Function):
         bf = torch.bfloat16
         if _shadows is not None and weights[0].dtype == torch.float32:
             w16, b16 = _shadows.lookup(weights, biases)
+            ctx.shadow = (_shadows, _shadows.generation)
         else:
+            ctx.shadow = None
             w16 = weights[0].to(bf) if n == 1 else torch.cat([w.to(bf) for w in weights])
             b16 = None if biases is None else (biases[0].to(bf) if n == 1 else torch.cat([b.to(bf) for b in biases]))
         # w16 rides on ctx, not in save_for_backward: a shadow is re-copied (with the same values) by the next forward, and
@@ -632,6 +641,9 @@ class _LinearWgrad(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         (x,), w16 = ctx.saved_tensors, ctx.w16
+        if ctx.shadow is not None and ctx.shadow[0].generation != ctx.shadow[1]:
+            raise RuntimeError("linear backward: the parameters were updated (optimizer step / load_state_dict) between this "
+                               "forward and its backward; the shared bf16 weight copies now hold the new values")
         n = ctx.n
         dx = dw = db = None
         dy2 = dy.reshape(-1, dy.shape[-1]).to(torch.bfloat16)      # a no-op except behind an fp16-autocast consumer

@@ -183,10 +183,20 @@ def save_checkpoint(path, module, optimizer=None, lr_scheduler=None, epoch=0, gl
     return path
 
 
+def mark_parameters_updated(module):
+    """call after an optimizer step or a load_state_dict: the bf16 weight copies the HIP backend's `linear` shares between
+    forwards (ops.WeightShadows) belong to a new generation; a backward of an older forward raises instead of reading them"""
+    for m in module.modules():
+        reg = m.__dict__.get("_weight_shadows")
+        if reg is not None:
+            reg.mark_stale()
+
+
 def load_checkpoint(path, module, optimizer=None, lr_scheduler=None, strict=False):
     ckpt = torch.load(path, map_location="cpu", weights_only=False)
     sd = {k: v for k, v in ckpt["state_dict"].items() if not k.endswith("position_ids")}   # 4.27.3 buffer
     missing, unexpected = module.load_state_dict(sd, strict=strict)
+    mark_parameters_updated(module)
     if optimizer is not None and ckpt.get("optimizer_states"):
         optimizer.load_state_dict(ckpt["optimizer_states"][0])
     if lr_scheduler is not None and ckpt.get("lr_schedulers"):
