@@ -566,10 +566,20 @@ __device__ __forceinline__ void attn_softmax_tile(f32x16& s0, f32x16& s1, f32x16
     const float mref = (mn == -__builtin_inff()) ? 0.f : mn;   // all hidden so far: exp2(-inf - 0) = 0, no NaN
     const float alpha = __builtin_amdgcn_exp2f(m - mref);
     const float nref = -mref;
+    // the exponent's argument two registers at a time (v_pk_fma_f32: one issue slot for two fmas; the exponentials and
+    // these fmas are most of the kernel's vector instructions)
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    const f32x2 sl2v = {sl2, sl2}, nrefv = {nref, nref};
 #pragma unroll
-    for (int t = 0; t < 16; ++t) s0[t] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[t], sl2, nref));
+    for (int t = 0; t < 16; t += 2) {
+        const f32x2 a = __builtin_elementwise_fma((f32x2){s0[t], s0[t + 1]}, sl2v, nrefv);
+        s0[t] = __builtin_amdgcn_exp2f(a.x); s0[t + 1] = __builtin_amdgcn_exp2f(a.y);
+    }
 #pragma unroll
-    for (int t = 0; t < 16; ++t) s1[t] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[t], sl2, nref));
+    for (int t = 0; t < 16; t += 2) {
+        const f32x2 a = __builtin_elementwise_fma((f32x2){s1[t], s1[t + 1]}, sl2v, nrefv);
+        s1[t] = __builtin_amdgcn_exp2f(a.x); s1[t + 1] = __builtin_amdgcn_exp2f(a.y);
+    }
     float ps = 0.f;
     if (DROP) {
         // the row sum takes every probability; the dropped ones are then zeroed for the P V product

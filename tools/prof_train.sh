@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $R/tools/train_step_one.py 4 hip ${1:-512} ${2:-160} > $OUT/log.txt 2>&1
 tail -2 $OUT/log.txt
 f=$(ls $OUT/*/*kernel_stats.csv | head -1)
-cp $f $R/gpurun_out/r01_train_step_kernel_stats_${1:-512}.csv
+cp $f $R/gpurun_out/train_step_kernel_stats_${1:-512}.csv
 python3 - <<PY
 import csv
 rows=list(csv.DictReader(open("$f")))
