@@ -294,7 +294,7 @@ static int search_batch(trx_index* idx, const void* q, int64_t nq, int is_bf, in
     if ((rc = idx->w_cnt.reserve((size_t)q_pad * nlists * sizeof(u32)))) return rc;
     if ((rc = idx->w_thr.reserve((size_t)q_pad * nlists * sizeof(u64)))) return rc;
     if ((rc = idx->w_flag.reserve((size_t)(nq + 4) * sizeof(int)))) return rc;
-    if ((rc = idx->w_gthr.reserve((size_t)q_pad * sizeof(u32)))) return rc;
+    if ((rc = idx->w_gthr.reserve((size_t)q_pad * 4 * sizeof(u32)))) return rc;
 
     // query operand + norms
     HIPCHK(hipMemsetAsync(idx->w_qg.p, 0, (size_t)q_pad * Kp * sizeof(bf16_t), st));
@@ -317,7 +317,7 @@ static int search_batch(trx_index* idx, const void* q, int64_t nq, int is_bf, in
     sp.stamp_out = (unsigned long long*)idx->w_stamp.p;
 #endif
     sp.g_thr = (u32*)idx->w_gthr.p;
-    HIPCHK(hipMemsetAsync(sp.g_thr, 0, (size_t)q_pad * sizeof(u32), st));
+    HIPCHK(hipMemsetAsync(sp.g_thr, 0, (size_t)q_pad * 4 * sizeof(u32), st));
     // seed the shared thresholds: every query tile scans a few tiles (selection bookkeeping only, no lists)
     const bool boot = !getenv("TRX_NO_BOOT") && ntiles > 2;
     if (boot) {

@@ -121,7 +121,7 @@ struct ScanParams {
     u64* cand;               // [q_pad][nsplits][8][cap_alloc] packed (key,id), append order
     u32* cand_cnt;           // [q_pad][nsplits][8]
     u64* cand_thr;           // [q_pad][nsplits][8] every unlisted row of the list's rows has comp <= this
-    u32* g_thr;              // [q_pad] ordkey of a key that at least kprime corpus rows reach; shared by all
+    u32* g_thr;              // [q_pad / 256][4 slots][256] ordkeys; the smallest of a query's 4 slots is a key that at least kprime corpus rows reach; shared by all
                              // workgroups of a query (atomicMax, monotone; a stale read is only looser)
     int bootstrap;           // 1: threshold bootstrap launch (boot_tiles tiles per query tile, publish g_thr only)
     int boot_tiles;

@@ -45,9 +45,14 @@
 //     query (4 row quads x 2 wave rows) see disjoint rows: the minimum over those 8 lanes of the J-th best is
 //     a key that at least 8 J = kprime corpus rows reach, so a row below it is outside the top kprime.
 //     Refreshed every 8th tile (2 cross-lane steps + the partner wave's value through LDS, which may be
-//     stale: stale = lower = still valid), shared between the splits of a query through g_thr (atomicMax
-//     every 32nd tile; a one-piece LDS-DMA brings the other splits' values back) and seeded by a bootstrap
-//     launch of this kernel over 16 tiles.
+//     stale: stale = lower = still valid) and seeded by a bootstrap launch of this kernel over 16 tiles.
+//   * shared between the splits of a query through g_thr, FOUR slots per query (slot = split & 3): a split
+//     publishes (atomicMax) a key that at least kprime / 4 of ITS rows reach -- kprime 16: the smaller of its two
+//     wave rows' second-best tracked maxima, 2 + 2 rows -- and the splits see disjoint rows, so the minimum over
+//     the four slots is a key that kprime rows of the corpus reach.  That is a far tighter bound than any split
+//     finds alone (its own needs all kprime rows inside the split, through per-lane J-th bests): the rows listed
+//     per tile fall by more than half.  Published at tiles 7, 15 and every 16th, read back by four one-piece
+//     LDS-DMAs.  The bootstrap launch (and kprime 32) publish a bound that stands alone into all four slots.
 //   * a list that could not take another tile (32 rows) is cut to its kprime best (key desc, id asc) by
 //     the whole wave at the end of the tile; the packed value in kprime-th place becomes the list's floor
 //     and its key the lane's threshold: tie-heavy or adversarially ordered corpora get here (random data
@@ -80,12 +85,13 @@ typedef __attribute__((address_space(1))) const void gbl_void;
 constexpr int LDS_A0 = 0;
 constexpr int LDS_B0 = 2 * TILE_M * 128;         // 65536
 constexpr int S_THRW = LDS_B0 + 2 * TILE_N * 128;  // 131072: f32 [2 wave rows][256 queries] own threshold of a wave row
-constexpr int S_GTHR = S_THRW + 2 * TILE_N * 4;  // u32 [256] copy of g_thr
-constexpr int S_BIAS = S_GTHR + TILE_N * 4;      // f32 [2 tile parities][256 rows]  (L2)
+constexpr int S_GTHR = S_THRW + 2 * TILE_N * 4;  // u32 [4 slots][256] copy of g_thr
+constexpr int S_E2 = S_GTHR + 4 * TILE_N * 4;    // f32 [2 wave rows][256] second-best tracked maximum of a wave row (what the split shares)
+constexpr int S_BIAS = S_E2 + 2 * TILE_N * 4;    // f32 [2 tile parities][256 rows]  (L2)
 constexpr int S_TRK = S_BIAS + 2 * TILE_M * 4;   // u32 [8][512 threads]: every lane's tracked tile maxima (see tile_end)
-constexpr int LDS_TOTAL = S_TRK + 8 * SCAN_THREADS * 4;   // 152,576 B -> one workgroup per CU
+constexpr int LDS_TOTAL = S_TRK + 8 * SCAN_THREADS * 4;   // 157,696 B -> one workgroup per CU
 // ds instruction offsets are 16-bit: the selection state is addressed relative to S_THRW
-constexpr int R_THRW = 0, R_GTHR = S_GTHR - S_THRW;
+constexpr int R_THRW = 0, R_GTHR = S_GTHR - S_THRW, R_E2 = S_E2 - S_THRW;
 
 // LDS accesses of the selection state go through asm: a C++ access to the array the LDS-DMA writes makes
 // hipcc drain vmcnt to 0 (cdna_hip_programming.md section 5, "Three .s-level traps").  Addresses are
@@ -245,12 +251,13 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
         lds_st32<0>(a_trk, ninf); lds_st32<2048>(a_trk, ninf); lds_st32<4096>(a_trk, ninf); lds_st32<6144>(a_trk, ninf);
         lds_st32<8192>(a_trk, ninf); lds_st32<10240>(a_trk, ninf); lds_st32<12288>(a_trk, ninf); lds_st32<14336>(a_trk, ninf);
     }
-    if (tid < TILE_N) {
-        const u32 g = BOOT ? 0u : __hip_atomic_load(p.g_thr + qbase + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    {   // g_thr: [query tile][4 slots][256 queries]
         const u32 t4 = lds0 + S_THRW + tid * 4;
-        lds_st32<R_GTHR>(t4, g);
-        lds_st32<R_THRW>(t4, __float_as_uint(NEG_INF));
-        lds_st32<R_THRW + 1024>(t4, __float_as_uint(NEG_INF));
+        const u32* gsrc = p.g_thr + qbase * 4;
+        lds_st32<R_GTHR>(t4, BOOT ? 0u : __hip_atomic_load(gsrc + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        lds_st32<R_GTHR + 2048>(t4, BOOT ? 0u : __hip_atomic_load(gsrc + 512 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        lds_st32<R_THRW>(t4, __float_as_uint(NEG_INF));      // 512 threads: both wave rows
+        lds_st32<R_E2>(t4, __float_as_uint(NEG_INF));
     }
 
     f32x4 acc[8][4];
@@ -301,7 +308,13 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
     }
 
     {
-        auto seed = [&](auto NT) { constexpr int nt = decltype(NT)::value; const u32 g = lds_ld32<R_GTHR + 64 * nt>(b4_0); if (g) thrk[nt] = KI * ordkey_inv(g); };
+        auto seed = [&](auto NT) {      // the smallest of the four slots (0 = a slot nobody has published to yet)
+            constexpr int nt = decltype(NT)::value;
+            const u32 g01 = min(lds_ld32<R_GTHR + 64 * nt>(b4_0), lds_ld32<R_GTHR + 1024 + 64 * nt>(b4_0));
+            const u32 g23 = min(lds_ld32<R_GTHR + 2048 + 64 * nt>(b4_0), lds_ld32<R_GTHR + 3072 + 64 * nt>(b4_0));
+            const u32 g = min(g01, g23);
+            if (g) thrk[nt] = KI * ordkey_inv(g);
+        };
         seed(ic<0>{}); seed(ic<1>{}); seed(ic<2>{}); seed(ic<3>{});
     }
 
@@ -492,22 +505,59 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
                 lds_st32<R_THRW + 0>(b4_m, __float_as_uint(g[0])); lds_st32<R_THRW + 64>(b4_m, __float_as_uint(g[1]));
                 lds_st32<R_THRW + 128>(b4_m, __float_as_uint(g[2])); lds_st32<R_THRW + 192>(b4_m, __float_as_uint(g[3]));
             }
-            u32 gp[4], gs[4];
-            asm volatile("ds_read_b32 %0, %8 offset:%10\n\tds_read_b32 %1, %8 offset:%11\n\tds_read_b32 %2, %8 offset:%12\n\tds_read_b32 %3, %8 offset:%13\n\t"
-                         "ds_read_b32 %4, %9 offset:%14\n\tds_read_b32 %5, %9 offset:%15\n\tds_read_b32 %6, %9 offset:%16\n\tds_read_b32 %7, %9 offset:%17\n\t"
-                         "s_waitcnt lgkmcnt(0)"
-                         : "=&v"(gp[0]), "=&v"(gp[1]), "=&v"(gp[2]), "=&v"(gp[3]), "=&v"(gs[0]), "=&v"(gs[1]), "=&v"(gs[2]), "=&v"(gs[3])
-                         : "v"(b4_p), "v"(b4_0), "n"(R_THRW), "n"(R_THRW + 64), "n"(R_THRW + 128), "n"(R_THRW + 192),
-                           "n"(R_GTHR), "n"(R_GTHR + 64), "n"(R_GTHR + 128), "n"(R_GTHR + 192)
-                         : "memory");
+            u32 gp[4], gs[4][4];
+            asm volatile("ds_read_b32 %0, %4 offset:%5\n\tds_read_b32 %1, %4 offset:%6\n\tds_read_b32 %2, %4 offset:%7\n\tds_read_b32 %3, %4 offset:%8"
+                         : "=&v"(gp[0]), "=&v"(gp[1]), "=&v"(gp[2]), "=&v"(gp[3])
+                         : "v"(b4_p), "n"(R_THRW), "n"(R_THRW + 64), "n"(R_THRW + 128), "n"(R_THRW + 192) : "memory");
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl)
+                asm volatile("ds_read_b32 %0, %4 offset:%5\n\tds_read_b32 %1, %4 offset:%6\n\tds_read_b32 %2, %4 offset:%7\n\tds_read_b32 %3, %4 offset:%8"
+                             : "=&v"(gs[sl][0]), "=&v"(gs[sl][1]), "=&v"(gs[sl][2]), "=&v"(gs[sl][3])
+                             : "v"(b4_0 + sl * 1024), "n"(R_GTHR), "n"(R_GTHR + 64), "n"(R_GTHR + 128), "n"(R_GTHR + 192) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const bool publish = !BOOT && ((TL & 15) == 15 || TL == 7);
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-                const float both = __builtin_fminf(g[nt], __uint_as_float(gp[nt]));      // 8 J rows reach this key
+                const float both = __builtin_fminf(g[nt], __uint_as_float(gp[nt]));      // 8 J rows of this split reach this key
                 float t = __builtin_fmaxf(thrk[nt], both);
-                if (gs[nt]) t = __builtin_fmaxf(t, KI * ordkey_inv(gs[nt]));               // what the other splits have published
+                const u32 gm = min(min(gs[0][nt], gs[1][nt]), min(gs[2][nt], gs[3][nt])); // kprime rows of the corpus reach this one
+                if (gm) t = __builtin_fmaxf(t, KI * ordkey_inv(gm));
                 thrk[nt] = t;
-                if (!BOOT && (TL & 31) == 31 && wave_m == 0 && fq == 0 && both > NEG_INF)    // tell the other splits, now and then
-                    __hip_atomic_fetch_max(p.g_thr + qbase + ql0 + 16 * nt, ordkey(KS * both), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (J != 2 && publish && wave_m == 0 && fq == 0 && both > NEG_INF) {         // a bound that stands alone: all four slots
+                    const u32 ok = ordkey(KS * both);
+#pragma unroll
+                    for (int sl = 0; sl < 4; ++sl)
+                        if (ok > gs[sl][nt]) __hip_atomic_fetch_max(p.g_thr + (qbase * 4 + sl * 256 + ql0 + 16 * nt), ok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            if (J == 2 && publish) {
+                // what this split tells the others: the second-best of the 8 tracked maxima of this wave row (4 lanes x 2),
+                // then the smaller of the two wave rows' values (the partner's may be one publish old: lower, still valid):
+                // 2 + 2 rows of this split reach it
+                float e2[4];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const float u0 = __shfl_xor(trk[0][nt], 16, 64), u1 = __shfl_xor(trk[1][nt], 16, 64);
+                    const float c0 = __builtin_fmaxf(trk[0][nt], u0);
+                    const float c1 = __builtin_fmaxf(__builtin_fminf(trk[0][nt], u0), __builtin_fmaxf(trk[1][nt], u1));
+                    const float d0 = __shfl_xor(c0, 32, 64), d1 = __shfl_xor(c1, 32, 64);
+                    e2[nt] = __builtin_fmaxf(__builtin_fminf(c0, d0), __builtin_fmaxf(c1, d1));
+                }
+                if (fq == 0) {
+                    lds_st32<R_E2 + 0>(b4_m, __float_as_uint(e2[0])); lds_st32<R_E2 + 64>(b4_m, __float_as_uint(e2[1]));
+                    lds_st32<R_E2 + 128>(b4_m, __float_as_uint(e2[2])); lds_st32<R_E2 + 192>(b4_m, __float_as_uint(e2[3]));
+                    u32 ep[4];
+                    asm volatile("ds_read_b32 %0, %4 offset:%5\n\tds_read_b32 %1, %4 offset:%6\n\tds_read_b32 %2, %4 offset:%7\n\tds_read_b32 %3, %4 offset:%8\n\t"
+                                 "s_waitcnt lgkmcnt(0)"
+                                 : "=&v"(ep[0]), "=&v"(ep[1]), "=&v"(ep[2]), "=&v"(ep[3])
+                                 : "v"(b4_p), "n"(R_E2), "n"(R_E2 + 64), "n"(R_E2 + 128), "n"(R_E2 + 192) : "memory");
+                    const int slot = split & 3;
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        const float v4 = __builtin_fminf(e2[nt], __uint_as_float(ep[nt]));
+                        if (v4 > NEG_INF) __hip_atomic_fetch_max(p.g_thr + (qbase * 4 + slot * 256 + ql0 + 16 * nt), ordkey(KS * v4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
             }
         }
 #ifdef TRX_STAMP_BUILD
@@ -524,9 +574,9 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
     // regular pieces (the other splits' thresholds every 8 tiles, wave 1; the next tile's bias, L2, wave 2)
 #define TRX_PAIR_HEAD()                                                                                    \
     {                                                                                                      \
-        const bool aux_g = !BOOT && wave == 1 && (tl & 31) == 15;                                          \
+        const bool aux_g = !BOOT && (wave >> 2) == 1 && ((tl & 15) == 3 || tl == 11);                      \
         const bool aux_b = L2 && wave == 2;                                                                \
-        const bool strict = tl > 0 && !dbg_nofilter && (BOOT || ((tl - 1) & 31) == 31);                    \
+        const bool strict = tl > 0 && !dbg_nofilter && (BOOT || ((tl - 1) & 15) == 15 || tl == 8);         \
         if (strict) {                                                                                      \
             /* bookkeeping that publishes thresholds to g_thr issues atomics, which count in vmcnt like the DMA    \
                pieces: retire the previous load phase's pieces first (two intervals old) and wait for nothing at   \
@@ -540,7 +590,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
         }                                                                                                  \
         TRX_READ(0, 0);                                                                                    \
         TRX_READ_BIAS();                                                                                   \
-        if (aux_g) __builtin_amdgcn_global_load_lds((gbl_void*)(p.g_thr + qbase + lane * 4), (lds_void*)(smem + S_GTHR), 16, 0, 0); \
+        if (aux_g) __builtin_amdgcn_global_load_lds((gbl_void*)(p.g_thr + (qbase * 4 + (wave & 3) * 256 + lane * 4)), (lds_void*)(smem + S_GTHR + (wave & 3) * 1024), 16, 0, 0); \
         if (aux_b) __builtin_amdgcn_global_load_lds((gbl_void*)(p.cbias + (int64_t)(tile0 + tl + 1) * TILE_M + lane * 4), \
                                                     (lds_void*)(smem + S_BIAS + ((tl + 1) & 1) * 1024), 16, 0, 0); \
         TRX_DMA_B(1);                                                                                      \
@@ -648,7 +698,11 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
                 const float a = __uint_as_float(lds_ld32<R_THRW + 64 * nt>(b4_m));
                 const float b = __uint_as_float(lds_ld32<R_THRW + 64 * nt>(b4_p));
                 const float both = __builtin_fminf(a, b);
-                if (both > NEG_INF) __hip_atomic_fetch_max(p.g_thr + qbase + ql0 + 16 * nt, ordkey(KS * both), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (both > NEG_INF) {     // kprime rows reach it: it stands alone, so it goes into all four slots
+#pragma unroll
+                    for (int sl = 0; sl < 4; ++sl)
+                        __hip_atomic_fetch_max(p.g_thr + (qbase * 4 + sl * 256 + ql0 + 16 * nt), ordkey(KS * both), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             };
             pubb(ic<0>{}); pubb(ic<1>{}); pubb(ic<2>{}); pubb(ic<3>{});
         }
