@@ -583,17 +583,18 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
                the end; the next load phase's vmcnt(4) covers everything issued here */                      \
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                               \
         }                                                                                                  \
-        if (tl > 0 && !dbg_nofilter) {                                                                     \
-            /* the partner wave on this SIMD is issuing MFMAs meanwhile */                                  \
-            tile_end(tl - 1);                                                                              \
-            __builtin_amdgcn_sched_barrier(0);                                                             \
-        }                                                                                                  \
         TRX_READ(0, 0);                                                                                    \
         TRX_READ_BIAS();                                                                                   \
         if (aux_g) __builtin_amdgcn_global_load_lds((gbl_void*)(p.g_thr + (qbase * 4 + (wave & 3) * 256 + lane * 4)), (lds_void*)(smem + S_GTHR + (wave & 3) * 1024), 16, 0, 0); \
         if (aux_b) __builtin_amdgcn_global_load_lds((gbl_void*)(p.cbias + (int64_t)(tile0 + tl + 1) * TILE_M + lane * 4), \
                                                     (lds_void*)(smem + S_BIAS + ((tl + 1) & 1) * 1024), 16, 0, 0); \
         TRX_DMA_B(1);                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        if (tl > 0 && !dbg_nofilter) {                                                                     \
+            /* the partner wave on this SIMD is issuing MFMAs meanwhile; the fragment reads above are in flight */ \
+            tile_end(tl - 1);                                                                              \
+            __builtin_amdgcn_sched_barrier(0);                                                             \
+        }                                                                                                  \
         if (strict) { TRX_WAIT_L(63); } else if (aux_g || aux_b) { TRX_WAIT_L(5); } else { TRX_WAIT_L(4); } \
     }
 #define TRX_PAIR_HEAD_PLAIN()                                                                              \
