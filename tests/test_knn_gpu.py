@@ -293,6 +293,18 @@ def test_more_than_one_query_batch_and_many_splits():
         assert st["n_splits"] > 1
 
 
+@pytest.mark.parametrize("nsplits", [1, 3, 4, 5, 8, 13])
+def test_shared_thresholds_with_any_number_of_splits(nsplits, monkeypatch):
+    """the splits of a query share thresholds through four slots (slot = split & 3, knn_scan.hip): exact for split counts
+    below, at and above four and not a multiple of it, for both threshold depths (k <= 12: k' = 16; k = 20: k' = 32),
+    on a corpus long enough (782 tiles) for the shared bound to take over from each split's own"""
+    monkeypatch.setenv("TRX_NSPLITS", str(nsplits))
+    y = gaussian(200_000, 64, 11); x = gaussian(520, 64, 12)
+    for metric, k in ((IP, 10), (L2, 20)):
+        st = _check(metric, x, y, k)
+        assert st["n_splits"] == min(nsplits, 782) and st["n_uncertified"] == 0
+
+
 def test_device_tensors_fp32_and_reset():
     import torch
     import textreact_amd.faiss_compat as faiss
