@@ -49,10 +49,10 @@
 //   * shared between the splits of a query through g_thr, FOUR slots per query (slot = split & 3): a split
 //     publishes (atomicMax) a key that at least kprime / 4 of ITS rows reach -- kprime 16: the smaller of its two
 //     wave rows' second-best tracked maxima, 2 + 2 rows -- and the splits see disjoint rows, so the minimum over
-//     the four slots is a key that kprime rows of the corpus reach.  That is a far tighter bound than any split
+//     the four slots is a key that kprime rows of the corpus reach (kprime 32: the fourth-best of 16, 4 + 4 rows).  That is a far tighter bound than any split
 //     finds alone (its own needs all kprime rows inside the split, through per-lane J-th bests): the rows listed
 //     per tile fall by more than half.  Published at tiles 7, 15 and every 16th, read back by four one-piece
-//     LDS-DMAs.  The bootstrap launch (and kprime 32) publish a bound that stands alone into all four slots.
+//     LDS-DMAs.  The bootstrap launch publishes a bound that stands alone into all four slots.
 //   * a list that could not take another tile (32 rows) is cut to its kprime best (key desc, id asc) by
 //     the whole wave at the end of the tile; the packed value in kprime-th place becomes the list's floor
 //     and its key the lane's threshold: tie-heavy or adversarially ordered corpora get here (random data
@@ -523,25 +523,35 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
                 const u32 gm = min(min(gs[0][nt], gs[1][nt]), min(gs[2][nt], gs[3][nt])); // kprime rows of the corpus reach this one
                 if (gm) t = __builtin_fmaxf(t, KI * ordkey_inv(gm));
                 thrk[nt] = t;
-                if (J != 2 && publish && wave_m == 0 && fq == 0 && both > NEG_INF) {         // a bound that stands alone: all four slots
-                    const u32 ok = ordkey(KS * both);
-#pragma unroll
-                    for (int sl = 0; sl < 4; ++sl)
-                        if (ok > gs[sl][nt]) __hip_atomic_fetch_max(p.g_thr + (qbase * 4 + sl * 256 + ql0 + 16 * nt), ok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
             }
-            if (J == 2 && publish) {
-                // what this split tells the others: the second-best of the 8 tracked maxima of this wave row (4 lanes x 2),
-                // then the smaller of the two wave rows' values (the partner's may be one publish old: lower, still valid):
-                // 2 + 2 rows of this split reach it
+            if (publish) {
+                // what this split tells the others: the J-th best of the 4 J tracked maxima of this wave row (4 lanes x their
+                // J best, each sorted), then the smaller of the two wave rows' values (the partner's may be one publish old:
+                // lower, still valid): J + J = kprime / 4 rows of this split reach it
                 float e2[4];
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) {
-                    const float u0 = __shfl_xor(trk[0][nt], 16, 64), u1 = __shfl_xor(trk[1][nt], 16, 64);
-                    const float c0 = __builtin_fmaxf(trk[0][nt], u0);
-                    const float c1 = __builtin_fmaxf(__builtin_fminf(trk[0][nt], u0), __builtin_fmaxf(trk[1][nt], u1));
-                    const float d0 = __shfl_xor(c0, 32, 64), d1 = __shfl_xor(c1, 32, 64);
-                    e2[nt] = __builtin_fmaxf(__builtin_fminf(c0, d0), __builtin_fmaxf(c1, d1));
+                    if (J == 2) {
+                        const float u0 = __shfl_xor(trk[0][nt], 16, 64), u1 = __shfl_xor(trk[1][nt], 16, 64);
+                        const float c0 = __builtin_fmaxf(trk[0][nt], u0);
+                        const float c1 = __builtin_fmaxf(__builtin_fminf(trk[0][nt], u0), __builtin_fmaxf(trk[1][nt], u1));
+                        const float d0 = __shfl_xor(c0, 32, 64), d1 = __shfl_xor(c1, 32, 64);
+                        e2[nt] = __builtin_fmaxf(__builtin_fminf(c0, d0), __builtin_fmaxf(c1, d1));
+                    } else {
+                        // two sorted lists of 4: the 4 largest of their union are max(a_i, b_(3-i)) -- a bitonic sequence,
+                        // sorted by two rounds of compare-exchange; the second merge only needs its smallest element
+                        float c[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) c[i] = __builtin_fmaxf(trk[i][nt], __shfl_xor(trk[3 - i][nt], 16, 64));
+                        const float x0 = __builtin_fmaxf(c[0], c[2]), x2 = __builtin_fminf(c[0], c[2]);
+                        const float x1 = __builtin_fmaxf(c[1], c[3]), x3 = __builtin_fminf(c[1], c[3]);
+                        c[0] = __builtin_fmaxf(x0, x1); c[1] = __builtin_fminf(x0, x1);
+                        c[2] = __builtin_fmaxf(x2, x3); c[3] = __builtin_fminf(x2, x3);
+                        float e = __builtin_fmaxf(c[0], __shfl_xor(c[3], 32, 64));
+#pragma unroll
+                        for (int i = 1; i < 4; ++i) e = __builtin_fminf(e, __builtin_fmaxf(c[i], __shfl_xor(c[3 - i], 32, 64)));
+                        e2[nt] = e;
+                    }
                 }
                 if (fq == 0) {
                     lds_st32<R_E2 + 0>(b4_m, __float_as_uint(e2[0])); lds_st32<R_E2 + 64>(b4_m, __float_as_uint(e2[1]));
