@@ -143,21 +143,45 @@ def dropout_keep_mask(seed, p, streams, rows, cols, device):
     return keep.bool()
 
 
+def _add_ln_fwd_launch(x, res, gamma, beta, eps, p, seed, want_stats):
+    """trx_add_layernorm_fwd_dropout: y = LayerNorm(dropout(x) + res); returns y, mean, rstd (None unless want_stats) and
+    the operands as the backward takes them"""
+    _need_gpu(x)
+    xs = x.contiguous()
+    rs = res.contiguous() if res is not None else None
+    cols = xs.shape[-1]
+    rows = xs.numel() // cols
+    y = torch.empty_like(xs)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device) if want_stats else None
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if want_stats else None
+    g, b = gamma.float().contiguous(), beta.float().contiguous()
+    _check(lib().trx_add_layernorm_fwd_dropout(_p(xs), _p(rs), _p(g), _p(b), float(eps), rows, cols, _dt(xs),
+                                               float(p), int(seed), _p(y), _p(mean), _p(rstd), _stream(xs)))
+    return y, mean, rstd, xs, rs, g
+
+
+def _add_ln_bwd_launch(dy, xs, rs, g, mean, rstd, p, seed):
+    """returns dz (the gradient of dropout(x) + res, = the residual's gradient), dx (x's gradient through its dropout; dz
+    itself when p == 0), dgamma, dbeta"""
+    dy = dy.contiguous()
+    cols = xs.shape[-1]
+    rows = xs.numel() // cols
+    nblk = lib().trx_add_layernorm_bwd_blocks(rows)
+    ws = torch.empty(2 * nblk * cols, dtype=torch.float32, device=xs.device)
+    dz = torch.empty_like(xs)
+    dx = torch.empty_like(xs) if p > 0 else None
+    dg = torch.empty(cols, dtype=torch.float32, device=xs.device)
+    db = torch.empty(cols, dtype=torch.float32, device=xs.device)
+    _check(lib().trx_add_layernorm_bwd_dropout(_p(dy), _p(xs), _p(rs), _p(g), _p(mean), _p(rstd), rows, cols, _dt(xs),
+                                               float(p), int(seed), _p(dz), _p(dx), _p(dg), _p(db), _p(ws), _stream(xs)))
+    return dz, (dx if p > 0 else dz), dg, db
+
+
 class _AddLayerNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, res, gamma, beta, eps, p, seed):
-        _need_gpu(x)
-        xs = x.contiguous()
-        rs = res.contiguous() if res is not None else None
-        cols = xs.shape[-1]
-        rows = xs.numel() // cols
-        y = torch.empty_like(xs)
         need = x.requires_grad or (res is not None and res.requires_grad) or gamma.requires_grad
-        mean = torch.empty(rows, dtype=torch.float32, device=x.device) if need else None
-        rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if need else None
-        g, b = gamma.float().contiguous(), beta.float().contiguous()
-        _check(lib().trx_add_layernorm_fwd_dropout(_p(xs), _p(rs), _p(g), _p(b), float(eps), rows, cols, _dt(xs),
-                                                   float(p), int(seed), _p(y), _p(mean), _p(rstd), _stream(xs)))
+        y, mean, rstd, xs, rs, g = _add_ln_fwd_launch(x, res, gamma, beta, eps, p, seed, need)
         if need:
             ctx.save_for_backward(xs, rs if rs is not None else xs.new_empty(0), g, mean, rstd)
             ctx.has_res = rs is not None
@@ -169,18 +193,8 @@ class _AddLayerNorm(torch.autograd.Function):
         xs, rs, g, mean, rstd = ctx.saved_tensors
         rs = rs if ctx.has_res else None
         p, seed = ctx.drop
-        dy = dy.contiguous()
-        cols = xs.shape[-1]
-        rows = xs.numel() // cols
-        nblk = lib().trx_add_layernorm_bwd_blocks(rows)
-        ws = torch.empty(2 * nblk * cols, dtype=torch.float32, device=xs.device)
-        dz = torch.empty_like(xs)
-        dx = torch.empty_like(xs) if p > 0 else None
-        dg = torch.empty(cols, dtype=torch.float32, device=xs.device)
-        db = torch.empty(cols, dtype=torch.float32, device=xs.device)
-        _check(lib().trx_add_layernorm_bwd_dropout(_p(dy), _p(xs), _p(rs), _p(g), _p(mean), _p(rstd), rows, cols, _dt(xs),
-                                                   p, seed, _p(dz), _p(dx), _p(dg), _p(db), _p(ws), _stream(xs)))
-        return (dx if p > 0 else dz), (dz if ctx.has_res else None), dg, db, None, None, None
+        dz, dx, dg, db = _add_ln_bwd_launch(dy, xs, rs, g, mean, rstd, p, seed)
+        return dx, (dz if ctx.has_res else None), dg, db, None, None, None
 
 
 class _AddLayerNormMixed(torch.autograd.Function):
@@ -287,22 +301,40 @@ def add_layernorm(x, res, gamma, beta, eps, backend="hip", dropout_p=0.0, seed=N
     return torch.nn.functional.layer_norm(z.float(), (z.shape[-1],), gamma.float(), beta.float(), eps).to(x.dtype)
 
 
+def _attention_fwd_launch(q, k, v, mask, causal, scale, p, seed, want_lse):
+    """trx_attention_fwd_dropout on contiguous [B, L, H, 64] operands; mask None | [B, Lk] | [B, Lq, Lk] (additive, fp32).
+    Returns out [B, Lq, H*64], lse [B, H, Lq] (None unless want_lse), and the mask as the kernels take it."""
+    B, Lq, H, D = q.shape
+    Lk = k.shape[1]
+    mode, m = MASK_NONE, None
+    if mask is not None:
+        m = mask.float().contiguous()
+        mode = MASK_KEY if m.dim() == 2 else MASK_FULL
+        assert m.shape == ((B, Lk) if mode == MASK_KEY else (B, Lq, Lk)), m.shape
+    out = torch.empty((B, Lq, H * D), dtype=q.dtype, device=q.device)
+    lse = torch.empty((B, H, Lq), dtype=torch.float32, device=q.device) if want_lse else None
+    _check(lib().trx_attention_fwd_dropout(_p(q), _p(k), _p(v), _p(m), mode, 1 if causal else 0, B, H, Lq, Lk,
+                                           float(scale), _dt(q), float(p), int(seed), _p(out), _p(lse), _stream(q)))
+    return out, lse, m, mode
+
+
+def _attention_bwd_launch(q, k, v, m, mode, causal, scale, p, seed, out, dout, lse):
+    B, Lq, H, D = q.shape
+    Lk = k.shape[1]
+    dout = dout.contiguous()
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    _check(lib().trx_attention_bwd_dropout(_p(q), _p(k), _p(v), _p(m) if mode != MASK_NONE else None, mode,
+                                           1 if causal else 0, B, H, Lq, Lk, float(scale), _dt(q), float(p), int(seed),
+                                           _p(out), _p(dout), _p(lse), _p(dq), _p(dk), _p(dv), _stream(q)))
+    return dq, dk, dv
+
+
 class _Attention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, mask, causal, scale, p, seed):
-        B, Lq, H, D = q.shape
-        Lk = k.shape[1]
         need = q.requires_grad or k.requires_grad or v.requires_grad   # before .contiguous(): a copy made here has no flag
         q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
-        mode, m = MASK_NONE, None
-        if mask is not None:
-            m = mask.float().contiguous()
-            mode = MASK_KEY if m.dim() == 2 else MASK_FULL
-            assert m.shape == ((B, Lk) if mode == MASK_KEY else (B, Lq, Lk)), m.shape
-        out = torch.empty((B, Lq, H * D), dtype=q.dtype, device=q.device)
-        lse = torch.empty((B, H, Lq), dtype=torch.float32, device=q.device) if need else None
-        _check(lib().trx_attention_fwd_dropout(_p(q), _p(k), _p(v), _p(m), mode, 1 if causal else 0, B, H, Lq, Lk,
-                                               float(scale), _dt(q), float(p), int(seed), _p(out), _p(lse), _stream(q)))
+        out, lse, m, mode = _attention_fwd_launch(q, k, v, mask, causal, scale, p, seed, need)
         if need:
             ctx.save_for_backward(q, k, v, m if m is not None else q.new_empty(0), out, lse)
             ctx.cfg = (mode, causal, scale, float(p), int(seed))
@@ -312,13 +344,7 @@ class _Attention(torch.autograd.Function):
     def backward(ctx, dout):
         q, k, v, m, out, lse = ctx.saved_tensors
         mode, causal, scale, p, seed = ctx.cfg
-        B, Lq, H, D = q.shape
-        Lk = k.shape[1]
-        dout = dout.contiguous()
-        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-        _check(lib().trx_attention_bwd_dropout(_p(q), _p(k), _p(v), _p(m) if mode != MASK_NONE else None, mode,
-                                               1 if causal else 0, B, H, Lq, Lk, float(scale), _dt(q), p, seed,
-                                               _p(out), _p(dout), _p(lse), _p(dq), _p(dk), _p(dv), _stream(q)))
+        dq, dk, dv = _attention_bwd_launch(q, k, v, m, mode, causal, scale, p, seed, out, dout, lse)
         return dq, dk, dv, None, None, None, None, None
 
 
@@ -703,3 +729,102 @@ def linear(x, weight, bias=None, backend="hip"):
             bf = torch.bfloat16
             return torch.nn.functional.linear(x, weight.to(bf), bias.to(bf) if bias is not None else None)
     return torch.nn.functional.linear(x, weight, bias)
+
+
+# ---- torch.ops.trx.*: the same launchers behind torch.library registrations ("exposes the kernel as
+# torch.ops.trx.attention_fwd / bwd backed by extern "C" launchers taking raw device pointers + hipStream_t").  The model
+# calls the autograd Functions above directly (no dispatcher hop on a path of ~100 calls per step); a caller that wants
+# dispatcher-visible ops -- a module swap inside the reference, torch.compile -- uses these.  GPU only: like everything in
+# this file they fail on CPU tensors instead of falling back.
+_trx_lib = torch.library.Library("trx", "DEF")
+_trx_lib.define("attention_fwd(Tensor q, Tensor k, Tensor v, Tensor? mask, bool causal, float scale, float p, int seed) -> (Tensor, Tensor)")
+_trx_lib.define("attention_bwd(Tensor q, Tensor k, Tensor v, Tensor? mask, bool causal, float scale, float p, int seed, "
+                "Tensor out, Tensor dout, Tensor lse) -> (Tensor, Tensor, Tensor)")
+_trx_lib.define("add_layernorm_fwd(Tensor x, Tensor? res, Tensor gamma, Tensor beta, float eps, float p, int seed) -> (Tensor, Tensor, Tensor)")
+_trx_lib.define("add_layernorm_bwd(Tensor dy, Tensor x, Tensor? res, Tensor gamma, Tensor mean, Tensor rstd, float p, int seed) "
+                "-> (Tensor, Tensor, Tensor, Tensor)")
+
+
+def _op_attention_fwd(q, k, v, mask, causal, scale, p, seed):
+    out, lse, _, _ = _attention_fwd_launch(q.contiguous(), k.contiguous(), v.contiguous(), mask, causal, scale, p, seed, True)
+    return out, lse
+
+
+def _op_attention_bwd(q, k, v, mask, causal, scale, p, seed, out, dout, lse):
+    m = mask.float().contiguous() if mask is not None else None
+    mode = MASK_NONE if m is None else (MASK_KEY if m.dim() == 2 else MASK_FULL)
+    return _attention_bwd_launch(q.contiguous(), k.contiguous(), v.contiguous(), m, mode, causal, scale, p, seed, out, dout, lse)
+
+
+def _op_add_ln_fwd(x, res, gamma, beta, eps, p, seed):
+    y, mean, rstd, _, _, _ = _add_ln_fwd_launch(x, res, gamma, beta, eps, p, seed, True)
+    return y, mean, rstd
+
+
+def _op_add_ln_bwd(dy, x, res, gamma, mean, rstd, p, seed):
+    dz, dx, dg, db = _add_ln_bwd_launch(dy, x.contiguous(), res.contiguous() if res is not None else None,
+                                        gamma.float().contiguous(), mean, rstd, p, seed)
+    return dx, dz, dg, db
+
+
+_trx_lib.impl("attention_fwd", _op_attention_fwd, "CUDA")
+_trx_lib.impl("attention_bwd", _op_attention_bwd, "CUDA")
+_trx_lib.impl("add_layernorm_fwd", _op_add_ln_fwd, "CUDA")
+_trx_lib.impl("add_layernorm_bwd", _op_add_ln_bwd, "CUDA")
+
+
+@torch.library.register_fake("trx::attention_fwd")
+def _(q, k, v, mask, causal, scale, p, seed):
+    B, Lq, H, D = q.shape
+    return q.new_empty((B, Lq, H * D)), q.new_empty((B, H, Lq), dtype=torch.float32)
+
+
+@torch.library.register_fake("trx::attention_bwd")
+def _(q, k, v, mask, causal, scale, p, seed, out, dout, lse):
+    return torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+
+
+@torch.library.register_fake("trx::add_layernorm_fwd")
+def _(x, res, gamma, beta, eps, p, seed):
+    rows = x.numel() // x.shape[-1]
+    return torch.empty_like(x), x.new_empty(rows, dtype=torch.float32), x.new_empty(rows, dtype=torch.float32)
+
+
+@torch.library.register_fake("trx::add_layernorm_bwd")
+def _(dy, x, res, gamma, mean, rstd, p, seed):
+    c = x.shape[-1]
+    return torch.empty_like(x), torch.empty_like(x), x.new_empty(c, dtype=torch.float32), x.new_empty(c, dtype=torch.float32)
+
+
+def _attn_setup(ctx, inputs, output):
+    q, k, v, mask, causal, scale, p, seed = inputs
+    out, lse = output
+    ctx.save_for_backward(q, k, v, mask if mask is not None else q.new_empty(0), out, lse)
+    ctx.has_mask = mask is not None
+    ctx.cfg = (causal, scale, p, seed)
+
+
+def _attn_backward(ctx, dout, dlse):
+    q, k, v, mask, out, lse = ctx.saved_tensors
+    causal, scale, p, seed = ctx.cfg
+    dq, dk, dv = torch.ops.trx.attention_bwd(q, k, v, mask if ctx.has_mask else None, causal, scale, p, seed, out, dout.contiguous(), lse)
+    return dq, dk, dv, None, None, None, None, None
+
+
+def _ln_setup(ctx, inputs, output):
+    x, res, gamma, beta, eps, p, seed = inputs
+    y, mean, rstd = output
+    ctx.save_for_backward(x, res if res is not None else x.new_empty(0), gamma, mean, rstd)
+    ctx.has_res = res is not None
+    ctx.drop = (p, seed)
+
+
+def _ln_backward(ctx, dy, dmean, drstd):
+    x, res, gamma, mean, rstd = ctx.saved_tensors
+    p, seed = ctx.drop
+    dx, dz, dg, db = torch.ops.trx.add_layernorm_bwd(dy.contiguous(), x, res if ctx.has_res else None, gamma, mean, rstd, p, seed)
+    return dx, (dz if ctx.has_res else None), dg.to(gamma.dtype), db.to(gamma.dtype), None, None, None
+
+
+torch.library.register_autograd("trx::attention_fwd", _attn_backward, setup_context=_attn_setup)
+torch.library.register_autograd("trx::add_layernorm_fwd", _ln_backward, setup_context=_ln_setup)
