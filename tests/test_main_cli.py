@@ -128,3 +128,24 @@ def test_two_ranks_gloo(tmp_path):
     assert ck["global_step"] == 1            # 12 samples / (batch 6 x 2 ranks)
     pred = json.loads((out / "prediction_test_0.json").read_text())
     assert sorted(pred) == ["100", "101", "102", "103"]
+
+
+@pytest.mark.gpu
+def test_train_and_test_on_the_hip_backend(tmp_path, capsys):
+    """the same cycle on a GPU through the HIP ops (widths of 256 so that every fused path is taken), bf16 autocast as
+    `--precision bf16-mixed`, then fp16 autocast + GradScaler as the scripts' `--precision 16-mixed`"""
+    argv = _toy(tmp_path)
+    for name in ("enc.json", "dec.json"):
+        cfg = json.loads((tmp_path / name).read_text())
+        cfg.update(hidden_size=256, num_attention_heads=4, intermediate_size=512)
+        (tmp_path / name).write_text(json.dumps(cfg))
+    argv[argv.index("--kernel_backend") + 1] = "hip"
+    out = tmp_path / "out"
+    for prec in ("bf16-mixed", "16-mixed"):
+        assert M.main(argv + ["--epochs", "1", "--do_train", "--do_valid", "--do_test", "--overwrite", "--precision", prec]) == 0
+        ck = torch.load(out / "best.ckpt", weights_only=False)
+        assert ck["global_step"] == 2
+        assert all(torch.isfinite(v).all() for v in ck["state_dict"].values() if v.is_floating_point())
+        pred = json.loads((out / "prediction_test_0.json").read_text())
+        assert sorted(pred) == ["100", "101", "102", "103"] and len(pred["100"]["prediction"]) == 3
+    assert '"val_loss/1"' in capsys.readouterr().out
