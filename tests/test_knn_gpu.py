@@ -106,6 +106,26 @@ def test_sorted_corpus_bursts():
     _check(IP, x, y, 10)
 
 
+@pytest.mark.parametrize("k", [10, 20])
+def test_adversarial_order_over_long_splits(k, monkeypatch):
+    """the same ordering over 586 tiles in 4 splits of 146: every tile beats all earlier ones for every query, so own and
+    shared thresholds always lag, lists fill and are compacted again and again -- still every row accounted for"""
+    monkeypatch.setenv("TRX_NSPLITS", "4")
+    rng = np.random.default_rng(15)
+    n = 150_000
+    base = rng.standard_normal(64).astype(np.float32)
+    scale = np.linspace(0.1, 4.0, n, dtype=np.float32)[:, None]
+    y = scale * base[None, :] + 0.01 * rng.standard_normal((n, 64)).astype(np.float32)
+    x = base[None, :] + 0.05 * rng.standard_normal((300, 64)).astype(np.float32)
+    st = _check(IP, x, y, k)
+    assert st["n_splits"] == 4
+    # L2: rows on a ray from the queries' neighbourhood, the radius shrinking with the row id
+    u = rng.standard_normal(64).astype(np.float32); u /= np.linalg.norm(u)
+    radius = np.linspace(40.0, 0.5, n, dtype=np.float32)[:, None]
+    y2 = base[None, :] + radius * u[None, :] + 0.01 * rng.standard_normal((n, 64)).astype(np.float32)
+    _check(L2, x, y2, k)
+
+
 def test_add_in_chunks_and_mode_transition():
     y = np.concatenate([bf16_round(gaussian(3000, 64, 1)), gaussian(2000, 64, 2)])  # exact block, then fp32 block
     _check(IP, gaussian(100, 64, 3), y, 10, chunks=5)
