@@ -1,0 +1,45 @@
+"""bench.py through its launch contract: N = 1 directly, N = 2 as the driver launches it (torch.distributed.run, one rank
+per "GPU") -- rehearsed on one device with the gloo backend (RCCL refuses two ranks on one GPU), small sizes."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--steps", "2", "--warmup", "1", "--n-corpus", "30000", "--n-queries", "1024"]
+
+
+def _line(out):
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line_has_the_contract_fields():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _line(r.stdout)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in j, key
+    assert j["n_gpus"] == 1 and j["steps"] == 2 and j["vs_baseline"] is None and j["value"] > 0
+    assert j["roofline"]["bound"] == "mfma" and 0 < j["roofline"]["frac"] < 1
+    assert j["cpu_baseline"]["kind"] in ("port", "reference") and j["cpu_baseline"]["index_agreement_with_gpu"] == 1.0
+
+
+@pytest.mark.parametrize("mode", [[], ["--replicas"]])
+def test_two_ranks_as_the_driver_launches_it(mode):
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]
+    env = dict(os.environ, TRX_BENCH_BACKEND="gloo", TRX_BENCH_DEVICE="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL + mode
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _line(r.stdout)
+    assert j["n_gpus"] == 2 and j["value"] > 0 and j["scaling"] == "strong"
+    assert ("replicas" in j["config"]["parallelism"]) == bool(mode)
