@@ -13,7 +13,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(os.path.dirname(_HERE), "csrc", "libtrxnn.so")
+_SO = os.path.join(os.path.dirname(_HERE), "csrc", os.environ.get("TRX_NN_LIB", "libtrxnn.so"))   # TRX_NN_LIB: diagnostic builds
 _lib = None
 F32, BF16 = 0, 1
 MASK_NONE, MASK_KEY, MASK_FULL = 0, 1, 2
