@@ -493,7 +493,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
         // ---- threshold refresh (every eighth tile): min over the query's 4 lanes of this wave, then the partner wave
         // row's value and the other splits' through LDS.  All LDS traffic of the 4 columns is issued together and
         // waited for once (one access at a time cost 8 ms per search).
-        if (!dbg_norefresh && (BOOT || (TL & 7) == 7)) {
+        if (!dbg_norefresh && (BOOT ? TL == ntl - 1 : (TL & 7) == 7)) {      // bootstrap launch: once, for its final publish
             float g[4];
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) g[nt] = trk[J - 1][nt];
@@ -586,7 +586,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
     {                                                                                                      \
         const bool aux_g = !BOOT && (wave >> 2) == 1 && ((tl & 15) == 3 || tl == 11);                      \
         const bool aux_b = L2 && wave == 2;                                                                \
-        const bool strict = tl > 0 && !dbg_nofilter && (BOOT || ((tl - 1) & 15) == 15 || tl == 8);         \
+        const bool strict = tl > 0 && !dbg_nofilter && !BOOT && (((tl - 1) & 15) == 15 || tl == 8);        \
         if (strict) {                                                                                      \
             /* bookkeeping that publishes thresholds to g_thr issues atomics, which count in vmcnt like the DMA    \
                pieces: retire the previous load phase's pieces first (two intervals old) and wait for nothing at   \
