@@ -76,7 +76,8 @@ __device__ __forceinline__ double canonical_score(const void* qrow, const void* 
 // survivors of the first move to lanes 32..63, those of the second stay in lanes 0..31, and the re-scoring -- the bulk of
 // the kernel's instructions, one lane per candidate -- runs once for both, as do the final sort (two 32-lane sorts side by
 // side) and the certificate.  (One wave per query left 50+ lanes of every fp64 instruction idle: ~11 candidates survive
-// the epsilon window.  The kernel is VALU-issue bound: 5.4 k vector instructions per query before, profiles/.)
+// the epsilon window.  The kernel is VALU-issue bound: 5.4 k vector instructions per query before, 2.7 k now:
+// profiles/r02_select_pmc.json.)
 template <bool L2, bool CBF, bool QBF>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void knn_select_kernel(SelectParams p) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, hl = lane & 31, half = lane >> 5;
