@@ -123,6 +123,15 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 #define TRX_SITE_COND(M) (__builtin_expect((M) != 0ull, 0))
 #endif
 
+// cache policy of the LDS-DMA streams (gfx940+ bits: 1 sc0, 2 nt, 16 sc1): A = corpus tiles (touched by the 8 workgroups
+// of an XCD that share the split, then never again), B = query tiles (re-read for every corpus tile)
+#ifndef TRX_CPOL_A
+#define TRX_CPOL_A 0
+#endif
+#ifndef TRX_CPOL_B
+#define TRX_CPOL_B 0
+#endif
+
 template <int N> struct ic { static constexpr int value = N; };
 
 // lane id, recomputed where it is needed (volatile: hipcc would otherwise hoist everything derived from the lane id out
@@ -376,7 +385,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
         const char* s_ = (const char*)(srcB + ksB * BK);                                                   \
         char* l_ = smem + LDS_B0 + (STG) * 32768 + wave_m * 16384 + lds_piece0;                            \
         _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                   \
-            __builtin_amdgcn_global_load_lds((gbl_void*)(s_ + (i_ >> 1) * pstep + ((i_ & 1) ? po1 : po0)), (lds_void*)(l_ + i_ * 1024), 16, 0, 0); \
+            __builtin_amdgcn_global_load_lds((gbl_void*)(s_ + (i_ >> 1) * pstep + ((i_ & 1) ? po1 : po0)), (lds_void*)(l_ + i_ * 1024), 16, 0, TRX_CPOL_B); \
     }                                                                                                      \
     ksB = (ksB + 1 == ksteps) ? 0 : ksB + 1;
     // A pieces: group 0 -> rows 128-255, group 1 -> rows 0-127, of the cursor's K-step -> stage STG
@@ -384,7 +393,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
     if (!dbg_nodma) {                                                                                      \
         char* l_ = smem + LDS_A0 + (STG) * 32768 + (wave_m ? 0 : 16384) + lds_piece0;                      \
         _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                   \
-            __builtin_amdgcn_global_load_lds((gbl_void*)((const char*)srcA + (i_ >> 1) * pstep + ((i_ & 1) ? po1 : po0)), (lds_void*)(l_ + i_ * 1024), 16, 0, 0); \
+            __builtin_amdgcn_global_load_lds((gbl_void*)((const char*)srcA + (i_ >> 1) * pstep + ((i_ & 1) ? po1 : po0)), (lds_void*)(l_ + i_ * 1024), 16, 0, TRX_CPOL_A); \
     }                                                                                                      \
     srcA += BK;                                                                                            \
     if (++ksA == ksteps) { ksA = 0; srcA += wrapA; }
