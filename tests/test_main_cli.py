@@ -149,3 +149,50 @@ def test_train_and_test_on_the_hip_backend(tmp_path, capsys):
         pred = json.loads((out / "prediction_test_0.json").read_text())
         assert sorted(pred) == ["100", "101", "102", "103"] and len(pred["100"]["prediction"]) == 3
     assert '"val_loss/1"' in capsys.readouterr().out
+
+
+def _toy_template(tmp_path, seed=0):
+    """tensor files of the --template_based branch: ragged atom / bond template labels per sample"""
+    g = torch.Generator().manual_seed(seed)
+    enc = dict(vocab_size=60, hidden_size=64, num_hidden_layers=1, num_attention_heads=1, intermediate_size=64,
+               max_position_embeddings=32, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    (tmp_path / "enc.json").write_text(json.dumps(enc))
+    na_t, nb_t = 7, 5
+    for name, m in (("train", 12), ("val", 5), ("test", 4)):
+        ids = torch.randint(3, 60, (m, 14), generator=g)
+        atoms, alab, blab, bonds, raw = [], [], [], [], []
+        for i in range(m):
+            n = 3 + int(torch.randint(0, 4, (1,), generator=g))
+            atoms.append(torch.arange(1, 1 + n))
+            alab.append(torch.randint(0, na_t, (n,), generator=g))
+            bl = torch.full((n, n), -100, dtype=torch.long)
+            bs = [(a, a + 1) for a in range(n - 1)]
+            for a, b in bs:
+                bl[a, b] = int(torch.randint(0, nb_t, (1,), generator=g))
+            blab.append(bl); bonds.append([list(b) for b in bs]); raw.append([["a", 0, 1]])
+        torch.save({"indices": list(range(200, 200 + m)), "input_ids": ids, "attention_mask": torch.ones_like(ids),
+                    "atom_indices": atoms, "decoder_atom_template_labels": alab, "decoder_bond_template_labels": blab,
+                    "bonds": bonds, "decoder_raw_template_labels": raw}, tmp_path / (name + ".pt"))
+    return ["--task", "retro", "--template_based", "--encoder", "allenai/scibert_scivocab_uncased", "--arch_encoder", str(tmp_path / "enc.json"),
+            "--tok_atom_templates", str(na_t), "--tok_bond_templates", str(nb_t), "--save_path", str(tmp_path / "out"),
+            "--kernel_backend", "torch", "--tensors_train", str(tmp_path / "train.pt"), "--tensors_valid", str(tmp_path / "val.pt"),
+            "--tensors_test", str(tmp_path / "test.pt"), "--batch_size", "6", "--lr", "1e-3", "--test_batch_size", "2",
+            "--val_metric", "val_acc", "--print_freq", "1"]
+
+
+def test_template_based_branch(tmp_path, capsys):
+    """scripts/train_RetroSyn_tb.sh's branch (main.py:112-123, 138-150, 201-216): encoder + template heads, monitored by the
+    greedy edit accuracy, test step writing the ranked edits"""
+    argv = _toy_template(tmp_path)
+    out = tmp_path / "out"
+    assert M.main(argv + ["--epochs", "2", "--do_train", "--do_valid", "--do_test", "--overwrite"]) == 0
+    ck = torch.load(out / "best.ckpt", weights_only=False)
+    assert ck["callbacks"]["ModelCheckpoint"]["monitor"] == "val_acc"
+    assert any(k.startswith("model.template_head.") for k in ck["state_dict"]) and all(k.startswith("model.") for k in ck["state_dict"])
+    pred = json.loads((out / "prediction_test_0.json").read_text())
+    assert sorted(pred) == ["200", "201", "202", "203"]
+    one = pred["200"]
+    assert set(one) == {"prediction", "score", "raw_template_labels", "top1_template_match"}
+    assert len(one["prediction"]) == len(one["score"]) > 0 and one["prediction"][0][0] in ("a", "b")
+    assert one["score"] == sorted(one["score"], reverse=True)
+    assert '"val_acc"' in capsys.readouterr().out

@@ -16,6 +16,11 @@ hands the model anyway:
     --arch_encoder JSON   encoder architecture when `--encoder` names a hub model (no network here); default: BERT-base
                             with the SciBERT vocabulary size
     --tok_vocab_size N, --tok_bos_id / --tok_eos_id / --tok_pad_id   what the decoder tokenizer would have said
+    --tok_atom_templates N, --tok_bond_templates N   (--template_based) the sizes of the two template vocabularies
+        (model.py:19: len(dec_tokenizer[0]), len(dec_tokenizer[1])); the tensor files of that branch carry, per sample and
+        ragged, atom_indices [n_atoms], decoder_atom_template_labels [n_atoms], decoder_bond_template_labels
+        [n_atoms, n_atoms] (-100 = no bond), bonds [[i, j], ...] and decoder_raw_template_labels -- what
+        dataset.py's collator pads into a batch (labels with -100)
 
 The data flags of the reference are accepted and ignored with a note.  One process per GPU: launch with
 `python -m torch.distributed.run --nproc-per-node G -m textreact_amd.main ...` (backend nccl = RCCL); `--gpus` is
@@ -110,6 +115,8 @@ def get_parser():
     p.add_argument('--tok_bos_id', type=int, default=1)
     p.add_argument('--tok_eos_id', type=int, default=2)
     p.add_argument('--tok_pad_id', type=int, default=0)
+    p.add_argument('--tok_atom_templates', type=int, default=None)
+    p.add_argument('--tok_bond_templates', type=int, default=None)
     p.add_argument('--kernel_backend', type=str, default=None, choices=['hip', 'torch'],
                    help="attention / add+LayerNorm backend: hip (libtrxnn.so, default on a GPU) or the PyTorch statement of "
                         "the same ops (CPU tests)")
@@ -131,9 +138,12 @@ def _configs(args):
         enc = json.load(open(args.encoder))
     else:       # BERT-base with the SciBERT vocabulary (allenai/scibert_scivocab_uncased; the hub is unreachable here)
         enc = dict(vocab_size=31090)
-    if not args.decoder or not os.path.isfile(args.decoder):
+    if args.template_based:
+        dec = {}                                        # model.py:12: no decoder in this branch
+    elif not args.decoder or not os.path.isfile(args.decoder):
         raise SystemExit("--decoder must be a decoder config JSON (the reference passes textreact/configs/bert_l6.json)")
-    dec = json.load(open(args.decoder))
+    else:
+        dec = json.load(open(args.decoder))
     if args.tok_vocab_size:
         dec["vocab_size"] = args.tok_vocab_size         # model.py:26: the decoder's vocabulary is the tokenizer's
     keep = ("vocab_size", "hidden_size", "num_hidden_layers", "num_attention_heads", "intermediate_size",
@@ -143,33 +153,61 @@ def _configs(args):
     ok = set(inspect.signature(Config.__init__).parameters)
     enc = {k: v for k, v in enc.items() if k in keep and k in ok}
     dec = {k: v for k, v in dec.items() if k in keep and k in ok}
-    return Config(**enc), Config(is_decoder=True, **dec)
+    return Config(**enc), (Config(is_decoder=True, **dec) if dec else None)
 
 
 class TensorSplit:
     """One pre-tokenised split: what the reference's DataLoader + collator yield, batch by batch
     (`indices, batch_in, batch_out`, main.py:165)."""
     IN_KEYS = ("input_ids", "attention_mask", "decoder_input_ids", "decoder_attention_mask")
+    PADDED = ("decoder_atom_template_labels", "decoder_bond_template_labels")     # per-sample tensors, padded with -100
+    LISTS = ("atom_indices", "bonds", "decoder_raw_template_labels")              # stay per-sample lists in the batch
 
     def __init__(self, path, name):
         d = torch.load(path, map_location="cpu", weights_only=False)
         self.name = name
         self.indices = [int(i) for i in (d["indices"].tolist() if torch.is_tensor(d["indices"]) else d["indices"])]
         self.tensors = {k: d[k] for k in self.IN_KEYS if k in d}
+        self.ragged = {k: d[k] for k in self.PADDED + self.LISTS if k in d}
         self.mlm_labels = d.get("mlm_labels")
         assert "input_ids" in self.tensors and len(self.indices) == self.tensors["input_ids"].shape[0], path
+        assert all(len(v) == len(self.indices) for v in self.ragged.values()), path
 
     def __len__(self):
         return len(self.indices)
+
+    def collate(self, sel, device):
+        """the batch of samples `sel` (a list of positions): (batch_in, batch_out) on `device`"""
+        st = torch.tensor(sel, dtype=torch.long)
+        batch_in = {k: v[st].to(device) for k, v in self.tensors.items()}
+        for k in self.PADDED:
+            if k in self.ragged:
+                items = [torch.as_tensor(self.ragged[k][i]) for i in sel]
+                shape = [max(t.shape[dim] for t in items) for dim in range(items[0].dim())]
+                out = torch.full([len(items)] + shape, -100, dtype=torch.long)
+                for j, t in enumerate(items):
+                    out[(j,) + tuple(slice(0, n) for n in t.shape)] = t
+                batch_in[k] = out.to(device)
+        for k in self.LISTS:
+            if k in self.ragged:
+                vals = [self.ragged[k][i] for i in sel]
+                if k == "atom_indices":
+                    vals = [torch.as_tensor(v, dtype=torch.long).to(device) for v in vals]
+                elif k == "bonds":
+                    vals = [[tuple(b) for b in v] for v in vals]                  # combined_edit tests `idx in bonds`
+                else:
+                    vals = [[tuple(t) for t in v] for v in vals]
+                batch_in[k] = vals
+        batch_out = {"mlm_labels": self.mlm_labels[st].to(device)} if self.mlm_labels is not None else {}
+        return batch_in, batch_out
 
     def batches(self, batch_size, rank=0, world=1, device="cpu", limit=None):
         n = len(self) if limit is None else min(limit, len(self))
         order = list(range(rank, n, world))             # DistributedSampler(shuffle=False) of Lightning's eval loaders
         for b0 in range(0, len(order), batch_size):
-            sel = torch.tensor(order[b0:b0 + batch_size], dtype=torch.long)
-            batch_in = {k: v[sel].to(device) for k, v in self.tensors.items()}
-            batch_out = {"mlm_labels": self.mlm_labels[sel].to(device)} if self.mlm_labels is not None else {}
-            yield [self.indices[i] for i in sel.tolist()], batch_in, batch_out
+            sel = order[b0:b0 + batch_size]
+            batch_in, batch_out = self.collate(sel, device)
+            yield [self.indices[i] for i in sel], batch_in, batch_out
 
 
 def _load_splits(spec, name):
@@ -209,15 +247,17 @@ def main(argv=None):
     if ignored and rank == 0:
         print("note: dataset / tokenizer flags are accepted and not used here (%s): inputs are the --tensors_* files"
               % ", ".join("--" + k for k in ignored), file=sys.stderr)
-    if args.template_based:
-        raise SystemExit("--template_based: the template model (predictor/template.py) has its own steps; this entry point "
-                         "drives the template-free encoder-decoder (scripts/train_RCR*.sh, train_RetroSyn_tf*.sh)")
-
     torch.manual_seed(args.seed)                      # pl.seed_everything (main.py:351)
     backend = args.kernel_backend or ("hip" if cuda else "torch")
     enc_cfg, dec_cfg = _configs(args)
-    module = T.Predictor(enc_cfg, dec_cfg, mlm=args.mlm, mlm_layer=args.mlm_layer, mlm_lambda=args.mlm_lambda,
-                         pad_token_id=args.tok_pad_id, backend=backend).to(device)
+    if args.template_based:                           # model.py:11-19: encoder + atom / bond template heads, no decoder
+        if not (args.tok_atom_templates and args.tok_bond_templates):
+            raise SystemExit("--template_based needs --tok_atom_templates and --tok_bond_templates (the template vocabularies' sizes)")
+        from .predictor.template import TemplatePredictor
+        module = TemplatePredictor(enc_cfg, args.tok_atom_templates, args.tok_bond_templates, backend=backend).to(device)
+    else:
+        module = T.Predictor(enc_cfg, dec_cfg, mlm=args.mlm, mlm_layer=args.mlm_layer, mlm_lambda=args.mlm_lambda,
+                             pad_token_id=args.tok_pad_id, backend=backend).to(device)
     train_sets = _load_splits(args.tensors_train, "train") if args.do_train else []
     val_sets = _load_splits(args.tensors_valid, "val") if (args.do_train or args.do_valid) else []
     test_sets = _load_splits(args.tensors_test, "test") if args.do_test else []
@@ -277,9 +317,7 @@ def main(argv=None):
             micro = 0
             opt.zero_grad(set_to_none=True)
             for b0 in range(0, len(mine), args.batch_size):
-                sel = torch.tensor(mine[b0:b0 + args.batch_size], dtype=torch.long)
-                batch_in = {k: v[sel].to(device) for k, v in train.tensors.items()}
-                batch_out = {"mlm_labels": train.mlm_labels[sel].to(device)} if train.mlm_labels is not None else None
+                batch_in, batch_out = train.collate(mine[b0:b0 + args.batch_size], device)
                 with _autocast(args, device):
                     total, logs = module.training_step(batch_in, batch_out)
                 (scaler.scale(total / args.gradient_accumulation_steps)).backward()
@@ -338,8 +376,11 @@ def main(argv=None):
             outputs = {}
             for indices, batch_in, _ in ds.batches(args.test_batch_size, rank, world, device):
                 with _autocast(args, device), torch.no_grad():
-                    outputs.update(T.test_step(module, indices, batch_in, args.num_beams, args.max_dec_length,
-                                               args.tok_bos_id, args.tok_eos_id, args.tok_pad_id))
+                    if args.template_based:
+                        outputs.update(module.test_step(indices, batch_in))               # main.py:201-216, top 500 edits
+                    else:
+                        outputs.update(T.test_step(module, indices, batch_in, args.num_beams, args.max_dec_length,
+                                                   args.tok_bos_id, args.tok_eos_id, args.tok_pad_id))
             outputs = T.gather_outputs(outputs)
             if rank == 0:       # main.py:243-245; json keys become strings exactly as json.dump of the reference's dict does
                 with open(os.path.join(args.save_path, "prediction_%s_%d.json" % (ds.name, di)), "w") as f:

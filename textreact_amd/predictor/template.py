@@ -140,3 +140,37 @@ def template_test_step(model, indices, batch_in, top_num=500):
         out[int(idx)] = {"prediction": pred, "score": prob, "raw_template_labels": raw,
                          "top1_template_match": pred[0] in raw}
     return out
+
+
+# ---- the LightningModule's three steps for this branch (main.py:165-233 with args.template_based) -----------------
+class TemplatePredictor(nn.Module):
+    """what `textreact_amd.main` drives under --template_based: the same step interface as predictor/train.py's Predictor,
+    parameters under `model.` like the reference's LightningModule (so the checkpoint keys are the reference's)"""
+
+    def __init__(self, enc_cfg, num_atom_templates, num_bond_templates, backend="hip"):
+        super().__init__()
+        self.model = TemplateBasedModel(enc_cfg, num_atom_templates, num_bond_templates, backend=backend)
+
+    @staticmethod
+    def _model_inputs(batch_in):
+        return {k: batch_in[k] for k in ("input_ids", "attention_mask", "atom_indices") if k in batch_in}
+
+    def training_step(self, batch_in, batch_out=None):
+        logits, _ = self.model(**self._model_inputs(batch_in))
+        loss = template_loss(logits, batch_in)
+        return loss, {"train_loss": loss.detach()}
+
+    @torch.no_grad()
+    def validation_step(self, indices, batch_in, val_metric="val_loss"):
+        logits, _ = self.model(**self._model_inputs(batch_in))
+        if val_metric == "val_loss":
+            scores = template_loss(logits, batch_in, reduction="none")
+        elif val_metric == "val_acc":
+            scores = template_acc(logits, batch_in, reduction="none")
+        else:
+            raise ValueError(val_metric)
+        return {int(i): float(s) for i, s in zip(indices, scores)}
+
+    @torch.no_grad()
+    def test_step(self, indices, batch_in, top_num=500):
+        return template_test_step(lambda **kw: self.model(**self._model_inputs(kw)), indices, batch_in, top_num=top_num)
