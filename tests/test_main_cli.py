@@ -196,3 +196,15 @@ def test_template_based_branch(tmp_path, capsys):
     assert len(one["prediction"]) == len(one["score"]) > 0 and one["prediction"][0][0] in ("a", "b")
     assert one["score"] == sorted(one["score"], reverse=True)
     assert '"val_acc"' in capsys.readouterr().out
+
+
+@pytest.mark.gpu
+def test_template_based_branch_on_the_hip_backend(tmp_path):
+    argv = _toy_template(tmp_path)
+    cfg = json.loads((tmp_path / "enc.json").read_text())
+    cfg.update(hidden_size=256, num_attention_heads=4, intermediate_size=512)
+    (tmp_path / "enc.json").write_text(json.dumps(cfg))
+    argv[argv.index("--kernel_backend") + 1] = "hip"
+    assert M.main(argv + ["--epochs", "1", "--do_train", "--do_test", "--overwrite", "--precision", "bf16-mixed"]) == 0
+    pred = json.loads((tmp_path / "out" / "prediction_test_0.json").read_text())
+    assert sorted(pred) == ["200", "201", "202", "203"] and pred["200"]["score"] == sorted(pred["200"]["score"], reverse=True)
