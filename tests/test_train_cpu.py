@@ -135,3 +135,12 @@ def test_training_mode_applies_dropout_and_eval_mode_does_not():
     torch.manual_seed(0); b2 = p.model(**batch)[0]
     torch.manual_seed(1); b3 = p.model(**batch)[0]
     assert torch.equal(b1, b2) and not torch.equal(b1, b3) and not torch.equal(a, b1)
+
+
+def test_merge_predictions_per_neighbor():
+    # main.py:239-240 / utils.py:55-64: samples 0..5 = reactions 0, 1 with 3 neighbours each, outputs concatenated per key
+    from textreact_amd.predictor import train
+    outs = {i: {"prediction": ["p%d" % i], "score": [float(i)]} for i in (3, 0, 5, 1, 4, 2)}
+    m = train.merge_predictions_per_neighbor(outs, 3)
+    assert m == {0: {"prediction": ["p0", "p1", "p2"], "score": [0.0, 1.0, 2.0]},
+                 1: {"prediction": ["p3", "p4", "p5"], "score": [3.0, 4.0, 5.0]}}

@@ -382,6 +382,8 @@ def main(argv=None):
                         outputs.update(T.test_step(module, indices, batch_in, args.num_beams, args.max_dec_length,
                                                    args.tok_bos_id, args.tok_eos_id, args.tok_pad_id))
             outputs = T.gather_outputs(outputs)
+            if args.test_each_neighbor:                                                  # main.py:239-240
+                outputs = T.merge_predictions_per_neighbor(outputs, args.test_num_neighbors)
             if rank == 0:       # main.py:243-245; json keys become strings exactly as json.dump of the reference's dict does
                 with open(os.path.join(args.save_path, "prediction_%s_%d.json" % (ds.name, di)), "w") as f:
                     json.dump(outputs, f)

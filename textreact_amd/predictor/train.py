@@ -137,6 +137,18 @@ def gather_outputs(outputs, group=None):
     return merged
 
 
+def merge_predictions_per_neighbor(outputs, num_neighbors):
+    """`--test_each_neighbor` (main.py:239-240, utils.py:55-64): the test set holds every reaction num_neighbors times,
+    sample i = reaction i // num_neighbors with its (i % num_neighbors)-th neighbour alone; the per-sample outputs of a
+    reaction are concatenated, key by key, in neighbour order"""
+    merged = {}
+    for i in sorted(outputs):
+        tgt = merged.setdefault(i // num_neighbors, {})
+        for key, val in outputs[i].items():
+            tgt[key] = (tgt[key] + val) if key in tgt else (list(val) if isinstance(val, (list, tuple)) else val)
+    return merged
+
+
 def configure_optimizer(module, lr, weight_decay, num_training_steps, warmup_ratio, scheduler="linear"):
     """main.py:270-276: AdamW + warm-up/decay schedule stepped per optimiser step"""
     params = list(module.parameters())
