@@ -13,12 +13,18 @@ assert stats, "no kernel_stats.csv under " + src
 shutil.copy(stats[0], os.path.join(root, "profiles", tag + "_kernel_stats.csv"))
 
 
+def is_boot(name):
+    """knn_scan_kernel<L2, J, BOOT, NKS>: the third template argument marks the bootstrap launch"""
+    args = [a.strip() for a in name.split("<", 1)[1].split(">", 1)[0].split(",")]
+    return len(args) > 2 and args[2] == "true"
+
+
 def counters(sub):
     agg = collections.defaultdict(list)
     name = None
     for f in glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if "knn_scan_kernel" in r["Kernel_Name"] and "true>" not in r["Kernel_Name"].split("(")[0][-6:]:
+            if "knn_scan_kernel" in r["Kernel_Name"] and not is_boot(r["Kernel_Name"]):
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
                 name = r["Kernel_Name"]
     return {k: sum(v) / len(v) for k, v in agg.items()}, name
@@ -26,7 +32,7 @@ def counters(sub):
 
 avg_ms = None
 for r in csv.DictReader(open(stats[0])):
-    if "knn_scan_kernel" in r["Name"] and r["Name"].rstrip(")").split("<")[1].split(">")[0].endswith("false"):
+    if "knn_scan_kernel" in r["Name"] and not is_boot(r["Name"]):
         avg_ms = float(r["AverageNs"]) / 1e6
         kname = r["Name"]
 fetch, _ = counters("pmc_fetch")
