@@ -773,6 +773,7 @@ static hipError_t launch_one(const ScanParams& p, hipStream_t st) {
 
 template <bool L2, int J, bool BOOT>
 static hipError_t launch_ks(const ScanParams& p, hipStream_t st) {
+    // (32 K-steps = 2048 components compiled in: no gain, 91.4 ms either way on the fingerprint workload)
     return p.Kp == 12 * BK ? launch_one<L2, J, BOOT, 12>(p, st) : launch_one<L2, J, BOOT, 0>(p, st);
 }
 
