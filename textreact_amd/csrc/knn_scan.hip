@@ -337,9 +337,13 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
     int ksA = wave_m ? 2 : 1;
     if (ksA >= ksteps) { ksA -= ksteps; srcA += 255 * Kp; }     // Kp == 128: K-step 2 is the next tile's K-step 0
     const int wrapA = 255 * Kp;       // added when a K-step cursor moves on to the next tile
+#ifdef TRX_SCAN_DEBUG_BUILD   // timing-only switches (TRX_SCAN_DEBUG bits 1, 2, 8; results are wrong): compiled in on request
     const bool dbg_nodma = (p.debug & 1) != 0;
     const bool dbg_nofilter = (p.debug & 2) != 0;
-    const bool dbg_norefresh = (p.debug & 8) != 0;   // timing-only: results are wrong
+    const bool dbg_norefresh = (p.debug & 8) != 0;
+#else
+    constexpr bool dbg_nodma = false, dbg_nofilter = false, dbg_norefresh = false;
+#endif
 
     if (wave_m) __builtin_amdgcn_s_barrier();       // group 1 runs one interval late
 
