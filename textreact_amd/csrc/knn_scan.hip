@@ -132,6 +132,12 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 #define TRX_CPOL_B 0
 #endif
 
+// the splits of a query publish their shared-threshold value every TRX_PUB_MASK + 1 tiles (a power of two >= 8: the
+// thresholds themselves are refreshed every 8th tile) and read the slots back 4 tiles later
+#ifndef TRX_PUB_MASK
+#define TRX_PUB_MASK 15
+#endif
+
 template <int N> struct ic { static constexpr int value = N; };
 
 // lane id, recomputed where it is needed (volatile: hipcc would otherwise hoist everything derived from the lane id out
@@ -530,7 +536,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
                              : "=&v"(gs[sl][0]), "=&v"(gs[sl][1]), "=&v"(gs[sl][2]), "=&v"(gs[sl][3])
                              : "v"(b4_0 + sl * 1024), "n"(R_GTHR), "n"(R_GTHR + 64), "n"(R_GTHR + 128), "n"(R_GTHR + 192) : "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            const bool publish = !BOOT && ((TL & 15) == 15 || TL == 7);
+            const bool publish = !BOOT && ((TL & TRX_PUB_MASK) == TRX_PUB_MASK || TL == 7);
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 const float both = __builtin_fminf(g[nt], __uint_as_float(gp[nt]));      // 8 J rows of this split reach this key
@@ -599,9 +605,9 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
     // regular pieces (the other splits' thresholds every 8 tiles, wave 1; the next tile's bias, L2, wave 2)
 #define TRX_PAIR_HEAD()                                                                                    \
     {                                                                                                      \
-        const bool aux_g = !BOOT && (wave >> 2) == 1 && ((tl & 15) == 3 || tl == 11);                      \
+        const bool aux_g = !BOOT && (wave >> 2) == 1 && ((tl & TRX_PUB_MASK) == 3 || tl == 11);            \
         const bool aux_b = L2 && wave == 2;                                                                \
-        const bool strict = tl > 0 && !dbg_nofilter && !BOOT && (((tl - 1) & 15) == 15 || tl == 8);        \
+        const bool strict = tl > 0 && !dbg_nofilter && !BOOT && (((tl - 1) & TRX_PUB_MASK) == TRX_PUB_MASK || tl == 8); \
         if (strict) {                                                                                      \
             /* bookkeeping that publishes thresholds to g_thr issues atomics, which count in vmcnt like the DMA    \
                pieces: retire the previous load phase's pieces first (two intervals old) and wait for nothing at   \
