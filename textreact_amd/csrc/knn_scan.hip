@@ -137,6 +137,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 #ifndef TRX_PUB_MASK
 #define TRX_PUB_MASK 15
 #endif
+#ifndef TRX_REFRESH_MASK
+#define TRX_REFRESH_MASK 7      // thresholds refreshed every 8th tile (4th / 16th measured: see DESIGN.md 6.2)
+#endif
 
 template <int N> struct ic { static constexpr int value = N; };
 
@@ -514,7 +517,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
         // ---- threshold refresh (every eighth tile): min over the query's 4 lanes of this wave, then the partner wave
         // row's value and the other splits' through LDS.  All LDS traffic of the 4 columns is issued together and
         // waited for once (one access at a time cost 8 ms per search).
-        if (!dbg_norefresh && (BOOT ? TL == ntl - 1 : (TL & 7) == 7)) {      // bootstrap launch: once, for its final publish
+        if (!dbg_norefresh && (BOOT ? TL == ntl - 1 : (TL & TRX_REFRESH_MASK) == TRX_REFRESH_MASK)) {      // bootstrap launch: once, for its final publish
             float g[4];
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) g[nt] = trk[J - 1][nt];
