@@ -14,6 +14,7 @@ import os
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch
 from textreact_amd.predictor import ops
+from oracle import nn_ref          # the PyTorch-eager statement of the ops: the reference timed beside the kernels
 
 
 def timeit(fn, iters=20, warm=3):
@@ -41,11 +42,11 @@ def train_step_bench(dev, steps=10, dtype=torch.bfloat16, L=512, T=160):
              "decoder_input_ids": torch.randint(14, 600, (B, T), generator=g).to(dev),
              "decoder_attention_mask": torch.ones(B, T, dtype=torch.long, device=dev)}
     batch["attention_mask"][::3, L * 4 // 5:] = 0
-    for backend in ("hip", "torch"):
+    for backend in ("hip", "torch"):      # the product, then the reference statement (oracle/nn_ref.py)
         enc = Config(vocab_size=31090)
         dec = Config(vocab_size=600, num_hidden_layers=6, type_vocab_size=1, layer_norm_eps=1e-5, is_decoder=True)
         torch.manual_seed(0)
-        p = train.Predictor(enc, dec, mlm=False, backend=backend).to(dev).train()
+        p = train.Predictor(enc, dec, mlm=False).to(dev).train()
         opt, _ = train.configure_optimizer(p, 1e-4, 0.01, 1000, 0.02)
 
         scaler = torch.amp.GradScaler("cuda") if dtype == torch.float16 else None      # what Lightning's 16-mixed adds
@@ -61,19 +62,21 @@ def train_step_bench(dev, steps=10, dtype=torch.bfloat16, L=512, T=160):
                 scaler.step(opt); scaler.update()
             opt.zero_grad(set_to_none=True)
             return loss
-        ms = timeit(step, iters=steps, warm=4)   # the caching allocator is still growing during the first steps
+        with nn_ref.implementation(backend):      # "torch": the PyTorch-eager statement of the ops timed beside the kernels
+            ms = timeit(step, iters=steps, warm=4)   # the caching allocator is still growing during the first steps
 
         def fwd():
             with torch.no_grad(), torch.autocast("cuda", dtype=dtype):
                 return p.model(**batch)[0]
         p.eval()
-        ms_eval = timeit(fwd, iters=steps, warm=2)
+        with nn_ref.implementation(backend):
+            ms_eval = timeit(fwd, iters=steps, warm=2)
         p.train()
         tokens = B * (L + T)
         name = "bf16 autocast" if dtype == torch.bfloat16 else "fp16 autocast + GradScaler"
-        res.append({"kernel": "train_step", "backend": backend, "dtype": name, "B": B, "L": L, "T": T,
+        res.append({"kernel": "train_step", "ops": backend, "dtype": name, "B": B, "L": L, "T": T,
                     "ms": ms, "tokens_per_s": tokens / (ms * 1e-3)})
-        res.append({"kernel": "forward_eval", "backend": backend, "dtype": name, "B": B, "L": L, "T": T,
+        res.append({"kernel": "forward_eval", "ops": backend, "dtype": name, "B": B, "L": L, "T": T,
                     "ms": ms_eval, "tokens_per_s": tokens / (ms_eval * 1e-3)})
         del p, opt
         torch.cuda.empty_cache()
@@ -93,14 +96,15 @@ def generate_bench(dev, B=8):
     for backend, graph in (("hip", True), ("hip", False), ("torch", False)):
         torch.manual_seed(0)
         m = TextReactModel(Config(vocab_size=31090), Config(vocab_size=600, num_hidden_layers=6, type_vocab_size=1,
-                                                            layer_norm_eps=1e-5, is_decoder=True), backend=backend).to(dev).eval()
+                                                            layer_norm_eps=1e-5, is_decoder=True)).to(dev).eval()
 
         def run():
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 return generate(m, ids, am, num_beams=nb, num_return_sequences=nb, max_length=T, length_penalty=0,
                                 bos_token_id=12, eos_token_id=13, pad_token_id=0, graph=graph)
-        ms = timeit(run, iters=2, warm=1)
-        res.append({"kernel": "generate", "backend": backend, "decode_step": "hip graph replay" if graph else "eager launches",
+        with nn_ref.implementation(backend):
+            ms = timeit(run, iters=2, warm=1)
+        res.append({"kernel": "generate", "ops": backend, "decode_step": "hip graph replay" if graph else "eager launches",
                     "dtype": "bf16 autocast", "B": B, "L": L, "num_beams": nb,
                     "max_length": T, "ms": ms, "decoded_tokens_per_s": B * nb * (T - 1) / (ms * 1e-3)})
         del m
@@ -131,7 +135,7 @@ def main():
             ms = timeit(lambda: ops.attention(q, k, v, mask=m, causal=causal), iters=10)
             fl = 4.0 * B * H * Lq * Lk * 64 * (0.5 if causal else 1.0)
             tf = fl / (ms * 1e-3) / 1e12
-            ref = timeit(lambda: ops.attention(q, k, v, mask=m, causal=causal, backend="torch"), iters=10)
+            ref = timeit(lambda: nn_ref.attention(q, k, v, mask=m, causal=causal), iters=10)
             out.append({"kernel": "attention_fwd", "what": name, "dtype": str(dtype), "B": B, "H": H, "Lq": Lq, "Lk": Lk,
                         "ms": ms, "torch_eager_fp32_ms": ref,
                         "roofline": ({"bound": "mfma", "achieved": tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": tf / 2500.0}
@@ -151,7 +155,7 @@ def main():
         fl = 10.0 * B * H * Lq * Lk * 64 * (0.5 if causal else 1.0)
         tf = fl / (ms * 1e-3) / 1e12
         qr, kr, vr = (t.detach().float().requires_grad_(True) for t in (q, k, v))
-        orf = ops.attention(qr, kr, vr, mask=m, causal=causal, backend="torch")
+        orf = nn_ref.attention(qr, kr, vr, mask=m, causal=causal)
         ref = timeit(lambda: torch.autograd.grad(orf, (qr, kr, vr), do.float(), retain_graph=True), iters=5)
         out.append({"kernel": "attention_bwd", "what": name, "dtype": str(dtype), "B": B, "H": H, "Lq": Lq, "Lk": Lk,
                     "ms": ms, "torch_eager_fp32_ms": ref,

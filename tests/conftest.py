@@ -12,6 +12,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture
+def reference_ops():
+    """the module tree / trainer on the fp32 PyTorch statement of the ops (oracle/nn_ref.py) instead of the HIP kernels:
+    CPU tests mark themselves with `pytestmark = pytest.mark.usefixtures("reference_ops")`"""
+    from oracle import nn_ref
+    with nn_ref.reference_ops():
+        yield
+
+
 def _has_gpu():
     try:
         import torch

@@ -62,4 +62,17 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
-                assert "libtrxoracle" not in text, f
+                assert "libtrxoracle" not in text and not re.search(r"\bnn_ref\b", text.replace("oracle/nn_ref.py", "")), f
+                # one implementation of the predictor ops: no backend switch, no PyTorch statement of them in the product
+                assert not re.search(r"kernel_backend|backend\s*==\s*[\"']torch", text), f
+
+
+def test_predictor_ops_have_no_cpu_implementation():
+    import torch
+    from textreact_amd.predictor import ops
+    q = torch.zeros(1, 4, 1, 64)
+    x = torch.zeros(4, 64)
+    for call in (lambda: ops.attention(q, q, q), lambda: ops.add_layernorm(x, x, torch.ones(64), torch.zeros(64), 1e-5),
+                 lambda: ops.attention_qkv(torch.zeros(1, 4, 3, 1, 64)), lambda: ops.require_device("cpu")):
+        with pytest.raises(ops.TrxNNError):
+            call()

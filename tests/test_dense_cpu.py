@@ -1,23 +1,26 @@
 """Dense embedding producer (textreact_amd/dense.py), host-checkable part: the module tree, CLS pooling,
-batching and the state-dict compatibility with the predictor's encoder ('torch' statement of the ops)."""
+batching and the state-dict compatibility with the predictor's encoder (on the PyTorch statement of the ops,
+oracle/nn_ref.py)."""
 import json
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from textreact_amd import dense
 from textreact_amd.predictor.model import Config, TextReactModel, random_state_dict
 
+pytestmark = pytest.mark.usefixtures("reference_ops")
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "predictor_small.npz")
 
 
 def _models():
     z = np.load(G)
     enc, dec = json.loads(str(z["enc_cfg"])), json.loads(str(z["dec_cfg"]))
-    m = TextReactModel(Config(**enc), Config(is_decoder=True, **dec), backend="torch")
+    m = TextReactModel(Config(**enc), Config(is_decoder=True, **dec))
     m.load_state_dict(random_state_dict(m, int(z["seed"])))
-    e = dense.DenseEncoder(Config(**enc), backend="torch")
+    e = dense.DenseEncoder(Config(**enc))
     missing, unexpected = e.load_state_dict({k: v for k, v in m.state_dict().items() if k.startswith("encoder.")}, strict=True)
     return z, m.eval(), e.eval()
 
@@ -40,7 +43,7 @@ def test_encode_is_batching_invariant_and_leaves_the_mode_alone():
     b = dense.encode(e, ids, am, batch_size=64, out_dtype=torch.float32)
     assert e.training and a.shape[0] == ids.shape[0]
     assert torch.allclose(a, b, atol=1e-6)
-    n = dense.DenseEncoder(Config(**json.loads(str(z["enc_cfg"]))), backend="torch", normalize=True)
+    n = dense.DenseEncoder(Config(**json.loads(str(z["enc_cfg"]))), normalize=True)
     n.load_state_dict(e.state_dict()); n.eval()
     with torch.no_grad():
         u = n(ids[:2], am[:2])

@@ -5,18 +5,20 @@ import json
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from textreact_amd.predictor.generate import generate
 from textreact_amd.predictor.model import Config, TextReactModel, random_state_dict
 
+pytestmark = pytest.mark.usefixtures("reference_ops")
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "generate_small.npz")
 
 
-def golden_model(backend="torch"):
+def golden_model():
     z = np.load(G)
     enc, dec = json.loads(str(z["enc_cfg"])), json.loads(str(z["dec_cfg"]))
-    m = TextReactModel(Config(**enc), Config(is_decoder=True, **dec), backend=backend)
+    m = TextReactModel(Config(**enc), Config(is_decoder=True, **dec))
     sd = random_state_dict(m, int(z["seed"]))
     sd["decoder.lm_head.bias"] = sd["decoder.lm_head.bias"].clone()
     sd["decoder.lm_head.bias"][dec["eos_token_id"]] += float(z["eos_boost"])

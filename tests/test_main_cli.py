@@ -1,5 +1,7 @@
 """`python -m textreact_amd.main`: the reference's flag surface (main.py:26-97) and the train / validate / test /
-resume cycle with its files (best.ckpt, last.ckpt, prediction_{split}_{i}.json), on CPU with toy tensors."""
+resume cycle with its files (best.ckpt, last.ckpt, prediction_{split}_{i}.json), on CPU with toy tensors (the
+`reference_ops` fixture puts the PyTorch statement of the ops, oracle/nn_ref.py, under the module tree: the CLI itself has
+one implementation and refuses to start without a GPU) and on the GPU through the HIP ops."""
 import glob
 import json
 import os
@@ -74,14 +76,14 @@ def _toy(tmp_path, n=12, seed=0):
                     "decoder_input_ids": dids, "decoder_attention_mask": torch.ones_like(dids),
                     "mlm_labels": torch.randint(0, 60, (m, 3), generator=g)}, tmp_path / (name + ".pt"))
     return ["--task", "condition", "--encoder", "allenai/scibert_scivocab_uncased", "--arch_encoder", str(tmp_path / "enc.json"),
-            "--decoder", str(tmp_path / "dec.json"), "--save_path", str(tmp_path / "out"), "--kernel_backend", "torch",
+            "--decoder", str(tmp_path / "dec.json"), "--save_path", str(tmp_path / "out"),
             "--tensors_train", str(tmp_path / "train.pt"), "--tensors_valid", "%s,%s" % (tmp_path / "val.pt", tmp_path / "val_nogold.pt"),
             "--tensors_test", str(tmp_path / "test.pt"), "--batch_size", "6", "--lr", "1e-3", "--mlm", "--mlm_layer", "mlp",
             "--mlm_lambda", "0.1", "--warmup", "0.5", "--num_beams", "3", "--max_dec_length", "8", "--test_batch_size", "2",
             "--val_metric", "val_loss", "--print_freq", "1"]
 
 
-def test_train_validate_test_resume(tmp_path, capsys):
+def test_train_validate_test_resume(tmp_path, capsys, reference_ops):
     argv = _toy(tmp_path)
     out = tmp_path / "out"
     # two optimiser steps (12 samples / batch 6), one epoch, then validate + test from best.ckpt
@@ -104,14 +106,51 @@ def test_train_validate_test_resume(tmp_path, capsys):
     from textreact_amd.predictor import train as T
     args = M.get_args(argv)
     enc_cfg, dec_cfg = M._configs(args)
-    fresh = T.Predictor(enc_cfg, dec_cfg, mlm=True, mlm_layer="mlp", backend="torch")
+    fresh = T.Predictor(enc_cfg, dec_cfg, mlm=True, mlm_layer="mlp")
     _, missing, unexpected = T.load_checkpoint(str(out / "last.ckpt"), fresh)
     assert not missing and not unexpected
 
 
 def _rank_main(rank, world, port, argv):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from oracle import nn_ref
+    nn_ref.install()                 # this child process: the module tree on the PyTorch statement of the ops
     assert M.main(argv) == 0
+
+
+def test_the_cli_refuses_to_run_without_a_gpu(tmp_path):
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from textreact_amd.predictor import ops
+    with pytest.raises(ops.TrxNNError):
+        M.main(_toy(tmp_path) + ["--epochs", "1", "--do_train", "--overwrite"])
+
+
+def test_epoch_shards_are_equal_and_follow_the_distributed_sampler():
+    # torch's DistributedSampler is what Lightning puts under the reference's loader: same permutation, same padding
+    from torch.utils.data.distributed import DistributedSampler
+    for n, world in ((13, 2), (12, 2), (7, 4), (5, 8)):
+        shards = [M.epoch_shard(n, 42, 3, r, world) for r in range(world)]
+        assert len({len(s) for s in shards}) == 1 and len(shards[0]) == -(-n // world)
+        assert set(sum(shards, [])) == set(range(n))
+        for r in range(world):
+            ds = DistributedSampler(range(n), num_replicas=world, rank=r, shuffle=True, seed=42)
+            ds.set_epoch(3)
+            assert list(ds) == shards[r]
+    assert M.epoch_shard(13, 42, 0, 0, 2) != M.epoch_shard(13, 42, 1, 0, 2)     # a resumed run does not replay epoch 0
+
+
+def test_two_ranks_gloo_uneven_shards(tmp_path):
+    # 13 samples on 2 ranks, batch 6: without padding rank 0 would run 2 micro-batches and rank 1 only 1, and rank 0's
+    # gradient all-reduce would pair with rank 1's barrier (a hang on RCCL)
+    import socket
+    import torch.multiprocessing as mp
+    argv = _toy(tmp_path, n=13) + ["--epochs", "2", "--do_train", "--do_test", "--overwrite", "--gpus", "2"]
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]
+    mp.spawn(_rank_main, args=(2, port, argv), nprocs=2, join=True)
+    ck = torch.load(tmp_path / "out" / "last.ckpt", weights_only=False)
+    assert ck["global_step"] == 4 and ck["epoch"] == 1          # ceil(13 / 12) = 2 steps per epoch (7 samples per rank)
 
 
 def test_two_ranks_gloo(tmp_path):
@@ -131,7 +170,7 @@ def test_two_ranks_gloo(tmp_path):
 
 
 @pytest.mark.gpu
-def test_train_and_test_on_the_hip_backend(tmp_path, capsys):
+def test_train_and_test_through_the_hip_ops(tmp_path, capsys):
     """the same cycle on a GPU through the HIP ops (widths of 256 so that every fused path is taken), bf16 autocast as
     `--precision bf16-mixed`, then fp16 autocast + GradScaler as the scripts' `--precision 16-mixed`"""
     argv = _toy(tmp_path)
@@ -139,7 +178,6 @@ def test_train_and_test_on_the_hip_backend(tmp_path, capsys):
         cfg = json.loads((tmp_path / name).read_text())
         cfg.update(hidden_size=256, num_attention_heads=4, intermediate_size=512)
         (tmp_path / name).write_text(json.dumps(cfg))
-    argv[argv.index("--kernel_backend") + 1] = "hip"
     out = tmp_path / "out"
     for prec in ("bf16-mixed", "16-mixed"):
         assert M.main(argv + ["--epochs", "1", "--do_train", "--do_valid", "--do_test", "--overwrite", "--precision", prec]) == 0
@@ -175,12 +213,12 @@ def _toy_template(tmp_path, seed=0):
                     "bonds": bonds, "decoder_raw_template_labels": raw}, tmp_path / (name + ".pt"))
     return ["--task", "retro", "--template_based", "--encoder", "allenai/scibert_scivocab_uncased", "--arch_encoder", str(tmp_path / "enc.json"),
             "--tok_atom_templates", str(na_t), "--tok_bond_templates", str(nb_t), "--save_path", str(tmp_path / "out"),
-            "--kernel_backend", "torch", "--tensors_train", str(tmp_path / "train.pt"), "--tensors_valid", str(tmp_path / "val.pt"),
+            "--tensors_train", str(tmp_path / "train.pt"), "--tensors_valid", str(tmp_path / "val.pt"),
             "--tensors_test", str(tmp_path / "test.pt"), "--batch_size", "6", "--lr", "1e-3", "--test_batch_size", "2",
             "--val_metric", "val_acc", "--print_freq", "1"]
 
 
-def test_template_based_branch(tmp_path, capsys):
+def test_template_based_branch(tmp_path, capsys, reference_ops):
     """scripts/train_RetroSyn_tb.sh's branch (main.py:112-123, 138-150, 201-216): encoder + template heads, monitored by the
     greedy edit accuracy, test step writing the ranked edits"""
     argv = _toy_template(tmp_path)
@@ -199,12 +237,11 @@ def test_template_based_branch(tmp_path, capsys):
 
 
 @pytest.mark.gpu
-def test_template_based_branch_on_the_hip_backend(tmp_path):
+def test_template_based_branch_through_the_hip_ops(tmp_path):
     argv = _toy_template(tmp_path)
     cfg = json.loads((tmp_path / "enc.json").read_text())
     cfg.update(hidden_size=256, num_attention_heads=4, intermediate_size=512)
     (tmp_path / "enc.json").write_text(json.dumps(cfg))
-    argv[argv.index("--kernel_backend") + 1] = "hip"
     assert M.main(argv + ["--epochs", "1", "--do_train", "--do_test", "--overwrite", "--precision", "bf16-mixed"]) == 0
     pred = json.loads((tmp_path / "out" / "prediction_test_0.json").read_text())
     assert sorted(pred) == ["200", "201", "202", "203"] and pred["200"]["score"] == sorted(pred["200"]["score"], reverse=True)

@@ -1,7 +1,7 @@
 """Predictor module tree on CPU: parameter names and eval-mode logits against the golden produced
-by the reference's own get_model (tests/golden/make_predictor_golden.py).  Uses the fp32 torch
-statement of the two ops (the HIP kernels are checked against the same statement in
-tests/test_predictor_gpu.py); the product backend must refuse to run without a GPU."""
+by the reference's own get_model (tests/golden/make_predictor_golden.py).  Uses the fp32 PyTorch
+statement of the two ops (oracle/nn_ref.py, injected by the `reference_ops` fixture; the HIP kernels are checked
+against the same statement in tests/test_predictor_gpu.py); the product itself must refuse to run without a GPU."""
 import json
 import os
 
@@ -15,17 +15,17 @@ from textreact_amd.predictor.model import Config, TextReactModel, random_state_d
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "predictor_small.npz")
 
 
-def _load(backend):
+def _load():
     z = np.load(G)
     enc, dec = json.loads(str(z["enc_cfg"])), json.loads(str(z["dec_cfg"]))
-    m = TextReactModel(Config(**enc), Config(is_decoder=True, **dec), backend=backend)
+    m = TextReactModel(Config(**enc), Config(is_decoder=True, **dec))
     m.load_state_dict(random_state_dict(m, int(z["seed"])))
     m.eval()
     return z, m
 
 
 def test_state_dict_names_match_the_reference():
-    z, m = _load("torch")
+    z, m = _load()
     assert sorted(m.state_dict().keys()) == json.loads(str(z["state_dict_keys"]))
     # the names SURVEY.md 5.4 lists for the Lightning checkpoint (prefix `model.` added by the LightningModule)
     keys = set(m.state_dict().keys())
@@ -37,8 +37,8 @@ def test_state_dict_names_match_the_reference():
         assert k in keys, k
 
 
-def test_logits_match_reference_golden_fp32():
-    z, m = _load("torch")
+def test_logits_match_reference_golden_fp32(reference_ops):
+    z, m = _load()
     t = lambda k: torch.from_numpy(z[k])
     with torch.no_grad():
         logits, enc = m(t("input_ids"), t("attention_mask"), t("decoder_input_ids"), t("decoder_attention_mask"))
@@ -46,8 +46,8 @@ def test_logits_match_reference_golden_fp32():
     assert float((enc - t("encoder_last_hidden_state")).abs().max()) <= 1e-3
 
 
-def test_hip_backend_refuses_cpu_tensors():
-    z, m = _load("hip")
+def test_the_product_refuses_cpu_tensors():
+    z, m = _load()
     t = lambda k: torch.from_numpy(z[k])
     with pytest.raises(ops.TrxNNError):
         m(t("input_ids"), t("attention_mask"), t("decoder_input_ids"), t("decoder_attention_mask"))
@@ -66,14 +66,14 @@ def test_nn_library_exports_the_header_symbols():
     assert b"bad argument" in L.trx_nn_last_error()
 
 
-def test_embedding_tables_grow_and_keep_their_rows():
+def test_embedding_tables_grow_and_keep_their_rows(reference_ops):
     import torch
     from textreact_amd.predictor.model import (Config, TextReactModel, expand_position_embeddings, expand_word_embeddings,
                                                gather_prediction_each_neighbor)
     m = TextReactModel(Config(vocab_size=50, hidden_size=128, num_hidden_layers=1, num_attention_heads=2, intermediate_size=64,
                               max_position_embeddings=16),
                        Config(vocab_size=20, hidden_size=128, num_hidden_layers=1, num_attention_heads=2, intermediate_size=64,
-                              max_position_embeddings=16, is_decoder=True), backend="torch").eval()
+                              max_position_embeddings=16, is_decoder=True)).eval()
     ids = torch.randint(1, 50, (2, 16)); dids = torch.randint(1, 20, (2, 5))
     with torch.no_grad():
         a = m(ids, None, dids)[0]

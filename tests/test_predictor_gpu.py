@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 import torch
 
+from oracle import nn_ref
 from textreact_amd.predictor import ops
 from textreact_amd.predictor.model import Config, TextReactModel, random_state_dict
 
@@ -28,8 +29,8 @@ def test_add_layernorm_forward(rows, cols, dtype, tol, with_res):
     x, r = _rand(rows, cols, dtype=dtype, seed=1), (_rand(rows, cols, dtype=dtype, seed=2) if with_res else None)
     g, b = _rand(cols, seed=3) * 0.1 + 1, _rand(cols, seed=4) * 0.1
     for eps in (1e-12, 1e-5):
-        y = ops.add_layernorm(x, r, g, b, eps, backend="hip")
-        ref = ops.add_layernorm(x.float(), None if r is None else r.float(), g, b, eps, backend="torch")
+        y = ops.add_layernorm(x, r, g, b, eps)
+        ref = nn_ref.add_layernorm(x.float(), None if r is None else r.float(), g, b, eps)
         assert y.dtype == dtype and float((y.float() - ref).abs().max()) <= tol
 
 
@@ -40,10 +41,11 @@ def test_add_layernorm_backward(rows, cols):
     dy = _rand(rows, cols, seed=5)
     outs = []
     for backend in ("hip", "torch"):
-        xs, rs, gs, bs = (t.clone().requires_grad_(True) for t in (x, r, g, b))
-        y = ops.add_layernorm(xs, rs, gs, bs, 1e-5, backend=backend)
-        y.backward(dy)
-        outs.append((xs.grad, rs.grad, gs.grad, bs.grad))
+        with nn_ref.implementation(backend):
+            xs, rs, gs, bs = (t.clone().requires_grad_(True) for t in (x, r, g, b))
+            y = ops.add_layernorm(xs, rs, gs, bs, 1e-5)
+            y.backward(dy)
+            outs.append((xs.grad, rs.grad, gs.grad, bs.grad))
     for a, c in zip(*outs):
         assert float((a - c).abs().max()) <= 2e-4 * max(1.0, float(c.abs().max()))
     # deterministic: two runs give the same bits (two-stage reduction, no float atomics)
@@ -75,8 +77,8 @@ def test_attention_forward(B, H, Lq, Lk, mask, causal, dtype, tol):
     elif mask == "full":
         keep = (torch.rand(B, Lq, Lk, device="cuda") > 0.3).float(); keep[:, :, 0] = 1
         m = (1 - keep) * neg
-    out = ops.attention(q, k, v, mask=m, causal=causal, backend="hip")
-    ref = ops.attention(q.float(), k.float(), v.float(), mask=m, causal=causal, backend="torch")
+    out = ops.attention(q, k, v, mask=m, causal=causal)
+    ref = nn_ref.attention(q.float(), k.float(), v.float(), mask=m, causal=causal)
     assert out.shape == (B, Lq, H * 64) and out.dtype == dtype
     assert float((out.float() - ref).abs().max()) <= tol
 
@@ -84,7 +86,7 @@ def test_attention_forward(B, H, Lq, Lk, mask, causal, dtype, tol):
 def test_model_logits_match_reference_golden_on_gpu():
     z = np.load(G)
     enc, dec = json.loads(str(z["enc_cfg"])), json.loads(str(z["dec_cfg"]))
-    m = TextReactModel(Config(**enc), Config(is_decoder=True, **dec), backend="hip")
+    m = TextReactModel(Config(**enc), Config(is_decoder=True, **dec))
     m.load_state_dict(random_state_dict(m, int(z["seed"])))
     m = m.cuda().eval()
     t = lambda k_: torch.from_numpy(z[k_]).cuda()
@@ -98,7 +100,7 @@ def test_full_size_model_hip_vs_torch_reference():
     # scripts' shapes: BERT-base encoder (SciBERT vocab 31090), bert_l6.json decoder, L = 512, T = 7
     enc = Config(vocab_size=31090)
     dec = Config(vocab_size=600, num_hidden_layers=6, type_vocab_size=1, layer_norm_eps=1e-5, is_decoder=True)
-    m = TextReactModel(enc, dec, backend="hip")
+    m = TextReactModel(enc, dec)
     m.load_state_dict(random_state_dict(m, 7))
     m = m.cuda().eval()
     g = torch.Generator().manual_seed(1)
@@ -106,8 +108,8 @@ def test_full_size_model_hip_vs_torch_reference():
     dids = torch.randint(14, 600, (4, 7), generator=g).cuda()
     with torch.no_grad():
         a, _ = m(ids, am, dids)
-        m.backend = "torch"
-        b, _ = m(ids, am, dids)
+        with nn_ref.reference_ops():
+            b, _ = m(ids, am, dids)
     assert float((a - b).abs().max()) <= 1e-3
 
 
@@ -128,10 +130,11 @@ def test_attention_backward(B, H, Lq, Lk, mask, causal):
         m = (1 - keep) * neg
     grads = []
     for backend in ("hip", "torch"):
-        qs, ks, vs = (t.clone().requires_grad_(True) for t in (q, k, v))
-        out = ops.attention(qs, ks, vs, mask=m, causal=causal, backend=backend)
-        out.backward(dout)
-        grads.append((out.detach(), qs.grad, ks.grad, vs.grad))
+        with nn_ref.implementation(backend):
+            qs, ks, vs = (t.clone().requires_grad_(True) for t in (q, k, v))
+            out = ops.attention(qs, ks, vs, mask=m, causal=causal)
+            out.backward(dout)
+            grads.append((out.detach(), qs.grad, ks.grad, vs.grad))
     for a, c in zip(*grads):
         assert float((a - c).abs().max()) <= 5e-5 * max(1.0, float(c.abs().max()))
 
@@ -160,10 +163,10 @@ def test_attention_backward_bf16_matrix_cores(B, H, Lq, Lk, mask, causal):
         keep = (torch.rand(B, Lq, Lk, device="cuda") > 0.3).float(); keep[:, :, 0] = 1
         m = (1 - keep) * neg
     qs, ks, vs = (t.clone().requires_grad_(True) for t in (q, k, v))
-    out = ops.attention(qs, ks, vs, mask=m, causal=causal, backend="hip")
+    out = ops.attention(qs, ks, vs, mask=m, causal=causal)
     out.backward(dout)
     qr, kr, vr = (t.float().clone().requires_grad_(True) for t in (q, k, v))
-    ref = ops.attention(qr, kr, vr, mask=m, causal=causal, backend="torch")
+    ref = nn_ref.attention(qr, kr, vr, mask=m, causal=causal)
     ref.backward(dout.float())
     for name, a, c in (("dq", qs.grad, qr.grad), ("dk", ks.grad, kr.grad), ("dv", vs.grad, vr.grad)):
         assert a.dtype == bf and a.shape == c.shape
@@ -196,12 +199,13 @@ def test_add_layernorm_dropout_forward_backward(rows, cols, dtype, tol, with_res
     dy = _rand(rows, cols, dtype=dtype, seed=5)
     res = []
     for backend in ("hip", "torch"):
-        xs = x.clone().requires_grad_(True) if backend == "hip" else x.float().clone().requires_grad_(True)
-        rs = None if r is None else (r.clone() if backend == "hip" else r.float().clone()).requires_grad_(True)
-        gs, bs = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
-        y = ops.add_layernorm(xs, rs, gs, bs, 1e-5, backend=backend, dropout_p=0.1, seed=99)
-        y.backward(dy if backend == "hip" else dy.float())
-        res.append((y.detach().float(), xs.grad.float(), None if rs is None else rs.grad.float(), gs.grad, bs.grad))
+        with nn_ref.implementation(backend):
+            xs = x.clone().requires_grad_(True) if backend == "hip" else x.float().clone().requires_grad_(True)
+            rs = None if r is None else (r.clone() if backend == "hip" else r.float().clone()).requires_grad_(True)
+            gs, bs = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+            y = ops.add_layernorm(xs, rs, gs, bs, 1e-5, dropout_p=0.1, seed=99)
+            y.backward(dy if backend == "hip" else dy.float())
+            res.append((y.detach().float(), xs.grad.float(), None if rs is None else rs.grad.float(), gs.grad, bs.grad))
     keep = ops.dropout_keep_mask(99, 0.1, 1, rows, cols, "cuda").view(rows, cols)
     assert bool((res[0][1][~keep] == 0).all())                 # dropped elements get no gradient
     for a, c in zip(*res):
@@ -234,10 +238,11 @@ def test_attention_dropout_forward_backward(B, H, Lq, Lk, mask, causal, dtype, t
         m = (1 - keep) * neg
     res = []
     for backend in ("hip", "torch"):
-        qs, ks, vs = ((t if backend == "hip" else t.float()).clone().requires_grad_(True) for t in (q, k, v))
-        out = ops.attention(qs, ks, vs, mask=m, causal=causal, backend=backend, dropout_p=0.1, seed=4242)
-        out.backward(dout if backend == "hip" else dout.float())
-        res.append((out.detach().float(), qs.grad.float(), ks.grad.float(), vs.grad.float()))
+        with nn_ref.implementation(backend):
+            qs, ks, vs = ((t if backend == "hip" else t.float()).clone().requires_grad_(True) for t in (q, k, v))
+            out = ops.attention(qs, ks, vs, mask=m, causal=causal, dropout_p=0.1, seed=4242)
+            out.backward(dout if backend == "hip" else dout.float())
+            res.append((out.detach().float(), qs.grad.float(), ks.grad.float(), vs.grad.float()))
     for name, a, c in zip(("out", "dq", "dk", "dv"), *res):
         err = float((a - c).abs().max())
         assert err <= tol * max(1.0, float(c.abs().max())), (name, err)
@@ -253,15 +258,16 @@ def test_model_backward_hip_vs_torch():
     t = lambda k_: torch.from_numpy(z[k_]).cuda()
     grads = {}
     for backend in ("hip", "torch"):
-        m = TextReactModel(Config(**enc), Config(is_decoder=True, **dec), backend=backend)
-        m.load_state_dict(random_state_dict(m, int(z["seed"])))
-        m = m.cuda().eval()
-        logits, _ = m(t("input_ids"), t("attention_mask"), t("decoder_input_ids"), t("decoder_attention_mask"))
-        labels = t("decoder_input_ids")[:, 1:]
-        loss = torch.nn.functional.cross_entropy(logits[:, :-1].reshape(-1, logits.shape[-1]), labels.reshape(-1), ignore_index=0)
-        loss.backward()
-        grads[backend] = {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
-        grads[backend]["__loss__"] = loss.detach()
+        with nn_ref.implementation(backend):
+            m = TextReactModel(Config(**enc), Config(is_decoder=True, **dec))
+            m.load_state_dict(random_state_dict(m, int(z["seed"])))
+            m = m.cuda().eval()
+            logits, _ = m(t("input_ids"), t("attention_mask"), t("decoder_input_ids"), t("decoder_attention_mask"))
+            labels = t("decoder_input_ids")[:, 1:]
+            loss = torch.nn.functional.cross_entropy(logits[:, :-1].reshape(-1, logits.shape[-1]), labels.reshape(-1), ignore_index=0)
+            loss.backward()
+            grads[backend] = {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+            grads[backend]["__loss__"] = loss.detach()
     assert set(grads["hip"]) == set(grads["torch"])
     for n in grads["hip"]:
         a, c = grads["hip"][n], grads["torch"][n]
@@ -276,16 +282,17 @@ def test_model_training_mode_dropout_hip_vs_torch():
     t = lambda k_: torch.from_numpy(z[k_]).cuda()
     grads = {}
     for backend in ("hip", "torch"):
-        m = TextReactModel(Config(**enc), Config(is_decoder=True, **dec), backend=backend)
-        m.load_state_dict(random_state_dict(m, int(z["seed"])))
-        m = m.cuda().train()
-        torch.manual_seed(11)
-        logits, _ = m(t("input_ids"), t("attention_mask"), t("decoder_input_ids"), t("decoder_attention_mask"))
-        labels = t("decoder_input_ids")[:, 1:]
-        loss = torch.nn.functional.cross_entropy(logits[:, :-1].reshape(-1, logits.shape[-1]), labels.reshape(-1), ignore_index=0)
-        loss.backward()
-        grads[backend] = {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
-        grads[backend]["__loss__"] = loss.detach()
+        with nn_ref.implementation(backend):
+            m = TextReactModel(Config(**enc), Config(is_decoder=True, **dec))
+            m.load_state_dict(random_state_dict(m, int(z["seed"])))
+            m = m.cuda().train()
+            torch.manual_seed(11)
+            logits, _ = m(t("input_ids"), t("attention_mask"), t("decoder_input_ids"), t("decoder_attention_mask"))
+            labels = t("decoder_input_ids")[:, 1:]
+            loss = torch.nn.functional.cross_entropy(logits[:, :-1].reshape(-1, logits.shape[-1]), labels.reshape(-1), ignore_index=0)
+            loss.backward()
+            grads[backend] = {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+            grads[backend]["__loss__"] = loss.detach()
     m.eval()
     with torch.no_grad():
         ev, _ = m(t("input_ids"), t("attention_mask"), t("decoder_input_ids"), t("decoder_attention_mask"))
@@ -319,8 +326,8 @@ def test_dense_producer_feeds_the_flat_index_on_device(tmp_path):
     neighbors.write_neighbors(str(tmp_path / "val.json"), result)
     assert neighbors.read_neighbors(str(tmp_path / "val.json"))["q3"] == result[3]["nn"]
     # the bf16 autocast path agrees with the fp32 statement of the ops to bf16 accuracy
-    enc.backend = "torch"
-    ref = dense.encode(enc, c_ids[:64], c_am[:64], autocast=False, out_dtype=torch.float32)
+    with nn_ref.reference_ops():
+        ref = dense.encode(enc, c_ids[:64], c_am[:64], autocast=False, out_dtype=torch.float32)
     assert float((corpus[:64].float() - ref).abs().max()) <= 5e-2 * max(1.0, float(ref.abs().max()))
 
 
@@ -334,17 +341,18 @@ def test_model_under_bf16_autocast_hip_vs_torch(train_mode):
     t = lambda k_: torch.from_numpy(z[k_]).cuda()
     res = {}
     for backend in ("hip", "torch"):
-        m = TextReactModel(Config(**enc), Config(is_decoder=True, **dec), backend=backend)
-        m.load_state_dict(random_state_dict(m, int(z["seed"])))
-        m = m.cuda().train(train_mode)
-        torch.manual_seed(5)
-        with torch.autocast("cuda", dtype=torch.bfloat16):
-            logits, _ = m(t("input_ids"), t("attention_mask"), t("decoder_input_ids"), t("decoder_attention_mask"))
-            labels = t("decoder_input_ids")[:, 1:]
-            loss = torch.nn.functional.cross_entropy(logits[:, :-1].reshape(-1, logits.shape[-1]).float(), labels.reshape(-1), ignore_index=0)
-        loss.backward()
-        assert bool(torch.isfinite(logits).all()) and bool(torch.isfinite(loss))
-        res[backend] = (logits.detach().float(), loss.detach(), {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
+        with nn_ref.implementation(backend):
+            m = TextReactModel(Config(**enc), Config(is_decoder=True, **dec))
+            m.load_state_dict(random_state_dict(m, int(z["seed"])))
+            m = m.cuda().train(train_mode)
+            torch.manual_seed(5)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                logits, _ = m(t("input_ids"), t("attention_mask"), t("decoder_input_ids"), t("decoder_attention_mask"))
+                labels = t("decoder_input_ids")[:, 1:]
+                loss = torch.nn.functional.cross_entropy(logits[:, :-1].reshape(-1, logits.shape[-1]).float(), labels.reshape(-1), ignore_index=0)
+            loss.backward()
+            assert bool(torch.isfinite(logits).all()) and bool(torch.isfinite(loss))
+            res[backend] = (logits.detach().float(), loss.detach(), {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
     assert float((res["hip"][0] - res["torch"][0]).abs().max()) <= 6e-2 * max(1.0, float(res["torch"][0].abs().max()))
     assert abs(float(res["hip"][1] - res["torch"][1])) <= 3e-2 * max(1.0, abs(float(res["torch"][1])))
     for n in res["hip"][2]:
@@ -362,13 +370,14 @@ def test_add_layernorm_mixed_storage(rows, cols, p):
     dy = _rand(rows, cols, seed=5)
     res = []
     for backend in ("hip", "torch"):
-        xs, rs = x.clone().requires_grad_(True), r.clone().requires_grad_(True)
-        gs, bs = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
-        y = ops.add_layernorm(xs, rs, gs, bs, 1e-12, backend=backend, dropout_p=p, seed=77)
-        assert y.dtype == torch.float32
-        y.backward(dy)
-        assert xs.grad.dtype == torch.bfloat16 and rs.grad.dtype == torch.float32
-        res.append((y.detach(), xs.grad.float(), rs.grad, gs.grad, bs.grad))
+        with nn_ref.implementation(backend):
+            xs, rs = x.clone().requires_grad_(True), r.clone().requires_grad_(True)
+            gs, bs = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+            y = ops.add_layernorm(xs, rs, gs, bs, 1e-12, dropout_p=p, seed=77)
+            assert y.dtype == torch.float32
+            y.backward(dy)
+            assert xs.grad.dtype == torch.bfloat16 and rs.grad.dtype == torch.float32
+            res.append((y.detach(), xs.grad.float(), rs.grad, gs.grad, bs.grad))
     tols = (3e-5, 1e-2, 3e-5, 3e-5, 3e-5)     # dx is rounded to bf16 once
     for a, c, tol in zip(*res, tols):
         assert float((a - c).abs().max()) <= tol * max(1.0, float(c.abs().max()))
@@ -380,7 +389,7 @@ def test_beam_search_on_the_hip_ops_matches_the_huggingface_golden():
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from test_generate_cpu import check_case, golden_model
-    z, dec, m = golden_model(backend="hip")
+    z, dec, m = golden_model()
     m = m.cuda()
     for graph in (False, True):               # the eager loop, and the step replayed from a captured HIP graph
         for i, c in enumerate(json.loads(str(z["cases"]))):
@@ -395,7 +404,7 @@ def test_graph_decode_equals_the_eager_loop(autocast):
     from textreact_amd.predictor.generate import generate
     torch.manual_seed(3)
     m = TextReactModel(Config(vocab_size=300, num_hidden_layers=2), Config(vocab_size=40, num_hidden_layers=2, type_vocab_size=1,
-                       layer_norm_eps=1e-5, is_decoder=True), backend="hip")
+                       layer_norm_eps=1e-5, is_decoder=True))
     m.load_state_dict(random_state_dict(m, 5))      # BERT-style init: logits small enough for bf16 to resolve
     m = m.cuda().eval()
     g = torch.Generator().manual_seed(1)
@@ -423,7 +432,7 @@ def test_template_based_branch_on_the_hip_ops():
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from test_template_cpu import check, load
-    z, m, batch = load(backend="hip")
+    z, m, batch = load()
     m = m.cuda()
     batch = {k: (v.cuda() if torch.is_tensor(v) else ([t.cuda() for t in v] if k == "atom_indices" else v)) for k, v in batch.items()}
     check(z, m, batch, 1e-3)
@@ -435,7 +444,7 @@ def test_repeated_graph_decodes_release_their_memory():
     from textreact_amd.predictor.generate import generate
     torch.manual_seed(0)
     m = TextReactModel(Config(vocab_size=300, num_hidden_layers=1), Config(vocab_size=40, num_hidden_layers=1, type_vocab_size=1,
-                       layer_norm_eps=1e-5, is_decoder=True), backend="hip").cuda().eval()
+                       layer_norm_eps=1e-5, is_decoder=True)).cuda().eval()
     g = torch.Generator().manual_seed(0)
     seen = []
     for it in range(8):
@@ -456,7 +465,7 @@ def test_graph_decode_step_on_bf16_weights_is_as_close_to_fp32_as_eager_autocast
     from textreact_amd.predictor.generate import _DecoderState
     torch.manual_seed(3)
     m = TextReactModel(Config(vocab_size=300, num_hidden_layers=2), Config(vocab_size=40, num_hidden_layers=2, type_vocab_size=1,
-                       layer_norm_eps=1e-5, is_decoder=True), backend="hip")
+                       layer_norm_eps=1e-5, is_decoder=True))
     m.load_state_dict(random_state_dict(m, 5))
     m = m.cuda().eval()
     g = torch.Generator().manual_seed(1)
@@ -498,7 +507,7 @@ def test_decode_attention_follows_the_ancestor_table(n, T, H):
             pos = torch.arange(t + 1, device="cuda")[None].expand_as(idx)
             k = kv[idx, pos, 0]                                                    # [n, t + 1, H, 64]: what beam i's history holds
             v = kv[idx, pos, 1]
-            ref = ops.attention(q.float(), k.float(), v.float(), backend="torch")
+            ref = nn_ref.attention(q.float(), k.float(), v.float())
             assert out.shape == (n, 1, H * 64)
             assert float((out.float() - ref).abs().max()) <= 2e-2
 
@@ -513,7 +522,7 @@ def test_attention_reads_a_key_value_cache_in_place(dtype, tol):
         assert Lk == Lmax or not k.is_contiguous()
         with torch.no_grad():
             out = ops.attention(q, k, v)                                   # strided: the kv-cache entry point
-            ref = ops.attention(q.float(), k.float(), v.float(), backend="torch")
+            ref = nn_ref.attention(q.float(), k.float(), v.float())
             same = ops.attention(q, k.contiguous(), v.contiguous())        # dense entry point
         assert float((out.float() - ref).abs().max()) <= tol
         assert torch.equal(out, same)
@@ -530,19 +539,20 @@ def test_add_layernorm_dual_output_and_two_gradient_paths(p):
     for use32, use16 in ((True, True), (True, False), (False, True)):
         res = []
         for backend in ("hip", "torch"):
-            xs, rs = x.clone().requires_grad_(True), r.clone().requires_grad_(True)
-            gs, bs = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
-            y, ylow = ops.add_layernorm(xs, rs, gs, bs, 1e-12, backend=backend, dropout_p=p, seed=5, dual=True)
-            if backend == "hip":
-                assert y.dtype == torch.float32 and ylow.dtype == torch.bfloat16
-                assert torch.equal(ylow, y.to(torch.bfloat16))
-            else:
-                ylow = y.to(torch.bfloat16)            # the statement: the low copy is a cast of y
-            loss = (y * d32).sum() * (1.0 if use32 else 0.0) + (ylow.float() * d16.float()).sum() * (1.0 if use16 else 0.0)
-            if backend == "hip":                       # really leave one output out of the graph
-                loss = ((y * d32).sum() if use32 else 0.0) + ((ylow.float() * d16.float()).sum() if use16 else 0.0)
-            loss.backward()
-            res.append((xs.grad.float(), rs.grad, gs.grad, bs.grad))
+            with nn_ref.implementation(backend):
+                xs, rs = x.clone().requires_grad_(True), r.clone().requires_grad_(True)
+                gs, bs = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+                y, ylow = ops.add_layernorm(xs, rs, gs, bs, 1e-12, dropout_p=p, seed=5, dual=True)
+                if backend == "hip":
+                    assert y.dtype == torch.float32 and ylow.dtype == torch.bfloat16
+                    assert torch.equal(ylow, y.to(torch.bfloat16))
+                else:
+                    ylow = y.to(torch.bfloat16)            # the statement: the low copy is a cast of y
+                loss = (y * d32).sum() * (1.0 if use32 else 0.0) + (ylow.float() * d16.float()).sum() * (1.0 if use16 else 0.0)
+                if backend == "hip":                       # really leave one output out of the graph
+                    loss = ((y * d32).sum() if use32 else 0.0) + ((ylow.float() * d16.float()).sum() if use16 else 0.0)
+                loss.backward()
+                res.append((xs.grad.float(), rs.grad, gs.grad, bs.grad))
         for a, c, tol in zip(*res, (1e-2, 3e-5, 3e-5, 3e-5)):
             assert float((a - c).abs().max()) <= tol * max(1.0, float(c.abs().max())), (use32, use16)
 
@@ -596,15 +606,16 @@ def test_add_layernorm_with_the_producing_linears_bias(p):
     dy = _rand(rows, cols, seed=5)
     res = []
     for backend in ("hip", "torch"):
-        xs, rs = x.clone().requires_grad_(True), r.clone().requires_grad_(True)
-        gs, bs, xbs = (t.clone().requires_grad_(True) for t in (g, b, xb))
-        if backend == "hip":
-            y, ylow = ops.add_layernorm(xs, rs, gs, bs, 1e-12, dropout_p=p, seed=3, dual=True, bias=xbs)
-            assert ylow.dtype == torch.bfloat16
-        else:   # the statement: bias added in fp32, then the plain op
-            y = ops.add_layernorm(xs.float() + xbs, rs, gs, bs, 1e-12, backend="torch", dropout_p=p, seed=3)
-        y.backward(dy)
-        res.append((y.detach(), xs.grad.float(), rs.grad, gs.grad, bs.grad, xbs.grad))
+        with nn_ref.implementation(backend):
+            xs, rs = x.clone().requires_grad_(True), r.clone().requires_grad_(True)
+            gs, bs, xbs = (t.clone().requires_grad_(True) for t in (g, b, xb))
+            if backend == "hip":
+                y, ylow = ops.add_layernorm(xs, rs, gs, bs, 1e-12, dropout_p=p, seed=3, dual=True, bias=xbs)
+                assert ylow.dtype == torch.bfloat16
+            else:   # the statement: bias added in fp32, then the plain op
+                y = nn_ref.add_layernorm(xs.float() + xbs, rs, gs, bs, 1e-12, dropout_p=p, seed=3)
+            y.backward(dy)
+            res.append((y.detach(), xs.grad.float(), rs.grad, gs.grad, bs.grad, xbs.grad))
     for a, c, tol in zip(*res, (3e-5, 1e-2, 3e-5, 3e-5, 3e-5, 2e-3)):   # dx (and so its column sums) is rounded to bf16
         assert float((a - c).abs().max()) <= tol * max(1.0, float(c.abs().max()))
 
@@ -627,7 +638,7 @@ def test_ddp_wrapper_single_rank_rccl_on_the_hip_ops():
     try:
         grads = []
         for wrap in (False, True):
-            p = train.Predictor(Config(**enc), Config(is_decoder=True, **dec), mlm=False, backend="hip").cuda().train()
+            p = train.Predictor(Config(**enc), Config(is_decoder=True, **dec), mlm=False).cuda().train()
             p.model.load_state_dict(random_state_dict(p.model, int(z["seed"])))
 
             class Step(torch.nn.Module):
@@ -702,17 +713,18 @@ def test_short_training_run_learns_and_tracks_the_pytorch_statement():
              "decoder_attention_mask": torch.ones(64, 10, dtype=torch.long).cuda()}
     curves = {}
     for backend in ("hip", "torch"):
-        torch.manual_seed(1)
-        p = train.Predictor(Config(**enc), Config(is_decoder=True, **dec), mlm=False, backend=backend).cuda().train()
-        opt, _ = train.configure_optimizer(p, 2e-3, 0.0, 1000, 0.0, scheduler="constant")
-        losses = []
-        for _ in range(60):
-            with torch.autocast("cuda", dtype=torch.bfloat16):
-                loss, _ = p.training_step(batch)
-            loss.backward(); opt.step(); opt.zero_grad(set_to_none=True)
-            losses.append(float(loss))
-        assert all(np.isfinite(losses)), backend
-        curves[backend] = losses
+        with nn_ref.implementation(backend):
+            torch.manual_seed(1)
+            p = train.Predictor(Config(**enc), Config(is_decoder=True, **dec), mlm=False).cuda().train()
+            opt, _ = train.configure_optimizer(p, 2e-3, 0.0, 1000, 0.0, scheduler="constant")
+            losses = []
+            for _ in range(60):
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    loss, _ = p.training_step(batch)
+                loss.backward(); opt.step(); opt.zero_grad(set_to_none=True)
+                losses.append(float(loss))
+            assert all(np.isfinite(losses)), backend
+            curves[backend] = losses
     for backend, l in curves.items():
         assert np.mean(l[-5:]) < 0.5 * np.mean(l[:3]), (backend, l[:3], l[-5:])
     assert abs(np.mean(curves["hip"][-5:]) - np.mean(curves["torch"][-5:])) < 0.25 * np.mean(curves["torch"][:3])
@@ -726,16 +738,17 @@ def test_model_under_fp16_autocast_runs_on_the_bf16_kernels():
     t = lambda k_: torch.from_numpy(z[k_]).cuda()
     out = {}
     for backend in ("hip", "torch"):
-        m = TextReactModel(Config(**enc), Config(is_decoder=True, **dec), backend=backend)
-        m.load_state_dict(random_state_dict(m, int(z["seed"])))
-        m = m.cuda().eval()
-        with torch.autocast("cuda", dtype=torch.float16):
-            logits, _ = m(t("input_ids"), t("attention_mask"), t("decoder_input_ids"), t("decoder_attention_mask"))
-            loss = torch.nn.functional.cross_entropy(logits[:, :-1].reshape(-1, logits.shape[-1]).float(),
-                                                     t("decoder_input_ids")[:, 1:].reshape(-1), ignore_index=0)
-        loss.backward()
-        assert bool(torch.isfinite(logits).all())
-        out[backend] = (logits.detach().float(), {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
+        with nn_ref.implementation(backend):
+            m = TextReactModel(Config(**enc), Config(is_decoder=True, **dec))
+            m.load_state_dict(random_state_dict(m, int(z["seed"])))
+            m = m.cuda().eval()
+            with torch.autocast("cuda", dtype=torch.float16):
+                logits, _ = m(t("input_ids"), t("attention_mask"), t("decoder_input_ids"), t("decoder_attention_mask"))
+                loss = torch.nn.functional.cross_entropy(logits[:, :-1].reshape(-1, logits.shape[-1]).float(),
+                                                         t("decoder_input_ids")[:, 1:].reshape(-1), ignore_index=0)
+            loss.backward()
+            assert bool(torch.isfinite(logits).all())
+            out[backend] = (logits.detach().float(), {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
     assert float((out["hip"][0] - out["torch"][0]).abs().max()) <= 6e-2 * max(1.0, float(out["torch"][0].abs().max()))
     for n in out["hip"][1]:
         a, c = out["hip"][1][n], out["torch"][1][n]
@@ -756,21 +769,22 @@ def test_fp16_autocast_training_step_through_the_weight_gradient_gemm():
              "decoder_attention_mask": torch.ones(B, T, dtype=torch.long).cuda()}
     grads = {}
     for backend in ("hip", "torch"):
-        enc = Config(vocab_size=300, hidden_size=256, num_hidden_layers=1, num_attention_heads=4, intermediate_size=512,
-                     hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
-        dec = Config(vocab_size=50, hidden_size=256, num_hidden_layers=1, num_attention_heads=4, intermediate_size=512, type_vocab_size=1,
-                     layer_norm_eps=1e-5, is_decoder=True, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
-        p = train.Predictor(enc, dec, mlm=False, backend=backend)
-        p.model.load_state_dict(random_state_dict(p.model, 4))
-        p = p.cuda().train()
-        opt, _ = train.configure_optimizer(p, 1e-4, 0.01, 100, 0.02)
-        scaler = torch.amp.GradScaler("cuda", init_scale=1024.0)
-        with torch.autocast("cuda", dtype=torch.float16):
-            loss, _ = p.training_step(batch)
-        scaler.scale(loss).backward()
-        grads[backend] = {n: q.grad.detach().float() / 1024.0 for n, q in p.named_parameters() if q.grad is not None}
-        scaler.step(opt); scaler.update()
-        assert bool(torch.isfinite(loss)) and all(bool(torch.isfinite(q).all()) for q in p.parameters())
+        with nn_ref.implementation(backend):
+            enc = Config(vocab_size=300, hidden_size=256, num_hidden_layers=1, num_attention_heads=4, intermediate_size=512,
+                         hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+            dec = Config(vocab_size=50, hidden_size=256, num_hidden_layers=1, num_attention_heads=4, intermediate_size=512, type_vocab_size=1,
+                         layer_norm_eps=1e-5, is_decoder=True, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+            p = train.Predictor(enc, dec, mlm=False)
+            p.model.load_state_dict(random_state_dict(p.model, 4))
+            p = p.cuda().train()
+            opt, _ = train.configure_optimizer(p, 1e-4, 0.01, 100, 0.02)
+            scaler = torch.amp.GradScaler("cuda", init_scale=1024.0)
+            with torch.autocast("cuda", dtype=torch.float16):
+                loss, _ = p.training_step(batch)
+            scaler.scale(loss).backward()
+            grads[backend] = {n: q.grad.detach().float() / 1024.0 for n, q in p.named_parameters() if q.grad is not None}
+            scaler.step(opt); scaler.update()
+            assert bool(torch.isfinite(loss)) and all(bool(torch.isfinite(q).all()) for q in p.parameters())
     assert set(grads["hip"]) == set(grads["torch"])
     for n, a in grads["hip"].items():
         c = grads["torch"][n]
@@ -818,28 +832,29 @@ def test_weight_shadows_follow_the_optimizer_and_allow_two_forwards_before_one_b
     b1, b2 = mk(4), mk(3)
     out = {}
     for backend in ("hip", "torch"):
-        p = train.Predictor(enc, dec, mlm=False, backend=backend)
-        p.model.load_state_dict(random_state_dict(p.model, 4))
-        p = p.cuda().train()
-        opt = torch.optim.AdamW(p.parameters(), lr=2e-3, fused=True)      # fused: updates parameters without moving their autograd version
-        losses = []
-        for _ in range(3):
-            with torch.autocast("cuda", dtype=torch.bfloat16):
-                l1, _ = p.training_step(b1)
-                l2, _ = p.training_step(b2)          # a second forward before the backward: the shadows must not be rewritten
-            (l1 + l2).backward()
-            opt.step(); opt.zero_grad(set_to_none=True)
-            losses.append(float(l1) + float(l2))
-        out[backend] = losses
-        if backend == "hip":
-            reg = p.model.__dict__["_weight_shadows"]
-            assert len(reg.groups) >= 8
-            for ws_, bs_, w16, b16 in reg.groups.values():           # after the last step the NEXT forward refreshes them
-                pass
-            with torch.autocast("cuda", dtype=torch.bfloat16):
-                p.training_step(b1)
-            for ws_, bs_, w16, b16 in reg.groups.values():
-                assert torch.equal(w16, torch.cat([w.detach() for w in ws_]).to(torch.bfloat16))
+        with nn_ref.implementation(backend):
+            p = train.Predictor(enc, dec, mlm=False)
+            p.model.load_state_dict(random_state_dict(p.model, 4))
+            p = p.cuda().train()
+            opt = torch.optim.AdamW(p.parameters(), lr=2e-3, fused=True)      # fused: updates parameters without moving their autograd version
+            losses = []
+            for _ in range(3):
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    l1, _ = p.training_step(b1)
+                    l2, _ = p.training_step(b2)          # a second forward before the backward: the shadows must not be rewritten
+                (l1 + l2).backward()
+                opt.step(); opt.zero_grad(set_to_none=True)
+                losses.append(float(l1) + float(l2))
+            out[backend] = losses
+            if backend == "hip":
+                reg = p.model.__dict__["_weight_shadows"]
+                assert len(reg.groups) >= 8
+                for ws_, bs_, w16, b16 in reg.groups.values():           # after the last step the NEXT forward refreshes them
+                    pass
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    p.training_step(b1)
+                for ws_, bs_, w16, b16 in reg.groups.values():
+                    assert torch.equal(w16, torch.cat([w.detach() for w in ws_]).to(torch.bfloat16))
     assert out["hip"][-1] < out["hip"][0] - 0.05                      # the optimizer moves the weights: stale shadows would not learn
     for a, c in zip(out["hip"], out["torch"]):
         assert abs(a - c) <= 3e-2 * max(1.0, abs(c)), (out["hip"], out["torch"])
@@ -861,7 +876,7 @@ def test_a_backward_across_a_parameter_update_is_refused():
              "decoder_input_ids": torch.cat([torch.full((64, 1), 2), src[:, :8], torch.full((64, 1), 3)], 1).cuda(),
              "decoder_attention_mask": torch.ones(64, 10, dtype=torch.long).cuda()}
     torch.manual_seed(1)
-    p = train.Predictor(Config(**enc), Config(is_decoder=True, **dec), mlm=False, backend="hip").cuda().train()
+    p = train.Predictor(Config(**enc), Config(is_decoder=True, **dec), mlm=False).cuda().train()
     with torch.autocast("cuda", dtype=torch.bfloat16):
         l1, _ = p.training_step(batch)
         l2, _ = p.training_step(batch)

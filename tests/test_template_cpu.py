@@ -5,11 +5,13 @@ import json
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from textreact_amd.predictor import template as T
 from textreact_amd.predictor.model import Config
 
+pytestmark = pytest.mark.usefixtures("reference_ops")
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "template_small.npz")
 
 
@@ -18,10 +20,10 @@ def _tup(x):
     return (x[0], tuple(x[1]) if isinstance(x[1], list) else x[1], x[2])
 
 
-def load(backend="torch"):
+def load():
     z = np.load(G)
     enc = json.loads(str(z["enc_cfg"]))
-    m = T.TemplateBasedModel(Config(**enc), int(z["n_atom_t"]), int(z["n_bond_t"]), backend=backend)
+    m = T.TemplateBasedModel(Config(**enc), int(z["n_atom_t"]), int(z["n_bond_t"]))
     g = torch.Generator().manual_seed(int(z["seed"]))
     sd = {}
     for name, t in m.state_dict().items():

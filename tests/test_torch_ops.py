@@ -49,7 +49,7 @@ def test_attention_op_matches_the_function_path():
             if use_op:
                 out, _ = torch.ops.trx.attention_fwd(a, b, c, mask, False, 0.125, 0.1, 1234)
             else:
-                out = ops.attention(a, b, c, mask=mask, scale=0.125, dropout_p=0.1, seed=1234, backend="hip")
+                out = ops.attention(a, b, c, mask=mask, scale=0.125, dropout_p=0.1, seed=1234)
             out.backward(go)
             res.append((out.detach(), a.grad, b.grad, c.grad))
         for x, y in zip(*res):
@@ -70,7 +70,7 @@ def test_add_layernorm_op_matches_the_function_path():
             if use_op:
                 y, _, _ = torch.ops.trx.add_layernorm_fwd(a, b, c, d, 1e-12, 0.1, 77)
             else:
-                y = ops.add_layernorm(a, b, c, d, 1e-12, dropout_p=0.1, seed=77, backend="hip")
+                y = ops.add_layernorm(a, b, c, d, 1e-12, dropout_p=0.1, seed=77)
             y.backward(go)
             res.append((y.detach(), a.grad, b.grad, c.grad, d.grad))
         for p_, q_ in zip(*res):

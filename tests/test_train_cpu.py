@@ -1,5 +1,5 @@
-"""Training step, losses, checkpoint layout and 2-rank DDP of the predictor on CPU (torch backend of
-the two ops; the HIP kernels' gradients are checked against the same backend on the GPU)."""
+"""Training step, losses, checkpoint layout and 2-rank DDP of the predictor on CPU (on the PyTorch statement of the
+two ops, oracle/nn_ref.py; the HIP kernels' gradients are checked against the same statement on the GPU)."""
 import json
 import os
 import socket
@@ -15,6 +15,7 @@ from textreact_amd.predictor.model import Config, random_state_dict
 from textreact_amd.predictor import train
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.usefixtures("reference_ops")
 G = os.path.join(ROOT, "tests", "golden", "predictor_small.npz")
 
 
@@ -23,7 +24,7 @@ def _predictor(mlm=True, dropout=0.0):
     enc, dec = json.loads(str(z["enc_cfg"])), json.loads(str(z["dec_cfg"]))
     for c in (enc, dec):   # these tests compare numbers across runs: dropout off unless asked for
         c["hidden_dropout_prob"] = c["attention_probs_dropout_prob"] = dropout
-    p = train.Predictor(Config(**enc), Config(is_decoder=True, **dec), mlm=mlm, backend="torch")
+    p = train.Predictor(Config(**enc), Config(is_decoder=True, **dec), mlm=mlm)
     g = torch.Generator().manual_seed(5)
     with torch.no_grad():
         for t in p.parameters():
@@ -87,6 +88,8 @@ def _ddp_worker2(rank, world, port, ret):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import nn_ref
+    nn_ref.install()                 # this child process runs the module tree on the PyTorch statement of the ops
     _, p, batch = _predictor(mlm=False)
 
     class Step(torch.nn.Module):

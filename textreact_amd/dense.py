@@ -31,15 +31,15 @@ class DenseEncoder(nn.Module):
     TextReactModel, so a predictor checkpoint's encoder or a Tevatron `model.lm_q` / `lm_p`
     state dict loads with the prefix renamed."""
 
-    def __init__(self, cfg, backend="hip", normalize=False):
+    def __init__(self, cfg, normalize=False):
         super().__init__()
         self.encoder = BertEncoder(cfg)
-        self.backend, self.normalize = backend, normalize
+        self.normalize = normalize
 
     def forward(self, input_ids, attention_mask=None):
         if attention_mask is None:
             attention_mask = torch.ones_like(input_ids)
-        h = self.encoder(input_ids, additive_key_mask(attention_mask), None, None, None, self.backend)
+        h = self.encoder(input_ids, additive_key_mask(attention_mask), None, None, None)
         cls = h[:, 0]
         return torch.nn.functional.normalize(cls.float(), dim=-1).to(cls.dtype) if self.normalize else cls
 

@@ -117,9 +117,6 @@ def get_parser():
     p.add_argument('--tok_pad_id', type=int, default=0)
     p.add_argument('--tok_atom_templates', type=int, default=None)
     p.add_argument('--tok_bond_templates', type=int, default=None)
-    p.add_argument('--kernel_backend', type=str, default=None, choices=['hip', 'torch'],
-                   help="attention / add+LayerNorm backend: hip (libtrxnn.so, default on a GPU) or the PyTorch statement of "
-                        "the same ops (CPU tests)")
     return p
 
 
@@ -210,6 +207,20 @@ class TensorSplit:
             yield [self.indices[i] for i in sel], batch_in, batch_out
 
 
+def epoch_shard(n, seed, epoch, rank, world):
+    """the sample positions rank `rank` trains on in `epoch`: torch's DistributedSampler(shuffle=True), which Lightning
+    puts under the reference's train loader (main.py:372) -- one permutation per epoch from a generator seeded with
+    seed + epoch (so a resumed run continues the sequence of an uninterrupted one), padded by wrapping around to a
+    multiple of the world size, dealt rank-strided.  Every rank gets ceil(n / world) samples: the same number of
+    micro-batches and optimiser steps everywhere, which the gradient all-reduce of the step relies on."""
+    g = torch.Generator().manual_seed(seed + epoch)
+    perm = torch.randperm(n, generator=g).tolist()
+    total = -(-n // world) * world
+    while len(perm) < total:
+        perm += perm[:total - len(perm)]
+    return perm[rank:total:world]
+
+
 def _load_splits(spec, name):
     return [TensorSplit(f, name) for f in spec.split(",")] if spec else []
 
@@ -226,7 +237,7 @@ def _autocast(args, device):
 
 def main(argv=None):
     args = get_args(argv)
-    from .predictor import train as T
+    from .predictor import ops, train as T
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -234,6 +245,7 @@ def main(argv=None):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     cuda = torch.cuda.is_available()
     device = torch.device("cuda", local_rank) if cuda else torch.device("cpu")
+    ops.require_device(device)        # the attention / add+LayerNorm ops exist as HIP kernels only: no GPU, no trainer
     if cuda:
         torch.cuda.set_device(local_rank)
     if world > 1 and not dist.is_initialized():
@@ -248,16 +260,15 @@ def main(argv=None):
         print("note: dataset / tokenizer flags are accepted and not used here (%s): inputs are the --tensors_* files"
               % ", ".join("--" + k for k in ignored), file=sys.stderr)
     torch.manual_seed(args.seed)                      # pl.seed_everything (main.py:351)
-    backend = args.kernel_backend or ("hip" if cuda else "torch")
     enc_cfg, dec_cfg = _configs(args)
     if args.template_based:                           # model.py:11-19: encoder + atom / bond template heads, no decoder
         if not (args.tok_atom_templates and args.tok_bond_templates):
             raise SystemExit("--template_based needs --tok_atom_templates and --tok_bond_templates (the template vocabularies' sizes)")
         from .predictor.template import TemplatePredictor
-        module = TemplatePredictor(enc_cfg, args.tok_atom_templates, args.tok_bond_templates, backend=backend).to(device)
+        module = TemplatePredictor(enc_cfg, args.tok_atom_templates, args.tok_bond_templates).to(device)
     else:
         module = T.Predictor(enc_cfg, dec_cfg, mlm=args.mlm, mlm_layer=args.mlm_layer, mlm_lambda=args.mlm_lambda,
-                             pad_token_id=args.tok_pad_id, backend=backend).to(device)
+                             pad_token_id=args.tok_pad_id).to(device)
     train_sets = _load_splits(args.tensors_train, "train") if args.do_train else []
     val_sets = _load_splits(args.tensors_valid, "val") if (args.do_train or args.do_valid) else []
     test_sets = _load_splits(args.tensors_test, "test") if args.do_test else []
@@ -309,11 +320,9 @@ def main(argv=None):
         # are averaged by ONE flat all-reduce per optimiser step (RCCL over xGMI; a 770 MB fp32 payload is bandwidth-
         # bound, so one collective instead of DDP's 25 MB buckets costs nothing and needs no forward() wrapper)
         scaler = torch.amp.GradScaler(enabled=cuda and str(args.precision).startswith("16"))
-        g = torch.Generator().manual_seed(args.seed)
         for epoch in range(start_epoch, args.epochs):
             module.train()
-            perm = torch.randperm(n_train, generator=g).tolist()       # one shuffle for all ranks, then rank-strided
-            mine = perm[rank::world]
+            mine = epoch_shard(n_train, args.seed, epoch, rank, world)
             micro = 0
             opt.zero_grad(set_to_none=True)
             for b0 in range(0, len(mine), args.batch_size):

@@ -67,11 +67,11 @@ _warmup_streams = {}
 
 
 def _use_graph(model, dev, graph):
-    """decode through one captured HIP graph per generate call?  Default: yes on a GPU with the HIP ops
-    (TRX_DECODE_GRAPH=0 turns it off); the eager loop is what runs on the CPU and for backend 'torch'."""
+    """decode through one captured HIP graph per generate call?  Default: yes (TRX_DECODE_GRAPH=0 or graph=False turns it
+    off and runs the same step as eager launches)."""
     if graph is None:
         graph = os.environ.get("TRX_DECODE_GRAPH", "1") != "0"
-    return bool(graph) and dev.type == "cuda" and model.backend == "hip"
+    return bool(graph) and dev.type == "cuda"
 
 
 class _DecoderState:
@@ -89,12 +89,12 @@ class _DecoderState:
 
     def __init__(self, model, input_ids, attention_mask, expand, max_length, graph=False):
         from .model import additive_key_mask
-        self.model, self.be = model, model.backend
+        self.model = model
         dec = model.decoder.roberta
         if attention_mask is None:
             attention_mask = torch.ones_like(input_ids)
         key = additive_key_mask(attention_mask)
-        enc = model.encoder(input_ids, key, None, None, None, self.be)
+        enc = model.encoder(input_ids, key, None, None, None)
         self.enc_states = enc
         # the `expand` beams of one input share its encoder states: they are the QUERY ROWS of one cross-attention
         # problem per input (q [B, expand, H, 64] against K / V [B, L, H, 64]), not `expand` copies of K / V
@@ -130,20 +130,20 @@ class _DecoderState:
 
     # ---- eager step ----------------------------------------------------------------------------------------
     def _layers(self, h, self_attention):
-        m, be, H = self.model, self.be, self.H
+        m, H = self.model, self.H
         n = h.shape[0]
         for li, ly in enumerate(self.layers):
             at = ly.attention
             q = at.self.query(h).view(n, 1, H, 64)
             ctx = self_attention(li, q, at.self.key(h), at.self.value(h))
-            h = ops.add_layernorm(at.output.dense(ctx), h, at.output.LayerNorm.weight, at.output.LayerNorm.bias, at.eps, backend=be)
+            h = ops.add_layernorm(at.output.dense(ctx), h, at.output.LayerNorm.weight, at.output.LayerNorm.bias, at.eps)
             ca = ly.crossattention
             q = ca.self.query(h).view(n // self.expand, self.expand, H, 64)
-            ctx = ops.attention(q, self.kx[li], self.vx[li], mask=self.key, causal=False, backend=be).view(n, 1, H * 64)
-            h = ops.add_layernorm(ca.output.dense(ctx), h, ca.output.LayerNorm.weight, ca.output.LayerNorm.bias, ca.eps, backend=be)
+            ctx = ops.attention(q, self.kx[li], self.vx[li], mask=self.key, causal=False).view(n, 1, H * 64)
+            h = ops.add_layernorm(ca.output.dense(ctx), h, ca.output.LayerNorm.weight, ca.output.LayerNorm.bias, ca.eps)
             f = torch.nn.functional.gelu(ly.intermediate.dense(h))
-            h = ops.add_layernorm(ly.output.dense(f), h, ly.output.LayerNorm.weight, ly.output.LayerNorm.bias, ly.eps, backend=be)
-        logits = m.decoder.lm_head(h, be)[:, -1]
+            h = ops.add_layernorm(ly.output.dense(f), h, ly.output.LayerNorm.weight, ly.output.LayerNorm.bias, ly.eps)
+        logits = m.decoder.lm_head(h)[:, -1]
         return torch.log_softmax(logits.float(), dim=-1)
 
     def step(self, tokens, t):
@@ -154,17 +154,17 @@ class _DecoderState:
             which = t % len(self.graph)           # with beams: even / odd positions alternate between two cache sets
             self.graph[which].replay()
             return self.g_logp[which]
-        be, H = self.be, self.H
+        H = self.H
         ids = tokens[:, None]
         # RoBERTa positions with a cache: (1 + past length) for real tokens, the padding index for padding
         pos = torch.where(ids.ne(self.pad), torch.full_like(ids, t + 1 + self.pad), torch.full_like(ids, self.pad))
-        h = self.model.decoder.roberta.embeddings(ids, pos, None, be)
+        h = self.model.decoder.roberta.embeddings(ids, pos, None)
         n = h.shape[0]
 
         def self_attention(li, q, k, v):
             self.kc[li][:, t] = k.view(n, H, 64)
             self.vc[li][:, t] = v.view(n, H, 64)
-            return ops.attention(q, self.kc[li][:, :t + 1], self.vc[li][:, :t + 1], mask=None, causal=False, backend=be)
+            return ops.attention(q, self.kc[li][:, :t + 1], self.vc[li][:, :t + 1], mask=None, causal=False)
         return self._layers(h, self_attention)
 
     def reorder(self, parents, t):
@@ -189,7 +189,7 @@ class _DecoderState:
     def _graph_step(self, previous):
         """previous: the cache set the step before wrote (re-ordered by the parents INTO the current set, which
         halves the traffic of re-ordering in place through a temporary), or None without beams"""
-        be, H = self.be, self.H
+        H = self.H
         n = self.g_tok.shape[0]
         if previous is not None:
             for src, dst in zip(previous, self._caches()):
@@ -200,14 +200,14 @@ class _DecoderState:
         self.g_mask.index_fill_(1, self.g_t, 0.0)
         ids = self.g_tok[:, None]
         pos = torch.where(ids.ne(self.pad), (self.g_t + (1 + self.pad)).expand_as(ids), torch.full_like(ids, self.pad))
-        h = self.model.decoder.roberta.embeddings(ids, pos, None, be)
+        h = self.model.decoder.roberta.embeddings(ids, pos, None)
         if self.fast:
             return self._fast_layers(h)
 
         def self_attention(li, q, k, v):
             self.kc[li].index_copy_(1, self.g_t, k.view(n, 1, H, 64).to(self.kc[li].dtype))
             self.vc[li].index_copy_(1, self.g_t, v.view(n, 1, H, 64).to(self.vc[li].dtype))
-            return ops.attention(q, self.kc[li], self.vc[li], mask=self.g_mask, causal=False, backend=be)
+            return ops.attention(q, self.kc[li], self.vc[li], mask=self.g_mask, causal=False)
         return self._layers(h, self_attention)
 
     def _prepare_fast(self, enc, n, max_length):
@@ -234,7 +234,7 @@ class _DecoderState:
     def _fast_layers(self, h):
         """the decoder layers of `_layers` on the prepared bf16 weights: fp32 residual stream, bf16 copies of it for the
         GEMMs written by the LayerNorm kernel, dense biases added inside that kernel"""
-        lin, be, H = torch.nn.functional.linear, self.be, self.H
+        lin, H = torch.nn.functional.linear, self.H
         n = h.shape[0]
         h16 = h.to(torch.bfloat16)
         for li, ly in enumerate(self.layers):
@@ -246,19 +246,19 @@ class _DecoderState:
             else:
                 q = lin(h16, *w["q"]).view(n, 1, H, 64)
                 self.kvc[li].index_copy_(1, self.g_t, lin(h16, *w["kv"]).view(n, 1, 2, H, 64))
-                ctx = ops.attention_q_kv(q, self.kvc[li], mask=self.g_mask, backend=be)
-            h, h16 = ops.add_layernorm(lin(ctx, w["o"]), h, at.output.LayerNorm.weight, at.output.LayerNorm.bias, at.eps, backend=be,
+                ctx = ops.attention_q_kv(q, self.kvc[li], mask=self.g_mask)
+            h, h16 = ops.add_layernorm(lin(ctx, w["o"]), h, at.output.LayerNorm.weight, at.output.LayerNorm.bias, at.eps,
                                        dual=True, bias=at.output.dense.bias)
             q = lin(h16, *w["qx"]).view(n // self.expand, self.expand, H, 64)
-            ctx = ops.attention_q_kv(q, self.kvx[li], mask=self.key, backend=be).view(n, 1, H * 64)
-            h, h16 = ops.add_layernorm(lin(ctx, w["ox"]), h, ca.output.LayerNorm.weight, ca.output.LayerNorm.bias, ca.eps, backend=be,
+            ctx = ops.attention_q_kv(q, self.kvx[li], mask=self.key).view(n, 1, H * 64)
+            h, h16 = ops.add_layernorm(lin(ctx, w["ox"]), h, ca.output.LayerNorm.weight, ca.output.LayerNorm.bias, ca.eps,
                                        dual=True, bias=ca.output.dense.bias)
             f = torch.nn.functional.gelu(lin(h16, *w["i"]))
-            h, h16 = ops.add_layernorm(lin(f, w["out"]), h, ly.output.LayerNorm.weight, ly.output.LayerNorm.bias, ly.eps, backend=be,
+            h, h16 = ops.add_layernorm(lin(f, w["out"]), h, ly.output.LayerNorm.weight, ly.output.LayerNorm.bias, ly.eps,
                                        dual=True, bias=ly.output.dense.bias)
         head = self.model.decoder.lm_head
         x = torch.nn.functional.gelu(lin(h16, *self.w_head[0]))
-        x = ops.add_layernorm(x, None, head.layer_norm.weight, head.layer_norm.bias, head.eps, backend=be)
+        x = ops.add_layernorm(x, None, head.layer_norm.weight, head.layer_norm.bias, head.eps)
         return torch.log_softmax(lin(x[:, -1].float(), *self.w_head[1]), dim=-1)
 
     def _capture(self, n, max_length, dev, reorder):

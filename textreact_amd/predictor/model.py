@@ -62,14 +62,14 @@ class AttnOutput(nn.Module):
         self.LayerNorm = LayerNormParams(cfg.hidden_size)
 
 
-def _dense_add_layernorm(dense, x, h, ln, eps, backend, p):
-    """(stream, low) = LayerNorm(dropout(dense(x)) + h).  Under bf16 autocast on the HIP ops (x bf16, stream fp32)
+def _dense_add_layernorm(dense, x, h, ln, eps, p):
+    """(stream, low) = LayerNorm(dropout(dense(x)) + h).  Under bf16 autocast (x bf16, stream fp32)
     the dense layer runs WITHOUT its bias and the fused kernel adds it: the bias gradient then falls out of the
     LayerNorm backward instead of a separate reduction over all rows."""
-    if backend == "hip" and x.dtype == torch.bfloat16 and h.dtype == torch.float32 and x.is_cuda:
-        return ops.add_layernorm(ops.linear(x, dense.weight, None, backend), h, ln.weight, ln.bias, eps, backend=backend,
+    if x.dtype == torch.bfloat16 and h.dtype == torch.float32 and x.is_cuda:
+        return ops.add_layernorm(ops.linear(x, dense.weight, None), h, ln.weight, ln.bias, eps,
                                  dropout_p=p, dual=True, bias=dense.bias)
-    return ops.add_layernorm(dense(x), h, ln.weight, ln.bias, eps, backend=backend, dropout_p=p, dual=True)
+    return ops.add_layernorm(dense(x), h, ln.weight, ln.bias, eps, dropout_p=p, dual=True)
 
 
 class Attention(nn.Module):
@@ -82,7 +82,7 @@ class Attention(nn.Module):
         self.heads, self.eps = cfg.num_attention_heads, cfg.layer_norm_eps
         self.p_attn, self.p_hidden = cfg.attention_probs_dropout_prob, cfg.hidden_dropout_prob
 
-    def forward(self, h, h_low, kv_low, mask, causal, backend):
+    def forward(self, h, h_low, kv_low, mask, causal):
         """h: the residual stream; h_low / kv_low: what the projections read (a bf16 copy of the stream under
         autocast, the stream itself otherwise).  Returns the new (stream, low) pair."""
         B, Lq, Hd = h.shape
@@ -93,13 +93,13 @@ class Attention(nn.Module):
             # self-attention: ONE [*, 768] x [768, 2304] GEMM for q, k, v (same parameters, concatenated per call);
             # the attention kernels read the three slices of its output in place
             qkv = ops.linear_multi(h_low, (sa.query.weight, sa.key.weight, sa.value.weight),
-                                   (sa.query.bias, sa.key.bias, sa.value.bias), backend).view(B, Lq, 3, self.heads, 64)
-            ctx = ops.attention_qkv(qkv, mask=mask, causal=causal, backend=backend, dropout_p=pa)
+                                   (sa.query.bias, sa.key.bias, sa.value.bias)).view(B, Lq, 3, self.heads, 64)
+            ctx = ops.attention_qkv(qkv, mask=mask, causal=causal, dropout_p=pa)
         else:
-            q = ops.linear(h_low, sa.query.weight, sa.query.bias, backend).view(B, Lq, self.heads, 64)
-            kv = ops.linear_multi(kv_low, (sa.key.weight, sa.value.weight), (sa.key.bias, sa.value.bias), backend).view(B, Lk, 2, self.heads, 64)
-            ctx = ops.attention_q_kv(q, kv, mask=mask, causal=causal, backend=backend, dropout_p=pa)
-        return _dense_add_layernorm(self.output.dense, ctx, h, self.output.LayerNorm, self.eps, backend,
+            q = ops.linear(h_low, sa.query.weight, sa.query.bias).view(B, Lq, self.heads, 64)
+            kv = ops.linear_multi(kv_low, (sa.key.weight, sa.value.weight), (sa.key.bias, sa.value.bias)).view(B, Lk, 2, self.heads, 64)
+            ctx = ops.attention_q_kv(q, kv, mask=mask, causal=causal, dropout_p=pa)
+        return _dense_add_layernorm(self.output.dense, ctx, h, self.output.LayerNorm, self.eps,
                                     self.p_hidden if self.training else 0.0)
 
 
@@ -119,12 +119,12 @@ class Layer(nn.Module):
         self.output = AttnOutput(cfg, in_features=cfg.intermediate_size)
         self.eps, self.cross, self.p_hidden = cfg.layer_norm_eps, cross, cfg.hidden_dropout_prob
 
-    def forward(self, h, h_low, self_mask, causal, enc_low, enc_mask, backend):
-        h, h_low = self.attention(h, h_low, h_low, self_mask, causal, backend)
+    def forward(self, h, h_low, self_mask, causal, enc_low, enc_mask):
+        h, h_low = self.attention(h, h_low, h_low, self_mask, causal)
         if self.cross:
-            h, h_low = self.crossattention(h, h_low, enc_low, enc_mask, False, backend)
-        f = torch.nn.functional.gelu(ops.linear(h_low, self.intermediate.dense.weight, self.intermediate.dense.bias, backend))
-        return _dense_add_layernorm(self.output.dense, f, h, self.output.LayerNorm, self.eps, backend,
+            h, h_low = self.crossattention(h, h_low, enc_low, enc_mask, False)
+        f = torch.nn.functional.gelu(ops.linear(h_low, self.intermediate.dense.weight, self.intermediate.dense.bias))
+        return _dense_add_layernorm(self.output.dense, f, h, self.output.LayerNorm, self.eps,
                                     self.p_hidden if self.training else 0.0)
 
 
@@ -145,7 +145,7 @@ class Embeddings(nn.Module):
         self.eps, self.roberta, self.pad = cfg.layer_norm_eps, roberta, cfg.pad_token_id
         self.p_hidden = cfg.hidden_dropout_prob
 
-    def forward(self, input_ids, position_ids, token_type_ids, backend):
+    def forward(self, input_ids, position_ids, token_type_ids):
         if position_ids is None:
             if self.roberta:   # RoBERTa: positions count non-pad tokens, starting at pad + 1
                 nz = input_ids.ne(self.pad).int()
@@ -156,7 +156,7 @@ class Embeddings(nn.Module):
             token_type_ids = torch.zeros_like(input_ids)
         e = self.word_embeddings(input_ids) + self.token_type_embeddings(token_type_ids)
         y = ops.add_layernorm(e, self.position_embeddings(position_ids), self.LayerNorm.weight,
-                              self.LayerNorm.bias, self.eps, backend=backend)
+                              self.LayerNorm.bias, self.eps)
         return torch.nn.functional.dropout(y, self.p_hidden, self.training)   # after the LayerNorm (BertEmbeddings)
 
 
@@ -175,12 +175,12 @@ class BertEncoder(nn.Module):
         self.encoder = LayerStack(cfg)
         self.pooler = Pooler(cfg)
 
-    def forward(self, input_ids, key_mask, position_ids, token_type_ids, full_mask, backend):
-        h = self.embeddings(input_ids, position_ids, token_type_ids, backend)
+    def forward(self, input_ids, key_mask, position_ids, token_type_ids, full_mask):
+        h = self.embeddings(input_ids, position_ids, token_type_ids)
         m = full_mask if full_mask is not None else key_mask
         h_low = h
         for layer in self.encoder.layer:
-            h, h_low = layer(h, h_low, m, False, None, None, backend)
+            h, h_low = layer(h, h_low, m, False, None, None)
         self.last_low = h_low      # bf16 copy of the output under autocast (cross-attention reads it)
         return h
 
@@ -202,9 +202,9 @@ class LMHead(nn.Module):
         self.decoder.bias = self.bias      # tied, as in RobertaLMHead
         self.eps = cfg.layer_norm_eps
 
-    def forward(self, h, backend):
+    def forward(self, h):
         x = torch.nn.functional.gelu(self.dense(h))
-        x = ops.add_layernorm(x, None, self.layer_norm.weight, self.layer_norm.bias, self.eps, backend=backend)
+        x = ops.add_layernorm(x, None, self.layer_norm.weight, self.layer_norm.bias, self.eps)
         return self.decoder(x)
 
 
@@ -224,7 +224,7 @@ def additive_key_mask(attention_mask, dtype=torch.float32):
 def weight_shadows(model, like):
     """the model's ops.WeightShadows registry (created on first use) when a training forward under autocast on the GPU can
     use it, else None"""
-    if not (model.backend == "hip" and like.is_cuda and torch.is_autocast_enabled("cuda") and torch.is_grad_enabled()) \
+    if not (like.is_cuda and torch.is_autocast_enabled("cuda") and torch.is_grad_enabled()) \
             or "TRX_NN_NO_SHADOWS" in os.environ:      # (the knob is for A/B timing)
         return None
     reg = model.__dict__.get("_weight_shadows")
@@ -236,11 +236,10 @@ def weight_shadows(model, like):
 class TextReactModel(nn.Module):
     """forward(input_ids, attention_mask, decoder_input_ids, ...) -> (logits, encoder_last_hidden_state)"""
 
-    def __init__(self, enc_cfg, dec_cfg, backend="hip"):
+    def __init__(self, enc_cfg, dec_cfg):
         super().__init__()
         self.encoder = BertEncoder(enc_cfg)
         self.decoder = RobertaCausalLM(dec_cfg)
-        self.backend = backend
 
     def forward(self, input_ids, attention_mask=None, decoder_input_ids=None, decoder_attention_mask=None,
                 position_ids=None, token_type_ids=None):
@@ -250,7 +249,6 @@ class TextReactModel(nn.Module):
         return self._forward(input_ids, attention_mask, decoder_input_ids, decoder_attention_mask, position_ids, token_type_ids)
 
     def _forward(self, input_ids, attention_mask, decoder_input_ids, decoder_attention_mask, position_ids, token_type_ids):
-        be = self.backend
         if attention_mask is None:
             attention_mask = torch.ones_like(input_ids)
         full = None
@@ -259,14 +257,14 @@ class TextReactModel(nn.Module):
             key = additive_key_mask(attention_mask.amax(dim=1))
         else:
             key = additive_key_mask(attention_mask)
-        enc = self.encoder(input_ids, key, position_ids, token_type_ids, full, be)
+        enc = self.encoder(input_ids, key, position_ids, token_type_ids, full)
         dmask = additive_key_mask(decoder_attention_mask) if decoder_attention_mask is not None else None
         enc_low = self.encoder.last_low
-        h = self.decoder.roberta.embeddings(decoder_input_ids, None, None, be)
+        h = self.decoder.roberta.embeddings(decoder_input_ids, None, None)
         h_low = h
         for layer in self.decoder.roberta.encoder.layer:
-            h, h_low = layer(h, h_low, dmask, True, enc_low, key, be)
-        return self.decoder.lm_head(h_low, be), enc
+            h, h_low = layer(h, h_low, dmask, True, enc_low, key)
+        return self.decoder.lm_head(h_low), enc
 
 
 def random_state_dict(model, seed):

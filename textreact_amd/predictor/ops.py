@@ -1,10 +1,9 @@
 """Attention and residual-add + LayerNorm as torch ops backed by libtrxnn.so (include/trx_nn.h).
 
-backend 'hip'  : the product path -- raw device pointers into the C ABI on torch's current stream.
-                 Raises if the library or a GPU is missing (no silent fallback).
-backend 'torch': plain fp32 PyTorch statement of the same two ops.  It exists as the NUMERICS
-                 REFERENCE for the kernels (tests) and so the module tree can be checked on a box
-                 without a GPU; TextReactModel never selects it by itself.
+There is ONE implementation: raw device pointers into the C ABI on torch's current stream.  Every op raises
+(TrxNNError) if the library or a GPU is missing -- no fallback.  The plain fp32 PyTorch statement of the same ops,
+which the kernel tests compare against and which lets the module tree be checked on a box without a GPU, is test
+infrastructure and lives in oracle/nn_ref.py; nothing in this package imports it.
 """
 import ctypes
 import math
@@ -75,6 +74,14 @@ def _need_gpu(t):
         raise TrxNNError("the HIP ops need tensors on a GPU (there is no CPU implementation behind them)")
 
 
+def require_device(device):
+    """the trainer / encoder entry points call this first: there is no CPU implementation behind the ops"""
+    if torch.device(device).type != "cuda":
+        raise TrxNNError("textreact_amd.predictor needs a GPU: attention and add+LayerNorm exist as HIP kernels only "
+                         "(libtrxnn.so), there is no CPU implementation behind them")
+    lib()
+
+
 def _dt(t):
     if t.dtype == torch.float32:
         return F32
@@ -134,8 +141,8 @@ def new_seed():
 
 
 def dropout_keep_mask(seed, p, streams, rows, cols, device):
-    """bool [streams, rows, cols]: the decisions the kernels take for (seed, p) -- tests and the
-    'torch' reference backend use it so that both backends drop the same elements"""
+    """bool [streams, rows, cols]: the decisions the kernels take for (seed, p), materialised -- so that a reference
+    statement of an op (oracle/nn_ref.py) can drop the same elements in the parity tests"""
     keep = torch.empty((streams, rows, cols), dtype=torch.uint8, device=device)
     if not keep.is_cuda:
         raise TrxNNError("dropout decisions are computed on the GPU (there is no CPU implementation)")
@@ -245,7 +252,7 @@ class _AddLayerNormMixed(torch.autograd.Function):
         return dx, dz, dg, db, None, None, None, None, dxb
 
 
-def add_layernorm(x, res, gamma, beta, eps, backend="hip", dropout_p=0.0, seed=None, dual=False, bias=None):
+def add_layernorm(x, res, gamma, beta, eps, dropout_p=0.0, seed=None, dual=False, bias=None):
     """LayerNorm(dropout(x) + res) * gamma + beta over the last dimension; res may be None.
     dropout_p > 0 (training): x is dropped before the residual is added, as BertSelfOutput /
     BertOutput / BertEmbeddings do; `seed` picks the decisions (default: a fresh one).
@@ -253,29 +260,28 @@ def add_layernorm(x, res, gamma, beta, eps, backend="hip", dropout_p=0.0, seed=N
     residual stream fp32 (autocast) -- for the Linear layers that read y next -- and y itself otherwise.
     bias: the bias of the Linear that produced x, when the caller ran that Linear WITHOUT it: x + bias is formed
     here, and in the mixed-storage path inside the kernel, whose backward then yields the bias gradient too."""
-    if backend == "hip" and x.dtype == torch.float16:
+    _need_gpu(x)
+    if x.dtype == torch.float16:
         # fp16 autocast (the reference's --precision 16-mixed): the kernels store bf16 or fp32 -- run on bf16, hand fp16 back
         # where the caller would have got x's type
         out = add_layernorm(x.to(torch.bfloat16), res.to(torch.bfloat16) if (res is not None and res.dtype == torch.float16) else res,
-                            gamma, beta, eps, backend=backend, dropout_p=dropout_p, seed=seed, dual=dual, bias=bias)
+                            gamma, beta, eps, dropout_p=dropout_p, seed=seed, dual=dual, bias=bias)
         if dual:
             return out[0].to(torch.float16) if out[0].dtype == torch.bfloat16 else out[0], out[1]
         return out.to(torch.float16) if out.dtype == torch.bfloat16 else out
 
     def _mixed(x, res):
         cols = x.shape[-1]
-        return (backend == "hip" and res is not None and x.dtype == torch.bfloat16 and res.dtype == torch.float32
-                and cols % 4 == 0 and cols <= 1024 and x.is_cuda)
+        return (res is not None and x.dtype == torch.bfloat16 and res.dtype == torch.float32
+                and cols % 4 == 0 and cols <= 1024)
     if bias is not None and not _mixed(x, res):
         x, bias = x + bias.to(x.dtype), None
     if dual:
-        cols = x.shape[-1]
-        if (backend == "hip" and res is not None and x.dtype == torch.bfloat16 and res.dtype == torch.float32
-                and cols % 4 == 0 and cols <= 1024 and x.is_cuda):
+        if _mixed(x, res):
             if dropout_p > 0 and seed is None:
                 seed = new_seed()
             return _AddLayerNormMixed.apply(x, res, gamma, beta, eps, float(dropout_p), 0 if seed is None else seed, True, bias)
-        y = add_layernorm(x, res, gamma, beta, eps, backend=backend, dropout_p=dropout_p, seed=seed)
+        y = add_layernorm(x, res, gamma, beta, eps, dropout_p=dropout_p, seed=seed)
         return y, y
     if dropout_p > 0 and seed is None:
         seed = new_seed()
@@ -283,22 +289,11 @@ def add_layernorm(x, res, gamma, beta, eps, backend="hip", dropout_p=0.0, seed=N
         # autocast: dense outputs are bf16 while the residual stream stays fp32 (torch runs layer_norm in
         # fp32 under autocast, so does the reference): the mixed kernels read x as bf16 and keep the
         # stream in fp32; anything else is widened to one storage type first.
-        cols = x.shape[-1]
-        if (backend == "hip" and x.dtype == torch.bfloat16 and res.dtype == torch.float32 and cols % 4 == 0
-                and cols <= 1024 and x.is_cuda):
+        if _mixed(x, res):
             return _AddLayerNormMixed.apply(x, res, gamma, beta, eps, float(dropout_p), 0 if seed is None else seed, False, bias)
         wide = torch.promote_types(x.dtype, res.dtype)
         x, res = x.to(wide), res.to(wide)
-    if backend == "hip":
-        return _AddLayerNorm.apply(x, res, gamma, beta, eps, float(dropout_p), 0 if seed is None else seed)
-    if dropout_p > 0 and not x.is_cuda:     # module tree on a box without a GPU: torch's own dropout
-        x = torch.nn.functional.dropout(x, dropout_p, True)
-    elif dropout_p > 0:
-        cols = x.shape[-1]
-        keep = dropout_keep_mask(seed, dropout_p, 1, x.numel() // cols, cols, x.device).view(x.shape)
-        x = x * keep.to(x.dtype) / (1.0 - dropout_p)
-    z = x if res is None else x + res
-    return torch.nn.functional.layer_norm(z.float(), (z.shape[-1],), gamma.float(), beta.float(), eps).to(x.dtype)
+    return _AddLayerNorm.apply(x, res, gamma, beta, eps, float(dropout_p), 0 if seed is None else seed)
 
 
 def _attention_fwd_launch(q, k, v, mask, causal, scale, p, seed, want_lse):
@@ -348,7 +343,7 @@ class _Attention(torch.autograd.Function):
         return dq, dk, dv, None, None, None, None, None
 
 
-def attention(q, k, v, mask=None, causal=False, scale=None, backend="hip", dropout_p=0.0, seed=None):
+def attention(q, k, v, mask=None, causal=False, scale=None, dropout_p=0.0, seed=None):
     """q [B, Lq, H, 64], k / v [B, Lk, H, 64] -> [B, Lq, H*64].
     mask: additive float, [B, Lk] (key padding) or [B, Lq, Lk]; causal: key j visible iff
     j <= i + (Lk - Lq).  dropout_p > 0 (training): dropout on the softmax probabilities
@@ -359,43 +354,26 @@ def attention(q, k, v, mask=None, causal=False, scale=None, backend="hip", dropo
         scale = 1.0 / math.sqrt(D)
     if dropout_p > 0 and seed is None:
         seed = new_seed()
-    if backend == "hip" and q.dtype == torch.float16:   # fp16 autocast: on the bf16 kernels, fp16 handed back
+    _need_gpu(q)
+    if q.dtype == torch.float16:   # fp16 autocast: on the bf16 kernels, fp16 handed back
         bf = torch.bfloat16
-        return attention(q.to(bf), k.to(bf), v.to(bf), mask=mask, causal=causal, scale=scale, backend=backend,
+        return attention(q.to(bf), k.to(bf), v.to(bf), mask=mask, causal=causal, scale=scale,
                          dropout_p=dropout_p, seed=seed).to(torch.float16)
-    if backend == "hip":
-        _need_gpu(q)
-        if D != 64:
-            raise TrxNNError("the attention kernel is specialised for heads of 64 (got %d)" % D)
-        if (not (q.requires_grad or k.requires_grad or v.requires_grad) and dropout_p == 0 and not k.is_contiguous()
-                and k.stride() == v.stride() and k.stride()[1:] == (H * D, D, 1) and k.stride(0) >= Lk * H * D):
-            # the first Lk positions of a key/value cache [B, Lmax, H, 64]: read in place (decoding)
-            qc = q.contiguous()
-            mode, m = MASK_NONE, None
-            if mask is not None:
-                m = mask.float().contiguous()
-                mode = MASK_KEY if m.dim() == 2 else MASK_FULL
-            out = torch.empty((B, Lq, H * D), dtype=q.dtype, device=q.device)
-            _check(lib().trx_attention_fwd_kvcache(_p(qc), _p(k), _p(v), _p(m), mode, 1 if causal else 0, B, H, Lq, Lk,
-                                                   k.stride(0), float(scale), _dt(qc), _p(out), _stream(qc)))
-            return out
-        return _Attention.apply(q, k, v, mask, causal, scale, float(dropout_p), 0 if seed is None else seed)
-    qf, kf, vf = (t.float().permute(0, 2, 1, 3) for t in (q, k, v))             # [B, H, L, D]
-    s = torch.matmul(qf, kf.transpose(-1, -2)) * scale
-    if mask is not None:
-        mm = mask.float()
-        s = s + (mm[:, None, None, :] if mm.dim() == 2 else mm[:, None, :, :])
-    if causal:
-        i = torch.arange(Lq, device=q.device)[:, None] + (Lk - Lq)
-        j = torch.arange(Lk, device=q.device)[None, :]
-        s = s.masked_fill(j > i, torch.finfo(torch.float32).min)
-    p = torch.softmax(s, dim=-1)
-    if dropout_p > 0 and not q.is_cuda:
-        p = torch.nn.functional.dropout(p, dropout_p, True)
-    elif dropout_p > 0:
-        keep = dropout_keep_mask(seed, dropout_p, B * H, Lq, Lk, q.device).view(B, H, Lq, Lk)
-        p = p * keep.float() / (1.0 - dropout_p)
-    return torch.matmul(p, vf).permute(0, 2, 1, 3).reshape(B, Lq, H * D).to(q.dtype)
+    if D != 64:
+        raise TrxNNError("the attention kernel is specialised for heads of 64 (got %d)" % D)
+    if (not (q.requires_grad or k.requires_grad or v.requires_grad) and dropout_p == 0 and not k.is_contiguous()
+            and k.stride() == v.stride() and k.stride()[1:] == (H * D, D, 1) and k.stride(0) >= Lk * H * D):
+        # the first Lk positions of a key/value cache [B, Lmax, H, 64]: read in place (decoding)
+        qc = q.contiguous()
+        mode, m = MASK_NONE, None
+        if mask is not None:
+            m = mask.float().contiguous()
+            mode = MASK_KEY if m.dim() == 2 else MASK_FULL
+        out = torch.empty((B, Lq, H * D), dtype=q.dtype, device=q.device)
+        _check(lib().trx_attention_fwd_kvcache(_p(qc), _p(k), _p(v), _p(m), mode, 1 if causal else 0, B, H, Lq, Lk,
+                                               k.stride(0), float(scale), _dt(qc), _p(out), _stream(qc)))
+        return out
+    return _Attention.apply(q, k, v, mask, causal, scale, float(dropout_p), 0 if seed is None else seed)
 
 
 def attention_decode_gather(q, kv, anc, t_dev, scale=None):
@@ -477,38 +455,38 @@ class _AttentionPacked(torch.autograd.Function):
         return da, dkv, None, None, None, None, None
 
 
-def _packed_ok(t, backend):
-    return backend == "hip" and t.is_cuda and t.dtype == torch.bfloat16 and t.shape[-1] == 64 and "TRX_NN_ATTN_VALU" not in os.environ
+def _packed_ok(t):
+    return t.is_cuda and t.dtype == torch.bfloat16 and t.shape[-1] == 64 and "TRX_NN_ATTN_VALU" not in os.environ
 
 
-def attention_qkv(qkv, mask=None, causal=False, scale=None, backend="hip", dropout_p=0.0, seed=None):
+def attention_qkv(qkv, mask=None, causal=False, scale=None, dropout_p=0.0, seed=None):
     """self-attention on a packed projection qkv [B, L, 3, H, 64] (one GEMM instead of three) -> [B, L, H*64]"""
     if scale is None:
         scale = 1.0 / math.sqrt(qkv.shape[-1])
     if dropout_p > 0 and seed is None:
         seed = new_seed()
-    if backend == "hip" and qkv.dtype == torch.float16:
-        return attention_qkv(qkv.to(torch.bfloat16), mask=mask, causal=causal, scale=scale, backend=backend,
+    if qkv.dtype == torch.float16:
+        return attention_qkv(qkv.to(torch.bfloat16), mask=mask, causal=causal, scale=scale,
                              dropout_p=dropout_p, seed=seed).to(torch.float16)
-    if _packed_ok(qkv, backend):
+    if _packed_ok(qkv):
         return _AttentionPacked.apply(qkv, None, mask, causal, scale, float(dropout_p), 0 if seed is None else seed)
     q, k, v = qkv.unbind(dim=2)
-    return attention(q, k, v, mask=mask, causal=causal, scale=scale, backend=backend, dropout_p=dropout_p, seed=seed)
+    return attention(q, k, v, mask=mask, causal=causal, scale=scale, dropout_p=dropout_p, seed=seed)
 
 
-def attention_q_kv(q, kv, mask=None, causal=False, scale=None, backend="hip", dropout_p=0.0, seed=None):
+def attention_q_kv(q, kv, mask=None, causal=False, scale=None, dropout_p=0.0, seed=None):
     """cross-attention: q [B, Lq, H, 64] and a packed key/value projection kv [B, Lk, 2, H, 64]"""
     if scale is None:
         scale = 1.0 / math.sqrt(q.shape[-1])
     if dropout_p > 0 and seed is None:
         seed = new_seed()
-    if backend == "hip" and q.dtype == torch.float16:
-        return attention_q_kv(q.to(torch.bfloat16), kv.to(torch.bfloat16), mask=mask, causal=causal, scale=scale, backend=backend,
+    if q.dtype == torch.float16:
+        return attention_q_kv(q.to(torch.bfloat16), kv.to(torch.bfloat16), mask=mask, causal=causal, scale=scale,
                               dropout_p=dropout_p, seed=seed).to(torch.float16)
-    if _packed_ok(q, backend) and kv.dtype == q.dtype:
+    if _packed_ok(q) and kv.dtype == q.dtype:
         return _AttentionPacked.apply(q, kv, mask, causal, scale, float(dropout_p), 0 if seed is None else seed)
     k, v = kv.unbind(dim=2)
-    return attention(q, k, v, mask=mask, causal=causal, scale=scale, backend=backend, dropout_p=dropout_p, seed=seed)
+    return attention(q, k, v, mask=mask, causal=causal, scale=scale, dropout_p=dropout_p, seed=seed)
 
 
 # ---- Linear layers: the weight gradient on a split-contraction TN GEMM ---------------------------------------------
@@ -703,25 +681,25 @@ class _LinearWgrad(torch.autograd.Function):
         return (dx, None, *grads)
 
 
-def linear_multi(x, weights, biases=None, backend="hip"):
+def linear_multi(x, weights, biases=None):
     """F.linear(x, cat(weights), cat(biases)) for Linear layers that read the same input (query / key / value): one
     product, no concatenation of the fp32 parameters (see _LinearWgrad); falls back to the concatenation otherwise"""
     w0 = weights[0]
-    if (backend == "hip" and x.is_cuda and x.dtype == torch.bfloat16 and torch.is_grad_enabled() and w0.requires_grad
+    if (x.is_cuda and x.dtype == torch.bfloat16 and torch.is_grad_enabled() and w0.requires_grad
             and sum(w.shape[0] for w in weights) % 256 == 0 and w0.shape[1] % 256 == 0):
         return _LinearWgrad.apply(x, len(weights), *weights, *(biases if biases is not None else ()))
     w = w0 if len(weights) == 1 else torch.cat(list(weights))
     b = None if biases is None else (biases[0] if len(biases) == 1 else torch.cat(list(biases)))
-    return linear(x, w, b, backend)
+    return linear(x, w, b)
 
 
-def linear(x, weight, bias=None, backend="hip"):
+def linear(x, weight, bias=None):
     """torch.nn.functional.linear; for bf16 activations on the GPU (autocast training) the weight gradient is routed
     to the split-contraction TN GEMM when its shape qualifies"""
-    if (backend == "hip" and x.is_cuda and x.dtype == torch.bfloat16 and torch.is_grad_enabled() and weight.requires_grad
+    if (x.is_cuda and x.dtype == torch.bfloat16 and torch.is_grad_enabled() and weight.requires_grad
             and weight.shape[0] % 256 == 0 and weight.shape[1] % 256 == 0):
         return _LinearWgrad.apply(x, 1, weight, *((bias,) if bias is not None else ()))
-    if (backend == "hip" and x.is_cuda and x.dtype == torch.bfloat16 and torch.is_autocast_enabled("cuda")
+    if (x.is_cuda and x.dtype == torch.bfloat16 and torch.is_autocast_enabled("cuda")
             and torch.get_autocast_dtype("cuda") == torch.float16):
         # fp16 autocast (--precision 16-mixed) over the bf16 stream the LayerNorm kernel writes: keep the product in bf16
         # (autocast would re-cast x to fp16 and every HIP op downstream would convert it back)
@@ -764,7 +742,7 @@ def _op_add_ln_fwd(x, res, gamma, beta, eps, p, seed):
 def _op_add_ln_bwd(dy, x, res, gamma, mean, rstd, p, seed):
     dz, dx, dg, db = _add_ln_bwd_launch(dy, x.contiguous(), res.contiguous() if res is not None else None,
                                         gamma.float().contiguous(), mean, rstd, p, seed)
-    return dx, dz, dg, db
+    return (dx.clone() if dx is dz else dx), dz, dg, db      # outputs of a custom op must not alias each other
 
 
 _trx_lib.impl("attention_fwd", _op_attention_fwd, "CUDA")

@@ -51,20 +51,19 @@ class TemplateBasedModel(nn.Module):
     """forward(input_ids, attention_mask, atom_indices=[LongTensor per reaction]) ->
     ((atom_logits, bond_logits), encoder_last_hidden_state)"""
 
-    def __init__(self, enc_cfg, num_atom_templates, num_bond_templates, backend="hip"):
+    def __init__(self, enc_cfg, num_atom_templates, num_bond_templates):
         super().__init__()
         self.encoder = BertEncoder(enc_cfg)
         self.template_head = TemplatePredictionHead(enc_cfg.hidden_size, num_atom_templates, num_bond_templates)
-        self.backend = backend
 
     def forward(self, input_ids, attention_mask=None, atom_indices=None, position_ids=None, token_type_ids=None, **_):
         if attention_mask is None:
             attention_mask = torch.ones_like(input_ids)
         if self.training:
             with ops.seed_scope(), ops.use_shadows(weight_shadows(self, input_ids)):
-                enc = self.encoder(input_ids, additive_key_mask(attention_mask), position_ids, token_type_ids, None, self.backend)
+                enc = self.encoder(input_ids, additive_key_mask(attention_mask), position_ids, token_type_ids, None)
         else:
-            enc = self.encoder(input_ids, additive_key_mask(attention_mask), position_ids, token_type_ids, None, self.backend)
+            enc = self.encoder(input_ids, additive_key_mask(attention_mask), position_ids, token_type_ids, None)
         atoms = pad_sequence([h[idx] for h, idx in zip(enc, atom_indices)], batch_first=True)
         return self.template_head(atoms), enc
 
@@ -147,9 +146,9 @@ class TemplatePredictor(nn.Module):
     """what `textreact_amd.main` drives under --template_based: the same step interface as predictor/train.py's Predictor,
     parameters under `model.` like the reference's LightningModule (so the checkpoint keys are the reference's)"""
 
-    def __init__(self, enc_cfg, num_atom_templates, num_bond_templates, backend="hip"):
+    def __init__(self, enc_cfg, num_atom_templates, num_bond_templates):
         super().__init__()
-        self.model = TemplateBasedModel(enc_cfg, num_atom_templates, num_bond_templates, backend=backend)
+        self.model = TemplateBasedModel(enc_cfg, num_atom_templates, num_bond_templates)
 
     @staticmethod
     def _model_inputs(batch_in):

@@ -28,29 +28,28 @@ class MLMTransform(nn.Module):
 class MLMHead(nn.Module):
     """BertLMPredictionHead (model.py:40-47, --mlm_layer mlp): transform.{dense,LayerNorm} -> decoder"""
 
-    def __init__(self, cfg, backend="hip"):
+    def __init__(self, cfg):
         super().__init__()
         self.transform = MLMTransform(cfg)
         self.decoder = nn.Linear(cfg.hidden_size, cfg.vocab_size)
         self.bias = nn.Parameter(torch.zeros(cfg.vocab_size))
         self.decoder.bias = self.bias
-        self.eps, self.backend = cfg.layer_norm_eps, backend
+        self.eps = cfg.layer_norm_eps
 
     def forward(self, h):
         x = F.gelu(self.transform.dense(h))
-        x = ops.add_layernorm(x, None, self.transform.LayerNorm.weight, self.transform.LayerNorm.bias, self.eps,
-                              backend=self.backend)
+        x = ops.add_layernorm(x, None, self.transform.LayerNorm.weight, self.transform.LayerNorm.bias, self.eps)
         return self.decoder(x)
 
 
 class Predictor(nn.Module):
     """the LightningModule's parameter tree without Lightning"""
 
-    def __init__(self, enc_cfg, dec_cfg, mlm=False, mlm_layer="mlp", mlm_lambda=1.0, pad_token_id=0, backend="hip"):
+    def __init__(self, enc_cfg, dec_cfg, mlm=False, mlm_layer="mlp", mlm_lambda=1.0, pad_token_id=0):
         super().__init__()
-        self.model = TextReactModel(enc_cfg, dec_cfg, backend=backend)
+        self.model = TextReactModel(enc_cfg, dec_cfg)
         if mlm:
-            self.mlm_head = MLMHead(enc_cfg, backend) if mlm_layer == "mlp" else nn.Linear(enc_cfg.hidden_size, enc_cfg.vocab_size)
+            self.mlm_head = MLMHead(enc_cfg) if mlm_layer == "mlp" else nn.Linear(enc_cfg.hidden_size, enc_cfg.vocab_size)
         self.mlm, self.mlm_lambda, self.pad = mlm, mlm_lambda, pad_token_id
 
     # main.py:129-134
@@ -196,7 +195,7 @@ def save_checkpoint(path, module, optimizer=None, lr_scheduler=None, epoch=0, gl
 
 
 def mark_parameters_updated(module):
-    """call after an optimizer step or a load_state_dict: the bf16 weight copies the HIP backend's `linear` shares between
+    """call after an optimizer step or a load_state_dict: the bf16 weight copies `ops.linear` shares between
     forwards (ops.WeightShadows) belong to a new generation; a backward of an older forward raises instead of reading them"""
     for m in module.modules():
         reg = m.__dict__.get("_weight_shadows")

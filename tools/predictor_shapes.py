@@ -26,7 +26,7 @@ for name, lq, lk, causal in ATT:
     v = torch.randn(B, lk, H, 64, device="cuda", generator=g).bfloat16().requires_grad_()
     mask = torch.zeros(B, lk, device="cuda")
     for _ in range(N):
-        o = ops.attention(q, k, v, mask=mask, causal=causal, backend="hip")
+        o = ops.attention(q, k, v, mask=mask, causal=causal)
         o.backward(torch.ones_like(o))
     torch.cuda.synchronize()
     plan["attention"].append({"shape": name, "Lq": lq, "Lk": lk, "causal": causal, "flops_fwd": 4.0 * B * H * lq * lk * 64 * (0.5 if causal else 1.0)})

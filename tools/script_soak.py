@@ -1,13 +1,14 @@
-"""the reference's script configurations at full model size on the HIP backend, a few steps each, under the precision
+"""the reference's script configurations at full model size on the HIP ops, a few steps each, under the precision
 the scripts pass (16-mixed = fp16 autocast + GradScaler): RCR (condition task, --mlm mlp head, train_RCR.sh), RetroSyn
 template-free (train_RetroSyn_tf.sh) incl. validation and a beam-search test step, RetroSyn template-based
-(train_RetroSyn_tb.sh).  Prints the losses of the hip and torch backends side by side."""
+(train_RetroSyn_tb.sh).  Prints the losses of the HIP ops and of their PyTorch statement (oracle/nn_ref.py) side by side."""
 import os
 import sys
 
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import nn_ref  # noqa: E402  (the PyTorch statement of the ops: the side the kernels are compared with)
 from textreact_amd.predictor import template, train  # noqa: E402
 from textreact_amd.predictor.model import Config  # noqa: E402
 
@@ -18,19 +19,20 @@ g = torch.Generator().manual_seed(0)
 def run(name, make, step_fn, steps=3):
     out = {}
     for backend in ("hip", "torch"):
-        torch.manual_seed(0)
-        p = make(backend).to(dev).train()
-        opt = torch.optim.AdamW(p.parameters(), lr=1e-4, fused=True)
-        scaler = torch.amp.GradScaler("cuda")
-        losses = []
-        for _ in range(steps):
-            with torch.autocast("cuda", dtype=torch.float16):
-                loss = step_fn(p)
-            scaler.scale(loss).backward()
-            scaler.step(opt); scaler.update(); opt.zero_grad(set_to_none=True)
-            losses.append(float(loss))
-        assert all(l == l and abs(l) < 1e4 for l in losses), (name, backend, losses)
-        out[backend] = (losses, p)
+        with nn_ref.implementation(backend):
+            torch.manual_seed(0)
+            p = make(backend).to(dev).train()
+            opt = torch.optim.AdamW(p.parameters(), lr=1e-4, fused=True)
+            scaler = torch.amp.GradScaler("cuda")
+            losses = []
+            for _ in range(steps):
+                with torch.autocast("cuda", dtype=torch.float16):
+                    loss = step_fn(p)
+                scaler.scale(loss).backward()
+                scaler.step(opt); scaler.update(); opt.zero_grad(set_to_none=True)
+                losses.append(float(loss))
+            assert all(l == l and abs(l) < 1e4 for l in losses), (name, backend, losses)
+            out[backend] = (losses, p)
     print(name, "hip", [round(l, 4) for l in out["hip"][0]], "torch", [round(l, 4) for l in out["torch"][0]], flush=True)
     for a, c in zip(out["hip"][0], out["torch"][0]):      # the trajectories must agree step by step (stale weights, a wrong gradient ... show here)
         assert abs(a - c) <= 5e-3 * max(1.0, abs(c)), (name, out["hip"][0], out["torch"][0])
@@ -47,11 +49,11 @@ batch["attention_mask"][::3, 400:] = 0
 mlm_labels = torch.randint(0, 31090, (B, 77), generator=g).to(dev)
 
 # 1. RCR: --mlm --mlm_layer mlp --mlm_lambda 0.1
-run("RCR mlm", lambda be: train.Predictor(Config(**enc), Config(**dec), mlm=True, mlm_layer="mlp", mlm_lambda=0.1, backend=be),
+run("RCR mlm", lambda be: train.Predictor(Config(**enc), Config(**dec), mlm=True, mlm_layer="mlp", mlm_lambda=0.1),
     lambda p: p.training_step(batch, {"mlm_labels": mlm_labels})[0])
 
 # 2. RetroSyn template-free + validation + test step (beam 20 in the script; 5 here, short)
-res = run("RetroSyn tf", lambda be: train.Predictor(Config(**enc), Config(**dec), mlm=False, backend=be), lambda p: p.training_step(batch)[0])
+res = run("RetroSyn tf", lambda be: train.Predictor(Config(**enc), Config(**dec), mlm=False), lambda p: p.training_step(batch)[0])
 p = res["hip"][1].eval()
 small = {k: v[:4] for k, v in batch.items()}
 with torch.autocast("cuda", dtype=torch.float16):
@@ -67,6 +69,6 @@ tb = {"input_ids": batch["input_ids"], "attention_mask": batch["attention_mask"]
       "decoder_atom_template_labels": torch.randint(0, 157, (B, n_atoms), generator=g).to(dev),
       "decoder_bond_template_labels": torch.randint(0, 500, (B, n_atoms, n_atoms), generator=g).to(dev)}
 tb["decoder_bond_template_labels"][:, :, 20:] = -100
-run("RetroSyn tb", lambda be: template.TemplateBasedModel(Config(**enc), 156, 499, backend=be),
+run("RetroSyn tb", lambda be: template.TemplateBasedModel(Config(**enc), 156, 499),
     lambda m: template.template_loss(m(**{k: tb[k] for k in ("input_ids", "attention_mask", "atom_indices")})[0], tb))
 print("soak ok")
