@@ -13,7 +13,14 @@ bf16) and resident in HBM before the timed region.  `value` = queries / second o
 Also reported on the same JSON line:
   roofline     -- the scan kernel (knn_scan_kernel) against the dense bf16 MFMA peak: algorithmic
                   FLOPs 2*Q*N_local*d per launch / mean launch duration from HIP events recorded
-                  around the launch on its own stream inside libtrxknn.so (trx_search_stats.scan_ms)
+                  around the launch on its own stream inside libtrxknn.so (trx_search_stats.scan_ms);
+                  hbm_frac = the algorithmic bytes 2(N d + Q d) + 8 Q k of the same launch against
+                  8 TB/s (SURVEY 8d: "report both fractions"; the contraction is not HBM-bound);
+                  traffic = L2-miss bytes per launch from the committed PMC passes, with the
+                  commit they were taken at (traffic_source)
+  ms_per_step  -- wall clock over the K timed steps (the contract); ms_per_step_median = median of
+                  >= 10 steps each timed with HIP events on the stream the kernels run on;
+                  ms_per_step_with_d2h = the same step plus the copy of D and I to pinned host memory
   cpu_baseline -- the oracle's FAISS restatement (host BLAS sgemm blocks + heap) timed on this
                   host's cores on a bounded query sample of the same workload (rank 0, N = 1 only)
 """
@@ -198,7 +205,10 @@ def main():
     if args.workload == "fingerprint":
         return fingerprint_workload(args, dev, local_rank)
     lo, hi = (0, n) if args.replicas else shard_bounds(n, world, rank)
-    shard = make_rows(hi - lo, d, 1234, dev, row0=lo)
+    if args.weak and not args.replicas:      # "8 shards x 1,000,000, shard s uses seed 1234 + s"
+        shard = make_rows(hi - lo, d, 1234 + rank, dev)
+    else:
+        shard = make_rows(hi - lo, d, 1234, dev, row0=lo)
     queries = make_rows(nq, d, 5678, dev)
     if args.replicas:
         qlo, qhi = shard_bounds(nq, world, rank)
@@ -221,14 +231,38 @@ def main():
     for _ in range(args.warmup):
         D, I = index.search(queries, k)
     scan_ms, launches, uncert = 0.0, 0, 0
+    # per-step HIP events on torch's current stream = the stream the library launches on (faiss_compat passes it through
+    # the C ABI): recording them costs nothing inside the timed region
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(max(args.steps, 10))]
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        ev[i][0].record()
         D, I = index.search(queries, k)
+        ev[i][1].record()
         st = local.last_stats()
         scan_ms += st["scan_ms"]; launches += st["scan_launches"]; uncert += st["n_uncertified"]
     sync()
     t1 = time.perf_counter()
+    # "median of >= 10 iterations, hipEvent timing; a second number includes D2H of I".  Outside the region
+    # the contract times: more event-timed steps up to 10 samples, then three steps that also copy D and I to the host.
+    for i in range(args.steps, len(ev)):
+        ev[i][0].record()
+        index.search(queries, k)
+        ev[i][1].record()
+    sync()
+    step_ms = sorted(a.elapsed_time(b) for a, b in ev)
+    D_host = torch.empty(D.shape, dtype=D.dtype).pin_memory()
+    I_host = torch.empty(I.shape, dtype=I.dtype).pin_memory()
+    d2h_ms = []
+    for _ in range(3):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        Dd, Id = index.search(queries, k)
+        D_host.copy_(Dd, non_blocking=True); I_host.copy_(Id, non_blocking=True)
+        b.record(); b.synchronize()
+        d2h_ms.append(a.elapsed_time(b))
+    sync()
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
@@ -240,16 +274,25 @@ def main():
         flops_launch = 2.0 * queries.shape[0] * (hi - lo) * d        # algorithmic: 2*Q_local*N_local*d per scan launch
         mean_launch_ms = scan_ms / max(launches, 1)
         achieved = flops_launch / (mean_launch_ms * 1e-3) / 1e12 if mean_launch_ms > 0 else 0.0
-        traffic = None
+        alg_bytes = 2.0 * ((hi - lo) * d + queries.shape[0] * d) + 8.0 * queries.shape[0] * k
+        hbm_gbs = alg_bytes / (mean_launch_ms * 1e-3) / 1e9 if mean_launch_ms > 0 else 0.0
+        traffic, traffic_source = None, None
         tf = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tf) and world == 1 and n == N_CORPUS and nq == N_QUERIES:   # measured for exactly this launch
             try:
-                traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+                tj = json.load(open(tf))
+                traffic = tj.get("hbm_bytes_per_launch")
+                # a constant from separate --pmc passes (profiles/run_profile.sh): say which commit it was taken at, and
+                # at what launch time, so that a stale one shows
+                traffic_source = "profiles/traffic.json@%s (kernel trace %.2f ms per launch there)" % (
+                    tj.get("git_sha", "unknown"), tj.get("avg_launch_ms_kernel_trace") or float("nan"))
             except Exception:
                 traffic = None
         line = {
             "metric": "queries/sec top-10 over 1Mx768 corpus", "value": value, "unit": "queries/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
+            "ms_per_step_median": step_ms[len(step_ms) // 2], "ms_per_step_min": step_ms[0], "timed_steps_for_median": len(step_ms),
+            "ms_per_step_with_d2h": sorted(d2h_ms)[1],
             "higher_is_better": True, "scaling": "weak" if args.weak else "strong", "vs_baseline": None, "dtype": "bf16",
             "data": "synthetic",
             "config": {"workload": ("exact IP top-%d, %dx%d bf16 corpus replicated on %d GPUs, %d queries per step split over them"
@@ -258,11 +301,16 @@ def main():
                        "corpus_rows": n, "dim": d, "queries": nq, "k": k,
                        "parallelism": ("query-sharded replicas x%d (whole corpus per GPU, no collective)" % world if args.replicas else
                                        "corpus row-sharded x%d + RCCL all-gather merge" % world) if world > 1 else "single GPU",
+                       "transport": ("RCCL (nccl backend), one GPU per rank" if backend == "nccl" else
+                                     "REHEARSAL: %d ranks share GPU %d, %s backend (host round trip in the all-gather); not a scaling measurement"
+                                     % (world, local_rank, backend)) if world > 1 else None,
                        "uncertified_queries_per_step": uncert / args.steps},
             "roofline": {"bound": "mfma", "kernel": "knn_scan_kernel", "achieved": achieved,
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
-                         "traffic": traffic, "launch_ms": mean_launch_ms,
-                         "flops_per_launch": flops_launch},
+                         "traffic": traffic, "traffic_source": traffic_source, "launch_ms": mean_launch_ms,
+                         "flops_per_launch": flops_launch,
+                         "hbm_frac": hbm_gbs / 8000.0, "hbm_achieved_GBps": hbm_gbs, "hbm_peak_GBps": 8000.0,
+                         "algorithmic_bytes_per_launch": alg_bytes},
         }
         if world == 1 and not args.no_cpu_baseline:
             base, I_cpu = cpu_baseline(shard, queries, k)

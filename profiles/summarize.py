@@ -39,7 +39,13 @@ fetch, _ = counters("pmc_fetch")
 write, _ = counters("pmc_write")
 sq, _ = counters("pmc_sq")
 fetch_kb, write_kb = fetch.get("FETCH_SIZE"), write.get("WRITE_SIZE")
+try:
+    import subprocess
+    sha = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"]).decode().strip()
+except Exception:
+    sha = "unknown"
 out = {
+    "git_sha": sha,
     "command": "python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline (profiles/run_profile.sh %s: one rocprofv3 pass for "
                "--kernel-trace --stats, one --pmc pass per counter group)" % tag,
     "kernel": kname, "avg_launch_ms_kernel_trace": avg_ms, "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb,

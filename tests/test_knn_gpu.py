@@ -126,6 +126,21 @@ def test_adversarial_order_over_long_splits(k, monkeypatch):
     _check(L2, x, y2, k)
 
 
+@pytest.mark.parametrize("n", [5000 + 37, 150_000 + 201])
+def test_pad_rows_of_an_inner_product_index_never_count(n, monkeypatch):
+    """inner product, NEGATIVE small-integer scores rising with the row id, n % 256 != 0: the zero pad rows of the last
+    tile score 0, above every real row, and the lists are full when the last tile arrives (adversarial order), so the
+    compaction sees them.  Exact-class inputs: no certificate stands behind the answer."""
+    monkeypatch.setenv("TRX_NSPLITS", "4")
+    rng = np.random.default_rng(23)
+    d = 64
+    x = np.zeros((300, d), dtype=np.float32); x[:, :8] = rng.integers(1, 4, (300, 8))
+    # corpus row i: -(a few units) on the first 8 components, magnitude falling with i -> x . y negative, rising with i
+    mag = np.linspace(9.0, 1.0, n).astype(np.int64)[:, None]
+    y = np.zeros((n, d), dtype=np.float32); y[:, :8] = -(mag + rng.integers(0, 2, (n, 8)))
+    _check(IP, x, y, 10, expect_exact_class=True)
+
+
 def test_add_in_chunks_and_mode_transition():
     y = np.concatenate([bf16_round(gaussian(3000, 64, 1)), gaussian(2000, 64, 2)])  # exact block, then fp32 block
     _check(IP, gaussian(100, 64, 3), y, 10, chunks=5)

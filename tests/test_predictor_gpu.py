@@ -96,21 +96,34 @@ def test_model_logits_match_reference_golden_on_gpu():
     assert float((encs.cpu() - torch.from_numpy(z["encoder_last_hidden_state"])).abs().max()) <= 1e-3
 
 
-def test_full_size_model_hip_vs_torch_reference():
-    # scripts' shapes: BERT-base encoder (SciBERT vocab 31090), bert_l6.json decoder, L = 512, T = 7
-    enc = Config(vocab_size=31090)
-    dec = Config(vocab_size=600, num_hidden_layers=6, type_vocab_size=1, layer_norm_eps=1e-5, is_decoder=True)
-    m = TextReactModel(enc, dec)
-    m.load_state_dict(random_state_dict(m, 7))
-    m = m.cuda().eval()
-    g = torch.Generator().manual_seed(1)
-    ids = torch.randint(1, 31090, (4, 512), generator=g).cuda(); am = torch.ones(4, 512, dtype=torch.long).cuda(); am[1, 300:] = 0
-    dids = torch.randint(14, 600, (4, 7), generator=g).cuda()
+def _full_size_case(T, device):
+    """the model and inputs tests/golden/predictor_full.npz was generated with (make_predictor_golden.py: main_full)"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from make_predictor_golden import full_inputs
+    z = np.load(os.path.join(os.path.dirname(G), "predictor_full.npz"))
+    enc, dec = json.loads(str(z["enc_cfg"])), json.loads(str(z["dec_cfg"]))
+    m = TextReactModel(Config(**enc), Config(is_decoder=True, **dec))
+    m.load_state_dict(random_state_dict(m, int(z["seed"])))
+    return z, m.to(device).eval(), [t.to(device) for t in full_inputs(T)]
+
+
+@pytest.mark.parametrize("T", [7, 160])
+def test_full_size_model_matches_the_reference_golden(T):
+    """scripts' shapes -- BERT-base encoder (SciBERT vocabulary), the bert_l6.json decoder, L = 512, T = 7 (RCR) and
+    160 (RetroSyn) -- through the HIP fp32 path against logits of the REFERENCE's own get_model (the full-size
+    golden): <= 1e-3, the north-star tolerance"""
+    z, m, (ids, am, dids) = _full_size_case(T, "cuda")
     with torch.no_grad():
-        a, _ = m(ids, am, dids)
-        with nn_ref.reference_ops():
-            b, _ = m(ids, am, dids)
-    assert float((a - b).abs().max()) <= 1e-3
+        logits, enc = m(ids, am, dids)
+    logits, enc = logits.cpu().numpy(), enc.cpu().numpy()
+    if T == 7:
+        assert np.abs(logits - z["logits_T7"]).max() <= 1e-3
+        pos = z["enc_pos"]
+        assert np.abs(enc[pos[:, 0], pos[:, 1]] - z["enc_at"]).max() <= 1e-3
+    else:
+        pos = z["logits_pos_T160"]
+        assert np.abs(logits[pos[:, 0], pos[:, 1]] - z["logits_at_T160"]).max() <= 1e-3
 
 
 @pytest.mark.parametrize("B,H,Lq,Lk,mask,causal", [

@@ -178,12 +178,18 @@ __device__ __forceinline__ void store_masked(u64 mask, u64* p, u64 v) {
 }
 
 // A list (`cap` valid entries, all written by ONE lane of this wave) is cut to its kprime best by (key desc, id asc).
-// Wave-wide; rare (see the header).  Returns the packed value in kprime-th place.
-__device__ __forceinline__ u64 compact_list(u64* list, int cap, int kprime, int lane) {
+// Wave-wide; rare (see the header).  Returns the packed value in kprime-th place (0 = fewer than kprime rows were
+// listed: nothing was dropped, the list gets no floor).  Entries with id >= n_valid are the pad rows of an
+// inner-product index's last tile (score 0, above every row when the real scores are negative): they are not rows --
+// they are dropped here, so that they can neither crowd real rows out of the kprime kept nor become the floor.
+__device__ __forceinline__ u64 compact_list(u64* list, int cap, int kprime, int lane, u32 n_valid) {
     __builtin_amdgcn_s_waitcnt(0);     // this wave's own stores to the list have left
     u64 e[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) e[i] = (lane + 64 * i) < cap ? ld_u64_l2(list + lane + 64 * i) : 0ull;   // L2: never a stale L1 line
+    for (int i = 0; i < 2; ++i) {
+        e[i] = (lane + 64 * i) < cap ? ld_u64_l2(list + lane + 64 * i) : 0ull;   // L2: never a stale L1 line
+        if (comp_id(e[i]) >= n_valid) e[i] = 0ull;
+    }
     u64 out = 0ull, last = 0ull;
     for (int t = 0; t < kprime; ++t) {
         u64 m = e[0] > e[1] ? e[0] : e[1];
@@ -452,14 +458,14 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
                         const int64_t li = li0 + nt * colstride;
                         const int64_t lsel = (int64_t)shfl_u64((u64)li, l);
                         const int ncur = (int)__shfl((int)((cnt4 >> (8 * nt)) & 0x7fu), l, 64);
-                        const u64 floor_c = compact_list(p.cand + lsel * p.cap_alloc, ncur, p.kprime, lane);
+                        const u64 floor_c = compact_list(p.cand + lsel * p.cap_alloc, ncur, p.kprime, lane, (u32)p.n_valid);
 #ifdef TRX_STAMP_BUILD
                         ++st_comp;
 #endif
                         if (lane == l) {
                             cnt4 = (cnt4 & ~(0xffu << (8 * nt))) | ((u32)(p.kprime | 0x80) << (8 * nt));
                             p.cand_thr[li] = floor_c;
-                            thrk[nt] = __builtin_fmaxf(thrk[nt], KI * comp_key(floor_c));
+                            if (floor_c) thrk[nt] = __builtin_fmaxf(thrk[nt], KI * comp_key(floor_c));
                         }
                     }
                 }

@@ -328,14 +328,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const int ksrc = (lane & 32) + (p.k <= 32 ? p.k - 1 : 31);
         const double s_k = __shfl(ssc, ksrc, 64);          // exact score in k-th place
         const double xx0 = __shfl(xx, lane & 32, 64);      // the first candidate's lane has walked the whole query row
-        if (!p.exact_class && tau != 0ull) {
-            if (nranked < p.k) {
-                certified = false;  // fewer ranked candidates than k although rows were dropped
-            } else {
-                const float tau_key = comp_key(tau);
-                const double bound = (double)tau_key + eps;  // upper bound of an outsider's exact key
-                certified = L2 ? (xx0 - s_k) > bound : s_k > bound;   // L2: key = |x|^2 - dist
-            }
+        if (tau != 0ull && nranked < p.k) {
+            certified = false;      // fewer ranked candidates than k although rows were dropped: exact inputs or not, redo it
+        } else if (!p.exact_class && tau != 0ull) {
+            const float tau_key = comp_key(tau);
+            const double bound = (double)tau_key + eps;  // upper bound of an outsider's exact key
+            certified = L2 ? (xx0 - s_k) > bound : s_k > bound;   // L2: key = |x|^2 - dist
         }
     }
 

@@ -31,10 +31,16 @@ class DenseEncoder(nn.Module):
     TextReactModel, so a predictor checkpoint's encoder or a Tevatron `model.lm_q` / `lm_p`
     state dict loads with the prefix renamed."""
 
-    def __init__(self, cfg, normalize=False):
+    def __init__(self, cfg, normalize=False, encoder=None):
         super().__init__()
-        self.encoder = BertEncoder(cfg)
+        self.encoder = encoder if encoder is not None else BertEncoder(cfg)
         self.normalize = normalize
+
+    @classmethod
+    def wrap(cls, encoder, normalize=False):
+        """[CLS] pooling over an EXISTING encoder module (the predictor's own, textreact_amd.live): no parameter is copied,
+        the embeddings follow the weights as they train"""
+        return cls(None, normalize=normalize, encoder=encoder)
 
     def forward(self, input_ids, attention_mask=None):
         if attention_mask is None:

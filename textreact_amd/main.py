@@ -22,6 +22,16 @@ hands the model anyway:
         [n_atoms, n_atoms] (-100 = no bond), bonds [[i, j], ...] and decoder_raw_template_labels -- what
         dataset.py's collator pads into a batch (labels with -100)
 
+    --live_every N, --live_corpus FILE [--live_k K] [--live_retriever FILE]   on-the-fly retrieval (BASELINE.json
+        configs[4]; textreact_amd/live.py): every N epochs the corpus passages (token ids in FILE) are re-embedded with the
+        retriever's current weights, row-sharded over the ranks, and every training query's neighbours are searched
+        again on the GPUs; each epoch the encoder inputs are assembled on the device from `query_ids` / `query_len` /
+        `gold_passage` of the tensor files following the reference's dataset options (--num_neighbors,
+        --use_gold_neighbor, --max_num_neighbors, --random_neighbor_ratio, --max_length, --mlm / --mlm_ratio); validation
+        and test inputs likewise (second loader: gold text removed).  The retriever is the predictor's own encoder
+        ([CLS] embedding) unless --live_retriever names a state dict (`lm_q.*` / `lm_p.*` as Tevatron saves its
+        bi-encoder, or `encoder.*` for a tied one).  The reference itself reads static neighbor files (main.py:311-323).
+
 The data flags of the reference are accepted and ignored with a note.  One process per GPU: launch with
 `python -m torch.distributed.run --nproc-per-node G -m textreact_amd.main ...` (backend nccl = RCCL); `--gpus` is
 checked against WORLD_SIZE.
@@ -117,6 +127,10 @@ def get_parser():
     p.add_argument('--tok_pad_id', type=int, default=0)
     p.add_argument('--tok_atom_templates', type=int, default=None)
     p.add_argument('--tok_bond_templates', type=int, default=None)
+    p.add_argument('--live_every', type=int, default=0, help="re-embed the corpus and re-retrieve every N epochs (0 = off)")
+    p.add_argument('--live_corpus', type=str, default=None, help="pre-tokenised corpus passages (textreact_amd/live.py)")
+    p.add_argument('--live_k', type=int, default=None, help="neighbours retrieved per query (default 2 x --max_num_neighbors)")
+    p.add_argument('--live_retriever', type=str, default=None, help="state dict of a separate bi-encoder retriever")
     return p
 
 
@@ -167,7 +181,10 @@ class TensorSplit:
         self.tensors = {k: d[k] for k in self.IN_KEYS if k in d}
         self.ragged = {k: d[k] for k in self.PADDED + self.LISTS if k in d}
         self.mlm_labels = d.get("mlm_labels")
-        assert "input_ids" in self.tensors and len(self.indices) == self.tensors["input_ids"].shape[0], path
+        # on-the-fly retrieval: the query tokens alone, and the row of the sample's own passage in the corpus
+        self.live = {k: d[k] for k in ("query_ids", "query_len", "gold_passage") if k in d}
+        first = self.tensors.get("input_ids", self.live.get("query_ids"))
+        assert first is not None and len(self.indices) == first.shape[0], path
         assert all(len(v) == len(self.indices) for v in self.ragged.values()), path
 
     def __len__(self):
@@ -198,6 +215,13 @@ class TensorSplit:
         batch_out = {"mlm_labels": self.mlm_labels[st].to(device)} if self.mlm_labels is not None else {}
         return batch_in, batch_out
 
+    def with_inputs(self, input_ids, attention_mask):
+        """this split with other encoder inputs (assembled by the on-the-fly retrieval)"""
+        import copy
+        other = copy.copy(self)
+        other.tensors = dict(self.tensors, input_ids=input_ids, attention_mask=attention_mask)
+        return other
+
     def batches(self, batch_size, rank=0, world=1, device="cpu", limit=None):
         n = len(self) if limit is None else min(limit, len(self))
         order = list(range(rank, n, world))             # DistributedSampler(shuffle=False) of Lightning's eval loaders
@@ -225,6 +249,77 @@ def _load_splits(spec, name):
     return [TensorSplit(f, name) for f in spec.split(",")] if spec else []
 
 
+class LiveData:
+    """--live_every: the retriever, the neighbour ids of every split, and the per-epoch assembly of encoder inputs on the
+    device (textreact_amd/live.py restates the reference's dataset logic on tensors)."""
+
+    def __init__(self, args, module, enc_cfg, device, rank, world):
+        from . import dense, live
+        self.args, self.live, self.device, self.rank, self.world = args, live, device, rank, world
+        if not args.live_corpus:
+            raise SystemExit("--live_every needs --live_corpus (pre-tokenised passages, see textreact_amd/live.py)")
+        self.corpus = live.LiveCorpus(args.live_corpus, device)
+        own = dense.DenseEncoder.wrap(module.model.encoder)       # the predictor's own encoder, current weights
+        self.q_enc = self.p_enc = own
+        if args.live_retriever:
+            sd = torch.load(args.live_retriever, map_location="cpu", weights_only=False)
+            sd = sd.get("state_dict", sd)
+            encs = []
+            for prefix in ("lm_q.", "lm_p."):
+                part = {"encoder." + k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+                part = part or {k: v for k, v in sd.items() if k.startswith("encoder.")}
+                e = dense.DenseEncoder(enc_cfg).to(device).eval()
+                e.load_state_dict(part, strict=False)
+                encs.append(e)
+            self.q_enc, self.p_enc = encs
+        self.k = args.live_k or 2 * max(args.max_num_neighbors, args.num_neighbors)
+        self.retriever = live.LiveRetriever(self.corpus, rank, world, batch_size=max(64, args.test_batch_size))
+        self.nn = {}                                                # split name -> [N, k] neighbour rows, on the device
+        self.gen = torch.Generator().manual_seed(args.seed + 7919 * (rank + 1))
+
+    def refresh(self, splits):
+        """re-embed the passages with the retriever's current weights and search every query of `splits` again"""
+        self.retriever.refresh_index(self.p_enc)
+        for ds in splits:
+            assert "query_ids" in ds.live, "--live_every: %s has no query_ids / query_len" % ds.name
+            self.nn[id(ds)] = self.retriever.neighbors(self.q_enc, ds.live["query_ids"], ds.live["query_len"], self.k)
+
+    def inputs(self, ds, rows, train, skip_gold=False):
+        """encoder inputs of the samples `rows` of `ds` for one pass: (input_ids, attention_mask, lengths, position_ids,
+        mlm_labels); the last two only for a training pass with --mlm.  In blocks of 32,768 samples."""
+        a, live, dev = self.args, self.live, self.device
+        rows_t = torch.as_tensor(rows, dtype=torch.long)
+        outs = []
+        for b0 in range(0, len(rows), 32768):
+            r = rows_t[b0:b0 + 32768]
+            gold = ds.live["gold_passage"][r].to(dev) if "gold_passage" in ds.live else None
+            sel = live.select_neighbors(self.nn[id(ds)][r.to(dev)], gold, self.corpus, train, a.use_gold_neighbor, a.max_num_neighbors,
+                                        a.num_neighbors, a.random_neighbor_ratio, skip_gold, self.gen)
+            ids, mask, lens = live.assemble_inputs(ds.live["query_ids"][r], ds.live["query_len"][r], sel, self.corpus, a.max_length,
+                                                   with_neighbors=a.num_neighbors > 0)
+            pos = labels = None
+            if train and a.mlm:
+                ids, pos, labels = live.apply_mlm(ids, lens, a.mlm_ratio, self.corpus.mask_id, self.gen)
+            outs.append((ids, mask, lens, pos, labels))
+        width = max(o[0].shape[1] for o in outs)
+        trunc = max((o[4].shape[1] for o in outs if o[4] is not None), default=0)
+
+        def cat(i, fill, w):
+            if outs[0][i] is None:
+                return None
+            return torch.cat([torch.nn.functional.pad(o[i], (0, w - o[i].shape[1]), value=fill) for o in outs])
+        return (cat(0, self.corpus.pad_id, width), cat(1, 0, width), torch.cat([o[2] for o in outs]), cat(3, 0, width), cat(4, -100, trunc))
+
+    def eval_views(self, sets):
+        """the reference's two evaluation loaders (main.py:336-340): neighbours as retrieved, and with the gold text removed"""
+        out = []
+        for ds in sets[:1]:
+            for skip in (False, True):
+                ids, mask, _, _, _ = self.inputs(ds, list(range(len(ds))), train=False, skip_gold=skip)
+                out.append(ds.with_inputs(ids, mask))
+        return out
+
+
 def _autocast(args, device):
     prec = str(args.precision)
     if prec.startswith("16"):
@@ -244,13 +339,16 @@ def main(argv=None):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     cuda = torch.cuda.is_available()
+    # TRX_DIST_BACKEND=gloo TRX_DEVICE=0: several ranks share one GPU to rehearse the N > 1 path on a one-GPU box (RCCL
+    # refuses two ranks on one device); the real run is nccl = RCCL, one GPU per rank
+    local_rank = int(os.environ.get("TRX_DEVICE", local_rank))
     device = torch.device("cuda", local_rank) if cuda else torch.device("cpu")
     ops.require_device(device)        # the attention / add+LayerNorm ops exist as HIP kernels only: no GPU, no trainer
     if cuda:
         torch.cuda.set_device(local_rank)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl" if cuda else "gloo")
+        dist.init_process_group(os.environ.get("TRX_DIST_BACKEND", "nccl" if cuda else "gloo"))
     if args.gpus != world and rank == 0:
         print("note: --gpus %d, WORLD_SIZE %d (one process per GPU: launch with torch.distributed.run)" % (args.gpus, world),
               file=sys.stderr)
@@ -274,12 +372,17 @@ def main(argv=None):
     test_sets = _load_splits(args.tensors_test, "test") if args.do_test else []
     os.makedirs(args.save_path, exist_ok=True)
     best_path, last_path = os.path.join(args.save_path, "best.ckpt"), os.path.join(args.save_path, "last.ckpt")
+    live = None
+    if args.live_every > 0:
+        if args.template_based:
+            raise SystemExit("--live_every drives the template-free predictor (train_RetroSyn_tf.sh / train_RCR.sh)")
+        live = LiveData(args, module, enc_cfg, device, rank, world)
 
     def validate(mod):
         """main.py:177-196: per-sample scores of every dataloader, gathered, averaged; the first one is the monitor"""
         mod.eval()
         out = {}
-        for di, ds in enumerate(val_sets):
+        for di, ds in enumerate(live.eval_views(val_sets) if live else val_sets):
             scores = {}
             for indices, batch_in, _ in ds.batches(args.batch_size, rank, world, device):
                 with _autocast(args, device):
@@ -321,12 +424,27 @@ def main(argv=None):
         # bound, so one collective instead of DDP's 25 MB buckets costs nothing and needs no forward() wrapper)
         scaler = torch.amp.GradScaler(enabled=cuda and str(args.precision).startswith("16"))
         for epoch in range(start_epoch, args.epochs):
-            module.train()
             mine = epoch_shard(n_train, args.seed, epoch, rank, world)
+            if live:
+                if epoch == start_epoch or (epoch - start_epoch) % args.live_every == 0:
+                    live.refresh([train] + val_sets[:1])          # passages re-embedded, every query searched again
+                    if rank == 0:
+                        print("epoch %d: neighbours refreshed (%d passages, k = %d)" % (epoch, len(live.corpus), live.k))
+                ep_ids, ep_mask, ep_len, ep_pos, ep_mlm = live.inputs(train, mine, train=True)
+                ep_len_h = ep_len.cpu()
+                ep_cnt_h = (ep_mlm != -100).sum(dim=1).cpu() if ep_mlm is not None else None
+            module.train()
             micro = 0
             opt.zero_grad(set_to_none=True)
             for b0 in range(0, len(mine), args.batch_size):
                 batch_in, batch_out = train.collate(mine[b0:b0 + args.batch_size], device)
+                if live:        # this epoch's encoder inputs, assembled on the device from the refreshed neighbours
+                    sl = slice(b0, b0 + args.batch_size)
+                    w = int(ep_len_h[sl].max())
+                    batch_in["input_ids"], batch_in["attention_mask"] = ep_ids[sl, :w], ep_mask[sl, :w]
+                    if ep_mlm is not None:
+                        batch_in["position_ids"] = ep_pos[sl, :w]
+                        batch_out = {"mlm_labels": ep_mlm[sl, :max(1, int(ep_cnt_h[sl].max()))]}
                 with _autocast(args, device):
                     total, logs = module.training_step(batch_in, batch_out)
                 (scaler.scale(total / args.gradient_accumulation_steps)).backward()
@@ -338,7 +456,10 @@ def main(argv=None):
                                 p_.grad = torch.zeros_like(p_)
                         grads = [p.grad for p in module.parameters() if p.grad is not None]
                         flat = torch.cat([gr.reshape(-1) for gr in grads])
-                        dist.all_reduce(flat)
+                        if flat.is_cuda and dist.get_backend() == "gloo":      # one-GPU rehearsal (TRX_DIST_BACKEND): through the host
+                            host = flat.cpu(); dist.all_reduce(host); flat.copy_(host)
+                        else:
+                            dist.all_reduce(flat)
                         flat /= world
                         off = 0
                         for gr in grads:
@@ -375,13 +496,15 @@ def main(argv=None):
         if rank == 0:
             print("Load model checkpoint:", best_model_path)
         T.load_checkpoint(best_model_path, module, strict=False)                          # main.py:404
+    if live and (args.do_valid or args.do_test):      # the checkpoint just loaded is the retriever now
+        live.refresh((val_sets[:1] if args.do_valid else []) + (test_sets[:1] if args.do_test else []))
     if args.do_valid and val_sets:
         metrics = validate(module)
         if rank == 0:
             print(json.dumps(metrics))
     if args.do_test:
         module.eval()
-        for di, ds in enumerate(test_sets):
+        for di, ds in enumerate(live.eval_views(test_sets) if live else test_sets):
             outputs = {}
             for indices, batch_in, _ in ds.batches(args.test_batch_size, rank, world, device):
                 with _autocast(args, device), torch.no_grad():
