@@ -12,13 +12,21 @@
  * (streams travel as void*).  Functions return 0 on success or a negative TRX_E* code and never
  * throw; trx_last_error() gives the message for the calling thread.
  *
- * Threading: thread-compatible -- one index per thread at a time.  EVERY call blocks the host until
- * its result is complete.  The *_device variants take their inputs and outputs in device memory and
- * run their kernels on the caller's `stream` (so they order against the caller's other work on that
- * stream), but they are not asynchronous: trx_index_add_device synchronises the stream before it
- * returns (the caller may free x), and a search synchronises it once per batch of 65,536 queries to
- * read back how many queries failed the exactness certificate (csrc/knn_api.hip: search_batch).  On
- * return the outputs are final; no further stream synchronisation is needed to read them.
+ * Threading: thread-compatible -- one index per thread at a time.  The *_device variants take their
+ * inputs and outputs in device memory and run their kernels on the caller's `stream` (so they order
+ * against the caller's other work on that stream).  trx_index_add_device synchronises the stream
+ * before it returns (the caller may free x).  A search is stream-ordered work followed by ONE read-back:
+ * trx_index_search_device_begin enqueues everything -- query statistics, the exact-class decision (a
+ * device-side flag), scan, select and the exact re-scan of up to 4 queries per 65,536-query batch whose
+ * certificate failed (a device-side count decides) -- and returns without waiting for the GPU;
+ * trx_index_search_finish waits for the stream, reads the certificate counts back and, when more
+ * queries failed than the enqueued re-scan covers (near-duplicate clusters; never on the benchmark
+ * inputs), completes them.  Work the caller enqueues on the same stream between the two calls (the
+ * all-gather and merge of the row-sharded search) overlaps nothing of the search but costs no host
+ * round trip either; stats.late_fallback says whether it consumed outputs that finish then changed.
+ * trx_index_search_device / _s64 / trx_index_search are begin + finish: on return the outputs are
+ * final.  (One exception to "no wait in begin": fp32 queries against an index that so far holds only
+ * bf16-exact data read their statistics back, because inexact queries re-lay the index out.)
  *
  * Results (both metrics): neighbours are the k best by the total order
  *   (score best-first, then id ascending), score = fp64 fma chain over the d components,
@@ -92,6 +100,12 @@ int trx_index_search_device(trx_index* idx, const void* q, int64_t nq, int dtype
 int trx_index_search_device_s64(trx_index* idx, const void* q, int64_t nq, int dtype, int k, float* D,
                                 int64_t* I, double* S, void* stream);
 
+/* Stream-ordered form of the two calls above (S may be null): see Threading.  D, I, S are final only
+ * after trx_index_search_finish(idx) has returned 0.  One search per index may be in flight. */
+int trx_index_search_device_begin(trx_index* idx, const void* q, int64_t nq, int dtype, int k, float* D,
+                                  int64_t* I, double* S, void* stream);
+int trx_index_search_finish(trx_index* idx);
+
 /* Merge step of the row-sharded search: nlists result lists per query,
  * ids already global, DEVICE memory, layout S_lists/I_lists [nlists][nq][k] exactly as an
  * all-gather of per-shard (S, I) leaves them (nlists <= 16).  Same total order as a single
@@ -110,12 +124,16 @@ typedef struct trx_search_stats {
     int32_t scan_launches; /* scan-kernel launches in the call */
     float scan_ms;         /* HIP-event time of the scan kernel(s), valid when timing is enabled */
     float total_ms;        /* HIP-event time of the whole call on its stream, ditto */
+    int32_t late_fallback; /* 1 = trx_index_search_finish re-did queries AFTER the enqueued work (more
+                              certificate failures than the inline re-scan covers): anything the caller
+                              computed from D / I / S between begin and finish must be redone */
+    int32_t reserved_;
 } trx_search_stats;
 
 int trx_index_last_stats(const trx_index* idx, trx_search_stats* out);
 
 /* Enable (1) / disable (0) HIP-event timing of the scan kernel inside search calls.  Timing makes
- * the call synchronise at its end; leave it off for overlapped pipelines. */
+ * begin synchronise after every batch; leave it off for overlapped pipelines. */
 int trx_index_set_timing(trx_index* idx, int enabled);
 
 /* Message of the last error on this thread ("" if none). */

@@ -16,7 +16,8 @@ MAX_K, FAST_MAX_K = 2048, 24
 SYMBOLS = [
     "trx_index_create", "trx_index_add", "trx_index_add_device", "trx_index_ntotal", "trx_index_dim",
     "trx_index_reset", "trx_index_destroy", "trx_index_search", "trx_index_search_device",
-    "trx_index_search_device_s64", "trx_merge_topk_device", "trx_index_last_stats",
+    "trx_index_search_device_s64", "trx_index_search_device_begin", "trx_index_search_finish",
+    "trx_merge_topk_device", "trx_index_last_stats",
     "trx_index_set_timing", "trx_last_error", "trx_version",
 ]
 
@@ -24,7 +25,8 @@ SYMBOLS = [
 class SearchStats(ctypes.Structure):
     _fields_ = [("nq", ctypes.c_int64), ("n_uncertified", ctypes.c_int64), ("k_split", ctypes.c_int32),
                 ("n_splits", ctypes.c_int32), ("exact_class", ctypes.c_int32), ("scan_launches", ctypes.c_int32),
-                ("scan_ms", ctypes.c_float), ("total_ms", ctypes.c_float)]
+                ("scan_ms", ctypes.c_float), ("total_ms", ctypes.c_float), ("late_fallback", ctypes.c_int32),
+                ("reserved_", ctypes.c_int32)]
 
 
 class TrxError(RuntimeError):
@@ -72,6 +74,8 @@ def lib():
     L.trx_index_search.argtypes = [vp, vp, i64, i32, i32, vp, vp]
     L.trx_index_search_device.argtypes = [vp, vp, i64, i32, i32, vp, vp, vp]
     L.trx_index_search_device_s64.argtypes = [vp, vp, i64, i32, i32, vp, vp, vp, vp]
+    L.trx_index_search_device_begin.argtypes = [vp, vp, i64, i32, i32, vp, vp, vp, vp]
+    L.trx_index_search_finish.argtypes = [vp]
     L.trx_merge_topk_device.argtypes = [i32, i32, i64, i32, vp, vp, vp, vp, vp]
     L.trx_index_last_stats.argtypes = [vp, ctypes.POINTER(SearchStats)]
     L.trx_index_set_timing.argtypes = [vp, i32]

@@ -18,8 +18,9 @@ hipError_t launch_row_stats(const void*, int, int64_t, int, int64_t, void*, floa
 hipError_t launch_build_operand(const void*, int, int, int64_t, int, int64_t, bf16_t*, int, hipStream_t);
 hipError_t launch_fill_bias(const float*, int64_t, int64_t, float*, hipStream_t);
 hipError_t launch_widen_rows(const bf16_t*, int64_t, int, int64_t, float*, hipStream_t);
-hipError_t launch_exact_scan(int, int, int, const int*, int, int64_t, const void*, int64_t, const void*,
+hipError_t launch_exact_scan(int, int, int, const int*, int, const int*, int64_t, const void*, int64_t, const void*,
                              int64_t, int, int, double*, float*, int64_t*, double*, hipStream_t);
+hipError_t launch_classify(const void*, int, int, float, int, int, int, int*, hipStream_t);
 hipError_t launch_merge(int, int, int64_t, int, const double*, const int64_t*, float*, int64_t*, hipStream_t);
 }  // namespace trx
 
@@ -68,10 +69,20 @@ struct trx_index {
     float maxabs = 0.f, maxnorm2 = 0.f;
     bool nonint = false;
     // workspaces
-    DevBuf w_stamp, w_stats, w_qg, w_qnorm2, w_cand, w_cnt, w_thr, w_flag, w_exact, w_io, w_tmp, w_gthr;
+    DevBuf w_stamp, w_stats, w_qg, w_qnorm2, w_cand, w_cnt, w_thr, w_flag, w_exact, w_io, w_tmp, w_gthr, w_cls;
     trx_search_stats stats{};
     bool timing = false;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    // a search that has been enqueued (trx_index_search_device_begin) and not yet finished: what
+    // trx_index_search_finish needs to read the certificate counts back and, rarely, complete the fall-back
+    struct PendingBatch { int* nflag; int* flagged; const void* q; float* D; int64_t* I; double* S64; };
+    struct Pending {
+        bool active = false;
+        hipStream_t st = nullptr;
+        int is_bf = 0, k = 0, corpus_is_bf16 = 0, no_fallback = 0;
+        const void* corpus_orig = nullptr; int64_t ld_c = 0;
+        std::vector<PendingBatch> batches;
+    } pend;
 
     // an even number of K-steps, at least 4: the scan kernel's loop handles two per iteration (LDS stage = K-step
     // parity) and treats the first and the last pair of a tile differently
@@ -159,7 +170,7 @@ void trx_index_destroy(trx_index* idx) {
     if (idx->cnorm2) (void)hipFree(idx->cnorm2);
     if (idx->cbias) (void)hipFree(idx->cbias);
     DevBuf* bufs[] = {&idx->w_stamp, &idx->w_stats, &idx->w_qg, &idx->w_qnorm2, &idx->w_cand, &idx->w_cnt, &idx->w_thr,
-                      &idx->w_flag, &idx->w_exact, &idx->w_io, &idx->w_tmp, &idx->w_gthr};
+                      &idx->w_flag, &idx->w_exact, &idx->w_io, &idx->w_tmp, &idx->w_gthr, &idx->w_cls};
     for (DevBuf* b : bufs) b->release();
     for (auto& e : idx->ev) if (e) (void)hipEventDestroy(e);
     delete idx;
@@ -265,7 +276,12 @@ int trx_index_add(trx_index* idx, const void* x, int64_t n, int dtype) {
 
 // ---- search --------------------------------------------------------------------------------
 
-static int search_batch(trx_index* idx, const void* q, const float* qnorm2, int64_t nq, int is_bf, int q_split, int exact_class,
+// certificate failures of a batch that are re-done by the exact scan inside the enqueued work (a device-side count
+// decides how many of these slots do anything); more than that -- near-duplicate clusters, adversarial data -- are
+// completed by trx_index_search_finish once the count has been read back
+constexpr int INLINE_FALLBACK = 4;
+
+static int search_batch(trx_index* idx, const void* q, const float* qnorm2, int64_t nq, int is_bf, int q_split, int batch_no,
                         float eps_rel, int k, float* D, int64_t* I, double* S64, hipStream_t st) {
     const int d = idx->d, Kp = idx->Kp;
     const int64_t q_pad = round_up64(nq, TILE_N);
@@ -295,7 +311,6 @@ static int search_batch(trx_index* idx, const void* q, const float* qnorm2, int6
     if ((rc = idx->w_cand.reserve((size_t)q_pad * nlists * cap_alloc * sizeof(u64)))) return rc;
     if ((rc = idx->w_cnt.reserve((size_t)q_pad * nlists * sizeof(u32)))) return rc;
     if ((rc = idx->w_thr.reserve((size_t)q_pad * nlists * sizeof(u64)))) return rc;
-    if ((rc = idx->w_flag.reserve((size_t)(nq + 4) * sizeof(int)))) return rc;
     if ((rc = idx->w_gthr.reserve((size_t)q_pad * 4 * sizeof(u32)))) return rc;
 
     // query operand + norms
@@ -303,7 +318,9 @@ static int search_batch(trx_index* idx, const void* q, const float* qnorm2, int6
         HIPCHK(hipMemsetAsync(idx->w_qg.p, 0, (size_t)q_pad * Kp * sizeof(bf16_t), st));
         HIPCHK(launch_build_operand(q, is_bf, q_split ? 2 : 0, nq, d, d, (bf16_t*)idx->w_qg.p, Kp, st));
     }
-    int* nflag = (int*)idx->w_flag.p;
+    // this batch's slice of the flag workspace (reserved for all batches by the caller: a DevBuf may not grow while
+    // earlier batches of the same call still point into it)
+    int* nflag = (int*)idx->w_flag.p + (size_t)batch_no * (4 + 65536);
     int* flagged = nflag + 4;
     HIPCHK(hipMemsetAsync(nflag, 0, 4 * sizeof(int), st));
 
@@ -356,32 +373,62 @@ static int search_batch(trx_index* idx, const void* q, const float* qnorm2, int6
     if (idx->mode == MODE_SPLIT) { se.corpus_orig = idx->Co; se.ld_c = d; se.corpus_is_bf16 = 0; }
     else { se.corpus_orig = idx->Cg; se.ld_c = Kp; se.corpus_is_bf16 = 1; }
     se.query_orig = q; se.ld_q = d; se.query_is_bf16 = is_bf;
-    se.d = d; se.metric = idx->metric; se.k = k; se.nq = (int)nq; se.n = idx->n; se.exact_class = exact_class;
+    se.d = d; se.metric = idx->metric; se.k = k; se.nq = (int)nq; se.n = idx->n; se.exact_class = (const int*)idx->w_cls.p;
     se.eps_rel = eps_rel; se.qnorm2 = qnorm2; se.ymax_norm2 = idx->maxnorm2;
     se.D = D; se.I = I; se.S64 = S64; se.flagged = flagged; se.nflagged = nflag;
     HIPCHK(launch_select(se, st));
 
-    // certificate failures -> exact scan of those queries
-    int nf = 0;
-    HIPCHK(hipMemcpyAsync(&nf, nflag, sizeof(int), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    if (idx->timing) {
+    // certificate failures -> exact scan of those queries.  The count stays on the device: the first INLINE_FALLBACK of
+    // them are re-done right here, stream-ordered (slots beyond the count leave at once: ~10 us when nothing failed, the
+    // common case); trx_index_search_finish reads the count and completes what is left.  No host synchronisation.
+    if (sp.debug == 0)      // (timing-only debug modes of the scan kernel produce wrong lists: no fall-back then)
+        HIPCHK(launch_exact_scan(idx->metric, se.corpus_is_bf16, is_bf, flagged, INLINE_FALLBACK, nflag, idx->n,
+                                 se.corpus_orig, se.ld_c, q, d, d, k, (double*)idx->w_exact.p, D, I, S64, st));
+    if (idx->timing) {      // timing mode is synchronous by contract (trx_index_set_timing)
+        HIPCHK(hipStreamSynchronize(st));
         float ms = 0.f;
         HIPCHK(hipEventElapsedTime(&ms, idx->ev[0], idx->ev[1]));
         idx->stats.scan_ms += ms;
     }
     idx->stats.scan_launches += 1;
     idx->stats.n_splits = nsplits;
-    idx->stats.n_uncertified += nf;
-    if (nf > 0 && sp.debug == 0) {      // (timing-only debug modes of the scan kernel produce wrong lists: no fall-back then)
-        const int64_t per = std::max<int64_t>(1, ((int64_t)1 << 29) / std::max<int64_t>(1, idx->n * 8));
-        if ((rc = idx->w_exact.reserve((size_t)std::min<int64_t>(per, nf) * idx->n * sizeof(double)))) return rc;
-        for (int f0 = 0; f0 < nf; f0 += (int)per) {
-            const int m = (int)std::min<int64_t>(per, nf - f0);
-            HIPCHK(launch_exact_scan(idx->metric, se.corpus_is_bf16, is_bf, flagged + f0, m, idx->n,
-                                     se.corpus_orig, se.ld_c, q, d, d, k, (double*)idx->w_exact.p, D, I, S64, st));
+    idx->pend.no_fallback = sp.debug != 0;
+    idx->pend.corpus_orig = se.corpus_orig; idx->pend.ld_c = se.ld_c; idx->pend.corpus_is_bf16 = se.corpus_is_bf16;
+    idx->pend.batches.push_back({nflag, flagged, q, D, I, S64});
+    return TRX_OK;
+}
+
+// read back what the enqueued search left on the device; complete the fall-back where more queries failed their
+// certificate than the inline slots cover
+static int finish_impl(trx_index* idx) {
+    auto& pd = idx->pend;
+    if (!pd.active) return TRX_OK;
+    pd.active = false;
+    hipStream_t st = pd.st;
+    int cls = 0;
+    std::vector<int> nf(pd.batches.size(), 0);
+    for (size_t b = 0; b < pd.batches.size(); ++b)
+        HIPCHK(hipMemcpyAsync(&nf[b], pd.batches[b].nflag, sizeof(int), hipMemcpyDeviceToHost, st));
+    if (idx->w_cls.p && !pd.batches.empty()) HIPCHK(hipMemcpyAsync(&cls, idx->w_cls.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (!pd.batches.empty()) idx->stats.exact_class = cls;
+    const int64_t per = std::max<int64_t>(INLINE_FALLBACK, ((int64_t)1 << 29) / std::max<int64_t>(1, idx->n * 8));
+    bool late = false;
+    for (size_t b = 0; b < pd.batches.size(); ++b) {
+        idx->stats.n_uncertified += nf[b];
+        if (pd.no_fallback || nf[b] <= INLINE_FALLBACK) continue;
+        late = true;
+        int rc = idx->w_exact.reserve((size_t)std::min<int64_t>(per, nf[b]) * idx->n * sizeof(double)); if (rc) return rc;
+        const auto& pb = pd.batches[b];
+        for (int f0 = INLINE_FALLBACK; f0 < nf[b]; f0 += (int)per) {
+            const int m = (int)std::min<int64_t>(per, nf[b] - f0);
+            HIPCHK(launch_exact_scan(idx->metric, pd.corpus_is_bf16, pd.is_bf, pb.flagged + f0, m, nullptr, idx->n,
+                                     pd.corpus_orig, pd.ld_c, pb.q, idx->d, idx->d, pd.k, (double*)idx->w_exact.p, pb.D, pb.I, pb.S64, st));
         }
     }
+    if (late) HIPCHK(hipStreamSynchronize(st));
+    idx->stats.late_fallback = late ? 1 : 0;
+    pd.batches.clear();
     return TRX_OK;
 }
 
@@ -392,6 +439,7 @@ static int search_device_impl(trx_index* idx, const void* q, int64_t nq, int dty
     if (k <= 0 || k > TRX_MAX_K) return fail(TRX_EINVAL, "k must be in [1, 2048]");
     if (dtype != TRX_DTYPE_F32 && dtype != TRX_DTYPE_BF16) return fail(TRX_EINVAL, "unknown dtype");
     int rc = set_device(idx); if (rc) return rc;
+    if (idx->pend.active) { rc = finish_impl(idx); if (rc) return rc; }     // a search begun and never finished
     hipStream_t st = (hipStream_t)stream;
     idx->stats = trx_search_stats{};
     idx->stats.nq = nq;
@@ -399,6 +447,8 @@ static int search_device_impl(trx_index* idx, const void* q, int64_t nq, int dty
     const int is_bf = dtype == TRX_DTYPE_BF16;
     const int d = idx->d;
     if (idx->timing) HIPCHK(hipEventRecord(idx->ev[2], st));
+    idx->pend = trx_index::Pending{};
+    idx->pend.active = true; idx->pend.st = st; idx->pend.is_bf = is_bf; idx->pend.k = k;
 
     if (idx->n == 0 || k > TRX_FAST_MAX_K) {
         // empty index: all pads.  large k: exact scan for every query (documented slow path)
@@ -410,13 +460,12 @@ static int search_device_impl(trx_index* idx, const void* q, int64_t nq, int dty
         const size_t esz = is_bf ? 2 : 4;
         for (int64_t f0 = 0; f0 < nq; f0 += per) {
             const int m = (int)std::min<int64_t>(per, nq - f0);
-            HIPCHK(launch_exact_scan(idx->metric, cbf, is_bf, nullptr, m, idx->n, corig, ldc,
+            HIPCHK(launch_exact_scan(idx->metric, cbf, is_bf, nullptr, m, nullptr, idx->n, corig, ldc,
                                      (const char*)q + (size_t)f0 * d * esz, d, d, k, (double*)idx->w_exact.p,
                                      D + f0 * k, I + f0 * k, S64 ? S64 + f0 * k : nullptr, st));
         }
         idx->stats.n_uncertified = nq;
-        HIPCHK(hipStreamSynchronize(st));
-        return TRX_OK;
+        return TRX_OK;              // enqueued; trx_index_search_finish waits for it
     }
 
     // classify the queries once
@@ -425,32 +474,49 @@ static int search_device_impl(trx_index* idx, const void* q, int64_t nq, int dty
     // one pass over the queries: the class flags and every query's fp32 norm (the select kernel's error bound)
     rc = idx->w_qnorm2.reserve((size_t)round_up64(nq, TILE_N) * sizeof(float)); if (rc) return rc;
     HIPCHK(launch_row_stats(q, is_bf, nq, d, d, idx->w_stats.p, (float*)idx->w_qnorm2.p, st));
-    HostStats hs; rc = read_stats(idx, st, &hs); if (rc) return rc;
-    if (hs.inexact_any && idx->mode == MODE_PLAIN) {
-        rc = restructure(idx, idx->cap, MODE_SPLIT, st); if (rc) return rc;
-        HIPCHK(launch_fill_bias(idx->cnorm2, idx->n, idx->cap + TILE_M, idx->cbias, st));
+    // The ONE host decision a search can need: fp32 queries that are not exact in bf16 against an index that holds only
+    // bf16 data turn the index into its split form.  bf16 queries are exact by construction, and a split index stays
+    // split, so only fp32 queries on a plain index read their statistics back; everything else stays on the device.
+    if (!is_bf && idx->mode == MODE_PLAIN) {
+        HostStats hs; rc = read_stats(idx, st, &hs); if (rc) return rc;
+        if (hs.inexact_any) {
+            rc = restructure(idx, idx->cap, MODE_SPLIT, st); if (rc) return rc;
+            HIPCHK(launch_fill_bias(idx->cnorm2, idx->n, idx->cap + TILE_M, idx->cbias, st));
+        }
     }
     const int q_split = idx->mode == MODE_SPLIT;
-    const float qmax = bits2f(hs.maxabs_bits);
-    // exact class: integer inputs small enough that every fp32 partial sum (and the L2 key) is exact
-    const double prod = (double)idx->Kp * (double)qmax * (double)idx->maxabs;
-    const double keymag = idx->metric == TRX_METRIC_L2 ? 2.0 * prod + (double)idx->d * idx->maxabs * idx->maxabs : prod;
-    const int exact_class = (!q_split && !hs.nonint_any && !idx->nonint && qmax <= 256.f && idx->maxabs <= 256.f &&
-                             keymag < 16777216.0) ? 1 : 0;
+    // exact class (integer inputs small enough that every fp32 partial sum and the L2 key are exact): decided by a
+    // one-thread kernel from the statistics just gathered; the select kernel reads the flag from device memory
+    rc = idx->w_cls.reserve(4 * sizeof(int)); if (rc) return rc;
+    HIPCHK(launch_classify(idx->w_stats.p, q_split, idx->nonint ? 1 : 0, idx->maxabs, idx->Kp, idx->d,
+                           idx->metric == TRX_METRIC_L2 ? 1 : 0, (int*)idx->w_cls.p, st));
     const float eps_rel = (float)((idx->Kp + 64) * std::ldexp(1.0, -23)) + (q_split ? (float)std::ldexp(1.0, -15) : 0.f);
     idx->stats.k_split = idx->Kp;
-    idx->stats.exact_class = exact_class;
 
     const int64_t QB = 65536;
     const size_t esz = is_bf ? 2 : 4;
+    const int nbatches = (int)((nq + QB - 1) / QB);
+    if ((rc = idx->w_flag.reserve((size_t)nbatches * (4 + QB) * sizeof(int)))) return rc;
+    // the inline fall-back's score rows (INLINE_FALLBACK x n doubles)
+    if ((rc = idx->w_exact.reserve((size_t)INLINE_FALLBACK * idx->n * sizeof(double)))) return rc;
     for (int64_t q0 = 0; q0 < nq; q0 += QB) {
         const int64_t m = std::min(QB, nq - q0);
-        rc = search_batch(idx, (const char*)q + (size_t)q0 * d * esz, (const float*)idx->w_qnorm2.p + q0, m, is_bf, q_split, exact_class, eps_rel, k,
+        rc = search_batch(idx, (const char*)q + (size_t)q0 * d * esz, (const float*)idx->w_qnorm2.p + q0, m, is_bf, q_split, (int)(q0 / QB), eps_rel, k,
                           D + q0 * k, I + q0 * k, S64 ? S64 + q0 * k : nullptr, st);
         if (rc) return rc;
     }
-    if (idx->timing) {
-        HIPCHK(hipEventRecord(idx->ev[3], st));
+    if (idx->timing) HIPCHK(hipEventRecord(idx->ev[3], st));
+    return TRX_OK;
+}
+
+int trx_index_search_finish(trx_index* idx) {
+    if (!idx) return fail(TRX_EINVAL, "index is null");
+    int rc = set_device(idx); if (rc) return rc;
+    const bool was = idx->pend.active;
+    hipStream_t st = idx->pend.st;
+    rc = finish_impl(idx); if (rc) return rc;       // (synchronises the stream)
+    (void)st;
+    if (was && idx->timing && idx->stats.scan_launches > 0) {
         HIPCHK(hipEventSynchronize(idx->ev[3]));
         float ms = 0.f;
         HIPCHK(hipEventElapsedTime(&ms, idx->ev[2], idx->ev[3]));
@@ -459,15 +525,22 @@ static int search_device_impl(trx_index* idx, const void* q, int64_t nq, int dty
     return TRX_OK;
 }
 
+int trx_index_search_device_begin(trx_index* idx, const void* q, int64_t nq, int dtype, int k, float* D,
+                                  int64_t* I, double* S64, void* stream) {
+    return search_device_impl(idx, q, nq, dtype, k, D, I, S64, stream);
+}
+
 int trx_index_search_device(trx_index* idx, const void* q, int64_t nq, int dtype, int k, float* D,
                             int64_t* I, void* stream) {
-    return search_device_impl(idx, q, nq, dtype, k, D, I, nullptr, stream);
+    int rc = search_device_impl(idx, q, nq, dtype, k, D, I, nullptr, stream);
+    return rc ? rc : trx_index_search_finish(idx);
 }
 
 // internal-but-exported: same as above plus the fp64 scores the cross-shard merge orders by
 int trx_index_search_device_s64(trx_index* idx, const void* q, int64_t nq, int dtype, int k, float* D,
                                 int64_t* I, double* S64, void* stream) {
-    return search_device_impl(idx, q, nq, dtype, k, D, I, S64, stream);
+    int rc = search_device_impl(idx, q, nq, dtype, k, D, I, S64, stream);
+    return rc ? rc : trx_index_search_finish(idx);
 }
 
 int trx_index_search(trx_index* idx, const void* q, int64_t nq, int dtype, int k, float* D, int64_t* I) {
@@ -485,6 +558,7 @@ int trx_index_search(trx_index* idx, const void* q, int64_t nq, int dtype, int k
     HIPCHK(hipMemcpy(base + qoff, q, qb, hipMemcpyHostToDevice));
     rc = search_device_impl(idx, base + qoff, nq, dtype, k, (float*)(base + doff), (int64_t*)(base + ioff), nullptr, nullptr);
     if (rc) return rc;
+    rc = trx_index_search_finish(idx); if (rc) return rc;
     HIPCHK(hipMemcpy(D, base + doff, db, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(I, base + ioff, ib, hipMemcpyDeviceToHost));
     return TRX_OK;

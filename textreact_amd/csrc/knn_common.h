@@ -146,7 +146,7 @@ struct SelectParams {
     int k;
     int nq;
     int64_t n;                // corpus rows: ids >= n are pad rows of the last tile (an inner-product scan may list them)
-    int exact_class;          // 1: no certificate needed
+    const int* exact_class;   // DEVICE int: 1 = no certificate needed (integer inputs, every partial sum exact)
     float eps_rel;            // certificate slack, relative to bound_q
     const float* qnorm2;      // fp32 |x_q|^2 (upper-bound use only)
     float ymax_norm2;         // max |y|^2 over the corpus

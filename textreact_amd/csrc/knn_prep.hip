@@ -97,6 +97,20 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const void* x, int64_t n
     }
 }
 
+// The exact class of a search -- integer inputs small enough that every fp32 partial sum (and the L2 key) is exact, so
+// the approximate order IS the exact order and no certificate is needed -- decided on the device from the query
+// statistics, so that a search need not read them back (knn_api.hip: the stream-ordered search).
+__global__ void classify_kernel(const RowStats* qs, int q_split, int idx_nonint, float idx_maxabs, int Kp, int d, int l2, int* out) {
+    const float qmax = __uint_as_float(qs->maxabs_bits);
+    const double prod = (double)Kp * (double)qmax * (double)idx_maxabs;
+    const double keymag = l2 ? 2.0 * prod + (double)d * idx_maxabs * idx_maxabs : prod;
+    out[0] = (!q_split && !qs->nonint_any && !idx_nonint && qmax <= 256.f && idx_maxabs <= 256.f && keymag < 16777216.0) ? 1 : 0;
+}
+hipError_t launch_classify(const void* qstats, int q_split, int idx_nonint, float idx_maxabs, int Kp, int d, int l2, int* out, hipStream_t st) {
+    hipLaunchKernelGGL(classify_kernel, dim3(1), dim3(1), 0, st, (const RowStats*)qstats, q_split, idx_nonint, idx_maxabs, Kp, d, l2, out);
+    return hipGetLastError();
+}
+
 // Build GEMM operand rows.  One thread per (row, 8-component group).
 // SPLIT: 0 plain, 1 split-corpus [hi|lo|hi], 2 split-query [hi|hi|lo]
 template <bool BF, int SPLIT>

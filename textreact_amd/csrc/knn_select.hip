@@ -81,6 +81,7 @@ __device__ __forceinline__ double canonical_score(const void* qrow, const void* 
 template <bool L2, bool CBF, bool QBF>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void knn_select_kernel(SelectParams p) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, hl = lane & 31, half = lane >> 5;
+    const int exact_class = *p.exact_class;         // decided on the device from the query statistics (knn_prep.hip: classify_kernel)
     const int q0 = (blockIdx.x * 4 + wv) * 2;       // q0 -> lanes 32..63, q0 + 1 -> lanes 0..31
     if (q0 >= p.nq) return;                         // wave-uniform; the kernel has no workgroup barrier
     // LDS per wave: the row slices of the re-scoring (64 rows x 144 bytes); the merge phase, over before the re-scoring
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     } else if (have && TRX_SEL_ABL != 1) {
         const char* crow = reinterpret_cast<const char*>(p.corpus_orig) + (int64_t)id * p.ld_c * CE;
         sc = canonical_score<L2, CBF, QBF>(qrow, crow, p.d);
-        if (L2 && !p.exact_class)
+        if (L2 && !exact_class)
             for (int i = 0; i < p.d; ++i) {     // |x|^2 in fp64, k-ordered (the certificate's key = |x|^2 - dist)
                 const double t = load_as_double<QBF>(qrow, i);
                 xx = __builtin_fma(t, t, xx);
@@ -330,7 +331,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const double xx0 = __shfl(xx, lane & 32, 64);      // the first candidate's lane has walked the whole query row
         if (tau != 0ull && nranked < p.k) {
             certified = false;      // fewer ranked candidates than k although rows were dropped: exact inputs or not, redo it
-        } else if (!p.exact_class && tau != 0ull) {
+        } else if (!exact_class && tau != 0ull) {
             const float tau_key = comp_key(tau);
             const double bound = (double)tau_key + eps;  // upper bound of an outsider's exact key
             certified = L2 ? (xx0 - s_k) > bound : s_k > bound;   // L2: key = |x|^2 - dist
@@ -371,13 +372,16 @@ hipError_t launch_select(const SelectParams& p, hipStream_t st) {
 // ------------------------------------------------------------------------------------------
 // exact scan (fall-back and k > TRX_FAST_MAX_K): canonical scores of `nf` listed queries against
 // every corpus row, then k rounds of "next best after the previous pick" per query.
+// nf_dev (optional): the number of listed queries lives on the device (the certificate failures of a search that has
+// not been read back): the launch covers `nf` slots and the blocks beyond *nf_dev leave at once.
 template <bool L2, bool CBF, bool QBF>
-__global__ __launch_bounds__(256) void exact_scores_kernel(const int* qlist, int nf, int64_t n,
+__global__ __launch_bounds__(256) void exact_scores_kernel(const int* qlist, int nf, const int* nf_dev, int64_t n,
                                                            const void* corpus, int64_t ld_c,
                                                            const void* queries, int64_t ld_q, int d,
                                                            double* out /* [nf][n] */) {
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int f = blockIdx.y;
+    if (nf_dev && f >= *nf_dev) return;
     if (f >= nf || j >= n) return;
     const int q = qlist ? qlist[f] : f;
     const char* qrow = reinterpret_cast<const char*>(queries) + (int64_t)q * ld_q * (QBF ? 2 : 4);
@@ -386,13 +390,13 @@ __global__ __launch_bounds__(256) void exact_scores_kernel(const int* qlist, int
 }
 
 template <bool L2>
-__global__ __launch_bounds__(256) void exact_pick_kernel(const int* qlist, int nf, int64_t n, int k,
+__global__ __launch_bounds__(256) void exact_pick_kernel(const int* qlist, int nf, const int* nf_dev, int64_t n, int k,
                                                          const double* sc, float* D, int64_t* I,
                                                          double* S64) {
     __shared__ u64 red_key[256];
     __shared__ int64_t red_id[256];
     const int f = blockIdx.x;
-    if (f >= nf) return;
+    if (f >= nf || (nf_dev && f >= *nf_dev)) return;
     const int q = qlist ? qlist[f] : f;
     const double* row = sc + (int64_t)f * n;
     u64 prev_key = ~0ull;      // previous pick (sort key: larger == earlier), start above all
@@ -436,7 +440,7 @@ __global__ __launch_bounds__(256) void exact_pick_kernel(const int* qlist, int n
     }
 }
 
-hipError_t launch_exact_scan(int metric, int cbf, int qbf, const int* qlist, int nf, int64_t n,
+hipError_t launch_exact_scan(int metric, int cbf, int qbf, const int* qlist, int nf, const int* nf_dev, int64_t n,
                              const void* corpus, int64_t ld_c, const void* queries, int64_t ld_q,
                              int d, int k, double* sc, float* D, int64_t* I, double* S64,
                              hipStream_t st) {
@@ -444,7 +448,7 @@ hipError_t launch_exact_scan(int metric, int cbf, int qbf, const int* qlist, int
     if (n > 0) {
         dim3 grid((unsigned)((n + 255) / 256), nf), block(256);
         const int sel = (metric ? 4 : 0) | (cbf ? 2 : 0) | (qbf ? 1 : 0);
-#define TRX_ES(a, b, c) hipLaunchKernelGGL((exact_scores_kernel<a, b, c>), grid, block, 0, st, qlist, nf, n, corpus, ld_c, queries, ld_q, d, sc)
+#define TRX_ES(a, b, c) hipLaunchKernelGGL((exact_scores_kernel<a, b, c>), grid, block, 0, st, qlist, nf, nf_dev, n, corpus, ld_c, queries, ld_q, d, sc)
         switch (sel) {
             case 0: TRX_ES(false, false, false); break;
             case 1: TRX_ES(false, false, true); break;
@@ -459,8 +463,8 @@ hipError_t launch_exact_scan(int metric, int cbf, int qbf, const int* qlist, int
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
-    if (metric) hipLaunchKernelGGL(exact_pick_kernel<true>, dim3(nf), dim3(256), 0, st, qlist, nf, n, k, sc, D, I, S64);
-    else hipLaunchKernelGGL(exact_pick_kernel<false>, dim3(nf), dim3(256), 0, st, qlist, nf, n, k, sc, D, I, S64);
+    if (metric) hipLaunchKernelGGL(exact_pick_kernel<true>, dim3(nf), dim3(256), 0, st, qlist, nf, nf_dev, n, k, sc, D, I, S64);
+    else hipLaunchKernelGGL(exact_pick_kernel<false>, dim3(nf), dim3(256), 0, st, qlist, nf, nf_dev, n, k, sc, D, I, S64);
     return hipGetLastError();
 }
 

@@ -86,6 +86,30 @@ class IndexFlat:
         """torch-only: (D, I, S) with S the fp64 canonical scores (row-sharded merge input)."""
         return self._search_torch(x, int(k), want_s64=True)
 
+    def search_s64_begin(self, x, k):
+        """stream-ordered: everything is enqueued on torch's current stream and (D, I, S) are returned at once; they are
+        final after `search_finish()` (include/trx_knn.h, Threading).  Work enqueued on the same stream in between -- the
+        all-gather and merge of the row-sharded search -- needs no host round trip."""
+        import torch
+        x, dt = self._torch_arg(x)
+        nq, k = x.shape[0], int(k)
+        dev = torch.device("cuda", self.device)
+        D = torch.empty((nq, k), dtype=torch.float32, device=dev)
+        I = torch.empty((nq, k), dtype=torch.int64, device=dev)
+        S = torch.empty((nq, k), dtype=torch.float64, device=dev)
+        st = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        self._keep = x          # the queries must outlive the enqueued work
+        _lib.check(_lib.lib().trx_index_search_device_begin(self._h, ctypes.c_void_p(x.data_ptr()), nq, dt, k, ctypes.c_void_p(D.data_ptr()),
+                                                            ctypes.c_void_p(I.data_ptr()), ctypes.c_void_p(S.data_ptr()), st))
+        return D, I, S
+
+    def search_finish(self):
+        """-> True when the finish changed outputs AFTER the enqueued work (more certificate failures than the inline
+        re-scan covers: rare): whatever was computed from them in between must be redone"""
+        _lib.check(_lib.lib().trx_index_search_finish(self._h))
+        self._keep = None
+        return bool(self.last_stats()["late_fallback"])
+
     # -- internals ----------------------------------------------------------------------------
     def _as_f32(self, x):
         x = np.asarray(x)

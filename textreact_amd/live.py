@@ -113,6 +113,9 @@ class LiveRetriever:
         pid, pmask = with_special_tokens(c.passage_ids[lo:hi], c.passage_len[lo:hi], c.cls_id, c.sep_id, c.pad_id)
         self.emb_p = dense.encode(p_encoder, pid, pmask, batch_size=self.batch_size, autocast=self.autocast)
         li = self._local_index() if callable(self._local_index) else self._local_index
+        if li is None:      # the HIP flat index, on the device the embeddings live on (not LOCAL_RANK: a rehearsal shares one GPU)
+            from . import faiss_compat
+            li = faiss_compat.IndexFlat(self.emb_p.shape[1], faiss_compat.METRIC_INNER_PRODUCT, device=self.emb_p.device.index or 0)
         self.index = ShardedFlatIndex(self.emb_p.shape[1], 0, group=self.group, local_index=li, merge=self._merge)
         self.index.add_shard(self.emb_p, lo, len(c))
 

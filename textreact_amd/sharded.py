@@ -1,10 +1,10 @@
 """Row-sharded exact k-NN across the GPUs of one node.
 
 One process per GPU.  Rank r holds corpus rows [r*N/G, (r+1)*N/G) in its own flat index; queries are
-replicated.  A search is: local search -> (fp64 score, local id + shard offset) -> ONE all-gather
-of nq*k*16 bytes per rank (RCCL over xGMI: `torch.distributed` backend "nccl") -> every rank merges
-the G lists with the same total order as a single unsharded index, so the result is identical to
-an unsharded IndexFlat over the concatenated corpus.
+replicated.  A search is: local search -> (fp64 score, local id + shard offset) -> an all-to-all that hands
+rank r every rank's lists for ITS nq/G queries -> rank r merges them with the same total order as a single
+unsharded index -> an all-gather of the merged slices (RCCL over xGMI: `torch.distributed` backend "nccl"), so
+the result is identical to an unsharded IndexFlat over the concatenated corpus, on every rank.
 
 The reference has no multi-GPU retrieval (retrieve/retrieve_faiss.py is single-process CPU FAISS);
 this is the north-star's scale-out of index_and_search (retrieve_faiss.py:62-74).
@@ -53,25 +53,60 @@ class ShardedFlatIndex:
         self.offset, self.ntotal = int(offset), int(ntotal)
 
     def search(self, x, k: int):
-        """x replicated on every rank (torch tensor on this rank's device).  Returns (D, I) with
-        global ids, identical on every rank."""
+        """x replicated on every rank (torch tensor on this rank's device).  Returns (D, I) with global ids, identical on
+        every rank.
+
+        Two collectives, both a G-th of what an all-gather of every rank's full list would move (the all-to-all
+        variant): rank r receives, from every rank, the lists of ITS 1/G of the queries (one all-to-all of nq*k*16 bytes
+        per rank in total), merges those nq/G queries, and an all-gather of the merged (D, I) slices (nq*k*12 bytes per
+        rank) replicates the result.  With the HIP index the local search is stream-ordered (trx_index_search_device_begin):
+        the exchange and the merge are enqueued behind it without a host round trip, and ONE wait at the end reads the
+        certificate counts back; should that wait have had to re-do queries after the exchange (stats.late_fallback on
+        any rank -- agreed on by a one-word all-reduce), the exchange is simply repeated on the final lists."""
+        import torch
+        begin = getattr(self.local, "search_s64_begin", None) if self.world_size > 1 else None
+        D, I_loc, S = begin(x, k) if begin is not None else self.local.search_s64(x, k)
+        if self.world_size == 1:
+            return D, torch.where(I_loc >= 0, I_loc + self.offset, I_loc)
+        out = self._exchange_and_merge(S, I_loc, k)
+        if begin is not None:
+            import torch.distributed as dist
+            late = torch.tensor([1 if self.local.search_finish() else 0], dtype=torch.int32)
+            if dist.get_backend(self.group) != "gloo":
+                late = late.to(S.device)
+            dist.all_reduce(late, op=dist.ReduceOp.MAX, group=self.group)
+            if int(late.item()):
+                out = self._exchange_and_merge(S, I_loc, k)
+        return out
+
+    def _exchange_and_merge(self, S, I_loc, k):
         import torch
         import torch.distributed as dist
-        D, I, S = self.local.search_s64(x, k)
-        I = torch.where(I >= 0, I + self.offset, I)
-        if self.world_size == 1:
-            return D, I
-        # one collective: pack (fp64 score bits, id) as int64 [2, nq, k]; nq*k*16 bytes per rank
-        nq = S.shape[0]
-        pack = torch.stack([S.contiguous().view(torch.int64), I.contiguous()])
-        out = torch.empty((self.world_size,) + tuple(pack.shape), dtype=torch.int64, device=pack.device)
-        if dist.get_backend(self.group) == "gloo":  # test path (gloo gathers host tensors only)
-            host = pack.cpu()
-            parts = [torch.empty_like(host) for _ in range(self.world_size)]
+        G, r, nq = self.world_size, self.rank, S.shape[0]
+        I = torch.where(I_loc >= 0, I_loc + self.offset, I_loc)
+        # query-major pack [nq, 2, k] (fp64 score bits, global id): the rows of destination j are contiguous
+        pack = torch.stack([S.contiguous().view(torch.int64), I.contiguous()], dim=1)
+        bounds = [shard_bounds(nq, G, j) for j in range(G)]
+        mine = bounds[r][1] - bounds[r][0]
+        gloo = dist.get_backend(self.group) == "gloo"       # test path: gloo moves host tensors
+        src = pack.cpu() if gloo else pack
+        got = torch.empty((G * mine, 2, k), dtype=torch.int64, device=src.device)
+        dist.all_to_all_single(got, src, output_split_sizes=[mine] * G, input_split_sizes=[hi - lo for lo, hi in bounds],
+                               group=self.group)
+        got = got.to(pack.device).view(G, mine, 2, k)
+        Dm, Im = self._merge(self.metric, got[:, :, 0].contiguous().view(torch.float64), got[:, :, 1].contiguous())
+        # replicate: slices are at most one query apart in length; pad to the longest, one all-gather
+        per = max(hi - lo for lo, hi in bounds)
+        buf = torch.zeros((per, 2, k), dtype=torch.int64, device=pack.device)
+        buf[:mine, 0] = Dm.contiguous().view(torch.int32).long()      # the float bits, widened: one tensor, one collective
+        buf[:mine, 1] = Im
+        if gloo:
+            host = buf.cpu()
+            parts = [torch.empty_like(host) for _ in range(G)]
             dist.all_gather(parts, host, group=self.group)
-            out = torch.stack(parts).to(pack.device)
+            allb = torch.stack(parts).to(pack.device)
         else:
-            dist.all_gather_into_tensor(out, pack, group=self.group)
-        S_all = out[:, 0].contiguous().view(torch.float64)
-        I_all = out[:, 1].contiguous()
-        return self._merge(self.metric, S_all, I_all)
+            allb = torch.empty((G,) + tuple(buf.shape), dtype=torch.int64, device=pack.device)
+            dist.all_gather_into_tensor(allb, buf, group=self.group)
+        rows = torch.cat([allb[j, :hi - lo] for j, (lo, hi) in enumerate(bounds)])
+        return rows[:, 0].to(torch.int32).view(torch.float32), rows[:, 1].contiguous()
