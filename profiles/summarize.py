@@ -41,7 +41,7 @@ sq, _ = counters("pmc_sq")
 fetch_kb, write_kb = fetch.get("FETCH_SIZE"), write.get("WRITE_SIZE")
 try:
     import subprocess
-    sha = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"]).decode().strip()
+    sha = sys.argv[2] if len(sys.argv) > 2 else subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"]).decode().strip()
 except Exception:
     sha = "unknown"
 out = {

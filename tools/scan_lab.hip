@@ -15,6 +15,7 @@
 //           bit1: no MFMA (fill only)
 //           bit2: no per-tile maximum
 //           bit3: (variant 4) fragments read once and reused: no LDS read traffic
+//           bit4: (variant 4) every tile re-reads the split's first corpus tile: the fill never misses L2
 // build: hipcc --offload-arch=gfx950 -O3 tools/scan_lab.hip -o tools/scan_lab
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -388,7 +389,9 @@ __global__ __launch_bounds__(THREADS, 2) void lab_v2(LabParams p) {
     int ksB = 1;                                       // G0: B of K-step u+1
     const bf16_t* srcH = gA + half_elems + BK; int ksH = 1;   // G1: A rows 128-255 of K-step u+1
     const bf16_t* srcL = gA + 2 * BK; int ksL = 2;            // G1: A rows 0-127 of K-step u+2
-    const int wrapA = 255 * Kp;
+    // flags bit4: every tile re-reads the split's FIRST corpus tile (the cursors step back instead of on): the whole fill is
+    // served from L2 -- what the fill costs when nothing misses (results differ from variant 0 by construction)
+    const int wrapA = (p.flags & 16) ? -Kp : 255 * Kp;
     const bool dma_on = !(p.flags & 1);
     const bool mfma_on = !(p.flags & 2);
     const bool rd_on = !(p.flags & 8);     // flags bit3: fragments are read once and reused (no LDS read traffic)
