@@ -900,3 +900,14 @@ def test_a_backward_across_a_parameter_update_is_refused():
     train.mark_parameters_updated(p)
     with pytest.raises(RuntimeError, match="between this forward and its backward"):
         l3.backward()
+
+
+def test_ping_pong_forward_kernel():
+    """attn_fwd_pp.h (two wave groups in ping-pong; off by default: it measured slower) stays correct: the randomised
+    attention cases with TRX_NN_ATTN_PP=1, in a process of their own (the switch is read once)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "attn_fuzz.py"), "60", "5"], capture_output=True, text=True,
+                       timeout=600, env=dict(os.environ, TRX_NN_ATTN_PP="1"))
+    assert r.returncode == 0 and "0 failures" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

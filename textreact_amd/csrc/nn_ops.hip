@@ -8,6 +8,7 @@
 // (vector kernels incl. the bf16-x / fp32-stream case of autocast, scalar fallbacks); attention forward
 // in fp32 (VALU, the <= 1e-3 parity path) and in bf16 on the matrix cores; the fp32 attention backward;
 // the C entry points.  The matrix-core attention backward is attn_bwd_mfma.h (included below).
+#include <atomic>
 #include "../../include/trx_nn.h"
 #include <hip/hip_runtime.h>
 #include <string>
@@ -915,6 +916,7 @@ __global__ __launch_bounds__(XW ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
     TRX_STAMP(31, __builtin_amdgcn_s_memtime()); TRX_STAMP(1, __builtin_amdgcn_s_memrealtime());
 }
 
+#include "attn_fwd_pp.h"
 #include "attn_bwd_mfma.h"
 #include "attn_decode.h"
 
@@ -1178,9 +1180,27 @@ static int attention_fwd_impl(const void* q, const void* k, const void* v, const
         static const bool use_xw = getenv("TRX_NN_ATTN_XW") != nullptr;         // (the experiment above; off: it measured slower)
         const bool xw = Lq > 128 && Lq <= 256 && use_xw;
         dim3 g2((unsigned)((int64_t)B * H * (xw ? 1 : (Lq + 127) / 128))), b2(xw ? 64 * ((Lq + 31) / 32) : 256);
+        // TRX_NN_ATTN_PP=1: the encoder's shape class (Lq >= 256, key mask or none) on the two-group ping-pong kernel of
+        // attn_fwd_pp.h -- correct (tests/test_predictor_gpu.py::test_ping_pong_forward_kernel) and 33 % SLOWER than this
+        // one at 512 x 512 (69.4 against 52.0 us, profiles/r03_attention_ab.json), so it is not the default
+        static const bool use_pp = getenv("TRX_NN_ATTN_PP") != nullptr;
+        const bool pp = use_pp && Lq >= 256 && Lk <= 1024 && mask_mode != TRX_NN_MASK_FULL;
+        dim3 g3((unsigned)((int64_t)B * H * ((Lq + 255) / 256))), b3(512);
 #define TRX_LAUNCH_MFMA(MM_, DROP_)                                                                                       \
     do {                                                                                                                  \
-        if (xw) hipLaunchKernelGGL((attention_fwd_mfma_kernel<MM_, DROP_, true>), g2, b2, 0, st, (const bf16_t*)q, (const bf16_t*)k, \
+        if (pp) {                                                                                                         \
+            auto kern_ = attention_fwd_pp_kernel<(MM_) == TRX_NN_MASK_FULL ? TRX_NN_MASK_NONE : (MM_), DROP_>;            \
+            static std::atomic<unsigned long long> attr_devs_{0ull};   /* the LDS limit is a per-device attribute */          \
+            int dev_ = 0;                                                                                                 \
+            (void)hipGetDevice(&dev_);                                                                                    \
+            if (!(attr_devs_.load() & (1ull << (dev_ & 63)))) {                                                           \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern_), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES); \
+                attr_devs_.fetch_or(1ull << (dev_ & 63));                                                                 \
+            }                                                                                                             \
+            hipLaunchKernelGGL(kern_, g3, b3, PP_LDS_BYTES, st, (const bf16_t*)q, (const bf16_t*)k,                       \
+                               (const bf16_t*)v, mask, causal, B, H, Lq, Lk, scale, (bf16_t*)out, lse, da);               \
+        }                                                                                                                 \
+        else if (xw) hipLaunchKernelGGL((attention_fwd_mfma_kernel<MM_, DROP_, true>), g2, b2, 0, st, (const bf16_t*)q, (const bf16_t*)k, \
                                    (const bf16_t*)v, mask, causal, B, H, Lq, Lk, scale, (bf16_t*)out, lse, da);           \
         else hipLaunchKernelGGL((attention_fwd_mfma_kernel<MM_, DROP_, false>), g2, b2, 0, st, (const bf16_t*)q, (const bf16_t*)k, \
                                 (const bf16_t*)v, mask, causal, B, H, Lq, Lk, scale, (bf16_t*)out, lse, da);              \
