@@ -160,7 +160,8 @@ def main():
         out.append({"kernel": "attention_bwd", "what": name, "dtype": str(dtype), "B": B, "H": H, "Lq": Lq, "Lk": Lk,
                     "ms": ms, "torch_eager_fp32_ms": ref,
                     "roofline": {"bound": "mfma", "achieved": tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": tf / 2500.0}})
-    out.extend(train_step_bench(dev))
+    out.extend(train_step_bench(dev))               # RetroSyn: decoder length 160 (train_RetroSyn_tf.sh:33)
+    out.extend(train_step_bench(dev, T=7))          # RCR: BOS + 5 condition tokens + EOS (train_RCR.sh), launch-bound decoder
     out.extend(generate_bench(dev))
     for o in out:
         print(json.dumps(o))
