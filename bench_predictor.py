@@ -43,6 +43,7 @@ def train_step_bench(dev, steps=10, dtype=torch.bfloat16, L=512, T=160):
              "decoder_attention_mask": torch.ones(B, T, dtype=torch.long, device=dev)}
     batch["attention_mask"][::3, L * 4 // 5:] = 0
     for backend in ("hip", "torch"):      # the product, then the reference statement (oracle/nn_ref.py)
+        print("train_step_bench T=%d: %s" % (T, backend), file=sys.stderr, flush=True)
         enc = Config(vocab_size=31090)
         dec = Config(vocab_size=600, num_hidden_layers=6, type_vocab_size=1, layer_norm_eps=1e-5, is_decoder=True)
         torch.manual_seed(0)
@@ -80,7 +81,41 @@ def train_step_bench(dev, steps=10, dtype=torch.bfloat16, L=512, T=160):
                     "ms": ms_eval, "tokens_per_s": tokens / (ms_eval * 1e-3)})
         del p, opt
         torch.cuda.empty_cache()
+    # the same step captured once in a HIP graph and replayed (train.GraphedStep: device-side dropout seeds, capturable AdamW),
+    # in a child process: the runtime switch it needs (train.GRAPH_RUNTIME_ENV) is read when the HIP runtime starts
+    if dtype == torch.bfloat16:
+        import subprocess
+        env = dict(os.environ); env[train.GRAPH_RUNTIME_ENV[0]] = train.GRAPH_RUNTIME_ENV[1]
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--graph-row", str(T), str(steps)], env=env,
+                           capture_output=True, text=True, timeout=900)
+        rows = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not rows:
+            raise RuntimeError("graph row failed: " + r.stdout[-1000:] + r.stderr[-2000:])
+        res.extend(rows)
     return res
+
+
+def graph_row(dev, T, steps, L=512, B=32):
+    """train_step_bench's step through train.GraphedStep: 3 eager steps, the capture, then replays"""
+    from textreact_amd.predictor.model import Config
+    from textreact_amd.predictor import train
+    g = torch.Generator().manual_seed(0)
+    batch = {"input_ids": torch.randint(1, 31090, (B, L), generator=g).to(dev),
+             "attention_mask": torch.ones(B, L, dtype=torch.long, device=dev),
+             "decoder_input_ids": torch.randint(14, 600, (B, T), generator=g).to(dev),
+             "decoder_attention_mask": torch.ones(B, T, dtype=torch.long, device=dev)}
+    batch["attention_mask"][::3, L * 4 // 5:] = 0
+    enc = Config(vocab_size=31090)
+    dec = Config(vocab_size=600, num_hidden_layers=6, type_vocab_size=1, layer_norm_eps=1e-5, is_decoder=True)
+    torch.manual_seed(0)
+    p = train.Predictor(enc, dec, mlm=False).to(dev).train()
+    opt, _ = train.configure_optimizer(p, 1e-4, 0.01, 1000, 0.02, capturable=True)
+    gs = train.GraphedStep(p, opt, max_grad_norm=None, autocast_dtype=torch.bfloat16)
+    ms = timeit(lambda: gs.step(batch), iters=steps, warm=6)
+    assert gs.replays >= steps, gs.replays
+    gs.close()
+    return {"kernel": "train_step", "ops": "hip, whole step replayed from one HIP graph", "dtype": "bf16 autocast", "B": B, "L": L, "T": T,
+            "ms": ms, "tokens_per_s": B * (L + T) / (ms * 1e-3), "env": "%s=%s" % train.GRAPH_RUNTIME_ENV}
 
 
 def generate_bench(dev, B=8):
@@ -160,12 +195,17 @@ def main():
         out.append({"kernel": "attention_bwd", "what": name, "dtype": str(dtype), "B": B, "H": H, "Lq": Lq, "Lk": Lk,
                     "ms": ms, "torch_eager_fp32_ms": ref,
                     "roofline": {"bound": "mfma", "achieved": tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": tf / 2500.0}})
-    out.extend(train_step_bench(dev))               # RetroSyn: decoder length 160 (train_RetroSyn_tf.sh:33)
-    out.extend(train_step_bench(dev, T=7))          # RCR: BOS + 5 condition tokens + EOS (train_RCR.sh), launch-bound decoder
-    out.extend(generate_bench(dev))
     for o in out:
-        print(json.dumps(o))
+        print(json.dumps(o), flush=True)
+    for rows in (lambda: train_step_bench(dev),              # RetroSyn: decoder length 160 (train_RetroSyn_tf.sh:33)
+                 lambda: train_step_bench(dev, T=7),         # RCR: BOS + 5 condition tokens + EOS (train_RCR.sh)
+                 lambda: generate_bench(dev)):
+        for o in rows():
+            print(json.dumps(o), flush=True)
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "--graph-row":
+        print(json.dumps(graph_row(torch.device("cuda", 0), int(sys.argv[2]), int(sys.argv[3]))), flush=True)
+    else:
+        main()

@@ -125,6 +125,22 @@ int trx_attention_bwd_strided(const void* q, const void* k, const void* v, const
 /* keep[streams][rows][cols] (1 = kept) exactly as the kernels above decide for (seed, p). */
 int trx_dropout_keep_mask(uint64_t seed, float p, int64_t streams, int64_t rows, int64_t cols, unsigned char* keep, void* stream);
 
+/* Device-side seed source (process-wide; NULL = off, the default).  While a pointer is set, every dropout launch above
+ * passes it along and its kernels use mix(*seed_dev, seed) as their seed: `seed` then only numbers the dropout site, and
+ * the uint64 behind the pointer -- which the caller bumps once per optimisation step, on the stream -- makes the
+ * decisions differ from step to step while the launch arguments stay the same.  This is what lets one HIP graph of the
+ * whole training step (forward, backward, optimizer) be replayed: textreact_amd/predictor/train.py: GraphedStep.
+ * trx_dropout_keep_mask follows the same rule, so a reference can still materialise the decisions. */
+int trx_nn_set_seed_device(const uint64_t* seed_dev);
+
+/* trx_attention_bwd_dropout / _strided with the caller's scratch for the matrix-core path's per-query scalars
+ * (trx_attention_bwd_ws_bytes(B, H, Lq) bytes, device memory; NULL = a stream-ordered allocation inside the call,
+ * which a stream capture cannot record).  ldq = ldkv = 0: dense operands; dtype as above. */
+int64_t trx_attention_bwd_ws_bytes(int B, int H, int Lq);
+int trx_attention_bwd_ws(const void* q, const void* k, const void* v, const float* mask, int mask_mode, int causal,
+                         int B, int H, int Lq, int Lk, int ldq, int ldkv, float scale, int dtype, float p, uint64_t seed,
+                         const void* out, const void* dout, const float* lse, void* dq, void* dk, void* dv, void* ws, void* stream);
+
 /* C[N, K] = A[M, N]^T . B[M, K]: bf16 operands and result, fp32 accumulation -- the weight gradient of a Linear
  * layer, dW = dY^T X, with the contraction over the M token rows split across workgroups (fp32 partial tiles in
  * ws, summed in a fixed order).  Any M >= 1 (the rows past M of the last 64-row step read as zeros), N % 256 == 0, K % 256 == 0, lda / ldb % 8 == 0, ldc % 4 == 0, A, B, ws

@@ -7,11 +7,14 @@ import json
 import os
 import re
 import shlex
+import sys
 
 import pytest
 import torch
 
 from textreact_amd import main as M
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 REF_SCRIPTS = "/root/reference/scripts"
 
@@ -187,6 +190,31 @@ def test_train_and_test_through_the_hip_ops(tmp_path, capsys):
         pred = json.loads((out / "prediction_test_0.json").read_text())
         assert sorted(pred) == ["100", "101", "102", "103"] and len(pred["100"]["prediction"]) == 3
     assert '"val_loss/1"' in capsys.readouterr().out
+
+
+@pytest.mark.gpu
+def test_train_with_the_step_replayed_from_a_hip_graph(tmp_path):
+    """--hip_graph_step: three epochs of two full batches each; the first three steps run eagerly, the fourth is captured,
+    the rest replay it; validation, checkpoints and the test step as always.  A child process, as a user starts the trainer:
+    main() selects the runtime's graph path (train.prepare_graph_runtime) before anything touches the GPU"""
+    import subprocess
+    argv = _toy(tmp_path)
+    for name in ("enc.json", "dec.json"):
+        cfg = json.loads((tmp_path / name).read_text())
+        cfg.update(hidden_size=256, num_attention_heads=4, intermediate_size=512, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+        (tmp_path / name).write_text(json.dumps(cfg))
+    out = tmp_path / "out"
+    env = {k: v for k, v in os.environ.items() if k != "DEBUG_CLR_GRAPH_PACKET_CAPTURE"}
+    r = subprocess.run([sys.executable, "-m", "textreact_amd.main"] + argv +
+                       ["--epochs", "3", "--do_train", "--do_valid", "--do_test", "--overwrite", "--precision", "bf16-mixed",
+                        "--hip_graph_step", "--print_freq", "4"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    ck = torch.load(out / "last.ckpt", weights_only=False)
+    assert ck["global_step"] == 6 and ck["epoch"] == 2
+    assert all(torch.isfinite(v).all() for v in ck["state_dict"].values() if v.is_floating_point())
+    assert len(re.findall(r"train_loss ([0-9.]+)", r.stdout)) >= 1
+    pred = json.loads((out / "prediction_test_0.json").read_text())
+    assert sorted(pred) == ["100", "101", "102", "103"]
 
 
 def _toy_template(tmp_path, seed=0):

@@ -911,3 +911,66 @@ def test_ping_pong_forward_kernel():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "attn_fuzz.py"), "60", "5"], capture_output=True, text=True,
                        timeout=600, env=dict(os.environ, TRX_NN_ATTN_PP="1"))
     assert r.returncode == 0 and "0 failures" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def _graph_case(seed=0):
+    from textreact_amd.predictor import train
+    enc = dict(vocab_size=300, hidden_size=256, num_hidden_layers=2, num_attention_heads=4, intermediate_size=512, max_position_embeddings=64)
+    dec = dict(vocab_size=40, hidden_size=256, num_hidden_layers=2, num_attention_heads=4, intermediate_size=512, max_position_embeddings=64,
+               type_vocab_size=1, layer_norm_eps=1e-5)
+    torch.manual_seed(seed)
+    p = train.Predictor(Config(**enc), Config(is_decoder=True, **dec), mlm=True, mlm_lambda=0.1).cuda().train()
+    g = torch.Generator().manual_seed(1)
+    batches = []
+    for _ in range(9):
+        ids = torch.randint(1, 300, (6, 40), generator=g).cuda(); dids = torch.randint(3, 40, (6, 9), generator=g).cuda()
+        batches.append(({"input_ids": ids, "attention_mask": torch.ones_like(ids), "decoder_input_ids": dids, "decoder_attention_mask": torch.ones_like(dids)},
+                        {"mlm_labels": torch.randint(0, 300, (6, 5), generator=g).cuda()}))
+    return train, p, batches
+
+
+def test_device_seed_dropout_hip_equals_the_reference_statement():
+    """ops.set_seed_device: a launch's seed only numbers the site, the kernels mix it with a device counter -- the materialised
+    decisions (trx_dropout_keep_mask) follow the same rule, so the PyTorch statement still drops the same elements"""
+    seed_t = torch.tensor([123456789], dtype=torch.int64, device="cuda")
+    ops.set_seed_device(seed_t)
+    try:
+        q, k, v = (_rand(2, 70, 3, 64, dtype=torch.bfloat16, seed=s_) for s_ in (1, 2, 3))
+        x, r = _rand(50, 768, seed=4), _rand(50, 768, seed=5)
+        gm, bt = _rand(768, seed=6) * 0.1 + 1, _rand(768, seed=7) * 0.1
+        outs = {}
+        for step_value in (5, 6):
+            seed_t.fill_(step_value)
+            for backend in ("hip", "torch"):
+                with nn_ref.implementation(backend):
+                    a = ops.attention(q if backend == "hip" else q.float(), k if backend == "hip" else k.float(),
+                                      v if backend == "hip" else v.float(), dropout_p=0.3, seed=7)
+                    y = ops.add_layernorm(x, r, gm, bt, 1e-12, dropout_p=0.3, seed=8)
+                outs[(step_value, backend)] = (a.float(), y)
+            assert float((outs[(step_value, "hip")][0] - outs[(step_value, "torch")][0]).abs().max()) <= 3e-2
+            assert float((outs[(step_value, "hip")][1] - outs[(step_value, "torch")][1]).abs().max()) <= 1e-4
+        assert float((outs[(5, "hip")][1] - outs[(6, "hip")][1]).abs().max()) > 0.1       # the counter moved: other decisions
+    finally:
+        ops.set_seed_device(None)
+
+
+def test_graphed_step_equals_the_eager_steps():
+    """train.GraphedStep: 3 eager steps, a capture, 5 replays -- against the same 9 steps all run eagerly with the same
+    device-side seeds: the losses agree step by step and the parameters end up the same.  Runs in a child process: the
+    runtime switch GraphedStep needs (train.GRAPH_RUNTIME_ENV) is read when the HIP runtime starts."""
+    import subprocess, sys
+    from textreact_amd.predictor import train
+    env = dict(os.environ); env[train.GRAPH_RUNTIME_ENV[0]] = train.GRAPH_RUNTIME_ENV[1]
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "graphed_step_case.py")],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "graphed step: ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_graphed_step_refuses_a_runtime_that_was_started_without_its_switch():
+    from textreact_amd.predictor import train
+    if os.environ.get(train.GRAPH_RUNTIME_ENV[0]) == train.GRAPH_RUNTIME_ENV[1]:
+        pytest.skip("this process was started with the switch")
+    _, p, _ = _graph_case()
+    opt, _ = train.configure_optimizer(p, 1e-3, 0.01, 100, 0.1, capturable=True)
+    with pytest.raises(ops.TrxNNError, match=train.GRAPH_RUNTIME_ENV[0]):
+        train.GraphedStep(p, opt)

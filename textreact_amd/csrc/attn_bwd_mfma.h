@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     constexpr bool keymask = MM == TRX_NN_MASK_KEY;
     const float* mkey = keymask ? mask + (int64_t)b * Lk : nullptr;
     // dropout hash input of (this lane's query, key pair 0) -- the same function the forward evaluated
-    const unsigned xdrop = DROP ? drop_base(da.seed_lo, da.seed_hi, (unsigned)(b * H + h)) + (unsigned)qidx * DROP_C1 + (unsigned)(2 * hh) * DROP_C2 : 0u;
+    const unsigned xdrop = DROP ? drop_base_da(da, (unsigned)(b * H + h)) + (unsigned)qidx * DROP_C1 + (unsigned)(2 * hh) * DROP_C2 : 0u;
 
     const int prow = lane >> 3, pslot = lane & 7;
     const unsigned rowbytes = (unsigned)ldk * 2u;
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int qmin = causal ? kidx - off : 0;                       // this lane's key is visible to queries >= qmin
     const int qmin_wave_max = causal ? kblk * 128 + wave * 32 + 31 - off : 0;
     // dropout hash input of (query 4 hh, this lane's key pair); the key's half of the hash is bit 4 of dshift
-    const unsigned xdrop = DROP ? drop_base(da.seed_lo, da.seed_hi, (unsigned)(b * H + h)) + (unsigned)(4 * hh) * DROP_C1 + ((unsigned)kc >> 1) * DROP_C2 : 0u;
+    const unsigned xdrop = DROP ? drop_base_da(da, (unsigned)(b * H + h)) + (unsigned)(4 * hh) * DROP_C1 + ((unsigned)kc >> 1) * DROP_C2 : 0u;
     const unsigned dshift = ((unsigned)kc & 1u) << 4;
 
     const int prow = lane >> 3, pslot = lane & 7;

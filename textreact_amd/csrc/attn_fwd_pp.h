@@ -133,7 +133,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int s = 0; s < 4; ++s) kfa[s] = ldsbase + (unsigned)(r * 128 + (((2 * s + hh) ^ kswz) << 4));
     constexpr bool keymask = MM == TRX_NN_MASK_KEY;
-    const unsigned xdrop = DROP ? drop_base(da.seed_lo, da.seed_hi, (unsigned)(b * H + h)) + (unsigned)qidx * DROP_C1 + (unsigned)(2 * hh) * DROP_C2 : 0u;
+    const unsigned xdrop = DROP ? drop_base_da(da, (unsigned)(b * H + h)) + (unsigned)qidx * DROP_C1 + (unsigned)(2 * hh) * DROP_C2 : 0u;
 
     // ---- prologue: the key mask of all <= 1024 keys (its loads first: they are consumed first), tiles 0, 1, 2 in flight (group A) ----
     float mv_[4] = {0.f, 0.f, 0.f, 0.f};

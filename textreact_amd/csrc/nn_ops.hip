@@ -25,18 +25,34 @@ int fail(int code, const std::string& m) { g_err = m; return code; }
 // passes and trx_dropout_keep_mask evaluate the same function, nothing is stored.  One 32-bit hash
 // (lowbias32, two multiply-xorshift rounds) serves the two columns 2c, 2c+1 with 16 bits each;
 // an element is dropped when its 16 bits are below thr = round(p * 65536).
-struct Drop { unsigned base, thr; float inv_keep; };   // thr == 0: dropout off
+// Seed source.  By default a launch carries its 64-bit seed by value.  With trx_nn_set_seed_device(ptr) every dropout launch
+// carries ptr as well and its kernels take  mix(*ptr, seed)  as the seed: `seed` then only numbers the dropout site, and
+// the value behind ptr -- bumped once per optimisation step by the caller, on the stream -- makes the decisions change from
+// step to step although the launch arguments do not: what a HIP graph of the whole training step needs.
+__host__ __device__ __forceinline__ unsigned long long mix_seed(unsigned long long dev, unsigned long long site) {
+    unsigned long long z = dev + site * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+struct Drop { unsigned base, thr; float inv_keep; const unsigned long long* seed_dev; unsigned seed_lo, seed_hi; };   // thr == 0: dropout off
 // attention: the dropout base is per (batch, head).  kv_bs: elements between consecutive batch items of k and
 // of v (0 = dense, Lk * H * 64); set by the key/value-cache entry point, forward kernels only
 // ldq / ldk: elements between consecutive rows (tokens) of q and of k / v (0 = dense, H * 64): operands that are
 // slices of one packed projection output [B, L, 3 * H * 64]; matrix-core kernels only
-struct DropArgs { unsigned seed_lo, seed_hi, thr; float inv_keep; long long kv_bs; int ldq, ldk; };
+struct DropArgs { unsigned seed_lo, seed_hi, thr; float inv_keep; long long kv_bs; int ldq, ldk; const unsigned long long* seed_dev; };
 __host__ __device__ __forceinline__ unsigned lowbias32(unsigned x) {
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
     return x;
 }
 __host__ __device__ __forceinline__ unsigned drop_base(unsigned seed_lo, unsigned seed_hi, unsigned stream) {
     return lowbias32(seed_lo ^ lowbias32(seed_hi + stream * 0x9E3779B9u));
+}
+// the seed a kernel uses: the launch's own, or mixed with the device-side value (see mix_seed)
+__device__ __forceinline__ unsigned drop_base_da(const DropArgs& da, unsigned stream) {
+    unsigned lo = da.seed_lo, hi = da.seed_hi;
+    if (da.seed_dev) { const unsigned long long s = mix_seed(*da.seed_dev, ((unsigned long long)hi << 32) | lo); lo = (unsigned)s; hi = (unsigned)(s >> 32); }
+    return drop_base(lo, hi, stream);
 }
 constexpr unsigned DROP_C1 = 0x9E3779B1u, DROP_C2 = 0x85EBCA77u;
 __device__ __forceinline__ unsigned drop_bits(unsigned base, unsigned row, unsigned colpair) {
@@ -49,6 +65,14 @@ __device__ __forceinline__ float drop_mult(const Drop& d, unsigned row, unsigned
     if (d.thr == 0) return 1.f;
     return drop_keep(drop_bits(d.base, row, col >> 1), col, d.thr) ? d.inv_keep : 0.f;
 }
+__device__ __forceinline__ Drop resolve_drop(Drop d) {     // add+LayerNorm kernels: the base of stream 0
+    if (d.seed_dev) {
+        const unsigned long long s = mix_seed(*d.seed_dev, ((unsigned long long)d.seed_hi << 32) | d.seed_lo);
+        d.base = drop_base((unsigned)s, (unsigned)(s >> 32), 0u);
+    }
+    return d;
+}
+static const unsigned long long* g_seed_dev = nullptr;       // trx_nn_set_seed_device
 unsigned drop_thr(float p) {
     const long t = lrintf(p * 65536.0f);
     return (unsigned)(t < 0 ? 0 : (t > 65535 ? 65535 : t));
@@ -57,11 +81,13 @@ Drop make_drop(float p, uint64_t seed, unsigned stream) {
     Drop d;
     d.thr = p > 0.f ? drop_thr(p) : 0u;
     d.base = drop_base((unsigned)seed, (unsigned)(seed >> 32), stream);
+    d.seed_dev = g_seed_dev; d.seed_lo = (unsigned)seed; d.seed_hi = (unsigned)(seed >> 32);
     d.inv_keep = 1.0f / (1.0f - p);
     return d;
 }
 __global__ void dropout_keep_mask_kernel(unsigned seed_lo, unsigned seed_hi, unsigned thr, int64_t streams, int64_t rows,
-                                         int64_t cols, unsigned char* __restrict__ keep) {
+                                         int64_t cols, unsigned char* __restrict__ keep, const unsigned long long* seed_dev) {
+    if (seed_dev) { const unsigned long long s = mix_seed(*seed_dev, ((unsigned long long)seed_hi << 32) | seed_lo); seed_lo = (unsigned)s; seed_hi = (unsigned)(s >> 32); }
     const int64_t n = streams * rows * cols;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t col = i % cols, sr = i / cols;
@@ -132,8 +158,9 @@ __device__ __forceinline__ uint2 pack8bf(const float* f) { return make_uint2(pac
 template <bool BF, bool MIX>
 __global__ __launch_bounds__(256) void add_ln_fwd_vec_kernel(const void* x, const void* res, const float* gamma,
                                                              const float* beta, float eps, int64_t rows, int cols,
-                                                             void* y, float* mean, float* rstd, Drop drop, void* y16 = nullptr,
+                                                             void* y, float* mean, float* rstd, Drop drop_in, void* y16 = nullptr,
                                                              const float* xbias = nullptr) {
+    const Drop drop = resolve_drop(drop_in);
     constexpr int V = Vec16<BF>::N;
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -200,7 +227,8 @@ __global__ __launch_bounds__(256) void add_ln_fwd_vec_kernel(const void* x, cons
 template <bool BF>
 __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const void* x, const void* res, const float* gamma,
                                                          const float* beta, float eps, int64_t rows, int cols,
-                                                         void* y, float* mean, float* rstd, Drop drop) {
+                                                         void* y, float* mean, float* rstd, Drop drop_in) {
+    const Drop drop = resolve_drop(drop_in);
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -247,7 +275,8 @@ constexpr int BWD_MAX_BLOCKS = 768;   // workgroups of 4 waves, rows dealt round
 template <bool BF>
 __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const void* dy, const void* x, const void* res,
                                                          const float* gamma, const float* mean, const float* rstd,
-                                                         int64_t rows, int cols, void* dz, void* dx, float* ws, int nblk, Drop drop) {
+                                                         int64_t rows, int cols, void* dz, void* dx, float* ws, int nblk, Drop drop_in) {
+    const Drop drop = resolve_drop(drop_in);
     extern __shared__ float sm[];  // [4 waves][2][cols]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float* pg = sm + (wave * 2) * cols;
@@ -289,8 +318,9 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const void* dy, const v
 template <bool BF, bool MIX>
 __global__ __launch_bounds__(256) void add_ln_bwd_vec_kernel(const void* dy, const void* x, const void* res,
                                                              const float* gamma, const float* mean, const float* rstd,
-                                                             int64_t rows, int cols, void* dz, void* dx, float* ws, int nblk, Drop drop,
+                                                             int64_t rows, int cols, void* dz, void* dx, float* ws, int nblk, Drop drop_in,
                                                              const void* dy16 = nullptr, const float* xbias = nullptr) {
+    const Drop drop = resolve_drop(drop_in);
     extern __shared__ float sm[];  // [4 waves][2][cols]
     constexpr int V = Vec16<BF>::N;
     constexpr int ES = BF ? 2 : 4;
@@ -464,7 +494,7 @@ __global__ __launch_bounds__(64) void attention_fwd_kernel(const void* __restric
     const int i = qb * 64 + threadIdx.x;
     const bool live = i < Lq;
     const int ii = live ? i : Lq - 1;
-    const unsigned dbase = DROP ? drop_base(da.seed_lo, da.seed_hi, (unsigned)(b * H + h)) : 0u;
+    const unsigned dbase = DROP ? drop_base_da(da, (unsigned)(b * H + h)) : 0u;
     const int64_t kvbs = da.kv_bs ? da.kv_bs : (int64_t)Lk * H * DH;
     float qr[DH], o[DH];
     const int64_t qoff = (((int64_t)b * Lq + ii) * H + h) * DH;
@@ -776,7 +806,7 @@ __global__ __launch_bounds__(XW ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
     constexpr bool keymask = MM == TRX_NN_MASK_KEY;
     const float* mkey = keymask ? mask + (int64_t)b * Lk : nullptr;
     // dropout hash input of (this lane's query, key pair 0): + 2 hh because register t's key is ... + 4 hh
-    const unsigned xdrop = DROP ? drop_base(da.seed_lo, da.seed_hi, (unsigned)(b * H + h)) + (unsigned)qidx * DROP_C1 + (unsigned)(2 * hh) * DROP_C2 : 0u;
+    const unsigned xdrop = DROP ? drop_base_da(da, (unsigned)(b * H + h)) + (unsigned)qidx * DROP_C1 + (unsigned)(2 * hh) * DROP_C2 : 0u;
 
     // the key mask of tiles 16j .. 16j+15 is (re)loaded when tile 16j starts: 4 keys per thread
 #define TRX_MASK_FILL(KB)                                                                                   \
@@ -937,7 +967,7 @@ __global__ __launch_bounds__(64) void attention_bwd_dq_kernel(const void* __rest
     const int i = qb * 64 + threadIdx.x;
     const bool live = i < Lq;
     const int ii = live ? i : Lq - 1;
-    const unsigned dbase = DROP ? drop_base(da.seed_lo, da.seed_hi, (unsigned)(b * H + h)) : 0u;
+    const unsigned dbase = DROP ? drop_base_da(da, (unsigned)(b * H + h)) : 0u;
     float qr[DH], dor[DH], acc[DH];
     const int64_t qoff = (((int64_t)b * Lq + ii) * H + h) * DH;
     const int64_t ooff = ((int64_t)b * Lq + ii) * H * DH + (int64_t)h * DH;
@@ -978,7 +1008,7 @@ __global__ __launch_bounds__(64) void attention_bwd_dkv_kernel(const void* __res
     const int kblocks = (Lk + 63) / 64;
     const int bid = blockIdx.x;
     const int kb = bid % kblocks, h = (bid / kblocks) % H, b = bid / (kblocks * H);
-    const unsigned dbase = DROP ? drop_base(da.seed_lo, da.seed_hi, (unsigned)(b * H + h)) : 0u;
+    const unsigned dbase = DROP ? drop_base_da(da, (unsigned)(b * H + h)) : 0u;
     const int j = kb * 64 + threadIdx.x;
     const bool live = j < Lk;
     const int jj = live ? j : Lk - 1;
@@ -1028,6 +1058,7 @@ extern "C" {
 
 const char* trx_nn_last_error(void) { return g_err.c_str(); }
 const char* trx_nn_version(void) { return "trxnn 0.1 (gfx950)"; }
+int trx_nn_set_seed_device(const uint64_t* seed_dev) { g_seed_dev = reinterpret_cast<const unsigned long long*>(seed_dev); return TRX_NN_OK; }
 int trx_add_layernorm_bwd_blocks(int64_t rows) { const int64_t b = (rows + 3) / 4; return (int)(b < 1 ? 1 : (b > BWD_MAX_BLOCKS ? BWD_MAX_BLOCKS : b)); }
 
 int trx_add_layernorm_fwd_dropout(const void* x, const void* res, const float* gamma, const float* beta, float eps,
@@ -1141,7 +1172,7 @@ int trx_dropout_keep_mask(uint64_t seed, float p, int64_t streams, int64_t rows,
     const int64_t n = streams * rows * cols;
     const unsigned grid = (unsigned)((n + 255) / 256 > 65536 ? 65536 : (n + 255) / 256);
     hipLaunchKernelGGL(dropout_keep_mask_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (unsigned)seed, (unsigned)(seed >> 32),
-                       p > 0.f ? drop_thr(p) : 0u, streams, rows, cols, keep);
+                       p > 0.f ? drop_thr(p) : 0u, streams, rows, cols, keep, g_seed_dev);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? TRX_NN_OK : fail(TRX_NN_EHIP, hipGetErrorString(e));
 }
@@ -1149,6 +1180,7 @@ int trx_dropout_keep_mask(uint64_t seed, float p, int64_t streams, int64_t rows,
 static DropArgs make_drop_args(float p, uint64_t seed) {
     DropArgs a;
     a.seed_lo = (unsigned)seed; a.seed_hi = (unsigned)(seed >> 32);
+    a.seed_dev = g_seed_dev;
     a.thr = p > 0.f ? drop_thr(p) : 0u;
     a.inv_keep = 1.0f / (1.0f - p);
     a.kv_bs = 0;
@@ -1249,7 +1281,8 @@ int trx_attention_fwd(const void* q, const void* k, const void* v, const float* 
 
 static int attention_bwd_impl(const void* q, const void* k, const void* v, const float* mask, int mask_mode, int causal,
                               int B, int H, int Lq, int Lk, float scale, int dtype, float p, uint64_t seed, const void* out,
-                              const void* dout, const float* lse, void* dq, void* dk, void* dv, void* stream, int ldq, int ldk) {
+                              const void* dout, const float* lse, void* dq, void* dk, void* dv, void* stream, int ldq, int ldk,
+                              void* ws_user = nullptr) {
     if ((ldq || ldk) && (dtype != TRX_NN_BF16 || getenv("TRX_NN_ATTN_VALU")))
         return fail(TRX_NN_EINVAL, "attention_bwd: strided operands are supported by the bf16 matrix-core path only");
     if ((ldq && ldq < H * 64) || (ldk && ldk < H * 64) || ((ldq | ldk) & 7))
@@ -1269,8 +1302,8 @@ static int attention_bwd_impl(const void* q, const void* k, const void* v, const
     if (dtype == TRX_NN_BF16 && !force_valu) {
         // matrix-core path; its per-query scalars (-lse/scale, -delta) live in a stream-ordered scratch
         const size_t n = (size_t)B * H * Lq;
-        float* ws = nullptr;
-        if (hipMallocAsync((void**)&ws, 2 * n * sizeof(float), st) != hipSuccess || !ws) {
+        float* ws = (float*)ws_user;        // caller's scratch (2 B H Lq floats: trx_attention_bwd_ws); else a stream-ordered one
+        if (!ws && (hipMallocAsync((void**)&ws, 2 * n * sizeof(float), st) != hipSuccess || !ws)) {
             (void)hipGetLastError();
             return fail(TRX_NN_EHIP, "attention_bwd: scratch allocation failed");
         }
@@ -1294,7 +1327,7 @@ static int attention_bwd_impl(const void* q, const void* k, const void* v, const
         }
 #undef TRX_LAUNCH_BWD
         hipError_t e1 = hipGetLastError();
-        (void)hipFreeAsync(ws, st);
+        if (!ws_user) (void)hipFreeAsync(ws, st);
         if (e1 != hipSuccess) return fail(TRX_NN_EHIP, hipGetErrorString(e1));
         return TRX_NN_OK;
     }
@@ -1326,6 +1359,14 @@ int trx_attention_bwd_strided(const void* q, const void* k, const void* v, const
                               int B, int H, int Lq, int Lk, int ldq, int ldkv, float scale, float p, uint64_t seed, const void* out,
                               const void* dout, const float* lse, void* dq, void* dk, void* dv, void* stream) {
     return attention_bwd_impl(q, k, v, mask, mask_mode, causal, B, H, Lq, Lk, scale, TRX_NN_BF16, p, seed, out, dout, lse, dq, dk, dv, stream, ldq, ldkv);
+}
+
+int64_t trx_attention_bwd_ws_bytes(int B, int H, int Lq) { return (int64_t)2 * B * H * Lq * (int64_t)sizeof(float); }
+
+int trx_attention_bwd_ws(const void* q, const void* k, const void* v, const float* mask, int mask_mode, int causal,
+                         int B, int H, int Lq, int Lk, int ldq, int ldkv, float scale, int dtype, float p, uint64_t seed, const void* out,
+                         const void* dout, const float* lse, void* dq, void* dk, void* dv, void* ws, void* stream) {
+    return attention_bwd_impl(q, k, v, mask, mask_mode, causal, B, H, Lq, Lk, scale, dtype, p, seed, out, dout, lse, dq, dk, dv, stream, ldq, ldkv, ws);
 }
 
 int trx_attention_decode_gather(const void* q, int ldq, const void* kv, const int32_t* anc, const int64_t* t_dev, void* out, int n, int H,

@@ -127,6 +127,9 @@ def get_parser():
     p.add_argument('--tok_pad_id', type=int, default=0)
     p.add_argument('--tok_atom_templates', type=int, default=None)
     p.add_argument('--tok_bond_templates', type=int, default=None)
+    p.add_argument('--hip_graph_step', action='store_true',
+                   help="replay the optimisation step from a HIP graph captured once per batch shape (predictor/train.py: "
+                        "GraphedStep): single process, no fp16 loss scaling, no gradient accumulation")
     p.add_argument('--live_every', type=int, default=0, help="re-embed the corpus and re-retrieve every N epochs (0 = off)")
     p.add_argument('--live_corpus', type=str, default=None, help="pre-tokenised corpus passages (textreact_amd/live.py)")
     p.add_argument('--live_k', type=int, default=None, help="neighbours retrieved per query (default 2 x --max_num_neighbors)")
@@ -335,6 +338,8 @@ def main(argv=None):
     from .predictor import ops, train as T
     import torch.distributed as dist
 
+    if args.hip_graph_step:
+        T.prepare_graph_runtime()     # an environment switch the HIP runtime reads when it starts: before anything touches the GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -401,8 +406,18 @@ def main(argv=None):
         num_training_steps = steps_per_epoch * args.epochs                                  # main.py:383-384
         if rank == 0:
             print("Num training steps: %d" % num_training_steps)
+        graphed = bool(args.hip_graph_step)
+        if graphed and (world > 1 or str(args.precision).startswith("16") or args.gradient_accumulation_steps != 1 or args.template_based):
+            if rank == 0:
+                print("note: --hip_graph_step needs one process, bf16 / fp32 precision, no gradient accumulation and the "
+                      "template-free model: running the step eagerly", file=sys.stderr)
+            graphed = False
         opt, sched = T.configure_optimizer(module, args.lr, args.weight_decay, num_training_steps, args.warmup_ratio,
-                                           scheduler=args.scheduler)
+                                           scheduler=args.scheduler, capturable=graphed)
+        gstep = None
+        if graphed:
+            ac = torch.bfloat16 if str(args.precision).startswith("bf16") else None
+            gstep = T.GraphedStep(module, opt, max_grad_norm=args.max_grad_norm, autocast_dtype=ac)
         start_epoch, global_step = 0, 0
         mode = METRIC_TO_MODE[args.val_metric]
         best = None
@@ -445,6 +460,14 @@ def main(argv=None):
                     if ep_mlm is not None:
                         batch_in["position_ids"] = ep_pos[sl, :w]
                         batch_out = {"mlm_labels": ep_mlm[sl, :max(1, int(ep_cnt_h[sl].max()))]}
+                if gstep is not None:       # forward, backward, clipping and the update: one graph replay
+                    total, logs = gstep.step(batch_in, batch_out)
+                    sched.step()
+                    global_step += 1
+                    if rank == 0 and global_step % max(1, args.print_freq) == 0:
+                        print("epoch %d step %d train_loss %.4f lr %.3g" % (epoch, global_step, float(logs["train_loss"]),
+                                                                            float(sched.get_last_lr()[0])))
+                    continue
                 with _autocast(args, device):
                     total, logs = module.training_step(batch_in, batch_out)
                 (scaler.scale(total / args.gradient_accumulation_steps)).backward()
@@ -490,6 +513,8 @@ def main(argv=None):
                 T.save_checkpoint(last_path, module, opt, sched, epoch, global_step, monitor=args.val_metric)
             if world > 1:
                 dist.barrier()
+        if gstep is not None:
+            gstep.close()
         best_model_path = best_path if os.path.isfile(best_path) else last_path
 
     if args.do_valid or args.do_test:

@@ -260,6 +260,7 @@ class TextReactModel(nn.Module):
         enc = self.encoder(input_ids, key, position_ids, token_type_ids, full)
         dmask = additive_key_mask(decoder_attention_mask) if decoder_attention_mask is not None else None
         enc_low = self.encoder.last_low
+        self.encoder.last_low = None       # (a tensor kept on the module would keep this pass's autograd graph alive into the next one)
         h = self.decoder.roberta.embeddings(decoder_input_ids, None, None)
         h_low = h
         for layer in self.decoder.roberta.encoder.layer:

@@ -21,7 +21,8 @@ SYMBOLS = ["trx_add_layernorm_fwd", "trx_add_layernorm_bwd", "trx_add_layernorm_
            "trx_add_layernorm_fwd_dropout", "trx_add_layernorm_bwd_dropout", "trx_attention_fwd_dropout",
            "trx_attention_bwd_dropout", "trx_dropout_keep_mask", "trx_add_layernorm_fwd_mixed",
            "trx_add_layernorm_bwd_mixed", "trx_attention_fwd_kvcache", "trx_attention_fwd_strided",
-           "trx_attention_bwd_strided", "trx_attention_decode_gather", "trx_gemm_tn_bf16", "trx_gemm_tn_ws_bytes", "trx_nn_last_error", "trx_nn_version"]
+           "trx_attention_bwd_strided", "trx_attention_decode_gather", "trx_gemm_tn_bf16", "trx_gemm_tn_ws_bytes", "trx_nn_last_error", "trx_nn_version",
+           "trx_nn_set_seed_device", "trx_attention_bwd_ws", "trx_attention_bwd_ws_bytes"]
 
 
 class TrxNNError(RuntimeError):
@@ -58,6 +59,11 @@ def lib():
         L.trx_gemm_tn_ws_bytes.argtypes = [i32, i32, i32]
         L.trx_gemm_tn_ws_bytes.restype = i64
         L.trx_gemm_tn_bf16.argtypes = [vp, i32, vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, vp]
+        L.trx_nn_set_seed_device.argtypes = [vp]
+        L.trx_attention_bwd_ws_bytes.argtypes = [i32, i32, i32]
+        L.trx_attention_bwd_ws_bytes.restype = i64
+        L.trx_attention_bwd_ws.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, i32, f32, u64,
+                                           vp, vp, vp, vp, vp, vp, vp, vp]
         L.trx_nn_last_error.restype = ctypes.c_char_p
         L.trx_nn_version.restype = ctypes.c_char_p
         _lib = L
@@ -104,12 +110,23 @@ def _stream(t):
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
-_seed_state = {"base": None, "n": 0}
+_seed_state = {"base": None, "n": 0, "device": None, "free": 0}
 _M64 = (1 << 64) - 1
 
 
 def _draw_seed():
     return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+
+
+def set_seed_device(t):
+    """device-side seed source (include/trx_nn.h: trx_nn_set_seed_device): `t` = an int64 tensor [1] on the GPU, or None to
+    go back to host seeds.  While set, a dropout site's `seed` is just its number inside the forward pass (no draw from the
+    host generator, the same arguments every step) and the kernels mix it with the value in `t`, which the training step
+    bumps on the stream: the step can then be captured in a HIP graph and replayed (train.GraphedStep)."""
+    if t is not None and not (t.is_cuda and t.dtype == torch.int64 and t.numel() == 1):
+        raise TrxNNError("set_seed_device: an int64 tensor with one element on the GPU")
+    _check(lib().trx_nn_set_seed_device(_p(t)))
+    _seed_state["device"] = t
 
 
 class seed_scope:
@@ -120,7 +137,8 @@ class seed_scope:
 
     def __enter__(self):
         self.prev = (_seed_state["base"], _seed_state["n"])
-        _seed_state["base"], _seed_state["n"] = _draw_seed(), 0
+        # device seeds: the sites of a pass are numbered 1, 2, ... (no host randomness: the pass may be a graph capture)
+        _seed_state["base"], _seed_state["n"] = (0 if _seed_state["device"] is not None else _draw_seed()), 0
         return self
 
     def __exit__(self, *exc):
@@ -131,6 +149,12 @@ class seed_scope:
 def new_seed():
     """a fresh 62-bit dropout seed (see seed_scope)"""
     st = _seed_state
+    if st["device"] is not None:
+        if st["base"] is None:          # outside a scope: still a distinct site number
+            st["free"] += 1
+            return (1 << 40) + st["free"]
+        st["n"] += 1
+        return st["n"]
     if st["base"] is None:
         return _draw_seed()
     st["n"] += 1
@@ -318,9 +342,10 @@ def _attention_bwd_launch(q, k, v, m, mode, causal, scale, p, seed, out, dout, l
     Lk = k.shape[1]
     dout = dout.contiguous()
     dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-    _check(lib().trx_attention_bwd_dropout(_p(q), _p(k), _p(v), _p(m) if mode != MASK_NONE else None, mode,
-                                           1 if causal else 0, B, H, Lq, Lk, float(scale), _dt(q), float(p), int(seed),
-                                           _p(out), _p(dout), _p(lse), _p(dq), _p(dk), _p(dv), _stream(q)))
+    ws = torch.empty(2 * B * H * Lq, dtype=torch.float32, device=q.device)       # the caller's scratch: capturable
+    _check(lib().trx_attention_bwd_ws(_p(q), _p(k), _p(v), _p(m) if mode != MASK_NONE else None, mode,
+                                      1 if causal else 0, B, H, Lq, Lk, 0, 0, float(scale), _dt(q), float(p), int(seed),
+                                      _p(out), _p(dout), _p(lse), _p(dq), _p(dk), _p(dv), _p(ws), _stream(q)))
     return dq, dk, dv
 
 
@@ -449,9 +474,10 @@ class _AttentionPacked(torch.autograd.Function):
             dkv = None
             ptrs = (a.data_ptr(), a.data_ptr() + H * D * es, a.data_ptr() + 2 * H * D * es,
                     da.data_ptr(), da.data_ptr() + H * D * es, da.data_ptr() + 2 * H * D * es)
-        _check(lib().trx_attention_bwd_strided(c(ptrs[0]), c(ptrs[1]), c(ptrs[2]), _p(m) if mode != MASK_NONE else None, mode,
-                                               1 if causal else 0, B, H, Lq, Lk, ldq, ldk, float(scale), p, seed, _p(out), _p(dout),
-                                               _p(lse), c(ptrs[3]), c(ptrs[4]), c(ptrs[5]), _stream(a)))
+        ws = torch.empty(2 * B * H * Lq, dtype=torch.float32, device=a.device)
+        _check(lib().trx_attention_bwd_ws(c(ptrs[0]), c(ptrs[1]), c(ptrs[2]), _p(m) if mode != MASK_NONE else None, mode,
+                                          1 if causal else 0, B, H, Lq, Lk, ldq, ldk, float(scale), BF16, p, seed, _p(out), _p(dout),
+                                          _p(lse), c(ptrs[3]), c(ptrs[4]), c(ptrs[5]), _p(ws), _stream(a)))
         return da, dkv, None, None, None, None, None
 
 

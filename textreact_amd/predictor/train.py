@@ -148,12 +148,18 @@ def merge_predictions_per_neighbor(outputs, num_neighbors):
     return merged
 
 
-def configure_optimizer(module, lr, weight_decay, num_training_steps, warmup_ratio, scheduler="linear"):
-    """main.py:270-276: AdamW + warm-up/decay schedule stepped per optimiser step"""
+def configure_optimizer(module, lr, weight_decay, num_training_steps, warmup_ratio, scheduler="linear", capturable=False):
+    """main.py:270-276: AdamW + warm-up/decay schedule stepped per optimiser step.  capturable=True (GraphedStep): the
+    step counter and the learning rate live in device tensors, so the update can sit inside a captured HIP graph and
+    the schedule still moves the rate between replays."""
     params = list(module.parameters())
     # same update rule; `fused` runs it as one multi-tensor kernel when the parameters live on the GPU
     fused = bool(params) and all(p.is_cuda for p in params)
-    opt = torch.optim.AdamW(params, lr=lr, weight_decay=weight_decay, fused=fused)
+    if capturable and fused:
+        opt = torch.optim.AdamW(params, lr=torch.tensor(float(lr), device=params[0].device), weight_decay=weight_decay, fused=True,
+                                capturable=True)
+    else:
+        opt = torch.optim.AdamW(params, lr=lr, weight_decay=weight_decay, fused=fused)
     warm = int(num_training_steps * warmup_ratio)
 
     def lr_lambda(step):
@@ -169,6 +175,136 @@ def configure_optimizer(module, lr, weight_decay, num_training_steps, warmup_rat
             return max(0.0, 0.5 * (1.0 + math.cos(math.pi * progress)))
         return max(0.0, float(num_training_steps - step) / float(max(1, num_training_steps - warm)))
     return opt, torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda)
+
+
+# ROCm 7.0 on MI355X: a captured step that holds the backward is replayed wrongly by the runtime's pre-built-packet path
+# ("graph packet capture", the default): after the host has waited on the stream once, replays queued behind one another
+# end in HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION.  The host pattern alone decides it (tools/graph_step_probe.py:
+# ".....t...." faults, "....." never does); no copy, allocation or host pointer is captured (rocprofv3 --hip-runtime-trace:
+# 834 kernel launches, 10 memsets, nothing else), and with the packets built at launch time every pattern -- 59 replays
+# under random waits -- is clean and the replay costs the same 25.4 ms.  The flag is read when the runtime starts.
+GRAPH_RUNTIME_ENV = ("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
+
+def prepare_graph_runtime():
+    """call before the first HIP call of the process (main.py does, on --hip_graph_step): selects the runtime's
+    launch-time packet path for HIP graphs; raises when it is too late to choose"""
+    name, want = GRAPH_RUNTIME_ENV
+    have = os.environ.get(name)
+    if have == want:
+        return
+    if torch.cuda.is_initialized():
+        raise ops.TrxNNError("GraphedStep needs %s=%s in the environment BEFORE the process first touches the GPU (it is %r): the "
+                             "default graph path of this ROCm faults on replays of a captured backward, see train.GRAPH_RUNTIME_ENV"
+                             % (name, want, have))
+    os.environ[name] = want
+
+
+class GraphedStep:
+    """One optimisation step -- the dropout seed's bump, forward, backward, gradient clipping, the AdamW update -- captured
+    ONCE per batch shape into a HIP graph and replayed.
+
+    What it buys: the step is ~830 kernel launches; at the scripts' per-GPU shapes (B 32 x L 512) their GPU time is the
+    step -- 25.4 ms replayed against 25.9 ms eager at T = 160 (bench_predictor.py): the GPU is the limit
+    there and the graph only frees the host.  It pays on small batches, where the launches are not hidden (the last,
+    ragged batches of an epoch are not captured: see below).  What made the step capturable: dropout seeds
+    that live on the device (ops.set_seed_device: a launch's `seed` only numbers its site, the kernels mix it with a
+    device counter this step bumps), the attention backward's scratch as a caller's tensor, AdamW with a device-side
+    step count and learning rate (configure_optimizer(capturable=True)), no host read inside the step, and the runtime
+    switch GRAPH_RUNTIME_ENV (prepare_graph_runtime).
+
+    The first `warmup` steps of a shape run eagerly (same code, same device seeds: real steps), the next one is
+    captured, later ones replay it.  A shape seen fewer times than that (the last, shorter batch of an epoch) simply
+    stays eager.  Single process only: with several ranks the gradient all-reduce would have to be captured too, and
+    RCCL capture could not be tested here (no multi-GPU node)."""
+
+    def __init__(self, module, optimizer, max_grad_norm=None, autocast_dtype=None, warmup=3):
+        from . import ops as _ops
+        self.module, self.opt, self.max_grad_norm, self.autocast_dtype, self.warmup = module, optimizer, max_grad_norm, autocast_dtype, warmup
+        dev = next(module.parameters()).device
+        if dev.type != "cuda":
+            raise _ops.TrxNNError("GraphedStep needs the module on a GPU")
+        if not all(g.get("capturable", False) for g in optimizer.param_groups):
+            raise ValueError("GraphedStep: build the optimizer with configure_optimizer(..., capturable=True)")
+        if os.environ.get(GRAPH_RUNTIME_ENV[0]) != GRAPH_RUNTIME_ENV[1]:
+            prepare_graph_runtime()           # raises: the module is on the GPU, the runtime has started
+        self.seed = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.seed.fill_(int(torch.randint(0, 2 ** 40, (1,)).item()))       # torch.manual_seed still fixes the run
+        _ops.set_seed_device(self.seed)
+        self._ops = _ops
+        self.shapes = {}          # shape key -> {"n": eager steps done, "graph", "inputs", "outputs"}
+        self.replays = 0
+        # every step of this object -- eager or captured -- runs on ONE side stream: autograd's per-parameter gradient
+        # accumulators remember the stream they were created on, and a capture breaks on one that belongs to another stream
+        self.stream = torch.cuda.Stream(device=dev)
+
+    def close(self):
+        self._ops.set_seed_device(None)
+        self.shapes.clear()
+
+    def _run(self, batch_in, batch_out, capturing):
+        self.seed.add_(1)
+        if self.autocast_dtype is not None:
+            ctx = torch.autocast("cuda", dtype=self.autocast_dtype, cache_enabled=not capturing)
+        else:
+            import contextlib
+            ctx = contextlib.nullcontext()
+        with ctx:
+            total, logs = self.module.training_step(batch_in, batch_out)
+        total.backward()
+        if self.max_grad_norm is not None:
+            torch.nn.utils.clip_grad_norm_(self.module.parameters(), self.max_grad_norm)
+        self.opt.step()
+        return total.detach(), {k: v.detach() for k, v in logs.items()}
+
+    @staticmethod
+    def _key(batch_in, batch_out):
+        items = []
+        for name, d in (("in", batch_in), ("out", batch_out or {})):
+            for k in sorted(d):
+                v = d[k]
+                items.append((name, k, tuple(v.shape), str(v.dtype)) if torch.is_tensor(v) else (name, k, "object"))
+        return tuple(items)
+
+    def step(self, batch_in, batch_out=None):
+        """-> (total loss, logs) as tensors on the device (read them with .item() only when they are printed)"""
+        batch_out = batch_out or {}
+        key = self._key(batch_in, batch_out)
+        st = self.shapes.setdefault(key, {"n": 0, "graph": None})
+        if any(not torch.is_tensor(v) for v in list(batch_in.values()) + list(batch_out.values())):
+            st["n"] = -(1 << 30)                  # per-sample python lists (the template branch): never captured
+        if st["graph"] is not None:
+            for k, v in batch_in.items():
+                st["inputs"][0][k].copy_(v, non_blocking=True)
+            for k, v in batch_out.items():
+                st["inputs"][1][k].copy_(v, non_blocking=True)
+            st["graph"].replay()
+            self.replays += 1
+            mark_parameters_updated(self.module)
+            return st["outputs"]
+        cur = torch.cuda.current_stream()
+        if 0 <= st["n"] < self.warmup or st["n"] < 0:
+            self.opt.zero_grad(set_to_none=True)
+            self.stream.wait_stream(cur)
+            with torch.cuda.stream(self.stream):
+                out = self._run(batch_in, batch_out, capturing=False)
+            cur.wait_stream(self.stream)
+            st["n"] += 1
+            mark_parameters_updated(self.module)
+            return out
+        # capture: static copies of the inputs; gradients must not exist yet (they are born inside the graph's pool)
+        s_in = {k: v.clone() for k, v in batch_in.items()}
+        s_out = {k: v.clone() for k, v in batch_out.items()}
+        self.opt.zero_grad(set_to_none=True)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=self.stream):
+            outputs = self._run(s_in, s_out, capturing=True)
+        st.update(graph=g, inputs=(s_in, s_out), outputs=outputs)
+        g.replay()                                 # the capture recorded the step, it did not run it
+        self.replays += 1
+        mark_parameters_updated(self.module)
+        return outputs
 
 
 # ---- checkpoint layout of pytorch-lightning 2.0 (SURVEY.md 5.4; main.py:358-360, :390-405) --------
