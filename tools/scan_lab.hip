@@ -15,7 +15,8 @@
 //           bit1: no MFMA (fill only)
 //           bit2: no per-tile maximum
 //           bit3: (variant 4) fragments read once and reused: no LDS read traffic
-//           bit4: (variant 4) every tile re-reads the split's first corpus tile: the fill never misses L2
+//           bit4: (variants 4, 9) every tile re-reads the split's first corpus tile: the fill never misses L2
+//     variant 9 : one wave per SIMD: 4 waves x (128 x 128), accumulators = the whole AGPR file (see lab_v3)
 // build: hipcc --offload-arch=gfx950 -O3 tools/scan_lab.hip -o tools/scan_lab
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -481,6 +482,156 @@ __global__ __launch_bounds__(THREADS, 2) void lab_v2(LabParams p) {
     for (int nt = 0; nt < 4; ++nt) o[nt] = mx[nt];
 }
 
+// ------------------------------------------------------------------------------------------------
+// variant 9: ONE wave per SIMD -- 4 waves x (128 x 128), 256 accumulator registers per wave (the whole AGPR file), the
+// fragments of the next 32-deep slice read into a second register set while the 64 MFMAs of the current one issue, the
+// LDS-DMA pieces of K-step u+2 issued inside the second slice of K-step u, ONE barrier per K-step (between the slices:
+// by then every wave holds all fragments of stage u&1 and its own pieces of K-step u+1 have landed).
+// Same LDS image as the other variants (two 64 KiB stages), 16 fragment reads per 128x128x32 instead of 12 per 128x64x32:
+// a third fewer LDS fragment bytes per MAC.  The first slice of a tile starts from C = 0 (no clearing pass), the per-query
+// maximum of a tile sits in the gaps of its last slice.
+// ------------------------------------------------------------------------------------------------
+constexpr int V3_THREADS = 256;
+// -DV3_EARLY_DMA=1: the 16 pieces of a K-step behind every 2nd MFMA of the slice instead of every 4th (longer lead).
+// Measured: SLOWER (74.9 against 67.4 ms: a wave holds about 12 LDS-DMA instructions in flight, tools/experiments/
+// ldsdma_counters.hip; the 13th stalls the wave's whole instruction stream, MFMAs included, and one wave per SIMD has nobody
+// to cover it) -- and the check against variant 0 FAILS with it (the last two query pieces of waves 1 and 3 read stale;
+// same with all 16 back to back, fine with up to 8 early): not understood, the option stays for whoever looks next.
+#ifndef V3_EARLY_DMA
+#define V3_EARLY_DMA 0
+#endif
+template <int FL>      // the run's flags bits 0..3, compiled in (a runtime test per MFMA would sit inside the stream)
+__global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void lab_v3(LabParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave >> 1, wave_n = wave & 1;
+    const int v = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = v % p.nsplits, qtile = v / p.nsplits;
+    int tile0 = split * p.tiles_per_split, tile1 = tile0 + p.tiles_per_split;
+    if (tile1 > p.ntiles) tile1 = p.ntiles;
+    const int ntl = tile1 > tile0 ? tile1 - tile0 : 0;
+    const int ksteps = p.ksteps;          // even, >= 6
+    const int prow = lane >> 3, pslot = lane & 7;
+    const int c_even = pslot ^ (prow >> 1), c_odd = pslot ^ (4 + (prow >> 1));
+    const int Kp = p.Kp;
+    int poff[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) poff[i] = ((wave * 8 + i) * 8 + prow) * Kp + ((i & 1) ? c_odd : c_even) * 8;
+    const bf16_t* gA = p.corpus + (int64_t)tile0 * TILE_M * Kp;
+    const bf16_t* gB = p.queries + (int64_t)qtile * TILE_N * Kp;
+    const int lds_piece0 = wave * 8 * 1024;
+    const int frow = lane & 15, fq = lane >> 4, swz = frow >> 1;
+    const int r_off0 = frow * 128 + ((fq ^ swz) << 4), r_off1 = frow * 128 + (((4 + fq) ^ swz) << 4);
+    const unsigned aA0 = LDS_A0 + wave_m * 128 * 128 + r_off0, aA1 = LDS_A0 + wave_m * 128 * 128 + r_off1;
+    const unsigned aB0 = LDS_B0 + wave_n * 128 * 128 + r_off0, aB1 = LDS_B0 + wave_n * 128 * 128 + r_off1;
+    f32x4 acc[8][8];
+    float mx[8];
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) mx[nt] = -3e38f;
+    if (ntl == 0) return;
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            __builtin_amdgcn_global_load_lds((gbl_void*)(gA + st * BK + poff[i]), (lds_void*)(smem + LDS_A0 + st * 32768 + lds_piece0 + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void*)(gB + st * BK + poff[i]), (lds_void*)(smem + LDS_B0 + st * 32768 + lds_piece0 + i * 1024), 16, 0, 0);
+        }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const bf16_t* srcA = gA + 2 * BK; int ksA = 2;     // K-step u+2 of the corpus stream
+    int ksB = 2;
+    const int wrapA = (p.flags & 16) ? -Kp : 255 * Kp;
+    constexpr bool dma_on = !(FL & 1), mfma_on = !(FL & 2), max_on = !(FL & 4), rd_on = !(FL & 8);
+    bf16x8 fa[2][8], fb[2][8];
+    // one fragment read: number R 0..7 = B column blocks, 8..15 = A row blocks, of slice KK in stage STG, into set SET
+#define V3_RD1(SET, KK, STG, R)                                                                            \
+    if ((R) < 8) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[SET][(R) & 7]) : "v"((KK) ? aB1 : aB0), "n"(((R) & 7) * 2048 + (STG) * 32768) : "memory"); \
+    else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[SET][(R) & 7]) : "v"((KK) ? aA1 : aA0), "n"(((R) & 7) * 2048 + (STG) * 32768) : "memory");
+    // one LDS-DMA piece of K-step u+2 into stage STG: piece D 0..7 corpus, 8..15 queries
+#define V3_DMA1(STG, D)                                                                                    \
+    if (dma_on) {                                                                                          \
+        if ((D) < 8) __builtin_amdgcn_global_load_lds((gbl_void*)(srcA + poff[(D) & 7]), (lds_void*)(smem + LDS_A0 + (STG) * 32768 + lds_piece0 + ((D) & 7) * 1024), 16, 0, 0); \
+        else __builtin_amdgcn_global_load_lds((gbl_void*)(gB + ksB * BK + poff[(D) & 7]), (lds_void*)(smem + LDS_B0 + (STG) * 32768 + lds_piece0 + ((D) & 7) * 1024), 16, 0, 0); \
+    }
+#define V3_MAXROW(MT)                                                                                      \
+    if (max_on) {                                                                                  \
+        _Pragma("unroll") for (int nt_ = 0; nt_ < 8; ++nt_)                                                \
+            mx[nt_] = fmaxf(mx[nt_], fmaxf(fmaxf(acc[MT][nt_][0], acc[MT][nt_][1]), fmaxf(acc[MT][nt_][2], acc[MT][nt_][3]))); \
+    } else { _Pragma("unroll") for (int nt_ = 0; nt_ < 8; ++nt_) asm volatile("" :: "v"(acc[MT][nt_])); }
+    // a phase = the 64 MFMAs of fragment set SET; beside them: READ -> the 16 fragment reads of (slice RKK, stage RSTG) into
+    // the other set; DMA -> the 16 pieces of K-step u+2 into stage DSTG; FIRST -> C = 0; LAST -> the tile's maxima
+#define V3_PHASE(SET, READ, RKK, RSTG, DMA, DSTG, FIRST, LAST)                                             \
+    {                                                                                                      \
+        __builtin_amdgcn_s_setprio(1);                                                                     \
+        _Pragma("unroll") for (int i_ = 0; i_ < 64; ++i_) {                                                \
+            const int mt_ = i_ >> 3, nt_ = i_ & 7;                                                         \
+            if (mfma_on) {   /* asm, accumulators pinned to the AGPR file in place: with the builtin hipcc re-homes part of */ \
+                             /* them in VGPRs (v_accvgpr_read + s_nop 7 behind every such MFMA) */         \
+                if (FIRST) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(acc[mt_][nt_]) : "v"(fa[SET][mt_]), "v"(fb[SET][nt_])); \
+                else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[mt_][nt_]) : "v"(fa[SET][mt_]), "v"(fb[SET][nt_])); \
+            }                                                                                              \
+            if ((READ) && (i_ & 3) == 1) { V3_RD1((SET) ^ 1, RKK, RSTG, i_ >> 2) __builtin_amdgcn_sched_barrier(0); } \
+            if ((DMA) && (V3_EARLY_DMA ? (i_ < 32 && (i_ & 1) == 0) : ((i_ & 3) == 3))) {                  \
+                V3_DMA1(DSTG, V3_EARLY_DMA ? (i_ >> 1) : (i_ >> 2)) __builtin_amdgcn_sched_barrier(0);     \
+            }                                                                                              \
+            if ((LAST) && nt_ == 7 && mt_ >= 2) { V3_MAXROW(mt_ - 2) }                                     \
+        }                                                                                                  \
+        if (LAST) { V3_MAXROW(6) V3_MAXROW(7) }                                                            \
+        if (!mfma_on) {                                                                                    \
+            _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) { asm volatile("" :: "v"(fa[SET][j_])); asm volatile("" :: "v"(fb[SET][j_])); } \
+            if (FIRST) { _Pragma("unroll") for (int a_ = 0; a_ < 8; ++a_) _Pragma("unroll") for (int b_ = 0; b_ < 8; ++b_) acc[a_][b_] = (f32x4){0.f, 0.f, 0.f, 0.f}; } \
+        }                                                                                                  \
+        __builtin_amdgcn_s_setprio(0);                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+    }
+    // between the two slices of a K-step: all my fragments of this stage are in registers, my pieces of the next K-step landed
+#define V3_SYNC()                                                                                          \
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(0)" ::: "memory");                               \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+    __builtin_amdgcn_s_barrier();                                                                          \
+    __builtin_amdgcn_sched_barrier(0);
+#define V3_ADVANCE()                                                                                       \
+    srcA += BK; if (++ksA == ksteps) { ksA = 0; srcA += wrapA; }                                           \
+    ksB = (ksB + 1 == ksteps) ? 0 : ksB + 1;
+#define V3_FRAGS_LANDED() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+    // K-step in stage STG: slice 0 from set 0 (reading slice 1 of the same stage into set 1), sync, slice 1 from set 1
+    // (issuing K-step u+2 into this stage and reading slice 0 of the other stage into set 0)
+#define V3_KSTEP(STG, FIRST, LAST)                                                                         \
+    V3_PHASE(0, rd_on, 1, STG, false, 0, FIRST, false)                                                     \
+    V3_SYNC()                                                                                              \
+    V3_PHASE(1, rd_on, 0, (STG) ^ 1, true, STG, false, LAST)                                               \
+    V3_ADVANCE()                                                                                           \
+    V3_FRAGS_LANDED()
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { V3_RD1(0, 0, 0, r) }
+    if (!rd_on) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { V3_RD1(1, 1, 0, r) }
+    }
+    V3_FRAGS_LANDED()
+    unsigned long long t0 = 0, r0 = 0;
+    if (p.clk) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    for (int tl = 0; tl < ntl; ++tl) {
+        V3_KSTEP(0, true, false)
+        V3_KSTEP(1, false, false)
+        for (int ks = 2; ks + 2 < ksteps; ks += 2) {
+            V3_KSTEP(0, false, false)
+            V3_KSTEP(1, false, false)
+        }
+        V3_KSTEP(0, false, false)
+        V3_KSTEP(1, false, true)
+    }
+    if (p.clk && tid == 0) {
+        unsigned long long* c = p.clk + (size_t)blockIdx.x * 4;
+        c[0] = t0; c[1] = r0; c[2] = __builtin_amdgcn_s_memtime(); c[3] = __builtin_amdgcn_s_memrealtime();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float* o = p.out + ((size_t)blockIdx.x * V3_THREADS + tid) * 8;
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) o[nt] = mx[nt];
+}
+
 static unsigned short f2bf(float f) {
     unsigned u; memcpy(&u, &f, 4);
     return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
@@ -524,10 +675,20 @@ int main(int argc, char** argv) {
         else if (var == 6) LAB_GO(lab_v2<12>)
         else if (var == 7) LAB_GO(lab_v2<20>)
         else if (var == 8) LAB_GO(lab_v1<7>)
+        else if (var == 9) {
+#define LAB_GO3(F) { CK(hipFuncSetAttribute((const void*)lab_v3<F>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL)); \
+                     hipLaunchKernelGGL(lab_v3<F>, dim3(grid), dim3(V3_THREADS), LDS_TOTAL, 0, p); }
+            switch (flags & 15) {
+                case 0: LAB_GO3(0) break; case 1: LAB_GO3(1) break; case 2: LAB_GO3(2) break; case 4: LAB_GO3(4) break;
+                case 8: LAB_GO3(8) break; case 9: LAB_GO3(9) break; case 5: LAB_GO3(5) break;
+                default: printf("variant 9: flags %d not instantiated\n", flags); exit(1);
+            }
+        }
         else { printf("unknown variant\n"); exit(1); }
     };
     // per-query maximum over the whole corpus, reduced on the host: out[wg][wave][lane][nt]
-    auto reduce = [&](std::vector<float>& q) {
+    auto reduce = [&](std::vector<float>& q, int var) {
+        const int T = var == 9 ? V3_THREADS : THREADS, NT = var == 9 ? 8 : 4, WN = var == 9 ? 1 : 3;
         std::vector<float> ho(out_n);
         CK(hipMemcpy(ho.data(), out, out_n * 4, hipMemcpyDeviceToHost));
         q.assign(qrow, -3e38f);
@@ -536,11 +697,11 @@ int main(int argc, char** argv) {
             const int nwg = grid, qq = nwg >> 3, r = nwg & 7, x = b & 7;
             const int base = x < r ? x * (qq + 1) : r * (qq + 1) + (x - r) * qq;
             const int v = base + (b >> 3), qt = v / nsplits;
-            for (int t = 0; t < THREADS; ++t) {
-                const int wave = t >> 6, lane = t & 63, wn = wave & 3, fr = lane & 15;
-                for (int nt = 0; nt < 4; ++nt) {
-                    float& d = q[(size_t)qt * TILE_N + wn * 64 + nt * 16 + fr];
-                    const float val = ho[((size_t)b * THREADS + t) * 4 + nt];
+            for (int t = 0; t < T; ++t) {
+                const int wave = t >> 6, lane = t & 63, wn = wave & WN, fr = lane & 15;
+                for (int nt = 0; nt < NT; ++nt) {
+                    float& d = q[(size_t)qt * TILE_N + wn * (NT * 16) + nt * 16 + fr];
+                    const float val = ho[((size_t)b * T + t) * NT + nt];
                     if (val > d) d = val;
                 }
             }
@@ -567,13 +728,18 @@ int main(int argc, char** argv) {
                                  (double)(hc[2] - hc[0]) / ((double)p.tiles_per_split * ksteps)); }
     }
     if (flags == 0 && variant != 0 && ntiles <= 600) {      // check against variant 0 (same operands, same accumulation order)
-        reduce(got);
+        reduce(got, variant);
         CK(hipMemset(out, 0, out_n * 4));
         launch(0); CK(hipDeviceSynchronize());
-        reduce(ref);
+        reduce(ref, 0);
         size_t bad = 0;
         for (size_t i = 0; i < qrow; ++i) if (ref[i] != got[i]) { if (bad < 5) printf("  mismatch q %zu: %g vs %g\n", i, got[i], ref[i]); ++bad; }
         printf("check vs variant 0: %zu of %zu queries differ\n", bad, qrow);
+        if (bad) {      // which 16-query blocks of a tile, and how many tiles
+            int blk[16] = {0}; size_t tiles = 0;
+            for (size_t t = 0; t < qrow / TILE_N; ++t) { bool any = false; for (int c = 0; c < TILE_N; ++c) if (ref[t * TILE_N + c] != got[t * TILE_N + c]) { ++blk[c >> 4]; any = true; } tiles += any; }
+            printf("  per 16-query block:"); for (int i = 0; i < 16; ++i) printf(" %d", blk[i]); printf("  (%zu query tiles affected)\n", tiles);
+        }
     }
     return 0;
 }
