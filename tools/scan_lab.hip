@@ -15,6 +15,8 @@
 //           bit1: no MFMA (fill only)
 //           bit2: no per-tile maximum
 //           bit3: (variant 4) fragments read once and reused: no LDS read traffic
+//           bits 8+: workgroup (query tile q of its XCD group of 8) starts (q & 7) * (flags >> 8) * ~1024 cycles late: the 8 workgroups
+//                 that share a corpus stream stop asking for the same tile at the same moment
 //           bit4: (variants 4, 9) every tile re-reads the split's first corpus tile: the fill never misses L2
 //     variant 9 : one wave per SIMD: 4 waves x (128 x 128), accumulators = the whole AGPR file (see lab_v3)
 // build: hipcc --offload-arch=gfx950 -O3 tools/scan_lab.hip -o tools/scan_lab
@@ -73,6 +75,7 @@ __global__ __launch_bounds__(THREADS, 2) void lab_v0(LabParams p) {
     const int wave_m = wave >> 2, wave_n = wave & 3;
     const int v = xcd_remap(blockIdx.x, gridDim.x);
     const int split = v % p.nsplits, qtile = v / p.nsplits;
+    if (p.flags >> 8) { const int n_ = (qtile & 7) * (p.flags >> 8); for (int i_ = 0; i_ < n_; ++i_) __builtin_amdgcn_s_sleep(16); }   // flags >> 8: start skew, ~1024 cycles per unit and per query tile of the XCD group
     int tile0 = split * p.tiles_per_split, tile1 = tile0 + p.tiles_per_split;
     if (tile1 > p.ntiles) tile1 = p.ntiles;
     const int ntl = tile1 > tile0 ? tile1 - tile0 : 0;
@@ -177,6 +180,7 @@ __global__ __launch_bounds__(THREADS, 2) void lab_v1(LabParams p) {
     const int wave_m = wave >> 2, wave_n = wave & 3;
     const int v = xcd_remap(blockIdx.x, gridDim.x);
     const int split = v % p.nsplits, qtile = v / p.nsplits;
+    if (p.flags >> 8) { const int n_ = (qtile & 7) * (p.flags >> 8); for (int i_ = 0; i_ < n_; ++i_) __builtin_amdgcn_s_sleep(16); }   // flags >> 8: start skew, ~1024 cycles per unit and per query tile of the XCD group
     int tile0 = split * p.tiles_per_split, tile1 = tile0 + p.tiles_per_split;
     if (tile1 > p.ntiles) tile1 = p.ntiles;
     const int ntl = tile1 > tile0 ? tile1 - tile0 : 0;
@@ -344,6 +348,7 @@ __global__ __launch_bounds__(THREADS, 2) void lab_v2(LabParams p) {
     const int wave_m = wave >> 2, wave_n = wave & 3;
     const int v = xcd_remap(blockIdx.x, gridDim.x);
     const int split = v % p.nsplits, qtile = v / p.nsplits;
+    if (p.flags >> 8) { const int n_ = (qtile & 7) * (p.flags >> 8); for (int i_ = 0; i_ < n_; ++i_) __builtin_amdgcn_s_sleep(16); }   // flags >> 8: start skew, ~1024 cycles per unit and per query tile of the XCD group
     int tile0 = split * p.tiles_per_split, tile1 = tile0 + p.tiles_per_split;
     if (tile1 > p.ntiles) tile1 = p.ntiles;
     const int ntl = tile1 > tile0 ? tile1 - tile0 : 0;
@@ -508,6 +513,7 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     const int wave_m = wave >> 1, wave_n = wave & 1;
     const int v = xcd_remap(blockIdx.x, gridDim.x);
     const int split = v % p.nsplits, qtile = v / p.nsplits;
+    if (p.flags >> 8) { const int n_ = (qtile & 7) * (p.flags >> 8); for (int i_ = 0; i_ < n_; ++i_) __builtin_amdgcn_s_sleep(16); }   // flags >> 8: start skew, ~1024 cycles per unit and per query tile of the XCD group
     int tile0 = split * p.tiles_per_split, tile1 = tile0 + p.tiles_per_split;
     if (tile1 > p.ntiles) tile1 = p.ntiles;
     const int ntl = tile1 > tile0 ? tile1 - tile0 : 0;
