@@ -150,16 +150,16 @@ def generate_bench(dev, B=8):
 def main():
     dev = "cuda"
     out = []
-    for dtype, esz in ((torch.bfloat16, 2), (torch.float32, 4)):
-        rows, cols = 32 * 512, 768
-        x = torch.randn(rows, cols, device=dev).to(dtype); r = torch.randn(rows, cols, device=dev).to(dtype)
-        g = torch.ones(cols, device=dev); b = torch.zeros(cols, device=dev)
-        ms = timeit(lambda: ops.add_layernorm(x, r, g, b, 1e-12))
-        gbs = rows * cols * 3 * esz / (ms * 1e-3) / 1e9
-        out.append({"kernel": "add_ln_fwd", "dtype": str(dtype), "rows": rows, "cols": cols, "ms": ms,
-                    "roofline": {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0}})
-        ref = timeit(lambda: torch.nn.functional.layer_norm(x + r, (cols,), g.to(dtype), b.to(dtype), 1e-12))
-        out[-1]["torch_unfused_ms"] = ref
+    # add+LayerNorm forward and backward through the C ABI (tools/ln_bench.py: operands allocated once), dropout 0.1 as in
+    # training; "mixed" = bf16 x + fp32 residual stream, the variant the trainer runs under bf16 autocast
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+    import ln_bench
+    for o in ln_bench.rows_for(16384):
+        for which in ("fwd", "bwd"):
+            out.append({"kernel": "add_ln_" + which, "variant": o["variant"], "rows": o["rows"], "cols": 768, "ms": o[which + "_us"] * 1e-3,
+                        "includes": "the dgamma / dbeta reduction launch" if which == "bwd" else None,
+                        "roofline": {"bound": "hbm", "achieved": o[which + "_GBs"], "peak": 8000.0, "unit": "GB/s", "frac": o[which + "_frac"],
+                                     "algorithmic_bytes": o[which + "_bytes"]}})
     for dtype in (torch.bfloat16, torch.float32):
         for (B, H, Lq, Lk, causal, name) in ((32, 12, 512, 512, False, "encoder self-attention"),
                                              (32, 12, 160, 512, False, "cross-attention"),

@@ -112,10 +112,22 @@ template <bool BF> __device__ __forceinline__ float ld(const void* p, int64_t i)
 template <bool BF> __device__ __forceinline__ void st(void* p, int64_t i, float v) {
     if (BF) reinterpret_cast<bf16_t*>(p)[i] = f2bf(v); else reinterpret_cast<float*>(p)[i] = v;
 }
+// sum over the 64 lanes, the same value in every lane: four DPP steps inside each row of 16 lanes (quad swaps, half-mirror,
+// mirror), then the four row sums through v_readlane.  (__shfl_xor compiles to six ds_bpermute_b32 round trips through the
+// LDS crossbar, ~100 cycles each and serial: the reductions were most of a row's latency in the LayerNorm kernels.)
+template <int CTRL> __device__ __forceinline__ float dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_f32<0xB1>(v);    // quad_perm [1, 0, 3, 2]
+    v += dpp_f32<0x4E>(v);    // quad_perm [2, 3, 0, 1]
+    v += dpp_f32<0x141>(v);   // row_half_mirror
+    v += dpp_f32<0x140>(v);   // row_mirror
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+    return (r0 + r1) + (r2 + r3);
 }
 
 // ---- add + LayerNorm forward: one wave per row, the row cached in registers -----------------------
@@ -124,6 +136,8 @@ __device__ __forceinline__ float wave_sum(float v) {
 // (cols <= 2048 bf16 / 1024 f32; 768 = 1.5 / 3 chunks per lane).  Other shapes: scalar fallback.
 constexpr int CPL = 32;  // scalar fallback: cached values per lane
 constexpr int NCH = 4;
+inline int chunks_per_lane(int cols, int V) { return (cols / V + 63) / 64; }      // 1 .. NCH on the vector path
+#define TRX_NC_SWITCH(NC, M) switch (NC) { case 1: { M(1) } break; case 2: { M(2) } break; case 3: { M(3) } break; default: { M(4) } break; }
 template <bool BF> struct Vec16 { static constexpr int N = BF ? 8 : 4; };
 template <bool BF> __device__ __forceinline__ void unpack16(const uint4& u, float* f) {
     const unsigned w[4] = {u.x, u.y, u.z, u.w};
@@ -155,7 +169,7 @@ __device__ __forceinline__ void unpack8bf(const uint2& u, float* f) {
 __device__ __forceinline__ uint2 pack8bf(const float* f) { return make_uint2(pack2bf(f[0], f[1]), pack2bf(f[2], f[3])); }
 
 // MIX: x is bf16 while res / y are fp32 (then BF is false and a lane step is 4 elements: 8 bytes of x)
-template <bool BF, bool MIX>
+template <bool BF, bool MIX, int NC>   // NC: 16-byte chunks a lane holds (cols <= 64 * NC * V): 768 columns are 2 (bf16) or 3 (fp32), and registers cut to that keep more rows in flight
 __global__ __launch_bounds__(256) void add_ln_fwd_vec_kernel(const void* x, const void* res, const float* gamma,
                                                              const float* beta, float eps, int64_t rows, int cols,
                                                              void* y, float* mean, float* rstd, Drop drop_in, void* y16 = nullptr,
@@ -169,10 +183,10 @@ __global__ __launch_bounds__(256) void add_ln_fwd_vec_kernel(const void* x, cons
     const char* xr = reinterpret_cast<const char*>(x) + row * cols * ((BF || MIX) ? 2 : 4);
     const char* rr = res ? reinterpret_cast<const char*>(res) + row * cols * (BF ? 2 : 4) : nullptr;
     char* yr = reinterpret_cast<char*>(y) + row * cols * (BF ? 2 : 4);
-    float v[NCH][V];
+    float v[NC][V];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
+    for (int i = 0; i < NC; ++i) {
         const int c = lane + 64 * i;
         if (c < nchunk) {
             if (MIX) unpack8bf(*reinterpret_cast<const uint2*>(xr + (size_t)c * 8), v[i]);
@@ -202,14 +216,14 @@ __global__ __launch_bounds__(256) void add_ln_fwd_vec_kernel(const void* x, cons
     const float mu = wave_sum(s) / (float)cols;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < NCH; ++i)
+    for (int i = 0; i < NC; ++i)
         if (lane + 64 * i < nchunk) {
 #pragma unroll
             for (int j = 0; j < V; ++j) { const float d = v[i][j] - mu; q += d * d; }
         }
     const float rs = rsqrtf(wave_sum(q) / (float)cols + eps);
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
+    for (int i = 0; i < NC; ++i) {
         const int c = lane + 64 * i;
         if (c < nchunk) {
             float o[V];
@@ -271,7 +285,8 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const void* x, const vo
 }
 
 // ---- backward: dz, and per-block partial column sums of dgamma / dbeta ----
-constexpr int BWD_MAX_BLOCKS = 768;   // workgroups of 4 waves, rows dealt round-robin to the waves
+constexpr int BWD_MAX_BLOCKS = 768;   // workgroups of 4 waves, rows dealt round-robin to the waves (cutting the registers to 128 for a fourth
+                                      // workgroup per CU, 1024 blocks: measured, no gain -- 43.8 against 43.4 us mixed, tools/ln_bench.py)
 template <bool BF>
 __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const void* dy, const void* x, const void* res,
                                                          const float* gamma, const float* mean, const float* rstd,
@@ -315,7 +330,7 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const void* dy, const v
 // accesses, one pass over dy / x / res), and because a lane owns the same columns in every row it also
 // carries the dgamma / dbeta partial sums of its columns in registers over all its rows; the four
 // waves of a workgroup are combined through LDS at the end.
-template <bool BF, bool MIX>
+template <bool BF, bool MIX, int NC>
 __global__ __launch_bounds__(256) void add_ln_bwd_vec_kernel(const void* dy, const void* x, const void* res,
                                                              const float* gamma, const float* mean, const float* rstd,
                                                              int64_t rows, int cols, void* dz, void* dx, float* ws, int nblk, Drop drop_in,
@@ -326,10 +341,10 @@ __global__ __launch_bounds__(256) void add_ln_bwd_vec_kernel(const void* dy, con
     constexpr int ES = BF ? 2 : 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nchunk = cols / V;
-    float ag[NCH][V], ab[NCH][V], gm[NCH][V];
-    float ax[MIX ? NCH : 1][MIX ? V : 1];   // MIX + xbias: column sums of dx = the gradient of that bias
+    float ag[NC][V], ab[NC][V], gm[NC][V];
+    float ax[MIX ? NC : 1][MIX ? V : 1];   // MIX + xbias: column sums of dx = the gradient of that bias
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
+    for (int i = 0; i < NC; ++i) {
         const int c = lane + 64 * i;
 #pragma unroll
         for (int j = 0; j < V; ++j) {
@@ -340,10 +355,10 @@ __global__ __launch_bounds__(256) void add_ln_bwd_vec_kernel(const void* dy, con
     for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
         const size_t rb = (size_t)row * cols * ES;
         const float mu = mean[row], rs = rstd[row];
-        float g[NCH][V], xh[NCH][V];
+        float g[NC][V], xh[NC][V];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) {
+        for (int i = 0; i < NC; ++i) {
             const int c = lane + 64 * i;
             if (c < nchunk) {
                 float d[V], z[V];
@@ -386,7 +401,7 @@ __global__ __launch_bounds__(256) void add_ln_bwd_vec_kernel(const void* dy, con
         }
         s1 = wave_sum(s1) / (float)cols; s2 = wave_sum(s2) / (float)cols;
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) {
+        for (int i = 0; i < NC; ++i) {
             const int c = lane + 64 * i;
             if (c < nchunk) {
                 float o[V];
@@ -414,7 +429,7 @@ __global__ __launch_bounds__(256) void add_ln_bwd_vec_kernel(const void* dy, con
     float* pg = sm + (wave * 2) * cols;
     float* pb = pg + cols;
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
+    for (int i = 0; i < NC; ++i) {
         const int c = lane + 64 * i;
         if (c < nchunk) {
 #pragma unroll
@@ -431,7 +446,7 @@ __global__ __launch_bounds__(256) void add_ln_bwd_vec_kernel(const void* dy, con
     if (MIX && xbias) {   // third partial row: the bias gradient, through the same LDS area
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) {
+        for (int i = 0; i < NC; ++i) {
             const int c = lane + 64 * i;
             if (c < nchunk) {
 #pragma unroll
@@ -1075,8 +1090,11 @@ int trx_add_layernorm_fwd_dropout(const void* x, const void* res, const float* g
     const bool aligned = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(res)) & 15) == 0;
     const bool vec = aligned && cols % V == 0 && cols <= 64 * NCH * V;
     if (vec) {
-        if (dtype == TRX_NN_BF16) hipLaunchKernelGGL((add_ln_fwd_vec_kernel<true, false>), grid, block, 0, st, x, res, gamma, beta, eps, rows, cols, y, mean, rstd, drop);
-        else hipLaunchKernelGGL((add_ln_fwd_vec_kernel<false, false>), grid, block, 0, st, x, res, gamma, beta, eps, rows, cols, y, mean, rstd, drop);
+#define TRX_LNF(NC_)                                                                                                              \
+        if (dtype == TRX_NN_BF16) hipLaunchKernelGGL((add_ln_fwd_vec_kernel<true, false, NC_>), grid, block, 0, st, x, res, gamma, beta, eps, rows, cols, y, mean, rstd, drop); \
+        else hipLaunchKernelGGL((add_ln_fwd_vec_kernel<false, false, NC_>), grid, block, 0, st, x, res, gamma, beta, eps, rows, cols, y, mean, rstd, drop);
+        TRX_NC_SWITCH(chunks_per_lane(cols, V), TRX_LNF)
+#undef TRX_LNF
     } else {
         if (dtype == TRX_NN_BF16) hipLaunchKernelGGL(add_ln_fwd_kernel<true>, grid, block, 0, st, x, res, gamma, beta, eps, rows, cols, y, mean, rstd, drop);
         else hipLaunchKernelGGL(add_ln_fwd_kernel<false>, grid, block, 0, st, x, res, gamma, beta, eps, rows, cols, y, mean, rstd, drop);
@@ -1100,10 +1118,10 @@ int trx_add_layernorm_bwd_dropout(const void* dy, const void* x, const void* res
     if (p > 0.f && !dx) return fail(TRX_NN_EINVAL, "add_layernorm_bwd: dropout needs the separate dx output");
     const Drop drop = make_drop(p, seed, 0);
     if ((size_t)cols * 8 * sizeof(float) > 160 * 1024) return fail(TRX_NN_EINVAL, "cols too large for the LDS partials");
-    const int nblk = trx_add_layernorm_bwd_blocks(rows);
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = (size_t)cols * 8 * sizeof(float);
     const int V = dtype == TRX_NN_BF16 ? 8 : 4;
+    const int nblk = trx_add_layernorm_bwd_blocks(rows);
     const bool aligned = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(res) |
                            reinterpret_cast<uintptr_t>(dz) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0;
     const bool vec = aligned && cols % V == 0 && cols <= 64 * NCH * V;
@@ -1113,8 +1131,11 @@ int trx_add_layernorm_bwd_dropout(const void* dy, const void* x, const void* res
         hipLaunchKernelGGL(KERNEL, dim3(nblk), dim3(256), lds, st, dy, x, res, gamma, mean, rstd, rows, cols, dz,           \
                            p > 0.f ? dx : nullptr, ws, nblk, drop);                                                         \
     }
-    if (dtype == TRX_NN_BF16) { if (vec) TRX_LAUNCH_LNB((add_ln_bwd_vec_kernel<true, false>)) else TRX_LAUNCH_LNB(add_ln_bwd_kernel<true>) }
-    else { if (vec) TRX_LAUNCH_LNB((add_ln_bwd_vec_kernel<false, false>)) else TRX_LAUNCH_LNB(add_ln_bwd_kernel<false>) }
+#define TRX_LNB(NC_) { if (dtype == TRX_NN_BF16) TRX_LAUNCH_LNB((add_ln_bwd_vec_kernel<true, false, NC_>)) else TRX_LAUNCH_LNB((add_ln_bwd_vec_kernel<false, false, NC_>)) }
+    if (vec) { TRX_NC_SWITCH(chunks_per_lane(cols, V), TRX_LNB) }
+    else if (dtype == TRX_NN_BF16) TRX_LAUNCH_LNB(add_ln_bwd_kernel<true>)
+    else TRX_LAUNCH_LNB(add_ln_bwd_kernel<false>)
+#undef TRX_LNB
 #undef TRX_LAUNCH_LNB
     hipLaunchKernelGGL(add_ln_bwd_reduce_kernel, dim3((cols + 15) / 16, 2), dim3(256), 0, st, ws, nblk, cols, dgamma, dbeta);
     hipError_t e = hipGetLastError();
@@ -1138,8 +1159,10 @@ int trx_add_layernorm_fwd_mixed(const void* x_bf16, const void* res_f32, const f
         return fail(TRX_NN_EINVAL, "add_layernorm_fwd_mixed: operands must be 16-byte (bf16 ones: 8-byte) aligned");
     if (rows == 0) return TRX_NN_OK;
     const Drop drop = make_drop(p, seed, 0);
-    hipLaunchKernelGGL((add_ln_fwd_vec_kernel<false, true>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                       x_bf16, res_f32, gamma, beta, eps, rows, cols, y_f32, mean, rstd, drop, y_bf16, x_bias);
+#define TRX_LNFM(NC_) hipLaunchKernelGGL((add_ln_fwd_vec_kernel<false, true, NC_>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, \
+                                         x_bf16, res_f32, gamma, beta, eps, rows, cols, y_f32, mean, rstd, drop, y_bf16, x_bias);
+    TRX_NC_SWITCH(chunks_per_lane(cols, 4), TRX_LNFM)
+#undef TRX_LNFM
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? TRX_NN_OK : fail(TRX_NN_EHIP, hipGetErrorString(e));
 }
@@ -1160,8 +1183,10 @@ int trx_add_layernorm_bwd_mixed(const void* dy_f32, const void* dy_bf16, const v
     const int nblk = trx_add_layernorm_bwd_blocks(rows);
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = (size_t)cols * 8 * sizeof(float);
-    hipLaunchKernelGGL((add_ln_bwd_vec_kernel<false, true>), dim3(nblk), dim3(256), lds, st, dy_f32, x_bf16, res_f32, gamma, mean, rstd,
-                       rows, cols, dz_f32, dx_bf16, ws, nblk, drop, dy_bf16, x_bias);
+#define TRX_LNBM(NC_) hipLaunchKernelGGL((add_ln_bwd_vec_kernel<false, true, NC_>), dim3(nblk), dim3(256), lds, st, dy_f32, x_bf16, res_f32, gamma, mean, rstd, \
+                                         rows, cols, dz_f32, dx_bf16, ws, nblk, drop, dy_bf16, x_bias);
+    TRX_NC_SWITCH(chunks_per_lane(cols, 4), TRX_LNBM)
+#undef TRX_LNBM
     hipLaunchKernelGGL(add_ln_bwd_reduce_kernel, dim3((cols + 15) / 16, x_bias ? 3 : 2), dim3(256), 0, st, ws, nblk, cols, dgamma, dbeta, dx_bias);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? TRX_NN_OK : fail(TRX_NN_EHIP, hipGetErrorString(e));
