@@ -126,6 +126,32 @@ def test_full_size_model_matches_the_reference_golden(T):
         assert np.abs(logits[pos[:, 0], pos[:, 1]] - z["logits_at_T160"]).max() <= 1e-3
 
 
+@pytest.mark.parametrize("cols", [64, 256, 512, 520, 768, 1024, 1280, 1536, 2040, 2048])
+@pytest.mark.parametrize("variant,tol", [("fp32", 3e-5), ("bf16", 3e-2), ("mixed", 2e-2)])
+def test_add_layernorm_every_chunk_count(cols, variant, tol):
+    """the vector kernels are compiled per number of 16-byte chunks a lane holds (1 .. 4: nn_ops.hip NC); widths on both sides of
+    every boundary, each storage variant, forward and backward with dropout, against the PyTorch statement.  (Widths the
+    vector path does not take -- fp32 / mixed beyond 1024 columns -- run the scalar kernels or the widened path: same answer.)"""
+    rows = 301
+    xd = torch.float32 if variant == "fp32" else torch.bfloat16
+    rd = torch.bfloat16 if variant == "bf16" else torch.float32
+    x, r = _rand(rows, cols, dtype=xd, seed=1), _rand(rows, cols, dtype=rd, seed=2)
+    g, b = _rand(cols, seed=3) * 0.2 + 1, _rand(cols, seed=4) * 0.2
+    dy = _rand(rows, cols, dtype=rd, seed=5)
+    res = []
+    for backend in ("hip", "torch"):
+        with nn_ref.implementation(backend):
+            hip = backend == "hip"
+            xs = (x.clone() if hip else x.float().clone()).requires_grad_(True)
+            rs = (r.clone() if hip else r.float().clone()).requires_grad_(True)
+            gs, bs = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+            y = ops.add_layernorm(xs, rs, gs, bs, 1e-12, dropout_p=0.1, seed=5)
+            y.backward(dy if hip else dy.float())
+            res.append((y.detach().float(), xs.grad.float(), rs.grad.float(), gs.grad, bs.grad))
+    for a, c in zip(*res):
+        assert float((a - c).abs().max()) <= tol * max(1.0, float(c.abs().max())), (cols, variant)
+
+
 @pytest.mark.parametrize("B,H,Lq,Lk,mask,causal", [
     (2, 3, 70, 70, "key", False), (2, 2, 33, 33, "none", True), (2, 2, 20, 77, "key", False),
     (1, 2, 65, 65, "full", False), (1, 1, 5, 37, "none", True),
