@@ -17,6 +17,8 @@
 //           bit3: (variant 4) fragments read once and reused: no LDS read traffic
 //           bits 8+: workgroup (query tile q of its XCD group of 8) starts (q & 7) * (flags >> 8) * ~1024 cycles late: the 8 workgroups
 //                 that share a corpus stream stop asking for the same tile at the same moment
+//           bit6: (variants 1-4, 9) drift gate: the 8 workgroups sharing a corpus stream wait for the slowest (LAB_DRIFT)
+//           bit5: (variants 4, 9) a prefetching load per wave and K-step for the corpus slice LAB_PF_DIST K-steps ahead
 //           bit4: (variants 4, 9) every tile re-reads the split's first corpus tile: the fill never misses L2
 //     variant 9 : one wave per SIMD: 4 waves x (128 x 128), accumulators = the whole AGPR file (see lab_v3)
 // build: hipcc --offload-arch=gfx950 -O3 tools/scan_lab.hip -o tools/scan_lab
@@ -36,6 +38,13 @@ typedef __attribute__((address_space(1))) const void gbl_void;
 
 constexpr int TILE_M = 256, TILE_N = 256, BK = 64, THREADS = 512;
 constexpr int LDS_A0 = 0, LDS_B0 = 2 * TILE_M * 128, LDS_TOTAL = LDS_B0 + 2 * TILE_N * 128;
+constexpr int LDS_PF = LDS_TOTAL, LDS_ALLOC = LDS_TOTAL + 2048;   // 256 B per wave: where the prefetching loads of flags bit5 land
+#ifndef LAB_PF_SHARE
+#define LAB_PF_SHARE 1
+#endif
+#ifndef LAB_PF_DIST
+#define LAB_PF_DIST 3          // K-steps between a prefetch and the LDS-DMA that asks for the same lines
+#endif
 
 struct LabParams {
     const bf16_t* corpus;
@@ -43,6 +52,7 @@ struct LabParams {
     float* out;          // [grid][8 waves][64 lanes][4]
     int Kp, ksteps, ntiles, tiles_per_split, nsplits, flags;
     unsigned long long* clk;   // [grid][4]: s_memtime / s_memrealtime at the start and at the end (wave 0)
+    unsigned* gate;            // [nqtiles / 8][nsplits]: flags bit6, see drift_gate
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -50,6 +60,24 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     int base = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
     return base + (bid >> 3);
 }
+
+// flags bit6: the 8 workgroups that share a corpus stream (one split, query tiles 8g .. 8g+7: one XCD, one round of its 32
+// workgroups) stay within LAB_DRIFT checkpoints (a checkpoint = two K-steps = 64 KiB of the stream) of the slowest of them,
+// so that a corpus line is still in the L2 when the last of them asks for it.  One lane per workgroup; the wait is bounded.
+#ifndef LAB_DRIFT
+#define LAB_DRIFT 2
+#endif
+__device__ __forceinline__ void drift_gate(unsigned* ctr, unsigned done) {
+    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (done > LAB_DRIFT) {
+        const unsigned need = 8u * (done - LAB_DRIFT);
+        for (int it = 0; it < 50000; ++it) {
+            if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) break;
+            __builtin_amdgcn_s_sleep(4);
+        }
+    }
+}
+#define LAB_GATE() if ((p.flags & 64) && tid == 0) { drift_gate(p.gate + (qtile >> 3) * p.nsplits + split, ++gate_done); }
 
 #define LAB_MAX_ACC()                                                                                     \
     if (!(p.flags & 4)) {                                                                                 \
@@ -298,8 +326,10 @@ __global__ __launch_bounds__(THREADS, 2) void lab_v1(LabParams p) {
     unsigned long long t0 = 0, r0 = 0;
     if (p.clk) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
     if (OPT & 2) __builtin_amdgcn_s_setprio(1);
+    unsigned gate_done = 0;
     for (int tl = 0; tl < ntl; ++tl) {
         for (int ks = 0; ks < ksteps; ks += 2) {
+            LAB_GATE()
             // ---------------- K-step u = even (stage 0) ----------------
             V1_L(0, 0, V1_DMA_B(1));     // B of u+1 -> stage 1
             V1_WAIT_L();
@@ -401,6 +431,8 @@ __global__ __launch_bounds__(THREADS, 2) void lab_v2(LabParams p) {
     const bool dma_on = !(p.flags & 1);
     const bool mfma_on = !(p.flags & 2);
     const bool rd_on = !(p.flags & 8);     // flags bit3: fragments are read once and reused (no LDS read traffic)
+    const bool pf_on = (p.flags & 32) && dma_on;   // flags bit5: group 1 touches the corpus lines LAB_PF_DIST K-steps ahead (into L2)
+    const int pf_row = (wave_n * 64 + lane) * Kp;
     if (wave_m) __builtin_amdgcn_s_barrier();
     bf16x8 fa[2][8], fb[2][4];
 #define V2_READ(STG)                                                                                       \
@@ -431,13 +463,16 @@ __global__ __launch_bounds__(THREADS, 2) void lab_v2(LabParams p) {
             _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                               \
                 __builtin_amdgcn_global_load_lds((gbl_void*)(srcL + poff[i_]), (lds_void*)(ll_ + i_ * 1024), 16, 0, 0); \
         }                                                                                                  \
+        if (pf_on) __builtin_amdgcn_global_load_lds((gbl_void*)(srcL + LAB_PF_DIST * BK + (ksL + LAB_PF_DIST >= ksteps ? wrapA : 0) + pf_row), \
+                                                    (lds_void*)(smem + LDS_PF + wave * 256), 4, 0, 0);     \
         srcH += BK; if (++ksH == ksteps) { ksH = 0; srcH += wrapA; }                                       \
         srcL += BK; if (++ksL == ksteps) { ksL = 0; srcL += wrapA; }                                       \
     }
     // end of a load phase: fragments in registers; G1 additionally needs its A rows 0-127 of the PREVIOUS
     // load phase landed (read by G0 in the next interval): all but the 8 pieces just issued
 #define V2_WAIT_L()                                                                                        \
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(8)" ::: "memory");                               \
+    if (pf_on && wave_m) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(10)" ::: "memory");   /* + this phase's prefetch and the previous one */ \
+    else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(8)" ::: "memory");                          \
     __builtin_amdgcn_sched_barrier(0);                                                                     \
     __builtin_amdgcn_s_barrier();                                                                          \
     __builtin_amdgcn_sched_barrier(0);
@@ -445,7 +480,8 @@ __global__ __launch_bounds__(THREADS, 2) void lab_v2(LabParams p) {
     // 128-255 (the first four of the eight it issued)
 #define V2_BAR_M()                                                                                         \
     __builtin_amdgcn_sched_barrier(0);                                                                     \
-    if (wave_m) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
+    if (wave_m) { if (pf_on) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); } \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                  \
     __builtin_amdgcn_s_barrier();                                                                          \
     __builtin_amdgcn_sched_barrier(0);
 #define V2_END_M() if (EARLY == 0) { V2_BAR_M(); }
@@ -468,8 +504,10 @@ __global__ __launch_bounds__(THREADS, 2) void lab_v2(LabParams p) {
     __builtin_amdgcn_sched_barrier(0);
     unsigned long long t0 = 0, r0 = 0;
     if (p.clk) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    unsigned gate_done = 0;
     for (int tl = 0; tl < ntl; ++tl) {
         for (int ks = 0; ks < ksteps; ks += 2) {
+            LAB_GATE()
             if (rd_on || (tl == 0 && ks == 0)) { V2_READ(0); } V2_DMA(0); V2_WAIT_L(); V2_MFMA(); V2_END_M();
             if (rd_on) { V2_READ(1); } V2_DMA(1); V2_WAIT_L(); V2_MFMA();
             if (ks + 2 == ksteps) { LAB_MAX_ACC(); }
@@ -548,7 +586,9 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     const bf16_t* srcA = gA + 2 * BK; int ksA = 2;     // K-step u+2 of the corpus stream
     int ksB = 2;
     const int wrapA = (p.flags & 16) ? -Kp : 255 * Kp;
-    constexpr bool dma_on = !(FL & 1), mfma_on = !(FL & 2), max_on = !(FL & 4), rd_on = !(FL & 8);
+    constexpr bool dma_on = !(FL & 1), mfma_on = !(FL & 2), max_on = !(FL & 4), rd_on = !(FL & 8), pf_on = (FL & 32) != 0;
+    int kcount = 0;
+    const int pf_row = (wave * 64 + lane) * Kp;     // flags bit5: this lane's row of the slice LAB_PF_DIST K-steps ahead (one 128-byte line)
     bf16x8 fa[2][8], fb[2][8];
     // one fragment read: number R 0..7 = B column blocks, 8..15 = A row blocks, of slice KK in stage STG, into set SET
 #define V3_RD1(SET, KK, STG, R)                                                                            \
@@ -593,11 +633,19 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     }
     // between the two slices of a K-step: all my fragments of this stage are in registers, my pieces of the next K-step landed
 #define V3_SYNC()                                                                                          \
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(0)" ::: "memory");                               \
+    if (pf_on) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(1)" ::: "memory");   /* the newest operation is the prefetch */ \
+    else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(0)" ::: "memory");                          \
     __builtin_amdgcn_sched_barrier(0);                                                                     \
     __builtin_amdgcn_s_barrier();                                                                          \
     __builtin_amdgcn_sched_barrier(0);
 #define V3_ADVANCE()                                                                                       \
+    if (pf_on && dma_on) { /* one dword per lane, 64 lines per wave: the whole 256-row slice between the four waves; the 8 workgroups */ \
+        /* that share the stream take turns (LAB_PF_SHARE), the others re-touch a query line so that the wave's VMEM count stays the same */ \
+        const bool mine_ = !LAB_PF_SHARE || ((kcount & 7) == (qtile & 7));                                 \
+        const bf16_t* a_ = mine_ ? srcA + LAB_PF_DIST * BK + (ksA + LAB_PF_DIST >= ksteps ? wrapA : 0) + pf_row : gB; \
+        __builtin_amdgcn_global_load_lds((gbl_void*)a_, (lds_void*)(smem + LDS_PF + wave * 256), 4, 0, 0); \
+        ++kcount;                                                                                          \
+    }                                                                                                      \
     srcA += BK; if (++ksA == ksteps) { ksA = 0; srcA += wrapA; }                                           \
     ksB = (ksB + 1 == ksteps) ? 0 : ksB + 1;
 #define V3_FRAGS_LANDED() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
@@ -618,13 +666,17 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     V3_FRAGS_LANDED()
     unsigned long long t0 = 0, r0 = 0;
     if (p.clk) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    unsigned gate_done = 0;
     for (int tl = 0; tl < ntl; ++tl) {
+        LAB_GATE()
         V3_KSTEP(0, true, false)
         V3_KSTEP(1, false, false)
         for (int ks = 2; ks + 2 < ksteps; ks += 2) {
+            LAB_GATE()
             V3_KSTEP(0, false, false)
             V3_KSTEP(1, false, false)
         }
+        LAB_GATE()
         V3_KSTEP(0, false, false)
         V3_KSTEP(1, false, true)
     }
@@ -667,10 +719,11 @@ int main(int argc, char** argv) {
     const size_t out_n = (size_t)grid * THREADS * 4;
     CK(hipMalloc(&out, out_n * 4));
     unsigned long long* clk; CK(hipMalloc(&clk, (size_t)grid * 32)); CK(hipMemset(clk, 0, (size_t)grid * 32));
-    LabParams p{corpus, queries, out, Kp, ksteps, ntiles, (ntiles + nsplits - 1) / nsplits, nsplits, flags, clk};
+    unsigned* gate; const size_t gate_bytes = (size_t)(nqtiles / 8) * nsplits * 4; CK(hipMalloc(&gate, gate_bytes));
+    LabParams p{corpus, queries, out, Kp, ksteps, ntiles, (ntiles + nsplits - 1) / nsplits, nsplits, flags, clk, gate};
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-#define LAB_GO(K) { CK(hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL)); \
-                    hipLaunchKernelGGL(K, dim3(grid), dim3(THREADS), LDS_TOTAL, 0, p); }
+#define LAB_GO(K) { CK(hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ALLOC)); \
+                    hipLaunchKernelGGL(K, dim3(grid), dim3(THREADS), LDS_ALLOC, 0, p); }
     auto launch = [&](int var) {
         if (var == 0) LAB_GO(lab_v0)
         else if (var == 1) LAB_GO(lab_v1<0>)
@@ -682,9 +735,10 @@ int main(int argc, char** argv) {
         else if (var == 7) LAB_GO(lab_v2<20>)
         else if (var == 8) LAB_GO(lab_v1<7>)
         else if (var == 9) {
-#define LAB_GO3(F) { CK(hipFuncSetAttribute((const void*)lab_v3<F>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL)); \
-                     hipLaunchKernelGGL(lab_v3<F>, dim3(grid), dim3(V3_THREADS), LDS_TOTAL, 0, p); }
-            switch (flags & 15) {
+#define LAB_GO3(F) { CK(hipFuncSetAttribute((const void*)lab_v3<F>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ALLOC)); \
+                     hipLaunchKernelGGL(lab_v3<F>, dim3(grid), dim3(V3_THREADS), LDS_ALLOC, 0, p); }
+            switch (flags & 47) {      // bit6 (the drift gate) is read at run time
+                case 32: LAB_GO3(32) break;
                 case 0: LAB_GO3(0) break; case 1: LAB_GO3(1) break; case 2: LAB_GO3(2) break; case 4: LAB_GO3(4) break;
                 case 8: LAB_GO3(8) break; case 9: LAB_GO3(9) break; case 5: LAB_GO3(5) break;
                 default: printf("variant 9: flags %d not instantiated\n", flags); exit(1);
@@ -717,6 +771,7 @@ int main(int argc, char** argv) {
     const double flop = 2.0 * qrow * (double)ntiles * TILE_M * Kp;
     const double fill = (double)grid * p.tiles_per_split * ksteps * 65536.0;
     for (int rep = 0; rep < reps; ++rep) {
+        CK(hipMemset(gate, 0, gate_bytes));
         CK(hipEventRecord(e0));
         launch(variant);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
@@ -736,6 +791,7 @@ int main(int argc, char** argv) {
     if (flags == 0 && variant != 0 && ntiles <= 600) {      // check against variant 0 (same operands, same accumulation order)
         reduce(got, variant);
         CK(hipMemset(out, 0, out_n * 4));
+        CK(hipMemset(gate, 0, gate_bytes));
         launch(0); CK(hipDeviceSynchronize());
         reduce(ref, 0);
         size_t bad = 0;
