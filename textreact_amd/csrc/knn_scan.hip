@@ -387,18 +387,28 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
     __builtin_amdgcn_sched_barrier(0);                                                                     \
     __builtin_amdgcn_s_barrier();                                                                          \
     __builtin_amdgcn_sched_barrier(0);
+// The query block index runs back and forth over consecutive rows of MFMAs (0 1 2 3 | 3 2 1 0 | ...): one operand changes per
+// instruction instead of two at every row end.  Lab (tools/scan_lab.hip -DLAB_SNAKE=1): MFMAs alone -0.9 ... -1.6 %, whole loop
+// -0.5 ... -1.0 %.
+#ifndef TRX_SNAKE
+#define TRX_SNAKE 1
+#endif
 #define TRX_MFMA_ACC()                                                                                     \
     __builtin_amdgcn_s_setprio(1);                                                                         \
     _Pragma("unroll") for (int mt_ = 0; mt_ < 8; ++mt_)                                                    \
-        _Pragma("unroll") for (int nt_ = 0; nt_ < 4; ++nt_)                                                \
+        _Pragma("unroll") for (int n0_ = 0; n0_ < 4; ++n0_) {                                              \
+            const int nt_ = (TRX_SNAKE && (mt_ & 1)) ? 3 - n0_ : n0_;                                      \
             acc[mt_][nt_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mt_], fb[nt_], acc[mt_][nt_], 0, 0, 0); \
+        }                                                                                                  \
     __builtin_amdgcn_s_setprio(0);
     // first phase of a tile: the accumulators start from zero (IP) or from -|y|^2 / 2 of their rows (L2): no clearing pass
 #define TRX_MFMA_ZERO()                                                                                    \
     __builtin_amdgcn_s_setprio(1);                                                                         \
     _Pragma("unroll") for (int mt_ = 0; mt_ < 8; ++mt_)                                                    \
-        _Pragma("unroll") for (int nt_ = 0; nt_ < 4; ++nt_)                                                \
+        _Pragma("unroll") for (int n0_ = 0; n0_ < 4; ++n0_) {                                              \
+            const int nt_ = (TRX_SNAKE && (mt_ & 1)) ? 3 - n0_ : n0_;                                      \
             acc[mt_][nt_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mt_], fb[nt_], L2 ? biasv[mt_] : zero4, 0, 0, 0); \
+        }                                                                                                  \
     __builtin_amdgcn_s_setprio(0);
     // B pieces of this wave's half for the K-step after the current one -> stage STG
 #define TRX_DMA_B(STG)                                                                                     \

@@ -64,6 +64,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // flags bit6: the 8 workgroups that share a corpus stream (one split, query tiles 8g .. 8g+7: one XCD, one round of its 32
 // workgroups) stay within LAB_DRIFT checkpoints (a checkpoint = two K-steps = 64 KiB of the stream) of the slowest of them,
 // so that a corpus line is still in the L2 when the last of them asks for it.  One lane per workgroup; the wait is bounded.
+#ifndef LAB_SNAKE
+#define LAB_SNAKE 0     // 1: the query block index runs back and forth over a row of MFMAs (variants 4-7, 9)
+#endif
 #ifndef LAB_DRIFT
 #define LAB_DRIFT 2
 #endif
@@ -489,7 +492,7 @@ __global__ __launch_bounds__(THREADS, 2) void lab_v2(LabParams p) {
     if (mfma_on) {                                                                                         \
         __builtin_amdgcn_s_setprio(1);                                                                     \
         _Pragma("unroll") for (int i_ = 0; i_ < 64; ++i_) {                                                \
-            const int kk_ = i_ >> 5, mt_ = (i_ >> 2) & 7, nt_ = i_ & 3;                                    \
+            const int kk_ = i_ >> 5, mt_ = (i_ >> 2) & 7, nt_ = (LAB_SNAKE && (mt_ & 1)) ? 3 - (i_ & 3) : (i_ & 3); \
             if (EARLY > 0 && i_ == 64 - EARLY) { V2_BAR_M(); }                                             \
             acc[mt_][nt_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[kk_][mt_], fb[kk_][nt_], acc[mt_][nt_], 0, 0, 0); \
         }                                                                                                  \
@@ -611,7 +614,7 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     {                                                                                                      \
         __builtin_amdgcn_s_setprio(1);                                                                     \
         _Pragma("unroll") for (int i_ = 0; i_ < 64; ++i_) {                                                \
-            const int mt_ = i_ >> 3, nt_ = i_ & 7;                                                         \
+            const int mt_ = i_ >> 3, nt_ = (LAB_SNAKE && (mt_ & 1)) ? 7 - (i_ & 7) : (i_ & 7);   /* LAB_SNAKE: one operand changes per MFMA */ \
             if (mfma_on) {   /* asm, accumulators pinned to the AGPR file in place: with the builtin hipcc re-homes part of */ \
                              /* them in VGPRs (v_accvgpr_read + s_nop 7 behind every such MFMA) */         \
                 if (FIRST) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(acc[mt_][nt_]) : "v"(fa[SET][mt_]), "v"(fb[SET][nt_])); \
@@ -621,7 +624,7 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
             if ((DMA) && (V3_EARLY_DMA ? (i_ < 32 && (i_ & 1) == 0) : ((i_ & 3) == 3))) {                  \
                 V3_DMA1(DSTG, V3_EARLY_DMA ? (i_ >> 1) : (i_ >> 2)) __builtin_amdgcn_sched_barrier(0);     \
             }                                                                                              \
-            if ((LAST) && nt_ == 7 && mt_ >= 2) { V3_MAXROW(mt_ - 2) }                                     \
+            if ((LAST) && (i_ & 7) == 7 && mt_ >= 2) { V3_MAXROW(mt_ - 2) }                                     \
         }                                                                                                  \
         if (LAST) { V3_MAXROW(6) V3_MAXROW(7) }                                                            \
         if (!mfma_on) {                                                                                    \
