@@ -195,6 +195,16 @@ def main():
         out.append({"kernel": "attention_bwd", "what": name, "dtype": str(dtype), "B": B, "H": H, "Lq": Lq, "Lk": Lk,
                     "ms": ms, "torch_eager_fp32_ms": ref,
                     "roofline": {"bound": "mfma", "achieved": tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": tf / 2500.0}})
+    # weight-gradient GEMM dW = dY^T X (trx_gemm_tn_bf16: contraction over the 16,384 token rows split over workgroups + a fixed-order
+    # reduction launch), at the encoder's four Linear shapes, against the library (torch.matmul on the transposed view)
+    for (N, K, name) in ((2304, 768, "query+key+value"), (768, 768, "attention output"), (3072, 768, "FFN up"), (768, 3072, "FFN down")):
+        M = 32 * 512
+        dy = torch.randn(M, N, device=dev).to(torch.bfloat16); x = torch.randn(M, K, device=dev).to(torch.bfloat16)
+        ms = timeit(lambda: ops.gemm_tn(dy, x, colsum=True, out_dtype=torch.float32), iters=20)
+        ref = timeit(lambda: torch.matmul(dy.t(), x), iters=20)
+        tf = 2.0 * M * N * K / (ms * 1e-3) / 1e12
+        out.append({"kernel": "gemm_tn (dW + db)", "what": name, "M": M, "N": N, "K": K, "ms": ms, "library_ms": ref,
+                    "roofline": {"bound": "mfma", "achieved": tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": tf / 2500.0}})
     for o in out:
         print(json.dumps(o), flush=True)
     for rows in (lambda: train_step_bench(dev),              # RetroSyn: decoder length 160 (train_RetroSyn_tf.sh:33)
