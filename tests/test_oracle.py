@@ -154,3 +154,25 @@ def test_oracle_agrees_with_an_independent_exact_search(metric):
         for q, j in diff:   # only near-ties may differ
             assert abs(s[q, I[q, j]] - s[q, ids[q, j]]) <= 1e-4 * max(1.0, abs(s[q, ids[q, j]])), (name, q, j)
         assert len(diff) <= 0.01 * ids.size, (name, len(diff))
+
+
+def test_oracle_agrees_with_an_independent_brute_force_library():
+    """scikit-learn's NearestNeighbors(algorithm='brute') -- a third implementation of exact flat search, written by nobody
+    here and unrelated to FAISS -- finds the same neighbours as the oracle's canonical rule and its literal FAISS restatement
+    on Gaussian data (no ties), and the same distances up to float rounding.  This does not pin the oracle to FAISS (nothing in
+    this image can: DESIGN.md section 1); it rules out a shared misreading of what "the k nearest rows" means."""
+    sk = pytest.importorskip("sklearn.neighbors")
+    y, x = gaussian(3000, 64, 11), gaussian(200, 64, 12)
+    nn = sk.NearestNeighbors(n_neighbors=10, algorithm="brute", metric="euclidean").fit(y.astype(np.float64))
+    dist, ind = nn.kneighbors(x.astype(np.float64))
+    Dc, Ic = oracle.knn_canonical(L2, x, y, 10)
+    Df, If = oracle.knn_faiss(L2, x, y, 10)
+    assert np.array_equal(Ic, ind) and np.array_equal(If, ind)
+    assert np.allclose(Dc, dist ** 2, rtol=1e-5, atol=1e-5) and np.allclose(Df, dist ** 2, rtol=1e-4, atol=1e-4)
+    # inner product: the same library's machinery on the augmented vectors (max x.y == min |x' - y'|^2 with y' = [y, sqrt(M - |y|^2)], x' = [x, 0])
+    n2 = (y.astype(np.float64) ** 2).sum(1)
+    ya = np.concatenate([y.astype(np.float64), np.sqrt(n2.max() - n2)[:, None]], 1)
+    xa = np.concatenate([x.astype(np.float64), np.zeros((len(x), 1))], 1)
+    _, ind_ip = sk.NearestNeighbors(n_neighbors=10, algorithm="brute", metric="euclidean").fit(ya).kneighbors(xa)
+    _, Ic_ip = oracle.knn_canonical(IP, x, y, 10)
+    assert np.array_equal(Ic_ip, ind_ip)
