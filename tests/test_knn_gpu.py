@@ -464,3 +464,16 @@ def test_real_faiss_when_the_box_has_it(metric):
     idx = _index(L2, 2048); idx.add(fy)
     D, I = idx.search(fx, 20)
     assert np.array_equal(I, If) and np.array_equal(D, Df)
+
+
+def test_hip_search_against_an_independent_brute_force_library():
+    """no oracle in the loop: the HIP index against scikit-learn's NearestNeighbors(algorithm='brute') in float64 on C0-sized
+    Gaussian data (10,000 x 768, 1,000 queries, k = 10) -- same neighbours in the same order, squared distances to fp32 rounding"""
+    sk = pytest.importorskip("sklearn.neighbors")
+    x, y = gaussian(1000, 768, 5678), gaussian(10000, 768, 1234)
+    dist, ind = sk.NearestNeighbors(n_neighbors=10, algorithm="brute", metric="euclidean").fit(y.astype(np.float64)).kneighbors(x.astype(np.float64))
+    idx = _index(L2, 768)
+    idx.add(y)
+    D, I = idx.search(x, 10)
+    assert np.array_equal(I, ind)
+    assert np.allclose(D, dist ** 2, rtol=2e-5, atol=1e-3)
