@@ -146,15 +146,21 @@ class Embeddings(nn.Module):
         self.p_hidden = cfg.hidden_dropout_prob
 
     def forward(self, input_ids, position_ids, token_type_ids):
-        if position_ids is None:
-            if self.roberta:   # RoBERTa: positions count non-pad tokens, starting at pad + 1
-                nz = input_ids.ne(self.pad).int()
-                position_ids = (torch.cumsum(nz, dim=1) * nz).long() + self.pad
-            else:
-                position_ids = torch.arange(input_ids.shape[1], device=input_ids.device)[None].expand_as(input_ids)
+        # The defaults of the reference's calls (no token types: all zero; BERT positions: 0 .. L-1 for every sample) are rows
+        # broadcast over the batch, not gathers: the same sums in the same order ((word + type) + position, BertEmbeddings), but
+        # the gradients of those two tables become plain reductions over the batch instead of two more sort-based
+        # embedding backward passes (~0.13 ms each at 16,384 tokens: profiles/r03_train_step_kernel_stats.csv).
         if token_type_ids is None:
-            token_type_ids = torch.zeros_like(input_ids)
-        e = self.word_embeddings(input_ids) + self.token_type_embeddings(token_type_ids)
+            e = self.word_embeddings(input_ids) + self.token_type_embeddings.weight[0]
+        else:
+            e = self.word_embeddings(input_ids) + self.token_type_embeddings(token_type_ids)
+        if position_ids is None and not self.roberta:
+            y = ops.add_layernorm(e + self.position_embeddings.weight[:input_ids.shape[1]], None, self.LayerNorm.weight,
+                                  self.LayerNorm.bias, self.eps)
+            return torch.nn.functional.dropout(y, self.p_hidden, self.training)
+        if position_ids is None:       # RoBERTa: positions count non-pad tokens, starting at pad + 1
+            nz = input_ids.ne(self.pad).int()
+            position_ids = (torch.cumsum(nz, dim=1) * nz).long() + self.pad
         y = ops.add_layernorm(e, self.position_embeddings(position_ids), self.LayerNorm.weight,
                               self.LayerNorm.bias, self.eps)
         return torch.nn.functional.dropout(y, self.p_hidden, self.training)   # after the LayerNorm (BertEmbeddings)
