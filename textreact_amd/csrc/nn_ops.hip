@@ -786,29 +786,34 @@ __global__ __launch_bounds__(XW ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
         kofs[i] = rw * rowbytes + (unsigned)((pslot ^ (4 * i + (prow >> 1))) * 16);
         vofs[i] = rw * rowbytes + (unsigned)((pslot ^ ((prow & 3) << 1)) * 16);
     }
+    // one piece: 32-bit per-lane offset against a wave-uniform 64-bit base in scalar registers (no 64-bit vector add per piece:
+    // the builtin, given a pointer, spent ~20 v_lshl_add_u64 / v_readfirstlane a tile on addresses), M0 written in the same statement
+#define TRX_GLDS16(SBASE, VOFF, LDSADDR)                                                                     \
+    {                                                                                                        \
+        unsigned vo_ = (VOFF);                                                                               \
+        const unsigned la_ = (unsigned)__builtin_amdgcn_readfirstlane((int)(LDSADDR));                        \
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : "+v"(vo_) : "s"(SBASE), "s"(la_) : "memory"); \
+    }
+    const unsigned ldsbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
 #define TRX_ATT_STAGE(KB, BUF)                                                                              \
     if (!XW || wave < 4) {                                                                                  \
-        const char* kt_ = kbase + (int64_t)(KB) * 64 * rowbytes;                                            \
-        const char* vt_ = vbase + (int64_t)(KB) * 64 * rowbytes;                                            \
+        const unsigned long long kt_ = (unsigned long long)(kbase + (int64_t)(KB) * 64 * rowbytes);         \
+        const unsigned long long vt_ = (unsigned long long)(vbase + (int64_t)(KB) * 64 * rowbytes);         \
+        const unsigned l_ = ldsbase + (unsigned)((BUF) * 16384 + 2 * wave * 1024);                          \
         if ((KB) * 64 + 64 <= Lk) {                                                                         \
             _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                              \
-                __builtin_amdgcn_global_load_lds((gbl_void*)(kt_ + kofs[i_]),                               \
-                                                 (lds_void*)(lds + (BUF) * 16384 + (2 * wave + i_) * 1024), 16, 0, 0);        \
-                __builtin_amdgcn_global_load_lds((gbl_void*)(vt_ + vofs[i_]),                               \
-                                                 (lds_void*)(lds + (BUF) * 16384 + 8192 + (2 * wave + i_) * 1024), 16, 0, 0); \
+                TRX_GLDS16(kt_, kofs[i_], l_ + i_ * 1024);                                                  \
+                TRX_GLDS16(vt_, vofs[i_], l_ + 8192 + i_ * 1024);                                           \
             }                                                                                               \
         } else { /* tail tile: rows past the last key re-read the last key (they are hidden anyway) */      \
             _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                              \
                 const int rw_ = min(8 * (2 * wave + i_) + prow, Lk - 1 - (KB) * 64);                        \
                 const unsigned ro_ = (unsigned)rw_ * rowbytes;                                              \
-                __builtin_amdgcn_global_load_lds((gbl_void*)(kt_ + (ro_ + (unsigned)((pslot ^ (4 * i_ + (prow >> 1))) * 16))), \
-                                                 (lds_void*)(lds + (BUF) * 16384 + (2 * wave + i_) * 1024), 16, 0, 0);        \
-                __builtin_amdgcn_global_load_lds((gbl_void*)(vt_ + (ro_ + (unsigned)((pslot ^ ((prow & 3) << 1)) * 16))), \
-                                                 (lds_void*)(lds + (BUF) * 16384 + 8192 + (2 * wave + i_) * 1024), 16, 0, 0); \
+                TRX_GLDS16(kt_, ro_ + (unsigned)((pslot ^ (4 * i_ + (prow >> 1))) * 16), l_ + i_ * 1024);   \
+                TRX_GLDS16(vt_, ro_ + (unsigned)((pslot ^ ((prow & 3) << 1)) * 16), l_ + 8192 + i_ * 1024); \
             }                                                                                               \
         }                                                                                                   \
     }
-    const unsigned ldsbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
     const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
     // V^T read addresses: row 4(g>>1) + qq (+16 per k-step, +8 for the second read), 16-byte chunk
     // c = 4 db + 2 (g&1) + (pp>>1) stored at slot c ^ ((row & 3) << 1) -- the four rows a 16-lane group
