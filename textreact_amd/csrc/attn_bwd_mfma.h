@@ -144,6 +144,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int rw = 8 * (2 * wave + i) + prow;
         sofs[i] = (unsigned)rw * rowbytes + TRX_BWD_SW_OFS(rw, pslot);
     }
+    const unsigned ldsbase0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
 #define TRX_BWD1_STAGE(KB, BUF)                                                                             \
     {                                                                                                       \
         const char* kt_ = kbase + (int64_t)(KB) * 64 * rowbytes;                                            \
@@ -154,10 +155,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const int rw_ = 8 * (2 * wave + i_) + prow;                                                 \
                 so_ = (unsigned)min(rw_, Lk - 1 - (KB) * 64) * rowbytes + TRX_BWD_SW_OFS(rw_, pslot);       \
             }                                                                                               \
-            __builtin_amdgcn_global_load_lds((gbl_void*)(kt_ + so_),                                        \
-                                             (lds_void*)(lds + (BUF) * 16384 + (2 * wave + i_) * 1024), 16, 0, 0);        \
-            __builtin_amdgcn_global_load_lds((gbl_void*)(vt_ + so_),                                        \
-                                             (lds_void*)(lds + (BUF) * 16384 + 8192 + (2 * wave + i_) * 1024), 16, 0, 0); \
+            TRX_GLDS16((unsigned long long)kt_, so_, ldsbase0 + (unsigned)((BUF) * 16384 + (2 * wave + i_) * 1024));        \
+            TRX_GLDS16((unsigned long long)vt_, so_, ldsbase0 + (unsigned)((BUF) * 16384 + 8192 + (2 * wave + i_) * 1024)); \
         }                                                                                                   \
     }
     const unsigned ldsbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
@@ -371,6 +370,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         sofd[i] = (unsigned)rw * rowbytes_d + TRX_BWD_SW_OFS(rw, pslot);
     }
     // per stage and wave: 4 tile loads (+ 2 loads of the per-query scalars on wave 0)
+    const unsigned ldsbase0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
 #define TRX_BWD2_STAGE(QT, BUF)                                                                             \
     {                                                                                                       \
         const char* qt_ = qbase + (int64_t)(QT) * 64 * rowbytes;                                            \
@@ -382,15 +382,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 so_ = (unsigned)min(rw_, Lq - 1 - (QT) * 64) * rowbytes + TRX_BWD_SW_OFS(rw_, pslot);       \
                 sd_ = (unsigned)min(rw_, Lq - 1 - (QT) * 64) * rowbytes_d + TRX_BWD_SW_OFS(rw_, pslot);     \
             }                                                                                               \
-            __builtin_amdgcn_global_load_lds((gbl_void*)(qt_ + so_),                                        \
-                                             (lds_void*)(lds + (BUF) * BWD2_STAGE + (2 * wave + i_) * 1024), 16, 0, 0);        \
-            __builtin_amdgcn_global_load_lds((gbl_void*)(dt_ + sd_),                                        \
-                                             (lds_void*)(lds + (BUF) * BWD2_STAGE + 8192 + (2 * wave + i_) * 1024), 16, 0, 0); \
+            TRX_GLDS16((unsigned long long)qt_, so_, ldsbase0 + (unsigned)((BUF) * BWD2_STAGE + (2 * wave + i_) * 1024));        \
+            TRX_GLDS16((unsigned long long)dt_, sd_, ldsbase0 + (unsigned)((BUF) * BWD2_STAGE + 8192 + (2 * wave + i_) * 1024)); \
         }                                                                                                   \
         if (wave == 0) {                                                                                    \
             const int qi_ = min((QT) * 64 + lane, Lq - 1);                                                  \
-            __builtin_amdgcn_global_load_lds((gbl_void*)(nlbase + qi_), (lds_void*)(lds + (BUF) * BWD2_STAGE + 16384), 4, 0, 0);       \
-            __builtin_amdgcn_global_load_lds((gbl_void*)(ndbase + qi_), (lds_void*)(lds + (BUF) * BWD2_STAGE + 16384 + 256), 4, 0, 0); \
+            TRX_GLDS4((unsigned long long)nlbase, (unsigned)qi_ * 4u, ldsbase0 + (unsigned)((BUF) * BWD2_STAGE + 16384));       \
+            TRX_GLDS4((unsigned long long)ndbase, (unsigned)qi_ * 4u, ldsbase0 + (unsigned)((BUF) * BWD2_STAGE + 16384 + 256)); \
         }                                                                                                   \
     }
     const unsigned ldsbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
