@@ -790,9 +790,9 @@ __global__ __launch_bounds__(XW ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
     // the builtin, given a pointer, spent ~20 v_lshl_add_u64 / v_readfirstlane a tile on addresses), M0 written in the same statement
 #define TRX_GLDS16(SBASE, VOFF, LDSADDR)                                                                     \
     {                                                                                                        \
-        unsigned vo_ = (VOFF);                                                                               \
+        const unsigned vo_ = (VOFF);                                                                         \
         const unsigned la_ = (unsigned)__builtin_amdgcn_readfirstlane((int)(LDSADDR));                        \
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : "+v"(vo_) : "s"(SBASE), "s"(la_) : "memory"); \
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(vo_), "s"(SBASE), "s"(la_) : "memory"); \
     }
 #define TRX_GLDS4(SBASE, VOFF, LDSADDR)      /* the same with 4 bytes per lane */                            \
     {                                                                                                        \
@@ -801,11 +801,12 @@ __global__ __launch_bounds__(XW ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" : "+v"(vo_) : "s"(SBASE), "s"(la_) : "memory"); \
     }
     const unsigned ldsbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+    const unsigned lds_w = (unsigned)__builtin_amdgcn_readfirstlane((int)(ldsbase + (unsigned)(2 * wave * 1024)));   // this wave's pieces, scalar
 #define TRX_ATT_STAGE(KB, BUF)                                                                              \
     if (!XW || wave < 4) {                                                                                  \
         const unsigned long long kt_ = (unsigned long long)(kbase + (int64_t)(KB) * 64 * rowbytes);         \
         const unsigned long long vt_ = (unsigned long long)(vbase + (int64_t)(KB) * 64 * rowbytes);         \
-        const unsigned l_ = ldsbase + (unsigned)((BUF) * 16384 + 2 * wave * 1024);                          \
+        const unsigned l_ = lds_w + (unsigned)((BUF) * 16384);                                              \
         if ((KB) * 64 + 64 <= Lk) {                                                                         \
             _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                              \
                 TRX_GLDS16(kt_, kofs[i_], l_ + i_ * 1024);                                                  \
