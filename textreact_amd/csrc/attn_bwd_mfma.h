@@ -56,6 +56,7 @@ __global__ __launch_bounds__(256) void attention_bwd_prep_kernel(const bf16_t* _
     negd[w] = -acc;
 }
 
+template <int N> struct ic_ { static constexpr int value = N; };     // a compile-time switch handed to a generic lambda
 // 8 rows x 128 B of a [rows][H][64] bf16 tensor into LDS, one global_load_lds_dwordx4 per wave:
 // lane -> (row base + lane / 8, slot lane % 8), source chunk slot ^ bwd_sw(row)
 #define TRX_BWD_SW_OFS(ROWINTILE, PSLOT) ((unsigned)(((PSLOT) ^ bwd_sw(ROWINTILE)) * 16))
@@ -255,15 +256,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     else { p0[t] = __builtin_fmaf(p0[t], k0, nd); p0[t + 1] = __builtin_fmaf(p0[t + 1], k1, nd); }
                 }
         }
+        // two copies behind ONE wave-uniform branch: written as `if (vis) pr = ...` inside the loop hipcc if-converts the test into
+        // a v_cmp + v_cndmask (+ s_and with vis) per element on EVERY tile -- a quarter of the loop's vector instructions, for a
+        // condition that holds on the diagonal and tail tiles only
+        auto elementwise = [&](auto VISC) __attribute__((always_inline)) {
+            constexpr bool VIS = decltype(VISC)::value != 0;
 #pragma unroll
-        for (int hb = 0; hb < 2; ++hb)
+            for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const int kr_ = hb * 32 + (t & 3) + 8 * (t >> 2) + 4 * hh;
-                float pr = __builtin_amdgcn_exp2f(fminf(__builtin_fmaf(hb ? s1[t] : s0[t], sl2, nlsl2), 0.f));   // p <= 1
-                if (vis) pr = (key0 + kr_ > klim) ? 0.f : pr;
-                if (hb) s1[t] = pr * p1[t]; else s0[t] = pr * p0[t];
-            }
+                for (int t = 0; t < 16; ++t) {
+                    const int kr_ = hb * 32 + (t & 3) + 8 * (t >> 2) + 4 * hh;
+                    float pr = __builtin_amdgcn_exp2f(fminf(__builtin_fmaf(hb ? s1[t] : s0[t], sl2, nlsl2), 0.f));   // p <= 1
+                    if (VIS) pr = (key0 + kr_ > klim) ? 0.f : pr;
+                    if (hb) s1[t] = pr * p1[t]; else s0[t] = pr * p0[t];
+                }
+        };
+        if (vis) elementwise(ic_<1>{}); else elementwise(ic_<0>{});
         // ---- dQ^T += K^T dS^T ----
         TRX_BWD_TRWAIT(kt0, 4)
         {
@@ -467,25 +475,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 TRX_BWD_TR(td0, 2, ta0 + 8192u, ta1 + 8192u) TRX_BWD_TR(td1, 3, ta0 + 8192u, ta1 + 8192u)
                 TRX_BWD_TR(tq0, 2, ta0, ta1) TRX_BWD_TR(tq1, 3, ta0, ta1)
             }
-            // ---- P = exp2(scale log2e (S - lse/scale) + mask log2e) ; dS = P (dP - delta) ----
+            // ---- P = exp2(scale log2e (S - lse/scale) + mask log2e) ; dS = P (dP - delta) ----  (two copies behind one
+            // wave-uniform branch, as in the dq pass)
+            auto elementwise = [&](auto VISC) __attribute__((always_inline)) {
+                constexpr bool VIS = decltype(VISC)::value != 0;
 #pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const int qr_ = q0 + hb * 32 + (t & 3) + 8 * (t >> 2) + 4 * hh;
-                float val = __builtin_fmaf(s[t], sl2, mk2);
-                if (MM == TRX_NN_MASK_FULL)
-                    val = __builtin_fmaf(fmaxf(mask[((int64_t)b * Lq + min(qr_, Lq - 1)) * Lk + kc], -1e30f), L2E, val);
-                float pr = __builtin_amdgcn_exp2f(fminf(val, 0.f));   // p <= 1
-                if (vis) pr = (qr_ >= Lq || qr_ < qmin) ? 0.f : pr;
-                if (DROP) {
-                    const unsigned bits = lowbias32(xdrop + (unsigned)(q0 + hb * 32 + (t & 3) + 8 * (t >> 2)) * DROP_C1);
-                    const float km = (((bits >> dshift) & 0xffffu) >= da.thr) ? da.inv_keep : 0.f;
-                    s[t] = pr * km;                                    // what the forward multiplied V with
-                    p[t] = pr * __builtin_fmaf(p[t], km, ndv[t]);
-                } else {
-                    s[t] = pr;
-                    p[t] = pr * p[t];
+                for (int t = 0; t < 16; ++t) {
+                    const int qr_ = q0 + hb * 32 + (t & 3) + 8 * (t >> 2) + 4 * hh;
+                    float val = __builtin_fmaf(s[t], sl2, mk2);
+                    if (MM == TRX_NN_MASK_FULL)
+                        val = __builtin_fmaf(fmaxf(mask[((int64_t)b * Lq + min(qr_, Lq - 1)) * Lk + kc], -1e30f), L2E, val);
+                    float pr = __builtin_amdgcn_exp2f(fminf(val, 0.f));   // p <= 1
+                    if (VIS) pr = (qr_ >= Lq || qr_ < qmin) ? 0.f : pr;
+                    if (DROP) {
+                        const unsigned bits = lowbias32(xdrop + (unsigned)(q0 + hb * 32 + (t & 3) + 8 * (t >> 2)) * DROP_C1);
+                        const float km = (((bits >> dshift) & 0xffffu) >= da.thr) ? da.inv_keep : 0.f;
+                        s[t] = pr * km;                                    // what the forward multiplied V with
+                        p[t] = pr * __builtin_fmaf(p[t], km, ndv[t]);
+                    } else {
+                        s[t] = pr;
+                        p[t] = pr * p[t];
+                    }
                 }
-            }
+            };
+            if (vis) elementwise(ic_<1>{}); else elementwise(ic_<0>{});
             // ---- dV^T += dO^T P ;  dK^T += Q^T dS ----
             TRX_BWD_TRWAIT(td0, 12)
             {
