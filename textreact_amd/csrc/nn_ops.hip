@@ -597,7 +597,9 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 template <bool VIS, bool DROP>
 __device__ __forceinline__ void attn_softmax_tile(f32x16& s0, f32x16& s1, f32x16& o0, f32x16& o1, float& m, float& lsum,
                                                   float sl2, int key0, int hh, int klim, unsigned xd, unsigned thr,
-                                                  unsigned (&pk)[2][8]) {
+                                                  unsigned (&pk)[2][8], int other_half = -1) {
+    // other_half: (lane ^ 32) * 4, the ds_bpermute address of the lane that holds this query's other 32 keys, computed ONCE by the
+    // caller (__shfl_xor recomputes it with seven vector instructions at every call: one per key tile, on the critical path)
     // the maximum is taken on the raw scores (scale > 0 commutes with it); the scaling then rides in the
     // exponent's fma: p = exp2(s * scale log2e - m)
     float mb = -__builtin_inff();
@@ -613,7 +615,16 @@ __device__ __forceinline__ void attn_softmax_tile(f32x16& s0, f32x16& s1, f32x16
             }
             mb = fmaxf(mb, val);
         }
-    mb = fmaxf(mb, __shfl_xor(mb, 32, 64)) * sl2;
+    {   // this query's other 32 keys sit in lane ^ 32.  v_permlane32_swap vdst, src swaps lanes 32-63 of vdst with lanes 0-31 of src:
+        // with the maximum in both, vdst = [lo | lo] and src = [hi | hi], and their maximum is the row's in every lane -- one
+        // instruction instead of the ds_bpermute round trip of __shfl_xor (~100 cycles on the tile's critical path: -3 %).  asm
+        // with its own two wait states: this hipcc's builtin returns vdst for both results and does not pad the VALU -> permlane
+        // hazard (tools/experiments/permlane_swap_check.hip).
+        float ma = mb, mc = mb;
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(ma), "+v"(mc));
+        mb = fmaxf(ma, mc) * sl2;
+    }
+    (void)other_half;
     const float mn = fmaxf(m, mb);
     const float mref = (mn == -__builtin_inff()) ? 0.f : mn;   // all hidden so far: exp2(-inf - 0) = 0, no NaN
     const float alpha = __builtin_amdgcn_exp2f(m - mref);
@@ -825,6 +836,7 @@ __global__ __launch_bounds__(XW ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
     // V^T read addresses: row 4(g>>1) + qq (+16 per k-step, +8 for the second read), 16-byte chunk
     // c = 4 db + 2 (g&1) + (pp>>1) stored at slot c ^ ((row & 3) << 1) -- the four rows a 16-lane group
     // touches then sit in four different 32-byte bank groups.  (row & 3) == qq for every read.
+    const int other_half = (lane ^ 32) << 2;
     const unsigned vtrA0 = ldsbase + (unsigned)(8192 + (4 * (g >> 1) + qq) * 128 + (((2 * (g & 1) + (pp >> 1)) ^ (qq << 1)) << 4) + 8 * (pp & 1));
     const int kswz = (r >> 1) & 7;
     unsigned kfa[4];   // K fragment addresses: row r (+32 by offset), chunk (2s + hh) ^ swizzle
@@ -935,8 +947,8 @@ __global__ __launch_bounds__(XW ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
         const bool vis = key0 + 63 > klim_wave_min;   // wave-uniform: some key of the tile is hidden for some lane
         const unsigned xd = xdrop + (unsigned)(kb * 32) * DROP_C2;
         unsigned pk[2][8];   // the tile's probabilities as bf16 pairs: the B operands of the second product
-        if (vis) attn_softmax_tile<true, DROP>(s0, s1, o0, o1, m, lsum, sl2, key0, hh, klim, xd, da.thr, pk);
-        else attn_softmax_tile<false, DROP>(s0, s1, o0, o1, m, lsum, sl2, key0, hh, klim, xd, da.thr, pk);
+        if (vis) attn_softmax_tile<true, DROP>(s0, s1, o0, o1, m, lsum, sl2, key0, hh, klim, xd, da.thr, pk, other_half);
+        else attn_softmax_tile<false, DROP>(s0, s1, o0, o1, m, lsum, sl2, key0, hh, klim, xd, da.thr, pk, other_half);
         // ---- O^T += V^T P^T: second half's reads fly under the first half's MFMAs ----
         TRX_VT_READ(2) TRX_VT_READ(3)
         TRX_VT_WAIT(0, 1, 8)

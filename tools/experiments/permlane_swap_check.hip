@@ -3,8 +3,11 @@
 #include <cstdio>
 __global__ void k(float* out) {
     float x = (float)threadIdx.x;
-    float a = x, b = x + 100.f;
-    asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));      // (the builtin of this hipcc returns the first register twice)
+    // v_permlane32_swap vdst, src: lanes 32-63 of vdst swap with lanes 0-31 of src.  Through asm with the two wait states the
+    // hazard rule asks for after a VALU write of an operand (this hipcc's builtin returns vdst as BOTH results and pads nothing).
+    // a = b = lane  ->  a = [lo | lo], b = [hi | hi]: max(a, b) is the cross-half maximum in every lane
+    float a = x, b = x;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
     out[threadIdx.x] = fmaxf(a, b);
     out[64 + threadIdx.x] = a; out[128 + threadIdx.x] = b;
 }
