@@ -625,7 +625,15 @@ __device__ __forceinline__ void attn_softmax_tile(f32x16& s0, f32x16& s1, f32x16
         mb = fmaxf(ma, mc) * sl2;
     }
     (void)other_half;
-    const float mn = fmaxf(m, mb);
+    // The reference the exponents are taken against only moves when the row's maximum has outgrown it by more than 2^TRX_ATT_LAZY
+    // (8: probabilities up to 256 before normalisation -- bf16 and the fp32 sums do not care, they would with fp16): on most
+    // tiles no lane moves it, alpha is 1 everywhere and the 16 v_pk_mul of the output rescale are skipped.  Any reference that
+    // is the same for all keys of a row is exact; the log-sum-exp written at the end is m + log2(sum) whatever m is.
+#ifndef TRX_ATT_LAZY
+#define TRX_ATT_LAZY 8
+#endif
+    const float mt_ = fmaxf(m, mb);
+    const float mn = (TRX_ATT_LAZY > 0 && !(mt_ > m + (float)TRX_ATT_LAZY)) ? m : mt_;      // m = -inf: any finite maximum moves it
     const float mref = (mn == -__builtin_inff()) ? 0.f : mn;   // all hidden so far: exp2(-inf - 0) = 0, no NaN
     const float alpha = __builtin_amdgcn_exp2f(m - mref);
     const float nref = -mref;
