@@ -146,6 +146,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         sofs[i] = (unsigned)rw * rowbytes + TRX_BWD_SW_OFS(rw, pslot);
     }
     const unsigned ldsbase0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+    const unsigned lds_w = (unsigned)__builtin_amdgcn_readfirstlane((int)(ldsbase0 + (unsigned)(2 * wave * 1024)));   // this wave's pieces, scalar
 #define TRX_BWD1_STAGE(KB, BUF)                                                                             \
     {                                                                                                       \
         const char* kt_ = kbase + (int64_t)(KB) * 64 * rowbytes;                                            \
@@ -156,8 +157,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const int rw_ = 8 * (2 * wave + i_) + prow;                                                 \
                 so_ = (unsigned)min(rw_, Lk - 1 - (KB) * 64) * rowbytes + TRX_BWD_SW_OFS(rw_, pslot);       \
             }                                                                                               \
-            TRX_GLDS16((unsigned long long)kt_, so_, ldsbase0 + (unsigned)((BUF) * 16384 + (2 * wave + i_) * 1024));        \
-            TRX_GLDS16((unsigned long long)vt_, so_, ldsbase0 + (unsigned)((BUF) * 16384 + 8192 + (2 * wave + i_) * 1024)); \
+            TRX_GLDS16((unsigned long long)kt_, so_, lds_w + (unsigned)((BUF) * 16384 + i_ * 1024));                      \
+            TRX_GLDS16((unsigned long long)vt_, so_, lds_w + (unsigned)((BUF) * 16384 + 8192 + i_ * 1024));               \
         }                                                                                                   \
     }
     const unsigned ldsbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
@@ -379,6 +380,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     // per stage and wave: 4 tile loads (+ 2 loads of the per-query scalars on wave 0)
     const unsigned ldsbase0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+    const unsigned lds_w = (unsigned)__builtin_amdgcn_readfirstlane((int)(ldsbase0 + (unsigned)(2 * wave * 1024)));
 #define TRX_BWD2_STAGE(QT, BUF)                                                                             \
     {                                                                                                       \
         const char* qt_ = qbase + (int64_t)(QT) * 64 * rowbytes;                                            \
@@ -390,8 +392,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 so_ = (unsigned)min(rw_, Lq - 1 - (QT) * 64) * rowbytes + TRX_BWD_SW_OFS(rw_, pslot);       \
                 sd_ = (unsigned)min(rw_, Lq - 1 - (QT) * 64) * rowbytes_d + TRX_BWD_SW_OFS(rw_, pslot);     \
             }                                                                                               \
-            TRX_GLDS16((unsigned long long)qt_, so_, ldsbase0 + (unsigned)((BUF) * BWD2_STAGE + (2 * wave + i_) * 1024));        \
-            TRX_GLDS16((unsigned long long)dt_, sd_, ldsbase0 + (unsigned)((BUF) * BWD2_STAGE + 8192 + (2 * wave + i_) * 1024)); \
+            TRX_GLDS16((unsigned long long)qt_, so_, lds_w + (unsigned)((BUF) * BWD2_STAGE + i_ * 1024));                 \
+            TRX_GLDS16((unsigned long long)dt_, sd_, lds_w + (unsigned)((BUF) * BWD2_STAGE + 8192 + i_ * 1024));          \
         }                                                                                                   \
         if (wave == 0) {                                                                                    \
             const int qi_ = min((QT) * 64 + lane, Lq - 1);                                                  \
