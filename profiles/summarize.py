@@ -8,7 +8,7 @@ import csv, glob, json, os, shutil, sys, collections
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "prof_" + tag)
-stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
+stats = sorted(glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime, reverse=True)      # gpurun MERGES into gpurun_out/: take the newest run's file
 assert stats, "no kernel_stats.csv under " + src
 shutil.copy(stats[0], os.path.join(root, "profiles", tag + "_kernel_stats.csv"))
 
@@ -22,7 +22,7 @@ def is_boot(name):
 def counters(sub):
     agg = collections.defaultdict(list)
     name = None
-    for f in glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True):
+    for f in sorted(glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime, reverse=True)[:1]:   # newest run only
         for r in csv.DictReader(open(f)):
             if "knn_scan_kernel" in r["Kernel_Name"] and not is_boot(r["Kernel_Name"]):
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))

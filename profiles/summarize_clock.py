@@ -8,11 +8,11 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "clock_" + tag)
 disp = {}
-for f in glob.glob(os.path.join(src, "pmc_grbm", "**", "*kernel_trace.csv"), recursive=True):
+for f in sorted(glob.glob(os.path.join(src, "pmc_grbm", "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime, reverse=True)[:1]:   # newest run only
     for r in csv.DictReader(open(f)):
         disp[r["Dispatch_Id"]] = (r["Kernel_Name"], int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 clocks = []
-for f in glob.glob(os.path.join(src, "pmc_grbm", "**", "*counter_collection.csv"), recursive=True):
+for f in sorted(glob.glob(os.path.join(src, "pmc_grbm", "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime, reverse=True)[:1]:
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"]
         if "knn_scan_kernel" in name and r["Counter_Name"] == "GRBM_GUI_ACTIVE":

@@ -14,7 +14,7 @@ N = plan["N"]
 
 def dispatches(sub):
     """per kernel-name substring: list of dispatches in launch order, each {counter: value, 'us': duration}"""
-    f = glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True)
+    f = sorted(glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime, reverse=True)      # gpurun MERGES into gpurun_out/: take the newest run's file
     by = collections.OrderedDict()
     for r in csv.DictReader(open(f[0])):
         key = (r["Dispatch_Id"], r["Kernel_Name"])
