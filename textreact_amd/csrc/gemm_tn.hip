@@ -48,9 +48,29 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_tn_kernel(Params p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave_n = wave >> 2, wave_k = wave & 3;      // 2 x 4 waves: 128 n x 64 k each
+    // Which (split, tile) a workgroup takes (TRX_TN_GROUP, default on).  The tn x tk tiles of ONE split read the same token rows: a
+    // row block of A is wanted by the tk workgroups of its tile column, one of B by the tn of its tile row.  Workgroups are
+    // placed on the 8 XCDs round-robin (bid & 7), each XCD with its own L2: numbered split-fastest (round 2) the ~32 workgroups of
+    // an XCD are 32 different (split, tile) pairs that share nothing, and every operand byte is fetched tk or tn times from the
+    // fabric -- 600 MB per FFN weight gradient, 7 TB/s: the kernel ran at the Infinity-Cache's bandwidth, not at its MFMAs'.
+    // Numbered split-SLOWEST and dealt to the XCDs in contiguous runs (the scan kernel's bijective remap), an XCD holds the tiles
+    // of one or two splits, which walk the same rows in step and find each other's lines in L2.
+#ifndef TRX_TN_GROUP
+#define TRX_TN_GROUP 1
+#endif
     int bid = blockIdx.x;
-    const int split = bid % p.nsplit; bid /= p.nsplit;
-    const int kt = bid % p.tk, nt = bid / p.tk;
+    int split, kt, nt;
+    if (TRX_TN_GROUP) {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = bid & 7;
+        const int v = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);      // XCD x owns [base, base + q (+1))
+        const int tiles = p.tn * p.tk;
+        split = v / tiles;
+        const int t = v - split * tiles;
+        kt = t % p.tk; nt = t / p.tk;
+    } else {
+        split = bid % p.nsplit; bid /= p.nsplit;
+        kt = bid % p.tk; nt = bid / p.tk;
+    }
     const int n0 = nt * TILE, k0 = kt * TILE;
     const int total_steps = (p.M + BM - 1) / BM;          // the last step may be partial: rows >= M read as zeros (A) / row M-1 (B)
     const int step0 = split * p.steps_per_split;
