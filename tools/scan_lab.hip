@@ -17,7 +17,7 @@
 //           bit3: (variant 4) fragments read once and reused: no LDS read traffic
 //           bits 8+: workgroup (query tile q of its XCD group of 8) starts (q & 7) * (flags >> 8) * ~1024 cycles late: the 8 workgroups
 //                 that share a corpus stream stop asking for the same tile at the same moment
-//           bit7: (variant 4) odd corpus tiles walk their K-steps downwards (boustrophedon): see lab_v2
+//           bit7: (variants 1-4) odd corpus tiles walk their K-steps downwards (boustrophedon): see lab_v2
 //           bit6: (variants 1-4, 9) drift gate: the 8 workgroups sharing a corpus stream wait for the slowest (LAB_DRIFT)
 //           bit5: (variants 4, 9) a prefetching load per wave and K-step for the corpus slice LAB_PF_DIST K-steps ahead
 //           bit4: (variants 4, 9) every tile re-reads the split's first corpus tile: the fill never misses L2
@@ -266,9 +266,14 @@ __global__ __launch_bounds__(THREADS, 2) void lab_v1(LabParams p) {
     // group 0 stages rows 128-255 of K-steps 1, 2, ...; group 1 rows 0-127 of K-steps 2, 3, ...
     const bf16_t* srcB = gB + (wave_m ? half_elems : 0);
     int ksB = 1;
-    const bf16_t* srcA = gA + (wave_m ? 0 : half_elems) + (wave_m ? 2 : 1) * BK;
+    const bf16_t* baseA1 = gA + (wave_m ? 0 : half_elems);
     int ksA = wave_m ? 2 : 1;
-    const int wrapA = 255 * Kp;       // elements to add when a K-step cursor moves on to the next tile
+    // flags bit7 (as in variant 4): odd tiles walk their K-steps downwards
+    const bool bous1 = (p.flags & 128) != 0;
+    int tlB1 = 0, tlA1 = 0;
+#define V1_KSE(KS, T) ((bous1 && ((T) & 1)) ? ksteps - 1 - (KS) : (KS))
+    int kbe1 = V1_KSE(ksB, tlB1);
+    const bf16_t* srcA = baseA1 + V1_KSE(ksA, tlA1) * BK;
     const bool dma_on = !(p.flags & 1);
     const bool mfma_on = !(p.flags & 2);
 
@@ -310,12 +315,13 @@ __global__ __launch_bounds__(THREADS, 2) void lab_v1(LabParams p) {
     // B pieces of this wave's half for the K-step after the current one -> stage STG
 #define V1_DMA_B(STG)                                                                                      \
     if (dma_on) {                                                                                          \
-        const bf16_t* s_ = srcB + ksB * BK;                                                                \
+        const bf16_t* s_ = srcB + kbe1 * BK;                                                                  \
         char* l_ = smem + LDS_B0 + (STG) * 32768 + wave_m * 16384 + lds_piece0;                            \
         _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                   \
             __builtin_amdgcn_global_load_lds((gbl_void*)(s_ + poff[i_]), (lds_void*)(l_ + i_ * 1024), 16, 0, 0); \
     }                                                                                                      \
-    ksB = (ksB + 1 == ksteps) ? 0 : ksB + 1;
+    if (++ksB == ksteps) { ksB = 0; ++tlB1; }                                                              \
+    kbe1 = V1_KSE(ksB, tlB1);
     // A pieces: group 0 -> rows 128-255, group 1 -> rows 0-127, of the cursor's K-step -> stage STG
 #define V1_DMA_A(STG)                                                                                      \
     if (dma_on) {                                                                                          \
@@ -323,8 +329,8 @@ __global__ __launch_bounds__(THREADS, 2) void lab_v1(LabParams p) {
         _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                   \
             __builtin_amdgcn_global_load_lds((gbl_void*)(srcA + poff[i_]), (lds_void*)(l_ + i_ * 1024), 16, 0, 0); \
     }                                                                                                      \
-    srcA += BK;                                                                                            \
-    if (++ksA == ksteps) { ksA = 0; srcA += wrapA; }
+    if (++ksA == ksteps) { ksA = 0; ++tlA1; baseA1 += 256 * Kp; }                                          \
+    srcA = baseA1 + V1_KSE(ksA, tlA1) * BK;
 
 #define V1_L(KK, STG, DMA)                                                                                 \
     if (OPT & 1) { V1_READ(KK, STG); DMA; } else { DMA; V1_READ(KK, STG); }
