@@ -1,0 +1,24 @@
+"""which ATen ops one optimisation step of the full-size predictor issues (counts, self device time): python3 tools/step_ops.py"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from torch.profiler import profile, ProfilerActivity
+from textreact_amd.predictor import train
+from textreact_amd.predictor.model import Config
+dev, B, L, T = torch.device("cuda", 0), 32, 512, 160
+g = torch.Generator().manual_seed(0)
+batch = {"input_ids": torch.randint(1, 31090, (B, L), generator=g).to(dev), "attention_mask": torch.ones(B, L, dtype=torch.long, device=dev),
+         "decoder_input_ids": torch.randint(14, 600, (B, T), generator=g).to(dev), "decoder_attention_mask": torch.ones(B, T, dtype=torch.long, device=dev)}
+p = train.Predictor(Config(vocab_size=31090), Config(vocab_size=600, num_hidden_layers=6, type_vocab_size=1, layer_norm_eps=1e-5, is_decoder=True), mlm=False).to(dev).train()
+opt, _ = train.configure_optimizer(p, 1e-4, 0.01, 1000, 0.02)
+def step():
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        loss, _ = p.training_step(batch)
+    loss.backward(); opt.step(); opt.zero_grad(set_to_none=True); train.mark_parameters_updated(p)
+for _ in range(3): step()
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+    step(); torch.cuda.synchronize()
+rows = sorted(prof.key_averages(), key=lambda e: -e.count)
+for e in rows[:45]:
+    print("%5d  %-50s self device %8.1f us" % (e.count, e.key[:50], getattr(e, "self_device_time_total", getattr(e, "self_cuda_time_total", 0))))
