@@ -67,38 +67,111 @@ def try_faiss():
         return None, "unavailable"
 
 
-def cpu_baseline(corpus_dev, queries_dev, k, target_seconds=15.0, metric=0):
+def cpu_baseline(corpus_dev, queries_dev, k, target_seconds=20.0, metric=0):
     """CPU search on a bounded sample of the same workload: real FAISS when importable ('reference'), otherwise the
-    oracle's FAISS-structured restatement with the host BLAS doing the 4096 x 1024 sgemm blocks ('port')."""
+    oracle's FAISS-structured restatement ('port': fp32 sgemm of 4096 x 1024 blocks by the host BLAS + the strict-
+    admission heap on every block).  ONE full FAISS query block (4,096 queries) against the whole corpus
+    unless a probe predicts more than 120 s.  The port spreads the corpus blocks over one worker thread per core with a
+    single BLAS thread per sgemm call (oracle.knn_faiss_blas_mt); FAISS's own form -- all threads inside each 6.4-GFLOP
+    sgemm -- is probed too and its rate reported beside it (`blas_internal_threading_tflops`)."""
     import numpy as np
     from oracle import flat_knn as oracle
     cores = len(os.sched_getaffinity(0))
     y = corpus_dev.float().cpu().numpy()
+    d = y.shape[1]
     faiss, faiss_version = try_faiss()
     if faiss is not None:
-        ref = (faiss.IndexFlatL2 if metric == 1 else faiss.IndexFlatIP)(y.shape[1])
+        ref = (faiss.IndexFlatL2 if metric == 1 else faiss.IndexFlatIP)(d)
         ref.add(y)
         nq = min(4096, queries_dev.shape[0])
         x = queries_dev[:nq].float().cpu().numpy()
         ref.search(x[:64], k)
         t0 = time.perf_counter(); D, I = ref.search(x, k); t1 = time.perf_counter()
         return {"value": nq / (t1 - t0), "unit": "queries/s", "cores": cores, "kind": "reference", "faiss": faiss_version,
+                "tflops": 2.0 * nq * y.shape[0] * d / (t1 - t0) / 1e12,
                 "sample": "%d of %d queries x full %dx%d corpus, faiss.IndexFlat%s %s" % (
-                    nq, queries_dev.shape[0], y.shape[0], y.shape[1], "L2" if metric == 1 else "IP", faiss_version)}, I
-    # size the sample from a probe with FAISS's own block shape (4096 queries x 8 corpus blocks) so
-    # the leg stays within ~10-40 s on any host; 4096 queries = one full FAISS query block
+                    nq, queries_dev.shape[0], y.shape[0], d, "L2" if metric == 1 else "IP", faiss_version)}, I
+    blas = "unknown"
+    try:
+        from threadpoolctl import threadpool_info
+        blas = "; ".join("%s %s (%s, %d threads max)" % (i.get("internal_api"), i.get("version"), i.get("threading_layer"), i.get("num_threads"))
+                         for i in threadpool_info() if i.get("user_api") == "blas") or "unknown"
+    except Exception:
+        pass
     nprobe = min(4096, queries_dev.shape[0])
     probe = queries_dev[:nprobe].float().cpu().numpy()
+    # (a) FAISS's own threading: every BLAS thread inside one block's sgemm.  8 corpus blocks.
     ysub = y[:8192]
     oracle.knn_faiss_blas(metric, probe[:64], ysub[:1024], k)  # warm BLAS threads
     t0 = time.perf_counter(); oracle.knn_faiss_blas(metric, probe, ysub, k); t1 = time.perf_counter()
-    est_full = (t1 - t0) * (y.shape[0] / float(ysub.shape[0]))
-    nq = nprobe if est_full <= 2.5 * target_seconds else max(512, int(nprobe * 2.5 * target_seconds / est_full))
-    x = queries_dev[:nq].float().cpu().numpy()
-    t0 = time.perf_counter(); D, I = oracle.knn_faiss_blas(metric, x, y, k); t1 = time.perf_counter()
+    internal_tflops = 2.0 * nprobe * ysub.shape[0] * d / (t1 - t0) / 1e12
+    # (b) one worker per core over the corpus blocks, one BLAS thread each: probe on 2 blocks per worker, then the sample
+    workers = cores
+    yprobe = y[:min(y.shape[0], 2 * 1024 * workers)]
+    oracle.knn_faiss_blas_mt(metric, probe[:256], yprobe[:1024 * min(workers, 8)], k, workers)
+    t0 = time.perf_counter(); oracle.knn_faiss_blas_mt(metric, probe, yprobe, k, workers); t1 = time.perf_counter()
+    est_full = (t1 - t0) * (y.shape[0] / float(yprobe.shape[0]))
+    nq = nprobe if est_full <= 120.0 else max(512, int(nprobe * target_seconds / est_full))
+    x = probe[:nq]
+    t0 = time.perf_counter(); D, I = oracle.knn_faiss_blas_mt(metric, x, y, k, workers); t1 = time.perf_counter()
     return {"value": nq / (t1 - t0), "unit": "queries/s", "cores": cores, "kind": "port", "faiss": faiss_version,
-            "sample": "%d of %d queries x full %dx%d corpus, fp32 host-BLAS sgemm 4096x1024 blocks + heap"
-                      % (nq, queries_dev.shape[0], y.shape[0], y.shape[1])}, I
+            "tflops": 2.0 * nq * y.shape[0] * d / (t1 - t0) / 1e12, "blas": blas,
+            "threads": "%d worker threads over the corpus blocks x 1 BLAS thread per sgemm call" % workers,
+            "blas_internal_threading_tflops": internal_tflops, "seconds": t1 - t0,
+            "sample": "%d of %d queries (%s) x full %dx%d corpus, fp32 host-BLAS sgemm 4096x1024 blocks + heap"
+                      % (nq, queries_dev.shape[0], "one full FAISS query block" if nq == 4096 else "probe predicted %.0f s for 4096" % est_full,
+                         y.shape[0], d)}, I
+
+
+def selfcheck(index, local, shard, lo, queries, k, D, I, world, rank, dev, n_sample=32):
+    """Before the timed region: (1) every rank holds the same (D, I) -- a hash per rank, gathered; (2) `n_sample` queries
+    are re-done with nothing of the search path in it: fp64 scores of the queries against this rank's shard by torch.matmul,
+    a local top-k, ONE plain all_gather of the (score, global id) lists, a sort by (score desc, id asc) on every rank.  A
+    wrong exchange (split sizes, offsets, the merge's list order, a stale buffer) shows up as a non-zero exit code, not as a
+    fast wrong number.  Returns the list of problems (empty = fine)."""
+    import torch
+    import torch.distributed as dist
+    problems = []
+    h = torch.stack([(I * torch.arange(1, k + 1, device=dev)).sum(), I.sum(), D.view(torch.int32).long().sum()])
+    if world > 1:
+        hs = [torch.empty_like(h) for _ in range(world)]
+        if dist.get_backend() == "gloo":
+            hh = [x.cpu() for x in hs]; dist.all_gather(hh, h.cpu()); hs = hh
+        else:
+            dist.all_gather(hs, h)
+        if any(not torch.equal(x.cpu(), hs[0].cpu()) for x in hs):
+            problems.append("ranks hold different (D, I): %r" % [x.tolist() for x in hs])
+    g = torch.Generator().manual_seed(11)
+    rows = torch.randperm(queries.shape[0], generator=g)[:n_sample].to(dev)
+    sc = queries[rows].double() @ shard.double().t()                       # [n_sample, n_local] fp64
+    kk = min(k, sc.shape[1])
+    top, idx = torch.topk(sc, kk, dim=1)
+    ids = idx + lo
+    if world > 1:
+        pack = torch.stack([top.view(torch.int64), ids], dim=0).contiguous()
+        parts = [torch.empty_like(pack) for _ in range(world)]
+        if dist.get_backend() == "gloo":
+            hp = [x.cpu() for x in parts]; dist.all_gather(hp, pack.cpu()); parts = [x.to(dev) for x in hp]
+        else:
+            dist.all_gather(parts, pack)
+        top = torch.cat([p_[0].view(torch.float64) for p_ in parts], dim=1)
+        ids = torch.cat([p_[1] for p_ in parts], dim=1)
+    order = torch.argsort(ids, dim=1, stable=True)                        # (score desc, id asc): sort by id, then stably by score
+    top, ids = torch.gather(top, 1, order), torch.gather(ids, 1, order)
+    order = torch.argsort(top, dim=1, descending=True, stable=True)[:, :k]
+    want_s, want_i = torch.gather(top, 1, order), torch.gather(ids, 1, order)
+    got_i, got_d = I[rows], D[rows]
+    bad = (got_i != want_i)
+    if bool(bad.any()):
+        # a swap between two rows whose fp64 scores agree to 1e-12 relative is a rounding tie of the matmul's summation
+        # order against the product's k-ordered fma chain, not an error
+        diff = (want_s - got_d.double()).abs() / want_s.abs().clamp(min=1.0)
+        real = bad & (diff > 1e-6)      # D is fp32: the id changed AND its score is a different fp32 number
+        if bool(real.any()):
+            problems.append("rank %d: %d of %d sampled entries differ from the independent fp64 re-computation" % (rank, int(real.sum()), bad.numel()))
+    if not bool(torch.allclose(got_d.double(), want_s, rtol=1e-6, atol=1e-6)):
+        problems.append("rank %d: distances of the sampled queries differ from the fp64 re-computation" % rank)
+    return problems
 
 
 def fingerprint_workload(args, dev, local_rank):
@@ -171,6 +244,9 @@ def main():
     ap.add_argument("--replicas", action="store_true",
                     help="query-sharded replicas (SURVEY 8e, the separate line): every GPU holds the WHOLE corpus and searches "
                          "its 1/G of the queries, no collective on the data path; not the north-star line (row-sharded)")
+    ap.add_argument("--selfcheck", action="store_true",
+                    help="also at N = 1 (always on at N > 1): before the timed region, compare every rank's result hashes and re-do "
+                         "32 sampled queries by an independent fp64 matmul + all_gather + sort; exit code 3 on a mismatch")
     ap.add_argument("--workload", default="dense", choices=["dense", "fingerprint"],
                     help="dense = the headline (BASELINE.json configs[1]); fingerprint = the reference's own call: "
                          "IndexFlatL2, k=20, 2048-d integer reaction fingerprints, train set searching itself (not the headline)")
@@ -220,7 +296,10 @@ def main():
         index.add(shard)
     else:
         index = ShardedFlatIndex(d, faiss.METRIC_INNER_PRODUCT, local_index=local)
-        index.add_shard(shard, lo, n)
+        # fault injection for tests/test_bench_gpu.py: the last rank reports its rows one id too high -- the kind of
+        # plumbing error the selfcheck exists for
+        wrong = 1 if (os.environ.get("TRX_BENCH_INJECT_FAULT") == "offset" and world > 1 and rank == world - 1) else 0
+        index.add_shard(shard, lo + wrong, n)
     torch.cuda.synchronize()
 
     def sync():
@@ -230,6 +309,23 @@ def main():
 
     for _ in range(args.warmup):
         D, I = index.search(queries, k)
+    checked = None
+    if (world > 1 or args.selfcheck) and not args.replicas:
+        D, I = index.search(queries, k)
+        problems = selfcheck(index, local, shard, lo, queries, k, D, I, world, rank, dev)
+        flag = torch.tensor([len(problems)], dtype=torch.int32, device=dev)
+        if world > 1:
+            if backend == "nccl":
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            else:
+                fh = flag.cpu(); dist.all_reduce(fh, op=dist.ReduceOp.MAX); flag = fh
+        if problems:
+            print("bench.py selfcheck FAILED on rank %d: %s" % (rank, "; ".join(problems)), file=sys.stderr, flush=True)
+        if int(flag.item()):
+            if world > 1:
+                dist.destroy_process_group()
+            sys.exit(3)
+        checked = "passed: identical (D, I) hashes on %d rank(s); 32 sampled queries equal an independent fp64 matmul + all_gather + sort" % world
     scan_ms, launches, uncert = 0.0, 0, 0
     # per-step HIP events on torch's current stream = the stream the library launches on (faiss_compat passes it through
     # the C ABI): recording them costs nothing inside the timed region
@@ -304,7 +400,7 @@ def main():
                        "transport": ("RCCL (nccl backend), one GPU per rank" if backend == "nccl" else
                                      "REHEARSAL: %d ranks share GPU %d, %s backend (host round trip in the all-gather); not a scaling measurement"
                                      % (world, local_rank, backend)) if world > 1 else None,
-                       "uncertified_queries_per_step": uncert / args.steps},
+                       "uncertified_queries_per_step": uncert / args.steps, "selfcheck": checked},
             "roofline": {"bound": "mfma", "kernel": "knn_scan_kernel", "achieved": achieved,
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
                          "traffic": traffic, "traffic_source": traffic_source, "launch_ms": mean_launch_ms,

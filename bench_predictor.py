@@ -147,6 +147,148 @@ def generate_bench(dev, B=8):
     return res
 
 
+def live_problem(P, N, Lp=128, Lq=128, vocab=31090, seed=0):
+    """BASELINE.json configs[4] at the size of scripts/train_RetroSyn_tf.sh: a USPTO-50K-sized training split (N ~ 40 k
+    product SMILES) against a text corpus of P passages, pre-tokenised (tokenizers are out of scope): passage lengths uniform
+    in [16, Lp], query lengths in [16, Lq], every 7th passage a duplicate text (the de-duplication has work to do), the
+    gold passage of 3 in 4 samples present in the corpus.  Seeded; the same tensors on every rank."""
+    g = torch.Generator().manual_seed(seed)
+    plen = torch.randint(16, Lp + 1, (P,), generator=g)
+    pids = torch.randint(1000, vocab, (P, Lp), generator=g, dtype=torch.int32)
+    dup = torch.arange(7, P, 7)
+    pids[dup], plen[dup] = pids[dup - 2], plen[dup - 2]
+    corpus = {"passage_ids": pids, "passage_len": plen, "marker_ids": torch.tensor([[1006, 1014 + j, 1007] for j in range(3)]),
+              "cls_id": 101, "sep_id": 102, "pad_id": 0, "mask_id": 103}
+    qlen = torch.randint(16, Lq + 1, (N,), generator=g)
+    qids = torch.randint(1000, vocab, (N, Lq), generator=g)
+    gold = torch.randint(0, P, (N,), generator=g)
+    gold[::4] = -1
+    return corpus, qids, qlen, gold
+
+
+def live_bench(dev, P=204800, N=40000, k=10, rank=0, world=1, encoder=None, max_length=512, train_step_ms=None,
+               return_tensors=False):
+    """One refresh of the on-the-fly retrieval (textreact_amd/live.py, main.py --live_every) at the scripts' size, stage by
+    stage: BERT-base DenseEncoder ([CLS] embeddings, bf16 autocast, the HIP attention / add+LayerNorm kernels) over this
+    rank's passages -> flat index add -> this rank's 1/G of the queries + one all-gather -> row-sharded exact top-k ->
+    per-epoch assembly of the encoder inputs (select_neighbors + assemble_inputs + apply_mlm with train_RetroSyn_tf.sh's
+    options).  BASELINE.md C4: "retrieval refresh time per epoch" beside the epoch's train time."""
+    import time
+    from textreact_amd import dense, live
+    from textreact_amd.predictor.model import Config
+    cd, qids, qlen, gold = live_problem(P, N)
+    corpus = live.LiveCorpus(cd, dev)
+    if encoder is None:
+        torch.manual_seed(0)
+        encoder = dense.DenseEncoder(Config(vocab_size=31090)).to(dev).eval()
+    ms = {}
+    nn, emb_q, emb_p = live.refresh_neighbors(encoder, encoder, corpus, qids, qlen, k, rank, world, return_embeddings=True,
+                                              timings={})          # warm-up: allocator, library heuristics, index workspaces
+    del nn, emb_q, emb_p
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    nn, emb_q, emb_p = live.refresh_neighbors(encoder, encoder, corpus, qids, qlen, k, rank, world, return_embeddings=True, timings=ms)
+    torch.cuda.synchronize()
+    refresh_ms = (time.perf_counter() - t0) * 1e3
+    # the epoch's inputs, as main.py's LiveData.inputs builds them (blocks of 32,768 samples)
+    gen = torch.Generator().manual_seed(1)
+    t0 = time.perf_counter()
+    widest = 0
+    for b0 in range(0, N, 32768):
+        r = slice(b0, b0 + 32768)
+        sel = live.select_neighbors(nn[r], gold[r].to(dev), corpus, True, use_gold_neighbor=True, max_num_neighbors=10, num_neighbors=3,
+                                    random_neighbor_ratio=0.2, generator=gen)
+        ids, mask, lens = live.assemble_inputs(qids[r], qlen[r], sel, corpus, max_length)
+        ids, pos, labels = live.apply_mlm(ids, lens, 0.15, corpus.mask_id, gen)
+        widest = max(widest, ids.shape[1])
+    torch.cuda.synchronize()
+    assemble_ms = (time.perf_counter() - t0) * 1e3
+    uncert = ms.pop("uncertified_queries", None)
+    # the search stage alone on embeddings with the spread of a TRAINED retriever: with random-init weights every [CLS]
+    # embedding is nearly the same vector (cosine of two passages > 0.99), the top-10 scores of a query lie within the
+    # certificate's a-priori rounding bound of each other, and every query takes the exact fp64 re-scan -- a worst case that
+    # says nothing about a real refresh.  Same shapes, Gaussian embeddings (BASELINE.json configs[1]'s data):
+    from textreact_amd import faiss_compat
+    from textreact_amd.sharded import ShardedFlatIndex, shard_bounds
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    lo, hi = shard_bounds(P, world, rank)
+    gp = torch.randn((P, 768), generator=g, device=dev).bfloat16()[lo:hi].contiguous()
+    gq = torch.randn((N, 768), generator=g, device=dev).bfloat16()
+    gi = ShardedFlatIndex(768, 0, local_index=faiss_compat.IndexFlatIP(768, device=dev.index or 0))
+    gi.add_shard(gp, lo, P)
+    gi.search(gq, k)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    gi.search(gq, k)
+    torch.cuda.synchronize()
+    search_gauss_ms = (time.perf_counter() - t0) * 1e3
+    gauss_uncert = gi.local.last_stats()["n_uncertified"]
+    del gi, gp, gq
+    cosine = float(torch.nn.functional.cosine_similarity(emb_p[:2048:2].float(), emb_p[1:2048:2].float()).mean())
+    steps_per_epoch = -(-N // (32 * world))
+    row = {"kernel": "live_refresh", "what": "BASELINE.json configs[4]: on-the-fly retrieval refresh at the size of train_RetroSyn_tf.sh",
+           "encoder": "BERT-base DenseEncoder (12 layers, hidden 768, vocab 31090), bf16 autocast, random init",
+           "passages": P, "passage_tokens": "16-128 + [CLS] [SEP]", "queries": N, "query_tokens": "16-128 + [CLS] [SEP]", "k": k,
+           "ranks": world, "ms": {**{k_: round(v, 2) for k_, v in ms.items()}, "assemble_epoch_inputs": round(assemble_ms, 2)},
+           "refresh_ms": round(refresh_ms, 2), "refresh_plus_assemble_ms": round(refresh_ms + assemble_ms, 2),
+           "uncertified_queries": uncert, "mean_cosine_of_passage_pairs": round(cosine, 4),
+           "search_ms_on_gaussian_embeddings_of_the_same_shape": round(search_gauss_ms, 2), "uncertified_on_gaussian": gauss_uncert,
+           "assembled_width": widest,
+           "passages_per_s_encode": (P / world) / (ms["encode_passages"] * 1e-3),
+           "steps_per_epoch": steps_per_epoch, "train_step_ms": train_step_ms,
+           "epoch_train_ms": None if train_step_ms is None else train_step_ms * steps_per_epoch,
+           "refresh_share_of_epoch": None if train_step_ms is None else (refresh_ms + assemble_ms) / (train_step_ms * steps_per_epoch + refresh_ms + assemble_ms)}
+    if world > 1:
+        row["transport"] = "REHEARSAL: %d ranks share one GPU over gloo (host round trips in the collectives; the stages time-slice the device): not a scaling number" % world
+    return (row, nn, emb_q, emb_p) if return_tensors else row
+
+
+def _live_rank(rank, world, port, P, N, ret):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    row = live_bench(dev, P, N, rank=rank, world=world)
+    if rank == 0:
+        ret["row"] = row
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def live_rows(dev, P=204800, N=40000):
+    """--live: the refresh on one rank (with the train step it is to be read against), then as a 2-rank one-device rehearsal"""
+    import socket
+    import torch.multiprocessing as mp
+    from textreact_amd.predictor.model import Config
+    from textreact_amd.predictor import train
+    # the epoch's train time: the step of train_RetroSyn_tf.sh's shapes (B 32 per GPU, L 512, T 160, bf16 autocast, --mlm)
+    B, L, T = 32, 512, 160
+    g = torch.Generator().manual_seed(0)
+    batch = {"input_ids": torch.randint(1, 31090, (B, L), generator=g).to(dev), "attention_mask": torch.ones(B, L, dtype=torch.long, device=dev),
+             "decoder_input_ids": torch.randint(14, 600, (B, T), generator=g).to(dev), "decoder_attention_mask": torch.ones(B, T, dtype=torch.long, device=dev)}
+    labels = {"mlm_labels": torch.randint(0, 31090, (B, 76), generator=g).to(dev)}
+    torch.manual_seed(0)
+    p = train.Predictor(Config(vocab_size=31090), Config(vocab_size=600, num_hidden_layers=6, type_vocab_size=1, layer_norm_eps=1e-5, is_decoder=True),
+                        mlm=True).to(dev).train()
+    opt, _ = train.configure_optimizer(p, 1e-4, 0.01, 1000, 0.02)
+
+    def step():
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss, _ = p.training_step(batch, labels)
+        loss.backward(); opt.step(); opt.zero_grad(set_to_none=True)
+    step_ms = timeit(step, iters=8, warm=4)
+    del p, opt
+    torch.cuda.empty_cache()
+    rows = [live_bench(dev, P, N, train_step_ms=step_ms)]
+    torch.cuda.empty_cache()
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]
+    ret = mp.Manager().dict()
+    mp.spawn(_live_rank, args=(2, port, P, N, ret), nprocs=2, join=True)
+    rows.append(dict(ret["row"]))
+    return rows
+
+
 def main():
     dev = "cuda"
     out = []
@@ -221,5 +363,8 @@ def main():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "--graph-row":
         print(json.dumps(graph_row(torch.device("cuda", 0), int(sys.argv[2]), int(sys.argv[3]))), flush=True)
+    elif len(sys.argv) > 1 and sys.argv[1] == "--live":       # [passages [queries]]
+        for row in live_rows(torch.device("cuda", 0), *[int(a) for a in sys.argv[2:4]]):
+            print(json.dumps(row), flush=True)
     else:
         main()

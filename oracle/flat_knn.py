@@ -49,8 +49,9 @@ def lib():
         L.trxo_l2_from_ip_block.argtypes = [i64, i64, i64, i64, _f32p, _f32p, _f32p]
         L.trxo_norms_f32.argtypes = [_f32p, i64, i32, _f32p]
         L.trxo_merge_lists.argtypes = [i32, i32, i64, i32, _f32p, _i64p, _f32p, _i64p]
+        L.trxo_set_threads.argtypes = [i32]
         for fn in (L.trxo_heap_begin, L.trxo_heap_end, L.trxo_heap_add_block,
-                   L.trxo_l2_from_ip_block, L.trxo_norms_f32, L.trxo_merge_lists):
+                   L.trxo_l2_from_ip_block, L.trxo_norms_f32, L.trxo_merge_lists, L.trxo_set_threads):
             fn.restype = None
         _LIB = L
     return _LIB
@@ -144,6 +145,50 @@ def knn_faiss_blas(metric, x, y, k, bs_x=4096, bs_y=1024):
                 L.trxo_heap_add_block(metric, k, i0, i1, j0, j1, bp, Dp, Ip)
     L.trxo_heap_end(metric, k, nq, Dp, Ip)
     return D, I
+
+
+def knn_faiss_blas_mt(metric, x, y, k, workers, bs_x=4096, bs_y=1024):
+    """knn_faiss_blas spread over the host's cores the way that scales on a many-core box: `workers` host threads, each
+    taking every workers-th 1024-row corpus block -- the same fp32 sgemm of a 4096 x 1024 block (ONE BLAS thread per call)
+    and the same strict-admission heap handler on it, into the worker's own heaps -- and one merge of the workers' lists at
+    the end.  FAISS itself threads INSIDE the sgemm and over the queries of the handler; a 6.4 GFLOP block split over
+    hundreds of BLAS threads is mostly synchronisation (bench.py records that rate too), so this form is the stronger CPU
+    baseline.  Same arithmetic per block; on tie-free data the same result as knn_faiss_blas (an inner-product heap's order
+    among EXACT ties depends on arrival order, which differs)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from threadpoolctl import threadpool_limits
+    x, y = _check(x, y)
+    L = lib()
+    nq, d = x.shape
+    nb = y.shape[0]
+    nblocks = (nb + bs_y - 1) // bs_y
+    workers = max(1, min(int(workers), nblocks))
+    if metric == METRIC_L2:
+        xn = np.empty(nq, dtype=np.float32); yn = np.empty(nb, dtype=np.float32)
+        L.trxo_norms_f32(x.ctypes.data_as(_f32p), nq, d, xn.ctypes.data_as(_f32p))
+        L.trxo_norms_f32(y.ctypes.data_as(_f32p), nb, d, yn.ctypes.data_as(_f32p))
+    Dw = np.empty((workers, nq, k), dtype=np.float32)
+    Iw = np.empty((workers, nq, k), dtype=np.int64)
+
+    def work(w):
+        L.trxo_set_threads(1)           # this thread's OpenMP team: the handler runs inline
+        Dp, Ip = Dw[w].ctypes.data_as(_f32p), Iw[w].ctypes.data_as(_i64p)
+        L.trxo_heap_begin(metric, k, nq, Dp, Ip)
+        for i0 in range(0, nq, bs_x):
+            i1 = min(i0 + bs_x, nq)
+            for b in range(w, nblocks, workers):
+                j0, j1 = b * bs_y, min((b + 1) * bs_y, nb)
+                blk = np.ascontiguousarray(x[i0:i1] @ y[j0:j1].T)
+                bp = blk.ctypes.data_as(_f32p)
+                if metric == METRIC_L2:
+                    L.trxo_l2_from_ip_block(i0, i1, j0, j1, xn.ctypes.data_as(_f32p), yn.ctypes.data_as(_f32p), bp)
+                L.trxo_heap_add_block(metric, k, i0, i1, j0, j1, bp, Dp, Ip)
+        L.trxo_heap_end(metric, k, nq, Dp, Ip)
+
+    with threadpool_limits(limits=1, user_api="blas"):
+        with ThreadPoolExecutor(workers) as pool:
+            list(pool.map(work, range(workers)))
+    return merge_lists(metric, Dw, Iw)
 
 
 def knn_numpy(metric, x, y, k):

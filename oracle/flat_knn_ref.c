@@ -45,6 +45,9 @@
  */
 #include <float.h>
 #include <math.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -159,6 +162,16 @@ void trxo_heap_add_block(int metric, int k, int64_t i0, int64_t i1, int64_t j0, 
             }
         }
     }
+}
+
+/* OpenMP team size of the CALLING thread (its own ICV): a host thread that is itself one of many workers -- the
+ * block-parallel driver of flat_knn.knn_faiss_blas_mt -- sets 1, so that the handlers above run inline in it. */
+void trxo_set_threads(int n) {
+#ifdef _OPENMP
+    omp_set_num_threads(n > 0 ? n : 1);
+#else
+    (void)n;
+#endif
 }
 
 /* [ResultHandler.h: begin_multiple -> heap_heapify with neutral values and ids -1] */

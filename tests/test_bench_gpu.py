@@ -29,6 +29,7 @@ def test_single_gpu_line_has_the_contract_fields():
     assert j["n_gpus"] == 1 and j["steps"] == 2 and j["vs_baseline"] is None and j["value"] > 0
     assert j["roofline"]["bound"] == "mfma" and 0 < j["roofline"]["frac"] < 1
     assert j["cpu_baseline"]["kind"] in ("port", "reference") and j["cpu_baseline"]["index_agreement_with_gpu"] == 1.0
+    assert j["cpu_baseline"]["tflops"] > 0 and j["cpu_baseline"]["cores"] >= 1
 
 
 @pytest.mark.parametrize("mode", [[], ["--replicas"]])
@@ -43,3 +44,23 @@ def test_two_ranks_as_the_driver_launches_it(mode):
     j = _line(r.stdout)
     assert j["n_gpus"] == 2 and j["value"] > 0 and j["scaling"] == "strong"
     assert ("replicas" in j["config"]["parallelism"]) == bool(mode)
+    assert bool(mode) or j["config"]["selfcheck"].startswith("passed")      # the row-sharded line checks itself before it times
+
+
+def test_selfcheck_turns_a_wrong_exchange_into_a_failing_exit_code():
+    """a rank that reports its rows under the wrong ids (TRX_BENCH_INJECT_FAULT=offset) must not produce a bench line"""
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]
+    env = dict(os.environ, TRX_BENCH_BACKEND="gloo", TRX_BENCH_DEVICE="0", TRX_BENCH_INJECT_FAULT="offset")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode != 0 and "selfcheck FAILED" in r.stderr, r.stderr[-2000:]
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_single_gpu_selfcheck_flag():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--selfcheck", "--no-cpu-baseline"] + SMALL,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert _line(r.stdout)["config"]["selfcheck"].startswith("passed")

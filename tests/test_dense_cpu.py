@@ -43,6 +43,13 @@ def test_encode_is_batching_invariant_and_leaves_the_mode_alone():
     b = dense.encode(e, ids, am, batch_size=64, out_dtype=torch.float32)
     assert e.training and a.shape[0] == ids.shape[0]
     assert torch.allclose(a, b, atol=1e-6)
+    # longest first, every batch cut to its longest row: same embeddings, rows back in their places
+    lens = am.sum(dim=1)
+    lens[1::2] = (lens[1::2] - 3).clamp(min=2)
+    am2 = (torch.arange(am.shape[1])[None] < lens[:, None]).long()
+    c = dense.encode(e, ids, am2, batch_size=2, out_dtype=torch.float32, lengths=lens)
+    d_ = dense.encode(e, ids, am2, batch_size=64, out_dtype=torch.float32)
+    assert torch.allclose(c, d_, atol=1e-5)
     n = dense.DenseEncoder(Config(**json.loads(str(z["enc_cfg"]))), normalize=True)
     n.load_state_dict(e.state_dict()); n.eval()
     with torch.no_grad():

@@ -4,6 +4,9 @@ Bar: I identical (int64) and D identical (float32 bits) to oracle.knn_canonical 
 class; on inputs whose fp32 partial sums are exact the oracle's literal FAISS restatement gives
 the same answer too (checked in tests/test_oracle.py on the CPU side).
 """
+import os
+import sys
+
 import numpy as np
 import pytest
 
@@ -409,6 +412,121 @@ def test_multi_rank_sharded_search_on_one_gpu(world):
             D, I = ret[r][metric]
             assert np.array_equal(I, Ir), (metric, r)
             assert np.array_equal(D.view(np.uint32), Dr.view(np.uint32)), (metric, r)
+
+
+def _late_worker(rank, world, port, ret):
+    import os, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+    import torch, torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from textreact_amd.sharded import ShardedFlatIndex, shard_bounds
+    y, x = _near_duplicate_problem()
+    lo, hi = shard_bounds(len(y), world, rank)
+    idx = ShardedFlatIndex(y.shape[1], 0)
+    idx.add_shard(torch.from_numpy(y[lo:hi]).cuda(), lo, len(y))
+    D, I = idx.search(torch.from_numpy(x).cuda(), 10)
+    ret[rank] = (D.cpu().numpy(), I.cpu().numpy(), idx.late_fallbacks, idx.local.last_stats()["n_uncertified"])
+    dist.destroy_process_group()
+
+
+def _near_duplicate_problem():
+    """clusters of 40 near-duplicates (differences far below the certificate's slack, above fp64 resolution) in the first
+    shard, and 12 queries that each point at one cluster: more than KEEP - k rows tie within the slack, so those queries
+    fail the certificate -- more of them than the 4 inline re-scan slots of a batch (csrc/knn_api.hip INLINE_FALLBACK)"""
+    rng = np.random.default_rng(21)
+    y = rng.standard_normal((6000, 64)).astype(np.float32)
+    x = rng.standard_normal((40, 64)).astype(np.float32)
+    for c in range(12):
+        base = 3.0 * rng.standard_normal(64).astype(np.float32)
+        for j in range(40):
+            row = base.copy()
+            row[j % 64] += np.float32(1e-6) * (j + 1)
+            y[100 * c + j] = row
+        x[c] = base
+    return y, x
+
+
+def test_late_fallback_repeats_the_exchange():
+    """more certificate failures in a batch than the inline slots -> trx_index_search_finish re-does queries AFTER
+    the exchange was enqueued; the one-word all-reduce makes every rank repeat the exchange.  Two ranks on one GPU (gloo);
+    the result must still be the unsharded oracle's, on both ranks -- also on the rank whose own shard had no failure."""
+    import socket
+    import torch.multiprocessing as mp
+    from oracle import flat_knn as oracle
+    y, x = _near_duplicate_problem()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ret = mp.Manager().dict()
+    mp.spawn(_late_worker, args=(2, port, ret), nprocs=2, join=True)
+    Dr, Ir = oracle.knn_canonical(IP, x, y, 10)
+    assert ret[0][2] == 1 and ret[0][3] > 4, "the problem no longer reaches the late path: %r" % (ret[0][2:],)
+    assert ret[1][2] == 0                                   # rank 1 had nothing to re-do and repeated the exchange all the same
+    for r in (0, 1):
+        assert np.array_equal(ret[r][1], Ir), r
+        assert np.array_equal(ret[r][0].view(np.uint32), Dr.view(np.uint32)), r
+
+
+def test_sharded_search_over_a_one_rank_rccl_group():
+    """the transport branch of sharded.py / live.py that only RCCL takes (device tensors through all_to_all_single with split
+    sizes, all_gather_into_tensor, the int32 MAX all-reduce of the late flag), on the one GPU a test box has: a one-rank nccl
+    group with the exchange forced on.  What two ranks would add -- uneven splits -- runs over gloo in the tests above."""
+    import torch
+    import torch.distributed as dist
+    from oracle import flat_knn as oracle
+    from textreact_amd.sharded import ShardedFlatIndex
+    from textreact_amd.live import all_gather_rows
+    import socket
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    assert not dist.is_initialized()
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        for (y, x) in ((gaussian(5000, 64, 1), gaussian(301, 64, 2)), _near_duplicate_problem()):
+            for metric in (IP, L2):
+                idx = ShardedFlatIndex(64, metric, exchange_always=True)
+                idx.add_shard(torch.from_numpy(y).cuda(), 100, len(y) + 100)
+                D, I = idx.search(torch.from_numpy(x).cuda(), 10)
+                Dr, Ir = oracle.knn_canonical(metric, x, y, 10)
+                assert np.array_equal(I.cpu().numpy(), Ir + 100) and np.array_equal(D.cpu().numpy().view(np.uint32), Dr.view(np.uint32))
+        assert idx.late_fallbacks == 1                     # the near-duplicate problem took the repeated exchange over RCCL too (L2)
+        e = torch.randn(37, 768, device="cuda").bfloat16()
+        assert torch.equal(all_gather_rows(e, 37, 0, 1, always=True), e)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_cli_writes_the_files_one_gpu_writes(tmp_path):
+    """python -m torch.distributed.run --nproc-per-node 2 -m textreact_amd.retrieve_faiss ...: the train vectors row-sharded
+    over two ranks (both on this box's GPU, gloo transport), the HIP index and HIP merge on each; rank 0's train / val /
+    test.json are byte for byte the files of the single-GPU run (retrieve/retrieve_faiss.py:112-130)"""
+    import subprocess
+    import pandas as pd
+    import textreact_amd.retrieve_faiss as rf
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fps = reaction_fp_like(1101, 2048, 3)
+    fps[700:720] = fps[3]                      # ties that straddle the shard boundary at row 501
+    fps[40:45] = fps[3]
+    pd.DataFrame({"id": np.arange(1001), "canonical_rxn": ["C>>C"] * 1001, "year": 2000 + np.arange(1001) % 20}).to_csv(tmp_path / "train.csv", index=False)
+    pd.DataFrame({"id": np.arange(50) + 5000, "canonical_rxn": ["C>>C"] * 50}).to_csv(tmp_path / "val.csv", index=False)
+    pd.DataFrame({"id": np.arange(50) + 6000, "canonical_rxn": ["C>>C"] * 50}).to_csv(tmp_path / "test.csv", index=False)
+    for name, sl in (("train", slice(0, 1001)), ("val", slice(1001, 1051)), ("test", slice(1051, 1101))):
+        np.save(tmp_path / (name + ".npy"), fps[sl].astype(np.int64))
+    for extra in ([], ["--before", "2013"]):
+        argv = ["--data_path", str(tmp_path), "--train_file", "train.csv", "--valid_file", "val.csv", "--test_file", "test.csv",
+                "--train_vectors", str(tmp_path / "train.npy"), "--valid_vectors", str(tmp_path / "val.npy"),
+                "--test_vectors", str(tmp_path / "test.npy")] + extra
+        one, two = tmp_path / ("one%d" % len(extra)), tmp_path / ("two%d" % len(extra))
+        assert rf.main(argv + ["--output_path", str(one)]) == 0
+        env = dict(os.environ, TRX_DIST_BACKEND="gloo", TRX_DEVICE="0")
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                            "--master-port", "29731", "-m", "textreact_amd.retrieve_faiss"] + argv + ["--output_path", str(two)],
+                           cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        for name in ("train.json", "val.json", "test.json"):
+            assert (two / name).read_bytes() == (one / name).read_bytes(), name
+        assert r.stdout.count("Faiss nearest neighbor search") == 3        # rank 0 alone prints
 
 
 # ---- the literal FAISS restatement (and FAISS itself when a box has it) on Gaussian C0 -----------------------------

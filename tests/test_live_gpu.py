@@ -127,3 +127,69 @@ def test_trainer_with_on_the_fly_retrieval_two_ranks_on_one_gpu(tmp_path):
     assert all(torch.isfinite(v).all() for v in ck["state_dict"].values() if v.is_floating_point())
     pred = json.loads((out / "prediction_test_1.json").read_text())
     assert sorted(pred) == ["100", "101", "102", "103", "104"]
+
+
+# ---- BASELINE.json configs[4] at the size of scripts/train_RetroSyn_tf.sh (bench_predictor.py --live) -------------------------
+# BERT-base retriever, 204,800 passages of 16-128 tokens, 40,000 queries (a USPTO-50K-sized training split), k = 10: one refresh,
+# stage by stage, on one rank and as a 2-rank one-device rehearsal; the refreshed ids of 64 sampled queries must be exactly what
+# the oracle finds over the FULL passage-embedding matrix.
+LIVE_P, LIVE_N = 204_800, 40_000
+
+
+def _check_against_the_oracle(nn, emb_q, emb_p, k=10):
+    from oracle import flat_knn as oracle
+    rows = np.random.default_rng(3).choice(emb_q.shape[0], 64, replace=False)
+    _, want = oracle.knn_canonical(0, emb_q[rows], emb_p, k)
+    assert np.array_equal(nn[rows], want)
+
+
+def test_refresh_at_the_scripts_size_one_rank():
+    sys.path.insert(0, ROOT)
+    import bench_predictor
+    dev = torch.device("cuda", 0)
+    row, nn, emb_q, emb_p = bench_predictor.live_bench(dev, LIVE_P, LIVE_N, return_tensors=True)
+    assert nn.shape == (LIVE_N, 10) and emb_p.shape == (LIVE_P, 768) and int(nn.min()) >= 0 and int(nn.max()) < LIVE_P
+    assert set(row["ms"]) >= {"encode_passages", "index_add", "encode_queries", "search", "assemble_epoch_inputs"}
+    assert row["assembled_width"] <= 512
+    _check_against_the_oracle(nn.cpu().numpy(), emb_q.float().cpu().numpy(), emb_p.float().cpu().numpy())
+    print(json.dumps(row))
+
+
+def _live_full_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench_predictor
+    from textreact_amd.sharded import shard_bounds
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    row, nn, emb_q, emb_p = bench_predictor.live_bench(dev, LIVE_P, LIVE_N, rank=rank, world=world, return_tensors=True)
+    lo, hi = shard_bounds(LIVE_P, world, rank)
+    assert emb_p.shape == (hi - lo, 768)
+    per = -(-LIVE_P // world)
+    mine = torch.zeros((per, 768), dtype=torch.bfloat16)
+    mine[:hi - lo] = emb_p.cpu()
+    parts = [torch.empty_like(mine).view(torch.uint8) for _ in range(world)]      # gloo gathers bytes
+    dist.all_gather(parts, mine.view(torch.uint8))
+    full = torch.cat([parts[r].view(torch.bfloat16)[:shard_bounds(LIVE_P, world, r)[1] - shard_bounds(LIVE_P, world, r)[0]] for r in range(world)])
+    h = torch.tensor([int(nn.sum()), int((nn * torch.arange(1, 11, device=nn.device)).sum())])
+    hs = [torch.empty_like(h) for _ in range(world)]
+    dist.all_gather(hs, h)
+    assert all(torch.equal(x, hs[0]) for x in hs), "ranks disagree on the neighbours"
+    if rank == 0:
+        _check_against_the_oracle(nn.cpu().numpy(), emb_q.float().cpu().numpy(), full.float().numpy())
+        ret["row"] = json.dumps(row)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_refresh_at_the_scripts_size_two_ranks_on_one_gpu():
+    import torch.multiprocessing as mp
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]
+    ret = mp.Manager().dict()
+    mp.spawn(_live_full_worker, args=(2, port, ret), nprocs=2, join=True)
+    row = json.loads(ret["row"])
+    assert row["ranks"] == 2 and "REHEARSAL" in row["transport"]
+    print(json.dumps(row))

@@ -215,6 +215,23 @@ def test_train_with_the_step_replayed_from_a_hip_graph(tmp_path):
     assert len(re.findall(r"train_loss ([0-9.]+)", r.stdout)) >= 1
     pred = json.loads((out / "prediction_test_0.json").read_text())
     assert sorted(pred) == ["100", "101", "102", "103"]
+    # the checkpoint of a graphed run is interchangeable with an eager run's (and the reference's): a float learning
+    # rate, capturable off -- and resumes either way: eagerly (epoch 3), then graphed again from that eager checkpoint
+    # (epochs 4-6: enough steps for a capture on top of the restored AdamW state)
+    grp = ck["optimizer_states"][0]["param_groups"][0]
+    assert isinstance(grp["lr"], float) and grp.get("capturable", False) is False
+    assert all(isinstance(v, float) for v in ck["lr_schedulers"][0]["_last_lr"] + ck["lr_schedulers"][0]["base_lrs"])
+    for extra, epochs, steps in (([], 4, 8), (["--hip_graph_step"], 7, 14)):
+        r = subprocess.run([sys.executable, "-m", "textreact_amd.main"] + argv +
+                           ["--epochs", str(epochs), "--do_train", "--precision", "bf16-mixed", "--load_ckpt", "last.ckpt",
+                            "--print_freq", "1"] + extra, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        assert "Resumed from" in r.stdout
+        ck = torch.load(out / "last.ckpt", weights_only=False)
+        assert ck["global_step"] == steps and ck["epoch"] == epochs - 1
+        assert all(torch.isfinite(v).all() for v in ck["state_dict"].values() if v.is_floating_point())
+        grp = ck["optimizer_states"][0]["param_groups"][0]
+        assert isinstance(grp["lr"], float) and grp.get("capturable", False) is False
 
 
 def _toy_template(tmp_path, seed=0):

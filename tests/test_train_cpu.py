@@ -80,6 +80,39 @@ def test_checkpoint_layout_round_trip(tmp_path):
     assert not os.listdir(tmp_path / "run")
 
 
+def test_checkpoints_are_interchangeable_between_graphed_and_eager_runs(tmp_path):
+    """a --hip_graph_step run keeps the learning rate in a tensor and AdamW `capturable`; its checkpoint holds what an eager
+    run (and the reference's Lightning run) writes, and loading an eager checkpoint into an optimizer built for the graph
+    keeps the optimizer's form: the SAME rate tensor (the captured update reads it) holding the loaded value"""
+    _, p, batch = _predictor()
+    opt, sch = train.configure_optimizer(p, 1e-3, 0.01, 100, 0.02)
+    total, _ = p.training_step(batch, {"mlm_labels": torch.randint(0, 120, (3, 5))})
+    total.backward(); opt.step(); sch.step(); sch.step()
+    eager_lr = opt.param_groups[0]["lr"]
+    path = train.save_checkpoint(str(tmp_path / "last.ckpt"), p, opt, sch, epoch=0, global_step=2)
+    # the graphed form of the same optimizer (built by hand: configure_optimizer only makes it for parameters on a GPU)
+    _, q, _ = _predictor()
+    lr_t = torch.tensor(1e-3)
+    gopt = torch.optim.AdamW(list(q.parameters()), lr=lr_t, weight_decay=0.01, capturable=True)
+    gsch = torch.optim.lr_scheduler.LambdaLR(gopt, lambda step: 1.0)
+    train.load_checkpoint(path, q, gopt, gsch)
+    g = gopt.param_groups[0]
+    assert g["lr"] is lr_t and abs(float(lr_t) - eager_lr) < 1e-9 and g["capturable"] is True
+    assert gsch._last_lr[0] is lr_t and gsch.last_epoch == 2
+    # ... and what it writes back is the portable form again
+    back = train.save_checkpoint(str(tmp_path / "graphed.ckpt"), q, gopt, gsch, epoch=1, global_step=3)
+    raw = torch.load(back, map_location="cpu", weights_only=False)
+    grp = raw["optimizer_states"][0]["param_groups"][0]
+    assert isinstance(grp["lr"], float) and grp["capturable"] is False and abs(grp["lr"] - eager_lr) < 1e-9
+    assert all(isinstance(v, float) for v in raw["lr_schedulers"][0]["_last_lr"] + raw["lr_schedulers"][0]["base_lrs"])
+    assert gopt.param_groups[0]["lr"] is lr_t          # saving did not touch the live optimizer
+    # an eager optimizer resumes from it without inheriting the graph's flags
+    _, r, _ = _predictor()
+    eopt, esch = train.configure_optimizer(r, 1e-3, 0.01, 100, 0.02)
+    train.load_checkpoint(back, r, eopt, esch)
+    assert isinstance(eopt.param_groups[0]["lr"], float) and not eopt.param_groups[0].get("capturable", False)
+
+
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); pt = s.getsockname()[1]; s.close(); return pt
 

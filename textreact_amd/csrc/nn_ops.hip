@@ -811,13 +811,13 @@ __global__ __launch_bounds__(XW ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
     {                                                                                                        \
         const unsigned vo_ = (VOFF);                                                                         \
         const unsigned la_ = (unsigned)__builtin_amdgcn_readfirstlane((int)(LDSADDR));                        \
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(vo_), "s"(SBASE), "s"(la_) : "memory"); \
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(vo_), "s"(SBASE), "s"(la_) : "memory", "m0"); \
     }
 #define TRX_GLDS4(SBASE, VOFF, LDSADDR)      /* the same with 4 bytes per lane */                            \
     {                                                                                                        \
         unsigned vo_ = (VOFF);                                                                               \
         const unsigned la_ = (unsigned)__builtin_amdgcn_readfirstlane((int)(LDSADDR));                        \
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" : "+v"(vo_) : "s"(SBASE), "s"(la_) : "memory"); \
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" : "+v"(vo_) : "s"(SBASE), "s"(la_) : "memory", "m0"); \
     }
     const unsigned ldsbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
     const unsigned lds_w = (unsigned)__builtin_amdgcn_readfirstlane((int)(ldsbase + (unsigned)(2 * wave * 1024)));   // this wave's pieces, scalar

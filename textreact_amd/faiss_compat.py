@@ -194,7 +194,7 @@ def merge_topk(metric, S_lists, I_lists):
 
 def _default_device():
     import os
-    lr = os.environ.get("LOCAL_RANK")
+    lr = os.environ.get("TRX_DEVICE", os.environ.get("LOCAL_RANK"))   # TRX_DEVICE: several ranks rehearse on one GPU
     if lr is not None:
         return int(lr)
     try:

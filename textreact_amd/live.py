@@ -71,9 +71,10 @@ def with_special_tokens(ids, lens, cls_id, sep_id, pad_id):
     return out[:, :width], mask[:, :width]
 
 
-def all_gather_rows(x, n_total, rank, world, group=None):
-    """rows [lo, hi) of an [n_total, H] matrix per rank (shard_bounds) -> the whole matrix on every rank: one collective"""
-    if world == 1:
+def all_gather_rows(x, n_total, rank, world, group=None, always=False):
+    """rows [lo, hi) of an [n_total, H] matrix per rank (shard_bounds) -> the whole matrix on every rank: one collective
+    (always=True: also in a one-rank group, which is how a one-GPU box drives the RCCL branch)"""
+    if world == 1 and not always:
         return x
     import torch.distributed as dist
     per = -(-n_total // world)
@@ -99,48 +100,84 @@ class LiveRetriever:
     """the passage side (embeddings of this rank's rows in a flat index, rebuilt by `refresh_index`) and the query side
     (`neighbors`) of the on-the-fly retrieval.  local_index / merge: injectable like ShardedFlatIndex's (CPU tests)."""
 
-    def __init__(self, corpus, rank=0, world=1, group=None, batch_size=256, local_index=None, merge=None, autocast=True):
+    def __init__(self, corpus, rank=0, world=1, group=None, batch_size=256, local_index=None, merge=None, autocast=True,
+                 timing=False):
         self.corpus, self.rank, self.world, self.group = corpus, rank, world, group
         self.batch_size, self.autocast = batch_size, autocast
         self._local_index, self._merge = local_index, merge
         self.index, self.emb_p = None, None
+        # timing=True: every stage is bracketed by a device synchronisation and its wall time lands in `ms`
+        # (bench_predictor.py --live, BASELINE.md C4 "retrieval refresh time per epoch"); off, nothing waits
+        self.timing, self.ms = timing, {}
+
+    def _lap(self, name, t0):
+        if not self.timing:
+            return None
+        import time
+        dev = self.corpus.device
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        if t0 is not None:
+            self.ms[name] = self.ms.get(name, 0.0) + (t1 - t0) * 1e3
+        return t1
 
     def refresh_index(self, p_encoder):
         """encode this rank's rows [lo, hi) of the corpus with the encoder's CURRENT weights and index them"""
         from . import dense
         c = self.corpus
         lo, hi = shard_bounds(len(c), self.world, self.rank)
+        t = self._lap(None, None)
         pid, pmask = with_special_tokens(c.passage_ids[lo:hi], c.passage_len[lo:hi], c.cls_id, c.sep_id, c.pad_id)
-        self.emb_p = dense.encode(p_encoder, pid, pmask, batch_size=self.batch_size, autocast=self.autocast)
+        self.emb_p = dense.encode(p_encoder, pid, pmask, batch_size=self.batch_size, autocast=self.autocast,
+                                  lengths=c.passage_len[lo:hi] + 2)
+        t = self._lap("encode_passages", t)
         li = self._local_index() if callable(self._local_index) else self._local_index
         if li is None:      # the HIP flat index, on the device the embeddings live on (not LOCAL_RANK: a rehearsal shares one GPU)
             from . import faiss_compat
             li = faiss_compat.IndexFlat(self.emb_p.shape[1], faiss_compat.METRIC_INNER_PRODUCT, device=self.emb_p.device.index or 0)
         self.index = ShardedFlatIndex(self.emb_p.shape[1], 0, group=self.group, local_index=li, merge=self._merge)
         self.index.add_shard(self.emb_p, lo, len(c))
+        self._lap("index_add", t)
 
     def embed_queries(self, q_encoder, query_ids, query_len):
         """every rank encodes 1/G of the queries; ONE all-gather replicates the embeddings [N, H]"""
         from . import dense
         c, N, dev = self.corpus, query_ids.shape[0], self.emb_p.device
         lo, hi = shard_bounds(N, self.world, self.rank)
-        qid, qmask = with_special_tokens(query_ids[lo:hi].to(dev), query_len[lo:hi].to(dev), c.cls_id, c.sep_id, c.pad_id)
-        e = dense.encode(q_encoder, qid, qmask, batch_size=self.batch_size, autocast=self.autocast)
-        return all_gather_rows(e, N, self.rank, self.world, self.group)
+        t = self._lap(None, None)
+        qlen = query_len[lo:hi].to(dev)
+        qid, qmask = with_special_tokens(query_ids[lo:hi].to(dev), qlen, c.cls_id, c.sep_id, c.pad_id)
+        e = dense.encode(q_encoder, qid, qmask, batch_size=self.batch_size, autocast=self.autocast, lengths=qlen + 2)
+        t = self._lap("encode_queries", t)
+        out = all_gather_rows(e, N, self.rank, self.world, self.group)
+        self._lap("gather_queries", t)
+        return out
 
     def neighbors(self, q_encoder, query_ids, query_len, k):
         """[N, k] rows of the corpus, best first (-1 = fewer than k passages), identical on every rank"""
-        _, nn = self.index.search(self.embed_queries(q_encoder, query_ids, query_len), k)
+        emb_q = self.embed_queries(q_encoder, query_ids, query_len)
+        t = self._lap(None, None)
+        _, nn = self.index.search(emb_q, k)
+        self._lap("search", t)
         return nn
 
 
 def refresh_neighbors(q_encoder, p_encoder, corpus, query_ids, query_len, k, rank=0, world=1, group=None, batch_size=256,
-                      local_index=None, merge=None, autocast=True, return_embeddings=False):
-    """one-call form: index the passages, search every query -> neighbor ids [N, k], identical on every rank"""
-    r = LiveRetriever(corpus, rank, world, group, batch_size, local_index, merge, autocast)
+                      local_index=None, merge=None, autocast=True, return_embeddings=False, timings=None):
+    """one-call form: index the passages, search every query -> neighbor ids [N, k], identical on every rank.
+    timings: a dict that receives the wall milliseconds of every stage (each bracketed by a device synchronisation)"""
+    r = LiveRetriever(corpus, rank, world, group, batch_size, local_index, merge, autocast, timing=timings is not None)
     r.refresh_index(p_encoder)
     emb_q = r.embed_queries(q_encoder, query_ids, query_len)
+    t = r._lap(None, None)
     _, nn = r.index.search(emb_q, k)
+    r._lap("search", t)
+    if timings is not None:
+        timings.update(r.ms)
+        stats = getattr(r.index.local, "last_stats", None)
+        if stats is not None:      # queries the fast path could not certify (re-done by the exact fp64 scan, this rank's shard)
+            timings["uncertified_queries"] = stats()["n_uncertified"]
     return (nn, emb_q, r.emb_p) if return_embeddings else nn
 
 

@@ -407,10 +407,13 @@ def main(argv=None):
         if rank == 0:
             print("Num training steps: %d" % num_training_steps)
         graphed = bool(args.hip_graph_step)
-        if graphed and (world > 1 or str(args.precision).startswith("16") or args.gradient_accumulation_steps != 1 or args.template_based):
+        # --live_every slices every batch to its own width (and its own mlm_labels width): hundreds of distinct shapes, each
+        # of which GraphedStep would capture into a graph with a private activation pool -- the run would end out of memory
+        if graphed and (world > 1 or str(args.precision).startswith("16") or args.gradient_accumulation_steps != 1 or args.template_based
+                        or args.live_every > 0):
             if rank == 0:
-                print("note: --hip_graph_step needs one process, bf16 / fp32 precision, no gradient accumulation and the "
-                      "template-free model: running the step eagerly", file=sys.stderr)
+                print("note: --hip_graph_step needs one process, bf16 / fp32 precision, no gradient accumulation, the "
+                      "template-free model and static inputs (no --live_every): running the step eagerly", file=sys.stderr)
             graphed = False
         opt, sched = T.configure_optimizer(module, args.lr, args.weight_decay, num_training_steps, args.warmup_ratio,
                                            scheduler=args.scheduler, capturable=graphed)

@@ -324,10 +324,41 @@ def save_checkpoint(path, module, optimizer=None, lr_scheduler=None, epoch=0, gl
     ckpt["state_dict"] = collections.OrderedDict((k, v.detach().cpu()) for k, v in module.state_dict().items())
     ckpt["loops"] = None      # Lightning's restore_loops skips a None entry (an empty dict would KeyError on 'fit_loop')
     ckpt["callbacks"] = {"ModelCheckpoint": {"monitor": monitor, "best_model_path": os.path.abspath(path)}}
-    ckpt["optimizer_states"] = [optimizer.state_dict()] if optimizer is not None else []
-    ckpt["lr_schedulers"] = [lr_scheduler.state_dict()] if lr_scheduler is not None else []
+    ckpt["optimizer_states"] = [_portable_optimizer_state(optimizer.state_dict())] if optimizer is not None else []
+    ckpt["lr_schedulers"] = [_portable_scheduler_state(lr_scheduler.state_dict())] if lr_scheduler is not None else []
     torch.save(ckpt, path)
     return path
+
+
+def _as_float(v):
+    return float(v.item()) if torch.is_tensor(v) else v
+
+
+def _portable_optimizer_state(sd):
+    """what an eager run (and Lightning's own AdamW) writes, whatever this run was: the learning rate as a Python float
+    and capturable = False.  A --hip_graph_step run keeps both on the device (configure_optimizer(capturable=True));
+    written as they are they would make the checkpoint unreadable for an eager resume (it would inherit capturable = True)
+    and differ from the reference's checkpoint contents."""
+    sd = dict(sd)
+    groups = []
+    for g in sd["param_groups"]:
+        g = dict(g)
+        g["lr"] = _as_float(g["lr"])
+        if "initial_lr" in g:
+            g["initial_lr"] = _as_float(g["initial_lr"])
+        if "capturable" in g:
+            g["capturable"] = False
+        groups.append(g)
+    sd["param_groups"] = groups
+    return sd
+
+
+def _portable_scheduler_state(sd):
+    sd = dict(sd)
+    for k in ("base_lrs", "_last_lr"):
+        if k in sd:
+            sd[k] = [_as_float(v) for v in sd[k]]
+    return sd
 
 
 def mark_parameters_updated(module):
@@ -345,9 +376,28 @@ def load_checkpoint(path, module, optimizer=None, lr_scheduler=None, strict=Fals
     missing, unexpected = module.load_state_dict(sd, strict=strict)
     mark_parameters_updated(module)
     if optimizer is not None and ckpt.get("optimizer_states"):
+        # load_state_dict replaces the groups' hyper-parameters with the checkpoint's: a float lr and capturable = False
+        # from an eager run or from the reference.  An optimizer built for GraphedStep keeps ITS form: the rate stays
+        # the device tensor the captured update reads (the loaded value is copied into it), capturable stays on, and the
+        # step counters move to the device (torch casts `step` by the flags of the CURRENT groups only when they are set
+        # in the loaded ones, so it is done here).
+        was = [(g.get("capturable", False), g["lr"]) for g in optimizer.param_groups]
         optimizer.load_state_dict(ckpt["optimizer_states"][0])
+        for g, (capturable, lr_t) in zip(optimizer.param_groups, was):
+            if capturable:
+                g["capturable"] = True
+            if torch.is_tensor(lr_t):
+                lr_t.fill_(_as_float(g["lr"]))
+                g["lr"] = lr_t
+            if capturable or g.get("fused", False):
+                for p_ in g["params"]:
+                    st = optimizer.state.get(p_)
+                    if st and torch.is_tensor(st.get("step")):
+                        st["step"] = st["step"].to(device=p_.device, dtype=torch.float32)
     if lr_scheduler is not None and ckpt.get("lr_schedulers"):
         lr_scheduler.load_state_dict(ckpt["lr_schedulers"][0])
+        if optimizer is not None:      # the schedule's view of the rates is the groups' (tensors stay tensors)
+            lr_scheduler._last_lr = [g["lr"] for g in optimizer.param_groups]
     return ckpt, missing, unexpected
 
 

@@ -11,6 +11,13 @@ Differences, all deliberate:
     index and re-adds the corpus for every split, :115/:121/:127);
   * ``--before`` filters ``train_df`` unconditionally; the reference skips the filter when the
     fingerprint cache exists, which misaligns ids and fingerprints (:101-103,:112);
+  * ``train_fp.pkl`` gets a sidecar (``train_fp.pkl.meta.json``: field, ``--before``, row count, SHA-256 of the id column
+    the rows belong to), so a cache is only reused for the rows it was computed from; a cache without one (written by the
+    reference) is accepted when its length identifies it (all rows / the filtered rows);
+  * launched by ``python -m torch.distributed.run --nproc-per-node G -m textreact_amd.retrieve_faiss ...`` the train
+    vectors are row-sharded over the G GPUs (rank r indexes rows ``shard_bounds(n, G, r)``), every search goes through
+    ``sharded.ShardedFlatIndex`` (local scan, all-to-all, merge, all-gather over RCCL) and rank 0 writes the same three
+    files, byte for byte what one GPU writes (tests/test_knn_gpu.py);
   * RDKit is imported only when fingerprints must be computed, and ``--train_vectors /
     --valid_vectors / --test_vectors`` (``.npy`` of shape [n, d]) feed precomputed vectors
     instead -- that is how the 768-d dense embeddings of the external retriever enter; with
@@ -133,19 +140,108 @@ def get_parser():
     return parser
 
 
+def _dist_setup():
+    """(rank, world): one process per GPU when launched by torch.distributed.run, else (0, 1).  TRX_DIST_BACKEND=gloo
+    TRX_DEVICE=0 lets several ranks share one GPU to rehearse the path on a one-GPU box (RCCL refuses two ranks on one
+    device); the real run is nccl = RCCL."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return 0, 1
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(os.environ.get("TRX_DIST_BACKEND", "nccl"))
+    return dist.get_rank(), dist.get_world_size()
+
+
+class ShardedSearcher:
+    """`index.search(x, k)` of retrieve_faiss.py:71 over a corpus row-sharded across the ranks: numpy in, numpy out, the
+    same (D, I) on every rank and the same as one flat index over all rows (sharded.ShardedFlatIndex).  Queries go to
+    the device in blocks of 65,536 rows: the train split searches itself, and 680 k x 2048 fp32 queries are 5.6 GB."""
+
+    QUERY_BLOCK = 65536
+
+    def __init__(self, local_rows, lo, ntotal, metric, rank, world):
+        from .sharded import ShardedFlatIndex
+        d = local_rows.shape[1]
+        local = faiss.IndexFlatL2(d) if metric == 'l2' else faiss.IndexFlatIP(d)
+        self.device = getattr(local, "device", None)          # the HIP index names its GPU; a CPU stand-in (tests) has none
+        self.index = ShardedFlatIndex(d, 1 if metric == 'l2' else 0, local_index=local, merge=getattr(faiss, "merge_topk", None))
+        self.index.add_shard(self._tensor(local_rows), lo, ntotal)
+
+    def _tensor(self, x):
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
+        return t.cuda(self.device) if self.device is not None else t
+
+    def search(self, x, k):
+        D, I = [], []
+        for q0 in range(0, len(x), self.QUERY_BLOCK):
+            d_, i_ = self.index.search(self._tensor(x[q0:q0 + self.QUERY_BLOCK]), k)
+            D.append(d_.cpu().numpy()); I.append(i_.cpu().numpy())
+        if not D:
+            return np.empty((0, k), np.float32), np.empty((0, k), np.int64)
+        return np.concatenate(D), np.concatenate(I)
+
+
+def _ids_digest(ids):
+    import hashlib
+    h = hashlib.sha256()
+    for v in ids:
+        h.update(str(v).encode("utf-8")); h.update(b"\0")
+    return h.hexdigest()
+
+
+def load_or_compute_train_fps(train_df, keep, args, fingerprint_fn, train_fp_file):
+    """the `train_fp.pkl` cache (retrieve_faiss.py:100-110; NumPy .npy bytes despite the name) -> the fingerprints of the
+    rows `keep` selects (None = all).  The reference reuses whatever file is there (:101-103,:112); here a sidecar says
+    which rows a cache holds, and a cache that does not belong to these rows is recomputed, not trusted."""
+    meta_file = train_fp_file + ".meta.json"
+    kept_df = train_df[keep].reset_index(drop=True) if keep is not None else train_df
+    want = {"field": args.field, "before": int(args.before), "rows": int(len(kept_df)), "ids_sha256": _ids_digest(kept_df['id'])}
+    if os.path.exists(train_fp_file):
+        with open(train_fp_file, 'rb') as f:
+            fps = np.load(f)
+        meta = None
+        if os.path.exists(meta_file):
+            with open(meta_file) as f:
+                meta = json.load(f)
+        if meta is not None:
+            if all(meta.get(k_) == want[k_] for k_ in ("field", "rows", "ids_sha256")) and len(fps) == want["rows"]:
+                return fps                                   # computed from exactly these rows
+            if (keep is not None and meta.get("field") == args.field and meta.get("before") == -1 and len(fps) == len(train_df)
+                    and meta.get("ids_sha256") == _ids_digest(train_df['id'])):
+                return fps[keep]                             # computed from all rows of this file: filter it like the ids
+            print("train_fp.pkl was computed from other rows (%s): recomputing" % json.dumps(meta))
+        elif keep is not None and len(fps) == len(train_df):
+            return fps[keep]       # no sidecar (a reference-written cache), one row per row of the file: unfiltered
+        elif len(fps) == len(kept_df):
+            return fps             # no sidecar, one row per kept row (the reference wrote it under the same --before)
+        else:
+            print("train_fp.pkl holds %d rows, the train file %d (%d after --before): recomputing" % (len(fps), len(train_df), len(kept_df)))
+    fps = fingerprint_fn(kept_df[args.field])
+    with open(train_fp_file, 'wb') as f:
+        np.save(f, fps)
+    with open(meta_file, 'w') as f:
+        json.dump(want, f)
+    return fps
+
+
 def main(argv=None):
     import pandas as pd
     args = get_parser().parse_args(argv)
+    rank, world = _dist_setup()
+    say = print if rank == 0 else (lambda *a, **k: None)
 
     train_df = pd.read_csv(os.path.join(args.data_path, args.train_file), keep_default_na=False)
     val_df = pd.read_csv(os.path.join(args.data_path, args.valid_file), keep_default_na=False)
     test_df = pd.read_csv(os.path.join(args.data_path, args.test_file), keep_default_na=False)
 
     if args.field == 'canonical_rxn':
-        print('Reaction fingerprint')
+        say('Reaction fingerprint')
         fingerprint_fn = compute_reaction_fingerprints
     else:
-        print('Molecule fingerprint')
+        say('Molecule fingerprint')
         fingerprint_fn = compute_molecule_fingerprints
 
     if args.before != -1:  # unconditional: see module docstring
@@ -153,50 +249,82 @@ def main(argv=None):
     else:
         keep = None
 
-    os.makedirs(args.output_path, exist_ok=True)
+    if rank == 0:
+        os.makedirs(args.output_path, exist_ok=True)
     train_fp_file = os.path.join(args.output_path, 'train_fp.pkl')
     if args.train_vectors:
-        train_fps = np.load(args.train_vectors)
+        train_fps = np.load(args.train_vectors, mmap_mode='r' if world > 1 else None)   # sharded: a rank touches its rows only
         if keep is not None:
-            train_fps = train_fps[keep]
-    elif os.path.exists(train_fp_file):
-        with open(train_fp_file, 'rb') as f:
-            train_fps = np.load(f)
-        if keep is not None and len(train_fps) == len(keep):
-            train_fps = train_fps[keep]   # cache written without the filter
+            train_fps = train_fps[keep] if world == 1 else _RowView(train_fps, np.flatnonzero(keep))
     else:
-        df = train_df[keep].reset_index(drop=True) if keep is not None else train_df
-        train_fps = fingerprint_fn(df[args.field])
-        with open(train_fp_file, 'wb') as f:
-            np.save(f, train_fps)
+        if rank == 0:      # one rank computes (a 64-process RDKit pool) and writes the cache; the others read it
+            train_fps = load_or_compute_train_fps(train_df, keep, args, fingerprint_fn, train_fp_file)
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            if rank != 0:
+                train_fps = load_or_compute_train_fps(train_df, keep, args, fingerprint_fn, train_fp_file)
     if keep is not None:
         train_df = train_df[keep].reset_index(drop=True)
     assert len(train_fps) == len(train_df), "fingerprints and train ids are misaligned"
     train_id = train_df['id']
 
-    print('Faiss build index')
-    index = build_index(train_fps, args.metric)
+    say('Faiss build index')
+    if world == 1:
+        index = build_index(train_fps, args.metric)
+    else:
+        from .sharded import shard_bounds
+        lo, hi = shard_bounds(len(train_fps), world, rank)
+        index = ShardedSearcher(np.asarray(train_fps[lo:hi]), lo, len(train_fps), args.metric, rank, world)
 
     def vectors(df, path):
-        return np.load(path) if path else fingerprint_fn(df[args.field])
+        if path:
+            return np.load(path)
+        if world == 1:
+            return fingerprint_fn(df[args.field])
+        import torch.distributed as dist
+        box = [fingerprint_fn(df[args.field]) if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        return box[0]
 
-    rank = None
+    rank_arr = None
     for name, df, fps in (('train', train_df, train_fps),
                           ('val', val_df, None),
                           ('test', test_df, None)):
         if fps is None:
             fps = vectors(df, args.valid_vectors if name == 'val' else args.test_vectors)
-        rank = index_and_search(train_fps, fps, k=args.k, metric=args.metric, index=index)
-        result = build_result(df['id'], rank, train_id)
-        write_neighbors(os.path.join(args.output_path, name + '.json'), result)
+        if rank == 0:
+            rank_arr = index_and_search(train_fps, fps, k=args.k, metric=args.metric, index=index)
+            result = build_result(df['id'], rank_arr, train_id)
+            write_neighbors(os.path.join(args.output_path, name + '.json'), result)
+        else:
+            index.search(fps, args.k)
 
-    if args.field == 'canonical_rxn' and all(f in test_df.columns for f in CONDITION_FIELDS):
-        cnt = hit_rates(rank, test_df, train_df)
+    if rank == 0 and args.field == 'canonical_rxn' and all(f in test_df.columns for f in CONDITION_FIELDS):
+        cnt = hit_rates(rank_arr, test_df, train_df)
         print(cnt, len(test_df))
         for x in cnt:
             print(f"Top-{x}: {cnt[x] / len(test_df):.4f}", end='  ')
         print()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
     return 0
+
+
+class _RowView:
+    """rows `rows` of a memory-mapped matrix, read when they are sliced (a rank of the sharded run touches its shard and
+    the query blocks, never the whole file at once)"""
+
+    def __init__(self, base, rows):
+        self.base, self.rows, self.shape = base, rows, (len(rows), base.shape[1])
+
+    def __len__(self):
+        return len(self.rows)
+
+    def __getitem__(self, sl):
+        return np.asarray(self.base[self.rows[sl]])
 
 
 if __name__ == '__main__':

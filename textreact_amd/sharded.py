@@ -27,7 +27,8 @@ def shard_bounds(n_total: int, world_size: int, rank: int) -> Tuple[int, int]:
 
 
 class ShardedFlatIndex:
-    def __init__(self, d: int, metric: int, group=None, local_index=None, merge: Optional[Callable] = None):
+    def __init__(self, d: int, metric: int, group=None, local_index=None, merge: Optional[Callable] = None,
+                 exchange_always: bool = False):
         import torch.distributed as dist
         self.d, self.metric = int(d), int(metric)
         self.group = group
@@ -44,6 +45,10 @@ class ShardedFlatIndex:
             merge = faiss_compat.merge_topk
         self.local = local_index
         self._merge = merge
+        # a one-rank group skips the exchange (nothing to exchange); exchange_always runs the collectives and the merge
+        # anyway, which is how a one-GPU box drives the RCCL branch of this file (tests/test_knn_gpu.py)
+        self.exchange_always = bool(exchange_always)
+        self.late_fallbacks = 0
         self.offset = 0      # global id of this shard's first row
         self.ntotal = 0      # rows over all shards
 
@@ -64,14 +69,17 @@ class ShardedFlatIndex:
         certificate counts back; should that wait have had to re-do queries after the exchange (stats.late_fallback on
         any rank -- agreed on by a one-word all-reduce), the exchange is simply repeated on the final lists."""
         import torch
-        begin = getattr(self.local, "search_s64_begin", None) if self.world_size > 1 else None
+        exchange = self.world_size > 1 or self.exchange_always
+        begin = getattr(self.local, "search_s64_begin", None) if exchange else None
         D, I_loc, S = begin(x, k) if begin is not None else self.local.search_s64(x, k)
-        if self.world_size == 1:
+        if not exchange:
             return D, torch.where(I_loc >= 0, I_loc + self.offset, I_loc)
         out = self._exchange_and_merge(S, I_loc, k)
         if begin is not None:
             import torch.distributed as dist
-            late = torch.tensor([1 if self.local.search_finish() else 0], dtype=torch.int32)
+            mine_late = 1 if self.local.search_finish() else 0
+            self.late_fallbacks += mine_late          # searches of THIS rank that had to repeat the exchange (tests read it)
+            late = torch.tensor([mine_late], dtype=torch.int32)
             if dist.get_backend(self.group) != "gloo":
                 late = late.to(S.device)
             dist.all_reduce(late, op=dist.ReduceOp.MAX, group=self.group)
