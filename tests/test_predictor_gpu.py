@@ -65,6 +65,9 @@ def test_add_layernorm_backward(rows, cols):
     (1, 1, 65, 200, "key", True),
     (1, 2, 130, 2100, "key", False),      # key mask longer than the 1024 keys the kernel keeps in LDS at a time
     (1, 2, 300, 1100, "full", True),
+    (2, 12, 7, 512, "key", False),        # RCR cross-attention: one 32-query unit, its keys split four ways inside the workgroup
+    (2, 3, 40, 200, "full", False),       # two units, keys split two ways
+    (1, 2, 161, 90, "key", True),         # a one-query tail block under causality: some key waves see no key at all
 ])
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
 def test_attention_forward(B, H, Lq, Lk, mask, causal, dtype, tol):
@@ -186,6 +189,10 @@ def test_attention_backward(B, H, Lq, Lk, mask, causal):
     (2, 4, 160, 512, "key", False),      # cross-attention
     (1, 2, 300, 1100, "key", False),     # key mask spans more than one 1024-key chunk
     (1, 2, 257, 129, "none", False), (1, 2, 129, 257, "none", True), (1, 1, 200, 200, "full", True),
+    # query blocks of one or two 32-query units split their KEYS over the idle waves (round 4): RCR's decoder (7 positions)
+    # over the encoder states, two units over several key tiles, a tail unit with a per-element mask, causal with idle key waves
+    (2, 12, 7, 512, "key", False), (2, 2, 40, 200, "key", False), (2, 2, 160, 512, "full", False), (1, 2, 7, 7, "key", True),
+    (1, 3, 161, 300, "key", True),
 ])
 def test_attention_backward_bf16_matrix_cores(B, H, Lq, Lk, mask, causal):
     """bf16 in / bf16 out through the MFMA backward (attn_bwd_mfma.h) against fp32 autograd on the
@@ -260,6 +267,7 @@ def test_add_layernorm_dropout_forward_backward(rows, cols, dtype, tol, with_res
 @pytest.mark.parametrize("B,H,Lq,Lk,mask,causal", [
     (2, 3, 70, 70, "key", False), (2, 2, 33, 33, "none", True), (2, 2, 20, 77, "key", False),
     (1, 2, 65, 65, "full", False), (2, 4, 200, 300, "key", False), (1, 2, 160, 160, "none", True),
+    (2, 4, 160, 512, "key", False), (2, 3, 7, 512, "key", False), (1, 2, 40, 200, "full", False),     # key-split query blocks
 ])
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 5e-5), (torch.bfloat16, 2e-2)])
 def test_attention_dropout_forward_backward(B, H, Lq, Lk, mask, causal, dtype, tol):

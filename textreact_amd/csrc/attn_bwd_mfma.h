@@ -25,6 +25,14 @@
 
 typedef __attribute__((ext_vector_type(4))) float f32x4v;
 
+// lane id, recomputed where an epilogue needs it (volatile: hipcc otherwise keeps the lane-derived output addresses alive in
+// registers the loop does not have, i.e. spills them before the loop and reloads them after it)
+__device__ __forceinline__ int lane_again() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
 __device__ __forceinline__ int bwd_sw(int row) {
     const int x = (row >> 1) & 7;
     return ((x & 1) << 2) | (x >> 1);
@@ -104,7 +112,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (bid < main_) bid = (bid & 7) * per + (bid >> 3);
     }
     const int qb = bid % nqb, h = (bid / nqb) % H, b = bid / (nqb * H);
-    const int qidx = qb * 128 + wave * 32 + r;
+    // a block with one or two 32-query units splits its KEYS over the waves that would otherwise compute on padding, as the
+    // forward kernel does (nn_ops.hip: attention_fwd_mfma_kernel); dQ is linear in the keys, so the merge is a sum through LDS
+    const int nuq = min(4, (Lq - qb * 128 + 31) / 32);
+    const int KS = nuq == 1 ? 4 : (nuq == 2 ? 2 : 1);         // block-uniform
+    const int uq = KS == 4 ? 0 : (KS == 2 ? (wave & 1) : wave);
+    const int kp = KS == 4 ? wave : (KS == 2 ? (wave >> 1) : 0);
+    // the same two as scalars, for the epilogue only (they sit in scalar registers across the loop; the vector copies above
+    // die with it instead of being spilled around it)
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    const int b_s = __builtin_amdgcn_readfirstlane(b), h_s = __builtin_amdgcn_readfirstlane(h), qb_s = __builtin_amdgcn_readfirstlane(qb);   // (the division that made them ran on the vector pipe)
+    const int uq_s = KS == 4 ? 0 : (KS == 2 ? (wave_s & 1) : wave_s), kp_s = KS == 4 ? wave_s : (KS == 2 ? (wave_s >> 1) : 0);
+    const int qidx = qb * 128 + uq * 32 + r;
     const int qc = qidx < Lq ? qidx : Lq - 1;
     const int ldq = da.ldq ? da.ldq : H * 64, ldk = da.ldk ? da.ldk : H * 64;
     bf16x8 qf[4], dof[4];
@@ -128,10 +147,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     int nkb = (Lk + 63) / 64;
     if (causal) nkb = min(nkb, (min(Lq - 1, qb * 128 + 127) + off) / 64 + 1);
     const int klim = causal ? min(Lk - 1, qidx + off) : Lk - 1;
-    const int klim_wave_min = causal ? min(Lk - 1, qb * 128 + wave * 32 + off) : Lk - 1;
+    const int klim_wave_min = causal ? min(Lk - 1, qb * 128 + uq * 32 + off) : Lk - 1;
     const float* mrow = (MM == TRX_NN_MASK_FULL) ? mask + ((int64_t)b * Lq + qc) * Lk : nullptr;
     constexpr bool keymask = MM == TRX_NN_MASK_KEY;
-    const float* mkey = keymask ? mask + (int64_t)b * Lk : nullptr;
+    const float* mkey = keymask ? mask + (int64_t)b_s * Lk : nullptr;      // a scalar base (b itself sits in a vector register)
     // dropout hash input of (this lane's query, key pair 0) -- the same function the forward evaluated
     const unsigned xdrop = DROP ? drop_base_da(da, (unsigned)(b * H + h)) + (unsigned)qidx * DROP_C1 + (unsigned)(2 * hh) * DROP_C2 : 0u;
 
@@ -181,10 +200,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (keymask) {
         if (kc > 0) __syncthreads();
         float mv_[4];
+        const int tid_ = lane_again() + 64 * wave_s;      // recomputed: the thread id would otherwise be kept (spilled) across the tile loop
 #pragma unroll
-        for (int i_ = 0; i_ < 4; ++i_) mv_[i_] = mkey[min(kc * 64 + 4 * tid + i_, Lk - 1)];
+        for (int i_ = 0; i_ < 4; ++i_) mv_[i_] = mkey[min(kc * 64 + 4 * tid_ + i_, Lk - 1)];
 #pragma unroll
-        for (int i_ = 0; i_ < 4; ++i_) ldsM[4 * tid + i_] = fmaxf(mv_[i_] * inv_scale, -1e30f);
+        for (int i_ = 0; i_ < 4; ++i_) ldsM[4 * tid_ + i_] = fmaxf(mv_[i_] * inv_scale, -1e30f);
     }
     const int kend = min(nkb, kc + 16);
     for (int kb = kc; kb < kend; ++kb) {
@@ -195,6 +215,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         asm volatile("" ::: "memory");
         const int buf1 = buf == 2 ? 0 : buf + 1, buf2 = buf == 0 ? 2 : buf - 1;
         if (kb + 2 < nkb) TRX_BWD1_STAGE(kb + 2, buf2);
+        if ((kb & (KS - 1)) == kp) {          // wave-uniform: this wave's tile
         const unsigned bofs = (unsigned)(buf * 16384);
         const int key0 = kb * 64;
         // ---- S^T = K Q^T (+ mask / scale) ----
@@ -300,19 +321,51 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(TRX_BWD_TRFRAG(kt1, 0), ds, a0, 0, 0, 0);
             a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(TRX_BWD_TRFRAG(kt1, 1), ds, a1, 0, 0, 0);
         }
+        }
         buf = buf1;
     }
     }
 #undef TRX_BWD1_STAGE
-    if (qidx < Lq) {
-        bf16_t* op = dq + ((int64_t)b * Lq + qidx) * ldq + h * 64;
+    // the epilogue's index arithmetic starts again from scalars the compiler cannot connect with the prologue's (an empty asm
+    // makes them opaque): every vector value of the prologue then dies with the loop instead of being spilled around it
+    int b_e = b_s, h_e = h_s, qb_e = qb_s;
+    asm volatile("" : "+s"(b_e), "+s"(h_e), "+s"(qb_e));
+    const int lane_e = lane_again(), hh_e = lane_e >> 5, qidx_e = qb_e * 128 + uq_s * 32 + (lane_e & 31);
+    if (KS > 1) {     // block-uniform: sum the key-split waves of every query unit, in wave order (deterministic)
+        const int lane = lane_e, uq = uq_s, kp = kp_s;
+        __syncthreads();
+        float4* part = reinterpret_cast<float4*>(lds);       // [slot][8][64 lanes] float4 in the K / V ring
+        const int per = 4 / KS;
+        if (kp > 0) {
+            float4* w = part + ((kp - 1) * per + uq) * 8 * 64 + lane;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                w[i * 64] = make_float4(a0[4 * i], a0[4 * i + 1], a0[4 * i + 2], a0[4 * i + 3]);
+                w[(4 + i) * 64] = make_float4(a1[4 * i], a1[4 * i + 1], a1[4 * i + 2], a1[4 * i + 3]);
+            }
+        }
+        __syncthreads();
+        if (kp == 0) {
+            for (int p_ = 1; p_ < KS; ++p_) {
+                const float4* rd = part + ((p_ - 1) * per + uq) * 8 * 64 + lane;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float4 x = rd[i * 64], y = rd[(4 + i) * 64];
+                    a0[4 * i] += x.x; a0[4 * i + 1] += x.y; a0[4 * i + 2] += x.z; a0[4 * i + 3] += x.w;
+                    a1[4 * i] += y.x; a1[4 * i + 1] += y.y; a1[4 * i + 2] += y.z; a1[4 * i + 3] += y.w;
+                }
+            }
+        }
+    }
+    if (qidx_e < Lq && kp_s == 0) {
+        bf16_t* op = dq + ((int64_t)b_e * Lq + qidx_e) * (da.ldq ? da.ldq : H * 64) + h_e * 64;
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {   // registers 4gq..4gq+3 = d rows 8gq + 4hh + 0..3
             uint2 w0, w1;
             w0.x = pack2bf(a0[4 * gq] * scale, a0[4 * gq + 1] * scale); w0.y = pack2bf(a0[4 * gq + 2] * scale, a0[4 * gq + 3] * scale);
             w1.x = pack2bf(a1[4 * gq] * scale, a1[4 * gq + 1] * scale); w1.y = pack2bf(a1[4 * gq + 2] * scale, a1[4 * gq + 3] * scale);
-            *reinterpret_cast<uint2*>(op + 8 * gq + 4 * hh) = w0;
-            *reinterpret_cast<uint2*>(op + 32 + 8 * gq + 4 * hh) = w1;
+            *reinterpret_cast<uint2*>(op + 8 * gq + 4 * hh_e) = w0;
+            *reinterpret_cast<uint2*>(op + 32 + 8 * gq + 4 * hh_e) = w1;
         }
     }
 }
@@ -337,6 +390,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (bid < main_) bid = (bid & 7) * per + (bid >> 3);
     }
     const int kblk = bid % nkblk, h = (bid / nkblk) % H, b = bid / (nkblk * H);
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);     // for the epilogue (see the dq pass)
+    const int b_s = __builtin_amdgcn_readfirstlane(b), h_s = __builtin_amdgcn_readfirstlane(h), kblk_s = __builtin_amdgcn_readfirstlane(kblk);
     const int kidx = kblk * 128 + wave * 32 + r;   // this lane's key
     const int kc = kidx < Lk ? kidx : Lk - 1;
     const int ldq = da.ldq ? da.ldq : H * 64, ldk = da.ldk ? da.ldk : H * 64;
@@ -371,6 +426,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const char* dobase = reinterpret_cast<const char*>(dout + ((int64_t)b * Lq * H + h) * 64);
     const float* nlbase = negl + ((int64_t)b * H + h) * Lq;
     const float* ndbase = negd + ((int64_t)b * H + h) * Lq;
+    const float* mfull = (MM == TRX_NN_MASK_FULL) ? mask + (int64_t)b * Lq * Lk : nullptr;     // this batch's [Lq][Lk] mask (Lq * Lk < 2^30)
     unsigned sofs[2], sofd[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -432,8 +488,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // some query row of the tile is past Lq, or hidden from some key of this wave by causality
         const bool vis = (q0 + 64 > Lq) || (causal && q0 < qmin_wave_max);
         const unsigned ta0 = tra0 + bofs, ta1 = tra1 + bofs;
-#pragma unroll
-        for (int hb = 0; hb < 2; ++hb) {   // 32 queries at a time
+        auto half_tile = [&](auto HB) __attribute__((always_inline)) {   // 32 queries at a time; hb is a compile-time constant (asm immediates)
+            constexpr int hb = decltype(HB)::value;
             // accumulators start from the per-query scalars: rows (t & 3) + 8 (t >> 2) + 4 hh
             f32x16 s, p;
             {
@@ -468,15 +524,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[s_], kf[s_], s, 0, 0, 0);
                 p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fd[s_], vf[s_], p, 0, 0, 0);
             }
-            // transposed fragments of this half: k-steps 2 hb, 2 hb + 1 of dO (for dV) and of Q (for dK)
+            // transposed fragments of this half: k-steps 2 hb, 2 hb + 1 of dO (for dV) and of Q (for dK).  They fly under the
+            // elementwise part -- except with a per-element mask, whose 16 values per half take the registers the fragments
+            // would hold meanwhile (that variant spilled into scratch, and a spill reload waits behind the LDS-DMA queue)
             uint2 td0[2][2], td1[2][2], tq0[2][2], tq1[2][2];
-            if (hb == 0) {
-                TRX_BWD_TR(td0, 0, ta0 + 8192u, ta1 + 8192u) TRX_BWD_TR(td1, 1, ta0 + 8192u, ta1 + 8192u)
-                TRX_BWD_TR(tq0, 0, ta0, ta1) TRX_BWD_TR(tq1, 1, ta0, ta1)
-            } else {
-                TRX_BWD_TR(td0, 2, ta0 + 8192u, ta1 + 8192u) TRX_BWD_TR(td1, 3, ta0 + 8192u, ta1 + 8192u)
-                TRX_BWD_TR(tq0, 2, ta0, ta1) TRX_BWD_TR(tq1, 3, ta0, ta1)
+#define TRX_BWD2_TRANSPOSED()                                                                               \
+            if (hb == 0) {                                                                                  \
+                TRX_BWD_TR(td0, 0, ta0 + 8192u, ta1 + 8192u) TRX_BWD_TR(td1, 1, ta0 + 8192u, ta1 + 8192u)   \
+                TRX_BWD_TR(tq0, 0, ta0, ta1) TRX_BWD_TR(tq1, 1, ta0, ta1)                                   \
+            } else {                                                                                        \
+                TRX_BWD_TR(td0, 2, ta0 + 8192u, ta1 + 8192u) TRX_BWD_TR(td1, 3, ta0 + 8192u, ta1 + 8192u)   \
+                TRX_BWD_TR(tq0, 2, ta0, ta1) TRX_BWD_TR(tq1, 3, ta0, ta1)                                   \
             }
+            if (MM != TRX_NN_MASK_FULL) { TRX_BWD2_TRANSPOSED() }
             // ---- P = exp2(scale log2e (S - lse/scale) + mask log2e) ; dS = P (dP - delta) ----  (two copies behind one
             // wave-uniform branch, as in the dq pass)
             auto elementwise = [&](auto VISC) __attribute__((always_inline)) {
@@ -485,8 +545,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 for (int t = 0; t < 16; ++t) {
                     const int qr_ = q0 + hb * 32 + (t & 3) + 8 * (t >> 2) + 4 * hh;
                     float val = __builtin_fmaf(s[t], sl2, mk2);
-                    if (MM == TRX_NN_MASK_FULL)
-                        val = __builtin_fmaf(fmaxf(mask[((int64_t)b * Lq + min(qr_, Lq - 1)) * Lk + kc], -1e30f), L2E, val);
+                    if (MM == TRX_NN_MASK_FULL)   // wave-uniform base + a 32-bit offset: row (uniform) * Lk + this lane's key
+                        val = __builtin_fmaf(fmaxf(mfull[(unsigned)(min(qr_, Lq - 1) * Lk) + (unsigned)kc], -1e30f), L2E, val);
                     float pr = __builtin_amdgcn_exp2f(fminf(val, 0.f));   // p <= 1
                     if (VIS) pr = (qr_ >= Lq || qr_ < qmin) ? 0.f : pr;
                     if (DROP) {
@@ -501,6 +561,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
             };
             if (vis) elementwise(ic_<1>{}); else elementwise(ic_<0>{});
+            if (MM == TRX_NN_MASK_FULL) { TRX_BWD2_TRANSPOSED() }
+#undef TRX_BWD2_TRANSPOSED
             // ---- dV^T += dO^T P ;  dK^T += Q^T dS ----
             TRX_BWD_TRWAIT(td0, 12)
             {
@@ -526,13 +588,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 ak0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(TRX_BWD_TRFRAG(tq1, 0), db, ak0, 0, 0, 0);
                 ak1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(TRX_BWD_TRFRAG(tq1, 1), db, ak1, 0, 0, 0);
             }
-        }
+        };
+        half_tile(ic_<0>{});
+        // wave-uniform: the second half lies wholly past the last query at Lq = 160's third tile and in every tile of a
+        // decoder with 7 positions -- arithmetic on padding otherwise
+        if (q0 + 32 < Lq) half_tile(ic_<1>{});
         buf = buf1;
     }
 #undef TRX_BWD2_STAGE
-    if (kidx < Lk) {
-        bf16_t* kp = dk + ((int64_t)b * Lk + kidx) * ldk + h * 64;
-        bf16_t* vp = dv + ((int64_t)b * Lk + kidx) * ldk + h * 64;
+    int b_e = b_s, h_e = h_s, kblk_e = kblk_s;      // opaque copies, as in the dq pass
+    asm volatile("" : "+s"(b_e), "+s"(h_e), "+s"(kblk_e));
+    const int lane_e = lane_again(), hh_e = lane_e >> 5, kidx_e = kblk_e * 128 + wave_s * 32 + (lane_e & 31);
+    if (kidx_e < Lk) {
+        const int hh = hh_e;
+        const int64_t ro_e = ((int64_t)b_e * Lk + kidx_e) * (da.ldk ? da.ldk : H * 64) + h_e * 64;
+        bf16_t* kp = dk + ro_e;
+        bf16_t* vp = dv + ro_e;
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
             uint2 w;

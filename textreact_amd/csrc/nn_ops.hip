@@ -761,7 +761,17 @@ __global__ __launch_bounds__(XW ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
         if (bid < main_) bid = (bid & 7) * per + (bid >> 3);
     }
     const int qb = bid % nqb, h = (bid / nqb) % H, b = bid / (nqb * H);
-    const int qidx = qb * 128 + wave * 32 + r;              // this lane's query
+    // A query block with one or two 32-query units (the last block of Lq = 160: 128 + 32; every block of a decoder with 7
+    // positions) would leave three or two of its four waves computing on padding.  Those waves take KEYS instead: the block's
+    // key tiles are dealt round-robin over KS = 4 (2) waves per query unit -- every wave still stages every tile and meets
+    // every barrier, it only skips the arithmetic of the tiles that are not its own -- and the partial (O, m, l) of a unit's
+    // waves are merged through LDS at the end (a log-sum-exp merge: any reference common to a row is exact).  The key-tile
+    // chain of such a block is a quarter (half) as long; the launch does the arithmetic of 5 units instead of 8 at Lq = 160.
+    const int nuq = XW ? 4 : min(4, (Lq - qb * 128 + 31) / 32);
+    const int KS = nuq == 1 ? 4 : (nuq == 2 ? 2 : 1);         // block-uniform
+    const int uq = KS == 4 ? 0 : (KS == 2 ? (wave & 1) : wave);
+    const int kp = KS == 4 ? wave : (KS == 2 ? (wave >> 1) : 0);
+    const int qidx = qb * 128 + uq * 32 + r;                // this lane's query
     const int qc = qidx < Lq ? qidx : Lq - 1;
     bf16x8 qf[4];   // B operand of S^T = K Q^T: B[k = 8hh + j][col r] = Q[query r][d = 16 s + 8 hh + j]
     {
@@ -786,7 +796,7 @@ __global__ __launch_bounds__(XW ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
     }
     // last visible key of this lane's query (also bounds the tail tile)
     const int klim = causal ? min(Lk - 1, qidx + off) : Lk - 1;
-    const int klim_wave_min = causal ? min(Lk - 1, qb * 128 + wave * 32 + off) : Lk - 1;   // smallest klim in the wave
+    const int klim_wave_min = causal ? min(Lk - 1, qb * 128 + uq * 32 + off) : Lk - 1;   // smallest klim in the wave
     const float* mrow = (MM == TRX_NN_MASK_FULL) ? mask + ((int64_t)b * Lq + qc) * Lk : nullptr;
 
     // LDS-DMA geometry: a piece is one global_load_lds_dwordx4 = 8 rows x 128 B written lane-linear
@@ -807,17 +817,24 @@ __global__ __launch_bounds__(XW ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
     }
     // one piece: 32-bit per-lane offset against a wave-uniform 64-bit base in scalar registers (no 64-bit vector add per piece:
     // the builtin, given a pointer, spent ~20 v_lshl_add_u64 / v_readfirstlane a tile on addresses), M0 written in the same statement
+    // (the base goes through readfirstlane: a wave-uniform 64-bit sum that instruction selection happened to put on the vector
+    // pipe would otherwise reach the "s" operand as a VGPR pair -- an assembler error at best; it folds away when the value
+    // is in scalar registers already)
+#define TRX_SGPR64(P) ((((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned long long)(P) >> 32))) << 32) | \
+                       (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)(P)))
 #define TRX_GLDS16(SBASE, VOFF, LDSADDR)                                                                     \
     {                                                                                                        \
         const unsigned vo_ = (VOFF);                                                                         \
         const unsigned la_ = (unsigned)__builtin_amdgcn_readfirstlane((int)(LDSADDR));                        \
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(vo_), "s"(SBASE), "s"(la_) : "memory", "m0"); \
+        const unsigned long long sb_ = TRX_SGPR64(SBASE);                                                    \
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(vo_), "s"(sb_), "s"(la_) : "memory", "m0"); \
     }
 #define TRX_GLDS4(SBASE, VOFF, LDSADDR)      /* the same with 4 bytes per lane */                            \
     {                                                                                                        \
         unsigned vo_ = (VOFF);                                                                               \
         const unsigned la_ = (unsigned)__builtin_amdgcn_readfirstlane((int)(LDSADDR));                        \
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" : "+v"(vo_) : "s"(SBASE), "s"(la_) : "memory", "m0"); \
+        const unsigned long long sb_ = TRX_SGPR64(SBASE);                                                    \
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" : "+v"(vo_) : "s"(sb_), "s"(la_) : "memory", "m0"); \
     }
     const unsigned ldsbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
     const unsigned lds_w = (unsigned)__builtin_amdgcn_readfirstlane((int)(ldsbase + (unsigned)(2 * wave * 1024)));   // this wave's pieces, scalar
@@ -887,6 +904,7 @@ __global__ __launch_bounds__(XW ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
         asm volatile("" ::: "memory");
         const int buf1 = buf == 2 ? 0 : buf + 1, buf2 = buf == 0 ? 2 : buf - 1;
         if (kb + 2 < nkb) TRX_ATT_STAGE(kb + 2, buf2);
+        if ((kb & (KS - 1)) == kp) {          // wave-uniform: this wave's tile (always, unless the block splits its keys)
         // ---- S^T = K Q^T for both 32-key halves ----
         f32x16 s0, s1;
         const int key0 = kb * 64;
@@ -965,6 +983,7 @@ __global__ __launch_bounds__(XW ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
         TRX_VT_WAIT(2, 3, 0)
         TRX_PV_STEP(2, 1) TRX_PV_STEP(3, 1)
         if (TRX_ATT_PRIO) __builtin_amdgcn_s_setprio(0);
+        }
         buf = buf1;
         TRX_STAMP(4 + (kb < 26 ? kb : 26), __builtin_amdgcn_s_memtime());
     }
@@ -975,8 +994,52 @@ __global__ __launch_bounds__(XW ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
 #undef TRX_ATT_STAGE
 #undef TRX_MASK_FILL
 #undef TRX_MASK_INIT
-    const float ltot = lsum + __shfl_xor(lsum, 32, 64);
-    if (qidx < Lq) {
+    float ltot = lsum + __shfl_xor(lsum, 32, 64);
+    if (KS > 1) {     // block-uniform: merge the key-split waves of every query unit
+        // partial state of a wave: 32 + 2 floats per lane, lane-major rows of float4 (conflict-free 16-byte accesses):
+        // [slot][9][64 lanes] float4 in the K / V ring, which nobody reads any more after the barrier
+        __syncthreads();
+        float4* part = reinterpret_cast<float4*>(lds);
+        const int per = 4 / KS;                              // query units of the block
+        if (kp > 0) {
+            float4* w = part + ((kp - 1) * per + uq) * 9 * 64 + lane;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                w[i * 64] = make_float4(o0[4 * i], o0[4 * i + 1], o0[4 * i + 2], o0[4 * i + 3]);
+                w[(4 + i) * 64] = make_float4(o1[4 * i], o1[4 * i + 1], o1[4 * i + 2], o1[4 * i + 3]);
+            }
+            w[8 * 64] = make_float4(m, ltot, 0.f, 0.f);
+        }
+        __syncthreads();
+        if (kp == 0) {
+            const float NINF = -__builtin_inff();
+            float mp[3], lp[3], M = m;
+            for (int p_ = 1; p_ < KS; ++p_) {
+                const float4 ml = part[((p_ - 1) * per + uq) * 9 * 64 + 8 * 64 + lane];
+                mp[p_ - 1] = ml.x; lp[p_ - 1] = ml.y;
+                M = fmaxf(M, ml.x);
+            }
+            const float ws = m == NINF ? 0.f : __builtin_amdgcn_exp2f(m - M);     // a wave without a visible key: m = -inf, O = 0, l = 0
+#pragma unroll
+            for (int t = 0; t < 16; ++t) { o0[t] *= ws; o1[t] *= ws; }
+            ltot *= ws;
+            for (int p_ = 1; p_ < KS; ++p_) {
+                const float wp = mp[p_ - 1] == NINF ? 0.f : __builtin_amdgcn_exp2f(mp[p_ - 1] - M);
+                const float4* rd = part + ((p_ - 1) * per + uq) * 9 * 64 + lane;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float4 a = rd[i * 64], c = rd[(4 + i) * 64];
+                    o0[4 * i] = __builtin_fmaf(a.x, wp, o0[4 * i]); o0[4 * i + 1] = __builtin_fmaf(a.y, wp, o0[4 * i + 1]);
+                    o0[4 * i + 2] = __builtin_fmaf(a.z, wp, o0[4 * i + 2]); o0[4 * i + 3] = __builtin_fmaf(a.w, wp, o0[4 * i + 3]);
+                    o1[4 * i] = __builtin_fmaf(c.x, wp, o1[4 * i]); o1[4 * i + 1] = __builtin_fmaf(c.y, wp, o1[4 * i + 1]);
+                    o1[4 * i + 2] = __builtin_fmaf(c.z, wp, o1[4 * i + 2]); o1[4 * i + 3] = __builtin_fmaf(c.w, wp, o1[4 * i + 3]);
+                }
+                ltot = __builtin_fmaf(lp[p_ - 1], wp, ltot);
+            }
+            m = M;
+        }
+    }
+    if (qidx < Lq && kp == 0) {
         const float inv = (DROP ? da.inv_keep : 1.0f) / ltot;
         // natural-log LSE of the scaled, masked scores (what the backward pass recomputes against)
         if (lse && hh == 0) lse[((int64_t)b * H + h) * Lq + qidx] = (m + __builtin_amdgcn_logf(ltot)) * 0.69314718055994530942f;
