@@ -24,6 +24,11 @@
  * inputs), completes them.  Work the caller enqueues on the same stream between the two calls (the
  * all-gather and merge of the row-sharded search) overlaps nothing of the search but costs no host
  * round trip either; stats.late_fallback says whether it consumed outputs that finish then changed.
+ * Memory: the large search workspaces (2.3 GiB for a 65,536-query batch at 4 corpus splits) are shared by all indexes of
+ * the process on one device and never shrink while an index exists there; searches of different indexes serialise on
+ * the GPU where they use them.  Per index: the data, 256 KiB of flags per batch, and the exact fall-back's rows
+ * (4 x n doubles: 32 MB per million vectors, reserved with the first fast-path search since the device decides
+ * whether the rows are needed).
  * trx_index_search_device / _s64 / trx_index_search are begin + finish: on return the outputs are
  * final.  (One exception to "no wait in begin": fp32 queries against an index that so far holds only
  * bf16-exact data read their statistics back, because inexact queries re-lay the index out.)
@@ -132,6 +137,10 @@ typedef struct trx_search_stats {
 
 int trx_index_last_stats(const trx_index* idx, trx_search_stats* out);
 
+/* sizeof(trx_search_stats) as this library was built: a caller compiled against another revision of the struct checks
+ * it before handing trx_index_last_stats a buffer (the struct grew by `late_fallback` in 0.2). */
+int trx_search_stats_size(void);
+
 /* Enable (1) / disable (0) HIP-event timing of the scan kernel inside search calls.  Timing makes
  * begin synchronise after every batch; leave it off for overlapped pipelines. */
 int trx_index_set_timing(trx_index* idx, int enabled);
@@ -139,7 +148,7 @@ int trx_index_set_timing(trx_index* idx, int enabled);
 /* Message of the last error on this thread ("" if none). */
 const char* trx_last_error(void);
 
-/* Library version string, e.g. "trxknn 0.1 (gfx950)". */
+/* Library version string, e.g. "trxknn 0.2 (gfx950)". */
 const char* trx_version(void);
 
 #ifdef __cplusplus

@@ -414,6 +414,27 @@ def test_multi_rank_sharded_search_on_one_gpu(world):
             assert np.array_equal(D.view(np.uint32), Dr.view(np.uint32)), (metric, r)
 
 
+def test_pad_queries_of_the_last_query_tile_cost_nothing():
+    """round 4: a query count that is not a multiple of 256 is padded with zero rows; under the inner product every corpus
+    row scores exactly 0 against a zero query -- one tie group of the whole corpus -- and the pad columns' lists used to fill
+    and be compacted at every tile: 40,000 queries took 190 ms where 40,192 took 12.  The scan never lists for pad columns now."""
+    import torch
+    import textreact_amd.faiss_compat as faiss
+    from oracle import flat_knn as oracle
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    y = torch.randn((204800, 768), generator=g, device="cuda").bfloat16()
+    x = torch.randn((40192, 768), generator=g, device="cuda").bfloat16()
+    idx = faiss.IndexFlatIP(768); idx.add(y); idx.set_timing(True)
+    ms = {}
+    for nq in (40192, 40000, 40192, 40000):
+        D, I = idx.search(x[:nq], 10)
+        ms[nq] = idx.last_stats()["scan_ms"]
+    assert ms[40000] < 1.5 * ms[40192], ms
+    rows = [0, 1, 39935, 39936, 39999]              # first tile, and the real queries that share the last tile with the pad rows
+    _, want = oracle.knn_canonical(IP, x[rows].float().cpu().numpy(), y.float().cpu().numpy(), 10)
+    assert np.array_equal(I[rows].cpu().numpy(), want)
+
+
 def _late_worker(rank, world, port, ret):
     import os, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

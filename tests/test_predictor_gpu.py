@@ -67,7 +67,8 @@ def test_add_layernorm_backward(rows, cols):
     (1, 2, 300, 1100, "full", True),
     (2, 12, 7, 512, "key", False),        # RCR cross-attention: one 32-query unit, its keys split four ways inside the workgroup
     (2, 3, 40, 200, "full", False),       # two units, keys split two ways
-    (1, 2, 161, 90, "key", True),         # a one-query tail block under causality: some key waves see no key at all
+    (1, 2, 161, 161, "key", True),        # a one-query tail block under causality: three key tiles, the fourth key wave sees no key at all
+    (1, 2, 161, 300, "key", True),
 ])
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
 def test_attention_forward(B, H, Lq, Lk, mask, causal, dtype, tol):

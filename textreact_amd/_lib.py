@@ -17,7 +17,7 @@ SYMBOLS = [
     "trx_index_create", "trx_index_add", "trx_index_add_device", "trx_index_ntotal", "trx_index_dim",
     "trx_index_reset", "trx_index_destroy", "trx_index_search", "trx_index_search_device",
     "trx_index_search_device_s64", "trx_index_search_device_begin", "trx_index_search_finish",
-    "trx_merge_topk_device", "trx_index_last_stats",
+    "trx_merge_topk_device", "trx_index_last_stats", "trx_search_stats_size",
     "trx_index_set_timing", "trx_last_error", "trx_version",
 ]
 
@@ -81,6 +81,9 @@ def lib():
     L.trx_index_set_timing.argtypes = [vp, i32]
     L.trx_last_error.restype = ctypes.c_char_p
     L.trx_version.restype = ctypes.c_char_p
+    if L.trx_search_stats_size() != ctypes.sizeof(SearchStats):
+        raise TrxError("libtrxknn.so was built with another trx_search_stats (%d bytes, this binding has %d): rebuild it"
+                       % (L.trx_search_stats_size(), ctypes.sizeof(SearchStats)))
     _lib = L
     return L
 

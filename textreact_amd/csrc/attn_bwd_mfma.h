@@ -107,11 +107,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int r = lane & 31, hh = lane >> 5;
     const int nqb = (Lq + 127) / 128;
     int bid = blockIdx.x;
+    int qsw = 0;
     {   // query blocks of one (batch, head) next to each other on one XCD (they share K and V)
         const int nwg = gridDim.x, per = nwg >> 3, main_ = per << 3;
+        if (nqb == 2 && !(per & 1) && bid < main_) qsw = (bid >> 3) >> 5;      // full and short blocks mixed per CU (see the forward kernel)
         if (bid < main_) bid = (bid & 7) * per + (bid >> 3);
     }
-    const int qb = bid % nqb, h = (bid / nqb) % H, b = bid / (nqb * H);
+    const int qb = (bid + qsw) % nqb, h = (bid / nqb) % H, b = bid / (nqb * H);
     // a block with one or two 32-query units splits its KEYS over the waves that would otherwise compute on padding, as the
     // forward kernel does (nn_ops.hip: attention_fwd_mfma_kernel); dQ is linear in the keys, so the merge is a sum through LDS
     const int nuq = min(4, (Lq - qb * 128 + 31) / 32);

@@ -6,6 +6,7 @@
 #include "knn_common.h"
 
 #include <algorithm>
+#include <mutex>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -53,6 +54,23 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
 };
 
+// The large search workspaces -- candidate lists (2 GiB for a 65,536-query batch), their counts and bounds, the shared
+// thresholds, the padded query operand -- are dead as soon as the select kernel of a batch has run, and that kernel is
+// enqueued inside trx_index_search_device_begin.  So every index of a process on one device shares ONE set of them (a
+// process with 8 indexes used to hold 8 x 2.3 GiB): a search enqueues under the pool's mutex, first makes its stream wait
+// for the event the previous user recorded behind its last kernel, and records its own at the end.  Searches of different
+// indexes therefore serialise on the GPU where they touch the pool -- each of them fills the device anyway.  What a
+// search still reads after begin() has returned (certificate counts, flagged queries, the exact fall-back's rows) stays
+// per index.
+struct DevPool {
+    std::mutex mu;
+    DevBuf cand, cnt, thr, gthr, qg;
+    hipEvent_t last = nullptr;
+    int users = 0;
+};
+static DevPool g_pool[64];
+static DevPool& pool_of(int device) { return g_pool[device & 63]; }
+
 enum { MODE_EMPTY = 0, MODE_PLAIN = 1, MODE_SPLIT = 2 };
 static int round_up(int64_t v, int m) { return (int)((v + m - 1) / m * m); }
 static int64_t round_up64(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
@@ -69,7 +87,7 @@ struct trx_index {
     float maxabs = 0.f, maxnorm2 = 0.f;
     bool nonint = false;
     // workspaces
-    DevBuf w_stamp, w_stats, w_qg, w_qnorm2, w_cand, w_cnt, w_thr, w_flag, w_exact, w_io, w_tmp, w_gthr, w_cls;
+    DevBuf w_stamp, w_stats, w_qnorm2, w_flag, w_exact, w_io, w_tmp, w_cls;      // (the big ones are shared: DevPool)
     trx_search_stats stats{};
     bool timing = false;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -144,7 +162,8 @@ static int restructure(trx_index* idx, int64_t newcap, int newmode, hipStream_t 
 extern "C" {
 
 const char* trx_last_error(void) { return g_err.c_str(); }
-const char* trx_version(void) { return "trxknn 0.1 (gfx950)"; }
+const char* trx_version(void) { return "trxknn 0.2 (gfx950)"; }
+int trx_search_stats_size(void) { return (int)sizeof(trx_search_stats); }
 
 int trx_index_create(int d, int metric, int device, trx_index** out) {
     if (!out) return fail(TRX_EINVAL, "out is null");
@@ -158,6 +177,7 @@ int trx_index_create(int d, int metric, int device, trx_index** out) {
     trx_index* idx = new (std::nothrow) trx_index();
     if (!idx) return fail(TRX_ENOMEM, "host allocation failed");
     idx->d = d; idx->metric = metric; idx->device = device;
+    { DevPool& pl = pool_of(device); std::lock_guard<std::mutex> g(pl.mu); pl.users++; }
     *out = idx;
     return TRX_OK;
 }
@@ -169,9 +189,19 @@ void trx_index_destroy(trx_index* idx) {
     if (idx->Co) (void)hipFree(idx->Co);
     if (idx->cnorm2) (void)hipFree(idx->cnorm2);
     if (idx->cbias) (void)hipFree(idx->cbias);
-    DevBuf* bufs[] = {&idx->w_stamp, &idx->w_stats, &idx->w_qg, &idx->w_qnorm2, &idx->w_cand, &idx->w_cnt, &idx->w_thr,
-                      &idx->w_flag, &idx->w_exact, &idx->w_io, &idx->w_tmp, &idx->w_gthr, &idx->w_cls};
+    DevBuf* bufs[] = {&idx->w_stamp, &idx->w_stats, &idx->w_qnorm2, &idx->w_flag, &idx->w_exact, &idx->w_io, &idx->w_tmp, &idx->w_cls};
     for (DevBuf* b : bufs) b->release();
+    {   // the last index of the process on this device takes the shared workspaces with it
+        DevPool& pl = pool_of(idx->device);
+        std::lock_guard<std::mutex> g(pl.mu);
+        if (--pl.users <= 0) {
+            pl.users = 0;
+            (void)hipDeviceSynchronize();
+            DevBuf* shared[] = {&pl.cand, &pl.cnt, &pl.thr, &pl.gthr, &pl.qg};
+            for (DevBuf* b : shared) b->release();
+            if (pl.last) { (void)hipEventDestroy(pl.last); pl.last = nullptr; }
+        }
+    }
     for (auto& e : idx->ev) if (e) (void)hipEventDestroy(e);
     delete idx;
 }
@@ -304,19 +334,20 @@ static int search_batch(trx_index* idx, const void* q, const float* qnorm2, int6
     const int cap = 127, cap_alloc = cap + 1;
 
     int rc;
+    DevPool& pl = pool_of(idx->device);      // (the caller holds its mutex)
     // bf16 queries of the operand's own width, a whole number of query tiles, 16-byte aligned: the scan kernel reads them
     // where they lie (no padded copy: 0.27 ms per 65,536 x 768 batch)
     const bool direct = is_bf && !q_split && Kp == d && q_pad == nq && (((uintptr_t)q) & 15) == 0;
-    if (!direct && (rc = idx->w_qg.reserve((size_t)q_pad * Kp * sizeof(bf16_t)))) return rc;
-    if ((rc = idx->w_cand.reserve((size_t)q_pad * nlists * cap_alloc * sizeof(u64)))) return rc;
-    if ((rc = idx->w_cnt.reserve((size_t)q_pad * nlists * sizeof(u32)))) return rc;
-    if ((rc = idx->w_thr.reserve((size_t)q_pad * nlists * sizeof(u64)))) return rc;
-    if ((rc = idx->w_gthr.reserve((size_t)q_pad * 4 * sizeof(u32)))) return rc;
+    if (!direct && (rc = pl.qg.reserve((size_t)q_pad * Kp * sizeof(bf16_t)))) return rc;
+    if ((rc = pl.cand.reserve((size_t)q_pad * nlists * cap_alloc * sizeof(u64)))) return rc;
+    if ((rc = pl.cnt.reserve((size_t)q_pad * nlists * sizeof(u32)))) return rc;
+    if ((rc = pl.thr.reserve((size_t)q_pad * nlists * sizeof(u64)))) return rc;
+    if ((rc = pl.gthr.reserve((size_t)q_pad * 4 * sizeof(u32)))) return rc;
 
     // query operand + norms
     if (!direct) {
-        HIPCHK(hipMemsetAsync(idx->w_qg.p, 0, (size_t)q_pad * Kp * sizeof(bf16_t), st));
-        HIPCHK(launch_build_operand(q, is_bf, q_split ? 2 : 0, nq, d, d, (bf16_t*)idx->w_qg.p, Kp, st));
+        HIPCHK(hipMemsetAsync(pl.qg.p, 0, (size_t)q_pad * Kp * sizeof(bf16_t), st));
+        HIPCHK(launch_build_operand(q, is_bf, q_split ? 2 : 0, nq, d, d, (bf16_t*)pl.qg.p, Kp, st));
     }
     // this batch's slice of the flag workspace (reserved for all batches by the caller: a DevBuf may not grow while
     // earlier batches of the same call still point into it)
@@ -325,17 +356,17 @@ static int search_batch(trx_index* idx, const void* q, const float* qnorm2, int6
     HIPCHK(hipMemsetAsync(nflag, 0, 4 * sizeof(int), st));
 
     ScanParams sp{};
-    sp.corpus = idx->Cg; sp.queries = direct ? (const bf16_t*)q : (const bf16_t*)idx->w_qg.p; sp.cbias = idx->cbias;
+    sp.corpus = idx->Cg; sp.queries = direct ? (const bf16_t*)q : (const bf16_t*)pl.qg.p; sp.cbias = idx->cbias;
     sp.Kp = Kp; sp.n_valid = (int)idx->n; sp.ntiles = ntiles; sp.tiles_per_split = tps; sp.nsplits = nsplits;
-    sp.nqtiles = nqt; sp.kprime = kprime; sp.cap = cap; sp.cap_alloc = cap_alloc;
-    sp.cand = (u64*)idx->w_cand.p; sp.cand_cnt = (u32*)idx->w_cnt.p; sp.cand_thr = (u64*)idx->w_thr.p;
+    sp.nqtiles = nqt; sp.nq_valid = (int)nq; sp.kprime = kprime; sp.cap = cap; sp.cap_alloc = cap_alloc;
+    sp.cand = (u64*)pl.cand.p; sp.cand_cnt = (u32*)pl.cnt.p; sp.cand_thr = (u64*)pl.thr.p;
     { const char* dbg = getenv("TRX_SCAN_DEBUG"); sp.debug = dbg ? atoi(dbg) : 0; }
     sp.stamp_out = nullptr;
 #ifdef TRX_STAMP_BUILD
     if ((rc = idx->w_stamp.reserve((size_t)nqt * nsplits * 8 * 4 * sizeof(unsigned long long)))) return rc;
     sp.stamp_out = (unsigned long long*)idx->w_stamp.p;
 #endif
-    sp.g_thr = (u32*)idx->w_gthr.p;
+    sp.g_thr = (u32*)pl.gthr.p;
     HIPCHK(hipMemsetAsync(sp.g_thr, 0, (size_t)q_pad * 4 * sizeof(u32), st));
     // seed the shared thresholds: every query tile scans a few tiles (selection bookkeeping only, no lists)
     const bool boot = !getenv("TRX_NO_BOOT") && ntiles > 2;
@@ -496,6 +527,11 @@ static int search_device_impl(trx_index* idx, const void* q, int64_t nq, int dty
     const int64_t QB = 65536;
     const size_t esz = is_bf ? 2 : 4;
     const int nbatches = (int)((nq + QB - 1) / QB);
+    DevPool& pl = pool_of(idx->device);
+    std::lock_guard<std::mutex> pool_guard(pl.mu);
+    // behind whatever search -- of this or another index, on this or another stream -- used the shared workspaces last
+    if (pl.last) HIPCHK(hipStreamWaitEvent(st, pl.last, 0));
+    else HIPCHK(hipEventCreateWithFlags(&pl.last, hipEventDisableTiming));
     if ((rc = idx->w_flag.reserve((size_t)nbatches * (4 + QB) * sizeof(int)))) return rc;
     // the inline fall-back's score rows (INLINE_FALLBACK x n doubles)
     if ((rc = idx->w_exact.reserve((size_t)INLINE_FALLBACK * idx->n * sizeof(double)))) return rc;
@@ -505,6 +541,7 @@ static int search_device_impl(trx_index* idx, const void* q, int64_t nq, int dty
                           D + q0 * k, I + q0 * k, S64 ? S64 + q0 * k : nullptr, st);
         if (rc) return rc;
     }
+    HIPCHK(hipEventRecord(pl.last, st));
     if (idx->timing) HIPCHK(hipEventRecord(idx->ev[3], st));
     return TRX_OK;
 }

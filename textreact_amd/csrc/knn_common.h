@@ -115,6 +115,7 @@ struct ScanParams {
     int tiles_per_split;
     int nsplits;
     int nqtiles;             // q_pad / TILE_N
+    int nq_valid;            // queries that exist: the zero pad rows of the last query tile are never listed (see knn_scan.hip)
     int kprime;              // 16 or 32: rows behind a query's threshold (8 per tracked maximum of a lane)
     int cap;                 // usable slots of a list, 63 or 127 (counter = 7 bits of a packed register)
     int cap_alloc;           // slots allocated per list (cap + 1)

@@ -756,11 +756,17 @@ __global__ __launch_bounds__(XW ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
     // workgroups are dealt round-robin to the 8 XCDs; renumber so that the query blocks of one
     // (batch, head) -- which re-read the same K/V -- are neighbours on ONE XCD and share its L2
     int bid = blockIdx.x;
+    int qsw = 0;
     {
         const int nwg = gridDim.x, per = nwg >> 3, main_ = per << 3;
+        // Two query blocks per (batch, head), the second one short (Lq = 160): its workgroup does a quarter of the first one's
+        // arithmetic.  An XCD hands its workgroups to its 32 CUs in turn, so numbered (full, short, full, short, ...) the three
+        // workgroups a CU holds -- j, j + 32, j + 64 of the XCD's list -- would be of ONE kind, half the CUs loaded four times
+        // as much as the others; the kinds swap every 32 places instead, and every CU gets a mix.
+        if (!XW && nqb == 2 && !(per & 1) && bid < main_) qsw = (bid >> 3) >> 5;
         if (bid < main_) bid = (bid & 7) * per + (bid >> 3);
     }
-    const int qb = bid % nqb, h = (bid / nqb) % H, b = bid / (nqb * H);
+    const int qb = (bid + qsw) % nqb, h = (bid / nqb) % H, b = bid / (nqb * H);
     // A query block with one or two 32-query units (the last block of Lq = 160: 128 + 32; every block of a decoder with 7
     // positions) would leave three or two of its four waves computing on padding.  Those waves take KEYS instead: the block's
     // key tiles are dealt round-robin over KS = 4 (2) waves per query unit -- every wave still stages every tile and meets
