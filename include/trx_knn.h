@@ -121,8 +121,8 @@ int trx_merge_topk_device(int metric, int nlists, int64_t nq, int k, const doubl
 /* Counters of the most recent search on this index (all zero before the first one). */
 typedef struct trx_search_stats {
     int64_t nq;            /* queries in the call */
-    int64_t n_uncertified; /* queries whose candidate set could not be certified exact and were
-                              re-done by the exact fp64 scan (0 on benign inputs) */
+    int64_t n_uncertified; /* queries whose candidate lists could not be certified exact and were
+                              re-done by the exact fp64 scan of the whole index (0 on benign inputs) */
     int32_t k_split;       /* K of the bf16 MFMA contraction: d (inputs exact in bf16) or 3d */
     int32_t n_splits;      /* corpus column-splits per query tile in the scan kernel */
     int32_t exact_class;   /* 1 = all partial sums exactly representable (integer inputs) */
@@ -132,7 +132,8 @@ typedef struct trx_search_stats {
     int32_t late_fallback; /* 1 = trx_index_search_finish re-did queries AFTER the enqueued work (more
                               certificate failures than the inline re-scan covers): anything the caller
                               computed from D / I / S between begin and finish must be redone */
-    int32_t reserved_;
+    int32_t n_rescored;    /* queries the select kernel flagged and the wide re-score looked at (all their listed rows
+                              re-scored exactly); n_uncertified of them went on to the exact scan */
 } trx_search_stats;
 
 int trx_index_last_stats(const trx_index* idx, trx_search_stats* out);

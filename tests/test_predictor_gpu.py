@@ -87,6 +87,34 @@ def test_attention_forward(B, H, Lq, Lk, mask, causal, dtype, tol):
     assert float((out.float() - ref).abs().max()) <= tol
 
 
+@pytest.mark.parametrize("Lq,Lk,masked", [
+    (20, 77, (64, 77)),        # one 32-query unit, its keys split over four waves: the wave that starts at tile 1 sees masked keys only
+    (40, 200, (64, 192)),      # two units, keys split two ways: both waves of a unit meet an all-masked tile first
+    (128, 200, (0, 70)),       # no split: left padding, the FIRST tile of every wave is all masked (latent since round 1)
+    (7, 512, (128, 512)),      # RCR cross-attention over a short encoder input
+])
+def test_attention_tiles_whose_keys_are_all_masked(Lq, Lk, masked):
+    """a key tile in which every key is masked (finfo.min, as Hugging Face builds its masks) opens the softmax of a wave with a
+    huge negative reference; the exponent's argument must stay within rounding of it -- with the -1e30 floor of rounds 1-3 it
+    came out as +-1e21 and the tile produced inf / NaN (found when the key-split waves of round 4 began at later tiles)"""
+    bf = torch.bfloat16
+    q, k, v = _rand(2, Lq, 3, 64, dtype=bf, seed=1), _rand(2, Lk, 3, 64, dtype=bf, seed=2), _rand(2, Lk, 3, 64, dtype=bf, seed=3)
+    dout = _rand(2, Lq, 3 * 64, dtype=bf, seed=4)
+    m = torch.zeros(2, Lk, device="cuda")
+    m[0, masked[0]:masked[1]] = torch.finfo(torch.float32).min
+    with nn_ref.implementation("hip"):
+        qs, ks, vs = (t.clone().requires_grad_(True) for t in (q, k, v))
+        out = ops.attention(qs, ks, vs, mask=m)
+        out.backward(dout)
+    qr, kr, vr = (t.float().requires_grad_(True) for t in (q, k, v))
+    ref = nn_ref.attention(qr, kr, vr, mask=m)
+    ref.backward(dout.float())
+    assert torch.isfinite(out).all() and float((out.float() - ref).abs().max()) <= 2e-2
+    for name, a, c in (("dq", qs.grad, qr.grad), ("dk", ks.grad, kr.grad), ("dv", vs.grad, vr.grad)):
+        assert torch.isfinite(a).all(), name
+        assert float((a.float() - c).abs().max()) <= 2e-2 * max(1.0, float(c.abs().max())), name
+
+
 def test_model_logits_match_reference_golden_on_gpu():
     z = np.load(G)
     enc, dec = json.loads(str(z["enc_cfg"])), json.loads(str(z["dec_cfg"]))

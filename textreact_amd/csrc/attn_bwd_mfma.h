@@ -140,6 +140,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     const float sl2 = scale * 1.44269504088896340736f;
     const float inv_scale = 1.0f / scale;
+    const float mask_floor = -268435456.0f / sl2;     // the forward kernel's floor of a masked score (nn_ops.hip: TRX_MASK_INIT)
     const float nlsl2 = negl[((int64_t)b * H + h) * Lq + qc] * sl2;   // -lse * log2 e
     const float nd = negd[((int64_t)b * H + h) * Lq + qc];            // -delta
     f32x16 a0, a1;   // dQ^T: d blocks 0..31 / 32..63 x this wave's 32 queries
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int i_ = 0; i_ < 4; ++i_) mv_[i_] = mkey[min(kc * 64 + 4 * tid_ + i_, Lk - 1)];
 #pragma unroll
-        for (int i_ = 0; i_ < 4; ++i_) ldsM[4 * tid_ + i_] = fmaxf(mv_[i_] * inv_scale, -1e30f);
+        for (int i_ = 0; i_ < 4; ++i_) ldsM[4 * tid_ + i_] = fmaxf(mv_[i_] * inv_scale, mask_floor);
     }
     const int kend = min(nkb, kc + 16);
     for (int kb = kc; kb < kend; ++kb) {
@@ -235,8 +236,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
                 const int kr_ = (t & 3) + 8 * (t >> 2) + 4 * hh;
-                s0[t] = fmaxf(mrow[min(key0 + kr_, Lk - 1)] * inv_scale, -1e30f);
-                s1[t] = fmaxf(mrow[min(key0 + 32 + kr_, Lk - 1)] * inv_scale, -1e30f);
+                s0[t] = fmaxf(mrow[min(key0 + kr_, Lk - 1)] * inv_scale, mask_floor);
+                s1[t] = fmaxf(mrow[min(key0 + 32 + kr_, Lk - 1)] * inv_scale, mask_floor);
             }
         } else {
 #pragma unroll
@@ -408,7 +409,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     constexpr float L2E = 1.44269504088896340736f;
     const float sl2 = scale * L2E;
-    const float mk2 = (MM == TRX_NN_MASK_KEY) ? fmaxf(mask[(int64_t)b * Lk + kc], -1e30f) * L2E : 0.f;
+    const float mk2 = (MM == TRX_NN_MASK_KEY) ? fmaxf(mask[(int64_t)b * Lk + kc] * L2E, -268435456.0f) : 0.f;     // the forward's floor, in the exponent's units
     f32x16 ak0, ak1, av0, av1;   // dK^T, dV^T: d blocks x this wave's 32 keys
 #pragma unroll
     for (int t = 0; t < 16; ++t) { ak0[t] = 0.f; ak1[t] = 0.f; av0[t] = 0.f; av1[t] = 0.f; }
@@ -548,7 +549,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     const int qr_ = q0 + hb * 32 + (t & 3) + 8 * (t >> 2) + 4 * hh;
                     float val = __builtin_fmaf(s[t], sl2, mk2);
                     if (MM == TRX_NN_MASK_FULL)   // wave-uniform base + a 32-bit offset: row (uniform) * Lk + this lane's key
-                        val = __builtin_fmaf(fmaxf(mfull[(unsigned)(min(qr_, Lq - 1) * Lk) + (unsigned)kc], -1e30f), L2E, val);
+                        val += fmaxf(mfull[(unsigned)(min(qr_, Lq - 1) * Lk) + (unsigned)kc] * L2E, -268435456.0f);
                     float pr = __builtin_amdgcn_exp2f(fminf(val, 0.f));   // p <= 1
                     if (VIS) pr = (qr_ >= Lq || qr_ < qmin) ? 0.f : pr;
                     if (DROP) {

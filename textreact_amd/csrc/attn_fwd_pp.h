@@ -149,7 +149,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     if (keymask && tid < 256) {     // (asm: a C++ store to the DMA's array would make hipcc drain vmcnt first)
 #pragma unroll
-        for (int i_ = 0; i_ < 4; ++i_) mv_[i_] = fmaxf(mv_[i_] * inv_scale, -1e30f);
+        for (int i_ = 0; i_ < 4; ++i_) mv_[i_] = fmaxf(mv_[i_] * inv_scale, -268435456.0f / (scale * 1.44269504088896340736f));
         asm volatile("ds_write_b128 %0, %1" :: "v"(ldsMbase + (unsigned)(16 * tid)), "v"(*reinterpret_cast<const f32x4_pp*>(mv_)) : "memory");
     }
     asm volatile("" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]));

@@ -310,6 +310,7 @@ int trx_index_add(trx_index* idx, const void* x, int64_t n, int dtype) {
 // decides how many of these slots do anything); more than that -- near-duplicate clusters, adversarial data -- are
 // completed by trx_index_search_finish once the count has been read back
 constexpr int INLINE_FALLBACK = 4;
+constexpr size_t FLAG_WORDS = 4 + 2 * 65536;      // per batch: two counters (+ 2 spare), two lists of query numbers
 
 static int search_batch(trx_index* idx, const void* q, const float* qnorm2, int64_t nq, int is_bf, int q_split, int batch_no,
                         float eps_rel, int k, float* D, int64_t* I, double* S64, hipStream_t st) {
@@ -351,8 +352,10 @@ static int search_batch(trx_index* idx, const void* q, const float* qnorm2, int6
     }
     // this batch's slice of the flag workspace (reserved for all batches by the caller: a DevBuf may not grow while
     // earlier batches of the same call still point into it)
-    int* nflag = (int*)idx->w_flag.p + (size_t)batch_no * (4 + 65536);
+    // [0] queries the select kernel could not certify, [1] those the wide re-score could not either (-> exact scan)
+    int* nflag = (int*)idx->w_flag.p + (size_t)batch_no * FLAG_WORDS;
     int* flagged = nflag + 4;
+    int* flagged2 = flagged + 65536;
     HIPCHK(hipMemsetAsync(nflag, 0, 4 * sizeof(int), st));
 
     ScanParams sp{};
@@ -408,12 +411,15 @@ static int search_batch(trx_index* idx, const void* q, const float* qnorm2, int6
     se.eps_rel = eps_rel; se.qnorm2 = qnorm2; se.ymax_norm2 = idx->maxnorm2;
     se.D = D; se.I = I; se.S64 = S64; se.flagged = flagged; se.nflagged = nflag;
     HIPCHK(launch_select(se, st));
+    // second tier: flagged queries are re-scored over ALL their listed rows (the lists are still in the shared workspace
+    // here); what that cannot certify either goes on to the exact scan
+    HIPCHK(launch_wide_rescore(se, flagged, nflag, flagged2, nflag + 1, st));
 
     // certificate failures -> exact scan of those queries.  The count stays on the device: the first INLINE_FALLBACK of
     // them are re-done right here, stream-ordered (slots beyond the count leave at once: ~10 us when nothing failed, the
     // common case); trx_index_search_finish reads the count and completes what is left.  No host synchronisation.
     if (sp.debug == 0)      // (timing-only debug modes of the scan kernel produce wrong lists: no fall-back then)
-        HIPCHK(launch_exact_scan(idx->metric, se.corpus_is_bf16, is_bf, flagged, INLINE_FALLBACK, nflag, idx->n,
+        HIPCHK(launch_exact_scan(idx->metric, se.corpus_is_bf16, is_bf, flagged2, INLINE_FALLBACK, nflag + 1, idx->n,
                                  se.corpus_orig, se.ld_c, q, d, d, k, (double*)idx->w_exact.p, D, I, S64, st));
     if (idx->timing) {      // timing mode is synchronous by contract (trx_index_set_timing)
         HIPCHK(hipStreamSynchronize(st));
@@ -425,7 +431,7 @@ static int search_batch(trx_index* idx, const void* q, const float* qnorm2, int6
     idx->stats.n_splits = nsplits;
     idx->pend.no_fallback = sp.debug != 0;
     idx->pend.corpus_orig = se.corpus_orig; idx->pend.ld_c = se.ld_c; idx->pend.corpus_is_bf16 = se.corpus_is_bf16;
-    idx->pend.batches.push_back({nflag, flagged, q, D, I, S64});
+    idx->pend.batches.push_back({nflag, flagged2, q, D, I, S64});
     return TRX_OK;
 }
 
@@ -437,9 +443,11 @@ static int finish_impl(trx_index* idx) {
     pd.active = false;
     hipStream_t st = pd.st;
     int cls = 0;
-    std::vector<int> nf(pd.batches.size(), 0);
-    for (size_t b = 0; b < pd.batches.size(); ++b)
-        HIPCHK(hipMemcpyAsync(&nf[b], pd.batches[b].nflag, sizeof(int), hipMemcpyDeviceToHost, st));
+    std::vector<int> nf(pd.batches.size(), 0), nf1(pd.batches.size(), 0);
+    for (size_t b = 0; b < pd.batches.size(); ++b) {      // [0]: flagged by the select kernel, [1]: still uncertified after the wide re-score
+        HIPCHK(hipMemcpyAsync(&nf1[b], pd.batches[b].nflag, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(&nf[b], pd.batches[b].nflag + 1, sizeof(int), hipMemcpyDeviceToHost, st));
+    }
     if (idx->w_cls.p && !pd.batches.empty()) HIPCHK(hipMemcpyAsync(&cls, idx->w_cls.p, sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (!pd.batches.empty()) idx->stats.exact_class = cls;
@@ -447,6 +455,7 @@ static int finish_impl(trx_index* idx) {
     bool late = false;
     for (size_t b = 0; b < pd.batches.size(); ++b) {
         idx->stats.n_uncertified += nf[b];
+        idx->stats.n_rescored += nf1[b];
         if (pd.no_fallback || nf[b] <= INLINE_FALLBACK) continue;
         late = true;
         int rc = idx->w_exact.reserve((size_t)std::min<int64_t>(per, nf[b]) * idx->n * sizeof(double)); if (rc) return rc;
@@ -532,7 +541,7 @@ static int search_device_impl(trx_index* idx, const void* q, int64_t nq, int dty
     // behind whatever search -- of this or another index, on this or another stream -- used the shared workspaces last
     if (pl.last) HIPCHK(hipStreamWaitEvent(st, pl.last, 0));
     else HIPCHK(hipEventCreateWithFlags(&pl.last, hipEventDisableTiming));
-    if ((rc = idx->w_flag.reserve((size_t)nbatches * (4 + QB) * sizeof(int)))) return rc;
+    if ((rc = idx->w_flag.reserve((size_t)nbatches * FLAG_WORDS * sizeof(int)))) return rc;
     // the inline fall-back's score rows (INLINE_FALLBACK x n doubles)
     if ((rc = idx->w_exact.reserve((size_t)INLINE_FALLBACK * idx->n * sizeof(double)))) return rc;
     for (int64_t q0 = 0; q0 < nq; q0 += QB) {

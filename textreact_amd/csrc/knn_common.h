@@ -161,5 +161,6 @@ struct SelectParams {
 // launchers implemented in the .hip files
 hipError_t launch_scan(const ScanParams& p, int metric, hipStream_t st);
 hipError_t launch_select(const SelectParams& p, hipStream_t st);
+hipError_t launch_wide_rescore(const SelectParams& p, const int* flagged, const int* nflagged, int* flagged2, int* nflagged2, hipStream_t st);
 
 }  // namespace trx

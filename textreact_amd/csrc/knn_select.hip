@@ -11,6 +11,8 @@
 // retrieve/retrieve_faiss.py:71, and gives the (D, I) it returns.
 #include "knn_common.h"
 #include <float.h>
+#include <cstdlib>
+#include <cstdint>
 
 namespace trx {
 
@@ -370,6 +372,152 @@ hipError_t launch_select(const SelectParams& p, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------
+// wide re-score: the second tier, between the select kernel and the exact scan.  The select kernel re-scores the best KEEP =
+// 32 candidates of a query and flags the query when it cannot prove the answer from those: more than KEEP - k rows lie within
+// the rounding bound of the k-th score (near-duplicate passages; the nearly collinear [CLS] embeddings of an untrained
+// encoder), or fewer than k ranked.  The candidate lists still hold EVERY row whose approximate key exceeds T, the largest
+// bound of the query's lists; so one workgroup per flagged query re-scores all listed rows that reach T -- tens to a few
+// thousand rows instead of the whole corpus -- ranks them by the canonical fp64 score, and the answer is proven exact when
+// the k-th exact score beats T + eps (no unlisted row can reach it).  Only queries that fail THAT go on to the exact scan
+// (flagged2 / nflagged2).  One workgroup of 256 threads per query, a thread per candidate row.
+constexpr int WIDE_MAX = 4096;     // listed rows of a query that reach T: at most nlists x 127 = 32 x 127 = 4064 at 4 splits
+
+template <bool L2, bool CBF, bool QBF>
+__global__ __launch_bounds__(256) void wide_rescore_kernel(SelectParams p, const int* flagged, const int* nflagged, int* flagged2, int* nflagged2) {
+    __shared__ double w_sc[WIDE_MAX];
+    __shared__ u32 w_id[WIDE_MAX];
+    __shared__ u64 red_key[256];
+    __shared__ u32 red_id[256];
+    __shared__ u64 w_T;
+    __shared__ int w_cnt;
+    __shared__ double pick_s[32];
+    __shared__ u32 pick_i[32];
+    const int tid = threadIdx.x;
+    const int nf = *nflagged;
+    const int exact_class = *p.exact_class;
+    constexpr int QE = QBF ? 2 : 4, CE = CBF ? 2 : 4;
+    for (int f = blockIdx.x; f < nf; f += gridDim.x) {
+        const int q = flagged[f];
+        __syncthreads();
+        // ---- T = the largest bound of the query's lists ----
+        u64 t = 0ull;
+        for (int l = tid; l < p.nlists; l += 256) { const u64 b = p.cand_thr[(int64_t)q * p.nlists + l]; t = b > t ? b : t; }
+        red_key[tid] = t;
+        if (tid == 0) w_cnt = 0;
+        __syncthreads();
+        for (int w = 128; w > 0; w >>= 1) { if (tid < w && red_key[tid + w] > red_key[tid]) red_key[tid] = red_key[tid + w]; __syncthreads(); }
+        if (tid == 0) w_T = red_key[0];
+        __syncthreads();
+        const u64 T = w_T;
+        // ---- every listed row that reaches T (a row listed twice after a compaction appears twice: the ranking below skips it) ----
+        bool overflow = false;
+        for (int l = 0; l < p.nlists; ++l) {
+            const int64_t o = (int64_t)q * p.nlists + l;
+            const int cnt = (int)p.cand_cnt[o];
+            for (int i = tid; i < cnt; i += 256) {
+                const u64 e = p.cand[o * p.cap_alloc + i];
+                if (e != 0ull && e >= T && (int64_t)comp_id(e) < p.n) {
+                    const int pos = atomicAdd(&w_cnt, 1);
+                    if (pos < WIDE_MAX) w_id[pos] = comp_id(e);
+                }
+            }
+        }
+        __syncthreads();
+        int C = w_cnt;
+        if (C > WIDE_MAX) { overflow = true; C = WIDE_MAX; }
+        // ---- canonical scores, a thread per row ----
+        const char* qrow = reinterpret_cast<const char*>(p.query_orig) + (int64_t)q * p.ld_q * QE;
+        for (int i = tid; i < C; i += 256) {
+            const char* crow = reinterpret_cast<const char*>(p.corpus_orig) + (int64_t)w_id[i] * p.ld_c * CE;
+            w_sc[i] = canonical_score<L2, CBF, QBF>(qrow, crow, p.d);
+        }
+        __syncthreads();
+        // ---- the k best by (score, id): k rounds of "next after the previous pick" ----
+        u64 prev_key = ~0ull; u32 prev_id = 0u; bool first = true;
+        int got = 0;
+        for (int r = 0; r < p.k; ++r) {
+            u64 bk = 0ull; u32 bi = 0xffffffffu;
+            for (int i = tid; i < C; i += 256) {
+                const double sv = w_sc[i];
+                if (!(sv == sv)) continue;
+                const u64 key = orddbl(L2 ? -sv : sv);
+                const u32 id = w_id[i];
+                const bool after = first || key < prev_key || (key == prev_key && id > prev_id);
+                if (!after) continue;
+                if (bi == 0xffffffffu || key > bk || (key == bk && id < bi)) { bk = key; bi = id; }
+            }
+            red_key[tid] = bk; red_id[tid] = bi;
+            __syncthreads();
+            for (int w = 128; w > 0; w >>= 1) {
+                if (tid < w) {
+                    const u64 ok = red_key[tid + w]; const u32 oi = red_id[tid + w];
+                    const u64 mk = red_key[tid]; const u32 mi = red_id[tid];
+                    if (oi != 0xffffffffu && (mi == 0xffffffffu || ok > mk || (ok == mk && oi < mi))) { red_key[tid] = ok; red_id[tid] = oi; }
+                }
+                __syncthreads();
+            }
+            const u64 wk = red_key[0]; const u32 wi = red_id[0];
+            __syncthreads();
+            if (wi == 0xffffffffu) break;
+            if (tid == 0) {
+                const u64 u = (wk >> 63) ? (wk & 0x7fffffffffffffffull) : ~wk;
+                const double dv = __longlong_as_double((long long)u);
+                pick_s[r] = L2 ? -dv : dv; pick_i[r] = wi;
+            }
+            prev_key = wk; prev_id = wi; first = false;
+            ++got;
+        }
+        __syncthreads();
+        // ---- certificate (same bound as the select kernel's) ----
+        bool certified;
+        if (overflow) certified = false;
+        else if (T == 0ull) certified = true;                         // nothing was ever dropped: every row is listed
+        else if (got < p.k) certified = false;
+        else if (exact_class) certified = true;                       // approximate order is the exact order
+        else {
+            const float xn2 = p.qnorm2[q];
+            const float bq = L2 ? (2.0f * sqrtf(xn2 * p.ymax_norm2) + p.ymax_norm2) : sqrtf(xn2 * p.ymax_norm2);
+            const double eps = (double)p.eps_rel * (double)bq * 1.0001 + 1e-30;
+            const double bound = (double)comp_key(T) + eps;
+            double xx = 0.0;
+            if (L2) for (int i = 0; i < p.d; ++i) { const double v = load_as_double<QBF>(qrow, i); xx = __builtin_fma(v, v, xx); }
+            const double s_k = pick_s[p.k - 1];
+            certified = L2 ? (xx - s_k) > bound : s_k > bound;
+        }
+        if (certified) {
+            for (int r = tid; r < p.k; r += 256) {
+                const bool ok = r < got;
+                const int64_t o = (int64_t)q * p.k + r;
+                p.D[o] = ok ? (float)pick_s[r] : (L2 ? FLT_MAX : -FLT_MAX);
+                p.I[o] = ok ? (int64_t)pick_i[r] : (int64_t)-1;
+                if (p.S64) p.S64[o] = ok ? pick_s[r] : (L2 ? (double)FLT_MAX : -(double)FLT_MAX);
+            }
+        } else if (tid == 0) {
+            flagged2[atomicAdd(nflagged2, 1)] = q;
+        }
+    }
+}
+
+hipError_t launch_wide_rescore(const SelectParams& p, const int* flagged, const int* nflagged, int* flagged2, int* nflagged2, hipStream_t st) {
+    if (p.nq <= 0) return hipSuccess;
+    dim3 grid((unsigned)(p.nq < 2048 ? p.nq : 2048)), block(256);      // blocks beyond the (device-side) count leave at once
+    const int sel = (p.metric ? 4 : 0) | (p.corpus_is_bf16 ? 2 : 0) | (p.query_is_bf16 ? 1 : 0);
+#define TRX_WR(a, b, c) hipLaunchKernelGGL((wide_rescore_kernel<a, b, c>), grid, block, 0, st, p, flagged, nflagged, flagged2, nflagged2)
+    switch (sel) {
+        case 0: TRX_WR(false, false, false); break;
+        case 1: TRX_WR(false, false, true); break;
+        case 2: TRX_WR(false, true, false); break;
+        case 3: TRX_WR(false, true, true); break;
+        case 4: TRX_WR(true, false, false); break;
+        case 5: TRX_WR(true, false, true); break;
+        case 6: TRX_WR(true, true, false); break;
+        default: TRX_WR(true, true, true); break;
+    }
+#undef TRX_WR
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
 // exact scan (fall-back and k > TRX_FAST_MAX_K): canonical scores of `nf` listed queries against
 // every corpus row, then k rounds of "next best after the previous pick" per query.
 // nf_dev (optional): the number of listed queries lives on the device (the certificate failures of a search that has
@@ -387,6 +535,75 @@ __global__ __launch_bounds__(256) void exact_scores_kernel(const int* qlist, int
     const char* qrow = reinterpret_cast<const char*>(queries) + (int64_t)q * ld_q * (QBF ? 2 : 4);
     const char* crow = reinterpret_cast<const char*>(corpus) + j * ld_c * (CBF ? 2 : 4);
     out[(int64_t)f * n + j] = canonical_score<L2, CBF, QBF>(qrow, crow, d);
+}
+
+// The same scores, tiled: a workgroup takes 256 corpus rows (a thread per row) and QT listed queries.  Row slices of 128
+// bytes are brought into LDS by all threads with coalesced 16-byte loads (8 threads per row slice; one thread streaming its
+// own row from global memory touches 64 cache lines per wave and load), each thread converts ITS slice to fp64 once and
+// runs the QT fma chains over it, the queries' slices coming from LDS as fp64 broadcasts.  A corpus row is read once per QT
+// queries instead of once per query, and the conversions are shared: 0.2 ms per query and 204,800 rows before, ~10 us now.
+// The summation order of every (query, row) pair is unchanged: k = 0 .. d-1, one fma per component.
+template <bool L2, bool CBF, bool QBF, int QT>
+__global__ __launch_bounds__(256) void exact_scores_tiled_kernel(const int* qlist, int nf, const int* nf_dev, int64_t n,
+                                                                 const void* corpus, int64_t ld_c,
+                                                                 const void* queries, int64_t ld_q, int d,
+                                                                 double* out /* [nf][n] */) {
+    constexpr int CE = CBF ? 2 : 4, SLICE = 128 / CE, ROWB = 128 + 16;
+    __shared__ __attribute__((aligned(16))) char rows_lds[256 * ROWB];
+    __shared__ __attribute__((aligned(16))) double xq[QT][SLICE];
+    const int tid = threadIdx.x;
+    const int f0 = blockIdx.y * QT;
+    const int nfl = nf_dev ? min(nf, *nf_dev) : nf;
+    if (f0 >= nfl) return;
+    const int64_t row0 = (int64_t)blockIdx.x * 256;
+    int qn[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) { const int f = min(f0 + t, nfl - 1); qn[t] = qlist ? qlist[f] : f; }
+    double acc[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) acc[t] = 0.0;
+    const int lrow = tid >> 3, part = tid & 7;          // loader role: 32 rows per pass, 8 passes
+    for (int k0 = 0; k0 < d; k0 += SLICE) {
+        __syncthreads();
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) {
+            const int r = ps * 32 + lrow;
+            const int64_t gr = row0 + r < n ? row0 + r : n - 1;
+            const uint4 u = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(corpus) + (gr * ld_c + k0) * CE + part * 16);
+            *reinterpret_cast<uint4*>(rows_lds + r * ROWB + part * 16) = u;
+        }
+        for (int i = tid; i < QT * SLICE; i += 256) {
+            const int t = i / SLICE, c = i - t * SLICE;
+            xq[t][c] = load_as_double<QBF>(reinterpret_cast<const char*>(queries) + (int64_t)qn[t] * ld_q * (QBF ? 2 : 4), k0 + c);
+        }
+        __syncthreads();
+        const char* rp = rows_lds + tid * ROWB;
+#pragma unroll 2
+        for (int c16 = 0; c16 < 8; ++c16) {
+            const uint4 u = *reinterpret_cast<const uint4*>(rp + c16 * 16);
+            const u32 w[4] = {u.x, u.y, u.z, u.w};
+            constexpr int NE = 16 / CE;
+            double y[NE];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (CBF) { y[2 * i] = (double)__uint_as_float(w[i] << 16); y[2 * i + 1] = (double)__uint_as_float(w[i] & 0xffff0000u); }
+                else y[i] = (double)__uint_as_float(w[i]);
+            }
+#pragma unroll
+            for (int t = 0; t < QT; ++t)
+#pragma unroll
+                for (int i = 0; i < NE; ++i) {
+                    const double x = xq[t][c16 * NE + i];
+                    if (L2) { const double dd = x - y[i]; acc[t] = __builtin_fma(dd, dd, acc[t]); }
+                    else acc[t] = __builtin_fma(x, y[i], acc[t]);
+                }
+        }
+    }
+    if (row0 + tid < n) {
+#pragma unroll
+        for (int t = 0; t < QT; ++t)
+            if (f0 + t < nfl) out[(int64_t)(f0 + t) * n + row0 + tid] = acc[t];
+    }
 }
 
 template <bool L2>
@@ -446,9 +663,16 @@ hipError_t launch_exact_scan(int metric, int cbf, int qbf, const int* qlist, int
                              hipStream_t st) {
     if (nf <= 0) return hipSuccess;
     if (n > 0) {
-        dim3 grid((unsigned)((n + 255) / 256), nf), block(256);
+        const int ce = cbf ? 2 : 4;
+        // the tiled kernel needs whole 128-byte slices and 16-byte aligned rows (every index built by knn_api.hip has them
+        // unless d is not a multiple of 64 / 32); the generic one takes anything
+        const bool tiled = (d % (128 / ce) == 0) && ((ld_c * ce) % 16 == 0) && ((uintptr_t)corpus % 16 == 0) && !getenv("TRX_EXACT_GENERIC");
+        constexpr int QT = 8;
+        dim3 grid((unsigned)((n + 255) / 256), tiled ? (nf + QT - 1) / QT : nf), block(256);
         const int sel = (metric ? 4 : 0) | (cbf ? 2 : 0) | (qbf ? 1 : 0);
-#define TRX_ES(a, b, c) hipLaunchKernelGGL((exact_scores_kernel<a, b, c>), grid, block, 0, st, qlist, nf, nf_dev, n, corpus, ld_c, queries, ld_q, d, sc)
+#define TRX_ES(a, b, c)                                                                                                           \
+        if (tiled) hipLaunchKernelGGL((exact_scores_tiled_kernel<a, b, c, QT>), grid, block, 0, st, qlist, nf, nf_dev, n, corpus, ld_c, queries, ld_q, d, sc); \
+        else hipLaunchKernelGGL((exact_scores_kernel<a, b, c>), grid, block, 0, st, qlist, nf, nf_dev, n, corpus, ld_c, queries, ld_q, d, sc)
         switch (sel) {
             case 0: TRX_ES(false, false, false); break;
             case 1: TRX_ES(false, false, true); break;

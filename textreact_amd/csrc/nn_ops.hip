@@ -792,7 +792,14 @@ __global__ __launch_bounds__(XW ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
     // additive mask enters as the accumulators' starting value, in raw-score units (mask / scale); the
     // clamp keeps finfo.min-style masks finite, so fully masked rows come out uniform like torch's
     const float inv_scale = 1.0f / scale;
-#define TRX_MASK_INIT(X) fmaxf((X) * inv_scale, -1e30f)
+    // The floor of a masked score, in raw-score units: 2^28 in the exponent's units (score * scale * log2 e).  Large enough that
+    // a masked key weighs exp2(-2^28) = 0 beside any other and that the q.k term is absorbed (a fully masked row comes out
+    // uniform, as torch's finfo.min does), small enough that the exponent's argument fma(s, scale log2e, -reference) of a tile
+    // whose keys are ALL masked stays within the rounding of 2^28 (+-16: probabilities up to 2^16, finite).  With the -1e30 of
+    // rounds 1-3 that residual was ~1e21 and such a tile -- the first tile of a left-padded row; since round 4 also any tile
+    // that opens a key-split wave -- produced inf and NaN.
+    const float mask_floor = -268435456.0f / sl2;
+#define TRX_MASK_INIT(X) fmaxf((X) * inv_scale, mask_floor)
     float m = -__builtin_inff(), lsum = 0.f;
     const int off = Lk - Lq;
     int nkb = (Lk + 63) / 64;

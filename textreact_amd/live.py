@@ -177,7 +177,9 @@ def refresh_neighbors(q_encoder, p_encoder, corpus, query_ids, query_len, k, ran
         timings.update(r.ms)
         stats = getattr(r.index.local, "last_stats", None)
         if stats is not None:      # queries the fast path could not certify (re-done by the exact fp64 scan, this rank's shard)
-            timings["uncertified_queries"] = stats()["n_uncertified"]
+            st = stats()
+            timings["uncertified_queries"] = st["n_uncertified"]
+            timings["rescored_queries"] = st.get("n_rescored", 0)
     return (nn, emb_q, r.emb_p) if return_embeddings else nn
 
 
