@@ -160,15 +160,31 @@ def test_k_range(k):
     _check(L2, gaussian(40, 48, 3), gaussian(2500, 48, 4), k)
 
 
-def test_near_duplicate_cluster_forces_exact_scan():
-    # 200 rows within ~1e-7 of each other: the certificate must fail and the exact scan take over
+def test_near_duplicate_cluster_is_resolved_by_the_wide_rescore():
+    # 200 rows within ~1e-7 of each other, far above everything else: the 32 candidates the select kernel re-scores cannot
+    # prove the top 10 (the 33rd row ties with them), so the query is flagged -- and the second tier (round 4) re-scores ALL
+    # rows its lists hold above their bound, the whole cluster, and certifies the answer without scanning the index
     rng = np.random.default_rng(6)
     y = gaussian(4000, 64, 1)
     c = gaussian(1, 64, 2)
     y[1000:1200] = c * (1.0 + 1e-7 * rng.standard_normal((200, 1)).astype(np.float32))
     x = np.repeat(c, 8, axis=0) + 1e-3 * gaussian(8, 64, 3)
     st = _check(IP, x, y, 10)
-    assert st["n_uncertified"] > 0
+    assert st["n_rescored"] == 8 and st["n_uncertified"] == 0
+    st = _check(L2, x, y, 10)
+    assert st["n_rescored"] == 8 and st["n_uncertified"] == 0
+
+
+def test_a_crowd_around_the_kth_place_still_takes_the_exact_scan():
+    # the same cluster with the k-th place INSIDE a crowd that reaches down to the lists' bound: scores fall off smoothly
+    # (steps far below the rounding bound) over 3000 rows, so whatever the bound is, rows just under it tie with the k-th
+    rng = np.random.default_rng(7)
+    y = gaussian(4000, 64, 1)
+    c = gaussian(1, 64, 2)
+    y[500:3500] = c * (1.0 - 1e-7 * np.arange(3000, dtype=np.float32)[:, None])
+    x = np.repeat(c, 4, axis=0)
+    st = _check(IP, x, y, 10)
+    assert st["n_rescored"] == 4 and st["n_uncertified"] == 4
 
 
 def test_dimension_mismatch_raises():
@@ -453,18 +469,17 @@ def _late_worker(rank, world, port, ret):
 
 
 def _near_duplicate_problem():
-    """clusters of 40 near-duplicates (differences far below the certificate's slack, above fp64 resolution) in the first
-    shard, and 12 queries that each point at one cluster: more than KEEP - k rows tie within the slack, so those queries
-    fail the certificate -- more of them than the 4 inline re-scan slots of a batch (csrc/knn_api.hip INLINE_FALLBACK)"""
+    """8 crowds of 300 rows in the first shard, each falling off from its query in steps far below the certificate's slack
+    (score steps ~6e-5, slack ~4e-2), so that the bound of the query's candidate lists lies INSIDE the crowd: neither the 32
+    re-scored candidates nor the wide re-score of everything listed can prove the top 10, and those 8 queries take the exact
+    scan -- more of them than the 4 inline slots of a batch (csrc/knn_api.hip INLINE_FALLBACK)"""
     rng = np.random.default_rng(21)
     y = rng.standard_normal((6000, 64)).astype(np.float32)
     x = rng.standard_normal((40, 64)).astype(np.float32)
-    for c in range(12):
+    fall = (1.0 - 1e-7 * np.arange(300, dtype=np.float32))[:, None]
+    for c in range(8):
         base = 3.0 * rng.standard_normal(64).astype(np.float32)
-        for j in range(40):
-            row = base.copy()
-            row[j % 64] += np.float32(1e-6) * (j + 1)
-            y[100 * c + j] = row
+        y[300 * c:300 * (c + 1)] = base[None] * fall
         x[c] = base
     return y, x
 
