@@ -54,6 +54,10 @@ for kname, fam, workkey, mult in KERN:
         if fam == "attention":       # algorithmic FLOPs: 4 B H Lq Lk 64 forward; dq pass 6/4, dk/dv pass 8/4 of it (GEMM units)
             rec["achieved_TFLOPs"] = work / (us * 1e-6) / 1e12
             rec["frac_of_2500_TFLOPs"] = rec["achieved_TFLOPs"] / 2500.0
+            bkey = {"attention_fwd_mfma_kernel": "bytes_fwd", "attention_bwd_dq_mfma_kernel": "bytes_dq", "attention_bwd_dkv_mfma_kernel": "bytes_dkv"}[kname]
+            if bkey in sh:       # the 7-position decoder shapes are byte-bound: K and V of 512 keys against 7 queries
+                rec["algorithmic_bytes"] = sh[bkey]
+                rec["frac_of_8000_GBs"] = sh[bkey] / (us * 1e-6) / 1e9 / 8000.0
         else:
             rec["algorithmic_bytes"] = work
             rec["achieved_GBs"] = work / (us * 1e-6) / 1e9

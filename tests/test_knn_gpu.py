@@ -469,17 +469,19 @@ def _late_worker(rank, world, port, ret):
 
 
 def _near_duplicate_problem():
-    """8 crowds of 300 rows in the first shard, each falling off from its query in steps far below the certificate's slack
-    (score steps ~6e-5, slack ~4e-2), so that the bound of the query's candidate lists lies INSIDE the crowd: neither the 32
-    re-scored candidates nor the wide re-score of everything listed can prove the top 10, and those 8 queries take the exact
-    scan -- more of them than the 4 inline slots of a batch (csrc/knn_api.hip INLINE_FALLBACK)"""
+    """8 crowds of 3000 rows in the first shard, each falling off from its query in steps far below the certificate's slack
+    (score steps ~6e-5, slack ~4e-2) over a range of several slacks, so that the bound of the query's candidate lists lies
+    INSIDE the crowd: neither the 32 re-scored candidates nor the wide re-score of everything listed can prove the top 10,
+    and those 8 queries take the exact scan -- more of them than the 4 inline slots of a batch (csrc/knn_api.hip
+    INLINE_FALLBACK).  (A crowd small enough to sit wholly above the lists' bound is resolved by the wide re-score:
+    test_near_duplicate_cluster_is_resolved_by_the_wide_rescore.)"""
     rng = np.random.default_rng(21)
-    y = rng.standard_normal((6000, 64)).astype(np.float32)
+    y = rng.standard_normal((60000, 64)).astype(np.float32)
     x = rng.standard_normal((40, 64)).astype(np.float32)
-    fall = (1.0 - 1e-7 * np.arange(300, dtype=np.float32))[:, None]
+    fall = (1.0 - 1e-7 * np.arange(3000, dtype=np.float32))[:, None]
     for c in range(8):
         base = 3.0 * rng.standard_normal(64).astype(np.float32)
-        y[300 * c:300 * (c + 1)] = base[None] * fall
+        y[3000 * c:3000 * (c + 1)] = base[None] * fall
         x[c] = base
     return y, x
 

@@ -199,7 +199,7 @@ void trx_index_destroy(trx_index* idx) {
             (void)hipDeviceSynchronize();
             DevBuf* shared[] = {&pl.cand, &pl.cnt, &pl.thr, &pl.gthr, &pl.qg};
             for (DevBuf* b : shared) b->release();
-            if (pl.last) { (void)hipEventDestroy(pl.last); pl.last = nullptr; }
+            // (the ordering event stays for the life of the process: a few bytes, and nothing can hold a stale handle to it)
         }
     }
     for (auto& e : idx->ev) if (e) (void)hipEventDestroy(e);

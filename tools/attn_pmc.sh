@@ -1,10 +1,11 @@
 #!/bin/bash
-# usage: tools/attn_pmc.sh <counters...>
+# usage: tools/attn_pmc.sh <counters...>   one --pmc pass over tools/predictor_shapes.py (the five attention shapes, 10 calls each;
+# the program itself directly behind "--": no env / bash -c hop under rocprofv3), counters of the forward MFMA kernel averaged
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/attn_pmc
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT -- python3 $R/tools/attn_one.py > $OUT/log.txt 2>&1
+rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT -- python3 $R/tools/predictor_shapes.py 10 > $OUT/log.txt 2>&1
 python3 - <<PY
 import csv,glob,collections
 fs=glob.glob("$OUT/*/*_counter_collection.csv")

@@ -29,7 +29,10 @@ for name, lq, lk, causal in ATT:
         o = ops.attention(q, k, v, mask=mask, causal=causal)
         o.backward(torch.ones_like(o))
     torch.cuda.synchronize()
-    plan["attention"].append({"shape": name, "Lq": lq, "Lk": lk, "causal": causal, "flops_fwd": 4.0 * B * H * lq * lk * 64 * (0.5 if causal else 1.0)})
+    plan["attention"].append({"shape": name, "Lq": lq, "Lk": lk, "causal": causal, "flops_fwd": 4.0 * B * H * lq * lk * 64 * (0.5 if causal else 1.0),
+                              # algorithmic bytes (bf16): forward q, out + k, v; dq pass q, dout, dq + k, v; dk/dv pass q, dout + k, v, dk, dv
+                              "bytes_fwd": 2.0 * B * H * 64 * (2 * lq + 2 * lk), "bytes_dq": 2.0 * B * H * 64 * (3 * lq + 2 * lk),
+                              "bytes_dkv": 2.0 * B * H * 64 * (2 * lq + 4 * lk)})
 for name, rows, dt in LN:
     x = torch.randn(rows, 768, device="cuda", generator=g).to(dt).requires_grad_()
     r = torch.randn(rows, 768, device="cuda", generator=g).to(dt).requires_grad_()

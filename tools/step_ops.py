@@ -17,18 +17,18 @@ def step():
     loss.backward(); opt.step(); opt.zero_grad(set_to_none=True); train.mark_parameters_updated(p)
 for _ in range(3): step()
 torch.cuda.synchronize()
-want = sys.argv[1] if len(sys.argv) > 1 else None      # e.g. "fill": where do the aten::fill_ / zero_ calls of a step come from
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=want is not None) as prof:
+want = sys.argv[1] if len(sys.argv) > 1 else None      # e.g. "fill": which aten::fill_ / zero_ calls does a step make (by input shape)
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=want is not None, with_stack=want is not None) as prof:
     step(); torch.cuda.synchronize()
 if want:
     import collections
     where = collections.Counter()
     for e in prof.events():
-        if want in e.name and e.stack:
-            fr = [f for f in e.stack if "textreact_amd" in f or "torch/optim" in f or "torch/autograd" in f][:3]
-            where[(e.name, " <- ".join(f.split("/")[-1] for f in fr) or e.stack[0].split("/")[-1])] += 1
-    for (name, st), c in where.most_common(25):
-        print("%5d  %-18s %s" % (c, name, st))
+        if want in e.name:
+            fr = [f for f in (e.stack or []) if "textreact_amd" in f or "torch/optim" in f or "torch/autograd" in f][:2]
+            where[(e.name, str(e.input_shapes)[:60], " <- ".join(f.split("/")[-1] for f in fr))] += 1
+    for (name, shp, st), c in where.most_common(30):
+        print("%5d  %-22s %-62s %s" % (c, name, shp, st))
     sys.exit(0)
 rows = sorted(prof.key_averages(), key=lambda e: -e.count)
 for e in rows[:45]:
