@@ -147,14 +147,17 @@ def knn_faiss_blas(metric, x, y, k, bs_x=4096, bs_y=1024):
     return D, I
 
 
-def knn_faiss_blas_mt(metric, x, y, k, workers, bs_x=4096, bs_y=1024):
+def knn_faiss_blas_mt(metric, x, y, k, workers, bs_x=4096, bs_y=1024, gemm=None):
     """knn_faiss_blas spread over the host's cores the way that scales on a many-core box: `workers` host threads, each
     taking every workers-th 1024-row corpus block -- the same fp32 sgemm of a 4096 x 1024 block (ONE BLAS thread per call)
     and the same strict-admission heap handler on it, into the worker's own heaps -- and one merge of the workers' lists at
     the end.  FAISS itself threads INSIDE the sgemm and over the queries of the handler; a 6.4 GFLOP block split over
     hundreds of BLAS threads is mostly synchronisation (bench.py records that rate too), so this form is the stronger CPU
     baseline.  Same arithmetic per block; on tie-free data the same result as knn_faiss_blas (an inner-product heap's order
-    among EXACT ties depends on arrival order, which differs)."""
+    among EXACT ties depends on arrival order, which differs).
+    gemm(a [m, d], b [n, d]) -> a @ b.T as a C-contiguous fp32 array: the sgemm of one block, called from `workers` threads at
+    once (default: numpy's BLAS under threadpool_limits(1); OpenBLAS builds with a 64-thread table complain beyond 64 callers
+    -- bench.py passes torch's MKL sgemm instead)."""
     from concurrent.futures import ThreadPoolExecutor
     from threadpoolctl import threadpool_limits
     x, y = _check(x, y)
@@ -178,7 +181,7 @@ def knn_faiss_blas_mt(metric, x, y, k, workers, bs_x=4096, bs_y=1024):
             i1 = min(i0 + bs_x, nq)
             for b in range(w, nblocks, workers):
                 j0, j1 = b * bs_y, min((b + 1) * bs_y, nb)
-                blk = np.ascontiguousarray(x[i0:i1] @ y[j0:j1].T)
+                blk = np.ascontiguousarray(x[i0:i1] @ y[j0:j1].T) if gemm is None else gemm(x[i0:i1], y[j0:j1])
                 bp = blk.ctypes.data_as(_f32p)
                 if metric == METRIC_L2:
                     L.trxo_l2_from_ip_block(i0, i1, j0, j1, xn.ctypes.data_as(_f32p), yn.ctypes.data_as(_f32p), bp)

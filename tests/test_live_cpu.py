@@ -190,3 +190,32 @@ def test_two_rank_refresh_equals_one_flat_index(reference_ops):
     _, want = oracle.knn_canonical(0, emb_q.float().numpy(), emb_p.float().numpy(), 8)
     assert np.array_equal(nn1.numpy(), want)
     assert np.array_equal(ret[0], want) and np.array_equal(ret[1], want)
+
+
+def test_live_retriever_file_must_hold_the_encoder_weights(tmp_path):
+    """--live_retriever loaded with strict=False and no check: a file with other key names left a randomly
+    initialised retriever behind.  Tevatron's lm_q.* / lm_p.* and a plain encoder.* tree load; anything else stops the run."""
+    from textreact_amd import dense
+    from textreact_amd.main import load_live_retriever
+    from textreact_amd.predictor.model import Config
+    cfg = Config(vocab_size=50, hidden_size=64, num_hidden_layers=1, num_attention_heads=1, intermediate_size=32, max_position_embeddings=16)
+    torch.manual_seed(0)
+    a, b = dense.DenseEncoder(cfg), dense.DenseEncoder(cfg)
+    tev = {"lm_q." + k[len("encoder."):]: v for k, v in a.state_dict().items()}
+    tev.update({"lm_p." + k[len("encoder."):]: v for k, v in b.state_dict().items()})
+    tev["lm_q.embeddings.position_ids"] = torch.arange(16)[None]            # a transformers-4.27.3 buffer: tolerated
+    torch.save(tev, tmp_path / "tev.pt")
+    q, p_ = load_live_retriever(str(tmp_path / "tev.pt"), cfg, "cpu")
+    assert all(torch.equal(v, a.state_dict()[k]) for k, v in q.state_dict().items())
+    assert all(torch.equal(v, b.state_dict()[k]) for k, v in p_.state_dict().items())
+    torch.save({"state_dict": a.state_dict()}, tmp_path / "one.pt")         # one encoder.* tree serves both sides
+    q, p_ = load_live_retriever(str(tmp_path / "one.pt"), cfg, "cpu")
+    assert all(torch.equal(v, a.state_dict()[k]) for k, v in p_.state_dict().items())
+    torch.save({"bert." + k: v for k, v in a.state_dict().items()}, tmp_path / "other.pt")
+    with pytest.raises(SystemExit) as e:
+        load_live_retriever(str(tmp_path / "other.pt"), cfg, "cpu")
+    assert "did not load" in str(e.value)
+    part = dict(tev); del part["lm_p.encoder.layer.0.attention.self.query.weight"]
+    torch.save(part, tmp_path / "part.pt")
+    with pytest.raises(SystemExit):
+        load_live_retriever(str(tmp_path / "part.pt"), cfg, "cpu")

@@ -67,8 +67,9 @@ def test_add_layernorm_backward(rows, cols):
     (1, 2, 300, 1100, "full", True),
     (2, 12, 7, 512, "key", False),        # RCR cross-attention: one 32-query unit, its keys split four ways inside the workgroup
     (2, 3, 40, 200, "full", False),       # two units, keys split two ways
-    (1, 2, 161, 161, "key", True),        # a one-query tail block under causality: three key tiles, the fourth key wave sees no key at all
-    (1, 2, 161, 300, "key", True),
+    (1, 2, 161, 161, "key", True),        # a one-query tail block under causality with three key tiles: too few to split
+    (1, 2, 161, 600, "key", True),        # ... with ten: split four ways, the waves' last tiles cut by the diagonal
+    (1, 2, 20, 140, "none", False),       # three tiles for one unit: not split (fewer than two per wave)
 ])
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
 def test_attention_forward(B, H, Lq, Lk, mask, causal, dtype, tol):
@@ -88,8 +89,9 @@ def test_attention_forward(B, H, Lq, Lk, mask, causal, dtype, tol):
 
 
 @pytest.mark.parametrize("Lq,Lk,masked", [
-    (20, 77, (64, 77)),        # one 32-query unit, its keys split over four waves: the wave that starts at tile 1 sees masked keys only
-    (40, 200, (64, 192)),      # two units, keys split two ways: both waves of a unit meet an all-masked tile first
+    (20, 600, (64, 600)),      # one 32-query unit, its keys split over four waves: three of them see masked keys only
+    (20, 77, (64, 77)),        # (too few tiles to split: the second tile of the one wave is all masked)
+    (40, 300, (64, 300)),      # two units, keys split two ways: the second wave of a unit meets all-masked tiles only
     (128, 200, (0, 70)),       # no split: left padding, the FIRST tile of every wave is all masked (latent since round 1)
     (7, 512, (128, 512)),      # RCR cross-attention over a short encoder input
 ])
@@ -221,7 +223,7 @@ def test_attention_backward(B, H, Lq, Lk, mask, causal):
     # query blocks of one or two 32-query units split their KEYS over the idle waves (round 4): RCR's decoder (7 positions)
     # over the encoder states, two units over several key tiles, a tail unit with a per-element mask, causal with idle key waves
     (2, 12, 7, 512, "key", False), (2, 2, 40, 200, "key", False), (2, 2, 160, 512, "full", False), (1, 2, 7, 7, "key", True),
-    (1, 3, 161, 300, "key", True),
+    (1, 3, 161, 300, "key", True), (1, 2, 161, 600, "key", True),
 ])
 def test_attention_backward_bf16_matrix_cores(B, H, Lq, Lk, mask, causal):
     """bf16 in / bf16 out through the MFMA backward (attn_bwd_mfma.h) against fp32 autograd on the

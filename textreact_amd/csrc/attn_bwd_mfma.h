@@ -117,7 +117,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // a block with one or two 32-query units splits its KEYS over the waves that would otherwise compute on padding, as the
     // forward kernel does (nn_ops.hip: attention_fwd_mfma_kernel); dQ is linear in the keys, so the merge is a sum through LDS
     const int nuq = min(4, (Lq - qb * 128 + 31) / 32);
-    const int KS = nuq == 1 ? 4 : (nuq == 2 ? 2 : 1);         // block-uniform
+    int KS = nuq == 1 ? 4 : (nuq == 2 ? 2 : 1);               // block-uniform
+    {   // (only with at least two key tiles per wave to deal out, as in the forward kernel)
+        int nkb_ = (Lk + 63) / 64;
+        if (causal) nkb_ = min(nkb_, (min(Lq - 1, qb * 128 + 127) + Lk - Lq) / 64 + 1);
+        if (nkb_ < 2 * KS) KS = 1;
+    }
     const int uq = KS == 4 ? 0 : (KS == 2 ? (wave & 1) : wave);
     const int kp = KS == 4 ? wave : (KS == 2 ? (wave >> 1) : 0);
     // the same two as scalars, for the epilogue only (they sit in scalar registers across the loop; the vector copies above

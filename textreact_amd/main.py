@@ -252,6 +252,30 @@ def _load_splits(spec, name):
     return [TensorSplit(f, name) for f in spec.split(",")] if spec else []
 
 
+def load_live_retriever(path, enc_cfg, device):
+    """--live_retriever: (query encoder, passage encoder) from a bi-encoder state dict -- Tevatron's `lm_q.*` / `lm_p.*`
+    (README.md:44-47), or one `encoder.*` tree for both.  strict=False tolerates what such a file may lack or carry (the
+    pooler Tevatron does not use; the position_ids buffer of transformers 4.27.3) -- never the encoder weights themselves:
+    a file with other key names would otherwise leave a randomly initialised retriever behind, silently."""
+    from . import dense
+    sd = torch.load(path, map_location="cpu", weights_only=False)
+    sd = sd.get("state_dict", sd)
+    encs = []
+    for prefix in ("lm_q.", "lm_p."):
+        part = {"encoder." + k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+        part = part or {k: v for k, v in sd.items() if k.startswith("encoder.")}
+        e = dense.DenseEncoder(enc_cfg).to(device).eval()
+        missing, unexpected = e.load_state_dict(part, strict=False)
+        missing = [k for k in missing if ".pooler." not in k]
+        unexpected = [k for k in unexpected if not k.endswith("position_ids") and ".pooler." not in k]
+        if missing or unexpected or not part:
+            raise SystemExit("--live_retriever %s: the %s encoder did not load (%d weights missing, e.g. %s; %d unexpected, e.g. %s): "
+                             "expected Tevatron's lm_q.* / lm_p.* or encoder.* names" % (
+                                 path, prefix.rstrip("."), len(missing), missing[:2], len(unexpected), unexpected[:2]))
+        encs.append(e)
+    return encs
+
+
 class LiveData:
     """--live_every: the retriever, the neighbour ids of every split, and the per-epoch assembly of encoder inputs on the
     device (textreact_amd/live.py restates the reference's dataset logic on tensors)."""
@@ -265,16 +289,7 @@ class LiveData:
         own = dense.DenseEncoder.wrap(module.model.encoder)       # the predictor's own encoder, current weights
         self.q_enc = self.p_enc = own
         if args.live_retriever:
-            sd = torch.load(args.live_retriever, map_location="cpu", weights_only=False)
-            sd = sd.get("state_dict", sd)
-            encs = []
-            for prefix in ("lm_q.", "lm_p."):
-                part = {"encoder." + k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
-                part = part or {k: v for k, v in sd.items() if k.startswith("encoder.")}
-                e = dense.DenseEncoder(enc_cfg).to(device).eval()
-                e.load_state_dict(part, strict=False)
-                encs.append(e)
-            self.q_enc, self.p_enc = encs
+            self.q_enc, self.p_enc = load_live_retriever(args.live_retriever, enc_cfg, device)
         self.k = args.live_k or 2 * max(args.max_num_neighbors, args.num_neighbors)
         self.retriever = live.LiveRetriever(self.corpus, rank, world, batch_size=max(64, args.test_batch_size))
         self.nn = {}                                                # split name -> [N, k] neighbour rows, on the device
