@@ -205,6 +205,7 @@ def live_bench(dev, P=204800, N=40000, k=10, rank=0, world=1, encoder=None, max_
     assemble_ms = (time.perf_counter() - t0) * 1e3
     uncert = ms.pop("uncertified_queries", None)
     rescored = ms.pop("rescored_queries", None)
+    rescanned = ms.pop("rescanned_queries", None)
     # the search stage alone on embeddings with the spread of a TRAINED retriever: with random-init weights every [CLS]
     # embedding is nearly the same vector (cosine of two passages > 0.99), the top-10 scores of a query lie within the
     # certificate's a-priori rounding bound of each other, and every query takes the exact fp64 re-scan -- a worst case that
@@ -231,7 +232,7 @@ def live_bench(dev, P=204800, N=40000, k=10, rank=0, world=1, encoder=None, max_
            "passages": P, "passage_tokens": "16-128 + [CLS] [SEP]", "queries": N, "query_tokens": "16-128 + [CLS] [SEP]", "k": k,
            "ranks": world, "ms": {**{k_: round(v, 2) for k_, v in ms.items()}, "assemble_epoch_inputs": round(assemble_ms, 2)},
            "refresh_ms": round(refresh_ms, 2), "refresh_plus_assemble_ms": round(refresh_ms + assemble_ms, 2),
-           "uncertified_queries": uncert, "rescored_queries": rescored, "mean_cosine_of_passage_pairs": round(cosine, 4),
+           "uncertified_queries": uncert, "rescored_queries": rescored, "rescanned_queries": rescanned, "mean_cosine_of_passage_pairs": round(cosine, 4),
            "search_ms_on_gaussian_embeddings_of_the_same_shape": round(search_gauss_ms, 2), "uncertified_on_gaussian": gauss_uncert,
            "assembled_width": widest,
            "passages_per_s_encode": (P / world) / (ms["encode_passages"] * 1e-3),

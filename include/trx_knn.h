@@ -133,13 +133,16 @@ typedef struct trx_search_stats {
                               certificate failures than the inline re-scan covers): anything the caller
                               computed from D / I / S between begin and finish must be redone */
     int32_t n_rescored;    /* queries the select kernel flagged and the wide re-score looked at (all their listed rows
-                              re-scored exactly); n_uncertified of them went on to the exact scan */
+                              re-scored exactly) */
+    int32_t n_rescanned;   /* of those, queries the wide re-score could not certify either and the fixed-threshold re-scan
+                              took; n_uncertified of them went on to the exact scan */
+    int32_t reserved_;
 } trx_search_stats;
 
 int trx_index_last_stats(const trx_index* idx, trx_search_stats* out);
 
 /* sizeof(trx_search_stats) as this library was built: a caller compiled against another revision of the struct checks
- * it before handing trx_index_last_stats a buffer (the struct grew by `late_fallback` in 0.2). */
+ * it before handing trx_index_last_stats a buffer (the struct grew in 0.2: `late_fallback`, `n_rescored`, `n_rescanned`). */
 int trx_search_stats_size(void);
 
 /* Enable (1) / disable (0) HIP-event timing of the scan kernel inside search calls.  Timing makes

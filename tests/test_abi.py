@@ -26,7 +26,7 @@ def test_library_loads_and_exports_every_symbol():
     for sym in _declared():
         assert hasattr(L, sym), sym
     assert L.trx_version().startswith(b"trxknn 0.2")
-    assert L.trx_search_stats_size() == ctypes.sizeof(_lib.SearchStats) == 48
+    assert L.trx_search_stats_size() == ctypes.sizeof(_lib.SearchStats) == 56
 
 
 def test_every_header_entry_cites_the_reference_call_it_replaces():

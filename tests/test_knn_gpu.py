@@ -175,16 +175,28 @@ def test_near_duplicate_cluster_is_resolved_by_the_wide_rescore():
     assert st["n_rescored"] == 8 and st["n_uncertified"] == 0
 
 
-def test_a_crowd_around_the_kth_place_still_takes_the_exact_scan():
-    # the same cluster with the k-th place INSIDE a crowd that reaches down to the lists' bound: scores fall off smoothly
-    # (steps far below the rounding bound) over 3000 rows, so whatever the bound is, rows just under it tie with the k-th
-    rng = np.random.default_rng(7)
+def test_a_crowd_around_the_kth_place_is_resolved_by_the_rescan():
+    # the k-th place INSIDE a crowd that reaches down to the lists' bound: scores fall off smoothly (steps far below the rounding
+    # bound) over 3000 rows, so whatever the bound is, rows just under it tie with the k-th and the wide re-score cannot
+    # certify.  Tier 3 scans again with the threshold fixed at (k-th exact score so far) - 2 eps: the ~1,400 rows above it
+    # are listed by construction and re-scored; no fp64 scan of the index
     y = gaussian(4000, 64, 1)
     c = gaussian(1, 64, 2)
     y[500:3500] = c * (1.0 - 1e-7 * np.arange(3000, dtype=np.float32)[:, None])
     x = np.repeat(c, 4, axis=0)
+    for metric in (IP, L2):
+        st = _check(metric, x, y, 10)
+        assert st["n_rescored"] == 4 and st["n_rescanned"] == 4 and st["n_uncertified"] == 0, st
+
+
+def test_a_crowd_wider_than_the_lists_still_takes_the_exact_scan():
+    # 10,000 rows within the rounding bound of each other: more than a query's lists (and the wide re-score) hold
+    y = gaussian(12000, 64, 1)
+    c = gaussian(1, 64, 2)
+    y[1000:11000] = c * (1.0 - 1e-8 * np.arange(10000, dtype=np.float32)[:, None])
+    x = np.repeat(c, 4, axis=0)
     st = _check(IP, x, y, 10)
-    assert st["n_rescored"] == 4 and st["n_uncertified"] == 4
+    assert st["n_rescanned"] == 4 and st["n_uncertified"] == 4, st
 
 
 def test_dimension_mismatch_raises():
@@ -469,19 +481,18 @@ def _late_worker(rank, world, port, ret):
 
 
 def _near_duplicate_problem():
-    """8 crowds of 3000 rows in the first shard, each falling off from its query in steps far below the certificate's slack
-    (score steps ~6e-5, slack ~4e-2) over a range of several slacks, so that the bound of the query's candidate lists lies
-    INSIDE the crowd: neither the 32 re-scored candidates nor the wide re-score of everything listed can prove the top 10,
-    and those 8 queries take the exact scan -- more of them than the 4 inline slots of a batch (csrc/knn_api.hip
-    INLINE_FALLBACK).  (A crowd small enough to sit wholly above the lists' bound is resolved by the wide re-score:
-    test_near_duplicate_cluster_is_resolved_by_the_wide_rescore.)"""
+    """8 crowds of 5,000 rows in the first shard, each within the certificate's slack of its query (float32 steps of 1e-8:
+    many exact duplicates among them): more rows than a query's candidate lists or the wide re-score hold, so neither the 32
+    re-scored candidates, nor the wide re-score, nor the fixed-threshold re-scan can prove the top 10, and those 8 queries take
+    the exact scan -- more of them than the 4 inline slots of a batch (csrc/knn_api.hip INLINE_FALLBACK).  (Smaller crowds are
+    resolved on the way: test_near_duplicate_cluster_is_resolved_by_the_wide_rescore, test_a_crowd_..._by_the_rescan.)"""
     rng = np.random.default_rng(21)
-    y = rng.standard_normal((60000, 64)).astype(np.float32)
+    y = rng.standard_normal((100000, 64)).astype(np.float32)
     x = rng.standard_normal((40, 64)).astype(np.float32)
-    fall = (1.0 - 1e-7 * np.arange(3000, dtype=np.float32))[:, None]
+    fall = (1.0 - 1e-8 * np.arange(5000, dtype=np.float32))[:, None]
     for c in range(8):
         base = 3.0 * rng.standard_normal(64).astype(np.float32)
-        y[3000 * c:3000 * (c + 1)] = base[None] * fall
+        y[5000 * c:5000 * (c + 1)] = base[None] * fall
         x[c] = base
     return y, x
 

@@ -64,7 +64,7 @@ struct DevBuf {
 // per index.
 struct DevPool {
     std::mutex mu;
-    DevBuf cand, cnt, thr, gthr, qg;
+    DevBuf cand, cnt, thr, gthr, qg, qg2, gthr2;
     hipEvent_t last = nullptr;
     int users = 0;
 };
@@ -93,7 +93,7 @@ struct trx_index {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     // a search that has been enqueued (trx_index_search_device_begin) and not yet finished: what
     // trx_index_search_finish needs to read the certificate counts back and, rarely, complete the fall-back
-    struct PendingBatch { int* nflag; int* flagged; const void* q; float* D; int64_t* I; double* S64; };
+    struct PendingBatch { int* nflag; int* flagged; int final_slot; const void* q; float* D; int64_t* I; double* S64; };
     struct Pending {
         bool active = false;
         hipStream_t st = nullptr;
@@ -197,7 +197,7 @@ void trx_index_destroy(trx_index* idx) {
         if (--pl.users <= 0) {
             pl.users = 0;
             (void)hipDeviceSynchronize();
-            DevBuf* shared[] = {&pl.cand, &pl.cnt, &pl.thr, &pl.gthr, &pl.qg};
+            DevBuf* shared[] = {&pl.cand, &pl.cnt, &pl.thr, &pl.gthr, &pl.qg, &pl.qg2, &pl.gthr2};
             for (DevBuf* b : shared) b->release();
             // (the ordering event stays for the life of the process: a few bytes, and nothing can hold a stale handle to it)
         }
@@ -310,7 +310,10 @@ int trx_index_add(trx_index* idx, const void* x, int64_t n, int dtype) {
 // decides how many of these slots do anything); more than that -- near-duplicate clusters, adversarial data -- are
 // completed by trx_index_search_finish once the count has been read back
 constexpr int INLINE_FALLBACK = 4;
-constexpr size_t FLAG_WORDS = 4 + 2 * 65536;      // per batch: two counters (+ 2 spare), two lists of query numbers
+// per batch: four counters -- [0] flagged by the select kernel, [1] still uncertified after the wide re-score, [2] after the
+// re-scan (-> exact scan), [3] how many the re-scan took -- three lists of query numbers and two of thresholds (floats)
+constexpr size_t FLAG_WORDS = 4 + 5 * 65536;
+constexpr int RESCAN_MAX = 16384;                 // queries per batch the re-scan is sized for (64 query tiles); more take the exact scan
 
 static int search_batch(trx_index* idx, const void* q, const float* qnorm2, int64_t nq, int is_bf, int q_split, int batch_no,
                         float eps_rel, int k, float* D, int64_t* I, double* S64, hipStream_t st) {
@@ -356,6 +359,9 @@ static int search_batch(trx_index* idx, const void* q, const float* qnorm2, int6
     int* nflag = (int*)idx->w_flag.p + (size_t)batch_no * FLAG_WORDS;
     int* flagged = nflag + 4;
     int* flagged2 = flagged + 65536;
+    int* flagged3 = flagged2 + 65536;
+    float* seed1 = (float*)(flagged3 + 65536);
+    float* seed2 = seed1 + 65536;
     HIPCHK(hipMemsetAsync(nflag, 0, 4 * sizeof(int), st));
 
     ScanParams sp{};
@@ -409,17 +415,37 @@ static int search_batch(trx_index* idx, const void* q, const float* qnorm2, int6
     se.query_orig = q; se.ld_q = d; se.query_is_bf16 = is_bf;
     se.d = d; se.metric = idx->metric; se.k = k; se.nq = (int)nq; se.n = idx->n; se.exact_class = (const int*)idx->w_cls.p;
     se.eps_rel = eps_rel; se.qnorm2 = qnorm2; se.ymax_norm2 = idx->maxnorm2;
-    se.D = D; se.I = I; se.S64 = S64; se.flagged = flagged; se.nflagged = nflag;
+    se.D = D; se.I = I; se.S64 = S64; se.flagged = flagged; se.nflagged = nflag; se.flag_seed = seed1; se.compact = 0;
     HIPCHK(launch_select(se, st));
     // second tier: flagged queries are re-scored over ALL their listed rows (the lists are still in the shared workspace
     // here); what that cannot certify either goes on to the exact scan
-    HIPCHK(launch_wide_rescore(se, flagged, nflag, flagged2, nflag + 1, st));
+    HIPCHK(launch_wide_rescore(se, flagged, nflag, seed1, flagged2, nflag + 1, seed2, st));
+    // third tier: the MFMA scan again, for the still-uncertified queries only, with every threshold FIXED at the query's seed --
+    // (exact k-th score of the candidates re-scored so far) - 2 eps, a key no row of the true top k falls below -- so that
+    // every row that can matter is listed by construction; then the wide re-score over THOSE lists.  A crowd of near-ties
+    // around the k-th place costs a few MFMA tile-passes instead of an fp64 scan of the index; what overflows the lists (more
+    // than ~4,000 rows above the seed) or the re-scan's capacity goes on to the exact scan.
+    int* final_list = flagged2; int* final_cnt = nflag + 1;
+    if (sp.debug == 0 && !getenv("TRX_NO_RESCAN")) {
+        const int rq = (int)std::min<int64_t>(RESCAN_MAX, q_pad);
+        if ((rc = pl.qg2.reserve((size_t)rq * Kp * sizeof(bf16_t)))) return rc;
+        if ((rc = pl.gthr2.reserve((size_t)rq * 4 * sizeof(u32)))) return rc;
+        HIPCHK(launch_gather_rescan(flagged2, nflag + 1, seed2, rq, sp.queries, Kp, (bf16_t*)pl.qg2.p, (u32*)pl.gthr2.p, nflag + 3, st));
+        ScanParams rp = sp;
+        rp.queries = (const bf16_t*)pl.qg2.p; rp.nqtiles = rq / TILE_N; rp.nq_valid = rq; rp.nq_valid_dev = nflag + 3;
+        rp.g_thr = (u32*)pl.gthr2.p; rp.fixed_thr = 1; rp.bootstrap = 0; rp.boot_tiles = 0;
+        HIPCHK(launch_scan(rp, idx->metric, st));
+        SelectParams we = se; we.compact = 1;
+        HIPCHK(launch_wide_rescore(we, flagged2, nflag + 3, nullptr, flagged3, nflag + 2, nullptr, st));
+        HIPCHK(launch_append_tail(flagged2, nflag + 1, rq, flagged3, nflag + 2, st));
+        final_list = flagged3; final_cnt = nflag + 2;
+    }
 
     // certificate failures -> exact scan of those queries.  The count stays on the device: the first INLINE_FALLBACK of
     // them are re-done right here, stream-ordered (slots beyond the count leave at once: ~10 us when nothing failed, the
     // common case); trx_index_search_finish reads the count and completes what is left.  No host synchronisation.
     if (sp.debug == 0)      // (timing-only debug modes of the scan kernel produce wrong lists: no fall-back then)
-        HIPCHK(launch_exact_scan(idx->metric, se.corpus_is_bf16, is_bf, flagged2, INLINE_FALLBACK, nflag + 1, idx->n,
+        HIPCHK(launch_exact_scan(idx->metric, se.corpus_is_bf16, is_bf, final_list, INLINE_FALLBACK, final_cnt, idx->n,
                                  se.corpus_orig, se.ld_c, q, d, d, k, (double*)idx->w_exact.p, D, I, S64, st));
     if (idx->timing) {      // timing mode is synchronous by contract (trx_index_set_timing)
         HIPCHK(hipStreamSynchronize(st));
@@ -431,7 +457,7 @@ static int search_batch(trx_index* idx, const void* q, const float* qnorm2, int6
     idx->stats.n_splits = nsplits;
     idx->pend.no_fallback = sp.debug != 0;
     idx->pend.corpus_orig = se.corpus_orig; idx->pend.ld_c = se.ld_c; idx->pend.corpus_is_bf16 = se.corpus_is_bf16;
-    idx->pend.batches.push_back({nflag, flagged2, q, D, I, S64});
+    idx->pend.batches.push_back({nflag, final_list, (int)(final_cnt - nflag), q, D, I, S64});
     return TRX_OK;
 }
 
@@ -443,19 +469,20 @@ static int finish_impl(trx_index* idx) {
     pd.active = false;
     hipStream_t st = pd.st;
     int cls = 0;
-    std::vector<int> nf(pd.batches.size(), 0), nf1(pd.batches.size(), 0);
-    for (size_t b = 0; b < pd.batches.size(); ++b) {      // [0]: flagged by the select kernel, [1]: still uncertified after the wide re-score
-        HIPCHK(hipMemcpyAsync(&nf1[b], pd.batches[b].nflag, sizeof(int), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(&nf[b], pd.batches[b].nflag + 1, sizeof(int), hipMemcpyDeviceToHost, st));
-    }
+    std::vector<int> nf(pd.batches.size(), 0);
+    std::vector<int> cnt4(pd.batches.size() * 4, 0);      // the four counters of every batch (FLAG_WORDS)
+    for (size_t b = 0; b < pd.batches.size(); ++b)
+        HIPCHK(hipMemcpyAsync(&cnt4[4 * b], pd.batches[b].nflag, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
     if (idx->w_cls.p && !pd.batches.empty()) HIPCHK(hipMemcpyAsync(&cls, idx->w_cls.p, sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (!pd.batches.empty()) idx->stats.exact_class = cls;
     const int64_t per = std::max<int64_t>(INLINE_FALLBACK, ((int64_t)1 << 29) / std::max<int64_t>(1, idx->n * 8));
     bool late = false;
     for (size_t b = 0; b < pd.batches.size(); ++b) {
+        nf[b] = cnt4[4 * b + pd.batches[b].final_slot];
         idx->stats.n_uncertified += nf[b];
-        idx->stats.n_rescored += nf1[b];
+        idx->stats.n_rescored += cnt4[4 * b];
+        idx->stats.n_rescanned += cnt4[4 * b + 3];
         if (pd.no_fallback || nf[b] <= INLINE_FALLBACK) continue;
         late = true;
         int rc = idx->w_exact.reserve((size_t)std::min<int64_t>(per, nf[b]) * idx->n * sizeof(double)); if (rc) return rc;

@@ -116,6 +116,9 @@ struct ScanParams {
     int nsplits;
     int nqtiles;             // q_pad / TILE_N
     int nq_valid;            // queries that exist: the zero pad rows of the last query tile are never listed (see knn_scan.hip)
+    const int* nq_valid_dev; // optional: the same count in device memory (the re-scan of uncertified queries: knn_api.hip); workgroups
+                             // whose query tile lies beyond it leave at once
+    int fixed_thr;           // 1: thresholds stay at their seeds from g_thr (re-scan: every row that reaches the seed is listed)
     int kprime;              // 16 or 32: rows behind a query's threshold (8 per tracked maximum of a lane)
     int cap;                 // usable slots of a list, 63 or 127 (counter = 7 bits of a packed register)
     int cap_alloc;           // slots allocated per list (cap + 1)
@@ -156,11 +159,17 @@ struct SelectParams {
     double* S64;              // optional fp64 scores [nq][k] (sharded merge), may be null
     int* flagged;             // queries that could not be certified
     int* nflagged;
+    float* flag_seed;         // [nq] per query: a key every row that can still reach the query's top k exceeds (see knn_api.hip, tier 3)
+    int compact;              // 1: the lists are indexed by the position in the flagged list (re-scan), not by the query number
 };
 
 // launchers implemented in the .hip files
 hipError_t launch_scan(const ScanParams& p, int metric, hipStream_t st);
 hipError_t launch_select(const SelectParams& p, hipStream_t st);
-hipError_t launch_wide_rescore(const SelectParams& p, const int* flagged, const int* nflagged, int* flagged2, int* nflagged2, hipStream_t st);
+hipError_t launch_wide_rescore(const SelectParams& p, const int* flagged, const int* nflagged, const float* seed_in, int* flagged2, int* nflagged2,
+                               float* seed_out, hipStream_t st);
+hipError_t launch_append_tail(const int* flagged, const int* nflagged, int from, int* out, int* nout, hipStream_t st);
+hipError_t launch_gather_rescan(const int* flagged, const int* nflagged, const float* seed, int max_q, const bf16_t* queries, int Kp,
+                                bf16_t* qg2, u32* gthr2, int* count_out, hipStream_t st);
 
 }  // namespace trx

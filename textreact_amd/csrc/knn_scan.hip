@@ -233,6 +233,10 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
     }
     const int ntl = tile1 > tile0 ? tile1 - tile0 : 0;
     const int64_t qbase = (int64_t)qtile * TILE_N;
+    // the number of queries may live on the device (the re-scan of a batch's uncertified queries is enqueued before anybody
+    // knows how many there are): query tiles beyond it have nothing to do, and nobody reads their lists
+    int nq_valid = p.nq_valid;
+    if (!BOOT && p.nq_valid_dev) { const int nd = *p.nq_valid_dev; nq_valid = nd < nq_valid ? nd : nq_valid; if (qbase >= nq_valid) return; }
     // NKS: the number of K-steps when it is known at compile time (12 = 768 components, BERT's width and the headline
     // case: the K loop of a tile unrolls and the DMA cursors' wrap tests fold, 71.3 -> 70.6 ms), 0 = read it from Kp
     const int ksteps = NKS ? NKS : p.Kp / BK;   // even, >= 4
@@ -347,7 +351,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
         // (a 40,000-query search, 157 tiles with 192 pad rows, took 190 ms instead of 12).  Thresholds only rise, so +inf stays.
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
-            if (qbase + ql0 + 16 * nt >= p.nq_valid) thrk[nt] = __builtin_inff();
+            if (qbase + ql0 + 16 * nt >= nq_valid) thrk[nt] = __builtin_inff();
     }
 
     // DMA cursors (wave-uniform).  B stream: K-steps 1, 2, ... (columns wrap per tile).  A stream: group 0
@@ -539,7 +543,9 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
         // ---- threshold refresh (every eighth tile): min over the query's 4 lanes of this wave, then the partner wave
         // row's value and the other splits' through LDS.  All LDS traffic of the 4 columns is issued together and
         // waited for once (one access at a time cost 8 ms per search).
-        if (!dbg_norefresh && (BOOT ? TL == ntl - 1 : (TL & TRX_REFRESH_MASK) == TRX_REFRESH_MASK)) {      // bootstrap launch: once, for its final publish
+        // (fixed_thr: the re-scan of uncertified queries keeps every threshold at its seed -- a key below which no row can reach the
+        // query's top k -- so that ALL rows above it end up listed; a refresh would raise it to the k'-th best again)
+        if (!dbg_norefresh && !p.fixed_thr && (BOOT ? TL == ntl - 1 : (TL & TRX_REFRESH_MASK) == TRX_REFRESH_MASK)) {      // bootstrap launch: once, for its final publish
             float g[4];
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) g[nt] = trk[J - 1][nt];

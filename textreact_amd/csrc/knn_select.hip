@@ -331,6 +331,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const int ksrc = (lane & 32) + (p.k <= 32 ? p.k - 1 : 31);
         const double s_k = __shfl(ssc, ksrc, 64);          // exact score in k-th place
         const double xx0 = __shfl(xx, lane & 32, 64);      // the first candidate's lane has walked the whole query row
+        // a key that every row of the true top k exceeds by more than eps: the exact k-th score of these candidates is a lower
+        // bound of the true k-th, so a row that can still matter has an approximate key above (that score - eps) > seed
+        // (written for every query, by query number: only a flagged query's is ever read -- tier 3 of the fall-back re-scans
+        // with it, knn_api.hip -- and nothing stays alive for the rare branch below)
+        if (p.flag_seed && hl == 0 && live)
+            p.flag_seed[q] = (nranked >= p.k && !exact_class) ? __double2float_rd((L2 ? xx0 - s_k : s_k) - 2.0 * eps) : -FLT_MAX;
         if (tau != 0ull && nranked < p.k) {
             certified = false;      // fewer ranked candidates than k although rows were dropped: exact inputs or not, redo it
         } else if (!exact_class && tau != 0ull) {
@@ -383,7 +389,8 @@ hipError_t launch_select(const SelectParams& p, hipStream_t st) {
 constexpr int WIDE_MAX = 4096;     // listed rows of a query that reach T: at most nlists x 127 = 32 x 127 = 4064 at 4 splits
 
 template <bool L2, bool CBF, bool QBF>
-__global__ __launch_bounds__(256) void wide_rescore_kernel(SelectParams p, const int* flagged, const int* nflagged, int* flagged2, int* nflagged2) {
+__global__ __launch_bounds__(256) void wide_rescore_kernel(SelectParams p, const int* flagged, const int* nflagged, const float* seed_in,
+                                                           int* flagged2, int* nflagged2, float* seed_out) {
     __shared__ double w_sc[WIDE_MAX];
     __shared__ u32 w_id[WIDE_MAX];
     __shared__ u64 red_key[256];
@@ -398,10 +405,11 @@ __global__ __launch_bounds__(256) void wide_rescore_kernel(SelectParams p, const
     constexpr int QE = QBF ? 2 : 4, CE = CBF ? 2 : 4;
     for (int f = blockIdx.x; f < nf; f += gridDim.x) {
         const int q = flagged[f];
+        const int64_t lq = p.compact ? f : q;        // where this query's lists are: by query number, or by place in the flagged list (re-scan)
         __syncthreads();
         // ---- T = the largest bound of the query's lists ----
         u64 t = 0ull;
-        for (int l = tid; l < p.nlists; l += 256) { const u64 b = p.cand_thr[(int64_t)q * p.nlists + l]; t = b > t ? b : t; }
+        for (int l = tid; l < p.nlists; l += 256) { const u64 b = p.cand_thr[lq * p.nlists + l]; t = b > t ? b : t; }
         red_key[tid] = t;
         if (tid == 0) w_cnt = 0;
         __syncthreads();
@@ -412,7 +420,7 @@ __global__ __launch_bounds__(256) void wide_rescore_kernel(SelectParams p, const
         // ---- every listed row that reaches T (a row listed twice after a compaction appears twice: the ranking below skips it) ----
         bool overflow = false;
         for (int l = 0; l < p.nlists; ++l) {
-            const int64_t o = (int64_t)q * p.nlists + l;
+            const int64_t o = lq * p.nlists + l;
             const int cnt = (int)p.cand_cnt[o];
             for (int i = tid; i < cnt; i += 256) {
                 const u64 e = p.cand[o * p.cap_alloc + i];
@@ -493,16 +501,31 @@ __global__ __launch_bounds__(256) void wide_rescore_kernel(SelectParams p, const
                 if (p.S64) p.S64[o] = ok ? pick_s[r] : (L2 ? (double)FLT_MAX : -(double)FLT_MAX);
             }
         } else if (tid == 0) {
-            flagged2[atomicAdd(nflagged2, 1)] = q;
+            const int pos2 = atomicAdd(nflagged2, 1);
+            flagged2[pos2] = q;
+            if (seed_out) {     // the threshold tier 3 re-scans with: the select kernel's, raised by what this pass has found
+                float sd = seed_in ? seed_in[q] : -FLT_MAX;        // (the select kernel's, by query number)
+                if (got >= p.k && !exact_class && !overflow) {
+                    const float xn2 = p.qnorm2[q];
+                    const float bq = L2 ? (2.0f * sqrtf(xn2 * p.ymax_norm2) + p.ymax_norm2) : sqrtf(xn2 * p.ymax_norm2);
+                    const double eps = (double)p.eps_rel * (double)bq * 1.0001 + 1e-30;
+                    double xx = 0.0;
+                    if (L2) for (int i = 0; i < p.d; ++i) { const double v = load_as_double<QBF>(qrow, i); xx = __builtin_fma(v, v, xx); }
+                    const float mine = __double2float_rd((L2 ? xx - pick_s[p.k - 1] : pick_s[p.k - 1]) - 2.0 * eps);
+                    sd = mine > sd ? mine : sd;
+                }
+                seed_out[pos2] = sd;
+            }
         }
     }
 }
 
-hipError_t launch_wide_rescore(const SelectParams& p, const int* flagged, const int* nflagged, int* flagged2, int* nflagged2, hipStream_t st) {
+hipError_t launch_wide_rescore(const SelectParams& p, const int* flagged, const int* nflagged, const float* seed_in, int* flagged2, int* nflagged2,
+                               float* seed_out, hipStream_t st) {
     if (p.nq <= 0) return hipSuccess;
     dim3 grid((unsigned)(p.nq < 2048 ? p.nq : 2048)), block(256);      // blocks beyond the (device-side) count leave at once
     const int sel = (p.metric ? 4 : 0) | (p.corpus_is_bf16 ? 2 : 0) | (p.query_is_bf16 ? 1 : 0);
-#define TRX_WR(a, b, c) hipLaunchKernelGGL((wide_rescore_kernel<a, b, c>), grid, block, 0, st, p, flagged, nflagged, flagged2, nflagged2)
+#define TRX_WR(a, b, c) hipLaunchKernelGGL((wide_rescore_kernel<a, b, c>), grid, block, 0, st, p, flagged, nflagged, seed_in, flagged2, nflagged2, seed_out)
     switch (sel) {
         case 0: TRX_WR(false, false, false); break;
         case 1: TRX_WR(false, false, true); break;
@@ -514,6 +537,38 @@ hipError_t launch_wide_rescore(const SelectParams& p, const int* flagged, const 
         default: TRX_WR(true, true, true); break;
     }
 #undef TRX_WR
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// tier 3, step 1: the operand rows of the still-uncertified queries, packed into a compact query matrix for the re-scan, and
+// their thresholds in the scan kernel's shared-threshold array (all four slots of a query: the bound stands alone).  Queries
+// beyond max_q (more than the re-scan is sized for) stay out: count_out = min(count, max_q), the others keep their place in the
+// flagged list and take the exact scan.  One workgroup per query row (Kp / 8 16-byte chunks).
+__global__ __launch_bounds__(128) void gather_rescan_kernel(const int* flagged, const int* nflagged, const float* seed, int max_q,
+                                                            const bf16_t* queries, int Kp, bf16_t* qg2, u32* gthr2, int* count_out) {
+    const int n = min(*nflagged, max_q);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *count_out = n;
+    for (int f = blockIdx.x; f < n; f += gridDim.x) {
+        const int q = flagged[f];
+        const uint4* src = reinterpret_cast<const uint4*>(queries + (int64_t)q * Kp);
+        uint4* dst = reinterpret_cast<uint4*>(qg2 + (int64_t)f * Kp);
+        for (int c = threadIdx.x; c < Kp / 8; c += 128) dst[c] = src[c];
+        if (threadIdx.x < 4) gthr2[((int64_t)(f >> 8) * 4 + threadIdx.x) * 256 + (f & 255)] = ordkey(seed[f]);
+    }
+}
+// queries beyond the re-scan's capacity keep their place in line for the exact scan
+__global__ void append_tail_kernel(const int* flagged, const int* nflagged, int from, int* out, int* nout) {
+    const int n = *nflagged;
+    for (int f = from + blockIdx.x * blockDim.x + threadIdx.x; f < n; f += gridDim.x * blockDim.x) out[atomicAdd(nout, 1)] = flagged[f];
+}
+hipError_t launch_append_tail(const int* flagged, const int* nflagged, int from, int* out, int* nout, hipStream_t st) {
+    hipLaunchKernelGGL(append_tail_kernel, dim3(64), dim3(256), 0, st, flagged, nflagged, from, out, nout);
+    return hipGetLastError();
+}
+hipError_t launch_gather_rescan(const int* flagged, const int* nflagged, const float* seed, int max_q, const bf16_t* queries, int Kp,
+                                bf16_t* qg2, u32* gthr2, int* count_out, hipStream_t st) {
+    hipLaunchKernelGGL(gather_rescan_kernel, dim3(1024), dim3(128), 0, st, flagged, nflagged, seed, max_q, queries, Kp, qg2, gthr2, count_out);
     return hipGetLastError();
 }
 

@@ -180,6 +180,7 @@ def refresh_neighbors(q_encoder, p_encoder, corpus, query_ids, query_len, k, ran
             st = stats()
             timings["uncertified_queries"] = st["n_uncertified"]
             timings["rescored_queries"] = st.get("n_rescored", 0)
+            timings["rescanned_queries"] = st.get("n_rescanned", 0)
     return (nn, emb_q, r.emb_p) if return_embeddings else nn
 
 
