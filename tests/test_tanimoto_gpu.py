@@ -1,5 +1,7 @@
 """libtrxtani.so against the oracle (oracle/tanimoto.py): similarities bit-identical doubles, ranks identical including
 the order among equal similarities (retrieve/retrieve.py:34-40,55-62)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -126,6 +128,29 @@ def test_command_line_writes_the_reference_json(tmp_path):
     want_s, want_r = oracle.search(queries[:5], corpus, 100)
     assert sorted(got) == ["0", "1", "2", "3", "4"]                     # json.dump turns the row numbers into strings
     assert got["3"]["rank"] == want_r[3].tolist() and got["3"]["similarity"] == want_s[3].tolist()
+
+
+def test_sharded_command_line_writes_the_file_one_gpu_writes(tmp_path):
+    """python -m torch.distributed.run --nproc-per-node 2 -m textreact_amd.tanimoto ...: the train rows split over two ranks (both
+    on this box's GPU, gloo transport), the HIP Tanimoto index on each, one all-gather of keys; rank 0's test_nn.json is byte
+    for byte the single-GPU file, ties across the shard boundary included"""
+    import subprocess
+    import sys
+    from textreact_amd import tanimoto
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rng = np.random.default_rng(11)
+    base = fingerprints(rng, 40, 2048)
+    corpus = base[rng.integers(0, 40, 901)]               # many equal similarities, spread over both shards
+    queries = base[:9]
+    np.save(tmp_path / "train.npy", corpus); np.save(tmp_path / "test.npy", queries)
+    argv = ["--train_fps", str(tmp_path / "train.npy"), "--test_fps", str(tmp_path / "test.npy"), "--limit", "-1"]
+    tanimoto.main(argv + ["--output", str(tmp_path / "one.json")])
+    env = dict(os.environ, TRX_DIST_BACKEND="gloo", TRX_DEVICE="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29741", "-m", "textreact_amd.tanimoto"] + argv + ["--output", str(tmp_path / "two.json")],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert (tmp_path / "two.json").read_bytes() == (tmp_path / "one.json").read_bytes()
 
 
 def test_single_rank_sharded_wrapper_applies_the_row_offset():

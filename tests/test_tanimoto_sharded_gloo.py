@@ -77,3 +77,33 @@ def test_two_rank_sharded_tanimoto_equals_unsharded():
 
 def test_shards_shorter_than_k_are_padded():
     _run(151, 64, 5, 100)
+
+
+def _cli_worker(rank, world, port, argv):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      TRX_DIST_BACKEND="gloo")
+    from textreact_amd import tanimoto
+    real = tanimoto.retrieve_sharded
+    tanimoto.retrieve_sharded = lambda *a, **k: real(*a, local_index=OracleLocalTanimoto(), **k)     # the oracle stands in for the HIP index
+    assert tanimoto.main(argv) == 0
+
+
+def test_two_rank_command_line_writes_the_unsharded_result(tmp_path):
+    """python -m torch.distributed.run --nproc-per-node 2 -m textreact_amd.tanimoto ...: rows split over the ranks, rank 0 writes
+    the structure retrieve.py dumps -- equal to the unsharded oracle's, tie order included"""
+    import json
+    from oracle import tanimoto as oracle
+    from test_tanimoto_cpu import fingerprints
+    rng = np.random.default_rng(12)
+    base = fingerprints(rng, 30, 64, density=0.1)
+    corpus = base[rng.integers(0, 30, 501)]
+    queries = base[:7]
+    np.save(tmp_path / "train.npy", corpus); np.save(tmp_path / "test.npy", queries)
+    argv = ["--train_fps", str(tmp_path / "train.npy"), "--test_fps", str(tmp_path / "test.npy"), "--limit", "-1", "--output", str(tmp_path / "two.json")]
+    mp.spawn(_cli_worker, args=(2, _free_port(), argv), nprocs=2, join=True)
+    got = json.load(open(tmp_path / "two.json"))
+    want_s, want_r = oracle.search(queries, corpus, 100)
+    assert sorted(got, key=int) == [str(i) for i in range(7)]
+    for i in range(7):
+        assert got[str(i)]["rank"] == want_r[i].tolist() and got[str(i)]["similarity"] == want_s[i].tolist()

@@ -296,10 +296,30 @@ def write_results(path, results):
         json.dump(results, f)
 
 
+def retrieve_sharded(test_fps, train_fps, k=100, limit=None, local_index=None):
+    """`retrieve` with the train rows split over the ranks of the initialised process group (rank r indexes rows
+    sharded.shard_bounds(n, G, r); `train_fps` may be a memory-mapped array: a rank reads its rows only): the same
+    structure on every rank, equal to what one GPU returns"""
+    import torch.distributed as dist
+    from .sharded import shard_bounds
+    n, d = train_fps.shape
+    rank, world = dist.get_rank(), dist.get_world_size()
+    lo, hi = shard_bounds(n, world, rank)
+    index = ShardedTanimotoIndex(d, local_index=local_index)
+    index.add_shard(np.asarray(train_fps[lo:hi]), lo, n)
+    q = np.asarray(test_fps if limit is None else test_fps[:limit])
+    sim, rank_ = index.search(q, k)
+    sim, rank_ = sim.cpu().numpy(), rank_.cpu().numpy()
+    return {i: {"rank": rank_[i].tolist(), "similarity": sim[i].tolist()} for i in range(len(rank_))}
+
+
 def main(argv=None):
     """retrieve.py's job on fingerprint arrays that already exist (retrieve_faiss.py caches them as train_fp.pkl):
-    python -m textreact_amd.tanimoto --train_fps train_fp.pkl --test_fps test_fp.pkl --output test_nn.json [--limit 100]"""
+    python -m textreact_amd.tanimoto --train_fps train_fp.pkl --test_fps test_fp.pkl --output test_nn.json [--limit 100]
+    Launched by `python -m torch.distributed.run --nproc-per-node G -m textreact_amd.tanimoto ...` the train rows are split
+    over the G GPUs (ShardedTanimotoIndex: one all-gather of keys over RCCL) and rank 0 writes the same file."""
     import argparse
+    import os
     import pickle
     ap = argparse.ArgumentParser(description=main.__doc__)
     ap.add_argument("--train_fps", required=True, help=".npy or pickle of an [N, d] integer array")
@@ -308,14 +328,35 @@ def main(argv=None):
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--limit", type=int, default=100, help="number of test rows (retrieve.py stops after 100); -1 = all")
     a = ap.parse_args(argv)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
 
-    def load(p):
+    def load(p, mmap=False):
         if p.endswith(".npy"):
-            return np.load(p)
+            return np.load(p, mmap_mode="r" if mmap else None)
         with open(p, "rb") as f:
-            return np.asarray(pickle.load(f))
-    write_results(a.output, retrieve(load(a.test_fps), load(a.train_fps), k=a.k, limit=None if a.limit < 0 else a.limit))
+            try:
+                return np.asarray(pickle.load(f))
+            except Exception:          # retrieve_faiss.py writes train_fp.pkl with np.save (NumPy bytes despite the name)
+                f.seek(0)
+                return np.load(f)
+    limit = None if a.limit < 0 else a.limit
+    if world <= 1:
+        write_results(a.output, retrieve(load(a.test_fps), load(a.train_fps), k=a.k, limit=limit))
+        return 0
+    import torch.distributed as dist
+    # TRX_DIST_BACKEND=gloo TRX_DEVICE=0: several ranks rehearse on one GPU (RCCL refuses two ranks on one device)
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(os.environ.get("TRX_DIST_BACKEND", "nccl"))
+    if torch.cuda.is_available():
+        torch.cuda.set_device(int(os.environ.get("TRX_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
+    res = retrieve_sharded(load(a.test_fps), load(a.train_fps, mmap=True), k=a.k, limit=limit)
+    if dist.get_rank() == 0:
+        write_results(a.output, res)
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    raise SystemExit(main())
