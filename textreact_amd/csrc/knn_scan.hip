@@ -648,7 +648,10 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
         TRX_READ(0, 0);                                                                                    \
         TRX_READ_BIAS();                                                                                   \
         if (aux_g) __builtin_amdgcn_global_load_lds((gbl_void*)(p.g_thr + (qbase * 4 + (wave & 3) * 256 + lane * 4)), (lds_void*)(smem + S_GTHR + (wave & 3) * 1024), 16, 0, 0); \
-        if (aux_b) __builtin_amdgcn_global_load_lds((gbl_void*)(p.cbias + (int64_t)(tile0 + tl + 1) * TILE_M + lane * 4), \
+        /* (the bias of the NEXT tile; clamped to the spare tile behind the last one: the extra head after a split's last  \
+           tile asked for the tile after the spare one -- 1 KiB past the array, a fault whenever the array ended on the    \
+           last mapped page: round 4's fuzzer found the layout) */                                        \
+        if (aux_b) __builtin_amdgcn_global_load_lds((gbl_void*)(p.cbias + (int64_t)min(tile0 + tl + 1, p.ntiles) * TILE_M + lane * 4), \
                                                     (lds_void*)(smem + S_BIAS + ((tl + 1) & 1) * 1024), 16, 0, 0); \
         TRX_DMA_B(1);                                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                 \

@@ -12,7 +12,7 @@ rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 nfail = 0
 for it in range(n_cases):
     metric = rng.choice([0, 1])
-    kind = rng.choice(["gauss", "gauss_bf16", "grid", "fp", "dup"])
+    kind = rng.choice(["gauss", "gauss_bf16", "grid", "fp", "dup", "crowd", "crowd"])
     d = rng.choice([1, 3, 17, 64, 65, 100, 128, 200, 256, 300, 768, 1024])
     n = rng.choice([1, 2, 7, 255, 256, 257, 1000, 5000, 20000, 60000])
     nq = rng.choice([1, 2, 63, 64, 65, 255, 256, 257, 700])
@@ -25,12 +25,29 @@ for it in range(n_cases):
         y, x = grid(n, d, 2 * it), grid(nq, d, 2 * it + 1)
     elif kind == "fp":
         y, x = morgan_like(n, d, 2 * it).astype(np.float32), morgan_like(nq, d, 2 * it + 1).astype(np.float32)
+    elif kind == "crowd":   # near-duplicates around the k-th place: crowds of random size that fall off from their queries in steps far
+        # below the certificate's slack -- small ones are settled by the wide re-score, wider ones by the fixed-threshold
+        # re-scan, the widest by the exact scan (round 4: the three fall-back tiers), mixed with ordinary queries
+        y, x = gaussian(n, d, 2 * it), gaussian(nq, d, 2 * it + 1)
+        r2 = np.random.default_rng(1000 + it)
+        pos = 0
+        for c in range(min(nq, r2.integers(1, 6))):
+            size = int(min(n - pos, r2.choice([40, 300, 1500, 6000])))
+            if size <= 0:
+                break
+            base = (3.0 * r2.standard_normal(d)).astype(np.float32)
+            step = float(r2.choice([1e-7, 1e-8, 3e-6]))
+            y[pos:pos + size] = base[None] * (1.0 - step * np.arange(size, dtype=np.float32))[:, None]
+            x[c] = base
+            pos += size
     else:   # clusters of exact duplicates: ties everywhere
         base = gaussian(max(1, n // 8), d, 2 * it)
         y = base[np.random.default_rng(it).integers(0, base.shape[0], n)]
         x = gaussian(nq, d, 2 * it + 1)
     idx = faiss.IndexFlat(d, metric)
     chunks = rng.choice([1, 1, 3])
+    if os.environ.get("TRX_FUZZ_VERBOSE"):
+        print("case", it, dict(metric=metric, kind=kind, d=d, n=n, nq=nq, k=k, chunks=chunks), flush=True)
     for part in np.array_split(y, chunks):
         if part.shape[0]:
             idx.add(part)
@@ -41,4 +58,7 @@ for it in range(n_cases):
         nfail += 1
         bad = np.argwhere(I != Ir)
         print("FAIL", it, dict(metric=metric, kind=kind, d=d, n=n, nq=nq, k=k, chunks=chunks), "first bad", bad[:3].tolist(), idx.last_stats())
-print(n_cases, "cases,", nfail, "failures")
+    tiers = idx.last_stats()
+    seen = globals().setdefault("seen", [0, 0, 0])
+    seen[0] += tiers["n_rescored"]; seen[1] += tiers["n_rescanned"]; seen[2] += tiers["n_uncertified"] if k <= 24 else 0
+print(n_cases, "cases,", nfail, "failures; queries through the wide re-score / the re-scan / the exact scan (k <= 24):", seen)
