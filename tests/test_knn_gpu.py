@@ -463,6 +463,35 @@ def test_pad_queries_of_the_last_query_tile_cost_nothing():
     assert np.array_equal(I[rows].cpu().numpy(), want)
 
 
+def test_indexes_share_one_workspace_across_streams():
+    """round 4: the large search workspaces are one set per device, shared by every index of the process; a search enqueues
+    behind the event the previous user recorded.  Two indexes of different shapes, searched on two different streams,
+    interleaved and with one search begun and not yet finished while the other index runs: every result is the oracle's"""
+    import torch
+    import textreact_amd.faiss_compat as faiss
+    from oracle import flat_knn as oracle
+    ya, xa = gaussian(30000, 96, 1), gaussian(700, 96, 2)
+    yb, xb = bf16_round(gaussian(8000, 768, 3)), bf16_round(gaussian(300, 768, 4))
+    a, b = faiss.IndexFlatIP(96), faiss.IndexFlatL2(768)
+    a.add(ya); b.add(yb)
+    xa_d, xb_d = torch.from_numpy(xa).cuda(), torch.from_numpy(xb).cuda().bfloat16()
+    Da_r, Ia_r = oracle.knn_canonical(IP, xa, ya, 10)
+    Db_r, Ib_r = oracle.knn_canonical(L2, xb, yb, 10)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for _ in range(4):
+        with torch.cuda.stream(s1):
+            Da, Ia, Sa = a.search_s64_begin(xa_d, 10)            # enqueued on s1, not waited for
+        with torch.cuda.stream(s2):
+            Db, Ib = b.search(xb_d, 10)                          # the other index, another stream, the same workspaces
+        a.search_finish()
+        assert np.array_equal(Ia.cpu().numpy(), Ia_r) and np.array_equal(Da.cpu().numpy().view(np.uint32), Da_r.view(np.uint32))
+        assert np.array_equal(Ib.cpu().numpy(), Ib_r) and np.array_equal(Db.cpu().numpy().view(np.uint32), Db_r.view(np.uint32))
+    del a
+    D2, I2 = b.search(xb_d, 10)                                  # the surviving index keeps the workspaces
+    assert np.array_equal(I2.cpu().numpy(), Ib_r)
+
+
 def _late_worker(rank, world, port, ret):
     import os, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
