@@ -5,13 +5,36 @@
 //
 // Here the contraction IS split: workgroup (tile, s) accumulates rows [s * M/S, (s+1) * M/S) of one 256 x 256 tile
 // of C into an fp32 partial, a second kernel sums the S partials in a fixed order (deterministic) and rounds to
-// bf16.  Inside a workgroup it is the retrieval scan's loop turned sideways: 8 waves, each 128 (n) x 64 (k) of the
-// tile = 4 x 2 tiles of v_mfma_f32_32x32x16_bf16 (128 accumulator registers), steps of 64 rows of A and B staged
-// by LDS-DMA into two 64 KiB stages.  Both operands are consumed TRANSPOSED (the contraction index m is the slow
-// dimension of both): every fragment is two ds_read_b64_tr_b16 on the row-major [m][n] / [m][k] tile, exactly the
-// V^T operand of the attention kernels.  A 32-lane half of such a read touches 4 rows x 64 B; rows are 512 B
-// apart, so 16-byte chunk c of row m is stored at slot c ^ (4 * (m & 3)) (applied to the DMA source chunk), which
-// spreads the 4 rows over the 4 quarters of a 256-byte bank row.
+// bf16.  Round 4: the loop is the retrieval scan's TWO-GROUP PING-PONG (knn_scan.hip) turned sideways.
+//
+//   Workgroup = 8 waves.  MFMA operands: P = B (X, the k index of C) on the MFMA's row side, S = A (dY, the n index)
+//   on its column side -- so a lane's 4 accumulator registers are 4 CONSECUTIVE k of one n.  Group g = wave >> 2 owns
+//   k columns 128 g .. 128 g + 127 of the tile, wave wq = wave & 3 the n columns 64 wq .. 64 wq + 63:
+//   8 x 4 tiles of v_mfma_f32_16x16x32_bf16 = 128 accumulator registers per wave.
+//
+//   A K-step is 64 token rows of both operands = four 16 KiB BANDS of 64 rows x 128 columns (X0, X1: the two groups'
+//   halves of P; Y0, Y1: the two halves of S), each band double-buffered (stage u & 1 of K-step u): 128 KiB of LDS.
+//   Bands arrive by LDS-DMA in 1 KiB pieces of 4 rows x 256 B (no staging registers).  Both operands are consumed
+//   TRANSPOSED (the contraction index m is the slow dimension of both): a fragment is two ds_read_b64_tr_b16 --
+//   16-lane group gg reads rows 4 gg .. 4 gg + 3 (+ 16 for the second read) of a 32-row half, 16 columns.  A 32-lane
+//   half of such a read touches 8 rows x 32 B that are 256 B apart, so 16-byte chunk c of row m is stored at slot
+//   c ^ (2 (m & 7)) (a permutation of the DMA's per-lane SOURCE address): conflict-free.
+//
+//   The two groups share the four SIMDs pairwise and run one barrier interval apart; K-step u, half kk (32 rows):
+//     interval 4u   : G0 L(u,0) [DMA Y0 of K-step u+1]     G1 M(u-1,1)
+//     interval 4u+1 : G0 M(u,0)                            G1 L(u,0) [DMA Y1 of u+1]
+//     interval 4u+2 : G0 L(u,1) [DMA X1 of u+1]            G1 M(u,0)
+//     interval 4u+3 : G0 M(u,1)                            G1 L(u,1) [DMA X0 of u+2]
+//   L = 24 transposed fragment reads of the next half + 4 DMA pieces per wave, M = 32 MFMAs.  Write-after-read: every
+//   fragment read is retired (lgkmcnt(0)) before the barrier that ends its interval and each DMA is issued at least one
+//   barrier after the last read of the band it overwrites (X0 is read by group 0 only, last in interval 4u+2; the
+//   other bands last in interval 4u+3).  Read-after-write: a wave waits vmcnt(4) at the end of every load phase -- the
+//   pieces of its PREVIOUS load phase, two intervals old -- and every band has a barrier between that wait and its
+//   first read.  Against the first form of this kernel (DMA burst, one __syncthreads per K-step, 32x32x16 MFMAs:
+//   both waves of a SIMD read, waited and multiplied together) see DESIGN.md section 3.4.
+//
+//   Partials leave in the accumulators' own layout (ws[split][tile][wave][fragment][lane][4]: every store is 1 KiB
+//   contiguous); the reduction kernel reads them the same way and writes C row-major.
 #include "../../include/trx_nn.h"
 #include <hip/hip_runtime.h>
 #include <atomic>
@@ -19,20 +42,17 @@
 
 namespace trxtn {
 
-__device__ const uint4 g_zero16 = {0u, 0u, 0u, 0u};      // what the rows past M of a ragged last step read as
-
 
 typedef unsigned short bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 constexpr int TILE = 256, BM = 64, THREADS = 512;
-constexpr int STAGE = 2 * BM * 512;           // A rows then B rows, 512 B each: 64 KiB
-constexpr int LDS_TOTAL = 2 * STAGE;
+constexpr int BAND2 = 2 * BM * 256;           // a band's two stages: 32 KiB
+constexpr int LDS_TOTAL = 4 * BAND2;          // X0 X1 Y0 Y1: 128 KiB
 
 struct Params {
     const bf16_t* A; const bf16_t* B; float* ws;
@@ -47,205 +67,246 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_tn_kernel(Params p) {
     typedef __attribute__((address_space(1))) const void gbl_void;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wave_n = wave >> 2, wave_k = wave & 3;      // 2 x 4 waves: 128 n x 64 k each
-    // Which (split, tile) a workgroup takes (TRX_TN_GROUP, default on).  The tn x tk tiles of ONE split read the same token rows: a
-    // row block of A is wanted by the tk workgroups of its tile column, one of B by the tn of its tile row.  Workgroups are
-    // placed on the 8 XCDs round-robin (bid & 7), each XCD with its own L2: numbered split-fastest (round 2) the ~32 workgroups of
-    // an XCD are 32 different (split, tile) pairs that share nothing, and every operand byte is fetched tk or tn times from the
-    // fabric -- 600 MB per FFN weight gradient, 7 TB/s: the kernel ran at the Infinity-Cache's bandwidth, not at its MFMAs'.
-    // Numbered split-SLOWEST and dealt to the XCDs in contiguous runs (the scan kernel's bijective remap), an XCD holds the tiles
-    // of one or two splits, which walk the same rows in step and find each other's lines in L2.
-#ifndef TRX_TN_GROUP
-#define TRX_TN_GROUP 1
-#endif
-    int bid = blockIdx.x;
+    const int grp = wave >> 2, wq = wave & 3;
+    // Which (split, tile) a workgroup takes.  The tn x tk tiles of ONE split read the same token rows: numbered
+    // split-SLOWEST and dealt to the XCDs in contiguous runs (the scan kernel's bijective remap), an XCD holds the tiles
+    // of one or two splits, which walk the same rows in step and find each other's lines in L2 (round 3: numbered
+    // split-fastest every operand byte came tk or tn times over the fabric).
     int split, kt, nt;
-    if (TRX_TN_GROUP) {
-        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    {
+        const int bid = blockIdx.x, nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = bid & 7;
         const int v = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);      // XCD x owns [base, base + q (+1))
         const int tiles = p.tn * p.tk;
         split = v / tiles;
         const int t = v - split * tiles;
         kt = t % p.tk; nt = t / p.tk;
-    } else {
-        split = bid % p.nsplit; bid /= p.nsplit;
-        kt = bid % p.tk; nt = bid / p.tk;
     }
     const int n0 = nt * TILE, k0 = kt * TILE;
     const int total_steps = (p.M + BM - 1) / BM;          // the last step may be partial: rows >= M read as zeros (A) / row M-1 (B)
     const int step0 = split * p.steps_per_split;
-    const int nsteps = max(0, min(p.steps_per_split, total_steps - step0));
+    const int nsteps = min(p.steps_per_split, total_steps - step0);     // >= 1 (plan())
 
-    // ---- staging: a piece = one global_load_lds_dwordx4 = 2 rows x 512 B; wave w moves pieces 4w .. 4w+3 of A and of B
-    const int prow = lane >> 5, pslot = lane & 31;
-    int64_t offA[4], offB[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = 2 * (4 * wave + i) + prow;            // row of the 64-row step
-        const int chunk = pslot ^ (4 * (row & 3));            // source chunk of this lane's slot
-        offA[i] = (int64_t)row * p.lda + n0 + chunk * 8;
-        offB[i] = (int64_t)row * p.ldb + k0 + chunk * 8;
-    }
-#define TRX_TN_STAGE(S, BUF)                                                                                     \
-    {                                                                                                            \
-        const int r0_ = (step0 + (S)) * BM;                                                                      \
-        const bf16_t* a_ = p.A + (int64_t)r0_ * p.lda;                                                           \
-        const bf16_t* b_ = p.B + (int64_t)r0_ * p.ldb;                                                           \
-        char* l_ = smem + (BUF) * STAGE + (4 * wave) * 1024;                                                     \
-        if (r0_ + BM <= p.M) {                                                                                   \
-            _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                   \
-                __builtin_amdgcn_global_load_lds((gbl_void*)(a_ + offA[i_]), (lds_void*)(l_ + i_ * 1024), 16, 0, 0); \
-                __builtin_amdgcn_global_load_lds((gbl_void*)(b_ + offB[i_]), (lds_void*)(l_ + BM * 512 + i_ * 1024), 16, 0, 0); \
-            }                                                                                                    \
-        } else { /* the ragged last step (wave-uniform): a row past M contributes nothing when its A half is zero */ \
-            _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                   \
-                const int over_ = r0_ + 2 * (4 * wave + i_) + prow - (p.M - 1);      /* > 0: rows past the end */ \
-                const bf16_t* pa_ = over_ > 0 ? reinterpret_cast<const bf16_t*>(&g_zero16) : a_ + offA[i_];      \
-                const bf16_t* pb_ = b_ + offB[i_] - (over_ > 0 ? (int64_t)over_ * p.ldb : 0);                    \
-                __builtin_amdgcn_global_load_lds((gbl_void*)pa_, (lds_void*)(l_ + i_ * 1024), 16, 0, 0);         \
-                __builtin_amdgcn_global_load_lds((gbl_void*)pb_, (lds_void*)(l_ + BM * 512 + i_ * 1024), 16, 0, 0); \
-            }                                                                                                    \
-        }                                                                                                        \
-    }
-
-    // ---- transposed fragment addresses: lane -> row 4 hh + qq (+ 8 for the second read, + 16 per sub-step),
-    // columns 16 (g & 1) + 4 pp .. + 3 of a 32-column block
-    const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3, hh = lane >> 5;
+    // ---- staging geometry: a piece = one buffer_load_dwordx4 ... lds = 4 rows x 256 B of a band, written lane-linear
+    // (row 4 piece + lane / 16, slot lane % 16); slot s of row r receives global chunk s ^ (2 (r & 7)).  In a load phase
+    // wave wq of the loading group moves pieces 4 wq .. 4 wq + 3 of one band: rows 16 wq + 4 i + prow.  The operands are
+    // addressed through buffer descriptors (wave-uniform base and K-step offset in scalar registers, a 32-bit lane
+    // offset): no 64-bit vector address arithmetic in the loop, and the range check IS the ragged edge -- a row past M lies
+    // past the descriptor's last byte and arrives in LDS as zeros (tools/experiments/buffer_lds_oob.hip), so the last
+    // step of a token count that is not a multiple of 64 needs no code at all, and neither do the pieces the DMA
+    // cursors issue past the end of a split (rows of the next split, or zeros; their stages are dead).
     const unsigned ldsbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-    unsigned fa[4], fb[2];
+    const int xb = grp ^ 1;                      // the X band this wave's group STAGES (it reads band grp)
+    unsigned voY[4], voX[4];                     // lane offsets of this wave's four pieces (bytes)
+    {
+        const int prow = lane >> 4, pslot = lane & 15;
+        const int c_even = pslot ^ (2 * prow);      // pieces with (piece & 1) == 0: (row & 7) == prow
+        const int c_odd = c_even ^ 8;               //                          1:              4 + prow
 #pragma unroll
-    for (int ib = 0; ib < 4; ++ib) {
-        const int c = 16 * wave_n + 4 * ib + 2 * (g & 1) + (pp >> 1);
-        fa[ib] = ldsbase + (unsigned)((4 * hh + qq) * 512 + ((c ^ (4 * qq)) << 4) + 8 * (pp & 1));
+        for (int i = 0; i < 4; ++i) {
+            voY[i] = (unsigned)(((16 * wq + 4 * i + prow) * p.lda + ((i & 1) ? c_odd : c_even) * 8) * 2);
+            voX[i] = (unsigned)(((16 * wq + 4 * i + prow) * p.ldb + ((i & 1) ? c_odd : c_even) * 8) * 2);
+        }
     }
-#pragma unroll
-    for (int jb = 0; jb < 2; ++jb) {
-        const int c = 8 * wave_k + 4 * jb + 2 * (g & 1) + (pp >> 1);
-        fb[jb] = ldsbase + (unsigned)(BM * 512 + (4 * hh + qq) * 512 + ((c ^ (4 * qq)) << 4) + 8 * (pp & 1));
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)(unsigned)((((int64_t)p.M - 1) * p.lda + p.N) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)(unsigned)((((int64_t)p.M - 1) * p.ldb + p.K) * 2), 0x00020000);
+#define TN_BUF16(RSRC, VOFF, SOFF, LDSADDR)                                                                      \
+    {                                                                                                            \
+        const unsigned la_ = (unsigned)__builtin_amdgcn_readfirstlane((int)(LDSADDR));                            \
+        const unsigned so_ = (unsigned)__builtin_amdgcn_readfirstlane((int)(SOFF));                               \
+        asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" :: "v"(VOFF), "s"(RSRC), "s"(so_), "s"(la_) : "memory", "m0"); \
+    }
+    // DMA cursors (wave-uniform byte offsets of the K-step whose band this wave's group stages next)
+    const unsigned kstepY = (unsigned)(BM * p.lda * 2), kstepX = (unsigned)(BM * p.ldb * 2);
+    unsigned soY = (unsigned)((((int64_t)step0 + 1) * BM * p.lda + n0 + 128 * grp) * 2);
+    unsigned soX = (unsigned)((((int64_t)step0 + (grp ? 2 : 1)) * BM * p.ldb + k0 + 128 * xb) * 2);
+#define TN_DMA_Y(STG)                                                                                            \
+    {                                                                                                            \
+        const unsigned l_ = ldsbase + (unsigned)((2 + grp) * BAND2 + (STG) * 16384 + wq * 4096);                 \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) TN_BUF16(rsA, voY[i_], soY, l_ + i_ * 1024);            \
+        soY += kstepY;                                                                                           \
+    }
+    // group 0 stages X1 of the next K-step into the other stage, group 1 X0 of the one after into this stage
+#define TN_DMA_X(STG)                                                                                            \
+    {                                                                                                            \
+        const unsigned l_ = ldsbase + (unsigned)(xb * BAND2 + ((STG) ^ xb) * 16384 + wq * 4096);                 \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) TN_BUF16(rsB, voX[i_], soX, l_ + i_ * 1024);            \
+        soX += kstepX;                                                                                           \
     }
 
-    f32x16 acc[4][2];
+    // ---- transposed fragment addresses.  Lane -> row 4 gg + qq of a 32-row half (+ 16 for the second read), columns
+    // 4 pp .. 4 pp + 3 of a 16-column block; the read hands lane l the 4 rows' values of column l & 15.
+    const int gg = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
+    const int r7 = 4 * (gg & 1) + qq;                   // (row & 7) of every row this lane addresses
+    const unsigned rowoff = ldsbase + (unsigned)((4 * gg + qq) * 256 + 8 * (pp & 1));
+    unsigned fx[8], fy[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int ib = 0; ib < 8; ++ib) fx[ib] = rowoff + (unsigned)(grp * BAND2 + (((2 * ib + (pp >> 1)) ^ (2 * r7)) << 4));
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int t = 0; t < 16; ++t) acc[i][j][t] = 0.f;
+    for (int jb = 0; jb < 4; ++jb) fy[jb] = rowoff + (unsigned)((2 + (wq >> 1)) * BAND2 + (((8 * (wq & 1) + 2 * jb + (pp >> 1)) ^ (2 * r7)) << 4));
 
-    // column sums of A (= db of the Linear whose dW this is) ride along in the workgroups of the first k tile: thread ->
-    // 16-byte chunk tid & 31 of rows (tid >> 5) + 16 j, which all share one swizzle
-    const bool colsum = p.ws_colsum != nullptr && kt == 0;
-    const unsigned csaddr = ldsbase + (unsigned)((tid >> 5) * 512 + (((tid & 31) ^ (4 * ((tid >> 5) & 3))) << 4));
-    float cs[8];
+    f32x4 acc[8][4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) cs[e] = 0.f;
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    if (nsteps > 0) TRX_TN_STAGE(0, 0);
-    __syncthreads();
-    int cur = 0;
-    for (int s = 0; s < nsteps; ++s) {
-        if (s + 1 < nsteps) TRX_TN_STAGE(s + 1, cur ^ 1);
-        const unsigned sb = (unsigned)(cur * STAGE);
-        u32x4 cv[4];
-        if (colsum) {   // older than every fragment read below: the first counted wait retires them
+    // Column sums of A (= db of the Linear whose dW this is) ride along ON THE MATRIX PIPE: the S fragments a wave holds
+    // anyway, multiplied by a P fragment of ones, are the column sums of its 64 n columns over the half K-step (all 16
+    // rows of the result equal): 4 more MFMAs per phase, no LDS reads, no vector instructions.  The tk workgroups of a
+    // tile row and split hold the same S bands, so they share the work: workgroup kt takes the K-steps with
+    // (step % tk) == kt (group 0 only) and writes its own partial row -- every workgroup of the launch pays the same
+    // 1 / (2 tk) of 12.5 %.  The four MFMAs and the scalar branch around them are ONE asm statement: with a branch it can
+    // see in this loop hipcc spills (40 .. 536 bytes of scratch per lane, depending on where the condition sits).
+    const bool cs_on = p.ws_colsum != nullptr && grp == 0;
+    f32x4 acs[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(cv[j]) : "v"(csaddr + sb), "n"(j * 8192) : "memory");
+    for (int j = 0; j < 4; ++j) acs[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    u32x4 ones4 = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+    asm volatile("" : "+v"(ones4));     // one register quad, not a constant rebuilt per use
+
+    // ---- prologue: K-step 0 in full and X0 of K-step 1 (all waves: 2 pieces of each band) ----
+    {
+        const int prow = lane >> 4, pslot = lane & 15;
+        const unsigned so0A = (unsigned)(((int64_t)step0 * BM * p.lda + n0) * 2), so0B = (unsigned)(((int64_t)step0 * BM * p.ldb + k0) * 2);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int pc = 2 * wave + i, row = 4 * pc + prow, chunk = (pslot ^ (2 * prow)) ^ (8 * i);
+            const unsigned va = (unsigned)((row * p.lda + chunk * 8) * 2), vb = (unsigned)((row * p.ldb + chunk * 8) * 2);
+            const unsigned l = ldsbase + (unsigned)(pc * 1024);
+            TN_BUF16(rsB, vb, so0B, l + 0 * BAND2);
+            TN_BUF16(rsB, vb, so0B + 256u, l + 1 * BAND2);
+            TN_BUF16(rsA, va, so0A, l + 2 * BAND2);
+            TN_BUF16(rsA, va, so0A + 256u, l + 3 * BAND2);
+            TN_BUF16(rsB, vb, so0B + kstepX, l + 0 * BAND2 + 16384);
         }
-        // 4 sub-steps of 16 rows; fragments of sub-step ss+1 are read while the MFMAs of ss run
-        uint2 ra[2][4][2], rb[2][2][2];     // [slot][block][low / high 4 rows]
-#define TRX_TN_READ(SLOT, SS)                                                                                    \
-    _Pragma("unroll") for (int ib_ = 0; ib_ < 4; ++ib_)                                                          \
-        asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"                \
-                     : "=&v"(ra[SLOT][ib_][0]), "=&v"(ra[SLOT][ib_][1]) : "v"(fa[ib_] + sb), "n"((SS) * 8192), "n"((SS) * 8192 + 4096) : "memory"); \
-    _Pragma("unroll") for (int jb_ = 0; jb_ < 2; ++jb_)                                                          \
-        asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"                \
-                     : "=&v"(rb[SLOT][jb_][0]), "=&v"(rb[SLOT][jb_][1]) : "v"(fb[jb_] + sb), "n"((SS) * 8192), "n"((SS) * 8192 + 4096) : "memory");
-#define TRX_TN_WAIT(SLOT, CNT)                                                                                   \
-    asm volatile("s_waitcnt lgkmcnt(" #CNT ")"                                                                   \
-                 : "+v"(ra[SLOT][0][0]), "+v"(ra[SLOT][0][1]), "+v"(ra[SLOT][1][0]), "+v"(ra[SLOT][1][1]),       \
-                   "+v"(ra[SLOT][2][0]), "+v"(ra[SLOT][2][1]), "+v"(ra[SLOT][3][0]), "+v"(ra[SLOT][3][1]),       \
-                   "+v"(rb[SLOT][0][0]), "+v"(rb[SLOT][0][1]), "+v"(rb[SLOT][1][0]), "+v"(rb[SLOT][1][1]) :: "memory");
-#define TRX_TN_FRAG(R) __builtin_bit_cast(bf16x8, uint4{R[0].x, R[0].y, R[1].x, R[1].y})
-#define TRX_TN_MFMA(SLOT)                                                                                        \
-    _Pragma("unroll") for (int ib_ = 0; ib_ < 4; ++ib_)                                                          \
-        _Pragma("unroll") for (int jb_ = 0; jb_ < 2; ++jb_)                                                      \
-            acc[ib_][jb_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(TRX_TN_FRAG(ra[SLOT][ib_]), TRX_TN_FRAG(rb[SLOT][jb_]), acc[ib_][jb_], 0, 0, 0);
-        TRX_TN_READ(0, 0)
-        TRX_TN_READ(1, 1)
-        TRX_TN_WAIT(0, 12)
-        TRX_TN_MFMA(0)
-        if (colsum) {
-            asm volatile("" : "+v"(cv[0]), "+v"(cv[1]), "+v"(cv[2]), "+v"(cv[3]));
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const unsigned w[4] = {cv[j][0], cv[j][1], cv[j][2], cv[j][3]};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    cs[2 * e] += __uint_as_float(w[e] << 16);
-                    cs[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u);
-                }
-            }
-        }
-        TRX_TN_READ(0, 2)
-        TRX_TN_WAIT(1, 12)
-        TRX_TN_MFMA(1)
-        TRX_TN_READ(1, 3)
-        TRX_TN_WAIT(0, 12)
-        TRX_TN_MFMA(0)
-        TRX_TN_WAIT(1, 0)
-        TRX_TN_MFMA(1)
-        __syncthreads();
-        cur ^= 1;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
     }
-#undef TRX_TN_STAGE
-    if (colsum) {   // 16 row groups -> one value per column, through the (now idle) stage memory
-        float* red = reinterpret_cast<float*>(smem);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) red[(tid >> 5) * 256 + (tid & 31) * 8 + e] = cs[e];
-        __syncthreads();
-        if (tid < 256) {
-            float t = 0.f;
-#pragma unroll
-            for (int g2 = 0; g2 < 16; ++g2) t += red[g2 * 256 + tid];
-            p.ws_colsum[(int64_t)split * p.N + n0 + tid] = t;
-        }
+    if (grp) __builtin_amdgcn_s_barrier();       // group 1 runs one interval late
+
+    uint2 xl[8], xh[8], yl[4], yh[4];           // fragments: low / high 4 rows of a lane's 8 contraction rows
+#define TN_READ(KK, STG)                                                                                         \
+    {                                                                                                            \
+        _Pragma("unroll") for (int jb_ = 0; jb_ < 4; ++jb_)                                                      \
+            asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"            \
+                         : "=&v"(yl[jb_]), "=&v"(yh[jb_]) : "v"(fy[jb_]), "n"((STG) * 16384 + (KK) * 8192), "n"((STG) * 16384 + (KK) * 8192 + 4096) : "memory"); \
+        _Pragma("unroll") for (int ib_ = 0; ib_ < 8; ++ib_)                                                      \
+            asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"            \
+                         : "=&v"(xl[ib_]), "=&v"(xh[ib_]) : "v"(fx[ib_]), "n"((STG) * 16384 + (KK) * 8192), "n"((STG) * 16384 + (KK) * 8192 + 4096) : "memory"); \
     }
-    // ---- partial tile (fp32): ws[split][n][k]; register t of acc[ib][jb] = C[n = .. + (t&3) + 8(t>>2) + 4hh][k = .. + (lane & 31)]
-    float* out = p.ws + (int64_t)split * p.N * p.K;
-    const int r = lane & 31;
+    // end of a load phase: the fragment reads are retired, all but the four pieces just issued have landed
+#define TN_WAIT_L()                                                                                              \
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(4)" ::: "memory");                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
+    __builtin_amdgcn_s_barrier();                                                                                \
+    __builtin_amdgcn_sched_barrier(0);
+#define TN_END_M()                                                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
+    __builtin_amdgcn_s_barrier();                                                                                \
+    __builtin_amdgcn_sched_barrier(0);
+#define TN_FRAG(LO, HI) __builtin_bit_cast(bf16x8, (u32x4){LO.x, LO.y, HI.x, HI.y})
+    // the n block index runs back and forth over consecutive rows of MFMAs: one operand changes per instruction
+#define TN_MFMA()                                                                                                \
+    __builtin_amdgcn_s_setprio(1);                                                                               \
+    _Pragma("unroll") for (int ib_ = 0; ib_ < 8; ++ib_)                                                          \
+        _Pragma("unroll") for (int j0_ = 0; j0_ < 4; ++j0_) {                                                    \
+            const int jb_ = (ib_ & 1) ? 3 - j0_ : j0_;                                                           \
+            acc[ib_][jb_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(TN_FRAG(xl[ib_], xh[ib_]), TN_FRAG(yl[jb_], yh[jb_]), acc[ib_][jb_], 0, 0, 0); \
+        }                                                                                                        \
+    __builtin_amdgcn_s_setprio(0);
+#define TN_MFMA_CS(COND)                                                                                         \
+    {                                                                                                            \
+        /* (indexed by a loop variable: with literal indices this hipcc folds yl[0].x to undef -- it does not see the   \
+           asm statements that wrote it -- and all four MFMAs read one garbage register) */                       \
+        bf16x8 yy_[4];                                                                                           \
+        _Pragma("unroll") for (int jb_ = 0; jb_ < 4; ++jb_) yy_[jb_] = TN_FRAG(yl[jb_], yh[jb_]);                \
+        asm volatile("s_cmp_eq_u32 %9, 0\n\ts_cbranch_scc1 1f\n\t"                                              \
+                     "v_mfma_f32_16x16x32_bf16 %0, %4, %5, %0\n\tv_mfma_f32_16x16x32_bf16 %1, %4, %6, %1\n\t"     \
+                     "v_mfma_f32_16x16x32_bf16 %2, %4, %7, %2\n\tv_mfma_f32_16x16x32_bf16 %3, %4, %8, %3\n1:"     \
+                     : "+v"(acs[0]), "+v"(acs[1]), "+v"(acs[2]), "+v"(acs[3])                                    \
+                     : "v"(ones4), "v"(yy_[0]), "v"(yy_[1]), "v"(yy_[2]), "v"(yy_[3]), "s"(COND) : "scc");           \
+    }
+    // one K-step in stage STG (see the interval table in the header)
+#define TN_KSTEP(STG)                                                                                            \
+    {                                                                                                            \
+        const unsigned cs_k_ = (unsigned)__builtin_amdgcn_readfirstlane((cs_on && cs_u == 0) ? 1 : 0);                                                  \
+        cs_u = cs_u + 1 == p.tk ? 0 : cs_u + 1;                                                                  \
+        TN_READ(0, STG);                                                                                         \
+        TN_DMA_Y((STG) ^ 1);                                                                                     \
+        TN_WAIT_L();                                                                                             \
+        TN_MFMA_CS(cs_k_);                                                                                       \
+        TN_MFMA();                                                                                               \
+        TN_END_M();                                                                                              \
+        TN_READ(1, STG);                                                                                         \
+        TN_DMA_X(STG);                                                                                           \
+        TN_WAIT_L();                                                                                             \
+        TN_MFMA_CS(cs_k_);                                                                                       \
+        TN_MFMA();                                                                                               \
+        TN_END_M();                                                                                              \
+    }
+    int cs_u = (step0 % p.tk + p.tk - kt) % p.tk;        // (step - kt) mod tk of the next K-step: 0 = this workgroup's turn
+    int u = 0;
+    for (; u + 1 < nsteps; u += 2) { TN_KSTEP(0); TN_KSTEP(1); }
+    if (u < nsteps) TN_KSTEP(0);
+    if (!grp) __builtin_amdgcn_s_barrier();      // group 0 waits for the interval group 1 is behind
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    if (cs_on && lane < 16) {      // partial row (split, kt): all 16 rows of the result are the same sums
+        float* o = p.ws_colsum + ((int64_t)split * p.tk + kt) * p.N + n0 + 64 * wq + lane;
 #pragma unroll
-    for (int ib = 0; ib < 4; ++ib)
+        for (int jb = 0; jb < 4; ++jb) o[16 * jb] = acs[jb][0];
+    }
+    // ---- partial tile (fp32) in the accumulators' layout: ws[split][tile][wave][ib][jb][lane][4]; register r of
+    // acc[ib][jb] = C[n = n0 + 64 wq + 16 jb + (lane & 15)][k = k0 + 128 grp + 16 ib + 4 (lane >> 4) + r]
+    float* out = p.ws + (((int64_t)split * (p.tn * p.tk) + (nt * p.tk + kt)) * 8 + wave) * (32 * 256) + lane * 4;
 #pragma unroll
-        for (int jb = 0; jb < 2; ++jb) {
-            const int kcol = k0 + 64 * wave_k + 32 * jb + r;
+    for (int ib = 0; ib < 8; ++ib)
 #pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const int nrow = n0 + 128 * wave_n + 32 * ib + (t & 3) + 8 * (t >> 2) + 4 * hh;
-                out[(int64_t)nrow * p.K + kcol] = acc[ib][jb][t];
-            }
-        }
+        for (int jb = 0; jb < 4; ++jb) *reinterpret_cast<f32x4*>(out + (ib * 4 + jb) * 256) = acc[ib][jb];
 }
 
-// OUT32: the results are written as fp32 (the gradient of an fp32 parameter: no rounding, no cast kernel afterwards)
+// OUT32: the results are written as fp32 (the gradient of an fp32 parameter: no rounding, no cast kernel afterwards).
+// A block = the 512 accumulator quads of one (tile, wave, jb): 16 rows of C x 128 consecutive k.  Its eight waves read
+// 1 KiB runs of every partial and, between them, write whole 512-byte (fp32) row segments -- all writers of a cache line
+// sit in ONE block, hence on one XCD (numbered linearly over the quads, the two halves of a line came from two XCDs'
+// L2s as partial lines: the pass took 15 .. 26 us instead of 12 .. 15).
 template <bool OUT32>
-__global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const float* __restrict__ ws, int nsplit, int64_t nk, int K, int ldc,
+__global__ __launch_bounds__(512) void gemm_tn_reduce_kernel(const float* __restrict__ ws, int nsplit, int64_t nk, int tk, int ldc,
                                                              void* __restrict__ C, const float* __restrict__ ws_colsum, int N,
                                                              void* __restrict__ colsum_out) {
-    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (ws_colsum && i < N) {   // the first N / 4 threads also finish the column sums
-        f32x4 c = *reinterpret_cast<const f32x4*>(ws_colsum + i);
-        for (int j = 1; j < nsplit; ++j) c += *reinterpret_cast<const f32x4*>(ws_colsum + (int64_t)j * N + i);
-        if (OUT32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(colsum_out) + i) = c;
-        else {
-            const f32x2 lo = {c[0], c[1]}, hi = {c[2], c[3]};
-            uint2 w;
-            w.x = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2));
-            w.y = __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2));
-            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(colsum_out) + i) = w;
+    const int nmain = (int)(nk >> 11);
+    if ((int)blockIdx.x >= nmain) {
+        // the column sums: block -> 128 columns, thread -> (column quad t & 31, row class t >> 5): rows class, class + 16, ...
+        // of the nsplit x tk partial rows, all of a thread's loads in flight at once (the rows were written by other XCDs a
+        // moment ago -- each load is a trip to memory: summed one after the other by one thread per column quad, the 72 .. 84
+        // rows of a 768-wide gradient took 30 us), then the 16 classes in a fixed order through LDS
+        __shared__ f32x4 red[16][32];
+        const int cq = threadIdx.x & 31, cls = threadIdx.x >> 5;
+        const int64_t i0 = ((int64_t)(blockIdx.x - nmain) * 32 + cq) * 4;
+        const int nrows = nsplit * tk;
+        f32x4 c = {0.f, 0.f, 0.f, 0.f};
+        for (int j = cls; j < nrows; j += 16) c += *reinterpret_cast<const f32x4*>(ws_colsum + (int64_t)j * N + i0);
+        red[cls][cq] = c;
+        __syncthreads();
+        if (cls == 0) {
+            f32x4 t = red[0][cq];
+#pragma unroll
+            for (int g = 1; g < 16; ++g) t += red[g][cq];
+            if (OUT32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(colsum_out) + i0) = t;
+            else {
+                const f32x2 lo = {t[0], t[1]}, hi = {t[2], t[3]};
+                uint2 w;
+                w.x = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2));
+                w.y = __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2));
+                *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(colsum_out) + i0) = w;
+            }
         }
+        return;
     }
-    if (i >= nk) return;
+    // this thread's quad in the accumulators' layout [tile][wave][ib][jb][lane] (see the end of gemm_tn_kernel)
+    const int jb = blockIdx.x & 3, wave = (blockIdx.x >> 2) & 7, tile = blockIdx.x >> 5;
+    const int ib = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t i = ((((int64_t)tile * 8 + wave) * 8 + ib) * 4 + jb) * 256 + lane * 4;
     // four partials in flight per thread (a plain loop waits for each one before asking for the next); the order of
     // the additions is fixed, so the result is reproducible
     f32x4 s4[4];
@@ -258,7 +319,9 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const float* __rest
     }
     for (; j < nsplit; ++j) s4[0] += *reinterpret_cast<const f32x4*>(ws + (int64_t)j * nk + i);
     const f32x4 s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
-    const int64_t n = i / K, k = i % K;
+    const int nt = tile / tk, kt = tile - nt * tk;
+    const int64_t n = nt * TILE + 64 * (wave & 3) + 16 * jb + (lane & 15);
+    const int k = kt * TILE + 128 * (wave >> 2) + 16 * ib + 4 * (lane >> 4);
     if (OUT32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(C) + n * ldc + k) = s;
     else {
         const f32x2 lo = {s[0], s[1]}, hi = {s[2], s[3]};
@@ -287,7 +350,7 @@ extern "C" int64_t trx_gemm_tn_ws_bytes(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0 || N % TILE || K % TILE) return -1;
     int tn, tk, ns, sps;
     plan(M, N, K, &tn, &tk, &ns, &sps);
-    return (int64_t)ns * ((int64_t)N * K + N) * (int64_t)sizeof(float);   // partial tiles + partial column sums
+    return (int64_t)ns * ((int64_t)N * K + (int64_t)tk * N) * (int64_t)sizeof(float);   // partial tiles + partial column sums (one row per split and k tile)
 }
 
 extern "C" int trx_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, void* ws, void* C, int ldc, void* colsum_bf16,
@@ -296,6 +359,8 @@ extern "C" int trx_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, 
     if (!A || !B || !C || !ws || M <= 0 || N <= 0 || K <= 0) return TRX_NN_EINVAL;
     if (colsum_bf16 && (reinterpret_cast<uintptr_t>(colsum_bf16) & 7)) return TRX_NN_EINVAL;
     if (N % TILE || K % TILE || lda < N || ldb < K || ldc < K || (lda | ldb) % 8 || ldc % 4) return TRX_NN_EINVAL;
+    // the operands are addressed through buffer descriptors: 32-bit byte offsets, a little past the last row
+    if (((int64_t)M + 4 * BM) * lda * 2 >= (1ll << 32) || ((int64_t)M + 4 * BM) * ldb * 2 >= (1ll << 32)) return TRX_NN_EINVAL;
     if (((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(ws)) & 15) ||
         (reinterpret_cast<uintptr_t>(C) & (out_f32 ? 15 : 7)) || (out_f32 && colsum_bf16 && (reinterpret_cast<uintptr_t>(colsum_bf16) & 15)))
         return TRX_NN_EINVAL;
@@ -318,10 +383,10 @@ extern "C" int trx_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, 
     hipLaunchKernelGGL(gemm_tn_kernel, dim3(p.tn * p.tk * p.nsplit), dim3(THREADS), LDS_TOTAL, st, p);
     const int64_t nk = (int64_t)N * K;
     if (out_f32)
-        hipLaunchKernelGGL(gemm_tn_reduce_kernel<true>, dim3((unsigned)((nk / 4 + 255) / 256)), dim3(256), 0, st, (const float*)ws, p.nsplit,
-                           nk, K, ldc, C, p.ws_colsum, N, colsum_bf16);
+        hipLaunchKernelGGL(gemm_tn_reduce_kernel<true>, dim3((unsigned)(nk / 2048 + (p.ws_colsum ? N / 128 : 0))), dim3(512), 0, st, (const float*)ws, p.nsplit,
+                           nk, p.tk, ldc, C, p.ws_colsum, N, colsum_bf16);
     else
-        hipLaunchKernelGGL(gemm_tn_reduce_kernel<false>, dim3((unsigned)((nk / 4 + 255) / 256)), dim3(256), 0, st, (const float*)ws, p.nsplit,
-                           nk, K, ldc, C, p.ws_colsum, N, colsum_bf16);
+        hipLaunchKernelGGL(gemm_tn_reduce_kernel<false>, dim3((unsigned)(nk / 2048 + (p.ws_colsum ? N / 128 : 0))), dim3(512), 0, st, (const float*)ws, p.nsplit,
+                           nk, p.tk, ldc, C, p.ws_colsum, N, colsum_bf16);
     return hipGetLastError() == hipSuccess ? TRX_NN_OK : TRX_NN_EHIP;
 }
