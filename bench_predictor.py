@@ -56,10 +56,10 @@ def train_step_bench(dev, steps=10, dtype=torch.bfloat16, L=512, T=160):
             with torch.autocast("cuda", dtype=dtype):
                 loss, _ = p.training_step(batch)
             if scaler is None:
-                loss.backward()
+                ops.backward(loss)          # what the trainer calls (main.py): the weight gradients as one grouped launch
                 opt.step()
             else:
-                scaler.scale(loss).backward()
+                ops.backward(scaler.scale(loss))
                 scaler.step(opt); scaler.update()
             opt.zero_grad(set_to_none=True)
             return loss
@@ -277,7 +277,7 @@ def live_rows(dev, P=204800, N=40000):
     def step():
         with torch.autocast("cuda", dtype=torch.bfloat16):
             loss, _ = p.training_step(batch, labels)
-        loss.backward(); opt.step(); opt.zero_grad(set_to_none=True)
+        ops.backward(loss); opt.step(); opt.zero_grad(set_to_none=True)
     step_ms = timeit(step, iters=8, warm=4)
     del p, opt
     torch.cuda.empty_cache()

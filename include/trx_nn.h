@@ -153,6 +153,26 @@ int trx_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, void* ws, v
  * Linear, computed from the A tiles while they are in LDS for dW.  out_f32 != 0: C and colsum are written as fp32
  * (the gradients of fp32 parameters: no rounding and no cast afterwards; C then 16-byte aligned), else bf16. */
 
+/* MANY weight gradients in one persistent launch (dW_i = dY_i^T X_i for every Linear layer of a backward pass: the callers
+ * of torch.nn.functional.linear that the reference's model makes through Hugging Face, /root/reference textreact/model.py:21-31,
+ * differentiated by autograd at main.py:164-175).  Nothing is split and nothing is reduced: with all of a step's problems in
+ * one work list every CU gets whole 256 x 256 tiles, and a tile's fp32 sums go straight to C.  Per problem: A [M, N] (dY),
+ * B [M, K] (X), bf16 row-major with leading dimensions lda / ldb; C [N, K] fp32 with ldc; colsum [N] fp32 or NULL (the bias
+ * gradient, from the same pass).  The constraints of trx_gemm_tn_bf16 apply to every problem.
+ * Three steps, so that no memory management hides behind the ABI:
+ *   trx_gemm_tn_grouped_block_bytes  size of the plan for these problems (-1: a problem this path does not take)
+ *   trx_gemm_tn_grouped_plan         writes the plan (problem table, per-XCD tile lists, zeroed counters) into the caller's
+ *                                    HOST memory
+ *   trx_gemm_tn_grouped_run          the caller has copied the block to the device (stream-ordered before this call);
+ *                                    launches on `stream`.  host_block is read during the call only. */
+typedef struct trx_tn_problem {
+    const void* A; const void* B; void* C; void* colsum;
+    int M, N, K, lda, ldb, ldc;
+} trx_tn_problem;
+int64_t trx_gemm_tn_grouped_block_bytes(const trx_tn_problem* problems, int n);
+int trx_gemm_tn_grouped_plan(const trx_tn_problem* problems, int n, void* host_block, int64_t host_bytes);
+int trx_gemm_tn_grouped_run(const void* dev_block, const void* host_block, void* stream);
+
 const char* trx_nn_last_error(void);
 const char* trx_nn_version(void);
 

@@ -758,6 +758,56 @@ def test_split_contraction_weight_gradient_gemm(M, N, K):
     assert torch.equal(ops.gemm_tn(sl, x), ops.gemm_tn(sl.contiguous(), x))
 
 
+def test_grouped_weight_gradient_gemm():
+    """trx_gemm_tn_grouped_*: many dW = dY^T X (+ db) in one persistent launch, nothing split, straight into the gradient:
+    the step's shapes, ragged token counts, a slice of a packed gradient; against fp32 matmul and against the per-call form"""
+    shapes = [(16384, 2304, 768), (1000, 768, 768), (5120, 3072, 768), (437, 256, 512), (64, 256, 256), (1, 256, 256), (13984, 768, 3072),
+              (4256, 1536, 768), (130, 512, 256)]
+    probs, refs = [], []
+    for i, (M, N, K) in enumerate(shapes):
+        dy, x = _rand(M, N + (256 if i % 3 == 0 else 0), dtype=torch.bfloat16, seed=10 + i), _rand(M, K, dtype=torch.bfloat16, seed=50 + i)
+        dy = dy[:, :N] if i % 3 == 0 else dy
+        dw = torch.full((N, K), float("nan"), device="cuda"); db = torch.full((N,), float("nan"), device="cuda") if i % 2 == 0 else None
+        probs.append((dy, x, dw, db)); refs.append((dy.float().t() @ x.float(), dy.float().sum(0)))
+    ops.gemm_tn_grouped(probs)
+    first = [(p[2].clone(), None if p[3] is None else p[3].clone()) for p in probs]
+    for (dy, x, dw, db), (rw, rb), (M, N, K) in zip(probs, refs, shapes):
+        assert float((dw - rw).abs().max()) <= 2e-5 * max(1.0, float(rw.abs().max())) * max(1.0, M / 512), (M, N, K)      # fp32 sums, two orders
+        if db is not None:
+            assert float((db - rb).abs().max()) <= 2e-5 * max(1.0, float(rb.abs().max())) * max(1.0, M / 512), (M, N, K)
+        if M >= 64:
+            c, cs = ops.gemm_tn(dy, x, colsum=True, out_dtype=torch.float32)                # the split form: other order, same sums
+            assert float((dw - c).abs().max()) <= 1e-5 * max(1.0, float(rw.abs().max())) * max(1.0, M / 512)
+    ops.gemm_tn_grouped(probs)                                                               # no split, no atomics: reproducible
+    for (dy, x, dw, db), (w0, b0) in zip(probs, first):
+        assert torch.equal(dw, w0) and (db is None or torch.equal(db, b0))
+
+
+def test_deferred_weight_gradients_equal_the_per_layer_calls():
+    """ops.backward (deferred_wgrad): the gradients a backward pass leaves in .grad with the one grouped launch at its end =
+    those of the per-layer calls, also when a .grad is already there (gradient accumulation) and for packed projections"""
+    x = _rand(3, 171, 768, dtype=torch.bfloat16, seed=1)
+    ws = [(_rand(768, 768, seed=2 + i) * 0.05) for i in range(3)]; bs = [_rand(768, seed=7 + i) for i in range(3)]
+    w2, dy = _rand(256, 2304, seed=11) * 0.05, _rand(3, 171, 256, dtype=torch.bfloat16, seed=12)
+    res = []
+    for mode in ("deferred", "percall"):
+        xs = x.clone().requires_grad_(True)
+        pw = [w.clone().requires_grad_(True) for w in ws]; pb = [b.clone().requires_grad_(True) for b in bs]
+        pw2 = w2.clone().requires_grad_(True)
+        for rep in range(2):                   # the second pass adds to the first's .grad
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                h = ops.linear_multi(xs, pw, pb)
+                y = ops.linear_multi(h, [pw2])
+            if mode == "deferred":
+                ops.backward((y.float() * dy.float()).sum())
+            else:
+                (y.float() * dy.float()).sum().backward()
+        res.append([xs.grad] + [p.grad for p in pw + pb + [pw2]])
+    for a, b in zip(*res):
+        assert a is not None and a.shape == b.shape and a.dtype == b.dtype
+        assert float((a.float() - b.float()).abs().max()) <= 2e-5 * max(1.0, float(b.float().abs().max()))
+
+
 @pytest.mark.parametrize("B,L", [(4, 128), (4, 131), (3, 437), (1, 63)])
 def test_linear_with_our_weight_gradient_equals_autograd(B, L):
     """token counts that are not multiples of 64 included (batches padded to their longest sequence); fewer than 64

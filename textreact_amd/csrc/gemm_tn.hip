@@ -52,7 +52,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 constexpr int TILE = 256, BM = 64, THREADS = 512;
 constexpr int BAND2 = 2 * BM * 256;           // a band's two stages: 32 KiB
-constexpr int LDS_TOTAL = 4 * BAND2;          // X0 X1 Y0 Y1: 128 KiB
+constexpr int LDS_TOTAL = 4 * BAND2 + 16;     // X0 X1 Y0 Y1: 128 KiB (+ one word of the grouped form)
 
 struct Params {
     const bf16_t* A; const bf16_t* B; float* ws;
@@ -61,30 +61,106 @@ struct Params {
     int tn, tk, nsplit, steps_per_split;
 };
 
-__global__ __launch_bounds__(THREADS, 2) void gemm_tn_kernel(Params p) {
+// ---- the grouped form (trx_gemm_tn_grouped_*): MANY weight gradients in one persistent launch.  A split contraction
+// pays for its partials whatever the shape -- every workgroup stores its 256 KB of accumulators and a second launch reads
+// them back: 64 MB each way per call, 25 of a call's 40 .. 78 us -- and one training step makes 88 such calls.  All of a
+// step's weight gradients together are ~1,900 tiles of 256 x 256: enough to give every CU whole tiles, so nothing is split,
+// nothing is reduced, a tile's result goes straight to the gradient.  Work list: problems are dealt to the 8 XCDs whole
+// (longest first; the tiles of a problem read the same token rows and find them in their XCD's L2), the workgroups of an XCD
+// (blockIdx & 7, the placement the scan kernel relies on as well: speed only) draw tiles from their XCD's list through
+// an atomic counter.
+struct GProblem {            // device format, 64 bytes
+    const bf16_t* A; const bf16_t* B; float* C; float* colsum;
+    int M, N, K, lda, ldb, ldc, tn, tk;
+};
+struct GHeader { unsigned magic; int nproblems, nitems, off_counters, off_begin, off_probs, off_items, bytes; };
+struct GParams { const char* block; int off_counters, off_begin, off_probs, off_items; };
+constexpr unsigned G_MAGIC = 0x54524e47u;      // "TRNG"
+constexpr int LDS_NEXT = 4 * (2 * BM * 256);   // one word behind the stages: the next item's index (grouped form)
+
+#define TN_SGPR64(P) ((((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned long long)(P) >> 32))) << 32) | \
+                      (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)(P)))
+
+template <bool GROUPED>
+__global__ __launch_bounds__(THREADS, 2) void gemm_tn_kernel(Params p, GParams g) {
     extern __shared__ __attribute__((aligned(128))) char smem[];
     typedef __attribute__((address_space(3))) void lds_void;
     typedef __attribute__((address_space(1))) const void gbl_void;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2, wq = wave & 3;
-    // Which (split, tile) a workgroup takes.  The tn x tk tiles of ONE split read the same token rows: numbered
-    // split-SLOWEST and dealt to the XCDs in contiguous runs (the scan kernel's bijective remap), an XCD holds the tiles
-    // of one or two splits, which walk the same rows in step and find each other's lines in L2 (round 3: numbered
-    // split-fastest every operand byte came tk or tn times over the fabric).
-    int split, kt, nt;
+    const unsigned ldsbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const int xb = grp ^ 1;                      // the X band this wave's group STAGES (it reads band grp)
+
+    // ---- transposed fragment addresses.  Lane -> row 4 gg + qq of a 32-row half (+ 16 for the second read), columns
+    // 4 pp .. 4 pp + 3 of a 16-column block; the read hands lane l the 4 rows' values of column l & 15.
+    unsigned fx[8], fy[4];
     {
+        const int gg = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
+        const int r7 = 4 * (gg & 1) + qq;                   // (row & 7) of every row this lane addresses
+        const unsigned rowoff = ldsbase + (unsigned)((4 * gg + qq) * 256 + 8 * (pp & 1));
+#pragma unroll
+        for (int ib = 0; ib < 8; ++ib) fx[ib] = rowoff + (unsigned)(grp * BAND2 + (((2 * ib + (pp >> 1)) ^ (2 * r7)) << 4));
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) fy[jb] = rowoff + (unsigned)((2 + (wq >> 1)) * BAND2 + (((8 * (wq & 1) + 2 * jb + (pp >> 1)) ^ (2 * r7)) << 4));
+    }
+    u32x4 ones4 = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+    asm volatile("" : "+v"(ones4));     // one register quad, not a constant rebuilt per use
+
+    // grouped form: this XCD's list and the first item
+    int g_end = 0, g_item = 0;
+    int* g_counter = nullptr;
+    if constexpr (GROUPED) {
+        const int x = blockIdx.x & 7;
+        const int* begin = reinterpret_cast<const int*>(g.block + g.off_begin);
+        g_end = begin[x + 1];
+        g_counter = reinterpret_cast<int*>(const_cast<char*>(g.block) + g.off_counters) + x;
+        int first = 0;
+        if (tid == 0) first = begin[x] + __hip_atomic_fetch_add(g_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (wave == 0) {
+            first = __builtin_amdgcn_readfirstlane(first);
+            asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" :: "v"(ldsbase + LDS_NEXT), "v"(first) : "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        unsigned it;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(it) : "v"(ldsbase + LDS_NEXT) : "memory");
+        g_item = __builtin_amdgcn_readfirstlane((int)it);
+        __builtin_amdgcn_s_barrier();       // everybody has read the word before wave 0 writes the next one
+    }
+  for (;;) {
+    // ---- what this workgroup computes now
+    const bf16_t* pA; const bf16_t* pB;
+    int pM, pN, pK, plda, pldb, ptk, split, kt, nt, step0, nsteps;
+    float* gC = nullptr; float* gcolsum = nullptr; int gldc = 0;
+    if constexpr (GROUPED) {
+        if (g_item >= g_end) break;
+        const unsigned item = (unsigned)__builtin_amdgcn_readfirstlane((int)reinterpret_cast<const unsigned*>(g.block + g.off_items)[g_item]);
+        const GProblem& q = reinterpret_cast<const GProblem*>(g.block + g.off_probs)[item >> 12];
+        const int t = (int)(item & 4095u);
+        // (wave-uniform values that arrive through vector loads -- the table is ordinary global memory -- made scalar by hand)
+        auto sp = [](const void* v) { return reinterpret_cast<const void*>(TN_SGPR64(v)); };
+        auto si = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+        pA = (const bf16_t*)sp(q.A); pB = (const bf16_t*)sp(q.B); pM = si(q.M); pN = si(q.N); pK = si(q.K); plda = si(q.lda); pldb = si(q.ldb);
+        ptk = si(q.tk); gC = (float*)sp(q.C); gcolsum = (float*)sp(q.colsum); gldc = si(q.ldc);
+        kt = t % ptk; nt = t / ptk; split = 0; step0 = 0;
+        nsteps = (pM + BM - 1) / BM;
+    } else {
+        // Which (split, tile) a workgroup takes.  The tn x tk tiles of ONE split read the same token rows: numbered
+        // split-SLOWEST and dealt to the XCDs in contiguous runs (the scan kernel's bijective remap), an XCD holds the tiles
+        // of one or two splits, which walk the same rows in step and find each other's lines in L2 (round 3: numbered
+        // split-fastest every operand byte came tk or tn times over the fabric).
         const int bid = blockIdx.x, nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = bid & 7;
         const int v = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);      // XCD x owns [base, base + q (+1))
         const int tiles = p.tn * p.tk;
         split = v / tiles;
         const int t = v - split * tiles;
         kt = t % p.tk; nt = t / p.tk;
+        pA = p.A; pB = p.B; pM = p.M; pN = p.N; pK = p.K; plda = p.lda; pldb = p.ldb; ptk = p.tk;
+        const int total_steps = (pM + BM - 1) / BM;          // the last step may be partial: rows >= M read as zeros
+        step0 = split * p.steps_per_split;
+        nsteps = min(p.steps_per_split, total_steps - step0);     // >= 1 (plan())
     }
     const int n0 = nt * TILE, k0 = kt * TILE;
-    const int total_steps = (p.M + BM - 1) / BM;          // the last step may be partial: rows >= M read as zeros (A) / row M-1 (B)
-    const int step0 = split * p.steps_per_split;
-    const int nsteps = min(p.steps_per_split, total_steps - step0);     // >= 1 (plan())
 
     // ---- staging geometry: a piece = one buffer_load_dwordx4 ... lds = 4 rows x 256 B of a band, written lane-linear
     // (row 4 piece + lane / 16, slot lane % 16); slot s of row r receives global chunk s ^ (2 (r & 7)).  In a load phase
@@ -94,8 +170,6 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_tn_kernel(Params p) {
     // past the descriptor's last byte and arrives in LDS as zeros (tools/experiments/buffer_lds_oob.hip), so the last
     // step of a token count that is not a multiple of 64 needs no code at all, and neither do the pieces the DMA
     // cursors issue past the end of a split (rows of the next split, or zeros; their stages are dead).
-    const unsigned ldsbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-    const int xb = grp ^ 1;                      // the X band this wave's group STAGES (it reads band grp)
     unsigned voY[4], voX[4];                     // lane offsets of this wave's four pieces (bytes)
     {
         const int prow = lane >> 4, pslot = lane & 15;
@@ -103,12 +177,12 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_tn_kernel(Params p) {
         const int c_odd = c_even ^ 8;               //                          1:              4 + prow
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            voY[i] = (unsigned)(((16 * wq + 4 * i + prow) * p.lda + ((i & 1) ? c_odd : c_even) * 8) * 2);
-            voX[i] = (unsigned)(((16 * wq + 4 * i + prow) * p.ldb + ((i & 1) ? c_odd : c_even) * 8) * 2);
+            voY[i] = (unsigned)(((16 * wq + 4 * i + prow) * plda + ((i & 1) ? c_odd : c_even) * 8) * 2);
+            voX[i] = (unsigned)(((16 * wq + 4 * i + prow) * pldb + ((i & 1) ? c_odd : c_even) * 8) * 2);
         }
     }
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)(unsigned)((((int64_t)p.M - 1) * p.lda + p.N) * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)(unsigned)((((int64_t)p.M - 1) * p.ldb + p.K) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)pA, 0, (int)(unsigned)((((int64_t)pM - 1) * plda + pN) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)pB, 0, (int)(unsigned)((((int64_t)pM - 1) * pldb + pK) * 2), 0x00020000);
 #define TN_BUF16(RSRC, VOFF, SOFF, LDSADDR)                                                                      \
     {                                                                                                            \
         const unsigned la_ = (unsigned)__builtin_amdgcn_readfirstlane((int)(LDSADDR));                            \
@@ -116,9 +190,9 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_tn_kernel(Params p) {
         asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" :: "v"(VOFF), "s"(RSRC), "s"(so_), "s"(la_) : "memory", "m0"); \
     }
     // DMA cursors (wave-uniform byte offsets of the K-step whose band this wave's group stages next)
-    const unsigned kstepY = (unsigned)(BM * p.lda * 2), kstepX = (unsigned)(BM * p.ldb * 2);
-    unsigned soY = (unsigned)((((int64_t)step0 + 1) * BM * p.lda + n0 + 128 * grp) * 2);
-    unsigned soX = (unsigned)((((int64_t)step0 + (grp ? 2 : 1)) * BM * p.ldb + k0 + 128 * xb) * 2);
+    const unsigned kstepY = (unsigned)(BM * plda * 2), kstepX = (unsigned)(BM * pldb * 2);
+    unsigned soY = (unsigned)((((int64_t)step0 + 1) * BM * plda + n0 + 128 * grp) * 2);
+    unsigned soX = (unsigned)((((int64_t)step0 + (grp ? 2 : 1)) * BM * pldb + k0 + 128 * xb) * 2);
 #define TN_DMA_Y(STG)                                                                                            \
     {                                                                                                            \
         const unsigned l_ = ldsbase + (unsigned)((2 + grp) * BAND2 + (STG) * 16384 + wq * 4096);                 \
@@ -133,17 +207,6 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_tn_kernel(Params p) {
         soX += kstepX;                                                                                           \
     }
 
-    // ---- transposed fragment addresses.  Lane -> row 4 gg + qq of a 32-row half (+ 16 for the second read), columns
-    // 4 pp .. 4 pp + 3 of a 16-column block; the read hands lane l the 4 rows' values of column l & 15.
-    const int gg = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
-    const int r7 = 4 * (gg & 1) + qq;                   // (row & 7) of every row this lane addresses
-    const unsigned rowoff = ldsbase + (unsigned)((4 * gg + qq) * 256 + 8 * (pp & 1));
-    unsigned fx[8], fy[4];
-#pragma unroll
-    for (int ib = 0; ib < 8; ++ib) fx[ib] = rowoff + (unsigned)(grp * BAND2 + (((2 * ib + (pp >> 1)) ^ (2 * r7)) << 4));
-#pragma unroll
-    for (int jb = 0; jb < 4; ++jb) fy[jb] = rowoff + (unsigned)((2 + (wq >> 1)) * BAND2 + (((8 * (wq & 1) + 2 * jb + (pp >> 1)) ^ (2 * r7)) << 4));
-
     f32x4 acc[8][4];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -157,21 +220,19 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_tn_kernel(Params p) {
     // (step % tk) == kt (group 0 only) and writes its own partial row -- every workgroup of the launch pays the same
     // 1 / (2 tk) of 12.5 %.  The four MFMAs and the scalar branch around them are ONE asm statement: with a branch it can
     // see in this loop hipcc spills (40 .. 536 bytes of scratch per lane, depending on where the condition sits).
-    const bool cs_on = p.ws_colsum != nullptr && grp == 0;
+    const int cs_tk = GROUPED ? 1 : ptk;      // grouped form: the workgroup of a tile row's first k tile takes every K-step
+    const bool cs_on = grp == 0 && (GROUPED ? (gcolsum != nullptr && kt == 0) : p.ws_colsum != nullptr);
     f32x4 acs[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) acs[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    u32x4 ones4 = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
-    asm volatile("" : "+v"(ones4));     // one register quad, not a constant rebuilt per use
-
     // ---- prologue: K-step 0 in full and X0 of K-step 1 (all waves: 2 pieces of each band) ----
     {
         const int prow = lane >> 4, pslot = lane & 15;
-        const unsigned so0A = (unsigned)(((int64_t)step0 * BM * p.lda + n0) * 2), so0B = (unsigned)(((int64_t)step0 * BM * p.ldb + k0) * 2);
+        const unsigned so0A = (unsigned)(((int64_t)step0 * BM * plda + n0) * 2), so0B = (unsigned)(((int64_t)step0 * BM * pldb + k0) * 2);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int pc = 2 * wave + i, row = 4 * pc + prow, chunk = (pslot ^ (2 * prow)) ^ (8 * i);
-            const unsigned va = (unsigned)((row * p.lda + chunk * 8) * 2), vb = (unsigned)((row * p.ldb + chunk * 8) * 2);
+            const unsigned va = (unsigned)((row * plda + chunk * 8) * 2), vb = (unsigned)((row * pldb + chunk * 8) * 2);
             const unsigned l = ldsbase + (unsigned)(pc * 1024);
             TN_BUF16(rsB, vb, so0B, l + 0 * BAND2);
             TN_BUF16(rsB, vb, so0B + 256u, l + 1 * BAND2);
@@ -179,7 +240,20 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_tn_kernel(Params p) {
             TN_BUF16(rsA, va, so0A + 256u, l + 3 * BAND2);
             TN_BUF16(rsB, vb, so0B + kstepX, l + 0 * BAND2 + 16384);
         }
+        // grouped form: the NEXT item's index is drawn here, under the prologue's loads (its wait is the one below), and
+        // parked in LDS for the end of this item
+        int nxt = 0;
+        if constexpr (GROUPED) {
+            if (tid == 0) nxt = __hip_atomic_fetch_add(g_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if constexpr (GROUPED) {
+            if (wave == 0) {
+                const int first_of_xcd = reinterpret_cast<const int*>(g.block + g.off_begin)[blockIdx.x & 7];
+                nxt = __builtin_amdgcn_readfirstlane(nxt) + first_of_xcd;
+                asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" :: "v"(ldsbase + LDS_NEXT), "v"(nxt) : "memory");
+            }
+        }
         __builtin_amdgcn_s_barrier();
     }
     if (grp) __builtin_amdgcn_s_barrier();       // group 1 runs one interval late
@@ -230,7 +304,7 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_tn_kernel(Params p) {
 #define TN_KSTEP(STG)                                                                                            \
     {                                                                                                            \
         const unsigned cs_k_ = (unsigned)__builtin_amdgcn_readfirstlane((cs_on && cs_u == 0) ? 1 : 0);                                                  \
-        cs_u = cs_u + 1 == p.tk ? 0 : cs_u + 1;                                                                  \
+        cs_u = cs_u + 1 == cs_tk ? 0 : cs_u + 1;                                                                  \
         TN_READ(0, STG);                                                                                         \
         TN_DMA_Y((STG) ^ 1);                                                                                     \
         TN_WAIT_L();                                                                                             \
@@ -244,25 +318,48 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_tn_kernel(Params p) {
         TN_MFMA();                                                                                               \
         TN_END_M();                                                                                              \
     }
-    int cs_u = (step0 % p.tk + p.tk - kt) % p.tk;        // (step - kt) mod tk of the next K-step: 0 = this workgroup's turn
+    int cs_u = GROUPED ? 0 : (step0 % ptk + ptk - kt) % ptk;        // (step - kt) mod tk of the next K-step: 0 = this workgroup's turn
     int u = 0;
     for (; u + 1 < nsteps; u += 2) { TN_KSTEP(0); TN_KSTEP(1); }
     if (u < nsteps) TN_KSTEP(0);
     if (!grp) __builtin_amdgcn_s_barrier();      // group 0 waits for the interval group 1 is behind
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    if (cs_on && lane < 16) {      // partial row (split, kt): all 16 rows of the result are the same sums
-        float* o = p.ws_colsum + ((int64_t)split * p.tk + kt) * p.N + n0 + 64 * wq + lane;
+    if constexpr (GROUPED) {
+        // ---- the tile itself, straight into the gradient: register r of acc[ib][jb] =
+        // C[n = n0 + 64 wq + 16 jb + (lane & 15)][k = k0 + 128 grp + 16 ib + 4 (lane >> 4) + r]
+        if (cs_on && lane < 16) {
+            float* o = gcolsum + n0 + 64 * wq + lane;
 #pragma unroll
-        for (int jb = 0; jb < 4; ++jb) o[16 * jb] = acs[jb][0];
+            for (int jb = 0; jb < 4; ++jb) o[16 * jb] = acs[jb][0];
+        }
+        float* out = gC + (int64_t)(n0 + 64 * wq + (lane & 15)) * gldc + k0 + 128 * grp + 4 * (lane >> 4);
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+            for (int ib = 0; ib < 8; ++ib) *reinterpret_cast<f32x4*>(out + (int64_t)16 * jb * gldc + 16 * ib) = acc[ib][jb];
+        // the next item: every wave's pieces have landed (its own vmcnt(0) above, then this barrier), so the next prologue
+        // may write the stages; the index was parked by wave 0 during this item's prologue
+        __builtin_amdgcn_s_barrier();
+        unsigned it;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(it) : "v"(ldsbase + LDS_NEXT) : "memory");
+        g_item = __builtin_amdgcn_readfirstlane((int)it);
+        __builtin_amdgcn_s_barrier();       // everybody has read the word before wave 0 parks the next one
+    } else {
+        if (cs_on && lane < 16) {      // partial row (split, kt): all 16 rows of the result are the same sums
+            float* o = p.ws_colsum + ((int64_t)split * p.tk + kt) * p.N + n0 + 64 * wq + lane;
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) o[16 * jb] = acs[jb][0];
+        }
+        // ---- partial tile (fp32) in the accumulators' layout: ws[split][tile][wave][ib][jb][lane][4]
+        float* out = p.ws + (((int64_t)split * (p.tn * p.tk) + (nt * p.tk + kt)) * 8 + wave) * (32 * 256) + lane * 4;
+#pragma unroll
+        for (int ib = 0; ib < 8; ++ib)
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) *reinterpret_cast<f32x4*>(out + (ib * 4 + jb) * 256) = acc[ib][jb];
+        break;
     }
-    // ---- partial tile (fp32) in the accumulators' layout: ws[split][tile][wave][ib][jb][lane][4]; register r of
-    // acc[ib][jb] = C[n = n0 + 64 wq + 16 jb + (lane & 15)][k = k0 + 128 grp + 16 ib + 4 (lane >> 4) + r]
-    float* out = p.ws + (((int64_t)split * (p.tn * p.tk) + (nt * p.tk + kt)) * 8 + wave) * (32 * 256) + lane * 4;
-#pragma unroll
-    for (int ib = 0; ib < 8; ++ib)
-#pragma unroll
-        for (int jb = 0; jb < 4; ++jb) *reinterpret_cast<f32x4*>(out + (ib * 4 + jb) * 256) = acc[ib][jb];
+  }
 }
 
 // OUT32: the results are written as fp32 (the gradient of an fp32 parameter: no rounding, no cast kernel afterwards).
@@ -375,12 +472,12 @@ extern "C" int trx_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, 
     if (hipGetDevice(&dev) != hipSuccess) return TRX_NN_EHIP;
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(attr_devs.load(std::memory_order_acquire) & bit)) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL) != hipSuccess)
             return TRX_NN_EHIP;
         attr_devs.fetch_or(bit, std::memory_order_release);
     }
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(p.tn * p.tk * p.nsplit), dim3(THREADS), LDS_TOTAL, st, p);
+    hipLaunchKernelGGL(gemm_tn_kernel<false>, dim3(p.tn * p.tk * p.nsplit), dim3(THREADS), LDS_TOTAL, st, p, GParams{});
     const int64_t nk = (int64_t)N * K;
     if (out_f32)
         hipLaunchKernelGGL(gemm_tn_reduce_kernel<true>, dim3((unsigned)(nk / 2048 + (p.ws_colsum ? N / 128 : 0))), dim3(512), 0, st, (const float*)ws, p.nsplit,
@@ -388,5 +485,106 @@ extern "C" int trx_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, 
     else
         hipLaunchKernelGGL(gemm_tn_reduce_kernel<false>, dim3((unsigned)(nk / 2048 + (p.ws_colsum ? N / 128 : 0))), dim3(512), 0, st, (const float*)ws, p.nsplit,
                            nk, p.tk, ldc, C, p.ws_colsum, N, colsum_bf16);
+    return hipGetLastError() == hipSuccess ? TRX_NN_OK : TRX_NN_EHIP;
+}
+
+// ---- the grouped form: plan on the host into the caller's (pinned) memory, upload by the caller, run ----
+#include <algorithm>
+#include <vector>
+
+static bool tn_problem_ok(const trx_tn_problem& q) {
+    using namespace trxtn;
+    if (!q.A || !q.B || !q.C || q.M <= 0 || q.N <= 0 || q.K <= 0) return false;
+    if (q.N % TILE || q.K % TILE || q.lda < q.N || q.ldb < q.K || q.ldc < q.K || (q.lda | q.ldb) % 8 || q.ldc % 4) return false;
+    if (((int64_t)q.M + 4 * BM) * q.lda * 2 >= (1ll << 32) || ((int64_t)q.M + 4 * BM) * q.ldb * 2 >= (1ll << 32)) return false;
+    if ((reinterpret_cast<uintptr_t>(q.A) | reinterpret_cast<uintptr_t>(q.B) | reinterpret_cast<uintptr_t>(q.C)) & 15) return false;
+    if (q.colsum && (reinterpret_cast<uintptr_t>(q.colsum) & 3)) return false;
+    if ((q.N / TILE) * (q.K / TILE) > 4096) return false;
+    return true;
+}
+
+extern "C" int64_t trx_gemm_tn_grouped_block_bytes(const trx_tn_problem* probs, int n) {
+    using namespace trxtn;
+    if (!probs || n <= 0 || n >= (1 << 19)) return -1;
+    int64_t items = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!tn_problem_ok(probs[i])) return -1;
+        items += (int64_t)(probs[i].N / TILE) * (probs[i].K / TILE);
+    }
+    return (int64_t)sizeof(GHeader) + 8 * 4 + 12 * 4 + (int64_t)n * (int64_t)sizeof(GProblem) + items * 4;
+}
+
+extern "C" int trx_gemm_tn_grouped_plan(const trx_tn_problem* probs, int n, void* host_block, int64_t host_bytes) {
+    using namespace trxtn;
+    const int64_t need = trx_gemm_tn_grouped_block_bytes(probs, n);
+    if (need < 0 || !host_block || host_bytes < need) return TRX_NN_EINVAL;
+    char* base = static_cast<char*>(host_block);
+    GHeader* h = reinterpret_cast<GHeader*>(base);
+    h->magic = G_MAGIC; h->nproblems = n;
+    h->off_counters = (int)sizeof(GHeader);
+    h->off_begin = h->off_counters + 8 * 4;
+    h->off_probs = h->off_begin + 12 * 4;
+    h->off_items = h->off_probs + n * (int)sizeof(GProblem);
+    int* counters = reinterpret_cast<int*>(base + h->off_counters);
+    int* begin = reinterpret_cast<int*>(base + h->off_begin);
+    GProblem* gp = reinterpret_cast<GProblem*>(base + h->off_probs);
+    unsigned* items = reinterpret_cast<unsigned*>(base + h->off_items);
+    for (int x = 0; x < 8; ++x) counters[x] = 0;
+    // problems to the 8 XCDs whole, longest first into the least loaded (work = tiles x 64-row steps) ...
+    std::vector<int> order(n);
+    std::vector<int64_t> work(n);
+    for (int i = 0; i < n; ++i) {
+        const trx_tn_problem& q = probs[i];
+        gp[i] = GProblem{(const bf16_t*)q.A, (const bf16_t*)q.B, (float*)q.C, (float*)q.colsum, q.M, q.N, q.K, q.lda, q.ldb, q.ldc, q.N / TILE, q.K / TILE};
+        order[i] = i;
+        work[i] = (int64_t)gp[i].tn * gp[i].tk * ((q.M + BM - 1) / BM);
+    }
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return work[a] > work[b]; });
+    std::vector<int> bin[8];
+    int64_t load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i : order) {
+        int best = 0;
+        for (int x = 1; x < 8; ++x) if (load[x] < load[best]) best = x;
+        bin[best].push_back(i); load[best] += work[i];
+    }
+    // ... and inside an XCD's list the problems with the most steps per tile first, so that what is left when the list
+    // runs dry are short tiles
+    int pos = 0;
+    for (int x = 0; x < 8; ++x) {
+        begin[x] = pos;
+        std::stable_sort(bin[x].begin(), bin[x].end(), [&](int a, int b) { return probs[a].M > probs[b].M; });
+        for (int i : bin[x])
+            for (int t = 0; t < gp[i].tn * gp[i].tk; ++t) items[pos++] = ((unsigned)i << 12) | (unsigned)t;
+    }
+    begin[8] = pos;
+    h->nitems = pos;
+    h->bytes = (int)need;
+    return TRX_NN_OK;
+}
+
+extern "C" int trx_gemm_tn_grouped_run(const void* dev_block, const void* host_block, void* stream) {
+    using namespace trxtn;
+    if (!dev_block || !host_block) return TRX_NN_EINVAL;
+    const GHeader* h = static_cast<const GHeader*>(host_block);
+    if (h->magic != G_MAGIC || h->nitems <= 0) return TRX_NN_EINVAL;
+    static std::atomic<unsigned long long> attr_devs{0ull};
+    static std::atomic<int> cus[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return TRX_NN_EHIP;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(attr_devs.load(std::memory_order_acquire) & bit)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL) != hipSuccess)
+            return TRX_NN_EHIP;
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return TRX_NN_EHIP;
+        cus[dev & 63].store(n, std::memory_order_relaxed);
+        attr_devs.fetch_or(bit, std::memory_order_release);
+    }
+    // one workgroup per CU (128 KiB of LDS each), a multiple of 8 so that every XCD has the same number
+    int nwg = cus[dev & 63].load(std::memory_order_relaxed) & ~7;
+    if (nwg < 8) nwg = 8;
+    if (nwg > ((h->nitems + 7) & ~7)) nwg = (h->nitems + 7) & ~7;
+    GParams g{static_cast<const char*>(dev_block), h->off_counters, h->off_begin, h->off_probs, h->off_items};
+    hipLaunchKernelGGL(gemm_tn_kernel<true>, dim3(nwg), dim3(THREADS), LDS_TOTAL, (hipStream_t)stream, Params{}, g);
     return hipGetLastError() == hipSuccess ? TRX_NN_OK : TRX_NN_EHIP;
 }

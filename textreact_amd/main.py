@@ -488,7 +488,7 @@ def main(argv=None):
                     continue
                 with _autocast(args, device):
                     total, logs = module.training_step(batch_in, batch_out)
-                (scaler.scale(total / args.gradient_accumulation_steps)).backward()
+                ops.backward(scaler.scale(total / args.gradient_accumulation_steps))      # the Linear layers' weight gradients: one grouped launch
                 micro += 1
                 if micro % args.gradient_accumulation_steps == 0 or b0 + args.batch_size >= len(mine):
                     if world > 1:

@@ -21,7 +21,7 @@ SYMBOLS = ["trx_add_layernorm_fwd", "trx_add_layernorm_bwd", "trx_add_layernorm_
            "trx_add_layernorm_fwd_dropout", "trx_add_layernorm_bwd_dropout", "trx_attention_fwd_dropout",
            "trx_attention_bwd_dropout", "trx_dropout_keep_mask", "trx_add_layernorm_fwd_mixed",
            "trx_add_layernorm_bwd_mixed", "trx_attention_fwd_kvcache", "trx_attention_fwd_strided",
-           "trx_attention_bwd_strided", "trx_attention_decode_gather", "trx_gemm_tn_bf16", "trx_gemm_tn_ws_bytes", "trx_nn_last_error", "trx_nn_version",
+           "trx_attention_bwd_strided", "trx_attention_decode_gather", "trx_gemm_tn_bf16", "trx_gemm_tn_ws_bytes", "trx_gemm_tn_grouped_block_bytes", "trx_gemm_tn_grouped_plan", "trx_gemm_tn_grouped_run", "trx_nn_last_error", "trx_nn_version",
            "trx_nn_set_seed_device", "trx_attention_bwd_ws", "trx_attention_bwd_ws_bytes"]
 
 
@@ -59,6 +59,10 @@ def lib():
         L.trx_gemm_tn_ws_bytes.argtypes = [i32, i32, i32]
         L.trx_gemm_tn_ws_bytes.restype = i64
         L.trx_gemm_tn_bf16.argtypes = [vp, i32, vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, vp]
+        L.trx_gemm_tn_grouped_block_bytes.argtypes = [vp, i32]
+        L.trx_gemm_tn_grouped_block_bytes.restype = i64
+        L.trx_gemm_tn_grouped_plan.argtypes = [vp, i32, vp, i64]
+        L.trx_gemm_tn_grouped_run.argtypes = [vp, vp, vp]
         L.trx_nn_set_seed_device.argtypes = [vp]
         L.trx_attention_bwd_ws_bytes.argtypes = [i32, i32, i32]
         L.trx_attention_bwd_ws_bytes.restype = i64
@@ -546,6 +550,71 @@ def gemm_tn(a, b, colsum=False, out_dtype=torch.bfloat16):
     return (out, cs) if colsum else out
 
 
+class _TnProblem(ctypes.Structure):      # include/trx_nn.h: trx_tn_problem
+    _fields_ = [("A", ctypes.c_void_p), ("B", ctypes.c_void_p), ("C", ctypes.c_void_p), ("colsum", ctypes.c_void_p),
+                ("M", ctypes.c_int), ("N", ctypes.c_int), ("K", ctypes.c_int), ("lda", ctypes.c_int), ("ldb", ctypes.c_int), ("ldc", ctypes.c_int)]
+
+
+def gemm_tn_grouped(problems):
+    """dW_i = a_i^T b_i (and db_i = a_i.sum(0)) for a LIST of (a [M, N] bf16, b [M, K] bf16, dw [N, K] fp32, db [N] fp32 or
+    None) in ONE persistent launch (trx_gemm_tn_grouped_*): nothing is split over workgroups, nothing is reduced -- every
+    tile's sums go straight into dw.  Stream-ordered; the plan travels through pinned memory."""
+    n = len(problems)
+    if n == 0:
+        return
+    arr = (_TnProblem * n)()
+    for q, (a, b, dw, db) in zip(arr, problems):
+        q.A, q.B, q.C, q.colsum = a.data_ptr(), b.data_ptr(), dw.data_ptr(), (db.data_ptr() if db is not None else None)
+        q.M, q.N, q.K, q.lda, q.ldb, q.ldc = a.shape[0], a.shape[1], b.shape[1], a.stride(0), b.stride(0), dw.stride(0)
+    nbytes = lib().trx_gemm_tn_grouped_block_bytes(ctypes.addressof(arr), n)
+    if nbytes < 0:
+        raise TrxNNError("trx_gemm_tn_grouped: a problem this path does not take (see gemm_tn_ok)")
+    host = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
+    _check(lib().trx_gemm_tn_grouped_plan(ctypes.addressof(arr), n, host.data_ptr(), nbytes))
+    dev = host.to(problems[0][0].device, non_blocking=True)
+    _check(lib().trx_gemm_tn_grouped_run(dev.data_ptr(), host.data_ptr(), _stream(problems[0][0])))
+
+
+_deferred = None      # a list while a deferred_wgrad() block is open: the weight gradients of the backward pass inside it
+
+
+class deferred_wgrad:
+    """`with ops.deferred_wgrad(): loss.backward()` -- the Linear layers' weight (and bias) gradients of this backward pass
+    are computed at the END of the block by one grouped launch (gemm_tn_grouped) instead of one split-contraction call per
+    layer, and are put into (or added to) the parameters' .grad directly: their backward nodes hand autograd no gradient
+    for them, so per-parameter hooks do not fire (DistributedDataParallel's reducer among them; main.py reduces the
+    gradients itself after the backward pass).  Outside such a block -- torch.autograd.grad, a stream capture -- every
+    layer makes its own call as before."""
+
+    def __enter__(self):
+        global _deferred
+        self.prev, _deferred = _deferred, []
+        return self
+
+    def __exit__(self, et, ev, tb):
+        global _deferred
+        pending, _deferred = _deferred, self.prev
+        if et is None and pending:
+            gemm_tn_grouped([(dy, x, dw, db) for (dy, x, dw, db, _) in pending])
+            for (_, _, dw, db, slots) in pending:
+                for (param, is_bias, lo, hi) in slots:
+                    g = (db if is_bias else dw)[lo:hi]
+                    if param.grad is None:
+                        param.grad = g
+                    else:
+                        param.grad.add_(g)
+        return False
+
+
+def backward(loss):
+    """loss.backward() with the weight gradients of the Linear layers deferred into one grouped launch"""
+    if loss.is_cuda and not torch.cuda.is_current_stream_capturing() and os.environ.get("TRX_NN_WGRAD", "grouped") != "percall":      # (the switch: same-box A/B)
+        with deferred_wgrad():
+            loss.backward()
+    else:
+        loss.backward()
+
+
 class WeightShadows:
     """bf16 copies of the Linear parameters a model feeds to `linear`, refreshed by ONE multi-tensor copy per forward.
 
@@ -656,6 +725,7 @@ class _LinearWgrad(torch.autograd.Function):
         # casts have (a parameter changed between a forward and its backward goes unnoticed there as well)
         ctx.save_for_backward(x)
         ctx.w16 = w16
+        ctx.params = params
         ctx.n, ctx.has_bias = n, biases is not None
         ctx.outs = [w.shape[0] for w in weights]
         ctx.wdtype = weights[0].dtype
@@ -682,6 +752,22 @@ class _LinearWgrad(torch.autograd.Function):
             dx = torch.matmul(dy2, w16).view(x.shape)
         need_w = any(ctx.needs_input_grad[2:2 + n])
         want_db = ctx.has_bias and any(ctx.needs_input_grad[2 + n:])
+        if (need_w and _deferred is not None and ctx.wdtype == torch.float32 and gemm_tn_ok(dy2, x2)
+                and not torch.cuda.is_current_stream_capturing()):
+            # deferred_wgrad(): this layer's problem joins the pass's one grouped launch; autograd gets no gradient for the
+            # parameters here -- the end of the block assigns them
+            ntot = dy2.shape[1]
+            dwbuf = torch.empty((ntot, x2.shape[1]), dtype=torch.float32, device=dy2.device)
+            dbbuf = torch.empty(ntot, dtype=torch.float32, device=dy2.device) if want_db else None
+            slots, lo = [], 0
+            for j, o in enumerate(ctx.outs):
+                if ctx.needs_input_grad[2 + j]:
+                    slots.append((ctx.params[j], False, lo, lo + o))
+                if want_db and ctx.needs_input_grad[2 + n + j]:
+                    slots.append((ctx.params[n + j], True, lo, lo + o))
+                lo += o
+            _deferred.append((dy2, x2, dwbuf, dbbuf, slots))
+            return (dx, None) + (None,) * len(ctx.params)
         if need_w:
             od = torch.float32 if ctx.wdtype == torch.float32 else torch.bfloat16
             if gemm_tn_ok(dy2, x2):        # any token count >= 64: the kernel zero-fills the rows past the end of its last step

@@ -3,7 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from torch.profiler import profile, ProfilerActivity
-from textreact_amd.predictor import train
+from textreact_amd.predictor import train, ops
 from textreact_amd.predictor.model import Config
 dev, B, L, T = torch.device("cuda", 0), 32, 512, 160
 g = torch.Generator().manual_seed(0)
@@ -14,7 +14,7 @@ opt, _ = train.configure_optimizer(p, 1e-4, 0.01, 1000, 0.02)
 def step():
     with torch.autocast("cuda", dtype=torch.bfloat16):
         loss, _ = p.training_step(batch)
-    loss.backward(); opt.step(); opt.zero_grad(set_to_none=True); train.mark_parameters_updated(p)
+    ops.backward(loss); opt.step(); opt.zero_grad(set_to_none=True); train.mark_parameters_updated(p)
 for _ in range(3): step()
 torch.cuda.synchronize()
 want = sys.argv[1] if len(sys.argv) > 1 else None      # e.g. "fill": which aten::fill_ / zero_ calls does a step make (by input shape)

@@ -6,7 +6,7 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from textreact_amd.predictor import train
+from textreact_amd.predictor import train, ops
 from textreact_amd.predictor.model import Config
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 4
@@ -23,7 +23,7 @@ opt, _ = train.configure_optimizer(p, 1e-4, 0.01, 1000, 0.02)
 for i in range(steps):
     with torch.autocast("cuda", dtype=torch.bfloat16):
         loss, _ = p.training_step(batch)
-    loss.backward(); opt.step(); opt.zero_grad(set_to_none=True)
+    ops.backward(loss); opt.step(); opt.zero_grad(set_to_none=True)
     train.mark_parameters_updated(p)
 torch.cuda.synchronize()
 print("steps", steps, "loss %.4f" % float(loss))

@@ -5,7 +5,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench_predictor as bp
-from textreact_amd.predictor import train
+from textreact_amd.predictor import train, ops
 from textreact_amd.predictor.model import Config
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 160
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 5
@@ -20,7 +20,7 @@ opt, _ = train.configure_optimizer(p, 1e-4, 0.01, 1000, 0.02)
 def step():
     with torch.autocast("cuda", dtype=torch.bfloat16):
         loss, _ = p.training_step(batch)
-    loss.backward(); opt.step(); opt.zero_grad(set_to_none=True)
+    ops.backward(loss); opt.step(); opt.zero_grad(set_to_none=True)
     return loss
 ts = sorted(bp.timeit(step, iters=10, warm=4 if i == 0 else 0) for i in range(rounds))
 print("T=%d train step: median %.2f ms  min %.2f ms  (loss %.4f)  env %s" % (T, ts[len(ts) // 2], ts[0], float(step()), {k: v for k, v in os.environ.items() if k.startswith("TRX_")}))
