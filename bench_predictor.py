@@ -353,6 +353,22 @@ def main():
         tf = 2.0 * M * N * K / (ms * 1e-3) / 1e12
         out.append({"kernel": "gemm_tn (dW + db)", "what": name, "M": M, "N": N, "K": K, "ms": ms, "library_ms": ref,
                     "roofline": {"bound": "mfma", "achieved": tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": tf / 2500.0}})
+    # the same products the way the trainer runs them (ops.backward -> trx_gemm_tn_grouped_*): ALL weight gradients of one
+    # training step (B32 . L512 . T160: 48 encoder + 42 decoder Linear layers) as one persistent launch -- no split, no
+    # partials, no reduction launch
+    enc = [(32 * 512, 2304, 768), (32 * 512, 768, 768), (32 * 512, 3072, 768), (32 * 512, 768, 3072)] * 12
+    dec = [(32 * 160, 2304, 768), (32 * 160, 768, 768), (32 * 160, 768, 768), (32 * 512, 1536, 768), (32 * 160, 768, 768), (32 * 160, 3072, 768),
+           (32 * 160, 768, 3072)] * 6
+    shapes = sorted(set(enc + dec))
+    ops_ab = {sh: (torch.randn(sh[0], sh[1], device=dev).to(torch.bfloat16), torch.randn(sh[0], sh[2], device=dev).to(torch.bfloat16)) for sh in shapes}
+    probs = [(ops_ab[sh][0], ops_ab[sh][1], torch.empty(sh[1], sh[2], device=dev), torch.empty(sh[1], device=dev)) for sh in enc + dec]
+    ms = timeit(lambda: ops.gemm_tn_grouped(probs), iters=10)
+    fl = sum(2.0 * m * n * k for (m, n, k) in enc + dec)
+    percall = sum(timeit(lambda: ops.gemm_tn(ops_ab[sh][0], ops_ab[sh][1], colsum=True, out_dtype=torch.float32), iters=10) * (enc + dec).count(sh) for sh in shapes)
+    tf = fl / (ms * 1e-3) / 1e12
+    out.append({"kernel": "gemm_tn grouped (dW + db of every Linear layer of a step)", "problems": len(probs), "flop": fl, "ms": ms,
+                "per_call_form_ms": percall, "roofline": {"bound": "mfma", "achieved": tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": tf / 2500.0}})
+    del probs, ops_ab
     for o in out:
         print(json.dumps(o), flush=True)
     for rows in (lambda: train_step_bench(dev),              # RetroSyn: decoder length 160 (train_RetroSyn_tf.sh:33)

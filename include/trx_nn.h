@@ -172,6 +172,11 @@ typedef struct trx_tn_problem {
 int64_t trx_gemm_tn_grouped_block_bytes(const trx_tn_problem* problems, int n);
 int trx_gemm_tn_grouped_plan(const trx_tn_problem* problems, int n, void* host_block, int64_t host_bytes);
 int trx_gemm_tn_grouped_run(const void* dev_block, const void* host_block, void* stream);
+/* The three steps in one call: the plan is staged in pinned memory the library owns (a ring of event-guarded slots; on a
+ * capturing stream a block of its own that is never reused, because the captured copy reads it again at every replay) and
+ * copied into dev_block (the caller's device memory, trx_gemm_tn_grouped_block_bytes() bytes, alive until the launch has
+ * run) on `stream`. */
+int trx_gemm_tn_grouped(const trx_tn_problem* problems, int n, void* dev_block, int64_t dev_bytes, void* stream);
 
 const char* trx_nn_last_error(void);
 const char* trx_nn_version(void);

@@ -588,3 +588,59 @@ extern "C" int trx_gemm_tn_grouped_run(const void* dev_block, const void* host_b
     hipLaunchKernelGGL(gemm_tn_kernel<true>, dim3(nwg), dim3(THREADS), LDS_TOTAL, (hipStream_t)stream, Params{}, g);
     return hipGetLastError() == hipSuccess ? TRX_NN_OK : TRX_NN_EHIP;
 }
+
+// The three steps in one call, with the plan staged in pinned memory the LIBRARY owns: a ring of slots, each guarded by an
+// event (a slot is rewritten only after the copy that read it has run); on a capturing stream a block of its own that is
+// never reused -- the captured copy reads it again at every replay (the operands' addresses in it are the graph's static
+// ones).  dev_block: trx_gemm_tn_grouped_block_bytes() bytes of device memory, the caller's, alive until the launch has run.
+#include <mutex>
+namespace trxtn {
+struct PlanSlot { void* host = nullptr; int64_t bytes = 0; hipEvent_t ev = nullptr; bool used = false; };
+static std::mutex g_plan_mu;
+static PlanSlot g_plan_ring[8];
+static int g_plan_next = 0;
+static void* pinned_alloc(int64_t bytes) {
+    // (allocation is not a stream operation, but a capture in "global" mode rejects it: relaxed for the length of the call)
+    hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+    hipThreadExchangeStreamCaptureMode(&mode);
+    void* p = nullptr;
+    const hipError_t e = hipHostMalloc(&p, (size_t)bytes, hipHostMallocDefault);
+    hipThreadExchangeStreamCaptureMode(&mode);
+    return e == hipSuccess ? p : nullptr;
+}
+}  // namespace trxtn
+
+extern "C" int trx_gemm_tn_grouped(const trx_tn_problem* probs, int n, void* dev_block, int64_t dev_bytes, void* stream) {
+    using namespace trxtn;
+    const int64_t need = trx_gemm_tn_grouped_block_bytes(probs, n);
+    if (need < 0 || !dev_block || dev_bytes < need) return TRX_NN_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess) return TRX_NN_EHIP;
+    std::lock_guard<std::mutex> lock(g_plan_mu);
+    void* host = nullptr;
+    PlanSlot* slot = nullptr;
+    if (cap != hipStreamCaptureStatusNone) {
+        host = pinned_alloc(need);                    // lives as long as the process: the graph may be replayed until then
+        if (!host) return TRX_NN_EHIP;
+    } else {
+        slot = &g_plan_ring[g_plan_next];
+        g_plan_next = (g_plan_next + 1) & 7;
+        if (slot->used && hipEventSynchronize(slot->ev) != hipSuccess) return TRX_NN_EHIP;
+        if (slot->bytes < need) {
+            if (slot->host) hipHostFree(slot->host);
+            slot->host = pinned_alloc(need); slot->bytes = slot->host ? need : 0;
+            if (!slot->host) return TRX_NN_EHIP;
+        }
+        if (!slot->ev && hipEventCreateWithFlags(&slot->ev, hipEventDisableTiming) != hipSuccess) return TRX_NN_EHIP;
+        host = slot->host;
+    }
+    int rc = trx_gemm_tn_grouped_plan(probs, n, host, need);
+    if (rc != TRX_NN_OK) return rc;
+    if (hipMemcpyAsync(dev_block, host, (size_t)need, hipMemcpyHostToDevice, st) != hipSuccess) return TRX_NN_EHIP;
+    if (slot) {
+        if (hipEventRecord(slot->ev, st) != hipSuccess) return TRX_NN_EHIP;
+        slot->used = true;
+    }
+    return trx_gemm_tn_grouped_run(dev_block, host, stream);
+}

@@ -21,7 +21,7 @@ SYMBOLS = ["trx_add_layernorm_fwd", "trx_add_layernorm_bwd", "trx_add_layernorm_
            "trx_add_layernorm_fwd_dropout", "trx_add_layernorm_bwd_dropout", "trx_attention_fwd_dropout",
            "trx_attention_bwd_dropout", "trx_dropout_keep_mask", "trx_add_layernorm_fwd_mixed",
            "trx_add_layernorm_bwd_mixed", "trx_attention_fwd_kvcache", "trx_attention_fwd_strided",
-           "trx_attention_bwd_strided", "trx_attention_decode_gather", "trx_gemm_tn_bf16", "trx_gemm_tn_ws_bytes", "trx_gemm_tn_grouped_block_bytes", "trx_gemm_tn_grouped_plan", "trx_gemm_tn_grouped_run", "trx_nn_last_error", "trx_nn_version",
+           "trx_attention_bwd_strided", "trx_attention_decode_gather", "trx_gemm_tn_bf16", "trx_gemm_tn_ws_bytes", "trx_gemm_tn_grouped_block_bytes", "trx_gemm_tn_grouped_plan", "trx_gemm_tn_grouped_run", "trx_gemm_tn_grouped", "trx_nn_last_error", "trx_nn_version",
            "trx_nn_set_seed_device", "trx_attention_bwd_ws", "trx_attention_bwd_ws_bytes"]
 
 
@@ -63,6 +63,7 @@ def lib():
         L.trx_gemm_tn_grouped_block_bytes.restype = i64
         L.trx_gemm_tn_grouped_plan.argtypes = [vp, i32, vp, i64]
         L.trx_gemm_tn_grouped_run.argtypes = [vp, vp, vp]
+        L.trx_gemm_tn_grouped.argtypes = [vp, i32, vp, i64, vp]
         L.trx_nn_set_seed_device.argtypes = [vp]
         L.trx_attention_bwd_ws_bytes.argtypes = [i32, i32, i32]
         L.trx_attention_bwd_ws_bytes.restype = i64
@@ -558,7 +559,7 @@ class _TnProblem(ctypes.Structure):      # include/trx_nn.h: trx_tn_problem
 def gemm_tn_grouped(problems):
     """dW_i = a_i^T b_i (and db_i = a_i.sum(0)) for a LIST of (a [M, N] bf16, b [M, K] bf16, dw [N, K] fp32, db [N] fp32 or
     None) in ONE persistent launch (trx_gemm_tn_grouped_*): nothing is split over workgroups, nothing is reduced -- every
-    tile's sums go straight into dw.  Stream-ordered; the plan travels through pinned memory."""
+    tile's sums go straight into dw.  Stream-ordered; the plan travels through pinned memory the library owns."""
     n = len(problems)
     if n == 0:
         return
@@ -569,10 +570,8 @@ def gemm_tn_grouped(problems):
     nbytes = lib().trx_gemm_tn_grouped_block_bytes(ctypes.addressof(arr), n)
     if nbytes < 0:
         raise TrxNNError("trx_gemm_tn_grouped: a problem this path does not take (see gemm_tn_ok)")
-    host = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
-    _check(lib().trx_gemm_tn_grouped_plan(ctypes.addressof(arr), n, host.data_ptr(), nbytes))
-    dev = host.to(problems[0][0].device, non_blocking=True)
-    _check(lib().trx_gemm_tn_grouped_run(dev.data_ptr(), host.data_ptr(), _stream(problems[0][0])))
+    dev = torch.empty(nbytes, dtype=torch.uint8, device=problems[0][0].device)
+    _check(lib().trx_gemm_tn_grouped(ctypes.addressof(arr), n, dev.data_ptr(), nbytes, _stream(problems[0][0])))
 
 
 _deferred = None      # a list while a deferred_wgrad() block is open: the weight gradients of the backward pass inside it
@@ -583,8 +582,8 @@ class deferred_wgrad:
     are computed at the END of the block by one grouped launch (gemm_tn_grouped) instead of one split-contraction call per
     layer, and are put into (or added to) the parameters' .grad directly: their backward nodes hand autograd no gradient
     for them, so per-parameter hooks do not fire (DistributedDataParallel's reducer among them; main.py reduces the
-    gradients itself after the backward pass).  Outside such a block -- torch.autograd.grad, a stream capture -- every
-    layer makes its own call as before."""
+    gradients itself after the backward pass).  Outside such a block -- torch.autograd.grad -- every layer makes its own
+    call as before.  (Inside a stream capture the library keeps the plan's pinned block for the life of the process.)"""
 
     def __enter__(self):
         global _deferred
@@ -608,7 +607,7 @@ class deferred_wgrad:
 
 def backward(loss):
     """loss.backward() with the weight gradients of the Linear layers deferred into one grouped launch"""
-    if loss.is_cuda and not torch.cuda.is_current_stream_capturing() and os.environ.get("TRX_NN_WGRAD", "grouped") != "percall":      # (the switch: same-box A/B)
+    if loss.is_cuda and os.environ.get("TRX_NN_WGRAD", "grouped") != "percall":      # (the switch: same-box A/B)
         with deferred_wgrad():
             loss.backward()
     else:
@@ -752,8 +751,7 @@ class _LinearWgrad(torch.autograd.Function):
             dx = torch.matmul(dy2, w16).view(x.shape)
         need_w = any(ctx.needs_input_grad[2:2 + n])
         want_db = ctx.has_bias and any(ctx.needs_input_grad[2 + n:])
-        if (need_w and _deferred is not None and ctx.wdtype == torch.float32 and gemm_tn_ok(dy2, x2)
-                and not torch.cuda.is_current_stream_capturing()):
+        if need_w and _deferred is not None and ctx.wdtype == torch.float32 and gemm_tn_ok(dy2, x2):
             # deferred_wgrad(): this layer's problem joins the pass's one grouped launch; autograd gets no gradient for the
             # parameters here -- the end of the block assigns them
             ntot = dy2.shape[1]

@@ -251,7 +251,7 @@ class GraphedStep:
             ctx = contextlib.nullcontext()
         with ctx:
             total, logs = self.module.training_step(batch_in, batch_out)
-        ops.backward(total)       # (inside a capture: plain backward, one weight-gradient call per layer)
+        ops.backward(total)       # the Linear layers' weight gradients: one grouped launch (also inside the capture)
         if self.max_grad_norm is not None:
             torch.nn.utils.clip_grad_norm_(self.module.parameters(), self.max_grad_norm)
         self.opt.step()
