@@ -11,8 +11,8 @@
 //
 // Everything is deterministic (no atomics): probabilities are recomputed from the forward's
 // log-sum-exp, once per pass.
-//   prep    negl[b,h,i] = -lse_i / scale,  negd[b,h,i] = -(dO_i . O_i)
-//   pass 1  workgroup = 128 queries (a lane per query), streams 64-key tiles of K and V:
+//   pass 1  workgroup = 128 queries (a lane per query), streams 64-key tiles of K and V; first makes the per-query scalars
+//           negl[b,h,i] = -lse_i / scale, negd[b,h,i] = -(dO_i . O_i) and leaves them for pass 2 (a launch of their own until round 4):
 //             S^T = K Q^T (+ mask/scale),  dP^T = V dO^T - delta,  P = exp(scale S - lse),
 //             dS = P (dP - delta),  dQ^T += K^T dS^T                       -> dQ = scale * acc
 //   pass 2  workgroup = 128 keys (a lane per key), streams 64-query tiles of Q and dO:
@@ -36,32 +36,6 @@ __device__ __forceinline__ int lane_again() {
 __device__ __forceinline__ int bwd_sw(int row) {
     const int x = (row >> 1) & 7;
     return ((x & 1) << 2) | (x >> 1);
-}
-
-__global__ __launch_bounds__(256) void attention_bwd_prep_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
-                                                                 const float* __restrict__ lse, int B, int H, int Lq, float scale,
-                                                                 float* __restrict__ negl, float* __restrict__ negd) {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;   // (b * Lq + i) * H + h: rows of 64 are contiguous
-    if (idx >= (int64_t)B * Lq * H) return;
-    const int h = (int)(idx % H);
-    const int64_t bi = idx / H;
-    const int i = (int)(bi % Lq), b = (int)(bi / Lq);
-    const uint4* op = reinterpret_cast<const uint4*>(o + idx * 64);
-    const uint4* dp = reinterpret_cast<const uint4*>(dout + idx * 64);
-    float acc = 0.f;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const uint4 a = op[c], d = dp[c];
-        const unsigned aw[4] = {a.x, a.y, a.z, a.w}, dw[4] = {d.x, d.y, d.z, d.w};
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            acc = __builtin_fmaf(__uint_as_float(aw[w] << 16), __uint_as_float(dw[w] << 16), acc);
-            acc = __builtin_fmaf(__uint_as_float(aw[w] & 0xffff0000u), __uint_as_float(dw[w] & 0xffff0000u), acc);
-        }
-    }
-    const int64_t w = ((int64_t)b * H + h) * Lq + i;
-    negl[w] = -lse[w] / scale;
-    negd[w] = -acc;
 }
 
 template <int N> struct ic_ { static constexpr int value = N; };     // a compile-time switch handed to a generic lambda
@@ -98,7 +72,8 @@ template <int MM, bool DROP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attention_bwd_dq_mfma_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, const float* __restrict__ mask,
     int causal, int B, int H, int Lq, int Lk, float scale, const bf16_t* __restrict__ dout,
-    const float* __restrict__ negl, const float* __restrict__ negd, bf16_t* __restrict__ dq, DropArgs da) {
+    const bf16_t* __restrict__ o, const float* __restrict__ lse, float* __restrict__ negl, float* __restrict__ negd,
+    bf16_t* __restrict__ dq, DropArgs da) {
     __shared__ __attribute__((aligned(128))) char lds[3 * 16384];   // ring of 3: [K 8 KiB | V 8 KiB]
     __shared__ __attribute__((aligned(16))) float ldsM[1024];       // key mask / scale of 16 tiles
     typedef __attribute__((address_space(3))) void lds_void;
@@ -146,8 +121,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const float sl2 = scale * 1.44269504088896340736f;
     const float inv_scale = 1.0f / scale;
     const float mask_floor = -268435456.0f / sl2;     // the forward kernel's floor of a masked score (nn_ops.hip: TRX_MASK_INIT)
-    const float nlsl2 = negl[((int64_t)b * H + h) * Lq + qc] * sl2;   // -lse * log2 e
-    const float nd = negd[((int64_t)b * H + h) * Lq + qc];            // -delta
+    // The per-query scalars are made HERE (rounds 1-3: a launch of their own, 12 us in front of every backward): a lane holds
+    // half of its query's dO row as fragments already, the same half of the O row is four more loads, and the two halves
+    // meet through one cross-half shuffle.  Written out for the dk/dv pass, which runs after this launch.
+    float nd;
+    {
+        const int64_t rod = (((int64_t)b * Lq + qc) * H + h) * 64 + 8 * hh;
+        float part = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const uint4 ow = *reinterpret_cast<const uint4*>(o + rod + 16 * s);
+            const uint4 dw = __builtin_bit_cast(uint4, dof[s]);
+            const unsigned aw[4] = {ow.x, ow.y, ow.z, ow.w}, bw[4] = {dw.x, dw.y, dw.z, dw.w};
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                part = __builtin_fmaf(__uint_as_float(aw[w] << 16), __uint_as_float(bw[w] << 16), part);
+                part = __builtin_fmaf(__uint_as_float(aw[w] & 0xffff0000u), __uint_as_float(bw[w] & 0xffff0000u), part);
+            }
+        }
+        nd = -(part + __shfl_xor(part, 32, 64));                      // -delta = -(dO . O)
+    }
+    const int64_t wq_ = ((int64_t)b * H + h) * Lq + qc;
+    const float nl = -lse[wq_] / scale;
+    const float nlsl2 = nl * sl2;                                     // -lse * log2 e
+    if (kp == 0 && hh == 0 && qidx < Lq) { negl[wq_] = nl; negd[wq_] = nd; }
     f32x16 a0, a1;   // dQ^T: d blocks 0..31 / 32..63 x this wave's 32 queries
 #pragma unroll
     for (int t = 0; t < 16; ++t) { a0[t] = 0.f; a1[t] = 0.f; }

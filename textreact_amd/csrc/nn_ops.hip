@@ -1447,12 +1447,10 @@ static int attention_bwd_impl(const void* q, const void* k, const void* v, const
             return fail(TRX_NN_EHIP, "attention_bwd: scratch allocation failed");
         }
         float *negl = ws, *negd = ws + n;
-        hipLaunchKernelGGL(attention_bwd_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const bf16_t*)out,
-                           (const bf16_t*)dout, lse, B, H, Lq, scale, negl, negd);
         dim3 g1((unsigned)((int64_t)B * H * ((Lq + 127) / 128))), g2((unsigned)((int64_t)B * H * ((Lk + 127) / 128))), b2(256);
 #define TRX_LAUNCH_BWD(MM_, DROP_)                                                                                          \
     hipLaunchKernelGGL((attention_bwd_dq_mfma_kernel<MM_, DROP_>), g1, b2, 0, st, (const bf16_t*)q, (const bf16_t*)k,       \
-                       (const bf16_t*)v, mask, causal, B, H, Lq, Lk, scale, (const bf16_t*)dout, negl, negd, (bf16_t*)dq, da); \
+                       (const bf16_t*)v, mask, causal, B, H, Lq, Lk, scale, (const bf16_t*)dout, (const bf16_t*)out, lse, negl, negd, (bf16_t*)dq, da); \
     hipLaunchKernelGGL((attention_bwd_dkv_mfma_kernel<MM_, DROP_>), g2, b2, 0, st, (const bf16_t*)q, (const bf16_t*)k,      \
                        (const bf16_t*)v, mask, causal, B, H, Lq, Lk, scale, (const bf16_t*)dout, negl, negd, (bf16_t*)dk, (bf16_t*)dv, da)
         if (da.thr) {
