@@ -158,7 +158,8 @@ int trx_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, void* ws, v
  * differentiated by autograd at main.py:164-175).  Nothing is split and nothing is reduced: with all of a step's problems in
  * one work list every CU gets whole 256 x 256 tiles, and a tile's fp32 sums go straight to C.  Per problem: A [M, N] (dY),
  * B [M, K] (X), bf16 row-major with leading dimensions lda / ldb; C [N, K] fp32 with ldc; colsum [N] fp32 or NULL (the bias
- * gradient, from the same pass).  The constraints of trx_gemm_tn_bf16 apply to every problem.
+ * gradient, from the same pass).  The constraints of trx_gemm_tn_bf16 apply to every problem, except that N may be any
+ * multiple of 8 (a vocabulary projection).
  * Three steps, so that no memory management hides behind the ABI:
  *   trx_gemm_tn_grouped_block_bytes  size of the plan for these problems (-1: a problem this path does not take)
  *   trx_gemm_tn_grouped_plan         writes the plan (problem table, per-XCD tile lists, zeroed counters) into the caller's

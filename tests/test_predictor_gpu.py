@@ -762,7 +762,7 @@ def test_grouped_weight_gradient_gemm():
     """trx_gemm_tn_grouped_*: many dW = dY^T X (+ db) in one persistent launch, nothing split, straight into the gradient:
     the step's shapes, ragged token counts, a slice of a packed gradient; against fp32 matmul and against the per-call form"""
     shapes = [(16384, 2304, 768), (1000, 768, 768), (5120, 3072, 768), (437, 256, 512), (64, 256, 256), (1, 256, 256), (13984, 768, 3072),
-              (4256, 1536, 768), (130, 512, 256)]
+              (4256, 1536, 768), (130, 512, 256), (5120, 600, 768), (333, 8, 256), (200, 264, 256)]      # the last three: N % 256 != 0 (a vocabulary projection)
     probs, refs = [], []
     for i, (M, N, K) in enumerate(shapes):
         dy, x = _rand(M, N + (256 if i % 3 == 0 else 0), dtype=torch.bfloat16, seed=10 + i), _rand(M, K, dtype=torch.bfloat16, seed=50 + i)
@@ -775,7 +775,7 @@ def test_grouped_weight_gradient_gemm():
         assert float((dw - rw).abs().max()) <= 2e-5 * max(1.0, float(rw.abs().max())) * max(1.0, M / 512), (M, N, K)      # fp32 sums, two orders
         if db is not None:
             assert float((db - rb).abs().max()) <= 2e-5 * max(1.0, float(rb.abs().max())) * max(1.0, M / 512), (M, N, K)
-        if M >= 64:
+        if M >= 64 and N % 256 == 0:
             c, cs = ops.gemm_tn(dy, x, colsum=True, out_dtype=torch.float32)                # the split form: other order, same sums
             assert float((dw - c).abs().max()) <= 1e-5 * max(1.0, float(rw.abs().max())) * max(1.0, M / 512)
     ops.gemm_tn_grouped(probs)                                                               # no split, no atomics: reproducible

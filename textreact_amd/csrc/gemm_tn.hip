@@ -328,16 +328,22 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_tn_kernel(Params p, GParams g
     if constexpr (GROUPED) {
         // ---- the tile itself, straight into the gradient: register r of acc[ib][jb] =
         // C[n = n0 + 64 wq + 16 jb + (lane & 15)][k = k0 + 128 grp + 16 ib + 4 (lane >> 4) + r]
+        // (N need not be a multiple of the tile here -- a vocabulary projection: the columns of dY past N that the last tile row
+        // staged are the next token row's first values, finite, and what they produced is simply not stored)
         if (cs_on && lane < 16) {
             float* o = gcolsum + n0 + 64 * wq + lane;
 #pragma unroll
-            for (int jb = 0; jb < 4; ++jb) o[16 * jb] = acs[jb][0];
+            for (int jb = 0; jb < 4; ++jb)
+                if (n0 + 64 * wq + lane + 16 * jb < pN) o[16 * jb] = acs[jb][0];
         }
-        float* out = gC + (int64_t)(n0 + 64 * wq + (lane & 15)) * gldc + k0 + 128 * grp + 4 * (lane >> 4);
+        const int nrow0 = n0 + 64 * wq + (lane & 15);
+        float* out = gC + (int64_t)nrow0 * gldc + k0 + 128 * grp + 4 * (lane >> 4);
 #pragma unroll
         for (int jb = 0; jb < 4; ++jb)
+            if (nrow0 + 16 * jb < pN) {
 #pragma unroll
-            for (int ib = 0; ib < 8; ++ib) *reinterpret_cast<f32x4*>(out + (int64_t)16 * jb * gldc + 16 * ib) = acc[ib][jb];
+                for (int ib = 0; ib < 8; ++ib) *reinterpret_cast<f32x4*>(out + (int64_t)16 * jb * gldc + 16 * ib) = acc[ib][jb];
+            }
         // the next item: every wave's pieces have landed (its own vmcnt(0) above, then this barrier), so the next prologue
         // may write the stages; the index was parked by wave 0 during this item's prologue
         __builtin_amdgcn_s_barrier();
@@ -495,11 +501,11 @@ extern "C" int trx_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, 
 static bool tn_problem_ok(const trx_tn_problem& q) {
     using namespace trxtn;
     if (!q.A || !q.B || !q.C || q.M <= 0 || q.N <= 0 || q.K <= 0) return false;
-    if (q.N % TILE || q.K % TILE || q.lda < q.N || q.ldb < q.K || q.ldc < q.K || (q.lda | q.ldb) % 8 || q.ldc % 4) return false;
+    if (q.N % 8 || q.K % TILE || q.lda < q.N || q.ldb < q.K || q.ldc < q.K || (q.lda | q.ldb) % 8 || q.ldc % 4) return false;      // (N: any multiple of 8)
     if (((int64_t)q.M + 4 * BM) * q.lda * 2 >= (1ll << 32) || ((int64_t)q.M + 4 * BM) * q.ldb * 2 >= (1ll << 32)) return false;
     if ((reinterpret_cast<uintptr_t>(q.A) | reinterpret_cast<uintptr_t>(q.B) | reinterpret_cast<uintptr_t>(q.C)) & 15) return false;
     if (q.colsum && (reinterpret_cast<uintptr_t>(q.colsum) & 3)) return false;
-    if ((q.N / TILE) * (q.K / TILE) > 4096) return false;
+    if (((q.N + TILE - 1) / TILE) * (q.K / TILE) > 4096) return false;
     return true;
 }
 
@@ -509,7 +515,7 @@ extern "C" int64_t trx_gemm_tn_grouped_block_bytes(const trx_tn_problem* probs, 
     int64_t items = 0;
     for (int i = 0; i < n; ++i) {
         if (!tn_problem_ok(probs[i])) return -1;
-        items += (int64_t)(probs[i].N / TILE) * (probs[i].K / TILE);
+        items += (int64_t)((probs[i].N + TILE - 1) / TILE) * (probs[i].K / TILE);
     }
     return (int64_t)sizeof(GHeader) + 8 * 4 + 12 * 4 + (int64_t)n * (int64_t)sizeof(GProblem) + items * 4;
 }
@@ -535,7 +541,7 @@ extern "C" int trx_gemm_tn_grouped_plan(const trx_tn_problem* probs, int n, void
     std::vector<int64_t> work(n);
     for (int i = 0; i < n; ++i) {
         const trx_tn_problem& q = probs[i];
-        gp[i] = GProblem{(const bf16_t*)q.A, (const bf16_t*)q.B, (float*)q.C, (float*)q.colsum, q.M, q.N, q.K, q.lda, q.ldb, q.ldc, q.N / TILE, q.K / TILE};
+        gp[i] = GProblem{(const bf16_t*)q.A, (const bf16_t*)q.B, (float*)q.C, (float*)q.colsum, q.M, q.N, q.K, q.lda, q.ldb, q.ldc, (q.N + TILE - 1) / TILE, q.K / TILE};
         order[i] = i;
         work[i] = (int64_t)gp[i].tn * gp[i].tk * ((q.M + BM - 1) / BM);
     }

@@ -521,12 +521,12 @@ def attention_q_kv(q, kv, mask=None, causal=False, scale=None, dropout_p=0.0, se
 
 
 # ---- Linear layers: the weight gradient on a split-contraction TN GEMM ---------------------------------------------
-def gemm_tn_ok(a, b):
-    """can trx_gemm_tn_bf16 take dW = a^T b (a [M, N], b [M, K])?"""
+def gemm_tn_ok(a, b, grouped=False):
+    """can trx_gemm_tn_bf16 take dW = a^T b (a [M, N], b [M, K])?  grouped: trx_gemm_tn_grouped (N: any multiple of 8)"""
     M, N = a.shape
     K = b.shape[1]
     return (a.is_cuda and a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and b.shape[0] == M and M >= 64
-            and N % 256 == 0 and K % 256 == 0 and a.stride(1) == 1 and b.stride(1) == 1 and a.stride(0) % 8 == 0
+            and N % (8 if grouped else 256) == 0 and K % 256 == 0 and a.stride(1) == 1 and b.stride(1) == 1 and a.stride(0) % 8 == 0
             and b.stride(0) % 8 == 0 and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0 and "TRX_NN_NO_GEMM" not in os.environ)
 
 
@@ -751,7 +751,7 @@ class _LinearWgrad(torch.autograd.Function):
             dx = torch.matmul(dy2, w16).view(x.shape)
         need_w = any(ctx.needs_input_grad[2:2 + n])
         want_db = ctx.has_bias and any(ctx.needs_input_grad[2 + n:])
-        if need_w and _deferred is not None and ctx.wdtype == torch.float32 and gemm_tn_ok(dy2, x2):
+        if need_w and _deferred is not None and ctx.wdtype == torch.float32 and gemm_tn_ok(dy2, x2, grouped=True):
             # deferred_wgrad(): this layer's problem joins the pass's one grouped launch; autograd gets no gradient for the
             # parameters here -- the end of the block assigns them
             ntot = dy2.shape[1]
@@ -807,7 +807,7 @@ def linear(x, weight, bias=None):
     """torch.nn.functional.linear; for bf16 activations on the GPU (autocast training) the weight gradient is routed
     to the split-contraction TN GEMM when its shape qualifies"""
     if (x.is_cuda and x.dtype == torch.bfloat16 and torch.is_grad_enabled() and weight.requires_grad
-            and weight.shape[0] % 256 == 0 and weight.shape[1] % 256 == 0):
+            and weight.shape[0] % 8 == 0 and weight.shape[1] % 256 == 0):      # (N % 256 != 0, the vocabulary projection: the grouped launch takes it, a single call hands it to the library)
         return _LinearWgrad.apply(x, 1, weight, *((bias,) if bias is not None else ()))
     if (x.is_cuda and x.dtype == torch.bfloat16 and torch.is_autocast_enabled("cuda")
             and torch.get_autocast_dtype("cuda") == torch.float16):
