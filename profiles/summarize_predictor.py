@@ -39,7 +39,8 @@ sq, fe, wr = dispatches("pmc_sq"), dispatches("pmc_fetch"), dispatches("pmc_writ
 out = {"command": "python3 tools/predictor_shapes.py %d under rocprofv3 (profiles/run_profile_predictor.sh %s)" % (N, tag), "kernels": []}
 KERN = [("attention_fwd_mfma_kernel", "attention", "flops_fwd", 1.0), ("attention_bwd_dq_mfma_kernel", "attention", "flops_fwd", 1.5),
         ("attention_bwd_dkv_mfma_kernel", "attention", "flops_fwd", 2.0), ("add_ln_fwd_vec_kernel", "add_ln", "bytes_fwd", 1.0),
-        ("add_ln_bwd_vec_kernel", "add_ln", "bytes_bwd", 1.0)]
+        ("add_ln_bwd_vec_kernel", "add_ln", "bytes_bwd", 1.0),
+        ("gemm_tn_kernel<true>", "gemm_tn_grouped", "flops", 1.0), ("gemm_tn_kernel<false>", "gemm_tn_split", "flops", 1.0)]
 for kname, fam, workkey, mult in KERN:
     shapes = plan[fam]
     try:
@@ -51,7 +52,11 @@ for kname, fam, workkey, mult in KERN:
         us = med(bsq[i], "us")
         rec = {"kernel": kname, "shape": sh["shape"], "median_us": us}
         work = sh[workkey] * mult
-        if fam == "attention":       # algorithmic FLOPs: 4 B H Lq Lk 64 forward; dq pass 6/4, dk/dv pass 8/4 of it (GEMM units)
+        if fam.startswith("gemm_tn"):       # the weight-gradient GEMM: MFMA-bound (2 M N K), its bytes beside it
+            rec["achieved_TFLOPs"] = work / (us * 1e-6) / 1e12
+            rec["frac_of_2500_TFLOPs"] = rec["achieved_TFLOPs"] / 2500.0
+            rec["algorithmic_bytes"] = sh["bytes"]
+        elif fam == "attention":       # algorithmic FLOPs: 4 B H Lq Lk 64 forward; dq pass 6/4, dk/dv pass 8/4 of it (GEMM units)
             rec["achieved_TFLOPs"] = work / (us * 1e-6) / 1e12
             rec["frac_of_2500_TFLOPs"] = rec["achieved_TFLOPs"] / 2500.0
             bkey = {"attention_fwd_mfma_kernel": "bytes_fwd", "attention_bwd_dq_mfma_kernel": "bytes_dq", "attention_bwd_dkv_mfma_kernel": "bytes_dkv"}[kname]
