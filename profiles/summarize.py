@@ -14,9 +14,10 @@ shutil.copy(stats[0], os.path.join(root, "profiles", tag + "_kernel_stats.csv"))
 
 
 def is_boot(name):
-    """knn_scan_kernel<L2, J, BOOT, NKS>: the third template argument marks the bootstrap launch"""
+    """knn_scan_kernel<L2, J, BOOT, NKS, RESCAN>: the third template argument marks the bootstrap launch, the fifth the
+    re-scan of a batch's uncertified queries (usually none: a launch of a few microseconds) -- neither is the main scan"""
     args = [a.strip() for a in name.split("<", 1)[1].split(">", 1)[0].split(",")]
-    return len(args) > 2 and args[2] == "true"
+    return (len(args) > 2 and args[2] == "true") or (len(args) > 4 and args[4] == "true")
 
 
 def counters(sub):
