@@ -1,7 +1,9 @@
 // Register-only MFMA loop at the scan kernel's shape (8 waves x 2 workgroups per CU, 128 accumulator registers per
 // wave, random bf16 operands) to compare the energy-limited rate of v_mfma_f32_16x16x32_bf16 (64 per K-step) and
 // v_mfma_f32_32x32x16_bf16 (32 per K-step): same MACs, same operand registers.
-//   mfma_shape_lab <0|1> [iters]
+//   mfma_shape_lab <0|1|2|3> [iters]      2: v_mfma_i32_16x16x64_i8 on the same 16-byte fragments (twice the MACs per
+//   instruction), operands = small counts like the reference's Morgan fingerprints (mostly 0, a few 1 .. 3); 3: the same
+//   operands as bf16 through v_mfma_f32_16x16x32_bf16 -- what an int8 path for the integer class could buy
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -72,6 +74,40 @@ __global__ __launch_bounds__(512, 2) void mfma_only(const uint4* src, float* out
     out[blockIdx.x * 512 + tid] = mx;
 }
 
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+__global__ __launch_bounds__(512, 2) void mfma_only_i8(const uint4* src, int* out, int iters) {
+    const int tid = threadIdx.x;
+    i32x4 fa[2][8], fb[2][4];      // 16 int8 per fragment
+    const uint4* s = src + (size_t)(blockIdx.x * 512 + tid) * 24;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { uint4 u = s[i]; fa[i >> 3][i & 7] = *reinterpret_cast<i32x4*>(&u); }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { uint4 u = s[16 + i]; fb[i >> 2][i & 3] = *reinterpret_cast<i32x4*>(&u); }
+    int mx = -2147483647;
+    i32x4 acc[8][4];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (i32x4){0, 0, 0, 0};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 64; ++i) {
+            const int kk = i >> 5, a = (i >> 2) & 7, b = i & 3;
+            acc[a][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[kk][a], fb[kk][b], acc[a][b], 0, 0, 0);
+        }
+        if ((it % 12) == 11) {
+#pragma unroll
+            for (int a = 0; a < 8; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { mx = max(mx, acc[a][b][e]); acc[a][b][e] = 0; }
+                }
+        }
+    }
+    out[blockIdx.x * 512 + tid] = mx;
+}
+
 int main(int argc, char** argv) {
     const int m32 = argc > 1 ? atoi(argv[1]) : 0;
     const int iters = argc > 2 ? atoi(argv[2]) : 977 * 12 * 2;     // two rounds of workgroups' worth in one
@@ -79,18 +115,29 @@ int main(int argc, char** argv) {
     std::vector<unsigned short> h((size_t)grid * 512 * 24 * 8);
     unsigned s = 12345u;
     for (auto& x : h) { s = s * 1664525u + 1013904223u; float f = ((s >> 8) & 0xffff) / 32768.0f - 1.0f; unsigned u; memcpy(&u, &f, 4); x = (unsigned short)(u >> 16); }
+    if (m32 >= 2) {      // fingerprint-like counts: 95 % zeros, else 1 .. 3 -- as int8 (mode 2) or as bf16 values (mode 3)
+        unsigned char* b8 = reinterpret_cast<unsigned char*>(h.data());
+        for (size_t i = 0; i < h.size() * (m32 == 2 ? 2 : 1); ++i) {
+            s = s * 1664525u + 1013904223u;
+            const unsigned r = (s >> 8) & 0xffff;
+            const int v = r < 62259 ? 0 : 1 + (int)(r % 3);
+            if (m32 == 2) b8[i] = (unsigned char)v;
+            else { float f = (float)v; unsigned u; memcpy(&u, &f, 4); h[i] = (unsigned short)(u >> 16); }
+        }
+    }
     uint4* src; float* out;
     CK(hipMalloc(&src, h.size() * 2)); CK(hipMemcpy(src, h.data(), h.size() * 2, hipMemcpyHostToDevice));
     CK(hipMalloc(&out, (size_t)grid * 512 * 4));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int rep = 0; rep < 4; ++rep) {
         CK(hipEventRecord(e0));
-        if (m32) hipLaunchKernelGGL(mfma_only<true>, dim3(grid), dim3(512), 0, 0, src, out, iters);
+        if (m32 == 2) hipLaunchKernelGGL(mfma_only_i8, dim3(grid), dim3(512), 0, 0, src, (int*)out, iters);
+        else if (m32 == 1) hipLaunchKernelGGL(mfma_only<true>, dim3(grid), dim3(512), 0, 0, src, out, iters);
         else hipLaunchKernelGGL(mfma_only<false>, dim3(grid), dim3(512), 0, 0, src, out, iters);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipGetLastError());
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-        const double flop = (double)grid * 8 * iters * 64.0 * 2 * 16 * 16 * 32;
-        printf("m32 %d: %.2f ms  %.1f TFLOP/s\n", m32, ms, flop / ms / 1e9);
+        const double flop = (double)grid * 8 * iters * 64.0 * 2 * 16 * 16 * (m32 == 2 ? 64 : 32);
+        printf("mode %d: %.2f ms  %.1f T(FL)OP/s\n", m32, ms, flop / ms / 1e9);
     }
     return 0;
 }
