@@ -8,6 +8,7 @@ infrastructure and lives in oracle/nn_ref.py; nothing in this package imports it
 import ctypes
 import math
 import os
+import struct
 
 import torch
 
@@ -563,10 +564,12 @@ def gemm_tn_grouped(problems):
     n = len(problems)
     if n == 0:
         return
-    arr = (_TnProblem * n)()
-    for q, (a, b, dw, db) in zip(arr, problems):
-        q.A, q.B, q.C, q.colsum = a.data_ptr(), b.data_ptr(), dw.data_ptr(), (db.data_ptr() if db is not None else None)
-        q.M, q.N, q.K, q.lda, q.ldb, q.ldc = a.shape[0], a.shape[1], b.shape[1], a.stride(0), b.stride(0), dw.stride(0)
+    # the table in one pack (90 problems x 10 fields set one attribute at a time were 0.35 ms of a step's host time)
+    flat = []
+    for (a, b, dw, db) in problems:
+        flat += (a.data_ptr(), b.data_ptr(), dw.data_ptr(), db.data_ptr() if db is not None else 0,
+                 a.shape[0], a.shape[1], b.shape[1], a.stride(0), b.stride(0), dw.stride(0))
+    arr = (_TnProblem * n).from_buffer_copy(struct.pack("<" + "4Q6i" * n, *flat))
     nbytes = lib().trx_gemm_tn_grouped_block_bytes(ctypes.addressof(arr), n)
     if nbytes < 0:
         raise TrxNNError("trx_gemm_tn_grouped: a problem this path does not take (see gemm_tn_ok)")
@@ -597,7 +600,9 @@ class deferred_wgrad:
             gemm_tn_grouped([(dy, x, dw, db) for (dy, x, dw, db, _) in pending])
             for (_, _, dw, db, slots) in pending:
                 for (param, is_bias, lo, hi) in slots:
-                    g = (db if is_bias else dw)[lo:hi]
+                    g = db if is_bias else dw
+                    if lo != 0 or hi != g.shape[0]:          # a packed projection: this parameter's row block
+                        g = g[lo:hi]
                     if param.grad is None:
                         param.grad = g
                     else:

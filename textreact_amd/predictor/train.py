@@ -364,7 +364,12 @@ def _portable_scheduler_state(sd):
 def mark_parameters_updated(module):
     """call after an optimizer step or a load_state_dict: the bf16 weight copies `ops.linear` shares between
     forwards (ops.WeightShadows) belong to a new generation; a backward of an older forward raises instead of reading them"""
-    for m in module.modules():
+    # (the module list is made once: walking the tree of ~400 modules through the generator at every step was 0.5 ms of a
+    # step's ~13 ms of host time, tools/host_profile.py; a registry itself is made lazily by the first forward)
+    holders = module.__dict__.get("_shadow_holders")
+    if holders is None:
+        holders = module.__dict__["_shadow_holders"] = list(module.modules())
+    for m in holders:
         reg = m.__dict__.get("_weight_shadows")
         if reg is not None:
             reg.mark_stale()
