@@ -601,7 +601,7 @@ extern "C" int trx_gemm_tn_grouped_run(const void* dev_block, const void* host_b
 // ones).  dev_block: trx_gemm_tn_grouped_block_bytes() bytes of device memory, the caller's, alive until the launch has run.
 #include <mutex>
 namespace trxtn {
-struct PlanSlot { void* host = nullptr; int64_t bytes = 0; hipEvent_t ev = nullptr; bool used = false; };
+struct PlanSlot { void* host = nullptr; int64_t bytes = 0; hipEvent_t ev = nullptr; int ev_dev = -1; bool used = false; };
 static std::mutex g_plan_mu;
 static PlanSlot g_plan_ring[8];
 static int g_plan_next = 0;
@@ -638,7 +638,13 @@ extern "C" int trx_gemm_tn_grouped(const trx_tn_problem* probs, int n, void* dev
             slot->host = pinned_alloc(need); slot->bytes = slot->host ? need : 0;
             if (!slot->host) return TRX_NN_EHIP;
         }
-        if (!slot->ev && hipEventCreateWithFlags(&slot->ev, hipEventDisableTiming) != hipSuccess) return TRX_NN_EHIP;
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return TRX_NN_EHIP;
+        if (slot->ev && slot->ev_dev != dev) { hipEventDestroy(slot->ev); slot->ev = nullptr; }      // an event belongs to the device it was made on
+        if (!slot->ev) {
+            if (hipEventCreateWithFlags(&slot->ev, hipEventDisableTiming) != hipSuccess) return TRX_NN_EHIP;
+            slot->ev_dev = dev;
+        }
         host = slot->host;
     }
     int rc = trx_gemm_tn_grouped_plan(probs, n, host, need);
