@@ -7,7 +7,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import nn_ref  # noqa: E402  (the PyTorch statement of the ops: the side the kernels are compared with)
-from textreact_amd.predictor import train  # noqa: E402
+from textreact_amd.predictor import train, ops  # noqa: E402
 from textreact_amd.predictor.model import Config, random_state_dict  # noqa: E402
 
 dev, steps = "cuda", int(sys.argv[1]) if len(sys.argv) > 1 else 200
@@ -30,7 +30,8 @@ for backend in ("hip", "torch"):
                      "decoder_input_ids": src.to(dev), "decoder_attention_mask": torch.ones(16, T, dtype=torch.long, device=dev)}
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 loss, _ = p.training_step(batch)
-            loss.backward(); opt.step(); opt.zero_grad(set_to_none=True)
+            ops.backward(loss); opt.step(); opt.zero_grad(set_to_none=True)      # what the trainer calls: the weight gradients as one grouped launch
+            train.mark_parameters_updated(p)
             if sched is not None:
                 sched.step()
             if it % 20 == 19:
