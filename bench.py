@@ -227,13 +227,15 @@ def fingerprint_workload(args, dev, local_rank):
     line = {"metric": "queries/sec, train self-search IndexFlatL2 k=20 over %dx2048 integer fingerprints (the reference's own workload)" % n,
             "value": n * steps / (t1 - t0), "unit": "queries/s", "n_gpus": 1, "steps": steps, "warmup": args.warmup,
             "ms_per_step": (t1 - t0) / steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
+            "dtype": "i8" if st.get("int8_scan") else "bf16", "data": "synthetic",
             "config": {"workload": "exact L2 top-20, %dx2048 sparse signed-count fingerprints (2 %% dense, |v| <= 10), the set searching itself"
                                    % n, "corpus_rows": n, "dim": 2048, "queries": n, "k": 20, "exact_class": st["exact_class"],
+                       "int8_scan": st.get("int8_scan", 0),      # 1: the scan's int8 form (v_mfma_i32_16x16x64_i8; TRX_NO_I8=1 for the bf16 form)
                        "uncertified_queries_per_step": st["n_uncertified"], "self_is_first": ok,
                        "scan_launches_per_step": launches // steps},
-            "roofline": {"bound": "mfma", "kernel": "knn_scan_kernel", "achieved": achieved, "peak": PEAK_BF16_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None, "launch_ms": mean_launch_ms,
+            "roofline": {"bound": "mfma", "kernel": "knn_scan_kernel", "achieved": achieved, "peak": 5000.0 if st.get("int8_scan") else PEAK_BF16_TFLOPS,
+                         "unit": "Top/s (dense int8 MFMA peak)" if st.get("int8_scan") else "TFLOP/s",
+                         "frac": achieved / (5000.0 if st.get("int8_scan") else PEAK_BF16_TFLOPS), "traffic": None, "launch_ms": mean_launch_ms,
                          "flops_per_launch": flops_step * steps / max(launches, 1)}}
     if not args.no_cpu_baseline:
         base, I_cpu = cpu_baseline(y, y, 20, metric=1)

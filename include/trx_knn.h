@@ -136,7 +136,9 @@ typedef struct trx_search_stats {
                               re-scored exactly) */
     int32_t n_rescanned;   /* of those, queries the wide re-score could not certify either and the fixed-threshold re-scan
                               took; n_uncertified of them went on to the exact scan */
-    int32_t reserved_;
+    int32_t int8_scan;     /* 1 = the scan ran in its int8 form (integer inputs that fit a signed byte -- the L2 scan stages
+                              the doubled query --, d >= 256: v_mfma_i32_16x16x64_i8, twice the MACs per instruction);
+                              same keys, same lists, same results as the bf16 form */
 } trx_search_stats;
 
 int trx_index_last_stats(const trx_index* idx, trx_search_stats* out);

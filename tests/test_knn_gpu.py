@@ -72,6 +72,42 @@ def test_morgan_fingerprints_l2_k20():
     _check(L2, y[:300], y, 20, expect_exact_class=True)
 
 
+@pytest.mark.parametrize("metric,d,maker", [(L2, 2048, reaction_fp_like), (IP, 2048, reaction_fp_like), (L2, 1024, morgan_like), (IP, 1000, reaction_fp_like),
+                                            (L2, 264, reaction_fp_like)])
+def test_int8_form_of_the_scan_for_the_integer_class(metric, d, maker):
+    """integer inputs that fit a signed byte run the scan in int8 (stats int8_scan): against the oracle like every other
+    path, and bit-identical to the bf16 form of the same search (TRX_NO_I8), incl. a second add and a ragged query count"""
+    y = maker(7000, d, 21)
+    x = np.concatenate([y[:300], maker(133, d, 22)])
+    st = _check(metric, x, y, 20, chunks=2, expect_exact_class=True)
+    assert st["int8_scan"] == 1 and st["n_uncertified"] == 0, st
+    idx = _index(metric, d); idx.add(y[:5000]); idx.add(y[5000:])
+    D8, I8 = idx.search(x, 20)
+    assert idx.last_stats()["int8_scan"] == 1
+    os.environ["TRX_NO_I8"] = "1"
+    try:
+        D16, I16 = idx.search(x, 20)
+        assert idx.last_stats()["int8_scan"] == 0
+    finally:
+        del os.environ["TRX_NO_I8"]
+    assert np.array_equal(I8, I16) and np.array_equal(D8.view(np.uint32), D16.view(np.uint32))
+
+
+def test_the_int8_form_is_gated_on_the_device():
+    """what decides is the QUERIES of each search, on the device: integers up to 63 (L2 stages 2 x) or 127 (IP) take the int8
+    form, larger counts, fractions or a narrow index take the bf16 form -- same answers either way"""
+    y = reaction_fp_like(6000, 512, 31)
+    big = y.copy(); big[:, :7] *= 9.0                       # counts up to 90: too large doubled, fine as they are
+    for metric, x, want in ((L2, y[:200], 1), (L2, big[:200], 0), (IP, big[:200], 1), (L2, y[:200] + 0.5, 0), (IP, y[:200] * 0.25, 0)):
+        st = _check(metric, x.astype(np.float32), y, 10)
+        assert st["int8_scan"] == want, (metric, want, st)
+    st = _check(L2, big[:200], big, 10)                     # corpus counts beyond 127? no: 90 -- but doubled queries are not bytes
+    assert st["int8_scan"] == 0
+    huge = y.copy(); huge[:, 0] = 200.0
+    assert _check(IP, y[:100], huge, 10)["int8_scan"] == 0      # a corpus value that is not a signed byte: never
+    assert _check(L2, reaction_fp_like(100, 128, 5), reaction_fp_like(3000, 128, 6), 10)["int8_scan"] == 0      # d < 256
+
+
 @pytest.mark.parametrize("metric", [IP, L2])
 def test_fingerprints_ip_and_l2_ties(metric):
     y = morgan_like(5000, 256, 9)

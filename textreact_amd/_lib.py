@@ -26,7 +26,7 @@ class SearchStats(ctypes.Structure):
     _fields_ = [("nq", ctypes.c_int64), ("n_uncertified", ctypes.c_int64), ("k_split", ctypes.c_int32),
                 ("n_splits", ctypes.c_int32), ("exact_class", ctypes.c_int32), ("scan_launches", ctypes.c_int32),
                 ("scan_ms", ctypes.c_float), ("total_ms", ctypes.c_float), ("late_fallback", ctypes.c_int32),
-                ("n_rescored", ctypes.c_int32), ("n_rescanned", ctypes.c_int32), ("reserved_", ctypes.c_int32)]
+                ("n_rescored", ctypes.c_int32), ("n_rescanned", ctypes.c_int32), ("int8_scan", ctypes.c_int32)]
 
 
 class TrxError(RuntimeError):

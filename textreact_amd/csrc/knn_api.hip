@@ -22,6 +22,8 @@ hipError_t launch_widen_rows(const bf16_t*, int64_t, int, int64_t, float*, hipSt
 hipError_t launch_exact_scan(int, int, int, const int*, int, const int*, int64_t, const void*, int64_t, const void*,
                              int64_t, int, int, double*, float*, int64_t*, double*, hipStream_t);
 hipError_t launch_classify(const void*, int, int, float, int, int, int, int*, hipStream_t);
+hipError_t launch_build_operand_i8(const void*, int, int64_t, int, int64_t, signed char*, int, float, hipStream_t);
+hipError_t launch_fill_bias_i32(const float*, int64_t, int64_t, int*, hipStream_t);
 hipError_t launch_merge(int, int, int64_t, int, const double*, const int64_t*, float*, int64_t*, hipStream_t);
 }  // namespace trx
 
@@ -64,7 +66,7 @@ struct DevBuf {
 // per index.
 struct DevPool {
     std::mutex mu;
-    DevBuf cand, cnt, thr, gthr, qg, qg2, gthr2;
+    DevBuf cand, cnt, thr, gthr, qg, qg2, gthr2, qg8;
     hipEvent_t last = nullptr;
     int users = 0;
 };
@@ -86,6 +88,10 @@ struct trx_index {
     float* cbias = nullptr;  // [cap]
     float maxabs = 0.f, maxnorm2 = 0.f;
     bool nonint = false;
+    // the int8 form of the scan for the integer class (knn_scan.hip, I8): an int8 copy of the operand rows and the int32 start
+    // values of the L2 accumulators, made by the first search that can use them after the index changed
+    signed char* C8 = nullptr; int* cbias8 = nullptr;
+    int64_t c8_cap = 0, c8_rows = -1; int Kp8 = 0;
     // workspaces
     DevBuf w_stamp, w_stats, w_qnorm2, w_flag, w_exact, w_io, w_tmp, w_cls;      // (the big ones are shared: DevPool)
     trx_search_stats stats{};
@@ -97,7 +103,7 @@ struct trx_index {
     struct Pending {
         bool active = false;
         hipStream_t st = nullptr;
-        int is_bf = 0, k = 0, corpus_is_bf16 = 0, no_fallback = 0;
+        int is_bf = 0, k = 0, corpus_is_bf16 = 0, no_fallback = 0, tried_i8 = 0;
         const void* corpus_orig = nullptr; int64_t ld_c = 0;
         std::vector<PendingBatch> batches;
     } pend;
@@ -189,6 +195,8 @@ void trx_index_destroy(trx_index* idx) {
     if (idx->Co) (void)hipFree(idx->Co);
     if (idx->cnorm2) (void)hipFree(idx->cnorm2);
     if (idx->cbias) (void)hipFree(idx->cbias);
+    if (idx->C8) (void)hipFree(idx->C8);
+    if (idx->cbias8) (void)hipFree(idx->cbias8);
     DevBuf* bufs[] = {&idx->w_stamp, &idx->w_stats, &idx->w_qnorm2, &idx->w_flag, &idx->w_exact, &idx->w_io, &idx->w_tmp, &idx->w_cls};
     for (DevBuf* b : bufs) b->release();
     {   // the last index of the process on this device takes the shared workspaces with it
@@ -197,7 +205,7 @@ void trx_index_destroy(trx_index* idx) {
         if (--pl.users <= 0) {
             pl.users = 0;
             (void)hipDeviceSynchronize();
-            DevBuf* shared[] = {&pl.cand, &pl.cnt, &pl.thr, &pl.gthr, &pl.qg, &pl.qg2, &pl.gthr2};
+            DevBuf* shared[] = {&pl.cand, &pl.cnt, &pl.thr, &pl.gthr, &pl.qg, &pl.qg2, &pl.gthr2, &pl.qg8};
             for (DevBuf* b : shared) b->release();
             // (the ordering event stays for the life of the process: a few bytes, and nothing can hold a stale handle to it)
         }
@@ -217,6 +225,9 @@ int trx_index_reset(trx_index* idx) {
     if (idx->cnorm2) (void)hipFree(idx->cnorm2);
     if (idx->cbias) (void)hipFree(idx->cbias);
     idx->Cg = nullptr; idx->Co = nullptr; idx->cnorm2 = nullptr; idx->cbias = nullptr;
+    if (idx->C8) (void)hipFree(idx->C8);
+    if (idx->cbias8) (void)hipFree(idx->cbias8);
+    idx->C8 = nullptr; idx->cbias8 = nullptr; idx->c8_cap = 0; idx->c8_rows = -1;
     idx->n = 0; idx->cap = 0; idx->mode = MODE_EMPTY; idx->Kp = 0;
     idx->maxabs = 0.f; idx->maxnorm2 = 0.f; idx->nonint = false;
     return TRX_OK;
@@ -273,6 +284,7 @@ int trx_index_add_device(trx_index* idx, const void* x, int64_t n, int dtype, vo
     }
     HIPCHK(hipMemcpyAsync(idx->cnorm2 + idx->n, idx->w_tmp.p, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, st));
     idx->n += n;
+    idx->c8_rows = -1;       // the int8 copy (if any) is rebuilt by the next search that can use it
     HIPCHK(launch_fill_bias(idx->cnorm2, idx->n, idx->cap + TILE_M, idx->cbias, st));
     idx->maxabs = std::max(idx->maxabs, bits2f(hs.maxabs_bits));
     idx->maxnorm2 = std::max(idx->maxnorm2, bits2f(hs.maxnorm2_bits));
@@ -386,8 +398,45 @@ static int search_batch(trx_index* idx, const void* q, const float* qnorm2, int6
         HIPCHK(launch_scan(bp, idx->metric, st));
     }
     sp.bootstrap = 0; sp.boot_tiles = 0;
+    // The integer class has an int8 form of the scan (knn_scan.hip, I8: twice the MACs per instruction, half the bytes per
+    // component).  What the HOST knows is the corpus side -- integers, |value| <= 127, stored as they are (plain mode);
+    // whether the queries qualify is known on the device only (w_cls[1], classify_kernel), so both launches are enqueued
+    // and gated there: exactly one of them runs, the other returns at once.  Thresholds (bootstrap, g_thr), lists and
+    // everything downstream are the same keys in both forms.
+    const bool try8 = idx->mode == MODE_PLAIN && !idx->nonint && idx->maxabs <= 127.f && d >= 256 && !q_split && !getenv("TRX_NO_I8");
+    if (try8) {
+        const int Kp8 = (int)round_up64(std::max(d, 512), 256);
+        const int64_t rows8 = idx->cap + TILE_M;
+        if (idx->c8_cap != rows8 || idx->Kp8 != Kp8) {
+            if (idx->C8) (void)hipFree(idx->C8);
+            if (idx->cbias8) (void)hipFree(idx->cbias8);
+            idx->C8 = nullptr; idx->cbias8 = nullptr; idx->c8_cap = 0; idx->c8_rows = -1;
+            HIPCHK(hipMalloc((void**)&idx->C8, (size_t)rows8 * Kp8));
+            HIPCHK(hipMalloc((void**)&idx->cbias8, (size_t)rows8 * sizeof(int)));
+            idx->c8_cap = rows8; idx->Kp8 = Kp8;
+        }
+        if (idx->c8_rows != idx->n) {
+            HIPCHK(hipMemsetAsync(idx->C8, 0, (size_t)rows8 * Kp8, st));
+            HIPCHK(launch_build_operand_i8(idx->Cg, 1, idx->n, d, Kp, idx->C8, Kp8, 1.f, st));
+            HIPCHK(launch_fill_bias_i32(idx->cnorm2, idx->n, rows8, idx->cbias8, st));
+            idx->c8_rows = idx->n;
+        }
+        if ((rc = pl.qg8.reserve((size_t)q_pad * Kp8))) return rc;
+        HIPCHK(hipMemsetAsync(pl.qg8.p, 0, (size_t)q_pad * Kp8, st));
+        HIPCHK(launch_build_operand_i8(q, is_bf, nq, d, d, (signed char*)pl.qg8.p, Kp8, idx->metric == TRX_METRIC_L2 ? 2.f : 1.f, st));
+        sp.gate = (const int*)idx->w_cls.p + 1; sp.gate_want = 0;
+        idx->pend.tried_i8 = 1;
+    }
     if (idx->timing) HIPCHK(hipEventRecord(idx->ev[0], st));
     HIPCHK(launch_scan(sp, idx->metric, st));
+    if (try8) {
+        ScanParams s8 = sp;
+        s8.i8 = 1; s8.gate_want = 1;
+        s8.corpus = (const bf16_t*)idx->C8; s8.queries = (const bf16_t*)pl.qg8.p; s8.cbias = (const float*)idx->cbias8;
+        s8.Kp = idx->Kp8 / 2;          // the kernel counts 2-byte units
+        HIPCHK(launch_scan(s8, idx->metric, st));
+    }
+    sp.gate = nullptr;      // (everything below -- the re-scan of uncertified queries -- is the bf16 form, ungated)
     if (idx->timing) HIPCHK(hipEventRecord(idx->ev[1], st));
 #ifdef TRX_STAMP_BUILD
     {
@@ -468,14 +517,14 @@ static int finish_impl(trx_index* idx) {
     if (!pd.active) return TRX_OK;
     pd.active = false;
     hipStream_t st = pd.st;
-    int cls = 0;
+    int cls[2] = {0, 0};
     std::vector<int> nf(pd.batches.size(), 0);
     std::vector<int> cnt4(pd.batches.size() * 4, 0);      // the four counters of every batch (FLAG_WORDS)
     for (size_t b = 0; b < pd.batches.size(); ++b)
         HIPCHK(hipMemcpyAsync(&cnt4[4 * b], pd.batches[b].nflag, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
-    if (idx->w_cls.p && !pd.batches.empty()) HIPCHK(hipMemcpyAsync(&cls, idx->w_cls.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    if (idx->w_cls.p && !pd.batches.empty()) HIPCHK(hipMemcpyAsync(cls, idx->w_cls.p, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    if (!pd.batches.empty()) idx->stats.exact_class = cls;
+    if (!pd.batches.empty()) { idx->stats.exact_class = cls[0]; idx->stats.int8_scan = (cls[1] && pd.tried_i8) ? 1 : 0; }
     const int64_t per = std::max<int64_t>(INLINE_FALLBACK, ((int64_t)1 << 29) / std::max<int64_t>(1, idx->n * 8));
     bool late = false;
     for (size_t b = 0; b < pd.batches.size(); ++b) {

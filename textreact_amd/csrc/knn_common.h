@@ -127,6 +127,9 @@ struct ScanParams {
     u64* cand_thr;           // [q_pad][nsplits][8] every unlisted row of the list's rows has comp <= this
     u32* g_thr;              // [q_pad / 256][4 slots][256] ordkeys; the smallest of a query's 4 slots is a key that at least kprime corpus rows reach; shared by all
                              // workgroups of a query (atomicMax, monotone; a stale read is only looser)
+    const int* gate;         // optional DEVICE int: the launch runs only when *gate == gate_want (the bf16 / int8 pair of the exact class)
+    int gate_want;
+    int i8;                  // 1: the int8 form (corpus / queries hold int8 rows of 2 Kp bytes, cbias int32 -|y|^2, L2 queries doubled)
     int bootstrap;           // 1: threshold bootstrap launch (boot_tiles tiles per query tile, publish g_thr only)
     int boot_tiles;
     int debug;               // timing-only diagnostics (TRX_SCAN_DEBUG), 0 in production

@@ -105,6 +105,9 @@ __global__ void classify_kernel(const RowStats* qs, int q_split, int idx_nonint,
     const double prod = (double)Kp * (double)qmax * (double)idx_maxabs;
     const double keymag = l2 ? 2.0 * prod + (double)d * idx_maxabs * idx_maxabs : prod;
     out[0] = (!q_split && !qs->nonint_any && !idx_nonint && qmax <= 256.f && idx_maxabs <= 256.f && keymag < 16777216.0) ? 1 : 0;
+    // [1]: the int8 form of the scan may run (knn_scan.hip, I8): the exact class, and both operands fit a signed byte --
+    // the L2 scan stages the DOUBLED query
+    out[1] = (out[0] && idx_maxabs <= 127.f && qmax * (l2 ? 2.f : 1.f) <= 127.f) ? 1 : 0;
 }
 hipError_t launch_classify(const void* qstats, int q_split, int idx_nonint, float idx_maxabs, int Kp, int d, int l2, int* out, hipStream_t st) {
     hipLaunchKernelGGL(classify_kernel, dim3(1), dim3(1), 0, st, (const RowStats*)qstats, q_split, idx_nonint, idx_maxabs, Kp, d, l2, out);
@@ -153,6 +156,48 @@ __global__ __launch_bounds__(256) void build_operand_kernel(const void* x, int64
             }
         }
     }
+}
+
+// int8 operand rows for the integer class: component c of row r -> (int8)(scale * value) (scale 2: the queries of an L2
+// search), zero beyond d up to the row's Kp8 bytes.  One thread per (row, 16-byte group).  A value that is not a small
+// integer gives garbage -- the launch that would read it is gated off on the device then (classify_kernel, out[1]).
+template <bool BF>
+__global__ __launch_bounds__(256) void build_operand_i8_kernel(const void* x, int64_t n, int d, int64_t ld, signed char* out, int Kp8, float scale) {
+    const int groups = Kp8 / 16;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n * groups) return;
+    const int64_t r = t / groups;
+    const int g = (int)(t - r * groups);
+    const char* row = reinterpret_cast<const char*>(x) + r * ld * (BF ? 2 : 4);
+    u32 w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = g * 16 + i;
+        const float v = c < d ? load_val<BF>(row, c) * scale : 0.f;
+        const int q = (int)fminf(fmaxf(v, -128.f), 127.f);
+        w[i >> 2] |= ((u32)q & 0xffu) << (8 * (i & 3));
+    }
+    *reinterpret_cast<uint4*>(out + r * Kp8 + g * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+hipError_t launch_build_operand_i8(const void* x, int is_bf16, int64_t n, int d, int64_t ld, signed char* out, int Kp8, float scale, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    const int64_t total = n * (Kp8 / 16);
+    dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    if (is_bf16) hipLaunchKernelGGL(build_operand_i8_kernel<true>, grid, block, 0, st, x, n, d, ld, out, Kp8, scale);
+    else hipLaunchKernelGGL(build_operand_i8_kernel<false>, grid, block, 0, st, x, n, d, ld, out, Kp8, scale);
+    return hipGetLastError();
+}
+// int8 form, L2: the accumulators of a tile start from -|y|^2 (an integer below 2^24 in the exact class); pad rows from a
+// value no sum can lift into any list
+__global__ void fill_bias_i32_kernel(const float* norm2, int64_t n, int64_t n_pad, int* bias) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_pad) return;
+    bias[j] = j < n ? -(int)fminf(norm2[j], 1073741824.f) : -(1 << 30);
+}
+hipError_t launch_fill_bias_i32(const float* norm2, int64_t n, int64_t n_pad, int* bias, hipStream_t st) {
+    if (n_pad <= 0) return hipSuccess;
+    hipLaunchKernelGGL(fill_bias_i32_kernel, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, st, norm2, n, n_pad, bias);
+    return hipGetLastError();
 }
 
 // bias[j] = -norm2[j] for j < n, -inf for n <= j < n_pad

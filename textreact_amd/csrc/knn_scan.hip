@@ -73,11 +73,13 @@
 #include "knn_common.h"
 #include <atomic>
 #include <cstdlib>
+#include <type_traits>
 
 namespace trx {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(3))) char lds_char;
 typedef __attribute__((address_space(1))) const void gbl_void;
@@ -157,6 +159,12 @@ __device__ __forceinline__ float max4f(const f32x4& a) {
     asm("v_max_f32 %0, %1, %2\n\tv_max3_f32 %0, %0, %3, %4" : "=&v"(g) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]));
     return g;
 }
+// the same for the int8 form's int32 accumulators, converted once per group (the exact class: every sum is below 2^24)
+__device__ __forceinline__ float max4f(const i32x4& a) {
+    int g;
+    asm("v_max_i32 %0, %1, %2\n\tv_max3_i32 %0, %0, %3, %4" : "=&v"(g) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]));
+    return (float)g;
+}
 // f32 -> bf16 bits rounded toward -infinity (a tracked maximum may only get smaller: it stays a valid lower bound)
 __device__ __forceinline__ u32 bf16_floor(float f) {
     const u32 u = __float_as_uint(f);
@@ -209,8 +217,18 @@ __device__ __forceinline__ u64 compact_list(u64* list, int cap, int kprime, int 
 // the scan for a batch's still-uncertified queries with thresholds fixed at their seeds (knn_api.hip; usually no query: a
 // launch of a few microseconds that halved the "average duration" of the scan in a kernel trace): the parameter changes
 // nothing in the code.
-template <bool L2, int J, bool BOOT, int NKS, bool RESCAN = false>
+// I8: the int8 form for the integer class (the reference's own workload: count fingerprints, retrieve_faiss.py:36-44).  The
+// operands are int8 -- a 128-byte row of a K-step holds 128 components instead of 64, v_mfma_i32_16x16x64_i8 does twice the
+// MACs of the bf16 instruction in the same time (tools/mfma_shape_lab: 4.73 Pop/s against 2.37 PFLOP/s on such data) -- the
+// accumulators int32; L2 stages the DOUBLED query and starts from -|y|^2, so that an accumulator is the key itself
+// (2 x.y - |y|^2, an integer).  The byte geometry of the loop is the bf16 form's (Kp counts 2-byte units); the filter takes
+// a group's maximum in int32 and converts it once.  Whether a search may use it is decided on the device (p.gate).
+template <bool L2, int J, bool BOOT, int NKS, bool RESCAN = false, bool I8 = false>
 __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p) {
+    // the exact class of a search is known on the device only (knn_prep.hip: classify_kernel): the bf16 and the int8 launch
+    // are both enqueued, and the one whose turn it is not leaves here
+    if (!BOOT && p.gate && *p.gate != p.gate_want) return;
+    typedef typename std::conditional<I8, i32x4, f32x4>::type acc_t;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const u32 lds0 = (u32)(uintptr_t)(lds_char*)smem;
 
@@ -273,7 +291,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
     // ---- selection state ----
     const int ql0 = wave_n * 64 + frow;           // query (inside the tile) of accumulator column nt: ql0 + 16 nt
     const float NEG_INF = -__builtin_inff();
-    constexpr float KS = L2 ? 2.0f : 1.0f, KI = L2 ? 0.5f : 1.0f;   // key = KS * accumulator (see the header, L2)
+    constexpr float KS = (L2 && !I8) ? 2.0f : 1.0f, KI = (L2 && !I8) ? 0.5f : 1.0f;   // key = KS * accumulator (see the header, L2; int8: the accumulator IS the key)
     // per-lane LDS bases of the selection state: [wave row][query] arrays of 4- and 8-byte entries; own row,
     // partner's row, row 0 (arrays without a wave-row dimension use b4_0)
     const u32 b4_0 = lds0 + S_THRW + ql0 * 4;
@@ -293,8 +311,8 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
         lds_st32<R_E2>(t4, __float_as_uint(NEG_INF));
     }
 
-    f32x4 acc[8][4];
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    acc_t acc[8][4];
+    const acc_t zero4 = {0, 0, 0, 0};
 #pragma unroll
     for (int mt = 0; mt < 8; ++mt)
 #pragma unroll
@@ -376,7 +394,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
     if (wave_m) __builtin_amdgcn_s_barrier();       // group 1 runs one interval late
 
     bf16x8 fa[8], fb[4];
-    f32x4 biasv[8];     // L2: -|y|^2 / 2 of this lane's rows of the tile that is about to start
+    acc_t biasv[8];     // L2: -|y|^2 / 2 (int8: -|y|^2, int32) of this lane's rows of the tile that is about to start
     const u32 a_bias = lds0 + S_BIAS + (wave_m * 128 + fq * 4) * 4;
 #define TRX_READ_BIAS()                                                                                    \
     if (L2) {                                                                                              \
@@ -406,12 +424,14 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
 #ifndef TRX_SNAKE
 #define TRX_SNAKE 1
 #endif
+#define TRX_MFMA1(A, B, C) (I8 ? (acc_t)__builtin_bit_cast(acc_t, __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, A), __builtin_bit_cast(i32x4, B), __builtin_bit_cast(i32x4, C), 0, 0, 0)) \
+                              : (acc_t)__builtin_bit_cast(acc_t, __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B, __builtin_bit_cast(f32x4, C), 0, 0, 0)))
 #define TRX_MFMA_ACC()                                                                                     \
     __builtin_amdgcn_s_setprio(1);                                                                         \
     _Pragma("unroll") for (int mt_ = 0; mt_ < 8; ++mt_)                                                    \
         _Pragma("unroll") for (int n0_ = 0; n0_ < 4; ++n0_) {                                              \
             const int nt_ = (TRX_SNAKE && (mt_ & 1)) ? 3 - n0_ : n0_;                                      \
-            acc[mt_][nt_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mt_], fb[nt_], acc[mt_][nt_], 0, 0, 0); \
+            acc[mt_][nt_] = TRX_MFMA1(fa[mt_], fb[nt_], acc[mt_][nt_]);                                    \
         }                                                                                                  \
     __builtin_amdgcn_s_setprio(0);
     // first phase of a tile: the accumulators start from zero (IP) or from -|y|^2 / 2 of their rows (L2): no clearing pass
@@ -420,7 +440,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
     _Pragma("unroll") for (int mt_ = 0; mt_ < 8; ++mt_)                                                    \
         _Pragma("unroll") for (int n0_ = 0; n0_ < 4; ++n0_) {                                              \
             const int nt_ = (TRX_SNAKE && (mt_ & 1)) ? 3 - n0_ : n0_;                                      \
-            acc[mt_][nt_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mt_], fb[nt_], L2 ? biasv[mt_] : zero4, 0, 0, 0); \
+            acc[mt_][nt_] = TRX_MFMA1(fa[mt_], fb[nt_], (L2 ? biasv[mt_] : zero4));                        \
         }                                                                                                  \
     __builtin_amdgcn_s_setprio(0);
     // B pieces of this wave's half for the K-step after the current one -> stage STG
@@ -715,7 +735,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
             u64 hA_[4] = {0ull, 0ull, 0ull, 0ull}, hB_[4] = {0ull, 0ull, 0ull, 0ull};                      \
             _Pragma("unroll") for (int mt = 0; mt < 10; ++mt) {                                            \
                 _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) {                                         \
-                    if (mt < 8) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mt], fb[nt], acc[mt][nt], 0, 0, 0); \
+                    if (mt < 8) acc[mt][nt] = TRX_MFMA1(fa[mt], fb[nt], acc[mt][nt]);                      \
                     hB_[nt] = hA_[nt];                                                                     \
                     if (mt >= 1 && mt < 9) {                /* reduce group mt - 1 */                        \
                         const float g = max4f(acc[mt - 1][nt]);                                            \
@@ -727,7 +747,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
                         u64* const lq_ = lp_l + nt * colstride_l + ((cnt4 >> (8 * nt)) & 0x7fu);           \
                         u32 ns_ = 0u;                                                                      \
                         _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                    \
-                            const float a_ = acc[mt - 2][nt][r];                                           \
+                            const float a_ = (float)acc[mt - 2][nt][r];                                    \
                             const u64 pk_ = mask_ge(a_, tk_);                                              \
                             if (pk_) {                                                                     \
                                 store_masked(pk_, lq_ + ns_, make_comp(KS * a_ + 0.0f, id_l + (mt - 2) * 16 + r)); \
@@ -799,7 +819,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
     }
 }
 
-template <bool L2, int J, bool BOOT, int NKS, bool RESCAN>
+template <bool L2, int J, bool BOOT, int NKS, bool RESCAN, bool I8 = false>
 static hipError_t launch_one(const ScanParams& p, hipStream_t st) {
     // the attribute is per device (the ABI takes a device ordinal): one bit per ordinal, per instantiation
     static std::atomic<unsigned long long> attr_devs{0ull};
@@ -808,19 +828,20 @@ static hipError_t launch_one(const ScanParams& p, hipStream_t st) {
     if (e != hipSuccess) return e;
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(attr_devs.load(std::memory_order_acquire) & bit)) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_scan_kernel<L2, J, BOOT, NKS, RESCAN>),
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_scan_kernel<L2, J, BOOT, NKS, RESCAN, I8>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
         if (e != hipSuccess) return e;
         attr_devs.fetch_or(bit, std::memory_order_release);
     }
     dim3 grid(BOOT ? p.nqtiles : p.nqtiles * p.nsplits), block(SCAN_THREADS);
-    hipLaunchKernelGGL((knn_scan_kernel<L2, J, BOOT, NKS, RESCAN>), grid, block, LDS_TOTAL, st, p);
+    hipLaunchKernelGGL((knn_scan_kernel<L2, J, BOOT, NKS, RESCAN, I8>), grid, block, LDS_TOTAL, st, p);
     return hipGetLastError();
 }
 
 template <bool L2, int J, bool BOOT>
 static hipError_t launch_ks(const ScanParams& p, hipStream_t st) {
     // (32 K-steps = 2048 components compiled in: no gain, 91.4 ms either way on the fingerprint workload)
+    if (!BOOT && p.i8) return launch_one<L2, J, false, 0, false, true>(p, st);      // the int8 form: main scan only
     if (!BOOT && p.fixed_thr) return p.Kp == 12 * BK ? launch_one<L2, J, false, 12, true>(p, st) : launch_one<L2, J, false, 0, true>(p, st);
     return p.Kp == 12 * BK ? launch_one<L2, J, BOOT, 12, false>(p, st) : launch_one<L2, J, BOOT, 0, false>(p, st);
 }
