@@ -389,15 +389,6 @@ static int search_batch(trx_index* idx, const void* q, const float* qnorm2, int6
 #endif
     sp.g_thr = (u32*)pl.gthr.p;
     HIPCHK(hipMemsetAsync(sp.g_thr, 0, (size_t)q_pad * 4 * sizeof(u32), st));
-    // seed the shared thresholds: every query tile scans a few tiles (selection bookkeeping only, no lists)
-    const bool boot = !getenv("TRX_NO_BOOT") && ntiles > 2;
-    if (boot) {
-        ScanParams bp = sp;
-        bp.bootstrap = 1; bp.nsplits = 1; bp.tiles_per_split = ntiles;
-        bp.boot_tiles = getenv("TRX_BOOT_TILES") ? std::max(2, atoi(getenv("TRX_BOOT_TILES"))) : 16;
-        HIPCHK(launch_scan(bp, idx->metric, st));
-    }
-    sp.bootstrap = 0; sp.boot_tiles = 0;
     // The integer class has an int8 form of the scan (knn_scan.hip, I8: twice the MACs per instruction, half the bytes per
     // component).  What the HOST knows is the corpus side -- integers, |value| <= 127, stored as they are (plain mode);
     // whether the queries qualify is known on the device only (w_cls[1], classify_kernel), so both launches are enqueued
@@ -427,6 +418,21 @@ static int search_batch(trx_index* idx, const void* q, const float* qnorm2, int6
         sp.gate = (const int*)idx->w_cls.p + 1; sp.gate_want = 0;
         idx->pend.tried_i8 = 1;
     }
+    // seed the shared thresholds: every query tile scans a few tiles (selection bookkeeping only, no lists)
+    const bool boot = !getenv("TRX_NO_BOOT") && ntiles > 2;
+    if (boot) {
+        ScanParams bp = sp;
+        bp.bootstrap = 1; bp.nsplits = 1; bp.tiles_per_split = ntiles;
+        bp.boot_tiles = getenv("TRX_BOOT_TILES") ? std::max(2, atoi(getenv("TRX_BOOT_TILES"))) : 16;
+        HIPCHK(launch_scan(bp, idx->metric, st));
+        if (try8) {      // the int8 twin of the bootstrap, gated like the main pair
+            ScanParams b8 = bp;
+            b8.i8 = 1; b8.gate_want = 1;
+            b8.corpus = (const bf16_t*)idx->C8; b8.queries = (const bf16_t*)pl.qg8.p; b8.cbias = (const float*)idx->cbias8; b8.Kp = idx->Kp8 / 2;
+            HIPCHK(launch_scan(b8, idx->metric, st));
+        }
+    }
+    sp.bootstrap = 0; sp.boot_tiles = 0;
     if (idx->timing) HIPCHK(hipEventRecord(idx->ev[0], st));
     HIPCHK(launch_scan(sp, idx->metric, st));
     if (try8) {

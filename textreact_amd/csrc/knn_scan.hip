@@ -226,8 +226,8 @@ __device__ __forceinline__ u64 compact_list(u64* list, int cap, int kprime, int 
 template <bool L2, int J, bool BOOT, int NKS, bool RESCAN = false, bool I8 = false>
 __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p) {
     // the exact class of a search is known on the device only (knn_prep.hip: classify_kernel): the bf16 and the int8 launch
-    // are both enqueued, and the one whose turn it is not leaves here
-    if (!BOOT && p.gate && *p.gate != p.gate_want) return;
+    // are both enqueued (bootstrap and main scan alike), and the one whose turn it is not leaves here
+    if (p.gate && *p.gate != p.gate_want) return;
     typedef typename std::conditional<I8, i32x4, f32x4>::type acc_t;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const u32 lds0 = (u32)(uintptr_t)(lds_char*)smem;
@@ -841,7 +841,7 @@ static hipError_t launch_one(const ScanParams& p, hipStream_t st) {
 template <bool L2, int J, bool BOOT>
 static hipError_t launch_ks(const ScanParams& p, hipStream_t st) {
     // (32 K-steps = 2048 components compiled in: no gain, 91.4 ms either way on the fingerprint workload)
-    if (!BOOT && p.i8) return launch_one<L2, J, false, 0, false, true>(p, st);      // the int8 form: main scan only
+    if (p.i8) return launch_one<L2, J, BOOT, 0, false, true>(p, st);      // the int8 form: the bootstrap and the main scan (the re-scan of uncertified queries stays bf16)
     if (!BOOT && p.fixed_thr) return p.Kp == 12 * BK ? launch_one<L2, J, false, 12, true>(p, st) : launch_one<L2, J, false, 0, true>(p, st);
     return p.Kp == 12 * BK ? launch_one<L2, J, BOOT, 12, false>(p, st) : launch_one<L2, J, BOOT, 0, false>(p, st);
 }
