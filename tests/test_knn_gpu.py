@@ -322,6 +322,21 @@ def test_single_rank_sharded_wrapper():
     assert np.array_equal(I.cpu().numpy(), Ir + 100) and np.array_equal(D.cpu().numpy(), Dr)
 
 
+def test_sharded_wrapper_over_fingerprints_runs_the_int8_form():
+    """the stream-ordered begin / finish path of a shard (what ShardedFlatIndex drives) with the integer class: int8 scan, bf16
+    device tensors in, ids offset by the shard's first row"""
+    import torch
+    from textreact_amd.sharded import ShardedFlatIndex
+    from oracle import flat_knn as oracle
+    y = reaction_fp_like(9000, 1024, 41); x = y[4000:4300]
+    idx = ShardedFlatIndex(1024, L2)
+    idx.add_shard(torch.from_numpy(y).cuda().to(torch.bfloat16), 700, 9700)
+    D, I = idx.search(torch.from_numpy(x).cuda().to(torch.bfloat16), 20)
+    Dr, Ir = oracle.knn_canonical(L2, x, y, 20)
+    assert np.array_equal(I.cpu().numpy(), Ir + 700) and np.array_equal(D.cpu().numpy(), Dr)
+    assert idx.local.last_stats()["int8_scan"] == 1
+
+
 def test_cli_on_the_real_index(tmp_path):
     import json
     import pandas as pd
