@@ -71,24 +71,25 @@ def encode(model, input_ids, attention_mask=None, batch_size=256, out_dtype=torc
         lengths = torch.as_tensor(lengths).to(input_ids.device)
         order = torch.argsort(lengths, descending=True, stable=True)
         widths = lengths[order][::batch_size].clamp(min=1, max=input_ids.shape[1]).tolist()      # one host read
+    import contextlib
+    # ONE autocast block around all batches: its cache holds the bf16 casts of the weights, so they are made once per call
+    # and not once per batch (~75 cast launches and half a gigabyte of traffic a batch for BERT-base)
+    ctx = torch.autocast("cuda", dtype=torch.bfloat16) if (autocast and dev.type == "cuda") else contextlib.nullcontext()
     try:
-        for b, lo in enumerate(range(0, n, batch_size)):
-            if order is None:
-                ids = input_ids[lo:lo + batch_size].to(dev)
-                am = None if attention_mask is None else attention_mask[lo:lo + batch_size].to(dev)
-            else:
-                rows = order[lo:lo + batch_size]
-                ids = input_ids[rows, :widths[b]].to(dev)
-                am = None if attention_mask is None else attention_mask[rows, :widths[b]].to(dev)
-            if autocast and dev.type == "cuda":
-                with torch.autocast("cuda", dtype=torch.bfloat16):
-                    e = model(ids, am)
-            else:
+        with ctx:
+            for b, lo in enumerate(range(0, n, batch_size)):
+                if order is None:
+                    ids = input_ids[lo:lo + batch_size].to(dev)
+                    am = None if attention_mask is None else attention_mask[lo:lo + batch_size].to(dev)
+                else:
+                    rows = order[lo:lo + batch_size]
+                    ids = input_ids[rows, :widths[b]].to(dev)
+                    am = None if attention_mask is None else attention_mask[rows, :widths[b]].to(dev)
                 e = model(ids, am)
-            if order is None:
-                out[lo:lo + ids.shape[0]] = e.to(out_dtype)
-            else:
-                out[rows.to(dev)] = e.to(out_dtype)
+                if order is None:
+                    out[lo:lo + ids.shape[0]] = e.to(out_dtype)
+                else:
+                    out[rows.to(dev)] = e.to(out_dtype)
     finally:
         model.train(was_training)
     return out
