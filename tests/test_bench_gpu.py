@@ -32,6 +32,18 @@ def test_single_gpu_line_has_the_contract_fields():
     assert j["cpu_baseline"]["tflops"] > 0 and j["cpu_baseline"]["cores"] >= 1
 
 
+def test_fingerprint_workload_line_runs_the_int8_form():
+    """bench.py --workload fingerprint (the reference's own FAISS call: L2, k = 20, 2048-d counts searching themselves), small:
+    the line says which arithmetic ran, prices it against that arithmetic's peak, and every row finds itself first"""
+    for env_extra, want in (({}, 1), ({"TRX_NO_I8": "1"}, 0)):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "fingerprint", "--steps", "1", "--warmup", "1",
+                            "--n-corpus", "20000", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env_extra))
+        assert r.returncode == 0, r.stderr[-2000:]
+        j = _line(r.stdout)
+        assert j["config"]["int8_scan"] == want and j["dtype"] == ("i8" if want else "bf16"), j
+        assert j["roofline"]["peak"] == (5000.0 if want else 2500.0) and j["config"]["self_is_first"] and j["config"]["exact_class"] == 1
+
+
 @pytest.mark.parametrize("mode", [[], ["--replicas"]])
 def test_two_ranks_as_the_driver_launches_it(mode):
     with socket.socket() as s_:
