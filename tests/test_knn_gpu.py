@@ -42,9 +42,31 @@ def _check(metric, x, y, k, chunks=1, expect_exact_class=None):
 
 @pytest.mark.parametrize("metric", [IP, L2])
 def test_c0_gaussian_fp32(metric):
-    # BASELINE.json configs[0]: 10k x 768 fp32 corpus, 1k queries, top-10 (split-bf16 operand, K = 3d)
+    # BASELINE.json configs[0]: 10k x 768 fp32 corpus, 1k queries, top-10.  Since round 4 the operand is the bf16 rounding
+    # of the fp32 data (K = d), every row within twice the rounding's key error of a query's bound is listed, and the
+    # candidates are certified on their exact scores (approx mode; the three-term split, K = 3d, is the next test)
+    st = _check(metric, gaussian(1000, 768, 5678), gaussian(10000, 768, 1234), 10)
+    assert st["k_split"] == 768 and st["n_uncertified"] == 0
+
+
+@pytest.mark.parametrize("metric", [IP, L2])
+def test_c0_gaussian_fp32_through_the_three_term_split(metric, monkeypatch):
+    """rounds 1-3's form for fp32 data, kept behind TRX_FP32_SPLIT=1: corpus [hi|lo|hi], queries [hi|hi|lo], K = 3d"""
+    monkeypatch.setenv("TRX_FP32_SPLIT", "1")
     st = _check(metric, gaussian(1000, 768, 5678), gaussian(10000, 768, 1234), 10)
     assert st["k_split"] == 3 * 768 and st["n_uncertified"] == 0
+
+
+@pytest.mark.parametrize("metric", [IP, L2])
+def test_fp32_queries_against_a_bf16_index_and_back(metric):
+    """the approx mode's other doors: fp32 queries that bf16 does not hold against an index of bf16 values (nothing about the
+    index changes), bf16 queries against an fp32 index, fp32 rows added to an index that held bf16 values, ragged sizes"""
+    yb, yf = bf16_round(gaussian(9000, 200, 3)), gaussian(4001, 200, 4)
+    xf, xb = gaussian(333, 200, 5), bf16_round(gaussian(130, 200, 6))
+    st = _check(metric, xf, yb, 10)
+    assert st["k_split"] == 256 and st["n_uncertified"] == 0
+    _check(metric, xb, yf, 10)
+    _check(metric, xf, np.concatenate([yb, yf]), 10, chunks=3)
 
 
 @pytest.mark.parametrize("metric", [IP, L2])
@@ -211,7 +233,13 @@ def test_near_duplicate_cluster_is_resolved_by_the_wide_rescore():
     assert st["n_rescored"] == 8 and st["n_uncertified"] == 0
 
 
-def test_a_crowd_around_the_kth_place_is_resolved_by_the_rescan():
+@pytest.mark.parametrize("split", [True, False])
+def test_a_crowd_around_the_kth_place_is_resolved_by_the_rescan(split, monkeypatch):
+    # (split: the three-term operand of rounds 1-3, whose tight key error this crowd was built against.  The approx mode's
+    # error bound is 2^-7 |x||y|: the whole crowd lies inside its listing slack, is listed by the FIRST scan and resolved by the
+    # wide re-score -- same answers, no second scan)
+    if split:
+        monkeypatch.setenv("TRX_FP32_SPLIT", "1")
     # the k-th place INSIDE a crowd that reaches down to the lists' bound: scores fall off smoothly (steps far below the rounding
     # bound) over 3000 rows, so whatever the bound is, rows just under it tie with the k-th and the wide re-score cannot
     # certify.  Tier 3 scans again with the threshold fixed at (k-th exact score so far) - 2 eps: the ~1,400 rows above it
@@ -222,17 +250,20 @@ def test_a_crowd_around_the_kth_place_is_resolved_by_the_rescan():
     x = np.repeat(c, 4, axis=0)
     for metric in (IP, L2):
         st = _check(metric, x, y, 10)
-        assert st["n_rescored"] == 4 and st["n_rescanned"] == 4 and st["n_uncertified"] == 0, st
+        assert st["n_rescored"] == 4 and st["n_rescanned"] == (4 if split else 0) and st["n_uncertified"] == 0, st
 
 
-def test_a_crowd_wider_than_the_lists_still_takes_the_exact_scan():
+@pytest.mark.parametrize("split", [True, False])
+def test_a_crowd_wider_than_the_lists_still_takes_the_exact_scan(split, monkeypatch):
     # 10,000 rows within the rounding bound of each other: more than a query's lists (and the wide re-score) hold
+    if split:
+        monkeypatch.setenv("TRX_FP32_SPLIT", "1")
     y = gaussian(12000, 64, 1)
     c = gaussian(1, 64, 2)
     y[1000:11000] = c * (1.0 - 1e-8 * np.arange(10000, dtype=np.float32)[:, None])
     x = np.repeat(c, 4, axis=0)
     st = _check(IP, x, y, 10)
-    assert st["n_rescanned"] == 4 and st["n_uncertified"] == 4, st
+    assert st["n_uncertified"] == 4 and (st["n_rescanned"] == 4 or not split), st
 
 
 def test_dimension_mismatch_raises():

@@ -24,6 +24,7 @@ hipError_t launch_exact_scan(int, int, int, const int*, int, const int*, int64_t
 hipError_t launch_classify(const void*, int, int, float, int, int, int, int*, hipStream_t);
 hipError_t launch_build_operand_i8(const void*, int, int64_t, int, int64_t, signed char*, int, float, hipStream_t);
 hipError_t launch_fill_bias_i32(const float*, int64_t, int64_t, int*, hipStream_t);
+hipError_t launch_slack(const float*, int64_t, int64_t, float, float, float, int, float*, hipStream_t);
 hipError_t launch_merge(int, int, int64_t, int, const double*, const int64_t*, float*, int64_t*, hipStream_t);
 }  // namespace trx
 
@@ -66,14 +67,20 @@ struct DevBuf {
 // per index.
 struct DevPool {
     std::mutex mu;
-    DevBuf cand, cnt, thr, gthr, qg, qg2, gthr2, qg8;
+    DevBuf cand, cnt, thr, gthr, qg, qg2, gthr2, qg8, slk;
     hipEvent_t last = nullptr;
     int users = 0;
 };
 static DevPool g_pool[64];
 static DevPool& pool_of(int device) { return g_pool[device & 63]; }
 
-enum { MODE_EMPTY = 0, MODE_PLAIN = 1, MODE_SPLIT = 2 };
+// PLAIN: every value is exact in bf16, the operand IS the data.  APPROX (round 4): the operand is the bf16 ROUNDING of fp32 data
+// (K = d), the fp32 rows are kept for the exact pass, and the key error this admits (2^-7 |x||y|) is paid for by listing every row
+// within twice that error of a query's bound and certifying on the exact scores (search_batch: slack).  SPLIT (rounds 1-3, now
+// behind TRX_FP32_SPLIT=1): a three-term bf16 split of the fp32 data, K = 3d, keys good to 2^-16.
+enum { MODE_EMPTY = 0, MODE_PLAIN = 1, MODE_SPLIT = 2, MODE_APPROX = 3 };
+static int inexact_mode() { return getenv("TRX_FP32_SPLIT") ? MODE_SPLIT : MODE_APPROX; }      // (read when an index first meets such data)
+static bool keeps_f32(int mode) { return mode == MODE_SPLIT || mode == MODE_APPROX; }
 static int round_up(int64_t v, int m) { return (int)((v + m - 1) / m * m); }
 static int64_t round_up64(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
@@ -103,7 +110,7 @@ struct trx_index {
     struct Pending {
         bool active = false;
         hipStream_t st = nullptr;
-        int is_bf = 0, k = 0, corpus_is_bf16 = 0, no_fallback = 0, tried_i8 = 0;
+        int is_bf = 0, k = 0, corpus_is_bf16 = 0, no_fallback = 0, tried_i8 = 0, approx = 0; float eps_round = 0.f;
         const void* corpus_orig = nullptr; int64_t ld_c = 0;
         std::vector<PendingBatch> batches;
     } pend;
@@ -137,20 +144,20 @@ static int restructure(trx_index* idx, int64_t newcap, int newmode, hipStream_t 
     HIPCHK(hipMalloc((void**)&nn2, (size_t)newcap * sizeof(float)));
     HIPCHK(hipMemsetAsync(nn2, 0, (size_t)newcap * sizeof(float), st));
     HIPCHK(hipMalloc((void**)&nb, rows_alloc * sizeof(float)));
-    if (newmode == MODE_SPLIT) {
+    if (keeps_f32(newmode)) {
         HIPCHK(hipMalloc((void**)&nCo, (size_t)newcap * idx->d * sizeof(float)));
     }
     if (idx->n > 0) {
         if (idx->mode == newmode) {
             HIPCHK(hipMemcpyAsync(nCg, idx->Cg, (size_t)idx->n * newKp * sizeof(bf16_t),
                                   hipMemcpyDeviceToDevice, st));
-            if (newmode == MODE_SPLIT)
+            if (keeps_f32(newmode))
                 HIPCHK(hipMemcpyAsync(nCo, idx->Co, (size_t)idx->n * idx->d * sizeof(float),
                                       hipMemcpyDeviceToDevice, st));
         } else {
-            // PLAIN -> SPLIT: exact values are the bf16 ones; widen, then lay out [hi|lo=0|hi]
+            // PLAIN -> SPLIT / APPROX: exact values are the bf16 ones; widen, then lay out [hi|lo=0|hi] / the rows as they are
             HIPCHK(launch_widen_rows(idx->Cg, idx->n, idx->d, idx->Kp, nCo, st));
-            HIPCHK(launch_build_operand(nCo, 0, 1, idx->n, idx->d, idx->d, nCg, newKp, st));
+            HIPCHK(launch_build_operand(nCo, 0, newmode == MODE_SPLIT ? 1 : 0, idx->n, idx->d, idx->d, nCg, newKp, st));
         }
         HIPCHK(hipMemcpyAsync(nn2, idx->cnorm2, (size_t)idx->n * sizeof(float), hipMemcpyDeviceToDevice, st));
     }
@@ -205,7 +212,7 @@ void trx_index_destroy(trx_index* idx) {
         if (--pl.users <= 0) {
             pl.users = 0;
             (void)hipDeviceSynchronize();
-            DevBuf* shared[] = {&pl.cand, &pl.cnt, &pl.thr, &pl.gthr, &pl.qg, &pl.qg2, &pl.gthr2, &pl.qg8};
+            DevBuf* shared[] = {&pl.cand, &pl.cnt, &pl.thr, &pl.gthr, &pl.qg, &pl.qg2, &pl.gthr2, &pl.qg8, &pl.slk};
             for (DevBuf* b : shared) b->release();
             // (the ordering event stays for the life of the process: a few bytes, and nothing can hold a stale handle to it)
         }
@@ -266,16 +273,16 @@ int trx_index_add_device(trx_index* idx, const void* x, int64_t n, int dtype, vo
     HostStats hs; rc = read_stats(idx, st, &hs); if (rc) return rc;
 
     int newmode = idx->mode;
-    if (idx->mode == MODE_EMPTY) newmode = hs.inexact_any ? MODE_SPLIT : MODE_PLAIN;
-    else if (idx->mode == MODE_PLAIN && hs.inexact_any) newmode = MODE_SPLIT;
+    if (idx->mode == MODE_EMPTY) newmode = hs.inexact_any ? inexact_mode() : MODE_PLAIN;
+    else if (idx->mode == MODE_PLAIN && hs.inexact_any) newmode = inexact_mode();
     int64_t need = idx->n + n, newcap = idx->cap;
     if (need > newcap) newcap = round_up64(std::max<int64_t>(need, idx->cap + idx->cap / 2), TILE_M);
     if (newcap != idx->cap || newmode != idx->mode) { rc = restructure(idx, newcap, newmode, st); if (rc) return rc; }
 
     // append
     bf16_t* dstg = idx->Cg + idx->n * idx->Kp;
-    if (idx->mode == MODE_SPLIT) {
-        HIPCHK(launch_build_operand(x, is_bf, 1, n, idx->d, idx->d, dstg, idx->Kp, st));
+    if (keeps_f32(idx->mode)) {
+        HIPCHK(launch_build_operand(x, is_bf, idx->mode == MODE_SPLIT ? 1 : 0, n, idx->d, idx->d, dstg, idx->Kp, st));
         float* dsto = idx->Co + idx->n * idx->d;
         if (is_bf) HIPCHK(launch_widen_rows((const bf16_t*)x, n, idx->d, idx->d, dsto, st));
         else HIPCHK(hipMemcpyAsync(dsto, x, (size_t)n * idx->d * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -389,6 +396,13 @@ static int search_batch(trx_index* idx, const void* q, const float* qnorm2, int6
 #endif
     sp.g_thr = (u32*)pl.gthr.p;
     HIPCHK(hipMemsetAsync(sp.g_thr, 0, (size_t)q_pad * 4 * sizeof(u32), st));
+    if (idx->pend.approx) {
+        // approximate operands: a query's listing threshold is its bound minus 2 eps_q (the select kernel's eps_q), so that the
+        // lists hold every row that can reach the top k and the candidates certify on their exact scores without a second scan
+        if ((rc = pl.slk.reserve((size_t)q_pad * sizeof(float)))) return rc;
+        HIPCHK(launch_slack(qnorm2, nq, q_pad, eps_rel, idx->pend.eps_round, idx->maxnorm2, idx->metric == TRX_METRIC_L2 ? 1 : 0, (float*)pl.slk.p, st));
+        sp.slack = (const float*)pl.slk.p;
+    }
     // The integer class has an int8 form of the scan (knn_scan.hip, I8: twice the MACs per instruction, half the bytes per
     // component).  What the HOST knows is the corpus side -- integers, |value| <= 127, stored as they are (plain mode);
     // whether the queries qualify is known on the device only (w_cls[1], classify_kernel), so both launches are enqueued
@@ -465,11 +479,11 @@ static int search_batch(trx_index* idx, const void* q, const float* qnorm2, int6
 
     SelectParams se{};
     se.cand = sp.cand; se.cand_cnt = sp.cand_cnt; se.cand_thr = sp.cand_thr; se.nlists = nlists; se.cap_alloc = cap_alloc;
-    if (idx->mode == MODE_SPLIT) { se.corpus_orig = idx->Co; se.ld_c = d; se.corpus_is_bf16 = 0; }
+    if (keeps_f32(idx->mode)) { se.corpus_orig = idx->Co; se.ld_c = d; se.corpus_is_bf16 = 0; }
     else { se.corpus_orig = idx->Cg; se.ld_c = Kp; se.corpus_is_bf16 = 1; }
     se.query_orig = q; se.ld_q = d; se.query_is_bf16 = is_bf;
     se.d = d; se.metric = idx->metric; se.k = k; se.nq = (int)nq; se.n = idx->n; se.exact_class = (const int*)idx->w_cls.p;
-    se.eps_rel = eps_rel; se.qnorm2 = qnorm2; se.ymax_norm2 = idx->maxnorm2;
+    se.eps_rel = eps_rel; se.eps_round = idx->pend.eps_round; se.qnorm2 = qnorm2; se.ymax_norm2 = idx->maxnorm2;
     se.D = D; se.I = I; se.S64 = S64; se.flagged = flagged; se.nflagged = nflag; se.flag_seed = seed1; se.compact = 0;
     HIPCHK(launch_select(se, st));
     // second tier: flagged queries are re-scored over ALL their listed rows (the lists are still in the shared workspace
@@ -488,7 +502,7 @@ static int search_batch(trx_index* idx, const void* q, const float* qnorm2, int6
         HIPCHK(launch_gather_rescan(flagged2, nflag + 1, seed2, rq, sp.queries, Kp, (bf16_t*)pl.qg2.p, (u32*)pl.gthr2.p, nflag + 3, st));
         ScanParams rp = sp;
         rp.queries = (const bf16_t*)pl.qg2.p; rp.nqtiles = rq / TILE_N; rp.nq_valid = rq; rp.nq_valid_dev = nflag + 3;
-        rp.g_thr = (u32*)pl.gthr2.p; rp.fixed_thr = 1; rp.bootstrap = 0; rp.boot_tiles = 0;
+        rp.g_thr = (u32*)pl.gthr2.p; rp.fixed_thr = 1; rp.bootstrap = 0; rp.boot_tiles = 0; rp.slack = nullptr;      // (its seeds are lowered already)
         HIPCHK(launch_scan(rp, idx->metric, st));
         SelectParams we = se; we.compact = 1;
         HIPCHK(launch_wide_rescore(we, flagged2, nflag + 3, nullptr, flagged3, nflag + 2, nullptr, st));
@@ -576,9 +590,9 @@ static int search_device_impl(trx_index* idx, const void* q, int64_t nq, int dty
         // empty index: all pads.  large k: exact scan for every query (documented slow path)
         const int64_t per = std::max<int64_t>(1, ((int64_t)1 << 29) / std::max<int64_t>(1, idx->n * 8));
         if ((rc = idx->w_exact.reserve((size_t)std::min<int64_t>(per, nq) * std::max<int64_t>(idx->n, 1) * sizeof(double)))) return rc;
-        const void* corig = idx->mode == MODE_SPLIT ? (const void*)idx->Co : (const void*)idx->Cg;
-        const int64_t ldc = idx->mode == MODE_SPLIT ? d : idx->Kp;
-        const int cbf = idx->mode == MODE_SPLIT ? 0 : 1;
+        const void* corig = keeps_f32(idx->mode) ? (const void*)idx->Co : (const void*)idx->Cg;
+        const int64_t ldc = keeps_f32(idx->mode) ? d : idx->Kp;
+        const int cbf = keeps_f32(idx->mode) ? 0 : 1;
         const size_t esz = is_bf ? 2 : 4;
         for (int64_t f0 = 0; f0 < nq; f0 += per) {
             const int m = (int)std::min<int64_t>(per, nq - f0);
@@ -599,20 +613,30 @@ static int search_device_impl(trx_index* idx, const void* q, int64_t nq, int dty
     // The ONE host decision a search can need: fp32 queries that are not exact in bf16 against an index that holds only
     // bf16 data turn the index into its split form.  bf16 queries are exact by construction, and a split index stays
     // split, so only fp32 queries on a plain index read their statistics back; everything else stays on the device.
+    // (Approx mode, the default since round 4: nothing about the index changes -- the queries' rounding to bf16 is one more
+    // term of the key error, paid for by the listing slack; the read-back only chooses the bound.)
+    bool q_inexact = false;
     if (!is_bf && idx->mode == MODE_PLAIN) {
         HostStats hs; rc = read_stats(idx, st, &hs); if (rc) return rc;
-        if (hs.inexact_any) {
+        if (hs.inexact_any && inexact_mode() == MODE_SPLIT) {
             rc = restructure(idx, idx->cap, MODE_SPLIT, st); if (rc) return rc;
             HIPCHK(launch_fill_bias(idx->cnorm2, idx->n, idx->cap + TILE_M, idx->cbias, st));
-        }
+        } else if (hs.inexact_any) q_inexact = true;
     }
     const int q_split = idx->mode == MODE_SPLIT;
+    // approximate operands: the corpus (approx mode) and / or the queries (fp32 that bf16 does not hold) reach the scan rounded
+    // to bf16: |x^.y^ - x.y| <= u (2 + u) |x||y| with u = 2^-8 (round to nearest, 8 significant bits).  fp32 queries against an
+    // approx index are rounded whatever their values (no read-back to find out): the bound covers it.
+    const bool approx = idx->mode == MODE_APPROX || q_inexact;
     // exact class (integer inputs small enough that every fp32 partial sum and the L2 key are exact): decided by a
     // one-thread kernel from the statistics just gathered; the select kernel reads the flag from device memory
     rc = idx->w_cls.reserve(4 * sizeof(int)); if (rc) return rc;
     HIPCHK(launch_classify(idx->w_stats.p, q_split, idx->nonint ? 1 : 0, idx->maxabs, idx->Kp, idx->d,
                            idx->metric == TRX_METRIC_L2 ? 1 : 0, (int*)idx->w_cls.p, st));
     const float eps_rel = (float)((idx->Kp + 64) * std::ldexp(1.0, -23)) + (q_split ? (float)std::ldexp(1.0, -15) : 0.f);
+    // the rounding's share: relative to the product term alone (the L2 key's |y|^2 comes from the exact rows)
+    const float eps_round = approx ? (float)(std::ldexp(1.0, -7) * (1.0 + std::ldexp(1.0, -8))) : 0.f;
+    idx->pend.approx = approx ? 1 : 0; idx->pend.eps_round = eps_round;
     idx->stats.k_split = idx->Kp;
 
     const int64_t QB = 65536;

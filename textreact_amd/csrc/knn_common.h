@@ -127,6 +127,8 @@ struct ScanParams {
     u64* cand_thr;           // [q_pad][nsplits][8] every unlisted row of the list's rows has comp <= this
     u32* g_thr;              // [q_pad / 256][4 slots][256] ordkeys; the smallest of a query's 4 slots is a key that at least kprime corpus rows reach; shared by all
                              // workgroups of a query (atomicMax, monotone; a stale read is only looser)
+    const float* slack;      // optional [q_pad]: a query's listing threshold = the bound its tracked maxima give minus this (accumulator
+                             // units; approximate operands: every row within twice the key error of the bound is listed)
     const int* gate;         // optional DEVICE int: the launch runs only when *gate == gate_want (the bf16 / int8 pair of the exact class)
     int gate_want;
     int i8;                  // 1: the int8 form (corpus / queries hold int8 rows of 2 Kp bytes, cbias int32 -|y|^2, L2 queries doubled)
@@ -155,6 +157,7 @@ struct SelectParams {
     int64_t n;                // corpus rows: ids >= n are pad rows of the last tile (an inner-product scan may list them)
     const int* exact_class;   // DEVICE int: 1 = no certificate needed (integer inputs, every partial sum exact)
     float eps_rel;            // certificate slack, relative to bound_q
+    float eps_round;          // approximate operands (knn_api.hip, approx mode): their rounding's share of the key error, relative to |x||y| (L2: 2|x||y|)
     const float* qnorm2;      // fp32 |x_q|^2 (upper-bound use only)
     float ymax_norm2;         // max |y|^2 over the corpus
     float* D;

@@ -158,6 +158,30 @@ __global__ __launch_bounds__(256) void build_operand_kernel(const void* x, int64
     }
 }
 
+// The listing slack of the approximate mode (knn_api.hip): 2 eps_q in the scan's accumulator units (the L2 form carries key / 2),
+// with eps_q computed exactly as the select kernel computes it (knn_select.hip: the certificate's bound), rounded up.
+__global__ void slack_kernel(const float* qnorm2, int64_t nq, int64_t q_pad, float eps_rel, float eps_round, float ymax_norm2, int l2, float* out) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= q_pad) return;
+    float r = 0.f;
+    if (q < nq) {
+        const float xn2 = qnorm2[q];
+        const float bq = l2 ? (2.0f * sqrtf(xn2 * ymax_norm2) + ymax_norm2) : sqrtf(xn2 * ymax_norm2);
+        const float bx = l2 ? 2.0f * sqrtf(xn2 * ymax_norm2) : sqrtf(xn2 * ymax_norm2);
+        const double eps = ((double)eps_rel * (double)bq + (double)eps_round * (double)bx) * 1.0001 + 1e-30;
+        const double sl = l2 ? eps : 2.0 * eps;        // 2 eps in key units = eps in units of key / 2
+        r = (float)sl;
+        if ((double)r < sl) r = nextafterf(r, __builtin_inff());
+        if (!(r < 3.0e38f)) r = 3.0e38f;              // a non-finite bound: list everything (the certificate fails anyway)
+    }
+    out[q] = r;
+}
+hipError_t launch_slack(const float* qnorm2, int64_t nq, int64_t q_pad, float eps_rel, float eps_round, float ymax_norm2, int l2, float* out, hipStream_t st) {
+    if (q_pad <= 0) return hipSuccess;
+    hipLaunchKernelGGL(slack_kernel, dim3((unsigned)((q_pad + 255) / 256)), dim3(256), 0, st, qnorm2, nq, q_pad, eps_rel, eps_round, ymax_norm2, l2, out);
+    return hipGetLastError();
+}
+
 // int8 operand rows for the integer class: component c of row r -> (int8)(scale * value) (scale 2: the queries of an L2
 // search), zero beyond d up to the row's Kp8 bytes.  One thread per (row, 16-byte group).  A value that is not a small
 // integer gives garbage -- the launch that would read it is gated off on the device then (classify_kernel, out[1]).

@@ -91,9 +91,10 @@ constexpr int S_GTHR = S_THRW + 2 * TILE_N * 4;  // u32 [4 slots][256] copy of g
 constexpr int S_E2 = S_GTHR + 4 * TILE_N * 4;    // f32 [2 wave rows][256] second-best tracked maximum of a wave row (what the split shares)
 constexpr int S_BIAS = S_E2 + 2 * TILE_N * 4;    // f32 [2 tile parities][256 rows]  (L2)
 constexpr int S_TRK = S_BIAS + 2 * TILE_M * 4;   // u32 [8][512 threads]: every lane's tracked tile maxima (see tile_end)
-constexpr int LDS_TOTAL = S_TRK + 8 * SCAN_THREADS * 4;   // 157,696 B -> one workgroup per CU
+constexpr int S_SLK = S_TRK + 8 * SCAN_THREADS * 4;       // f32 [256 queries]: the listing slack of a query (ScanParams.slack), zeros without one
+constexpr int LDS_TOTAL = S_SLK + TILE_N * 4;             // 158,720 B -> one workgroup per CU
 // ds instruction offsets are 16-bit: the selection state is addressed relative to S_THRW
-constexpr int R_THRW = 0, R_GTHR = S_GTHR - S_THRW, R_E2 = S_E2 - S_THRW;
+constexpr int R_THRW = 0, R_GTHR = S_GTHR - S_THRW, R_E2 = S_E2 - S_THRW, R_SLK = S_SLK - S_THRW;
 
 // LDS accesses of the selection state go through asm: a C++ access to the array the LDS-DMA writes makes
 // hipcc drain vmcnt to 0 (cdna_hip_programming.md section 5, "Three .s-level traps").  Addresses are
@@ -309,6 +310,10 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
         lds_st32<R_GTHR + 2048>(t4, BOOT ? 0u : __hip_atomic_load(gsrc + 512 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         lds_st32<R_THRW>(t4, __float_as_uint(NEG_INF));      // 512 threads: both wave rows
         lds_st32<R_E2>(t4, __float_as_uint(NEG_INF));
+        // the listing slack of this tile's queries (approximate operands: knn_api.hip, the approx mode): a query's threshold
+        // is the bound its tracked maxima give MINUS this, so that every row within twice the key error of the bound is
+        // listed and the candidates can be certified without a second scan; shared bounds (g_thr) stay raw
+        if (tid < TILE_N) lds_st32<R_SLK>(t4, (!BOOT && p.slack) ? __float_as_uint(p.slack[qbase + tid]) : 0u);
     }
 
     acc_t acc[8][4];
@@ -364,7 +369,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
             const u32 g01 = min(lds_ld32<R_GTHR + 64 * nt>(b4_0), lds_ld32<R_GTHR + 1024 + 64 * nt>(b4_0));
             const u32 g23 = min(lds_ld32<R_GTHR + 2048 + 64 * nt>(b4_0), lds_ld32<R_GTHR + 3072 + 64 * nt>(b4_0));
             const u32 g = min(g01, g23);
-            if (g) thrk[nt] = KI * ordkey_inv(g);
+            if (g) thrk[nt] = KI * ordkey_inv(g) - __uint_as_float(lds_ld32<R_SLK + 64 * nt>(b4_0));
         };
         seed(ic<0>{}); seed(ic<1>{}); seed(ic<2>{}); seed(ic<3>{});
         // the pad rows of the last query tile (zero vectors) list nothing: under the inner product every corpus row scores
@@ -589,14 +594,25 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
                 asm volatile("ds_read_b32 %0, %4 offset:%5\n\tds_read_b32 %1, %4 offset:%6\n\tds_read_b32 %2, %4 offset:%7\n\tds_read_b32 %3, %4 offset:%8"
                              : "=&v"(gs[sl][0]), "=&v"(gs[sl][1]), "=&v"(gs[sl][2]), "=&v"(gs[sl][3])
                              : "v"(b4_0 + sl * 1024), "n"(R_GTHR), "n"(R_GTHR + 64), "n"(R_GTHR + 128), "n"(R_GTHR + 192) : "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            u32 sk[4];      // the queries' listing slack (zeros unless the operands are approximate): a threshold = a bound minus it
+            // (the reads and their wait in ONE statement, and the wait names the earlier reads' registers: a wait that names
+            // nothing orders nothing -- the first form of this had its subtraction scheduled in front of the wait, a quarter of
+            // a batch's queries got a threshold off by whatever the register held and went through the re-scan)
+            asm volatile("ds_read_b32 %0, %4 offset:%5\n\tds_read_b32 %1, %4 offset:%6\n\tds_read_b32 %2, %4 offset:%7\n\tds_read_b32 %3, %4 offset:%8\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(sk[0]), "=&v"(sk[1]), "=&v"(sk[2]), "=&v"(sk[3])
+                         : "v"(b4_0), "n"(R_SLK), "n"(R_SLK + 64), "n"(R_SLK + 128), "n"(R_SLK + 192) : "memory");
+            asm volatile("" : "+v"(gp[0]), "+v"(gp[1]), "+v"(gp[2]), "+v"(gp[3]));
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl) asm volatile("" : "+v"(gs[sl][0]), "+v"(gs[sl][1]), "+v"(gs[sl][2]), "+v"(gs[sl][3]));
             const bool publish = !BOOT && ((TL & TRX_PUB_MASK) == TRX_PUB_MASK || TL == 7);
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
+                const float slk = __uint_as_float(sk[nt]);
                 const float both = __builtin_fminf(g[nt], __uint_as_float(gp[nt]));      // 8 J rows of this split reach this key
-                float t = __builtin_fmaxf(thrk[nt], both);
+                float t = __builtin_fmaxf(thrk[nt], both - slk);
                 const u32 gm = min(min(gs[0][nt], gs[1][nt]), min(gs[2][nt], gs[3][nt])); // kprime rows of the corpus reach this one
-                if (gm) t = __builtin_fmaxf(t, KI * ordkey_inv(gm));
+                if (gm) t = __builtin_fmaxf(t, KI * ordkey_inv(gm) - slk);
                 thrk[nt] = t;
             }
             if (publish) {

@@ -183,7 +183,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         // error bound of an approximate key (the same one the certificate uses below)
         const float xn2 = p.qnorm2[q];
         const float bq = L2 ? (2.0f * sqrtf(xn2 * p.ymax_norm2) + p.ymax_norm2) : sqrtf(xn2 * p.ymax_norm2);
-        const double eps = (double)p.eps_rel * (double)bq * 1.0001 + 1e-30;
+        const float bx = L2 ? 2.0f * sqrtf(xn2 * p.ymax_norm2) : sqrtf(xn2 * p.ymax_norm2);      // what operand rounding scales with: the product term alone
+        const double eps = ((double)p.eps_rel * (double)bq + (double)p.eps_round * (double)bx) * 1.0001 + 1e-30;
         // ---- 1b. epsilon window: |approximate - exact| <= eps for every row, so the k candidates with the best
         // approximate keys all have exact keys >= a_k - eps (a_k = the k-th best approximate key); a candidate whose
         // approximate key is below a_k - 2 eps has an exact key < a_k - eps and cannot reach the top k: it is not
@@ -485,7 +486,8 @@ __global__ __launch_bounds__(256) void wide_rescore_kernel(SelectParams p, const
         else {
             const float xn2 = p.qnorm2[q];
             const float bq = L2 ? (2.0f * sqrtf(xn2 * p.ymax_norm2) + p.ymax_norm2) : sqrtf(xn2 * p.ymax_norm2);
-            const double eps = (double)p.eps_rel * (double)bq * 1.0001 + 1e-30;
+            const float bx = L2 ? 2.0f * sqrtf(xn2 * p.ymax_norm2) : sqrtf(xn2 * p.ymax_norm2);      // what operand rounding scales with: the product term alone
+            const double eps = ((double)p.eps_rel * (double)bq + (double)p.eps_round * (double)bx) * 1.0001 + 1e-30;
             const double bound = (double)comp_key(T) + eps;
             double xx = 0.0;
             if (L2) for (int i = 0; i < p.d; ++i) { const double v = load_as_double<QBF>(qrow, i); xx = __builtin_fma(v, v, xx); }
@@ -508,7 +510,8 @@ __global__ __launch_bounds__(256) void wide_rescore_kernel(SelectParams p, const
                 if (got >= p.k && !exact_class && !overflow) {
                     const float xn2 = p.qnorm2[q];
                     const float bq = L2 ? (2.0f * sqrtf(xn2 * p.ymax_norm2) + p.ymax_norm2) : sqrtf(xn2 * p.ymax_norm2);
-                    const double eps = (double)p.eps_rel * (double)bq * 1.0001 + 1e-30;
+                    const float bx = L2 ? 2.0f * sqrtf(xn2 * p.ymax_norm2) : sqrtf(xn2 * p.ymax_norm2);      // what operand rounding scales with: the product term alone
+                    const double eps = ((double)p.eps_rel * (double)bq + (double)p.eps_round * (double)bx) * 1.0001 + 1e-30;
                     double xx = 0.0;
                     if (L2) for (int i = 0; i < p.d; ++i) { const double v = load_as_double<QBF>(qrow, i); xx = __builtin_fma(v, v, xx); }
                     const float mine = __double2float_rd((L2 ? xx - pick_s[p.k - 1] : pick_s[p.k - 1]) - 2.0 * eps);
