@@ -368,8 +368,10 @@ def mark_parameters_updated(module):
     # step's ~13 ms of host time, tools/host_profile.py; a registry itself is made lazily by the first forward)
     holders = module.__dict__.get("_shadow_holders")
     if holders is None:
-        holders = module.__dict__["_shadow_holders"] = list(module.modules())
-    for m in holders:
+        # (without the module itself: a list that holds its owner is a reference cycle, and the model would wait for the
+        # cycle collector instead of being freed with its last reference)
+        holders = module.__dict__["_shadow_holders"] = [m for m in module.modules() if m is not module]
+    for m in [module] + holders:
         reg = m.__dict__.get("_weight_shadows")
         if reg is not None:
             reg.mark_stale()
