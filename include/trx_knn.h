@@ -123,7 +123,8 @@ typedef struct trx_search_stats {
     int64_t nq;            /* queries in the call */
     int64_t n_uncertified; /* queries whose candidate lists could not be certified exact and were
                               re-done by the exact fp64 scan of the whole index (0 on benign inputs) */
-    int32_t k_split;       /* K of the bf16 MFMA contraction: d (inputs exact in bf16) or 3d */
+    int32_t k_split;       /* K of the bf16 MFMA contraction: d (inputs exact in bf16; since round 4 also fp32 inputs, through
+                              their bf16 rounding and a listing slack) or 3d (fp32 inputs as a three-term split: TRX_FP32_SPLIT=1) */
     int32_t n_splits;      /* corpus column-splits per query tile in the scan kernel */
     int32_t exact_class;   /* 1 = all partial sums exactly representable (integer inputs) */
     int32_t scan_launches; /* scan-kernel launches in the call */
