@@ -218,6 +218,66 @@ def test_k_range(k):
     _check(L2, gaussian(40, 48, 3), gaussian(2500, 48, 4), k)
 
 
+def _clustered(n, nq, d, seed):
+    rng = np.random.default_rng(seed)
+    c = rng.standard_normal((40, d)).astype(np.float32)
+    y = c[rng.integers(0, 40, n)] + 0.3 * rng.standard_normal((n, d)).astype(np.float32)
+    x = c[rng.integers(0, 40, nq)] + 0.3 * rng.standard_normal((nq, d)).astype(np.float32)
+    return y, x
+
+
+@pytest.mark.parametrize("k", [25, 64, 100, 256])
+@pytest.mark.parametrize("kind", ["bf16", "fp32", "fingerprints", "clustered"])
+def test_two_scan_path_for_k_above_24(k, kind):
+    """TRX_FAST_MAX_K < k <= TRX_WIDE_MAX_K: a first scan ranks 24 rows per query, a second lists every row above a threshold
+    extrapolated from them and the wide re-score proves the k best; a query left with fewer than k rows (n_rescored) gets a
+    better threshold from the rows it did find and a third scan (n_rescanned); only what fails that takes the exact scan.  The
+    oracle's answer in every case; on continuous data, clustered or not, (almost) nobody needs the exact scan."""
+    if kind == "fingerprints":
+        y = reaction_fp_like(20000, 512, 61); x = np.concatenate([y[:200], reaction_fp_like(56, 512, 62)])
+    elif kind == "clustered":      # 1,000-row clusters: the scores of a query fall off a cliff the first 24 know nothing about
+        y, x = _clustered(40000, 300, 96, 65)
+        y, x = bf16_round(y), bf16_round(x)
+    else:
+        y, x = gaussian(40000, 96, 63), gaussian(300, 96, 64)
+        if kind == "bf16":
+            y, x = bf16_round(y), bf16_round(x)
+    for metric in (IP, L2):
+        st = _check(metric, x, y, k)
+        assert st["n_rescanned"] == st["n_rescored"], st                # every unproven query had room in the third scan
+        if kind != "fingerprints":                                        # (count data ties by the hundred at the k-th place)
+            assert st["n_rescored"] <= x.shape[0] // (3 if kind == "clustered" else 10), st
+            assert st["n_uncertified"] <= x.shape[0] // 100, st
+
+
+def test_two_scan_path_on_small_and_awkward_indexes():
+    # fewer rows than k, fewer than 24, a crowd of near-duplicates around the k-th place, k = 257 (the exact scan for every query)
+    for n, k in ((10, 25), (30, 100), (300, 256), (5000, 257)):
+        _check(IP, gaussian(37, 48, 5), gaussian(n, 48, 6), k)
+        _check(L2, gaussian(37, 48, 5), gaussian(n, 48, 6), k)
+    y = gaussian(6000, 64, 1); c = gaussian(1, 64, 2)
+    y[1000:1400] = c * (1.0 - 1e-7 * np.arange(400, dtype=np.float32)[:, None])
+    _check(IP, np.repeat(c, 4, axis=0), y, 100)
+
+
+@pytest.mark.parametrize("k", [5, 300, 2048])
+def test_exact_scan_selection_radix_descent_sort_and_ties(k):
+    """the exact scan's selection (k > TRX_WIDE_MAX_K, and every fall-back): radix descent to the k-th key, one sort; more rows
+    TIED at the k-th score than the sort holds (12,000 copies of three rows; count data) -> the first of them in row order"""
+    x = gaussian(9, 32, 11)
+    _check(IP, x, gaussian(30000, 32, 12), k)
+    _check(L2, x, gaussian(30000, 32, 12), k)
+    three = gaussian(3, 32, 13)
+    y = three[np.random.default_rng(14).integers(0, 3, 12000)]
+    if k > 24:                                                           # (k <= 24 only reaches the exact scan as a fall-back)
+        _check(IP, x, y, k)
+        _check(L2, x, y, k)
+    fp = reaction_fp_like(15000, 256, 15)
+    _check(IP, fp[:7], fp, max(k, 257))
+    _check(L2, fp[:7], fp, max(k, 257))
+    _check(IP, x, gaussian(100, 32, 16), max(k, 257))                    # fewer rows than k
+
+
 def test_near_duplicate_cluster_is_resolved_by_the_wide_rescore():
     # 200 rows within ~1e-7 of each other, far above everything else: the 32 candidates the select kernel re-scores cannot
     # prove the top 10 (the 33rd row ties with them), so the query is flagged -- and the second tier (round 4) re-scores ALL

@@ -25,6 +25,7 @@ hipError_t launch_classify(const void*, int, int, float, int, int, int, int*, hi
 hipError_t launch_build_operand_i8(const void*, int, int64_t, int, int64_t, signed char*, int, float, hipStream_t);
 hipError_t launch_fill_bias_i32(const float*, int64_t, int64_t, int*, hipStream_t);
 hipError_t launch_slack(const float*, int64_t, int64_t, float, float, float, int, float*, hipStream_t);
+hipError_t launch_bigk_seeds(int, const float*, const int64_t*, int, int, int, const float*, float, float, float, int*, int*, float*, hipStream_t);
 hipError_t launch_merge(int, int, int64_t, int, const double*, const int64_t*, float*, int64_t*, hipStream_t);
 }  // namespace trx
 
@@ -67,7 +68,7 @@ struct DevBuf {
 // per index.
 struct DevPool {
     std::mutex mu;
-    DevBuf cand, cnt, thr, gthr, qg, qg2, gthr2, qg8, slk;
+    DevBuf cand, cnt, thr, gthr, qg, qg2, gthr2, qg8, slk, d1, i1;
     hipEvent_t last = nullptr;
     int users = 0;
 };
@@ -212,7 +213,7 @@ void trx_index_destroy(trx_index* idx) {
         if (--pl.users <= 0) {
             pl.users = 0;
             (void)hipDeviceSynchronize();
-            DevBuf* shared[] = {&pl.cand, &pl.cnt, &pl.thr, &pl.gthr, &pl.qg, &pl.qg2, &pl.gthr2, &pl.qg8, &pl.slk};
+            DevBuf* shared[] = {&pl.cand, &pl.cnt, &pl.thr, &pl.gthr, &pl.qg, &pl.qg2, &pl.gthr2, &pl.qg8, &pl.slk, &pl.d1, &pl.i1};
             for (DevBuf* b : shared) b->release();
             // (the ordering event stays for the life of the process: a few bytes, and nothing can hold a stale handle to it)
         }
@@ -350,7 +351,10 @@ static int search_batch(trx_index* idx, const void* q, const float* qnorm2, int6
     { const char* e = getenv("TRX_NSPLITS"); if (e) nsplits = std::max(1, std::min(atoi(e), ntiles)); }
     int tps = (ntiles + nsplits - 1) / nsplits;
     nsplits = (ntiles + tps - 1) / tps;  // drop empty trailing splits
-    const int kprime = k <= 12 ? 16 : 32;
+    // TRX_FAST_MAX_K < k <= TRX_WIDE_MAX_K: the first scan serves kf = 24 (its exact scores seed the second scan's threshold)
+    const bool bigk = k > TRX_FAST_MAX_K;
+    const int kf = bigk ? TRX_FAST_MAX_K : k;
+    const int kprime = kf <= 12 ? 16 : 32;
     const int nlists = nsplits * LISTS_PER_SPLIT;
     // a lane lists ~20 (kprime 16) to ~40 (kprime 32) rows per split on random data; a list that could not take another
     // tile (32 rows) is compacted by the scan kernel, so leave room: 127 = the most a 7-bit counter counts
@@ -482,10 +486,46 @@ static int search_batch(trx_index* idx, const void* q, const float* qnorm2, int6
     if (keeps_f32(idx->mode)) { se.corpus_orig = idx->Co; se.ld_c = d; se.corpus_is_bf16 = 0; }
     else { se.corpus_orig = idx->Cg; se.ld_c = Kp; se.corpus_is_bf16 = 1; }
     se.query_orig = q; se.ld_q = d; se.query_is_bf16 = is_bf;
-    se.d = d; se.metric = idx->metric; se.k = k; se.nq = (int)nq; se.n = idx->n; se.exact_class = (const int*)idx->w_cls.p;
+    se.d = d; se.metric = idx->metric; se.k = kf; se.nq = (int)nq; se.n = idx->n; se.exact_class = (const int*)idx->w_cls.p;
     se.eps_rel = eps_rel; se.eps_round = idx->pend.eps_round; se.qnorm2 = qnorm2; se.ymax_norm2 = idx->maxnorm2;
     se.D = D; se.I = I; se.S64 = S64; se.flagged = flagged; se.nflagged = nflag; se.flag_seed = seed1; se.compact = 0;
+    if (bigk) {      // the first scan's 24 exact scores per query go to a scratch of their own
+        if ((rc = pl.d1.reserve((size_t)q_pad * kf * sizeof(float)))) return rc;
+        if ((rc = pl.i1.reserve((size_t)q_pad * kf * sizeof(int64_t)))) return rc;
+        se.D = (float*)pl.d1.p; se.I = (int64_t*)pl.i1.p; se.S64 = nullptr;
+    }
     HIPCHK(launch_select(se, st));
+    int* final_list; int* final_cnt;
+    if (bigk) {
+        // Second scan, for EVERY query: thresholds fixed at a guess of the k-th best key (bigk_seed_kernel), every row above it
+        // listed by construction; the wide re-score ranks those rows exactly and proves the answer -- k exact scores above
+        // (threshold + eps).  A query it cannot prove (the guess left fewer than k rows: clustered data; or a crowd of ties
+        // at the threshold) comes back with a better threshold, from the rows the second scan did find, for a third scan of
+        // those queries alone; what fails that too, or exceeds its capacity, takes the exact scan.
+        //   counters: [1] all queries (the identity list), [0] unproven after the second scan, [3] of those, the ones the
+        //   third scan has room for, [2] unproven after that (-> exact scan)
+        HIPCHK(hipMemsetAsync(nflag, 0, 4 * sizeof(int), st));      // (the select kernel's flags concerned the 24)
+        HIPCHK(launch_bigk_seeds(idx->metric == TRX_METRIC_L2 ? 1 : 0, (const float*)pl.d1.p, (const int64_t*)pl.i1.p, (int)nq, kf, k, qnorm2, eps_rel,
+                                 idx->pend.eps_round, idx->maxnorm2, flagged2, nflag + 1, seed2, st));
+        const int rq2 = (int)q_pad;
+        if ((rc = pl.qg2.reserve((size_t)rq2 * Kp * sizeof(bf16_t)))) return rc;
+        if ((rc = pl.gthr2.reserve((size_t)rq2 * 4 * sizeof(u32)))) return rc;
+        HIPCHK(launch_gather_rescan(flagged2, nflag + 1, seed2, rq2, sp.queries, Kp, (bf16_t*)pl.qg2.p, (u32*)pl.gthr2.p, nflag + 1, st));
+        ScanParams rp = sp;
+        rp.queries = (const bf16_t*)pl.qg2.p; rp.nqtiles = rq2 / TILE_N; rp.nq_valid = rq2; rp.nq_valid_dev = nflag + 1;
+        rp.g_thr = (u32*)pl.gthr2.p; rp.fixed_thr = 1; rp.bootstrap = 0; rp.boot_tiles = 0; rp.slack = nullptr; rp.kprime = 32;
+        HIPCHK(launch_scan(rp, idx->metric, st));
+        SelectParams we = se; we.compact = 1; we.k = k; we.D = D; we.I = I; we.S64 = S64; we.extrap = 1;
+        HIPCHK(launch_wide_rescore(we, flagged2, nflag + 1, seed2, flagged, nflag, seed1, st));
+        const int rq3 = (int)std::min<int64_t>(RESCAN_MAX, q_pad);
+        HIPCHK(launch_gather_rescan(flagged, nflag, seed1, rq3, sp.queries, Kp, (bf16_t*)pl.qg2.p, (u32*)pl.gthr2.p, nflag + 3, st));
+        rp.nqtiles = rq3 / TILE_N; rp.nq_valid = rq3; rp.nq_valid_dev = nflag + 3;
+        HIPCHK(launch_scan(rp, idx->metric, st));
+        we.extrap = 0;
+        HIPCHK(launch_wide_rescore(we, flagged, nflag + 3, nullptr, flagged3, nflag + 2, nullptr, st));
+        HIPCHK(launch_append_tail(flagged, nflag, rq3, flagged3, nflag + 2, st));
+        final_list = flagged3; final_cnt = nflag + 2;
+    } else {
     // second tier: flagged queries are re-scored over ALL their listed rows (the lists are still in the shared workspace
     // here); what that cannot certify either goes on to the exact scan
     HIPCHK(launch_wide_rescore(se, flagged, nflag, seed1, flagged2, nflag + 1, seed2, st));
@@ -494,7 +534,7 @@ static int search_batch(trx_index* idx, const void* q, const float* qnorm2, int6
     // every row that can matter is listed by construction; then the wide re-score over THOSE lists.  A crowd of near-ties
     // around the k-th place costs a few MFMA tile-passes instead of an fp64 scan of the index; what overflows the lists (more
     // than ~4,000 rows above the seed) or the re-scan's capacity goes on to the exact scan.
-    int* final_list = flagged2; int* final_cnt = nflag + 1;
+    final_list = flagged2; final_cnt = nflag + 1;
     if (sp.debug == 0 && !getenv("TRX_NO_RESCAN")) {
         const int rq = (int)std::min<int64_t>(RESCAN_MAX, q_pad);
         if ((rc = pl.qg2.reserve((size_t)rq * Kp * sizeof(bf16_t)))) return rc;
@@ -508,6 +548,7 @@ static int search_batch(trx_index* idx, const void* q, const float* qnorm2, int6
         HIPCHK(launch_wide_rescore(we, flagged2, nflag + 3, nullptr, flagged3, nflag + 2, nullptr, st));
         HIPCHK(launch_append_tail(flagged2, nflag + 1, rq, flagged3, nflag + 2, st));
         final_list = flagged3; final_cnt = nflag + 2;
+    }
     }
 
     // certificate failures -> exact scan of those queries.  The count stays on the device: the first INLINE_FALLBACK of
@@ -586,8 +627,8 @@ static int search_device_impl(trx_index* idx, const void* q, int64_t nq, int dty
     idx->pend = trx_index::Pending{};
     idx->pend.active = true; idx->pend.st = st; idx->pend.is_bf = is_bf; idx->pend.k = k;
 
-    if (idx->n == 0 || k > TRX_FAST_MAX_K) {
-        // empty index: all pads.  large k: exact scan for every query (documented slow path)
+    if (idx->n == 0 || k > TRX_WIDE_MAX_K) {
+        // empty index: all pads.  k > TRX_WIDE_MAX_K: exact scan for every query (documented slow path)
         const int64_t per = std::max<int64_t>(1, ((int64_t)1 << 29) / std::max<int64_t>(1, idx->n * 8));
         if ((rc = idx->w_exact.reserve((size_t)std::min<int64_t>(per, nq) * std::max<int64_t>(idx->n, 1) * sizeof(double)))) return rc;
         const void* corig = keeps_f32(idx->mode) ? (const void*)idx->Co : (const void*)idx->Cg;

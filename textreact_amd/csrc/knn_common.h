@@ -167,6 +167,8 @@ struct SelectParams {
     int* nflagged;
     float* flag_seed;         // [nq] per query: a key every row that can still reach the query's top k exceeds (see knn_api.hip, tier 3)
     int compact;              // 1: the lists are indexed by the position in the flagged list (re-scan), not by the query number
+    int extrap;               // wide re-score of the two-scan path (k > TRX_FAST_MAX_K): a query with fewer than k rows above its guessed
+                              // threshold gets a lower one, extrapolated from the rows it did find (seed_out), for one more scan
 };
 
 // launchers implemented in the .hip files

@@ -16,7 +16,7 @@ for it in range(n_cases):
     d = rng.choice([1, 3, 17, 64, 65, 100, 128, 200, 256, 300, 768, 1024])
     n = rng.choice([1, 2, 7, 255, 256, 257, 1000, 5000, 20000, 60000])
     nq = rng.choice([1, 2, 63, 64, 65, 255, 256, 257, 700])
-    k = rng.choice([1, 2, 10, 20, 24, 25, 64, 100])
+    k = rng.choice([1, 2, 10, 20, 24, 25, 64, 100, 256, 300, 2048])      # (25 .. 256: the two-scan path; above: the exact scan)
     if kind == "gauss":
         y, x = gaussian(n, d, 2 * it), gaussian(nq, d, 2 * it + 1)
     elif kind == "gauss_bf16":
