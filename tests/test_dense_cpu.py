@@ -50,6 +50,11 @@ def test_encode_is_batching_invariant_and_leaves_the_mode_alone():
     c = dense.encode(e, ids, am2, batch_size=2, out_dtype=torch.float32, lengths=lens)
     d_ = dense.encode(e, ids, am2, batch_size=64, out_dtype=torch.float32)
     assert torch.allclose(c, d_, atol=1e-5)
+    # a batch holds as many rows as fit `batch_tokens` padded tokens (multiples of 64, at least batch_size): any budget, the
+    # fixed-rows form (0) included, gives the same embeddings in the same places
+    for bt in (0, 1, 64 * int(lens.max()), 1 << 20):
+        f = dense.encode(e, ids, am2, batch_size=2, out_dtype=torch.float32, lengths=lens, batch_tokens=bt)
+        assert torch.allclose(f, d_, atol=1e-5), bt
     n = dense.DenseEncoder(Config(**json.loads(str(z["enc_cfg"]))), normalize=True)
     n.load_state_dict(e.state_dict()); n.eval()
     with torch.no_grad():

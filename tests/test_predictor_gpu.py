@@ -409,6 +409,31 @@ def test_dense_producer_feeds_the_flat_index_on_device(tmp_path):
     assert float((corpus[:64].float() - ref).abs().max()) <= 5e-2 * max(1.0, float(ref.abs().max()))
 
 
+def test_packed_projection_weights_of_the_inference_path_follow_the_parameters(monkeypatch):
+    """ops.linear_multi keeps the packed bf16 query / key / value weight of a layer between the batches of an encode and
+    drops it when a parameter changes in place (an optimiser step between two refreshes); the embeddings are those of the
+    concatenate-every-call form, bit for bit, before and after"""
+    from textreact_amd import dense
+    cfg = Config(vocab_size=500, num_hidden_layers=2, max_position_embeddings=64)
+    torch.manual_seed(0)
+    enc = dense.DenseEncoder(cfg).cuda().eval()
+    g = torch.Generator().manual_seed(3)
+    ids = torch.randint(1, 500, (300, 40), generator=g).cuda(); am = torch.ones_like(ids); am[::3, 17:] = 0
+    lens = am.sum(dim=1)
+    a = dense.encode(enc, ids, am, lengths=lens)
+    w = enc.encoder.encoder.layer[0].attention.self.query.weight
+    assert "_trx_packed" in w.__dict__
+    with torch.no_grad():
+        enc.encoder.encoder.layer[0].attention.self.key.bias.add_(0.5)
+        enc.encoder.encoder.layer[1].attention.self.value.weight.mul_(1.25)
+    b = dense.encode(enc, ids, am, lengths=lens)
+    assert not torch.equal(a, b)
+    plain = lambda x, ws, bs=None: ops.linear(x, torch.cat(list(ws)), None if bs is None else torch.cat(list(bs)))
+    monkeypatch.setattr(ops, "linear_multi", plain)
+    c = dense.encode(enc, ids, am, lengths=lens)
+    assert torch.equal(b, c)
+
+
 @pytest.mark.parametrize("train_mode", [False, True])
 def test_model_under_bf16_autocast_hip_vs_torch(train_mode):
     """--precision 16-mixed style: Linear layers emit bf16, the residual stream stays fp32 (mixed operand

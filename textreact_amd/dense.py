@@ -51,43 +51,58 @@ class DenseEncoder(nn.Module):
 
 
 @torch.no_grad()
-def encode(model, input_ids, attention_mask=None, batch_size=256, out_dtype=torch.bfloat16, autocast=True, lengths=None):
+def encode(model, input_ids, attention_mask=None, batch_size=256, out_dtype=torch.bfloat16, autocast=True, lengths=None,
+           batch_tokens=65536):
     """[N, L] token ids -> [N, hidden] embeddings on the model's device, in batches; eval mode, and by
-    default bf16 autocast (the matrix-core attention path).  The ids may live on the host: only one
-    batch at a time is moved.
+    default bf16 autocast (the matrix-core attention path).  The ids may live on the host (up to 1 GiB of them are moved
+    at once, more a batch at a time).
 
     lengths [N] (tokens per row, special tokens included; padding behind them): the rows are encoded longest first and
     every batch is cut to ITS longest row -- a corpus of passages of 16 ... 130 tokens padded to 130 is 44 % padding, and
     the encoder's cost is linear in the padded width (a key mask hides padding from the attention, it does not make it
-    free).  The embedding of a row does not depend on the width it was padded to beyond the rounding of the library
-    GEMMs, whose tile choice may change with the batch shape."""
+    free) -- and holds as many rows as fit `batch_tokens` padded tokens (a multiple of 64, at least `batch_size`): the
+    encoder's GEMMs see ~65,000 rows whatever the width (256 rows of 74 tokens are 19,000: 46.9 k passages/s of 16 ... 128
+    tokens through BERT-base on one MI355X; 65,536 tokens a batch: 55.6 k; tools/encode_profile.py).  The embedding of a row does not depend on the width it was padded to, nor on its batch,
+    beyond the rounding of the library GEMMs, whose tile choice may change with the batch shape."""
     dev = next(model.parameters()).device
     was_training = model.training
     model.eval()
     n = input_ids.shape[0]
     out = torch.empty((n, model.encoder.embeddings.word_embeddings.embedding_dim), dtype=out_dtype, device=dev)
+    if input_ids.device != dev and input_ids.numel() * input_ids.element_size() <= (1 << 30):
+        # (row gathers of a host tensor cost tens of milliseconds a batch where torch's CPU thread pool is larger than the
+        # cores the process may use; one copy of the ids is a few hundred megabytes at most)
+        input_ids = input_ids.to(dev)
+        attention_mask = None if attention_mask is None else attention_mask.to(dev)
     order = None
     if lengths is not None and n:
         lengths = torch.as_tensor(lengths).to(input_ids.device)
         order = torch.argsort(lengths, descending=True, stable=True)
-        widths = lengths[order][::batch_size].clamp(min=1, max=input_ids.shape[1]).tolist()      # one host read
+        sorted_len = lengths[order].clamp(min=1, max=input_ids.shape[1]).tolist()      # one host read
+        bounds, lo = [], 0
+        while lo < n:
+            rows = max(batch_size, (batch_tokens // sorted_len[lo]) // 64 * 64) if batch_tokens else batch_size
+            bounds.append((lo, min(n, lo + rows), sorted_len[lo]))
+            lo += rows
+    else:
+        bounds = [(lo, min(n, lo + batch_size), None) for lo in range(0, n, batch_size)]
     import contextlib
     # ONE autocast block around all batches: its cache holds the bf16 casts of the weights, so they are made once per call
     # and not once per batch (~75 cast launches and half a gigabyte of traffic a batch for BERT-base)
     ctx = torch.autocast("cuda", dtype=torch.bfloat16) if (autocast and dev.type == "cuda") else contextlib.nullcontext()
     try:
         with ctx:
-            for b, lo in enumerate(range(0, n, batch_size)):
+            for lo, hi, width in bounds:
                 if order is None:
-                    ids = input_ids[lo:lo + batch_size].to(dev)
-                    am = None if attention_mask is None else attention_mask[lo:lo + batch_size].to(dev)
+                    ids = input_ids[lo:hi].to(dev)
+                    am = None if attention_mask is None else attention_mask[lo:hi].to(dev)
                 else:
-                    rows = order[lo:lo + batch_size]
-                    ids = input_ids[rows, :widths[b]].to(dev)
-                    am = None if attention_mask is None else attention_mask[rows, :widths[b]].to(dev)
+                    rows = order[lo:hi]
+                    ids = input_ids[rows, :width].to(dev)
+                    am = None if attention_mask is None else attention_mask[rows, :width].to(dev)
                 e = model(ids, am)
                 if order is None:
-                    out[lo:lo + ids.shape[0]] = e.to(out_dtype)
+                    out[lo:hi] = e.to(out_dtype)
                 else:
                     out[rows.to(dev)] = e.to(out_dtype)
     finally:
