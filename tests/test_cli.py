@@ -196,3 +196,10 @@ def test_two_rank_cli_writes_the_files_one_rank_writes(tmp_path, fake_faiss, bef
     mp.spawn(_cli_rank, args=(2, port, _argv(tmp_path, two, *vec)), nprocs=2, join=True)
     for name in ("train.json", "val.json", "test.json"):
         assert (two / name).read_bytes() == (one / name).read_bytes(), name
+    # --replicas: every rank all train vectors, a half of every query block each (sharded.ReplicatedFlatIndex)
+    three = tmp_path / "three"
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]
+    mp.spawn(_cli_rank, args=(2, port, _argv(tmp_path, three, "--replicas", *vec)), nprocs=2, join=True)
+    for name in ("train.json", "val.json", "test.json"):
+        assert (three / name).read_bytes() == (one / name).read_bytes(), name

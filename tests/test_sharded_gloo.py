@@ -23,7 +23,14 @@ class OracleLocalIndex:
         self.metric, self.y = metric, None
 
     def add(self, x):
-        self.y = x.numpy().astype(np.float32)
+        x = x.numpy().astype(np.float32)
+        self.y = x if self.y is None else np.concatenate([self.y, x])
+
+    ntotal = property(lambda self: 0 if self.y is None else self.y.shape[0])
+
+    def search(self, x, k):
+        D, I, _ = self.search_s64(x, k)
+        return D, I
 
     def search_s64(self, x, k):
         from oracle import flat_knn as oracle
@@ -63,6 +70,19 @@ def _worker(rank, world, port, metric, n, d, nq, k, ret):
     dist.destroy_process_group()
 
 
+def _replica_worker(rank, world, port, metric, n, d, nq, k, ret):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from _data import grid
+    from textreact_amd.sharded import ReplicatedFlatIndex
+    idx = ReplicatedFlatIndex(d, metric, local_index=OracleLocalIndex(metric))
+    idx.add(torch.from_numpy(grid(n, d, 1)))
+    D, I = idx.search(torch.from_numpy(grid(nq, d, 2)), k)
+    ret[rank] = (D.numpy(), I.numpy(), idx.ntotal)
+    dist.destroy_process_group()
+
+
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
@@ -79,6 +99,21 @@ def test_two_rank_sharded_search_equals_unsharded(metric):
         D, I = ret[r]
         assert np.array_equal(I, Ir), "rank %d" % r
         assert np.array_equal(D, Dr)
+
+
+@pytest.mark.parametrize("world,nq", [(2, 37), (3, 2), (3, 100)])
+def test_replicated_search_equals_one_index(world, nq):
+    """FAISS' IndexReplicas form (every rank all rows, a G-th of the queries each, one all-gather of the slices): uneven
+    slices, and fewer queries than ranks (a rank with an empty slice still joins the collective)"""
+    from _data import grid
+    from oracle import flat_knn as oracle
+    n, d, k = 500, 32, 10
+    mgr = mp.Manager(); ret = mgr.dict()
+    mp.spawn(_replica_worker, args=(world, _free_port(), 1, n, d, nq, k, ret), nprocs=world, join=True)
+    Dr, Ir = oracle.knn_canonical(1, grid(nq, d, 2), grid(n, d, 1), k)
+    for r in range(world):
+        D, I, nt = ret[r]
+        assert nt == n and np.array_equal(I, Ir) and np.array_equal(D, Dr), "rank %d" % r
 
 
 def test_shard_bounds_cover_and_balance():

@@ -137,6 +137,9 @@ def get_parser():
     parser.add_argument('--test_vectors', type=str, default=None)
     parser.add_argument('--metric', type=str, default='l2', choices=['l2', 'ip'])
     parser.add_argument('--k', type=int, default=20)
+    parser.add_argument('--replicas', action='store_true',
+                        help='under torch.distributed.run: every GPU holds all train vectors and searches 1/G of the queries '
+                             '(FAISS IndexReplicas; sharded.ReplicatedFlatIndex) instead of a row shard of the train vectors')
     return parser
 
 
@@ -182,6 +185,19 @@ class ShardedSearcher:
         if not D:
             return np.empty((0, k), np.float32), np.empty((0, k), np.int64)
         return np.concatenate(D), np.concatenate(I)
+
+
+class ReplicaSearcher(ShardedSearcher):
+    """the same protocol over sharded.ReplicatedFlatIndex: all rows on every rank, a G-th of each query block per rank (--replicas)"""
+
+    def __init__(self, rows, metric, rank, world):
+        from .sharded import ReplicatedFlatIndex
+        d = rows.shape[1]
+        local = faiss.IndexFlatL2(d) if metric == 'l2' else faiss.IndexFlatIP(d)
+        self.device = getattr(local, "device", None)
+        self.index = ReplicatedFlatIndex(d, 1 if metric == 'l2' else 0, local_index=local)
+        for r0 in range(0, len(rows), self.QUERY_BLOCK):      # (in blocks: the fp32 staging copy of 680 k x 2048 rows is 5.6 GB)
+            self.index.add(self._tensor(rows[r0:r0 + self.QUERY_BLOCK]))
 
 
 def _ids_digest(ids):
@@ -275,7 +291,8 @@ def main(argv=None):
     else:
         from .sharded import shard_bounds
         lo, hi = shard_bounds(len(train_fps), world, rank)
-        index = ShardedSearcher(np.asarray(train_fps[lo:hi]), lo, len(train_fps), args.metric, rank, world)
+        index = (ReplicaSearcher(train_fps, args.metric, rank, world) if args.replicas else
+                 ShardedSearcher(np.asarray(train_fps[lo:hi]), lo, len(train_fps), args.metric, rank, world))
 
     def vectors(df, path):
         if path:

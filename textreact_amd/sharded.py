@@ -103,18 +103,65 @@ class ShardedFlatIndex:
                                group=self.group)
         got = got.to(pack.device).view(G, mine, 2, k)
         Dm, Im = self._merge(self.metric, got[:, :, 0].contiguous().view(torch.float64), got[:, :, 1].contiguous())
-        # replicate: slices are at most one query apart in length; pad to the longest, one all-gather
-        per = max(hi - lo for lo, hi in bounds)
-        buf = torch.zeros((per, 2, k), dtype=torch.int64, device=pack.device)
-        buf[:mine, 0] = Dm.contiguous().view(torch.int32).long()      # the float bits, widened: one tensor, one collective
-        buf[:mine, 1] = Im
-        if gloo:
-            host = buf.cpu()
-            parts = [torch.empty_like(host) for _ in range(G)]
-            dist.all_gather(parts, host, group=self.group)
-            allb = torch.stack(parts).to(pack.device)
-        else:
-            allb = torch.empty((G,) + tuple(buf.shape), dtype=torch.int64, device=pack.device)
-            dist.all_gather_into_tensor(allb, buf, group=self.group)
-        rows = torch.cat([allb[j, :hi - lo] for j, (lo, hi) in enumerate(bounds)])
-        return rows[:, 0].to(torch.int32).view(torch.float32), rows[:, 1].contiguous()
+        return _gather_query_slices(Dm, Im, bounds, mine, k, self.group)
+
+
+def _gather_query_slices(Dm, Im, bounds, mine, k, group):
+    """every rank holds the final (D, I) of ITS slice of the queries (bounds[rank]) -> all of them on every rank: slices are
+    at most one query apart in length; pad to the longest, one all-gather"""
+    import torch
+    import torch.distributed as dist
+    G = len(bounds)
+    gloo = dist.get_backend(group) == "gloo"       # test path: gloo moves host tensors
+    per = max(hi - lo for lo, hi in bounds)
+    buf = torch.zeros((per, 2, k), dtype=torch.int64, device=Dm.device)
+    buf[:mine, 0] = Dm.contiguous().view(torch.int32).long()      # the float bits, widened: one tensor, one collective
+    buf[:mine, 1] = Im
+    if gloo:
+        host = buf.cpu()
+        parts = [torch.empty_like(host) for _ in range(G)]
+        dist.all_gather(parts, host, group=group)
+        allb = torch.stack(parts).to(Dm.device)
+    else:
+        allb = torch.empty((G,) + tuple(buf.shape), dtype=torch.int64, device=Dm.device)
+        dist.all_gather_into_tensor(allb, buf, group=group)
+    rows = torch.cat([allb[j, :hi - lo] for j, (lo, hi) in enumerate(bounds)])
+    return rows[:, 0].to(torch.int32).view(torch.float32), rows[:, 1].contiguous()
+
+
+class ReplicatedFlatIndex:
+    """The other way to use G GPUs, FAISS' own default (`faiss.index_cpu_to_all_gpus` builds an IndexReplicas unless
+    `co.shard` is set): every rank holds ALL rows in its own flat index and searches rank r's 1/G of the queries
+    (`shard_bounds(nq, G, r)`); one all-gather of the (D, I) slices replicates the result.  No exchange of candidates, no
+    merge, and the per-(query tile, corpus split) warm-up of the scan is paid on a G-th of the query tiles: at 8 ranks one
+    rank's share of the headline search is 9.95 ms against 11.3 for the row shard.  For a corpus that
+    fits one GPU; `ShardedFlatIndex` is the form for one that does not, and the one `north_star` names.
+    Same results as one flat index, on every rank: queries are independent."""
+
+    def __init__(self, d: int, metric: int, group=None, local_index=None):
+        import torch.distributed as dist
+        self.d, self.metric, self.group = int(d), int(metric), group
+        self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        if local_index is None:
+            from . import faiss_compat
+            local_index = faiss_compat.IndexFlat(d, metric)
+        self.local = local_index
+
+    @property
+    def ntotal(self):
+        return self.local.ntotal
+
+    def add(self, x):
+        """all rows, on every rank"""
+        self.local.add(x)
+
+    def search(self, x, k: int):
+        """x replicated on every rank (torch tensor on this rank's device) -> (D, I), identical on every rank"""
+        nq = x.shape[0]
+        if self.world_size == 1:
+            return self.local.search(x, k)
+        bounds = [shard_bounds(nq, self.world_size, j) for j in range(self.world_size)]
+        lo, hi = bounds[self.rank]
+        D, I = self.local.search(x[lo:hi].contiguous(), k)
+        return _gather_query_slices(D, I, bounds, hi - lo, k, self.group)
