@@ -213,18 +213,26 @@ class TanimotoIndex:
                 thr = (torch.topk(bmax, kk, dim=1, largest=True, sorted=True).values[:, -1] * (1.0 - 2.0 ** -19)).contiguous()
                 cand, counts = keys_of(None, thr, cap)
                 top = torch.topk(cand, kk, dim=1, largest=True, sorted=True).values
-                over = (counts > cap).nonzero().flatten().to(torch.int32)
-                if over.numel():                            # more rows above the bound than the list holds (heavily tied data)
-                    full, _ = keys_of(over, None, n)
-                    top[over.long()] = torch.topk(full, kk, dim=1, largest=True, sorted=True).values
+                over_any = (counts > cap).any()
             else:
                 full, _ = keys_of(None, None, n)
                 top = torch.topk(full, kk, dim=1, largest=True, sorted=True).values
-            r = top & ((1 << KEY_ID_BITS) - 1)
-            a = both.gather(1, r).to(torch.int64)
-            keys_out[lo:lo + m] = top
-            a_out[lo:lo + m] = a
-            den_out[lo:lo + m] = self.row_sum[:n].to(torch.int64)[r] + q_sum[:m].to(torch.int64)[:, None] - a
+                over_any = None
+
+            def finish(top):
+                r = top & ((1 << KEY_ID_BITS) - 1)
+                a = both.gather(1, r).to(torch.int64)
+                keys_out[lo:lo + m] = top
+                a_out[lo:lo + m] = a
+                den_out[lo:lo + m] = self.row_sum[:n].to(torch.int64)[r] + q_sum[:m].to(torch.int64)[:, None] - a
+            finish(top)
+            # the one host read of a batch comes AFTER its outputs are enqueued (the device never waits for the host to decide):
+            # more rows above the bound than the list holds -- heavily tied data -- and those queries are done again from all keys
+            if over_any is not None and bool(over_any):
+                over = (counts > cap).nonzero().flatten().to(torch.int32)
+                full, _ = keys_of(over, None, n)
+                top[over.long()] = torch.topk(full, kk, dim=1, largest=True, sorted=True).values
+                finish(top)
         return keys_out, a_out, den_out
 
 
