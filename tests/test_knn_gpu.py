@@ -561,6 +561,8 @@ def _rank_worker(rank, world, port, ret):
         idx.add_shard(torch.from_numpy(y[lo:hi]).cuda(), lo, n)
         D, I = idx.search(torch.from_numpy(x).cuda(), 10)
         out[metric] = (D.cpu().numpy(), I.cpu().numpy())
+        D, I = idx.search(torch.from_numpy(x[:64]).cuda(), 100)      # the two-scan path's fp64 scores through the exchange and the merge
+        out[("k100", metric)] = (D.cpu().numpy(), I.cpu().numpy())
         # the other decomposition (FAISS' IndexReplicas): all rows on every rank, a G-th of the queries each
         from textreact_amd.sharded import ReplicatedFlatIndex
         rep = ReplicatedFlatIndex(d, metric)
@@ -589,6 +591,10 @@ def test_multi_rank_sharded_search_on_one_gpu(world):
                 D, I = ret[r][key]
                 assert np.array_equal(I, Ir), (key, r)
                 assert np.array_equal(D.view(np.uint32), Dr.view(np.uint32)), (key, r)
+        Dr, Ir = oracle.knn_canonical(metric, x[:64], y, 100)
+        for r in range(world):
+            D, I = ret[r][("k100", metric)]
+            assert np.array_equal(I, Ir) and np.array_equal(D.view(np.uint32), Dr.view(np.uint32)), ("k100", metric, r)
 
 
 def test_pad_queries_of_the_last_query_tile_cost_nothing():
