@@ -51,7 +51,10 @@ extern "C" {
 typedef struct trx_index trx_index;
 
 enum { TRX_METRIC_IP = 0, TRX_METRIC_L2 = 1 };
-enum { TRX_DTYPE_F32 = 0, TRX_DTYPE_BF16 = 1 };
+enum { TRX_DTYPE_F32 = 0, TRX_DTYPE_BF16 = 1,
+       TRX_DTYPE_I8 = 2 /* HOST entry points only (trx_index_add, trx_index_search): int8 rows -- the Morgan bit vectors of
+                           retrieve_faiss.py:36-44 -- cross PCIe as bytes and are widened on the device; same values, same
+                           results as their float32 conversion */ };
 
 enum {
     TRX_OK = 0,

@@ -401,6 +401,46 @@ def test_merge_kernel_equals_oracle_merge():
         assert np.array_equal(Im, Ir)
 
 
+def test_int8_and_bool_host_arrays_travel_as_bytes_and_give_the_float32_results():
+    """the reference's Morgan fingerprints are int8 arrays (retrieve_faiss.py:36-44); faiss' wrapper would convert them to
+    float32 on the host -- here they reach the library as bytes (TRX_DTYPE_I8) and are widened on the device: the same values,
+    so the oracle's answer on the float32 conversion, bit for bit; negative values and a dimension that is not a multiple of 16"""
+    from oracle import flat_knn as oracle
+    for d, signed in ((1024, False), (100, True)):
+        y = morgan_like(6000, d, 7); x = morgan_like(300, d, 8)
+        if signed:
+            y = reaction_fp_like(6000, d, 9, density=0.2); x = reaction_fp_like(300, d, 10, density=0.2)
+        for metric in (IP, L2):
+            Dr, Ir = oracle.knn_canonical(metric, x, y, 20)
+            for cast in ((np.int8, np.bool_) if not signed else (np.int8,)):
+                idx = _index(metric, d)
+                idx.add(y.astype(cast)[:2500]); idx.add(y.astype(cast)[2500:])
+                D, I = idx.search(x.astype(cast), 20)
+                assert np.array_equal(I, Ir) and np.array_equal(D.view(np.uint32), Dr.view(np.uint32)), (d, metric, cast)
+                assert idx.last_stats()["exact_class"] == 1
+
+
+def test_host_searches_longer_than_one_block_overlap_the_next_copy_and_keep_their_statistics():
+    """trx_index_search takes host queries in blocks of 65,536: block c + 1 crosses PCIe while block c is searched; results in
+    place, the statistics of the call are those of all blocks"""
+    from oracle import flat_knn as oracle
+    y = gaussian(3000, 64, 21); x = gaussian(65536 + 4500, 64, 22)
+    for metric in (IP, L2):
+        idx = _index(metric, 64)
+        idx.add(y)
+        D, I = idx.search(x, 10)
+        st = idx.last_stats()
+        assert st["nq"] == x.shape[0] and st["scan_launches"] >= 2, st
+        sel = np.r_[0:300, 65536 - 150:65536 + 150, x.shape[0] - 300:x.shape[0]]
+        Dr, Ir = oracle.knn_canonical(metric, x[sel], y, 10)
+        assert np.array_equal(I[sel], Ir) and np.array_equal(D[sel].view(np.uint32), Dr.view(np.uint32))
+        x8 = np.clip(np.rint(x * 3), -100, 100).astype(np.int8)           # the same through the int8 transport
+        idx8 = _index(metric, 64); idx8.add(np.clip(np.rint(y * 3), -100, 100).astype(np.int8))
+        D8, I8 = idx8.search(x8, 10)
+        Dr, Ir = oracle.knn_canonical(metric, x8[sel].astype(np.float32), np.clip(np.rint(y * 3), -100, 100).astype(np.float32), 10)
+        assert np.array_equal(I8[sel], Ir) and np.array_equal(D8[sel].view(np.uint32), Dr.view(np.uint32))
+
+
 def test_single_rank_sharded_wrapper():
     import torch
     from textreact_amd.sharded import ShardedFlatIndex

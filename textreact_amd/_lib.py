@@ -9,7 +9,7 @@ _CSRC = os.path.join(_HERE, "csrc")
 _SO = os.path.join(_CSRC, os.environ.get("TRX_LIB", "libtrxknn.so"))  # TRX_LIB: diagnostic builds
 
 METRIC_IP, METRIC_L2 = 0, 1
-DTYPE_F32, DTYPE_BF16 = 0, 1
+DTYPE_F32, DTYPE_BF16, DTYPE_I8 = 0, 1, 2
 MAX_K, FAST_MAX_K = 2048, 24
 
 # every symbol include/trx_knn.h declares (tests/test_abi.py checks the header against this list)

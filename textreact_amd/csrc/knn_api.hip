@@ -19,6 +19,7 @@ hipError_t launch_row_stats(const void*, int, int64_t, int, int64_t, void*, floa
 hipError_t launch_build_operand(const void*, int, int, int64_t, int, int64_t, bf16_t*, int, hipStream_t);
 hipError_t launch_fill_bias(const float*, int64_t, int64_t, float*, hipStream_t);
 hipError_t launch_widen_rows(const bf16_t*, int64_t, int, int64_t, float*, hipStream_t);
+hipError_t launch_widen_i8(const signed char*, int64_t, int, bf16_t*, hipStream_t);
 hipError_t launch_exact_scan(int, int, int, const int*, int, const int*, int64_t, const void*, int64_t, const void*,
                              int64_t, int, int, double*, float*, int64_t*, double*, hipStream_t);
 hipError_t launch_classify(const void*, int, int, float, int, int, int, int*, hipStream_t);
@@ -105,6 +106,7 @@ struct trx_index {
     trx_search_stats stats{};
     bool timing = false;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t copy_stream = nullptr;      // host entry points: the next block's host-to-device copy under this block's search
     // a search that has been enqueued (trx_index_search_device_begin) and not yet finished: what
     // trx_index_search_finish needs to read the certificate counts back and, rarely, complete the fall-back
     struct PendingBatch { int* nflag; int* flagged; int final_slot; const void* q; float* D; int64_t* I; double* S64; };
@@ -219,6 +221,7 @@ void trx_index_destroy(trx_index* idx) {
         }
     }
     for (auto& e : idx->ev) if (e) (void)hipEventDestroy(e);
+    if (idx->copy_stream) (void)hipStreamDestroy(idx->copy_stream);
     delete idx;
 }
 
@@ -304,23 +307,32 @@ int trx_index_add_device(trx_index* idx, const void* x, int64_t n, int dtype, vo
 int trx_index_add(trx_index* idx, const void* x, int64_t n, int dtype) {
     if (!idx) return fail(TRX_EINVAL, "index is null");
     if (n < 0 || (n > 0 && !x)) return fail(TRX_EINVAL, "bad vector block");
-    if (dtype != TRX_DTYPE_F32 && dtype != TRX_DTYPE_BF16) return fail(TRX_EINVAL, "unknown dtype");
+    if (dtype != TRX_DTYPE_F32 && dtype != TRX_DTYPE_BF16 && dtype != TRX_DTYPE_I8) return fail(TRX_EINVAL, "unknown dtype");
     if (n == 0) return TRX_OK;
     int rc = set_device(idx); if (rc) return rc;
-    const size_t esz = dtype == TRX_DTYPE_BF16 ? 2 : 4;
-    // stream the block through a bounded staging buffer (<= 1 GiB at a time)
-    const int64_t rows_per = std::max<int64_t>(1, ((int64_t)1 << 30) / (int64_t)(idx->d * esz));
-    void* dev = nullptr;
-    HIPCHK(hipMalloc(&dev, (size_t)std::min(rows_per, n) * idx->d * esz));
+    const size_t esz = dtype == TRX_DTYPE_F32 ? 4 : dtype == TRX_DTYPE_BF16 ? 2 : 1;
+    // stream the block through a bounded staging buffer (<= 1 GiB at a time); int8 rows cross PCIe as bytes and are widened
+    // to bf16 (every int8 value is one) on the device
+    const int64_t rows_per = std::max<int64_t>(1, ((int64_t)1 << 30) / (int64_t)(idx->d * (dtype == TRX_DTYPE_I8 ? 2 : esz)));
+    const int64_t rows = std::min(rows_per, n);
+    char* dev = nullptr; char* wide = nullptr;
+    HIPCHK(hipMalloc((void**)&dev, (size_t)rows * idx->d * esz));
+    if (dtype == TRX_DTYPE_I8 && hipMalloc((void**)&wide, (size_t)rows * idx->d * 2) != hipSuccess) {
+        (void)hipFree(dev);
+        return fail(TRX_EHIP, "out of device memory for the staging copy");
+    }
+    struct Free { char* a; char* b; ~Free() { if (a) (void)hipFree(a); if (b) (void)hipFree(b); } } guard{dev, wide};
     for (int64_t r0 = 0; r0 < n; r0 += rows_per) {
         const int64_t m = std::min(rows_per, n - r0);
-        hipError_t e = hipMemcpy(dev, (const char*)x + (size_t)r0 * idx->d * esz, (size_t)m * idx->d * esz,
-                                 hipMemcpyHostToDevice);
-        if (e != hipSuccess) { (void)hipFree(dev); return fail(TRX_EHIP, hipGetErrorString(e)); }
-        rc = trx_index_add_device(idx, dev, m, dtype, nullptr);
-        if (rc) { (void)hipFree(dev); return rc; }
+        HIPCHK(hipMemcpy(dev, (const char*)x + (size_t)r0 * idx->d * esz, (size_t)m * idx->d * esz, hipMemcpyHostToDevice));
+        if (dtype == TRX_DTYPE_I8) {
+            HIPCHK(launch_widen_i8((const signed char*)dev, m, idx->d, (bf16_t*)wide, nullptr));
+            rc = trx_index_add_device(idx, wide, m, TRX_DTYPE_BF16, nullptr);
+        } else {
+            rc = trx_index_add_device(idx, dev, m, dtype, nullptr);
+        }
+        if (rc) return rc;
     }
-    (void)hipFree(dev);
     return TRX_OK;
 }
 
@@ -740,20 +752,56 @@ int trx_index_search(trx_index* idx, const void* q, int64_t nq, int dtype, int k
     if (!idx) return fail(TRX_EINVAL, "index is null");
     if (nq < 0 || (nq > 0 && (!q || !D || !I))) return fail(TRX_EINVAL, "null query/result pointer");
     if (k <= 0 || k > TRX_MAX_K) return fail(TRX_EINVAL, "k must be in [1, 2048]");
-    if (dtype != TRX_DTYPE_F32 && dtype != TRX_DTYPE_BF16) return fail(TRX_EINVAL, "unknown dtype");
+    if (dtype != TRX_DTYPE_F32 && dtype != TRX_DTYPE_BF16 && dtype != TRX_DTYPE_I8) return fail(TRX_EINVAL, "unknown dtype");
     if (nq == 0) return TRX_OK;
     int rc = set_device(idx); if (rc) return rc;
-    const size_t esz = dtype == TRX_DTYPE_BF16 ? 2 : 4;
-    const size_t qb = (size_t)nq * idx->d * esz, db = (size_t)nq * k * sizeof(float), ib = (size_t)nq * k * sizeof(int64_t);
-    const size_t qoff = 0, doff = round_up64((int64_t)qb, 256), ioff = doff + round_up64((int64_t)db, 256);
-    if ((rc = idx->w_io.reserve(ioff + ib))) return rc;
+    // Host arrays in, host arrays out (the FAISS protocol as retrieve_faiss.py:71 calls it), in blocks of 65,536 queries: block
+    // c is searched (enqueued, stream-ordered) while block c + 1 crosses PCIe on a stream of its own -- the search of a block
+    // of 1024-d fingerprints takes 16 ms and its 268 MB of float32 longer than that to arrive --, then c's results go back.
+    // int8 queries travel as bytes and are widened to bf16 on the device.
+    constexpr int64_t BLOCK = 65536;
+    const size_t esz = dtype == TRX_DTYPE_F32 ? 4 : dtype == TRX_DTYPE_BF16 ? 2 : 1;
+    const int64_t rows = std::min<int64_t>(BLOCK, nq);
+    const size_t qb = (size_t)round_up64((int64_t)((size_t)rows * idx->d * esz), 256);
+    const size_t wb = dtype == TRX_DTYPE_I8 ? (size_t)round_up64((int64_t)((size_t)rows * idx->d * 2), 256) : 0;
+    const size_t db = (size_t)round_up64((int64_t)((size_t)rows * k * sizeof(float)), 256), ib = (size_t)rows * k * sizeof(int64_t);
+    if ((rc = idx->w_io.reserve(2 * qb + wb + db + ib))) return rc;
     char* base = (char*)idx->w_io.p;
-    HIPCHK(hipMemcpy(base + qoff, q, qb, hipMemcpyHostToDevice));
-    rc = search_device_impl(idx, base + qoff, nq, dtype, k, (float*)(base + doff), (int64_t*)(base + ioff), nullptr, nullptr);
-    if (rc) return rc;
-    rc = trx_index_search_finish(idx); if (rc) return rc;
-    HIPCHK(hipMemcpy(D, base + doff, db, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(I, base + ioff, ib, hipMemcpyDeviceToHost));
+    char* stage[2] = {base, base + qb};
+    char* wide = base + 2 * qb;
+    float* Dd = (float*)(base + 2 * qb + wb);
+    int64_t* Id = (int64_t*)(base + 2 * qb + wb + db);
+    if (!idx->copy_stream) HIPCHK(hipStreamCreateWithFlags(&idx->copy_stream, hipStreamNonBlocking));
+    const char* qh = (const char*)q;
+    trx_search_stats acc{};
+    HIPCHK(hipMemcpy(stage[0], qh, (size_t)rows * idx->d * esz, hipMemcpyHostToDevice));
+    int blk = 0;
+    for (int64_t q0 = 0; q0 < nq; q0 += BLOCK, ++blk) {
+        const int64_t m = std::min<int64_t>(BLOCK, nq - q0);
+        const void* qd = stage[blk & 1];
+        int qdt = dtype;
+        if (dtype == TRX_DTYPE_I8) {
+            HIPCHK(launch_widen_i8((const signed char*)qd, m, idx->d, (bf16_t*)wide, nullptr));
+            qd = wide; qdt = TRX_DTYPE_BF16;
+        }
+        rc = search_device_impl(idx, qd, m, qdt, k, Dd, Id, nullptr, nullptr);
+        if (rc) return rc;
+        if (q0 + BLOCK < nq) {      // the next block's copy, while this one is being searched
+            const int64_t m2 = std::min<int64_t>(BLOCK, nq - q0 - BLOCK);
+            HIPCHK(hipMemcpyAsync(stage[(blk + 1) & 1], qh + (size_t)(q0 + BLOCK) * idx->d * esz, (size_t)m2 * idx->d * esz,
+                                  hipMemcpyHostToDevice, idx->copy_stream));
+            HIPCHK(hipStreamSynchronize(idx->copy_stream));
+        }
+        rc = trx_index_search_finish(idx); if (rc) return rc;
+        HIPCHK(hipMemcpy(D + q0 * k, Dd, (size_t)m * k * sizeof(float), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(I + q0 * k, Id, (size_t)m * k * sizeof(int64_t), hipMemcpyDeviceToHost));
+        const trx_search_stats& s1 = idx->stats;
+        acc.nq += s1.nq; acc.n_uncertified += s1.n_uncertified; acc.n_rescored += s1.n_rescored; acc.n_rescanned += s1.n_rescanned;
+        acc.scan_launches += s1.scan_launches; acc.scan_ms += s1.scan_ms; acc.total_ms += s1.total_ms;
+        acc.late_fallback |= s1.late_fallback;
+        acc.n_splits = s1.n_splits; acc.k_split = s1.k_split; acc.exact_class = s1.exact_class; acc.int8_scan = s1.int8_scan;
+    }
+    idx->stats = acc;
     return TRX_OK;
 }
 

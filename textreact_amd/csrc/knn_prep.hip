@@ -285,4 +285,34 @@ hipError_t launch_widen_rows(const bf16_t* in, int64_t n, int d, int64_t ld_in, 
     return hipGetLastError();
 }
 
+// int8 host data (TRX_DTYPE_I8: Morgan bit vectors, retrieve_faiss.py:36-44) crosses PCIe as bytes and becomes bf16 here --
+// every int8 value is a bf16 number -- so the index and the search see the values a float32 conversion on the host would
+// have given them.  The block is contiguous (ld = d): 16 values per thread, a scalar tail.
+__global__ __launch_bounds__(256) void widen_i8_kernel(const signed char* in, int64_t total, bf16_t* out) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t e0 = t * 16;
+    if (e0 >= total) return;
+    if (e0 + 16 <= total) {
+        const uint4 u = *reinterpret_cast<const uint4*>(in + e0);
+        const u32 w[4] = {u.x, u.y, u.z, u.w};
+        u32 o[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int a = (int)(signed char)((w[i >> 1] >> (16 * (i & 1))) & 0xffu);
+            const int b = (int)(signed char)((w[i >> 1] >> (16 * (i & 1) + 8)) & 0xffu);
+            o[i] = (u32)f32_to_bf16_rn((float)a) | ((u32)f32_to_bf16_rn((float)b) << 16);
+        }
+        *reinterpret_cast<uint4*>(out + e0) = make_uint4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<uint4*>(out + e0 + 8) = make_uint4(o[4], o[5], o[6], o[7]);
+    } else {
+        for (int64_t e = e0; e < total; ++e) out[e] = f32_to_bf16_rn((float)in[e]);
+    }
+}
+hipError_t launch_widen_i8(const signed char* in, int64_t n, int d, bf16_t* out, hipStream_t st) {
+    const int64_t total = n * d;
+    if (total <= 0) return hipSuccess;
+    hipLaunchKernelGGL(widen_i8_kernel, dim3((unsigned)((total + 4095) / 4096)), dim3(256), 0, st, in, total, out);
+    return hipGetLastError();
+}
+
 }  // namespace trx

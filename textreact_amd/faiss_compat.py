@@ -54,19 +54,19 @@ class IndexFlat:
     def add(self, x):
         if _is_torch(x):
             return self._add_torch(x)
-        x = self._as_f32(x)
-        _lib.check(_lib.lib().trx_index_add(self._h, x.ctypes.data_as(ctypes.c_void_p), x.shape[0], _lib.DTYPE_F32))
+        x, dt = self._host_arg(x)
+        _lib.check(_lib.lib().trx_index_add(self._h, x.ctypes.data_as(ctypes.c_void_p), x.shape[0], dt))
 
     def search(self, x, k):
         k = int(k)
         assert k > 0, "k must be positive"
         if _is_torch(x):
             return self._search_torch(x, k)
-        x = self._as_f32(x)
+        x, dt = self._host_arg(x)
         nq = x.shape[0]
         D = np.empty((nq, k), dtype=np.float32)
         I = np.empty((nq, k), dtype=np.int64)
-        _lib.check(_lib.lib().trx_index_search(self._h, x.ctypes.data_as(ctypes.c_void_p), nq, _lib.DTYPE_F32, k,
+        _lib.check(_lib.lib().trx_index_search(self._h, x.ctypes.data_as(ctypes.c_void_p), nq, dt, k,
                                                D.ctypes.data_as(ctypes.c_void_p), I.ctypes.data_as(ctypes.c_void_p)))
         return D, I
 
@@ -111,11 +111,18 @@ class IndexFlat:
         return bool(self.last_stats()["late_fallback"])
 
     # -- internals ----------------------------------------------------------------------------
-    def _as_f32(self, x):
+    def _host_arg(self, x):
+        """-> (C-contiguous array, dtype code).  float32 as faiss' wrapper converts everything -- except int8 and bool arrays
+        (the reference's Morgan bit vectors, retrieve_faiss.py:36-44, are int8): those go to the library as they are, a
+        quarter of the bytes over PCIe and no conversion pass on the host; the values, and so the results, are the same"""
         x = np.asarray(x)
         assert x.ndim == 2, "expected a 2-D array"
         assert x.shape[1] == self.d, "dimension mismatch: got %d, index has d=%d" % (x.shape[1], self.d)
-        return np.ascontiguousarray(x, dtype=np.float32)
+        if x.dtype == np.bool_:
+            x = x.view(np.int8)
+        if x.dtype == np.int8:
+            return np.ascontiguousarray(x), _lib.DTYPE_I8
+        return np.ascontiguousarray(x, dtype=np.float32), _lib.DTYPE_F32
 
     def _torch_arg(self, x):
         import torch
