@@ -434,6 +434,12 @@ def test_host_searches_longer_than_one_block_overlap_the_next_copy_and_keep_thei
         sel = np.r_[0:300, 65536 - 150:65536 + 150, x.shape[0] - 300:x.shape[0]]
         Dr, Ir = oracle.knn_canonical(metric, x[sel], y, 10)
         assert np.array_equal(I[sel], Ir) and np.array_equal(D[sel].view(np.uint32), Dr.view(np.uint32))
+        x64 = np.rint(x * 3).astype(np.int64); y64 = np.rint(y * 3).astype(np.int64)      # int64 (the difference fingerprints): the
+        idx64 = _index(metric, 64); idx64.add(y64)                           # float32 conversion of block c + 1 runs beside block c
+        D64, I64 = idx64.search(x64, 10)
+        assert idx64.last_stats()["nq"] == x.shape[0]
+        Dr, Ir = oracle.knn_canonical(metric, x64[sel].astype(np.float32), y64.astype(np.float32), 10)
+        assert np.array_equal(I64[sel], Ir) and np.array_equal(D64[sel].view(np.uint32), Dr.view(np.uint32))
         x8 = np.clip(np.rint(x * 3), -100, 100).astype(np.int8)           # the same through the int8 transport
         idx8 = _index(metric, 64); idx8.add(np.clip(np.rint(y * 3), -100, 100).astype(np.int8))
         D8, I8 = idx8.search(x8, 10)

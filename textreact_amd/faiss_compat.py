@@ -54,20 +54,33 @@ class IndexFlat:
     def add(self, x):
         if _is_torch(x):
             return self._add_torch(x)
-        x, dt = self._host_arg(x)
-        _lib.check(_lib.lib().trx_index_add(self._h, x.ctypes.data_as(ctypes.c_void_p), x.shape[0], dt))
+        for blk, dt in self._host_blocks(x):
+            _lib.check(_lib.lib().trx_index_add(self._h, blk.ctypes.data_as(ctypes.c_void_p), blk.shape[0], dt))
 
     def search(self, x, k):
         k = int(k)
         assert k > 0, "k must be positive"
         if _is_torch(x):
             return self._search_torch(x, k)
-        x, dt = self._host_arg(x)
-        nq = x.shape[0]
+        self._stats_override = None
+        nq = np.shape(x)[0]
         D = np.empty((nq, k), dtype=np.float32)
         I = np.empty((nq, k), dtype=np.int64)
-        _lib.check(_lib.lib().trx_index_search(self._h, x.ctypes.data_as(ctypes.c_void_p), nq, dt, k,
-                                               D.ctypes.data_as(ctypes.c_void_p), I.ctypes.data_as(ctypes.c_void_p)))
+        q0, st = 0, None
+        for blk, dt in self._host_blocks(x):
+            m = blk.shape[0]
+            _lib.check(_lib.lib().trx_index_search(self._h, blk.ctypes.data_as(ctypes.c_void_p), m, dt, k,
+                                                   D[q0:q0 + m].ctypes.data_as(ctypes.c_void_p), I[q0:q0 + m].ctypes.data_as(ctypes.c_void_p)))
+            if m != nq:      # several blocks: the statistics of the call are those of all of them
+                s1 = self.last_stats()
+                if st is None:
+                    st = s1
+                else:
+                    for key in ("nq", "n_uncertified", "n_rescored", "n_rescanned", "scan_launches", "scan_ms", "total_ms"):
+                        st[key] += s1[key]
+                    st["late_fallback"] |= s1["late_fallback"]
+            q0 += m
+        self._stats_override = st
         return D, I
 
     def reset(self):
@@ -78,6 +91,8 @@ class IndexFlat:
         _lib.check(_lib.lib().trx_index_set_timing(self._h, 1 if enabled else 0))
 
     def last_stats(self):
+        if getattr(self, "_stats_override", None) is not None:      # a host search that went to the library in several blocks
+            return dict(self._stats_override)
         st = _lib.SearchStats()
         _lib.check(_lib.lib().trx_index_last_stats(self._h, ctypes.byref(st)))
         return {f: getattr(st, f) for f, _ in st._fields_}
@@ -91,6 +106,7 @@ class IndexFlat:
         final after `search_finish()` (include/trx_knn.h, Threading).  Work enqueued on the same stream in between -- the
         all-gather and merge of the row-sharded search -- needs no host round trip."""
         import torch
+        self._stats_override = None
         x, dt = self._torch_arg(x)
         nq, k = x.shape[0], int(k)
         dev = torch.device("cuda", self.device)
@@ -111,6 +127,26 @@ class IndexFlat:
         return bool(self.last_stats()["late_fallback"])
 
     # -- internals ----------------------------------------------------------------------------
+    HOST_BLOCK = 65536
+
+    def _host_blocks(self, x):
+        """(C-contiguous block, dtype code) pairs covering the rows of a host array.  float32, int8 and bool arrays go to the
+        library whole (it blocks and overlaps the copies itself); any other dtype -- the int64 difference fingerprints of
+        retrieve_faiss.py:24-33 -- needs faiss' float32 conversion first, 3 GB a block read at memory speed: block c + 1 is
+        converted by a helper thread (numpy releases the GIL, and so does the ctypes call) while block c is in the library"""
+        x = np.asarray(x)
+        if x.dtype in (np.float32, np.int8, np.bool_) or x.shape[0] <= self.HOST_BLOCK:
+            yield self._host_arg(x)
+            return
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(1) as pool:
+            nxt = pool.submit(self._host_arg, x[:self.HOST_BLOCK])
+            for r0 in range(0, x.shape[0], self.HOST_BLOCK):
+                cur = nxt.result()
+                if r0 + self.HOST_BLOCK < x.shape[0]:
+                    nxt = pool.submit(self._host_arg, x[r0 + self.HOST_BLOCK:r0 + 2 * self.HOST_BLOCK])
+                yield cur
+
     def _host_arg(self, x):
         """-> (C-contiguous array, dtype code).  float32 as faiss' wrapper converts everything -- except int8 and bool arrays
         (the reference's Morgan bit vectors, retrieve_faiss.py:36-44, are int8): those go to the library as they are, a
@@ -145,6 +181,7 @@ class IndexFlat:
 
     def _search_torch(self, x, k, want_s64=False):
         import torch
+        self._stats_override = None
         x, dt = self._torch_arg(x)
         nq = x.shape[0]
         dev = torch.device("cuda", self.device)
