@@ -792,11 +792,14 @@ def test_sharded_cli_writes_the_files_one_gpu_writes(tmp_path):
     pd.DataFrame({"id": np.arange(50) + 6000, "canonical_rxn": ["C>>C"] * 50}).to_csv(tmp_path / "test.csv", index=False)
     for name, sl in (("train", slice(0, 1001)), ("val", slice(1001, 1051)), ("test", slice(1051, 1101))):
         np.save(tmp_path / (name + ".npy"), fps[sl].astype(np.int64))
-    for extra in ([], ["--before", "2013"]):
+    for case, extra in enumerate(([], ["--before", "2013"], ["--replicas"])):
+        if case == 2:      # int8 arrays (what morgan_fingerprint returns): bytes over PCIe, widened on the device; and the replicated form
+            for name, sl in (("train", slice(0, 1001)), ("val", slice(1001, 1051)), ("test", slice(1051, 1101))):
+                np.save(tmp_path / (name + ".npy"), fps[sl].astype(np.int8))
         argv = ["--data_path", str(tmp_path), "--train_file", "train.csv", "--valid_file", "val.csv", "--test_file", "test.csv",
                 "--train_vectors", str(tmp_path / "train.npy"), "--valid_vectors", str(tmp_path / "val.npy"),
                 "--test_vectors", str(tmp_path / "test.npy")] + extra
-        one, two = tmp_path / ("one%d" % len(extra)), tmp_path / ("two%d" % len(extra))
+        one, two = tmp_path / ("one%d" % case), tmp_path / ("two%d" % case)
         assert rf.main(argv + ["--output_path", str(one)]) == 0
         env = dict(os.environ, TRX_DIST_BACKEND="gloo", TRX_DEVICE="0")
         r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",

@@ -174,6 +174,9 @@ class ShardedSearcher:
 
     def _tensor(self, x):
         import torch
+        x = np.asarray(x)
+        if self.device is not None and x.dtype in (np.int8, np.bool_):      # Morgan bit vectors: bytes over PCIe, bf16 (exact) on the GPU
+            return torch.from_numpy(np.ascontiguousarray(x).view(np.int8)).cuda(self.device).to(torch.bfloat16)
         t = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
         return t.cuda(self.device) if self.device is not None else t
 
