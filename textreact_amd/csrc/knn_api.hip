@@ -344,7 +344,7 @@ int trx_index_add(trx_index* idx, const void* x, int64_t n, int dtype) {
 constexpr int INLINE_FALLBACK = 4;
 // per batch: four counters -- [0] flagged by the select kernel, [1] still uncertified after the wide re-score, [2] after the
 // re-scan (-> exact scan), [3] how many the re-scan took -- three lists of query numbers and two of thresholds (floats)
-constexpr size_t FLAG_WORDS = 4 + 5 * 65536;
+constexpr size_t FLAG_WORDS = 8 + 5 * 65536;      // (8 header words: the four counters, [4] the re-scan tier's form)
 constexpr int RESCAN_MAX = 16384;                 // queries per batch the re-scan is sized for (64 query tiles); more take the exact scan
 
 static int search_batch(trx_index* idx, const void* q, const float* qnorm2, int64_t nq, int is_bf, int q_split, int batch_no,
@@ -392,12 +392,12 @@ static int search_batch(trx_index* idx, const void* q, const float* qnorm2, int6
     // earlier batches of the same call still point into it)
     // [0] queries the select kernel could not certify, [1] those the wide re-score could not either (-> exact scan)
     int* nflag = (int*)idx->w_flag.p + (size_t)batch_no * FLAG_WORDS;
-    int* flagged = nflag + 4;
+    int* flagged = nflag + 8;
     int* flagged2 = flagged + 65536;
     int* flagged3 = flagged2 + 65536;
     float* seed1 = (float*)(flagged3 + 65536);
     float* seed2 = seed1 + 65536;
-    HIPCHK(hipMemsetAsync(nflag, 0, 4 * sizeof(int), st));
+    HIPCHK(hipMemsetAsync(nflag, 0, 8 * sizeof(int), st));
 
     ScanParams sp{};
     sp.corpus = idx->Cg; sp.queries = direct ? (const bf16_t*)q : (const bf16_t*)pl.qg.p; sp.cbias = idx->cbias;
@@ -507,6 +507,44 @@ static int search_batch(trx_index* idx, const void* q, const float* qnorm2, int6
         se.D = (float*)pl.d1.p; se.I = (int64_t*)pl.i1.p; se.S64 = nullptr;
     }
     HIPCHK(launch_select(se, st));
+    // The re-scan tier (third tier of a k <= 24 search, third scan of the two-scan path): the still-unproven queries of `list`,
+    // packed, scanned again with every threshold FIXED at the query's seed, then the wide re-score over those lists; what it
+    // cannot prove goes to out_list, and so does what exceeds its capacity cap_q.  Usually a handful of queries -- one query
+    // tile -- and with the search's own corpus splits that is 4 workgroups streaming the whole corpus: 14.8 ms at 1,000,000
+    // rows, as long as a scan of 16,384 queries.  So the tier is enqueued in TWO forms and a device-side flag (written by the
+    // gather kernel from the count) runs one of them: up to an eighth of the query tiles with eight times the splits (same
+    // list storage: an eighth of the queries x eight times the lists), or all of cap_q with the search's splits.
+    auto rescan_tier = [&](const int* list, const int* list_cnt, const float* seeds, int cap_q, SelectParams we, int* out_list, int* out_cnt) -> int {
+        int rc2;
+        if ((rc2 = pl.qg2.reserve((size_t)cap_q * Kp * sizeof(bf16_t)))) return rc2;
+        if ((rc2 = pl.gthr2.reserve((size_t)cap_q * 4 * sizeof(u32)))) return rc2;
+        const int tiles = cap_q / TILE_N, small_tiles = std::max(1, tiles / 8), factor = tiles / small_tiles;
+        int ns_small = std::min(std::min(nsplits * factor, ntiles), 256);
+        const int tps_small = (ntiles + ns_small - 1) / ns_small;
+        ns_small = (ntiles + tps_small - 1) / tps_small;
+        const bool two = factor > 1 && ns_small > nsplits && !getenv("TRX_RESCAN_ONE_FORM");
+        int* gate = nflag + 4;
+        HIPCHK(launch_gather_rescan(list, list_cnt, seeds, cap_q, sp.queries, Kp, (bf16_t*)pl.qg2.p, (u32*)pl.gthr2.p, nflag + 3,
+                                    small_tiles * TILE_N, two ? gate : nullptr, st));
+        ScanParams rp = sp;
+        rp.queries = (const bf16_t*)pl.qg2.p; rp.nqtiles = cap_q / TILE_N; rp.nq_valid = cap_q; rp.nq_valid_dev = nflag + 3;
+        rp.g_thr = (u32*)pl.gthr2.p; rp.fixed_thr = 1; rp.bootstrap = 0; rp.boot_tiles = 0; rp.slack = nullptr;      // (the seeds are lowered already)
+        rp.kprime = we.k <= 12 ? 16 : 32;
+        we.compact = 1; we.extrap = 0;
+        if (two) {
+            ScanParams rs = rp;
+            rs.nqtiles = small_tiles; rs.nq_valid = small_tiles * TILE_N; rs.nsplits = ns_small; rs.tiles_per_split = tps_small;
+            rs.gate = gate; rs.gate_want = 1;
+            HIPCHK(launch_scan(rs, idx->metric, st));
+            SelectParams ws = we; ws.nlists = ns_small * LISTS_PER_SPLIT; ws.gate = gate; ws.gate_want = 1;
+            HIPCHK(launch_wide_rescore(ws, list, nflag + 3, nullptr, out_list, out_cnt, nullptr, st));
+            rp.gate = gate; rp.gate_want = 0; we.gate = gate; we.gate_want = 0;
+        }
+        HIPCHK(launch_scan(rp, idx->metric, st));
+        HIPCHK(launch_wide_rescore(we, list, nflag + 3, nullptr, out_list, out_cnt, nullptr, st));
+        HIPCHK(launch_append_tail(list, list_cnt, cap_q, out_list, out_cnt, st));
+        return TRX_OK;
+    };
     int* final_list; int* final_cnt;
     if (bigk) {
         // Second scan, for EVERY query: thresholds fixed at a guess of the k-th best key (bigk_seed_kernel), every row above it
@@ -522,20 +560,14 @@ static int search_batch(trx_index* idx, const void* q, const float* qnorm2, int6
         const int rq2 = (int)q_pad;
         if ((rc = pl.qg2.reserve((size_t)rq2 * Kp * sizeof(bf16_t)))) return rc;
         if ((rc = pl.gthr2.reserve((size_t)rq2 * 4 * sizeof(u32)))) return rc;
-        HIPCHK(launch_gather_rescan(flagged2, nflag + 1, seed2, rq2, sp.queries, Kp, (bf16_t*)pl.qg2.p, (u32*)pl.gthr2.p, nflag + 1, st));
+        HIPCHK(launch_gather_rescan(flagged2, nflag + 1, seed2, rq2, sp.queries, Kp, (bf16_t*)pl.qg2.p, (u32*)pl.gthr2.p, nflag + 1, 0, nullptr, st));
         ScanParams rp = sp;
         rp.queries = (const bf16_t*)pl.qg2.p; rp.nqtiles = rq2 / TILE_N; rp.nq_valid = rq2; rp.nq_valid_dev = nflag + 1;
         rp.g_thr = (u32*)pl.gthr2.p; rp.fixed_thr = 1; rp.bootstrap = 0; rp.boot_tiles = 0; rp.slack = nullptr; rp.kprime = 32;
         HIPCHK(launch_scan(rp, idx->metric, st));
         SelectParams we = se; we.compact = 1; we.k = k; we.D = D; we.I = I; we.S64 = S64; we.extrap = 1;
         HIPCHK(launch_wide_rescore(we, flagged2, nflag + 1, seed2, flagged, nflag, seed1, st));
-        const int rq3 = (int)std::min<int64_t>(RESCAN_MAX, q_pad);
-        HIPCHK(launch_gather_rescan(flagged, nflag, seed1, rq3, sp.queries, Kp, (bf16_t*)pl.qg2.p, (u32*)pl.gthr2.p, nflag + 3, st));
-        rp.nqtiles = rq3 / TILE_N; rp.nq_valid = rq3; rp.nq_valid_dev = nflag + 3;
-        HIPCHK(launch_scan(rp, idx->metric, st));
-        we.extrap = 0;
-        HIPCHK(launch_wide_rescore(we, flagged, nflag + 3, nullptr, flagged3, nflag + 2, nullptr, st));
-        HIPCHK(launch_append_tail(flagged, nflag, rq3, flagged3, nflag + 2, st));
+        if ((rc = rescan_tier(flagged, nflag, seed1, (int)std::min<int64_t>(RESCAN_MAX, q_pad), we, flagged3, nflag + 2))) return rc;
         final_list = flagged3; final_cnt = nflag + 2;
     } else {
     // second tier: flagged queries are re-scored over ALL their listed rows (the lists are still in the shared workspace
@@ -548,17 +580,7 @@ static int search_batch(trx_index* idx, const void* q, const float* qnorm2, int6
     // than ~4,000 rows above the seed) or the re-scan's capacity goes on to the exact scan.
     final_list = flagged2; final_cnt = nflag + 1;
     if (sp.debug == 0 && !getenv("TRX_NO_RESCAN")) {
-        const int rq = (int)std::min<int64_t>(RESCAN_MAX, q_pad);
-        if ((rc = pl.qg2.reserve((size_t)rq * Kp * sizeof(bf16_t)))) return rc;
-        if ((rc = pl.gthr2.reserve((size_t)rq * 4 * sizeof(u32)))) return rc;
-        HIPCHK(launch_gather_rescan(flagged2, nflag + 1, seed2, rq, sp.queries, Kp, (bf16_t*)pl.qg2.p, (u32*)pl.gthr2.p, nflag + 3, st));
-        ScanParams rp = sp;
-        rp.queries = (const bf16_t*)pl.qg2.p; rp.nqtiles = rq / TILE_N; rp.nq_valid = rq; rp.nq_valid_dev = nflag + 3;
-        rp.g_thr = (u32*)pl.gthr2.p; rp.fixed_thr = 1; rp.bootstrap = 0; rp.boot_tiles = 0; rp.slack = nullptr;      // (its seeds are lowered already)
-        HIPCHK(launch_scan(rp, idx->metric, st));
-        SelectParams we = se; we.compact = 1;
-        HIPCHK(launch_wide_rescore(we, flagged2, nflag + 3, nullptr, flagged3, nflag + 2, nullptr, st));
-        HIPCHK(launch_append_tail(flagged2, nflag + 1, rq, flagged3, nflag + 2, st));
+        if ((rc = rescan_tier(flagged2, nflag + 1, seed2, (int)std::min<int64_t>(RESCAN_MAX, q_pad), se, flagged3, nflag + 2))) return rc;
         final_list = flagged3; final_cnt = nflag + 2;
     }
     }

@@ -167,6 +167,8 @@ struct SelectParams {
     int* nflagged;
     float* flag_seed;         // [nq] per query: a key every row that can still reach the query's top k exceeds (see knn_api.hip, tier 3)
     int compact;              // 1: the lists are indexed by the position in the flagged list (re-scan), not by the query number
+    const int* gate;          // optional DEVICE int: the wide re-score runs only when *gate == gate_want (the two list layouts of the
+    int gate_want;            // re-scan tier: few queries x many corpus splits, or many queries x the search's own splits)
     int extrap;               // wide re-score of the two-scan path (k > TRX_FAST_MAX_K): a query with fewer than k rows above its guessed
                               // threshold gets a lower one, extrapolated from the rows it did find (seed_out), for one more scan
 };
@@ -178,6 +180,6 @@ hipError_t launch_wide_rescore(const SelectParams& p, const int* flagged, const 
                                float* seed_out, hipStream_t st);
 hipError_t launch_append_tail(const int* flagged, const int* nflagged, int from, int* out, int* nout, hipStream_t st);
 hipError_t launch_gather_rescan(const int* flagged, const int* nflagged, const float* seed, int max_q, const bf16_t* queries, int Kp,
-                                bf16_t* qg2, u32* gthr2, int* count_out, hipStream_t st);
+                                bf16_t* qg2, u32* gthr2, int* count_out, int small_q, int* gate_out, hipStream_t st);
 
 }  // namespace trx

@@ -422,6 +422,7 @@ __global__ __launch_bounds__(256) void wide_rescore_kernel(SelectParams p, const
     __shared__ double pick_s[WIDE_K_MAX];
     __shared__ u32 pick_i[WIDE_K_MAX];
     const int tid = threadIdx.x;
+    if (p.gate && *p.gate != p.gate_want) return;
     const int nf = *nflagged;
     const int exact_class = *p.exact_class;
     constexpr int QE = QBF ? 2 : 4, CE = CBF ? 2 : 4;
@@ -686,9 +687,13 @@ hipError_t launch_bigk_seeds(int metric, const float* D1, const int64_t* I1, int
 // beyond max_q (more than the re-scan is sized for) stay out: count_out = min(count, max_q), the others keep their place in the
 // flagged list and take the exact scan.  One workgroup per query row (Kp / 8 16-byte chunks).
 __global__ __launch_bounds__(128) void gather_rescan_kernel(const int* flagged, const int* nflagged, const float* seed, int max_q,
-                                                            const bf16_t* queries, int Kp, bf16_t* qg2, u32* gthr2, int* count_out) {
+                                                            const bf16_t* queries, int Kp, bf16_t* qg2, u32* gthr2, int* count_out,
+                                                            int small_q, int* gate_out) {
     const int n = min(*nflagged, max_q);
-    if (blockIdx.x == 0 && threadIdx.x == 0) *count_out = n;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *count_out = n;
+        if (gate_out) *gate_out = n <= small_q ? 1 : 0;      // few enough for the many-splits form of the re-scan (knn_api.hip)
+    }
     for (int f = blockIdx.x; f < n; f += gridDim.x) {
         const int q = flagged[f];
         const uint4* src = reinterpret_cast<const uint4*>(queries + (int64_t)q * Kp);
@@ -707,8 +712,9 @@ hipError_t launch_append_tail(const int* flagged, const int* nflagged, int from,
     return hipGetLastError();
 }
 hipError_t launch_gather_rescan(const int* flagged, const int* nflagged, const float* seed, int max_q, const bf16_t* queries, int Kp,
-                                bf16_t* qg2, u32* gthr2, int* count_out, hipStream_t st) {
-    hipLaunchKernelGGL(gather_rescan_kernel, dim3(1024), dim3(128), 0, st, flagged, nflagged, seed, max_q, queries, Kp, qg2, gthr2, count_out);
+                                bf16_t* qg2, u32* gthr2, int* count_out, int small_q, int* gate_out, hipStream_t st) {
+    hipLaunchKernelGGL(gather_rescan_kernel, dim3(1024), dim3(128), 0, st, flagged, nflagged, seed, max_q, queries, Kp, qg2, gthr2, count_out,
+                       small_q, gate_out);
     return hipGetLastError();
 }
 
