@@ -186,53 +186,53 @@ class TanimotoIndex:
         den_out = torch.zeros((nq, kk), dtype=torch.int64, device=self.dev)
         if nq == 0 or kk == 0:
             return keys_out, a_out, den_out
-        for lo in range(0, nq, batch):
+        def run_batch(lo, all_keys):
+            """one batch of queries -> its rows of the outputs; returns a device flag "some query had more rows above its
+            bound than the candidate list holds" (None when every key was formed anyway).  all_keys: form every key of every
+            row (the answer to that flag)"""
             qb = q[lo:lo + batch]
             m = qb.shape[0]
             q_t, q_sum = self._pack_queries(qb)
             both = torch.empty((m, n), dtype=torch.int16, device=self.dev)       # sums of minima (< 32768)
             nblocks = (n + 63) // 64
             cap = max(4 * kk, 1024)
-            shortlist = nblocks >= kk and n > 4 * cap       # otherwise every key of a row is formed and selected from directly
+            shortlist = nblocks >= kk and n > 4 * cap and not all_keys      # otherwise every key of a row is formed and selected from directly
             bmax = torch.empty((m, nblocks), dtype=torch.float32, device=self.dev) if shortlist else None
             st = _stream(self.dev)
             _check(lib().trx_tanimoto_scores(self.packed.data_ptr(), self.row_sum.data_ptr(), n, self.d, q_t.data_ptr(), q_sum.data_ptr(),
                                              m, both.data_ptr(), n, bmax.data_ptr() if shortlist else None, st))
 
-            def keys_of(q_ids, thr, width):
-                nsel = m if q_ids is None else q_ids.numel()
-                cand = torch.full((nsel, width), -1, dtype=torch.int64, device=self.dev)
-                counts = torch.zeros(nsel, dtype=torch.int32, device=self.dev)
-                _check(lib().trx_tanimoto_filter(both.data_ptr(), n, self.row_sum.data_ptr(), q_sum.data_ptr(),
-                                                 None if q_ids is None else q_ids.data_ptr(), nsel, n,
+            def keys_of(thr, width):
+                cand = torch.full((m, width), -1, dtype=torch.int64, device=self.dev)
+                counts = torch.zeros(m, dtype=torch.int32, device=self.dev)
+                _check(lib().trx_tanimoto_filter(both.data_ptr(), n, self.row_sum.data_ptr(), q_sum.data_ptr(), None, m, n,
                                                  None if thr is None else thr.data_ptr(), width, cand.data_ptr(), counts.data_ptr(), st))
                 return cand, counts
             if shortlist:
                 # the k-th best block maximum bounds the k-th best similarity from below (header): only rows whose approximate
                 # similarity reaches it (less the rounding margin) can be among the k best; exact keys are formed for those only
                 thr = (torch.topk(bmax, kk, dim=1, largest=True, sorted=True).values[:, -1] * (1.0 - 2.0 ** -19)).contiguous()
-                cand, counts = keys_of(None, thr, cap)
-                top = torch.topk(cand, kk, dim=1, largest=True, sorted=True).values
+                cand, counts = keys_of(thr, cap)
                 over_any = (counts > cap).any()
             else:
-                full, _ = keys_of(None, None, n)
-                top = torch.topk(full, kk, dim=1, largest=True, sorted=True).values
-                over_any = None
+                cand, over_any = keys_of(None, n)[0], None
+            top = torch.topk(cand, kk, dim=1, largest=True, sorted=True).values
+            r = top & ((1 << KEY_ID_BITS) - 1)
+            a = both.gather(1, r).to(torch.int64)
+            keys_out[lo:lo + m] = top
+            a_out[lo:lo + m] = a
+            den_out[lo:lo + m] = self.row_sum[:n].to(torch.int64)[r] + q_sum[:m].to(torch.int64)[:, None] - a
+            return over_any
 
-            def finish(top):
-                r = top & ((1 << KEY_ID_BITS) - 1)
-                a = both.gather(1, r).to(torch.int64)
-                keys_out[lo:lo + m] = top
-                a_out[lo:lo + m] = a
-                den_out[lo:lo + m] = self.row_sum[:n].to(torch.int64)[r] + q_sum[:m].to(torch.int64)[:, None] - a
-            finish(top)
-            # the one host read of a batch comes AFTER its outputs are enqueued (the device never waits for the host to decide):
-            # more rows above the bound than the list holds -- heavily tied data -- and those queries are done again from all keys
-            if over_any is not None and bool(over_any):
-                over = (counts > cap).nonzero().flatten().to(torch.int32)
-                full, _ = keys_of(over, None, n)
-                top[over.long()] = torch.topk(full, kk, dim=1, largest=True, sorted=True).values
-                finish(top)
+        # ONE host read per call, after every batch's outputs are enqueued (the device never waits for the host to decide): a
+        # batch in which some query had more rows above its bound than the list holds -- heavily tied data -- is done again
+        # from all keys
+        flags = [(lo, run_batch(lo, False)) for lo in range(0, nq, batch)]
+        flags = [(lo, f) for lo, f in flags if f is not None]
+        if flags:
+            for (lo, _), again in zip(flags, torch.stack([f for _, f in flags]).tolist()):
+                if again:
+                    run_batch(lo, True)
         return keys_out, a_out, den_out
 
 
