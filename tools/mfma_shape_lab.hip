@@ -3,7 +3,9 @@
 // v_mfma_f32_32x32x16_bf16 (32 per K-step): same MACs, same operand registers.
 //   mfma_shape_lab <0|1|2|3> [iters]      2: v_mfma_i32_16x16x64_i8 on the same 16-byte fragments (twice the MACs per
 //   instruction), operands = small counts like the reference's Morgan fingerprints (mostly 0, a few 1 .. 3); 3: the same
-//   operands as bf16 through v_mfma_f32_16x16x32_bf16 -- what an int8 path for the integer class could buy
+//   operands as bf16 through v_mfma_f32_16x16x32_bf16 -- what an int8 path for the integer class could buy; 4: bit vectors
+//   (Morgan fingerprints: 95 % zeros, else 1) as fp4 (E2M1 holds 0 and 1 exactly; fp32 accumulation of 0 / 1 products is exact)
+//   through v_mfma_scale_f32_16x16x128_f8f6f4 with unit scales: 128 components per instruction on the same 16-byte fragments
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -108,6 +110,40 @@ __global__ __launch_bounds__(512, 2) void mfma_only_i8(const uint4* src, int* ou
     out[blockIdx.x * 512 + tid] = mx;
 }
 
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+__global__ __launch_bounds__(512, 2) void mfma_only_fp4(const uint4* src, float* out, int iters) {
+    const int tid = threadIdx.x;
+    i32x8 fa[2][8], fb[2][4];      // 32 fp4 per fragment in the low four registers (the instruction reads only those for fp4)
+    const uint4* s = src + (size_t)(blockIdx.x * 512 + tid) * 24;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { uint4 u = s[i]; fa[i >> 3][i & 7] = (i32x8){(int)u.x, (int)u.y, (int)u.z, (int)u.w, 0, 0, 0, 0}; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { uint4 u = s[16 + i]; fb[i >> 2][i & 3] = (i32x8){(int)u.x, (int)u.y, (int)u.z, (int)u.w, 0, 0, 0, 0}; }
+    float mx = -3e38f;
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 64; ++i) {
+            const int kk = i >> 5, a = (i >> 2) & 7, b = i & 3;
+            acc[a][b] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fa[kk][a], fb[kk][b], acc[a][b], 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        }
+        if ((it % 12) == 11) {
+#pragma unroll
+            for (int a = 0; a < 8; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { mx = fmaxf(mx, acc[a][b][e]); acc[a][b][e] = 0.f; }
+                }
+        }
+    }
+    out[blockIdx.x * 512 + tid] = mx;
+}
+
 int main(int argc, char** argv) {
     const int m32 = argc > 1 ? atoi(argv[1]) : 0;
     const int iters = argc > 2 ? atoi(argv[2]) : 977 * 12 * 2;     // two rounds of workgroups' worth in one
@@ -117,11 +153,15 @@ int main(int argc, char** argv) {
     for (auto& x : h) { s = s * 1664525u + 1013904223u; float f = ((s >> 8) & 0xffff) / 32768.0f - 1.0f; unsigned u; memcpy(&u, &f, 4); x = (unsigned short)(u >> 16); }
     if (m32 >= 2) {      // fingerprint-like counts: 95 % zeros, else 1 .. 3 -- as int8 (mode 2) or as bf16 values (mode 3)
         unsigned char* b8 = reinterpret_cast<unsigned char*>(h.data());
-        for (size_t i = 0; i < h.size() * (m32 == 2 ? 2 : 1); ++i) {
+        for (size_t i = 0; i < h.size() * (m32 == 3 ? 1 : 2); ++i) {
             s = s * 1664525u + 1013904223u;
             const unsigned r = (s >> 8) & 0xffff;
             const int v = r < 62259 ? 0 : 1 + (int)(r % 3);
-            if (m32 == 2) b8[i] = (unsigned char)v;
+            if (m32 == 4) {      // two fp4 per byte: 0x2 = 1.0 (E2M1), 5 % of the positions
+                s = s * 1664525u + 1013904223u;
+                const unsigned r2 = (s >> 8) & 0xffff;
+                b8[i] = (unsigned char)((r < 62259 ? 0 : 0x2) | (r2 < 62259 ? 0 : 0x20));
+            } else if (m32 == 2) b8[i] = (unsigned char)v;
             else { float f = (float)v; unsigned u; memcpy(&u, &f, 4); h[i] = (unsigned short)(u >> 16); }
         }
     }
@@ -131,12 +171,13 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int rep = 0; rep < 4; ++rep) {
         CK(hipEventRecord(e0));
-        if (m32 == 2) hipLaunchKernelGGL(mfma_only_i8, dim3(grid), dim3(512), 0, 0, src, (int*)out, iters);
+        if (m32 == 4) hipLaunchKernelGGL(mfma_only_fp4, dim3(grid), dim3(512), 0, 0, src, out, iters);
+        else if (m32 == 2) hipLaunchKernelGGL(mfma_only_i8, dim3(grid), dim3(512), 0, 0, src, (int*)out, iters);
         else if (m32 == 1) hipLaunchKernelGGL(mfma_only<true>, dim3(grid), dim3(512), 0, 0, src, out, iters);
         else hipLaunchKernelGGL(mfma_only<false>, dim3(grid), dim3(512), 0, 0, src, out, iters);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipGetLastError());
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-        const double flop = (double)grid * 8 * iters * 64.0 * 2 * 16 * 16 * (m32 == 2 ? 64 : 32);
+        const double flop = (double)grid * 8 * iters * 64.0 * 2 * 16 * 16 * (m32 == 4 ? 128 : m32 == 2 ? 64 : 32);
         printf("mode %d: %.2f ms  %.1f T(FL)OP/s\n", m32, ms, flop / ms / 1e9);
     }
     return 0;
