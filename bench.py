@@ -193,19 +193,23 @@ def fingerprint_workload(args, dev, local_rank):
     """retrieve/retrieve_faiss.py:62-74 as the reference runs it: IndexFlatL2, k = 20, d = 2048 sparse signed counts
     (reaction difference fingerprints, :18-27), the training set searching itself (:114-115).  One step = the whole
     self-search (680,000 queries in batches of 65,536 = 11 scan launches).  Not the headline metric: a second line with
-    its own roofline (same kernel, K = 2048 -> 32 K-steps per tile) and CPU baseline, recorded under profiles/."""
+    its own roofline (same kernel, K = 2048 -> 32 K-steps per tile) and CPU baseline, recorded under profiles/.
+    --workload morgan: the molecule form of the same call (retrieve/retro.sh: --field product_smiles -> :36-44, Morgan bit
+    vectors of 1024 components, 0 or 1, 5 % set), which the scan runs on fp4 operands."""
     import torch
     import textreact_amd.faiss_compat as faiss
     n = args.n_corpus if args.n_corpus != N_CORPUS else 680_000     # ~ USPTO-condition train size
     g = torch.Generator(device=dev); g.manual_seed(1)
-    y = torch.empty((n, 2048), dtype=torch.bfloat16, device=dev)
+    morgan = args.workload == "morgan"
+    dim = 1024 if morgan else 2048
+    y = torch.empty((n, dim), dtype=torch.bfloat16, device=dev)
     for r0 in range(0, n, 65536):                                   # blockwise: the int64 temporaries of the whole set are 11 GB
         m = min(65536, n - r0)
-        mask = torch.rand((m, 2048), generator=g, device=dev) < 0.02
-        vals = torch.randint(-10, 11, (m, 2048), generator=g, device=dev)
+        mask = torch.rand((m, dim), generator=g, device=dev) < (0.05 if morgan else 0.02)
+        vals = torch.ones((m, dim), dtype=torch.int64, device=dev) if morgan else torch.randint(-10, 11, (m, dim), generator=g, device=dev)
         y[r0:r0 + m] = (mask * vals).to(torch.bfloat16)
     del mask, vals
-    idx = faiss.IndexFlatL2(2048, device=local_rank)
+    idx = faiss.IndexFlatL2(dim, device=local_rank)
     idx.set_timing(True)
     idx.add(y)
     for _ in range(args.warmup):
@@ -221,21 +225,24 @@ def fingerprint_workload(args, dev, local_rank):
     t1 = time.perf_counter()
     steps = max(1, min(args.steps, 3))
     ok = bool((I[:, 0] == torch.arange(n, device=dev)).float().mean() > 0.99) and bool((D[:, 0] == 0).all())
-    flops_step = 2.0 * n * n * 2048
+    flops_step = 2.0 * n * n * dim
+    form = st.get("int8_scan", 0)
+    peak = {0: PEAK_BF16_TFLOPS, 1: 5000.0, 2: 10000.0}[form]
     mean_launch_ms = scan_ms / max(launches, 1)
     achieved = flops_step * steps / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else 0.0
-    line = {"metric": "queries/sec, train self-search IndexFlatL2 k=20 over %dx2048 integer fingerprints (the reference's own workload)" % n,
+    line = {"metric": "queries/sec, train self-search IndexFlatL2 k=20 over %dx%d integer fingerprints (the reference's own workload)" % (n, dim),
             "value": n * steps / (t1 - t0), "unit": "queries/s", "n_gpus": 1, "steps": steps, "warmup": args.warmup,
             "ms_per_step": (t1 - t0) / steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "i8" if st.get("int8_scan") else "bf16", "data": "synthetic",
-            "config": {"workload": "exact L2 top-20, %dx2048 sparse signed-count fingerprints (2 %% dense, |v| <= 10), the set searching itself"
-                                   % n, "corpus_rows": n, "dim": 2048, "queries": n, "k": 20, "exact_class": st["exact_class"],
-                       "int8_scan": st.get("int8_scan", 0),      # 1: the scan's int8 form (v_mfma_i32_16x16x64_i8; TRX_NO_I8=1 for the bf16 form)
+            "dtype": ("bf16", "i8", "fp4")[form], "data": "synthetic",
+            "config": {"workload": ("exact L2 top-20, %dx1024 Morgan-like bit vectors (5 %% set), the set searching itself" if morgan else
+                                    "exact L2 top-20, %dx2048 sparse signed-count fingerprints (2 %% dense, |v| <= 10), the set searching itself")
+                                   % n, "corpus_rows": n, "dim": dim, "queries": n, "k": 20, "exact_class": st["exact_class"],
+                       "int8_scan": form,      # 1: the scan's int8 form (v_mfma_i32_16x16x64_i8), 2: its fp4 form (v_mfma_f32_16x16x128_f8f6f4); TRX_NO_FP4=1 / TRX_NO_I8=1 for the others
                        "uncertified_queries_per_step": st["n_uncertified"], "self_is_first": ok,
                        "scan_launches_per_step": launches // steps},
-            "roofline": {"bound": "mfma", "kernel": "knn_scan_kernel", "achieved": achieved, "peak": 5000.0 if st.get("int8_scan") else PEAK_BF16_TFLOPS,
-                         "unit": "Top/s (dense int8 MFMA peak)" if st.get("int8_scan") else "TFLOP/s",
-                         "frac": achieved / (5000.0 if st.get("int8_scan") else PEAK_BF16_TFLOPS), "traffic": None, "launch_ms": mean_launch_ms,
+            "roofline": {"bound": "mfma", "kernel": "knn_scan_kernel", "achieved": achieved, "peak": peak,
+                         "unit": ("TFLOP/s", "Top/s (dense int8 MFMA peak)", "TFLOP/s (dense fp4 MFMA peak: twice fp8's)")[form],
+                         "frac": achieved / peak, "traffic": None, "launch_ms": mean_launch_ms,
                          "flops_per_launch": flops_step * steps / max(launches, 1)}}
     if not args.no_cpu_baseline:
         base, I_cpu = cpu_baseline(y, y, 20, metric=1)
@@ -264,7 +271,7 @@ def main():
     ap.add_argument("--selfcheck", action="store_true",
                     help="also at N = 1 (always on at N > 1): before the timed region, compare every rank's result hashes and re-do "
                          "32 sampled queries by an independent fp64 matmul + all_gather + sort; exit code 3 on a mismatch")
-    ap.add_argument("--workload", default="dense", choices=["dense", "fingerprint"],
+    ap.add_argument("--workload", default="dense", choices=["dense", "fingerprint", "morgan"],
                     help="dense = the headline (BASELINE.json configs[1]); fingerprint = the reference's own call: "
                          "IndexFlatL2, k=20, 2048-d integer reaction fingerprints, train set searching itself (not the headline)")
     args = ap.parse_args()
@@ -295,7 +302,7 @@ def main():
     from textreact_amd.sharded import ShardedFlatIndex, shard_bounds
 
     n, d, nq, k = args.n_corpus * (world if args.weak else 1), DIM, args.n_queries, TOPK
-    if args.workload == "fingerprint":
+    if args.workload in ("fingerprint", "morgan"):
         return fingerprint_workload(args, dev, local_rank)
     lo, hi = (0, n) if args.replicas else shard_bounds(n, world, rank)
     if args.weak and not args.replicas:      # "8 shards x 1,000,000, shard s uses seed 1234 + s"

@@ -148,6 +148,8 @@ typedef struct trx_search_stats {
                               took; n_uncertified of them went on to the exact scan */
     int32_t int8_scan;     /* 1 = the scan ran in its int8 form (integer inputs that fit a signed byte -- the L2 scan stages
                               the doubled query --, d >= 256: v_mfma_i32_16x16x64_i8, twice the MACs per instruction);
+                              2 = in its fp4 form (every value on both sides one of 0, +-1, +-2, +-3, +-4, +-6 -- Morgan bit
+                              vectors: v_mfma_f32_16x16x128_f8f6f4 on E2M1 operands, four times the MACs per instruction);
                               same keys, same lists, same results as the bf16 form */
 } trx_search_stats;
 

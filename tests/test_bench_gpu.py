@@ -44,6 +44,17 @@ def test_fingerprint_workload_line_runs_the_int8_form():
         assert j["roofline"]["peak"] == (5000.0 if want else 2500.0) and j["config"]["self_is_first"] and j["config"]["exact_class"] == 1
 
 
+def test_morgan_workload_line_runs_the_fp4_form():
+    """bench.py --workload morgan (retrieve/retro.sh's call: 1024-component Morgan bit vectors searching themselves), small: the
+    scan runs on fp4 operands and the line prices it against that peak"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "morgan", "--steps", "1", "--warmup", "1",
+                        "--n-corpus", "20000", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _line(r.stdout)
+    assert j["config"]["int8_scan"] == 2 and j["dtype"] == "fp4" and j["roofline"]["peak"] == 10000.0, j
+    assert j["config"]["self_is_first"] and j["config"]["exact_class"] == 1 and j["config"]["dim"] == 1024
+
+
 @pytest.mark.parametrize("mode", [[], ["--replicas"]])
 def test_two_ranks_as_the_driver_launches_it(mode):
     with socket.socket() as s_:

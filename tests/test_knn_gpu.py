@@ -101,11 +101,12 @@ def test_int8_form_of_the_scan_for_the_integer_class(metric, d, maker):
     path, and bit-identical to the bf16 form of the same search (TRX_NO_I8), incl. a second add and a ragged query count"""
     y = maker(7000, d, 21)
     x = np.concatenate([y[:300], maker(133, d, 22)])
+    form = 2 if maker is morgan_like else 1                # bit vectors take the fp4 form (next test), counts up to 10 the int8 form
     st = _check(metric, x, y, 20, chunks=2, expect_exact_class=True)
-    assert st["int8_scan"] == 1 and st["n_uncertified"] == 0, st
+    assert st["int8_scan"] == form and st["n_uncertified"] == 0, st
     idx = _index(metric, d); idx.add(y[:5000]); idx.add(y[5000:])
     D8, I8 = idx.search(x, 20)
-    assert idx.last_stats()["int8_scan"] == 1
+    assert idx.last_stats()["int8_scan"] == form
     os.environ["TRX_NO_I8"] = "1"
     try:
         D16, I16 = idx.search(x, 20)
@@ -113,6 +114,51 @@ def test_int8_form_of_the_scan_for_the_integer_class(metric, d, maker):
     finally:
         del os.environ["TRX_NO_I8"]
     assert np.array_equal(I8, I16) and np.array_equal(D8.view(np.uint32), D16.view(np.uint32))
+
+
+def _e2m1_like(n, d, seed, density=0.1, signed=True):
+    rng = np.random.default_rng(seed)
+    vals = np.array([1, 1, 1, 2, 2, 3, 4, 6], dtype=np.float32)[rng.integers(0, 8, (n, d))]
+    if signed:
+        vals *= rng.choice(np.array([-1.0, 1.0], dtype=np.float32), (n, d))
+    return ((rng.random((n, d)) < density) * vals).astype(np.float32)
+
+
+@pytest.mark.parametrize("metric", [IP, L2])
+@pytest.mark.parametrize("d,maker", [(1024, morgan_like), (1000, _e2m1_like), (2048, _e2m1_like), (300, morgan_like)])
+def test_fp4_form_of_the_scan_for_bit_vectors_and_tiny_counts(metric, d, maker):
+    """every value on both sides one of 0, +-1, +-2, +-3, +-4, +-6 (what E2M1 holds; the reference's Morgan fingerprints are
+    0 / 1): the scan runs on v_mfma_f32_16x16x128_f8f6f4 with fp4 operands (stats int8_scan == 2) -- the oracle's answer, and
+    bit-identical to the int8 form (TRX_NO_FP4) and the bf16 form (TRX_NO_I8) of the same search; a second add, a ragged query
+    count, widths that are not a multiple of 32"""
+    y = maker(7000, d, 51)
+    x = np.concatenate([y[:300], maker(133, d, 52)])
+    st = _check(metric, x, y, 20, chunks=2, expect_exact_class=True)
+    assert st["int8_scan"] == 2 and st["n_uncertified"] == 0, st
+    idx = _index(metric, d); idx.add(y[:5000]); idx.add(y[5000:])
+    D4, I4 = idx.search(x, 20)
+    assert idx.last_stats()["int8_scan"] == 2
+    for env, want in (("TRX_NO_FP4", 1), ("TRX_NO_I8", 0)):
+        os.environ[env] = "1"
+        try:
+            D, I = idx.search(x, 20)
+            assert idx.last_stats()["int8_scan"] == want
+        finally:
+            del os.environ[env]
+        assert np.array_equal(I4, I) and np.array_equal(D4.view(np.uint32), D.view(np.uint32)), env
+
+
+def test_the_fp4_form_is_gated_on_the_device_and_by_the_corpus():
+    y = _e2m1_like(6000, 512, 61)
+    five = y[:200].copy(); five[:, 3] = 5.0                 # 5 is an int8 but not an E2M1 number
+    assert _check(L2, y[:200], y, 10)["int8_scan"] == 2
+    assert _check(L2, five, y, 10)["int8_scan"] == 1        # the QUERIES decide per search, on the device ...
+    assert _check(IP, y[:200] * 0.5, y, 10)["int8_scan"] == 0
+    y5 = y.copy(); y5[17, 0] = 5.0
+    assert _check(L2, y[:200], y5, 10)["int8_scan"] == 1    # ... a corpus value outside the set rules the form out for good
+    idx = _index(L2, 512); idx.add(y); idx.add(y5[:100])    # (also when it arrives with a later add)
+    idx.search(y[:64], 10)
+    assert idx.last_stats()["int8_scan"] == 1
 
 
 def test_the_int8_form_is_gated_on_the_device():

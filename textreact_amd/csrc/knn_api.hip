@@ -22,7 +22,8 @@ hipError_t launch_widen_rows(const bf16_t*, int64_t, int, int64_t, float*, hipSt
 hipError_t launch_widen_i8(const signed char*, int64_t, int, bf16_t*, hipStream_t);
 hipError_t launch_exact_scan(int, int, int, const int*, int, const int*, int64_t, const void*, int64_t, const void*,
                              int64_t, int, int, double*, float*, int64_t*, double*, hipStream_t);
-hipError_t launch_classify(const void*, int, int, float, int, int, int, int*, hipStream_t);
+hipError_t launch_classify(const void*, int, int, float, int, int, int, int, int*, hipStream_t);
+hipError_t launch_build_operand_fp4(const void*, int, int64_t, int, int64_t, unsigned char*, int, hipStream_t);
 hipError_t launch_build_operand_i8(const void*, int, int64_t, int, int64_t, signed char*, int, float, hipStream_t);
 hipError_t launch_fill_bias_i32(const float*, int64_t, int64_t, int*, hipStream_t);
 hipError_t launch_slack(const float*, int64_t, int64_t, float, float, float, int, float*, hipStream_t);
@@ -42,7 +43,7 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
                         std::string(#expr) + ": " + hipGetErrorString(e__));               \
     } while (0)
 
-struct HostStats { uint32_t inexact_any, nonint_any, maxabs_bits, maxnorm2_bits; };
+struct HostStats { uint32_t inexact_any, nonint_any, maxabs_bits, maxnorm2_bits, nonfp4_any; };
 static float bits2f(uint32_t b) { float f; std::memcpy(&f, &b, 4); return f; }
 
 // grow-only device buffer
@@ -69,7 +70,7 @@ struct DevBuf {
 // per index.
 struct DevPool {
     std::mutex mu;
-    DevBuf cand, cnt, thr, gthr, qg, qg2, gthr2, qg8, slk, d1, i1;
+    DevBuf cand, cnt, thr, gthr, qg, qg2, gthr2, qg8, qg4, slk, d1, i1;
     hipEvent_t last = nullptr;
     int users = 0;
 };
@@ -97,10 +98,13 @@ struct trx_index {
     float* cbias = nullptr;  // [cap]
     float maxabs = 0.f, maxnorm2 = 0.f;
     bool nonint = false;
+    bool nonfp4 = false;      // some value is not one of 0, +-1, +-2, +-3, +-4, +-6 (what the fp4 form of the scan can hold)
     // the int8 form of the scan for the integer class (knn_scan.hip, I8): an int8 copy of the operand rows and the int32 start
     // values of the L2 accumulators, made by the first search that can use them after the index changed
     signed char* C8 = nullptr; int* cbias8 = nullptr;
     int64_t c8_cap = 0, c8_rows = -1; int Kp8 = 0;
+    unsigned char* C4 = nullptr;      // the fp4 copy of a bit-vector corpus (two components per byte)
+    int64_t c4_cap = 0, c4_rows = -1; int Kp4 = 0;
     // workspaces
     DevBuf w_stamp, w_stats, w_qnorm2, w_flag, w_exact, w_io, w_tmp, w_cls;      // (the big ones are shared: DevPool)
     trx_search_stats stats{};
@@ -207,6 +211,7 @@ void trx_index_destroy(trx_index* idx) {
     if (idx->cbias) (void)hipFree(idx->cbias);
     if (idx->C8) (void)hipFree(idx->C8);
     if (idx->cbias8) (void)hipFree(idx->cbias8);
+    if (idx->C4) (void)hipFree(idx->C4);
     DevBuf* bufs[] = {&idx->w_stamp, &idx->w_stats, &idx->w_qnorm2, &idx->w_flag, &idx->w_exact, &idx->w_io, &idx->w_tmp, &idx->w_cls};
     for (DevBuf* b : bufs) b->release();
     {   // the last index of the process on this device takes the shared workspaces with it
@@ -215,7 +220,7 @@ void trx_index_destroy(trx_index* idx) {
         if (--pl.users <= 0) {
             pl.users = 0;
             (void)hipDeviceSynchronize();
-            DevBuf* shared[] = {&pl.cand, &pl.cnt, &pl.thr, &pl.gthr, &pl.qg, &pl.qg2, &pl.gthr2, &pl.qg8, &pl.slk, &pl.d1, &pl.i1};
+            DevBuf* shared[] = {&pl.cand, &pl.cnt, &pl.thr, &pl.gthr, &pl.qg, &pl.qg2, &pl.gthr2, &pl.qg8, &pl.qg4, &pl.slk, &pl.d1, &pl.i1};
             for (DevBuf* b : shared) b->release();
             // (the ordering event stays for the life of the process: a few bytes, and nothing can hold a stale handle to it)
         }
@@ -239,6 +244,8 @@ int trx_index_reset(trx_index* idx) {
     if (idx->C8) (void)hipFree(idx->C8);
     if (idx->cbias8) (void)hipFree(idx->cbias8);
     idx->C8 = nullptr; idx->cbias8 = nullptr; idx->c8_cap = 0; idx->c8_rows = -1;
+    if (idx->C4) (void)hipFree(idx->C4);
+    idx->C4 = nullptr; idx->c4_cap = 0; idx->c4_rows = -1; idx->nonfp4 = false;
     idx->n = 0; idx->cap = 0; idx->mode = MODE_EMPTY; idx->Kp = 0;
     idx->maxabs = 0.f; idx->maxnorm2 = 0.f; idx->nonint = false;
     return TRX_OK;
@@ -296,10 +303,12 @@ int trx_index_add_device(trx_index* idx, const void* x, int64_t n, int dtype, vo
     HIPCHK(hipMemcpyAsync(idx->cnorm2 + idx->n, idx->w_tmp.p, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, st));
     idx->n += n;
     idx->c8_rows = -1;       // the int8 copy (if any) is rebuilt by the next search that can use it
+    idx->c4_rows = -1;       // (the fp4 copy likewise)
     HIPCHK(launch_fill_bias(idx->cnorm2, idx->n, idx->cap + TILE_M, idx->cbias, st));
     idx->maxabs = std::max(idx->maxabs, bits2f(hs.maxabs_bits));
     idx->maxnorm2 = std::max(idx->maxnorm2, bits2f(hs.maxnorm2_bits));
     idx->nonint = idx->nonint || hs.nonint_any;
+    idx->nonfp4 = idx->nonfp4 || hs.nonfp4_any;
     HIPCHK(hipStreamSynchronize(st));  // x may be freed by the caller on return
     return TRX_OK;
 }
@@ -448,6 +457,27 @@ static int search_batch(trx_index* idx, const void* q, const float* qnorm2, int6
         sp.gate = (const int*)idx->w_cls.p + 1; sp.gate_want = 0;
         idx->pend.tried_i8 = 1;
     }
+    // ... and a corpus of bit vectors (every value one of 0, +-1, +-2, +-3, +-4, +-6) an fp4 form: a third launch of each pair,
+    // run when the queries are of that kind too (w_cls[1] == 2)
+    const bool try4 = try8 && !idx->nonfp4 && !getenv("TRX_NO_FP4");
+    if (try4) {
+        const int Kp4 = (int)round_up64(std::max(d, 1024), 512) / 2;      // bytes per row: a K-step is 128 of them = 256 components, at least 4, an even number
+        const int64_t rows4 = idx->cap + TILE_M;
+        if (idx->c4_cap != rows4 || idx->Kp4 != Kp4) {
+            if (idx->C4) (void)hipFree(idx->C4);
+            idx->C4 = nullptr; idx->c4_cap = 0; idx->c4_rows = -1;
+            HIPCHK(hipMalloc((void**)&idx->C4, (size_t)rows4 * Kp4));
+            idx->c4_cap = rows4; idx->Kp4 = Kp4;
+        }
+        if (idx->c4_rows != idx->n) {
+            HIPCHK(hipMemsetAsync(idx->C4, 0, (size_t)rows4 * Kp4, st));
+            HIPCHK(launch_build_operand_fp4(idx->Cg, 1, idx->n, d, Kp, idx->C4, Kp4, st));
+            idx->c4_rows = idx->n;
+        }
+        if ((rc = pl.qg4.reserve((size_t)q_pad * Kp4))) return rc;
+        HIPCHK(hipMemsetAsync(pl.qg4.p, 0, (size_t)q_pad * Kp4, st));
+        HIPCHK(launch_build_operand_fp4(q, is_bf, nq, d, d, (unsigned char*)pl.qg4.p, Kp4, st));
+    }
     // seed the shared thresholds: every query tile scans a few tiles (selection bookkeeping only, no lists)
     const bool boot = !getenv("TRX_NO_BOOT") && ntiles > 2;
     if (boot) {
@@ -461,6 +491,12 @@ static int search_batch(trx_index* idx, const void* q, const float* qnorm2, int6
             b8.corpus = (const bf16_t*)idx->C8; b8.queries = (const bf16_t*)pl.qg8.p; b8.cbias = (const float*)idx->cbias8; b8.Kp = idx->Kp8 / 2;
             HIPCHK(launch_scan(b8, idx->metric, st));
         }
+        if (try4) {      // (the fp4 form computes in the bf16 form's arithmetic: its float bias, its accumulators)
+            ScanParams b4 = bp;
+            b4.i8 = 2; b4.gate_want = 2;
+            b4.corpus = (const bf16_t*)idx->C4; b4.queries = (const bf16_t*)pl.qg4.p; b4.Kp = idx->Kp4 / 2;
+            HIPCHK(launch_scan(b4, idx->metric, st));
+        }
     }
     sp.bootstrap = 0; sp.boot_tiles = 0;
     if (idx->timing) HIPCHK(hipEventRecord(idx->ev[0], st));
@@ -471,6 +507,12 @@ static int search_batch(trx_index* idx, const void* q, const float* qnorm2, int6
         s8.corpus = (const bf16_t*)idx->C8; s8.queries = (const bf16_t*)pl.qg8.p; s8.cbias = (const float*)idx->cbias8;
         s8.Kp = idx->Kp8 / 2;          // the kernel counts 2-byte units
         HIPCHK(launch_scan(s8, idx->metric, st));
+    }
+    if (try4) {
+        ScanParams s4 = sp;
+        s4.i8 = 2; s4.gate_want = 2;
+        s4.corpus = (const bf16_t*)idx->C4; s4.queries = (const bf16_t*)pl.qg4.p; s4.Kp = idx->Kp4 / 2;
+        HIPCHK(launch_scan(s4, idx->metric, st));
     }
     sp.gate = nullptr;      // (everything below -- the re-scan of uncertified queries -- is the bf16 form, ungated)
     if (idx->timing) HIPCHK(hipEventRecord(idx->ev[1], st));
@@ -619,7 +661,7 @@ static int finish_impl(trx_index* idx) {
         HIPCHK(hipMemcpyAsync(&cnt4[4 * b], pd.batches[b].nflag, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
     if (idx->w_cls.p && !pd.batches.empty()) HIPCHK(hipMemcpyAsync(cls, idx->w_cls.p, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    if (!pd.batches.empty()) { idx->stats.exact_class = cls[0]; idx->stats.int8_scan = (cls[1] && pd.tried_i8) ? 1 : 0; }
+    if (!pd.batches.empty()) { idx->stats.exact_class = cls[0]; idx->stats.int8_scan = pd.tried_i8 ? cls[1] : 0; }
     const int64_t per = std::max<int64_t>(INLINE_FALLBACK, ((int64_t)1 << 29) / std::max<int64_t>(1, idx->n * 8));
     bool late = false;
     for (size_t b = 0; b < pd.batches.size(); ++b) {
@@ -707,7 +749,7 @@ static int search_device_impl(trx_index* idx, const void* q, int64_t nq, int dty
     // one-thread kernel from the statistics just gathered; the select kernel reads the flag from device memory
     rc = idx->w_cls.reserve(4 * sizeof(int)); if (rc) return rc;
     HIPCHK(launch_classify(idx->w_stats.p, q_split, idx->nonint ? 1 : 0, idx->maxabs, idx->Kp, idx->d,
-                           idx->metric == TRX_METRIC_L2 ? 1 : 0, (int*)idx->w_cls.p, st));
+                           idx->metric == TRX_METRIC_L2 ? 1 : 0, (idx->nonfp4 || getenv("TRX_NO_FP4")) ? 1 : 0, (int*)idx->w_cls.p, st));
     const float eps_rel = (float)((idx->Kp + 64) * std::ldexp(1.0, -23)) + (q_split ? (float)std::ldexp(1.0, -15) : 0.f);
     // the rounding's share: relative to the product term alone (the L2 key's |y|^2 comes from the exact rows)
     const float eps_round = approx ? (float)(std::ldexp(1.0, -7) * (1.0 + std::ldexp(1.0, -8))) : 0.f;

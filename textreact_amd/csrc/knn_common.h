@@ -131,7 +131,8 @@ struct ScanParams {
                              // units; approximate operands: every row within twice the key error of the bound is listed)
     const int* gate;         // optional DEVICE int: the launch runs only when *gate == gate_want (the bf16 / int8 pair of the exact class)
     int gate_want;
-    int i8;                  // 1: the int8 form (corpus / queries hold int8 rows of 2 Kp bytes, cbias int32 -|y|^2, L2 queries doubled)
+    int i8;                  // 1: the int8 form (corpus / queries hold int8 rows of 2 Kp bytes, cbias int32 -|y|^2, L2 queries doubled);
+                             // 2: the fp4 form (rows of 2 Kp bytes = 4 Kp components; bias and arithmetic of the bf16 form)
     int bootstrap;           // 1: threshold bootstrap launch (boot_tiles tiles per query tile, publish g_thr only)
     int boot_tiles;
     int debug;               // timing-only diagnostics (TRX_SCAN_DEBUG), 0 in production

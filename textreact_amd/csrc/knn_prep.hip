@@ -19,6 +19,7 @@ struct RowStats {          // device-side accumulators (zeroed before each pass)
     u32 nonint_any;        // some value is not an integer
     u32 maxabs_bits;       // max |v| as float bits (non-negative floats order like uints)
     u32 maxnorm2_bits;     // max over rows of |row|^2
+    u32 nonfp4_any;        // some |value| is not one of 0, 1, 2, 3, 4, 6 (the integers E2M1 holds: the fp4 form of the scan)
 };
 
 template <bool BF>
@@ -33,9 +34,10 @@ __device__ __forceinline__ float load_val(const void* p, int64_t i) {
 template <bool BF>
 __device__ __forceinline__ void stat_one(float v, float& s, float& maxabs, u32& inexact, u32& nonint) {
     s = __builtin_fmaf(v, v, s);
-    maxabs = fmaxf(maxabs, fabsf(v));
+    const float a = fabsf(v);
+    maxabs = fmaxf(maxabs, a);
     if (!BF) inexact |= (bf16_to_f32(f32_to_bf16_rn(v)) != v) ? 1u : 0u;
-    nonint |= (rintf(v) != v) ? 1u : 0u;
+    nonint |= ((rintf(v) != v) ? 1u : 0u) | ((a > 4.f && a != 6.f) ? 2u : 0u);      // bit 1: beyond the integers of E2M1
 }
 template <bool BF>
 __global__ __launch_bounds__(256) void row_stats_kernel(const void* x, int64_t n, int d, int64_t ld,
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const void* x, int64_t n
     __shared__ float sh_abs[4], sh_n2[4];
     __shared__ u32 sh_flags[4];
     const int w = threadIdx.x >> 6;
-    if (lane == 0) { sh_abs[w] = maxabs; sh_n2[w] = maxn2; sh_flags[w] = (inexact ? 1u : 0u) | (nonint ? 2u : 0u); }
+    if (lane == 0) { sh_abs[w] = maxabs; sh_n2[w] = maxn2; sh_flags[w] = (inexact ? 1u : 0u) | ((nonint & 1u) ? 2u : 0u) | ((nonint & 3u) ? 4u : 0u); }
     __syncthreads();
     if (threadIdx.x == 0) {
         float a = fmaxf(fmaxf(sh_abs[0], sh_abs[1]), fmaxf(sh_abs[2], sh_abs[3]));
@@ -92,6 +94,7 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const void* x, int64_t n
         const u32 f = sh_flags[0] | sh_flags[1] | sh_flags[2] | sh_flags[3];
         if (f & 1u) atomicOr(&st->inexact_any, 1u);
         if (f & 2u) atomicOr(&st->nonint_any, 1u);
+        if (f & 4u) atomicOr(&st->nonfp4_any, 1u);
         atomicMax(&st->maxabs_bits, __float_as_uint(a));
         atomicMax(&st->maxnorm2_bits, __float_as_uint(m));
     }
@@ -100,17 +103,19 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const void* x, int64_t n
 // The exact class of a search -- integer inputs small enough that every fp32 partial sum (and the L2 key) is exact, so
 // the approximate order IS the exact order and no certificate is needed -- decided on the device from the query
 // statistics, so that a search need not read them back (knn_api.hip: the stream-ordered search).
-__global__ void classify_kernel(const RowStats* qs, int q_split, int idx_nonint, float idx_maxabs, int Kp, int d, int l2, int* out) {
+__global__ void classify_kernel(const RowStats* qs, int q_split, int idx_nonint, float idx_maxabs, int Kp, int d, int l2, int idx_nonfp4, int* out) {
     const float qmax = __uint_as_float(qs->maxabs_bits);
     const double prod = (double)Kp * (double)qmax * (double)idx_maxabs;
     const double keymag = l2 ? 2.0 * prod + (double)d * idx_maxabs * idx_maxabs : prod;
     out[0] = (!q_split && !qs->nonint_any && !idx_nonint && qmax <= 256.f && idx_maxabs <= 256.f && keymag < 16777216.0) ? 1 : 0;
-    // [1]: the int8 form of the scan may run (knn_scan.hip, I8): the exact class, and both operands fit a signed byte --
-    // the L2 scan stages the DOUBLED query
-    out[1] = (out[0] && idx_maxabs <= 127.f && qmax * (l2 ? 2.f : 1.f) <= 127.f) ? 1 : 0;
+    // [1]: the form of the scan (knn_scan.hip, FMT).  1 = int8: the exact class, and both operands fit a signed byte -- the L2
+    // scan stages the DOUBLED query.  2 = fp4: every value on both sides is an integer E2M1 holds (0, 1, 2, 3, 4, 6 and their
+    // negatives: Morgan bit vectors are 0 / 1) -- products and fp32 sums exact as in the bf16 form, 256 components per K-step
+    const int i8 = (out[0] && idx_maxabs <= 127.f && qmax * (l2 ? 2.f : 1.f) <= 127.f) ? 1 : 0;
+    out[1] = (out[0] && !idx_nonfp4 && !qs->nonfp4_any) ? 2 : i8;
 }
-hipError_t launch_classify(const void* qstats, int q_split, int idx_nonint, float idx_maxabs, int Kp, int d, int l2, int* out, hipStream_t st) {
-    hipLaunchKernelGGL(classify_kernel, dim3(1), dim3(1), 0, st, (const RowStats*)qstats, q_split, idx_nonint, idx_maxabs, Kp, d, l2, out);
+hipError_t launch_classify(const void* qstats, int q_split, int idx_nonint, float idx_maxabs, int Kp, int d, int l2, int idx_nonfp4, int* out, hipStream_t st) {
+    hipLaunchKernelGGL(classify_kernel, dim3(1), dim3(1), 0, st, (const RowStats*)qstats, q_split, idx_nonint, idx_maxabs, Kp, d, l2, idx_nonfp4, out);
     return hipGetLastError();
 }
 
@@ -179,6 +184,39 @@ __global__ void slack_kernel(const float* qnorm2, int64_t nq, int64_t q_pad, flo
 hipError_t launch_slack(const float* qnorm2, int64_t nq, int64_t q_pad, float eps_rel, float eps_round, float ymax_norm2, int l2, float* out, hipStream_t st) {
     if (q_pad <= 0) return hipSuccess;
     hipLaunchKernelGGL(slack_kernel, dim3((unsigned)((q_pad + 255) / 256)), dim3(256), 0, st, qnorm2, nq, q_pad, eps_rel, eps_round, ymax_norm2, l2, out);
+    return hipGetLastError();
+}
+
+// fp4 (E2M1) operand rows for bit vectors and other tiny counts: component c of row r -> its 4-bit code (sign, two exponent
+// bits, one mantissa bit: 0 -> 0, 1 -> 2, 2 -> 4, 3 -> 5, 4 -> 6, 6 -> 7), two per byte, low nibble first, zero beyond d up to
+// the row's Kp4 bytes.  One thread per (row, 16-byte group = 32 components).  A value outside the set gives garbage -- the
+// launch that would read it is gated off on the device then (classify_kernel, out[1]).
+template <bool BF>
+__global__ __launch_bounds__(256) void build_operand_fp4_kernel(const void* x, int64_t n, int d, int64_t ld, unsigned char* out, int Kp4) {
+    const int groups = Kp4 / 16;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n * groups) return;
+    const int64_t r = t / groups;
+    const int g = (int)(t - r * groups);
+    const char* row = reinterpret_cast<const char*>(x) + r * ld * (BF ? 2 : 4);
+    u32 w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const int c = g * 32 + i;
+        const float v = c < d ? load_val<BF>(row, c) : 0.f;
+        const int a = (int)fminf(fabsf(v), 7.f);
+        const u32 mag = a <= 2 ? (u32)(2 * a) : (a == 3 ? 5u : (a == 4 ? 6u : 7u));      // (a == 0 -> 0, 1 -> 2, 2 -> 4)
+        const u32 code = mag | (v < 0.f ? 8u : 0u);
+        w[i >> 3] |= code << (4 * (i & 7));
+    }
+    *reinterpret_cast<uint4*>(out + r * Kp4 + g * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+hipError_t launch_build_operand_fp4(const void* x, int is_bf16, int64_t n, int d, int64_t ld, unsigned char* out, int Kp4, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    const int64_t total = n * (Kp4 / 16);
+    dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    if (is_bf16) hipLaunchKernelGGL(build_operand_fp4_kernel<true>, grid, block, 0, st, x, n, d, ld, out, Kp4);
+    else hipLaunchKernelGGL(build_operand_fp4_kernel<false>, grid, block, 0, st, x, n, d, ld, out, Kp4);
     return hipGetLastError();
 }
 

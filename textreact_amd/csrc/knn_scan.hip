@@ -80,6 +80,7 @@ namespace trx {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(8))) int i32x8;
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(3))) char lds_char;
 typedef __attribute__((address_space(1))) const void gbl_void;
@@ -224,11 +225,18 @@ __device__ __forceinline__ u64 compact_list(u64* list, int cap, int kprime, int 
 // accumulators int32; L2 stages the DOUBLED query and starts from -|y|^2, so that an accumulator is the key itself
 // (2 x.y - |y|^2, an integer).  The byte geometry of the loop is the bf16 form's (Kp counts 2-byte units); the filter takes
 // a group's maximum in int32 and converts it once.  Whether a search may use it is decided on the device (p.gate).
-template <bool L2, int J, bool BOOT, int NKS, bool RESCAN = false, bool I8 = false>
+// FMT 2, fp4: bit vectors and other tiny counts (every value one of 0, +-1, +-2, +-3, +-4, +-6: what E2M1 holds; the reference's
+// Morgan fingerprints, retrieve_faiss.py:36-44, are 0 / 1).  v_mfma_scale_f32_16x16x128_f8f6f4 with fp4 operands and unit scales
+// takes 128 components from the same 16-byte fragments in the time of the other two instructions (tools/mfma_shape_lab: 9.3
+// PFLOP/s on such data against 4.7 int8 and 2.4 bf16); products and fp32 sums are exact, so the accumulators, the bias and
+// the filter are the bf16 form's.  Which component a nibble of a fragment stands for is the hardware's business: corpus and
+// query rows are packed by the same kernel, and a dot product does not care about a permutation applied to both sides.
+template <bool L2, int J, bool BOOT, int NKS, bool RESCAN = false, int FMT = 0>
 __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p) {
     // the exact class of a search is known on the device only (knn_prep.hip: classify_kernel): the bf16 and the int8 launch
     // are both enqueued (bootstrap and main scan alike), and the one whose turn it is not leaves here
     if (p.gate && *p.gate != p.gate_want) return;
+    constexpr bool I8 = FMT == 1;      // (FMT 2, fp4: float accumulators and the bf16 form's arithmetic -- only the instruction differs)
     typedef typename std::conditional<I8, i32x4, f32x4>::type acc_t;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const u32 lds0 = (u32)(uintptr_t)(lds_char*)smem;
@@ -429,7 +437,11 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
 #ifndef TRX_SNAKE
 #define TRX_SNAKE 1
 #endif
-#define TRX_MFMA1(A, B, C) (I8 ? (acc_t)__builtin_bit_cast(acc_t, __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, A), __builtin_bit_cast(i32x4, B), __builtin_bit_cast(i32x4, C), 0, 0, 0)) \
+// (the instruction reads four registers of an fp4 operand; the builtin's eight-register type gets an UNDEFINED upper half, which
+// the instruction selection drops -- zeros there cost four more live registers per fragment and 500 bytes of scratch)
+#define TRX_F4OP(X) __builtin_shufflevector(__builtin_bit_cast(i32x4, X), __builtin_bit_cast(i32x4, X), 0, 1, 2, 3, -1, -1, -1, -1)
+#define TRX_MFMA1(A, B, C) (FMT == 1 ? (acc_t)__builtin_bit_cast(acc_t, __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, A), __builtin_bit_cast(i32x4, B), __builtin_bit_cast(i32x4, C), 0, 0, 0)) \
+                  : FMT == 2 ? (acc_t)__builtin_bit_cast(acc_t, __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(TRX_F4OP(A), TRX_F4OP(B), __builtin_bit_cast(f32x4, C), 4, 4, 0, 0, 0, 0)) \
                               : (acc_t)__builtin_bit_cast(acc_t, __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B, __builtin_bit_cast(f32x4, C), 0, 0, 0)))
 #define TRX_MFMA_ACC()                                                                                     \
     __builtin_amdgcn_s_setprio(1);                                                                         \
@@ -835,7 +847,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
     }
 }
 
-template <bool L2, int J, bool BOOT, int NKS, bool RESCAN, bool I8 = false>
+template <bool L2, int J, bool BOOT, int NKS, bool RESCAN, int FMT = 0>
 static hipError_t launch_one(const ScanParams& p, hipStream_t st) {
     // the attribute is per device (the ABI takes a device ordinal): one bit per ordinal, per instantiation
     static std::atomic<unsigned long long> attr_devs{0ull};
@@ -844,20 +856,21 @@ static hipError_t launch_one(const ScanParams& p, hipStream_t st) {
     if (e != hipSuccess) return e;
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(attr_devs.load(std::memory_order_acquire) & bit)) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_scan_kernel<L2, J, BOOT, NKS, RESCAN, I8>),
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_scan_kernel<L2, J, BOOT, NKS, RESCAN, FMT>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
         if (e != hipSuccess) return e;
         attr_devs.fetch_or(bit, std::memory_order_release);
     }
     dim3 grid(BOOT ? p.nqtiles : p.nqtiles * p.nsplits), block(SCAN_THREADS);
-    hipLaunchKernelGGL((knn_scan_kernel<L2, J, BOOT, NKS, RESCAN, I8>), grid, block, LDS_TOTAL, st, p);
+    hipLaunchKernelGGL((knn_scan_kernel<L2, J, BOOT, NKS, RESCAN, FMT>), grid, block, LDS_TOTAL, st, p);
     return hipGetLastError();
 }
 
 template <bool L2, int J, bool BOOT>
 static hipError_t launch_ks(const ScanParams& p, hipStream_t st) {
     // (32 K-steps = 2048 components compiled in: no gain, 91.4 ms either way on the fingerprint workload)
-    if (p.i8) return launch_one<L2, J, BOOT, 0, false, true>(p, st);      // the int8 form: the bootstrap and the main scan (the re-scan of uncertified queries stays bf16)
+    if (p.i8 == 1) return launch_one<L2, J, BOOT, 0, false, 1>(p, st);      // the int8 form: the bootstrap and the main scan (the re-scan of uncertified queries stays bf16)
+    if (p.i8 == 2) return launch_one<L2, J, BOOT, 0, false, 2>(p, st);      // the fp4 form, likewise
     if (!BOOT && p.fixed_thr) return p.Kp == 12 * BK ? launch_one<L2, J, false, 12, true>(p, st) : launch_one<L2, J, false, 0, true>(p, st);
     return p.Kp == 12 * BK ? launch_one<L2, J, BOOT, 12, false>(p, st) : launch_one<L2, J, BOOT, 0, false>(p, st);
 }

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(512, 2) void mfma_only_fp4(const uint4* src, float*
 #pragma unroll
         for (int i = 0; i < 64; ++i) {
             const int kk = i >> 5, a = (i >> 2) & 7, b = i & 3;
-            acc[a][b] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fa[kk][a], fb[kk][b], acc[a][b], 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+            acc[a][b] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fa[kk][a], fb[kk][b], acc[a][b], 4, 4, 0, 0, 0, 0);
         }
         if ((it % 12) == 11) {
 #pragma unroll
