@@ -11,6 +11,9 @@ python -m pytest tests -q -m gpu > $O/gputest.log 2>&1; echo "rc=$?" >> $O/gpute
 python bench.py > $O/bench.jsonl 2> $O/bench.err
 python bench.py --steps 20 --warmup 2 --no-cpu-baseline >> $O/bench.jsonl 2>> $O/bench.err
 python bench.py --workload fingerprint > $O/fingerprint_bench.jsonl 2> $O/fingerprint_bench.err
+python bench.py --workload morgan --n-corpus 800000 > $O/morgan_bench.jsonl 2> $O/morgan_bench.err
+TRX_NO_FP4=1 python bench.py --workload morgan --n-corpus 800000 --no-cpu-baseline >> $O/morgan_bench.jsonl 2>> $O/morgan_bench.err
+python tools/bigk_probe.py 1000000 16384 > $O/bigk_probe.jsonl 2> $O/bigk_probe.err
 TRX_BENCH_BACKEND=gloo TRX_BENCH_DEVICE=0 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29655 bench.py --gpus 8 --weak --steps 3 --warmup 1 > $O/c2_rehearsal_bench.jsonl 2> $O/c2_rehearsal_bench.err
 bash profiles/run_profile.sh $TAG > $O/run_profile.log 2>&1
 python bench_predictor.py > $O/predictor_bench.jsonl 2> $O/predictor_bench.err
