@@ -409,10 +409,10 @@ def test_dense_producer_feeds_the_flat_index_on_device(tmp_path):
     assert float((corpus[:64].float() - ref).abs().max()) <= 5e-2 * max(1.0, float(ref.abs().max()))
 
 
-def test_packed_projection_weights_of_the_inference_path_follow_the_parameters(monkeypatch):
-    """ops.linear_multi keeps the packed bf16 query / key / value weight of a layer between the batches of an encode and
-    drops it when a parameter changes in place (an optimiser step between two refreshes); the embeddings are those of the
-    concatenate-every-call form, bit for bit, before and after"""
+def test_packed_projection_weights_live_for_one_encode_call_only(monkeypatch):
+    """inside dense.encode, ops.linear_multi keeps the packed bf16 query / key / value weight of a layer between the batches;
+    nothing survives the call -- a fused optimizer updates parameters WITHOUT moving their autograd version, so no cache may
+    outlive the block that vouches for them -- and the embeddings are those of the concatenate-every-call form, bit for bit"""
     from textreact_amd import dense
     cfg = Config(vocab_size=500, num_hidden_layers=2, max_position_embeddings=64)
     torch.manual_seed(0)
@@ -420,17 +420,23 @@ def test_packed_projection_weights_of_the_inference_path_follow_the_parameters(m
     g = torch.Generator().manual_seed(3)
     ids = torch.randint(1, 500, (300, 40), generator=g).cuda(); am = torch.ones_like(ids); am[::3, 17:] = 0
     lens = am.sum(dim=1)
-    a = dense.encode(enc, ids, am, lengths=lens)
+    built = []
+    real_cat = torch.cat
+    monkeypatch.setattr(torch, "cat", lambda ts, *a, **k: (built.append(len(ts)), real_cat(ts, *a, **k))[1])
+    a = dense.encode(enc, ids, am, lengths=lens, batch_tokens=2048)          # several batches
+    assert built.count(3) == 2 * 2 and ops._packed_cache is None             # (weights + biases) x 2 layers, once; nothing left behind
+    opt = torch.optim.AdamW(enc.parameters(), lr=0.05, fused=True)
+    for p_ in enc.parameters():
+        p_.grad = torch.ones_like(p_)
     w = enc.encoder.encoder.layer[0].attention.self.query.weight
-    assert "_trx_packed" in w.__dict__
-    with torch.no_grad():
-        enc.encoder.encoder.layer[0].attention.self.key.bias.add_(0.5)
-        enc.encoder.encoder.layer[1].attention.self.value.weight.mul_(1.25)
-    b = dense.encode(enc, ids, am, lengths=lens)
-    assert not torch.equal(a, b)
+    v0 = w._version
+    opt.step()
+    b = dense.encode(enc, ids, am, lengths=lens, batch_tokens=2048)
+    assert not torch.equal(a, b)                                              # the update is seen (whatever _version says: w._version - v0 may be 0)
+    monkeypatch.setattr(torch, "cat", real_cat)
     plain = lambda x, ws, bs=None: ops.linear(x, torch.cat(list(ws)), None if bs is None else torch.cat(list(bs)))
     monkeypatch.setattr(ops, "linear_multi", plain)
-    c = dense.encode(enc, ids, am, lengths=lens)
+    c = dense.encode(enc, ids, am, lengths=lens, batch_tokens=2048)
     assert torch.equal(b, c)
 
 

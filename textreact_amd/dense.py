@@ -90,8 +90,9 @@ def encode(model, input_ids, attention_mask=None, batch_size=256, out_dtype=torc
     # ONE autocast block around all batches: its cache holds the bf16 casts of the weights, so they are made once per call
     # and not once per batch (~75 cast launches and half a gigabyte of traffic a batch for BERT-base)
     ctx = torch.autocast("cuda", dtype=torch.bfloat16) if (autocast and dev.type == "cuda") else contextlib.nullcontext()
+    from .predictor import ops
     try:
-        with ctx:
+        with ctx, ops.packed_projections():      # (the packed bf16 q / k / v weight of a layer: made once per call, like the casts)
             for lo, hi, width in bounds:
                 if order is None:
                     ids = input_ids[lo:hi].to(dev)

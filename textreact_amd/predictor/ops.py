@@ -796,6 +796,26 @@ class _LinearWgrad(torch.autograd.Function):
         return (dx, None, *grads)
 
 
+_packed_cache = None
+
+
+class packed_projections:
+    """with ops.packed_projections(): ... -- for the duration, `linear_multi` under no_grad + bf16 autocast keeps the packed bf16
+    weights it builds (one per group of parameters) instead of rebuilding them at every call.  The caller vouches that the
+    parameters do not change inside the block (dense.encode: one inference pass over a corpus).  Deliberately not keyed on
+    the parameters' autograd version: fused optimizers update parameters without moving it (WeightShadows.refresh)."""
+
+    def __enter__(self):
+        global _packed_cache
+        self._outer, _packed_cache = _packed_cache, ({} if _packed_cache is None else _packed_cache)
+        return self
+
+    def __exit__(self, *exc):
+        global _packed_cache
+        _packed_cache = self._outer
+        return False
+
+
 def linear_multi(x, weights, biases=None):
     """F.linear(x, cat(weights), cat(biases)) for Linear layers that read the same input (query / key / value): one
     product, no concatenation of the fp32 parameters (see _LinearWgrad); falls back to the concatenation otherwise"""
@@ -803,19 +823,18 @@ def linear_multi(x, weights, biases=None):
     if (x.is_cuda and x.dtype == torch.bfloat16 and torch.is_grad_enabled() and w0.requires_grad
             and sum(w.shape[0] for w in weights) % 256 == 0 and w0.shape[1] % 256 == 0):
         return _LinearWgrad.apply(x, len(weights), *weights, *(biases if biases is not None else ()))
-    if (len(weights) > 1 and x.is_cuda and not torch.is_grad_enabled() and torch.is_autocast_enabled("cuda")
-            and torch.get_autocast_dtype("cuda") == torch.bfloat16):
-        # inference under bf16 autocast (dense.encode: ~1,000 batches through the same 12 layers): the packed bf16 weight is
-        # made once and kept on the first parameter until one of the parameters changes (in-place updates bump _version);
-        # concatenating the fp32 parameters and casting the result cost four launches and 20 us per layer and batch,
-        # 4 % of an encoder forward at 256 x ~74 tokens
-        ver = tuple(t._version for t in weights) + tuple(t._version for t in (biases or ())) + tuple(id(t) for t in weights[1:]) + (x.device,)
-        hit = w0.__dict__.get("_trx_packed")
-        if hit is None or hit[0] != ver:
+    if (_packed_cache is not None and len(weights) > 1 and x.is_cuda and not torch.is_grad_enabled()
+            and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16):
+        # inside `packed_projections()` (dense.encode: ~100 batches through the same 12 layers, the parameters fixed for the
+        # duration): the packed bf16 weight of a layer is made once; concatenating the fp32 parameters and casting the result
+        # cost four launches and 20 us per layer and batch, 4 % of an encoder forward at 256 x ~74 tokens
+        key = tuple(id(t) for t in weights) + tuple(id(t) for t in (biases or ()))
+        hit = _packed_cache.get(key)
+        if hit is None:
             w = torch.cat([t.detach() for t in weights]).to(torch.bfloat16)
             b = None if biases is None else torch.cat([t.detach() for t in biases]).to(torch.bfloat16)
-            hit = w0.__dict__["_trx_packed"] = (ver, w, b)
-        return torch.nn.functional.linear(x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16), hit[1], hit[2])
+            hit = _packed_cache[key] = (w, b, weights, biases)      # (the parameters themselves: their ids stay theirs while the cache lives)
+        return torch.nn.functional.linear(x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16), hit[0], hit[1])
     w = w0 if len(weights) == 1 else torch.cat(list(weights))
     b = None if biases is None else (biases[0] if len(biases) == 1 else torch.cat(list(biases)))
     return linear(x, w, b)

@@ -24,17 +24,24 @@ def run(name, make, step_fn, steps=3):
             p = make(backend).to(dev).train()
             opt = torch.optim.AdamW(p.parameters(), lr=1e-4, fused=True)
             scaler = torch.amp.GradScaler("cuda")
-            losses = []
+            losses, scales = [], []
             for _ in range(steps):
                 with torch.autocast("cuda", dtype=torch.float16):
                     loss = step_fn(p)
                 scaler.scale(loss).backward()
                 scaler.step(opt); scaler.update(); opt.zero_grad(set_to_none=True)
-                losses.append(float(loss))
+                losses.append(float(loss)); scales.append(scaler.get_scale())
             assert all(l == l and abs(l) < 1e4 for l in losses), (name, backend, losses)
-            out[backend] = (losses, p)
-    print(name, "hip", [round(l, 4) for l in out["hip"][0]], "torch", [round(l, 4) for l in out["torch"][0]], flush=True)
-    for a, c in zip(out["hip"][0], out["torch"][0]):      # the trajectories must agree step by step (stale weights, a wrong gradient ... show here)
+            out[backend] = (losses, p, scales)
+    print(name, "hip", [round(l, 4) for l in out["hip"][0]], "torch", [round(l, 4) for l in out["torch"][0]],
+          "loss scales", out["hip"][2], out["torch"][2], flush=True)
+    # the trajectories must agree step by step (stale weights, a wrong gradient ... show here) -- as long as the two GradScalers
+    # took the same decisions: the HIP ops carry fp16-autocast activations and gradients in bf16, which does not overflow where
+    # fp16 does, so the PyTorch statement may skip a step (and halve its scale) that the HIP run takes
+    for i, (a, c) in enumerate(zip(out["hip"][0], out["torch"][0])):
+        if i > 0 and out["hip"][2][:i] != out["torch"][2][:i]:
+            print(name, "  (the loss scalers part ways at step %d: later losses are not compared)" % i, flush=True)
+            break
         assert abs(a - c) <= 5e-3 * max(1.0, abs(c)), (name, out["hip"][0], out["torch"][0])
     return out
 
