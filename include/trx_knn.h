@@ -98,7 +98,9 @@ int trx_index_reset(trx_index* idx);
 void trx_index_destroy(trx_index* idx);
 
 /* distance, rank = index.search(q, k)  [retrieve_faiss.py:70-71]: HOST in, HOST out.
- * D: float[nq*k], I: int64[nq*k], caller-allocated. */
+ * D: float[nq*k], I: int64[nq*k], caller-allocated.  Queries are taken in blocks of 65,536: the next block's copy to the
+ * device runs beside the current block's search; trx_index_last_stats afterwards covers all blocks.  dtype TRX_DTYPE_I8
+ * is accepted here and by trx_index_add (bytes over PCIe, widened on the device). */
 int trx_index_search(trx_index* idx, const void* q, int64_t nq, int dtype, int k, float* D,
                      int64_t* I);
 
