@@ -113,6 +113,9 @@ __global__ void classify_kernel(const RowStats* qs, int q_split, int idx_nonint,
     // negatives: Morgan bit vectors are 0 / 1) -- products and fp32 sums exact as in the bf16 form, 256 components per K-step
     const int i8 = (out[0] && idx_maxabs <= 127.f && qmax * (l2 ? 2.f : 1.f) <= 127.f) ? 1 : 0;
     out[1] = (out[0] && !idx_nonfp4 && !qs->nonfp4_any) ? 2 : i8;
+    // [2]: the keys of the candidates ARE their canonical scores (knn_select.hip re-scores nothing): the exact class, and for L2
+    // the query norms |x|^2 (fp32 sums of squares) exact as well -- dist = |x|^2 - key, every term an integer below 2^24
+    out[2] = (out[0] && (!l2 || (double)d * (double)qmax * (double)qmax < 16777216.0)) ? 1 : 0;
 }
 hipError_t launch_classify(const void* qstats, int q_split, int idx_nonint, float idx_maxabs, int Kp, int d, int l2, int idx_nonfp4, int* out, hipStream_t st) {
     hipLaunchKernelGGL(classify_kernel, dim3(1), dim3(1), 0, st, (const RowStats*)qstats, q_split, idx_nonint, idx_maxabs, Kp, d, l2, idx_nonfp4, out);

@@ -235,6 +235,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     float* xq = sel_xq[wv][half];
     double sc = 0.0, xx = 0.0;
     const bool vec_ok = (p.d % SLICE == 0) && ((p.ld_c * CE) % 16 == 0);
+    // integer inputs whose keys are exact (classify_kernel, flag [2]): the key of a candidate IS its canonical score -- x.y, or
+    // |x|^2 - dist with every term an integer below 2^24, the value the fp64 fma chain arrives at as well -- so no row is
+    // fetched (32 rows of 2 - 4 KB per query: 0.45 of the 0.66 ms this kernel took per 65,536 fingerprint queries)
+    const bool keys_are_scores = p.exact_class[2] != 0 && TRX_SEL_ABL == 0;
+    if (keys_are_scores) {
+        if (have) { const double key = (double)comp_key(v); sc = L2 ? (double)p.qnorm2[q] - key : key; }
+    } else
 #if TRX_SEL_ABL == 1
     if (0) {
 #else
