@@ -821,7 +821,8 @@ int trx_index_search(trx_index* idx, const void* q, int64_t nq, int dtype, int k
     int rc = set_device(idx); if (rc) return rc;
     // Host arrays in, host arrays out (the FAISS protocol as retrieve_faiss.py:71 calls it), in blocks of 65,536 queries: block
     // c is searched (enqueued, stream-ordered) while block c + 1 crosses PCIe on a stream of its own -- the search of a block
-    // of 1024-d fingerprints takes 16 ms and its 268 MB of float32 longer than that to arrive --, then c's results go back.
+    // of 1024-d fingerprints takes 16 ms and its 268 MB of float32 longer than that to arrive --, and the results of block c go
+    // back while block c + 1 is searched (two result buffers).
     // int8 queries travel as bytes and are widened to bf16 on the device.
     constexpr int64_t BLOCK = 65536;
     const size_t esz = dtype == TRX_DTYPE_F32 ? 4 : dtype == TRX_DTYPE_BF16 ? 2 : 1;
@@ -829,41 +830,45 @@ int trx_index_search(trx_index* idx, const void* q, int64_t nq, int dtype, int k
     const size_t qb = (size_t)round_up64((int64_t)((size_t)rows * idx->d * esz), 256);
     const size_t wb = dtype == TRX_DTYPE_I8 ? (size_t)round_up64((int64_t)((size_t)rows * idx->d * 2), 256) : 0;
     const size_t db = (size_t)round_up64((int64_t)((size_t)rows * k * sizeof(float)), 256), ib = (size_t)rows * k * sizeof(int64_t);
-    if ((rc = idx->w_io.reserve(2 * qb + wb + db + ib))) return rc;
+    if ((rc = idx->w_io.reserve(2 * qb + wb + 2 * (db + ib)))) return rc;
     char* base = (char*)idx->w_io.p;
     char* stage[2] = {base, base + qb};
     char* wide = base + 2 * qb;
-    float* Dd = (float*)(base + 2 * qb + wb);
-    int64_t* Id = (int64_t*)(base + 2 * qb + wb + db);
+    float* Dd[2]; int64_t* Id[2];
+    for (int i = 0; i < 2; ++i) { Dd[i] = (float*)(base + 2 * qb + wb + i * (db + ib)); Id[i] = (int64_t*)((char*)Dd[i] + db); }
     if (!idx->copy_stream) HIPCHK(hipStreamCreateWithFlags(&idx->copy_stream, hipStreamNonBlocking));
     const char* qh = (const char*)q;
     trx_search_stats acc{};
-    HIPCHK(hipMemcpy(stage[0], qh, (size_t)rows * idx->d * esz, hipMemcpyHostToDevice));
-    int blk = 0;
-    for (int64_t q0 = 0; q0 < nq; q0 += BLOCK, ++blk) {
-        const int64_t m = std::min<int64_t>(BLOCK, nq - q0);
-        const void* qd = stage[blk & 1];
+    const int64_t nblk = (nq + BLOCK - 1) / BLOCK;
+    auto rows_of = [&](int64_t c) { return std::min<int64_t>(BLOCK, nq - c * BLOCK); };
+    auto begin = [&](int64_t c) -> int {      // enqueue the search of block c (its queries are in stage[c & 1]) into result set c & 1
+        const void* qd = stage[c & 1];
         int qdt = dtype;
         if (dtype == TRX_DTYPE_I8) {
-            HIPCHK(launch_widen_i8((const signed char*)qd, m, idx->d, (bf16_t*)wide, nullptr));
+            HIPCHK(launch_widen_i8((const signed char*)qd, rows_of(c), idx->d, (bf16_t*)wide, nullptr));
             qd = wide; qdt = TRX_DTYPE_BF16;
         }
-        rc = search_device_impl(idx, qd, m, qdt, k, Dd, Id, nullptr, nullptr);
-        if (rc) return rc;
-        if (q0 + BLOCK < nq) {      // the next block's copy, while this one is being searched
-            const int64_t m2 = std::min<int64_t>(BLOCK, nq - q0 - BLOCK);
-            HIPCHK(hipMemcpyAsync(stage[(blk + 1) & 1], qh + (size_t)(q0 + BLOCK) * idx->d * esz, (size_t)m2 * idx->d * esz,
+        return search_device_impl(idx, qd, rows_of(c), qdt, k, Dd[c & 1], Id[c & 1], nullptr, nullptr);
+    };
+    HIPCHK(hipMemcpy(stage[0], qh, (size_t)rows * idx->d * esz, hipMemcpyHostToDevice));
+    if ((rc = begin(0))) return rc;
+    for (int64_t c = 0; c < nblk; ++c) {
+        const int64_t m = rows_of(c);
+        if (c + 1 < nblk) {      // the next block's queries cross PCIe while this block is being searched
+            HIPCHK(hipMemcpyAsync(stage[(c + 1) & 1], qh + (size_t)(c + 1) * BLOCK * idx->d * esz, (size_t)rows_of(c + 1) * idx->d * esz,
                                   hipMemcpyHostToDevice, idx->copy_stream));
             HIPCHK(hipStreamSynchronize(idx->copy_stream));
         }
         rc = trx_index_search_finish(idx); if (rc) return rc;
-        HIPCHK(hipMemcpy(D + q0 * k, Dd, (size_t)m * k * sizeof(float), hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(I + q0 * k, Id, (size_t)m * k * sizeof(int64_t), hipMemcpyDeviceToHost));
-        const trx_search_stats& s1 = idx->stats;
+        const trx_search_stats s1 = idx->stats;
         acc.nq += s1.nq; acc.n_uncertified += s1.n_uncertified; acc.n_rescored += s1.n_rescored; acc.n_rescanned += s1.n_rescanned;
         acc.scan_launches += s1.scan_launches; acc.scan_ms += s1.scan_ms; acc.total_ms += s1.total_ms;
         acc.late_fallback |= s1.late_fallback;
         acc.n_splits = s1.n_splits; acc.k_split = s1.k_split; acc.exact_class = s1.exact_class; acc.int8_scan = s1.int8_scan;
+        if (c + 1 < nblk && (rc = begin(c + 1))) return rc;      // ... and this block's results go back while the next one is searched
+        HIPCHK(hipMemcpyAsync(D + c * BLOCK * k, Dd[c & 1], (size_t)m * k * sizeof(float), hipMemcpyDeviceToHost, idx->copy_stream));
+        HIPCHK(hipMemcpyAsync(I + c * BLOCK * k, Id[c & 1], (size_t)m * k * sizeof(int64_t), hipMemcpyDeviceToHost, idx->copy_stream));
+        HIPCHK(hipStreamSynchronize(idx->copy_stream));
     }
     idx->stats = acc;
     return TRX_OK;
