@@ -573,6 +573,37 @@ def test_c1_full_size_properties():
         del idx
 
 
+def test_bit_vectors_at_size_through_the_fp4_form():
+    """retrieve/retro.sh at USPTO-full scale: 500,000 x 1024 Morgan-like bit vectors, the first 70,000 searching the set (two
+    query batches), L2, k = 20, on fp4 operands -- every row finds itself at distance 0, results are sorted, idempotent, equal
+    to the int8 form's, and 64 sampled queries equal the oracle over the FULL corpus bit for bit"""
+    import torch
+    import textreact_amd.faiss_compat as faiss
+    from oracle import flat_knn as oracle
+    n, d, nq, k = 500_000, 1024, 70_000, 20
+    g = torch.Generator(device="cuda"); g.manual_seed(11)
+    y = (torch.rand((n, d), generator=g, device="cuda") < 0.05).to(torch.bfloat16)
+    idx = faiss.IndexFlatL2(d); idx.add(y)
+    D, I = idx.search(y[:nq], k)
+    st = idx.last_stats()
+    assert st["int8_scan"] == 2 and st["exact_class"] == 1 and st["n_uncertified"] == 0, st
+    Dh, Ih = D.cpu().numpy(), I.cpu().numpy()
+    assert (Dh[:, 0] == 0).all() and (np.diff(Dh, axis=1) >= 0).all() and (Ih >= 0).all() and (Ih < n).all()
+    assert (Ih[:, 0] <= np.arange(nq)).all()                      # self, or an identical row with a smaller number
+    D2, I2 = idx.search(y[:nq], k)
+    assert torch.equal(I, I2) and torch.equal(D, D2)
+    os.environ["TRX_NO_FP4"] = "1"
+    try:
+        D8, I8 = idx.search(y[:nq], k)
+        assert idx.last_stats()["int8_scan"] == 1
+    finally:
+        del os.environ["TRX_NO_FP4"]
+    assert torch.equal(I, I8) and torch.equal(D, D8)
+    sel = np.r_[0:8, 65530:65546, np.random.default_rng(0).integers(0, nq, 40)]
+    Dr, Ir = oracle.knn_canonical(L2, y[torch.from_numpy(sel).cuda()].float().cpu().numpy(), y.float().cpu().numpy(), k)
+    assert np.array_equal(Ih[sel], Ir) and np.array_equal(Dh[sel].view(np.uint32), Dr.view(np.uint32))
+
+
 def test_more_than_one_query_batch_and_many_splits():
     # 70,000 queries -> two internal batches (65,536 + 4,464); small corpus -> many corpus splits
     import torch
