@@ -254,6 +254,66 @@ def fingerprint_workload(args, dev, local_rank):
     print(json.dumps(line))
 
 
+SCAN_SOURCES = ("textreact_amd/csrc/knn_scan.hip", "textreact_amd/csrc/knn_common.h")
+
+
+def scan_source_sha256(root=ROOT):
+    """sha256 over the sources the scan kernel is compiled from.  profiles/summarize.py stores it beside the PMC figures
+    (the GPU box has no .git, so a commit id cannot be checked there; the text of the kernel can)."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in SCAN_SOURCES:
+        with open(os.path.join(root, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def committed_traffic(root=ROOT):
+    """roofline.traffic: L2-miss bytes per scan launch from the separate --pmc passes of profiles/run_profile.sh, a committed
+    constant -- reported ONLY when it was measured on the kernel text this run compiled from; otherwise null, and the
+    source field says why."""
+    tf = os.path.join(root, "profiles", "traffic.json")
+    try:
+        tj = json.load(open(tf))
+    except Exception:
+        return None, None
+    want = tj.get("scan_source_sha256")
+    if want is None or want != scan_source_sha256(root):
+        return None, "profiles/traffic.json@%s is STALE for this knn_scan.hip / knn_common.h (source hash differs): traffic not reported" % tj.get("git_sha", "unknown")
+    return tj.get("hbm_bytes_per_launch"), "profiles/traffic.json@%s (same scan-kernel source as this run; kernel trace %.2f ms per launch there)" % (
+        tj.get("git_sha", "unknown"), tj.get("avg_launch_ms_kernel_trace") or float("nan"))
+
+
+def launch_or_refuse(args):
+    """--gpus N must be what runs.  Decided before anything of this process touches the GPU (no torch import yet):
+      * WORLD_SIZE set (a launcher started us) and != --gpus: exit 2 -- a line that says n_gpus = WORLD_SIZE under a command
+        that says --gpus N is a mis-measurement, not a warning;
+      * WORLD_SIZE unset and --gpus N > 1: this process becomes the launcher's parent -- it starts
+        `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same
+        arguments>` as a CHILD process (never exec), relays its output (rank 0's JSON line) and exits with its code."""
+    ws = os.environ.get("WORLD_SIZE")
+    if ws is not None:
+        if int(ws) != args.gpus:
+            sys.stderr.write("bench.py: --gpus %d but the launcher set WORLD_SIZE=%s; refusing to measure a different job than "
+                             "the command names\n" % (args.gpus, ws))
+            sys.exit(2)
+        return
+    if args.gpus <= 1:
+        return
+    import socket
+    import subprocess
+    port = os.environ.get("TRX_BENCH_MASTER_PORT")
+    if port is None:
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            port = s_.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write("bench.py: --gpus %d without a launcher: starting %s\n" % (args.gpus, " ".join(cmd)))
+    sys.stderr.flush()
+    sys.exit(subprocess.run(cmd).returncode)      # the child inherits stdout / stderr: rank 0's JSON line goes straight through
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -275,6 +335,7 @@ def main():
                     help="dense = the headline (BASELINE.json configs[1]); fingerprint = the reference's own call: "
                          "IndexFlatL2, k=20, 2048-d integer reaction fingerprints, train set searching itself (not the headline)")
     args = ap.parse_args()
+    launch_or_refuse(args)
 
     import torch
     import torch.distributed as dist
@@ -295,8 +356,6 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-    if args.gpus != world and rank == 0 and world > 1:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
 
     import textreact_amd.faiss_compat as faiss
     from textreact_amd.sharded import ShardedFlatIndex, shard_bounds
@@ -397,17 +456,8 @@ def main():
         alg_bytes = 2.0 * ((hi - lo) * d + queries.shape[0] * d) + 8.0 * queries.shape[0] * k
         hbm_gbs = alg_bytes / (mean_launch_ms * 1e-3) / 1e9 if mean_launch_ms > 0 else 0.0
         traffic, traffic_source = None, None
-        tf = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tf) and world == 1 and n == N_CORPUS and nq == N_QUERIES:   # measured for exactly this launch
-            try:
-                tj = json.load(open(tf))
-                traffic = tj.get("hbm_bytes_per_launch")
-                # a constant from separate --pmc passes (profiles/run_profile.sh): say which commit it was taken at, and
-                # at what launch time, so that a stale one shows
-                traffic_source = "profiles/traffic.json@%s (kernel trace %.2f ms per launch there)" % (
-                    tj.get("git_sha", "unknown"), tj.get("avg_launch_ms_kernel_trace") or float("nan"))
-            except Exception:
-                traffic = None
+        if world == 1 and n == N_CORPUS and nq == N_QUERIES:   # measured for exactly this launch
+            traffic, traffic_source = committed_traffic()
         line = {
             "metric": "queries/sec top-10 over 1Mx768 corpus", "value": value, "unit": "queries/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,

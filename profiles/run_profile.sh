@@ -5,6 +5,10 @@ TAG=${1:-r01}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
+# what was measured: the text of the sources of this snapshot (the box has no .git); profiles/summarize.py refuses to write
+# the committed summaries unless these are the files HEAD holds
+(cd $R && sha256sum textreact_amd/csrc/knn_scan.hip textreact_amd/csrc/knn_common.h textreact_amd/csrc/knn_api.hip \
+   textreact_amd/csrc/knn_select.hip textreact_amd/csrc/knn_prep.hip bench.py) > $OUT/source.sha256
 cd /tmp && export TMPDIR=/tmp
 CMD="python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1

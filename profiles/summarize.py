@@ -10,6 +10,28 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "prof_" + tag)
 stats = sorted(glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime, reverse=True)      # gpurun MERGES into gpurun_out/: take the newest run's file
 assert stats, "no kernel_stats.csv under " + src
+
+
+def head_is_what_was_profiled():
+    """The summaries name a commit.  Refuse unless (1) the tracked sources are clean against HEAD and (2) every file the GPU
+    box hashed when it took the profile (source.sha256, written by run_profile.sh) has the same hash in HEAD -- so
+    traffic.json / <tag>_kernel_stats.csv can never describe another binary than the commit they cite."""
+    import hashlib, subprocess
+    dirty = subprocess.check_output(["git", "-C", root, "status", "--porcelain", "--", "textreact_amd", "bench.py"]).decode().strip()
+    if dirty:
+        sys.exit("summarize.py: uncommitted changes under textreact_amd/ or bench.py:\n%s\ncommit first, then profile, then summarize" % dirty)
+    f = os.path.join(src, "source.sha256")
+    if not os.path.exists(f):
+        sys.exit("summarize.py: %s missing (taken with an old run_profile.sh?)" % f)
+    for line in open(f):
+        want, rel = line.split()
+        blob = subprocess.check_output(["git", "-C", root, "show", "HEAD:" + rel])
+        if hashlib.sha256(blob).hexdigest() != want:
+            sys.exit("summarize.py: %s changed between the profile run and HEAD; re-take the profile" % rel)
+    return subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"]).decode().strip()
+
+
+sha = head_is_what_was_profiled()
 shutil.copy(stats[0], os.path.join(root, "profiles", tag + "_kernel_stats.csv"))
 
 
@@ -40,13 +62,11 @@ fetch, _ = counters("pmc_fetch")
 write, _ = counters("pmc_write")
 sq, _ = counters("pmc_sq")
 fetch_kb, write_kb = fetch.get("FETCH_SIZE"), write.get("WRITE_SIZE")
-try:
-    import subprocess
-    sha = sys.argv[2] if len(sys.argv) > 2 else subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"]).decode().strip()
-except Exception:
-    sha = "unknown"
+sys.path.insert(0, root)
+from bench import scan_source_sha256
 out = {
     "git_sha": sha,
+    "scan_source_sha256": scan_source_sha256(root),      # bench.py reports the traffic only for this kernel text
     "command": "python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline (profiles/run_profile.sh %s: one rocprofv3 pass for "
                "--kernel-trace --stats, one --pmc pass per counter group)" % tag,
     "kernel": kname, "avg_launch_ms_kernel_trace": avg_ms, "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb,

@@ -70,6 +70,25 @@ def test_two_ranks_as_the_driver_launches_it(mode):
     assert bool(mode) or j["config"]["selfcheck"].startswith("passed")      # the row-sharded line checks itself before it times
 
 
+def test_gpus_2_without_a_launcher_measures_two_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (the shape of the driver's N = 1 command) must not print an
+    n_gpus = 1 line: bench.py starts the two ranks itself as a child process and relays rank 0's line"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(TRX_BENCH_BACKEND="gloo", TRX_BENCH_DEVICE="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL, capture_output=True, text=True,
+                       timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _line(r.stdout)
+    assert j["n_gpus"] == 2 and j["config"]["selfcheck"].startswith("passed")
+
+
+def test_gpus_that_disagree_with_world_size_exit_non_zero():
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0", TRX_BENCH_BACKEND="gloo", TRX_BENCH_DEVICE="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL, capture_output=True, text=True,
+                       timeout=300, env=env)
+    assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
 def test_selfcheck_turns_a_wrong_exchange_into_a_failing_exit_code():
     """a rank that reports its rows under the wrong ids (TRX_BENCH_INJECT_FAULT=offset) must not produce a bench line"""
     with socket.socket() as s_:

@@ -150,10 +150,21 @@ def _dist_setup():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world <= 1:
         return 0, 1
+    import torch
     import torch.distributed as dist
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(os.environ.get("TRX_DIST_BACKEND", "nccl"))
+        backend = os.environ.get("TRX_DIST_BACKEND", "nccl")
+        # this rank's GPU is the current device BEFORE the group exists: with the nccl backend the object collectives
+        # (broadcast_object_list of the val / test fingerprints) put their tensors on torch.cuda.current_device(), which
+        # would be cuda:0 on every rank -- RCCL refuses two ranks on one device
+        ordinal = int(os.environ.get("TRX_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        if torch.cuda.is_available():
+            torch.cuda.set_device(ordinal)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", ordinal))
+        else:
+            dist.init_process_group(backend)
     return dist.get_rank(), dist.get_world_size()
 
 
