@@ -129,6 +129,30 @@ int trx_index_search_finish(trx_index* idx);
 int trx_merge_topk_device(int metric, int nlists, int64_t nq, int k, const double* S_lists,
                           const int64_t* I_lists, float* D, int64_t* I, void* stream);
 
+/* The same merge, and additionally the merged fp64 scores S[nq*k] (may be null): what trx_faiss_tie_order_device reads. */
+int trx_merge_topk_device_s64(int metric, int nlists, int64_t nq, int k, const double* S_lists,
+                              const int64_t* I_lists, float* D, int64_t* I, double* S, void* stream);
+
+/* Order among EXACT score ties.  TRX_TIES_BY_ID (default): the total order above -- score best first, then id ascending,
+ * both metrics.  TRX_TIES_FAISS: what faiss.IndexFlatIP / IndexFlatL2 [retrieve_faiss.py:65, :71] return.  For L2 that IS
+ * the total order (FAISS' max-heap ordered by (distance, id) with strict admission keeps the k smallest (distance, id));
+ * for the inner product FAISS' min-heap gives another deterministic answer -- of the rows tied at the k-th score, those
+ * admitted while the heap was not yet full minus the smallest ids evicted by better rows that arrived later, and the output
+ * ordered (score descending, id DESCENDING) -- which this mode reproduces exactly (closed form in knn_select.hip:
+ * faiss_tie_kernel; checked against the heap replay of oracle/flat_knn_ref.c).  Ties are ties of the canonical fp64 score:
+ * duplicates and exact-arithmetic inputs (integer fingerprints, the 2^-3 grid); on inputs whose fp32 sums round, FAISS'
+ * own near-tie order depends on its BLAS and is not defined by FAISS either.  Cost: an inner-product search runs for the
+ * canonical top 2k (k <= 1024).  Set before searching; not while a search is in flight. */
+enum { TRX_TIES_BY_ID = 0, TRX_TIES_FAISS = 1 };
+int trx_index_set_tie_rule(trx_index* idx, int rule);
+
+/* The FAISS order from a canonical list: S2 / I2 [nq][k2] hold each query's canonical top k2 >= 2k (fp64 scores best first,
+ * ids ascending among equal scores, pads I = -1 last) of an INNER-PRODUCT search, DEVICE memory; writes FAISS' top k to
+ * D / I [nq][k].  The row-sharded search applies it after its merge (trx_merge_topk_device_s64 at k2), so that a sharded
+ * index answers as one FAISS index over all rows would. */
+int trx_faiss_tie_order_device(int64_t nq, int k2, int k, const double* S2, const int64_t* I2, float* D, int64_t* I,
+                               void* stream);
+
 /* Counters of the most recent search on this index (all zero before the first one). */
 typedef struct trx_search_stats {
     int64_t nq;            /* queries in the call */

@@ -81,6 +81,80 @@ def test_grid_ties(metric):
     _check(metric, grid(300, 128, 2), grid(9000, 128, 1), 10)
 
 
+def _tie_inputs():
+    """inner-product inputs with exact score ties, every fp32 partial sum exact (so the literal FAISS restatement's fp32
+    scores ARE the scores): the 2^-3 grid at small d (ties everywhere), integer counts, bit vectors, and Gaussian rows
+    repeated in blocks that straddle the k-th place (identical rows score identically in any arithmetic)"""
+    yg, xg = grid(9000, 24, 41), grid(300, 24, 42)
+    yg[4000:4040] = yg[7]; yg[8000:8013] = yg[7]; xg[0] = yg[7]; xg[1] = yg[4001]
+    yield "grid", xg, yg, True
+    yc = reaction_fp_like(6000, 512, 43, density=0.01); yc[100:160] = yc[5]
+    yield "counts", yc[:200].copy(), yc, True
+    ym = morgan_like(5000, 256, 44)
+    yield "bits", ym[:150].copy(), ym, True
+    yd = bf16_round(gaussian(6000, 64, 45))
+    yd[1000:1017] = yd[2]; yd[3000:3009] = yd[2]; yd[5990:6000] = yd[2]
+    xd = bf16_round(gaussian(100, 64, 46)); xd[0] = yd[2]; xd[1] = -yd[2]
+    yield "duplicates", xd, yd, False
+
+
+@pytest.mark.parametrize("k", [1, 3, 10, 12, 20])
+def test_faiss_tie_rule_for_the_inner_product(k):
+    """TRX_TIES_FAISS: on inputs with exact score ties the HIP index returns what faiss.IndexFlatIP's heap returns -- I and D of
+    the literal restatement (oracle.knn_faiss: blocks, strict admission, (score, id) min-heap, heap_reorder) -- where the
+    default rule returns (score desc, id asc); L2 is unaffected by the rule (FAISS' max-heap IS the total order)"""
+    import textreact_amd.faiss_compat as faiss
+    from oracle import flat_knn as oracle
+    told_apart = 0
+    for name, x, y, exact in _tie_inputs():
+        idx = faiss.IndexFlatIP(y.shape[1], tie_rule="faiss")
+        idx.add(y[:len(y) // 2]); idx.add(y[len(y) // 2:])
+        D, I = idx.search(x, k)
+        Df, If = oracle.knn_faiss(IP, x, y, k)
+        Dc, Ic = oracle.knn_canonical(IP, x, y, k)
+        if exact:
+            assert np.array_equal(I, If), (name, k, np.argwhere(I != If)[:3].tolist())
+            assert np.array_equal(D.view(np.uint32), Df.view(np.uint32)), (name, k)
+        else:       # Gaussian rows: only the duplicated block ties exactly; compare the queries that look at it
+            assert np.array_equal(I[:2], If[:2]) and np.array_equal(np.sort(I, 1), np.sort(Ic, 1)), (name, k)
+        told_apart += int(not np.array_equal(If, Ic))
+        idx.set_tie_rule("id")
+        D, I = idx.search(x, k)
+        assert np.array_equal(I, Ic) and np.array_equal(D.view(np.uint32), Dc.view(np.uint32)), (name, k)
+        l2 = faiss.IndexFlatL2(y.shape[1], tie_rule="faiss"); l2.add(y)
+        D, I = l2.search(x, k)
+        Df, If = oracle.knn_faiss(L2, x, y, k) if exact else oracle.knn_canonical(L2, x, y, k)
+        assert np.array_equal(I, If) and np.array_equal(D.view(np.uint32), Df.view(np.uint32)), (name, k, "L2")
+    assert told_apart >= (2 if k > 1 else 1)       # (k = 1: the set is what differs, not the order -- the first-seen row wins)
+
+
+def test_faiss_tie_rule_edges(monkeypatch):
+    """fewer rows than k (pads behind, ties still FAISS-ordered), a corpus of identical rows, torch tensors on the device, the
+    environment default, k beyond the rule's range"""
+    import torch
+    import textreact_amd.faiss_compat as faiss
+    from oracle import flat_knn as oracle
+    y = np.ones((6, 8), dtype=np.float32); x = np.ones((25, 8), dtype=np.float32)
+    monkeypatch.setenv("TRX_TIE_RULE", "faiss")
+    idx = faiss.IndexFlatIP(8); assert idx.tie_rule == "faiss"
+    monkeypatch.delenv("TRX_TIE_RULE")
+    idx.add(y)
+    for k in (4, 6, 9):
+        D, I = idx.search(x, k)
+        Df, If = oracle.knn_faiss(IP, x, y, k)
+        assert np.array_equal(I, If) and np.array_equal(D, Df), (k, I[0], If[0])
+    y2 = grid(3000, 16, 51); x2 = grid(70, 16, 52)
+    idx = faiss.IndexFlatIP(16, tie_rule="faiss"); idx.add(torch.from_numpy(y2).cuda())
+    D, I = idx.search(torch.from_numpy(x2).cuda(), 10)
+    Df, If = oracle.knn_faiss(IP, x2, y2, 10)
+    assert np.array_equal(I.cpu().numpy(), If) and np.array_equal(D.cpu().numpy(), Df)
+    D, I, S = idx.search_s64(torch.from_numpy(x2).cuda(), 10)
+    assert np.array_equal(I.cpu().numpy(), If) and np.array_equal(S.float().cpu().numpy(), Df)
+    with pytest.raises(AssertionError):
+        idx.search(x2, 1025)
+    assert faiss.IndexFlatIP(16).tie_rule == "id"
+
+
 def test_reaction_fingerprints_l2_k20():
     # the reference's own call: IndexFlatL2, k = 20, d = 2048 integer counts, train searches itself
     y = reaction_fp_like(6000, 2048, 7)
@@ -692,6 +766,16 @@ def _rank_worker(rank, world, port, ret):
         rep.add(torch.from_numpy(y).cuda())
         D, I = rep.search(torch.from_numpy(x).cuda(), 10)
         out[("replicas", metric)] = (D.cpu().numpy(), I.cpu().numpy())
+    # FAISS' own order among exact inner-product ties, through the shards: canonical top 2k per shard, merged, the rule once
+    import textreact_amd.faiss_compat as fc
+    from _data import grid as grid_
+    yt, xt = grid_(20003, 32, 31), grid_(200, 32, 32)
+    yt[7000:7030] = yt[3]; yt[15000:15025] = yt[3]; xt[0] = yt[3]
+    lo, hi = shard_bounds(len(yt), world, rank)
+    idx = ShardedFlatIndex(32, 0, local_index=fc.IndexFlatIP(32, tie_rule="faiss"))
+    idx.add_shard(torch.from_numpy(yt[lo:hi]).cuda(), lo, len(yt))
+    D, I = idx.search(torch.from_numpy(xt).cuda(), 10)
+    out["faiss_ties"] = (D.cpu().numpy(), I.cpu().numpy())
     ret[rank] = out
     dist.destroy_process_group()
 
@@ -718,6 +802,13 @@ def test_multi_rank_sharded_search_on_one_gpu(world):
         for r in range(world):
             D, I = ret[r][("k100", metric)]
             assert np.array_equal(I, Ir) and np.array_equal(D.view(np.uint32), Dr.view(np.uint32)), ("k100", metric, r)
+    yt, xt = grid(20003, 32, 31), grid(200, 32, 32)
+    yt[7000:7030] = yt[3]; yt[15000:15025] = yt[3]; xt[0] = yt[3]
+    Df, If = oracle.knn_faiss(IP, xt, yt, 10)
+    assert not np.array_equal(If, oracle.knn_canonical(IP, xt, yt, 10)[1])       # the input does tell the two rules apart
+    for r in range(world):
+        D, I = ret[r]["faiss_ties"]
+        assert np.array_equal(I, If) and np.array_equal(D.view(np.uint32), Df.view(np.uint32)), ("faiss_ties", r)
 
 
 def test_pad_queries_of_the_last_query_tile_cost_nothing():

@@ -70,8 +70,9 @@ def test_l2_faiss_restatement_equals_canonical_on_exact_inputs():
 
 
 def test_ip_faiss_restatement_tie_order_is_a_heap_artefact():
-    # equal scores: the min-heap keeps first-seen ids and emits larger ids first (documented
-    # divergence: the product uses (score desc, id asc)); the SETS agree when ties do not straddle k
+    # equal scores: the min-heap keeps first-seen ids and emits larger ids first; the product's DEFAULT rule is
+    # (score desc, id asc) and its TRX_TIES_FAISS mode returns the heap's answer (next test; tests/test_knn_gpu.py:
+    # test_faiss_tie_rule_for_the_inner_product); the SETS agree when ties do not straddle k
     y = np.ones((6, 4), dtype=np.float32)
     x = np.ones((25, 4), dtype=np.float32)
     Df, If = oracle.knn_faiss(IP, x, y, 6)
@@ -79,6 +80,56 @@ def test_ip_faiss_restatement_tie_order_is_a_heap_artefact():
     assert np.array_equal(np.sort(If, 1), np.sort(Ic, 1)) and np.array_equal(Df, Dc)
     assert Ic[0].tolist() == [0, 1, 2, 3, 4, 5]
     assert If[0].tolist() != Ic[0].tolist()
+
+
+def faiss_ip_order_from_canonical(Dc, Ic, k):
+    """The closed form the product's TRX_TIES_FAISS mode computes (knn_select.hip: faiss_tie_kernel), restated in numpy: from
+    the canonical top 2k (score desc, id asc) of an inner-product search, what FAISS' min-heap returns.  a = rows above the
+    k-th score, G = the rows tied at it (ids ascending); of G only the rows among the first k of (better u G) by id were
+    admitted (the heap was not yet full), each better row that came later evicted the smallest id among them, and
+    heap_reorder emits (score desc, id desc)."""
+    nq = Dc.shape[0]
+    D = np.full((nq, k), -np.finfo(np.float32).max, dtype=np.float32); I = np.full((nq, k), -1, dtype=np.int64)
+    for q in range(nq):
+        d, i = Dc[q], Ic[q]
+        nvalid = int((i >= 0).sum())
+        if nvalid <= k:
+            res = [(d[t], i[t]) for t in range(nvalid)]
+        else:
+            sk = d[k - 1]
+            a = int((d[:nvalid] > sk).sum())
+            better = [(d[t], i[t]) for t in range(a)]
+            tied = [i[t] for t in range(a, min(nvalid, a + k)) if d[t] == sk]
+            first_k = sorted([(idv, 1) for _, idv in better] + [(g, 0) for g in tied])[:k]
+            admitted = [idv for idv, is_better in first_k if not is_better]
+            res = better + [(sk, g) for g in admitted[len(admitted) - (k - a):]]
+        res.sort(key=lambda t: (-t[0], -t[1]))
+        D[q, :len(res)] = [t[0] for t in res]; I[q, :len(res)] = [t[1] for t in res]
+    return D, I
+
+
+def test_ip_tie_order_of_the_faiss_heap_has_a_closed_form():
+    """the divergence the test above documents is closed by a mode of the product (TRX_TIES_FAISS); this pins the rule that
+    mode computes against the heap replay of the literal restatement, on inputs with exact ties of every kind"""
+    rng = np.random.default_rng(0)
+    differ = 0
+    for trial in range(120):
+        n = int(rng.integers(5, 400)); d = int(rng.choice([4, 8, 16, 32])); k = int(rng.integers(1, 25)); nq = 20
+        if trial % 3 == 0:
+            y = rng.integers(-2, 3, (n, d)).astype(np.float32); x = rng.integers(-2, 3, (nq, d)).astype(np.float32)
+        elif trial % 3 == 1:      # Gaussian rows repeated: identical rows score identically
+            base = rng.standard_normal((max(2, n // 5), d)).astype(np.float32)
+            y = base[rng.integers(0, len(base), n)]; x = rng.standard_normal((nq, d)).astype(np.float32)
+        else:
+            y = grid(n, d, trial); x = grid(nq, d, trial + 1000)
+        Df, If = oracle.knn_faiss(IP, x, y, k)
+        Dc, Ic = oracle.knn_canonical(IP, x, y, 2 * k)
+        D2, I2 = faiss_ip_order_from_canonical(Dc, Ic, k)
+        assert np.array_equal(I2, If), (trial, n, d, k)
+        if trial % 3 != 1:
+            assert np.array_equal(D2, Df), (trial, n, d, k)
+        differ += int(not np.array_equal(If, Ic[:, :k]))
+    assert differ > 60
 
 
 @pytest.mark.parametrize("metric", [IP, L2])

@@ -9,6 +9,7 @@ _CSRC = os.path.join(_HERE, "csrc")
 _SO = os.path.join(_CSRC, os.environ.get("TRX_LIB", "libtrxknn.so"))  # TRX_LIB: diagnostic builds
 
 METRIC_IP, METRIC_L2 = 0, 1
+TIES_BY_ID, TIES_FAISS = 0, 1
 DTYPE_F32, DTYPE_BF16, DTYPE_I8 = 0, 1, 2
 MAX_K, FAST_MAX_K = 2048, 24
 
@@ -19,6 +20,7 @@ SYMBOLS = [
     "trx_index_search_device_s64", "trx_index_search_device_begin", "trx_index_search_finish",
     "trx_merge_topk_device", "trx_index_last_stats", "trx_search_stats_size",
     "trx_index_set_timing", "trx_last_error", "trx_version",
+    "trx_merge_topk_device_s64", "trx_index_set_tie_rule", "trx_faiss_tie_order_device",
 ]
 
 
@@ -77,6 +79,9 @@ def lib():
     L.trx_index_search_device_begin.argtypes = [vp, vp, i64, i32, i32, vp, vp, vp, vp]
     L.trx_index_search_finish.argtypes = [vp]
     L.trx_merge_topk_device.argtypes = [i32, i32, i64, i32, vp, vp, vp, vp, vp]
+    L.trx_merge_topk_device_s64.argtypes = [i32, i32, i64, i32, vp, vp, vp, vp, vp, vp]
+    L.trx_index_set_tie_rule.argtypes = [vp, i32]
+    L.trx_faiss_tie_order_device.argtypes = [i64, i32, i32, vp, vp, vp, vp, vp]
     L.trx_index_last_stats.argtypes = [vp, ctypes.POINTER(SearchStats)]
     L.trx_index_set_timing.argtypes = [vp, i32]
     L.trx_last_error.restype = ctypes.c_char_p

@@ -28,7 +28,8 @@ hipError_t launch_build_operand_i8(const void*, int, int64_t, int, int64_t, sign
 hipError_t launch_fill_bias_i32(const float*, int64_t, int64_t, int*, hipStream_t);
 hipError_t launch_slack(const float*, int64_t, int64_t, float, float, float, int, float*, hipStream_t);
 hipError_t launch_bigk_seeds(int, const float*, const int64_t*, int, int, int, const float*, float, float, float, int*, int*, float*, hipStream_t);
-hipError_t launch_merge(int, int, int64_t, int, const double*, const int64_t*, float*, int64_t*, hipStream_t);
+hipError_t launch_merge(int, int, int64_t, int, const double*, const int64_t*, float*, int64_t*, double*, hipStream_t);
+hipError_t launch_faiss_ties(int64_t, int, int, const double*, const int64_t*, float*, int64_t*, double*, hipStream_t);
 }  // namespace trx
 
 using namespace trx;
@@ -107,6 +108,8 @@ struct trx_index {
     int64_t c4_cap = 0, c4_rows = -1; int Kp4 = 0;
     // workspaces
     DevBuf w_stamp, w_stats, w_qnorm2, w_flag, w_exact, w_io, w_tmp, w_cls;      // (the big ones are shared: DevPool)
+    DevBuf w_tie;             // TRX_TIES_FAISS: the canonical top 2k (D, I, S) the FAISS order is derived from
+    int tie_rule = TRX_TIES_BY_ID;
     trx_search_stats stats{};
     bool timing = false;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -120,6 +123,8 @@ struct trx_index {
         int is_bf = 0, k = 0, corpus_is_bf16 = 0, no_fallback = 0, tried_i8 = 0, approx = 0; float eps_round = 0.f;
         const void* corpus_orig = nullptr; int64_t ld_c = 0;
         std::vector<PendingBatch> batches;
+        // TRX_TIES_FAISS: the search ran for k2 = 2k into w_tie; these are the caller's arrays the tie kernel fills
+        int tie_k = 0, tie_k2 = 0; int64_t tie_nq = 0; float* tie_D = nullptr; int64_t* tie_I = nullptr; double* tie_S = nullptr;
     } pend;
 
     // an even number of K-steps, at least 4: the scan kernel's loop handles two per iteration (LDS stage = K-step
@@ -679,13 +684,44 @@ static int finish_impl(trx_index* idx) {
                                      pd.corpus_orig, pd.ld_c, pb.q, idx->d, idx->d, pd.k, (double*)idx->w_exact.p, pb.D, pb.I, pb.S64, st));
         }
     }
+    if (late && pd.tie_k) {      // the FAISS order was derived from lists the late fall-back has just changed: derive it again
+        const float* D2 = (const float*)idx->w_tie.p; (void)D2;
+        const int64_t* I2 = (const int64_t*)((char*)idx->w_tie.p + (size_t)pd.tie_nq * pd.tie_k2 * sizeof(float));
+        const double* S2 = (const double*)((const char*)I2 + (size_t)pd.tie_nq * pd.tie_k2 * sizeof(int64_t));
+        HIPCHK(launch_faiss_ties(pd.tie_nq, pd.tie_k2, pd.tie_k, S2, I2, pd.tie_D, pd.tie_I, pd.tie_S, st));
+    }
     if (late) HIPCHK(hipStreamSynchronize(st));
     idx->stats.late_fallback = late ? 1 : 0;
     pd.batches.clear();
     return TRX_OK;
 }
 
+static int search_device_core(trx_index* idx, const void* q, int64_t nq, int dtype, int k, float* D,
+                              int64_t* I, double* S64, void* stream);
+
+// TRX_TIES_FAISS on an inner-product index: the search runs for k2 = 2k in the canonical order into a scratch of the index,
+// and faiss_tie_kernel (knn_select.hip) derives what FAISS' heap returns from it; everything else goes straight through.
 static int search_device_impl(trx_index* idx, const void* q, int64_t nq, int dtype, int k, float* D,
+                              int64_t* I, double* S64, void* stream) {
+    if (!idx || idx->tie_rule != TRX_TIES_FAISS || idx->metric != TRX_METRIC_IP || nq <= 0 || k <= 0)
+        return search_device_core(idx, q, nq, dtype, k, D, I, S64, stream);
+    if (2 * k > TRX_MAX_K) return fail(TRX_EINVAL, "TRX_TIES_FAISS needs the canonical top 2k: k must be in [1, 1024]");
+    if (!q || !D || !I) return fail(TRX_EINVAL, "null query/result pointer");
+    int rc = set_device(idx); if (rc) return rc;
+    if (idx->pend.active) { rc = finish_impl(idx); if (rc) return rc; }      // (its tie kernel reads w_tie)
+    const int k2 = 2 * k;
+    if ((rc = idx->w_tie.reserve((size_t)nq * k2 * (sizeof(float) + sizeof(int64_t) + sizeof(double))))) return rc;
+    float* D2 = (float*)idx->w_tie.p;
+    int64_t* I2 = (int64_t*)((char*)D2 + (size_t)nq * k2 * sizeof(float));
+    double* S2 = (double*)((char*)I2 + (size_t)nq * k2 * sizeof(int64_t));
+    rc = search_device_core(idx, q, nq, dtype, k2, D2, I2, S2, stream); if (rc) return rc;
+    idx->pend.tie_k = k; idx->pend.tie_k2 = k2; idx->pend.tie_nq = nq; idx->pend.tie_D = D; idx->pend.tie_I = I; idx->pend.tie_S = S64;
+    HIPCHK(launch_faiss_ties(nq, k2, k, S2, I2, D, I, S64, (hipStream_t)stream));
+    if (idx->timing) HIPCHK(hipEventRecord(idx->ev[3], (hipStream_t)stream));
+    return TRX_OK;
+}
+
+static int search_device_core(trx_index* idx, const void* q, int64_t nq, int dtype, int k, float* D,
                               int64_t* I, double* S64, void* stream) {
     if (!idx) return fail(TRX_EINVAL, "index is null");
     if (nq < 0 || (nq > 0 && (!q || !D || !I))) return fail(TRX_EINVAL, "null query/result pointer");
@@ -874,13 +910,33 @@ int trx_index_search(trx_index* idx, const void* q, int64_t nq, int dtype, int k
     return TRX_OK;
 }
 
-int trx_merge_topk_device(int metric, int nlists, int64_t nq, int k, const double* S_lists,
-                          const int64_t* I_lists, float* D, int64_t* I, void* stream) {
+int trx_merge_topk_device_s64(int metric, int nlists, int64_t nq, int k, const double* S_lists,
+                              const int64_t* I_lists, float* D, int64_t* I, double* S, void* stream) {
     if (metric != TRX_METRIC_IP && metric != TRX_METRIC_L2) return fail(TRX_EINVAL, "unknown metric");
     if (nlists <= 0 || nlists > 16) return fail(TRX_EINVAL, "nlists must be in [1, 16]");
     if (nq < 0 || k <= 0 || k > TRX_MAX_K) return fail(TRX_EINVAL, "bad nq / k");
     if (nq > 0 && (!S_lists || !I_lists || !D || !I)) return fail(TRX_EINVAL, "null pointer");
-    HIPCHK(launch_merge(metric, nlists, nq, k, S_lists, I_lists, D, I, (hipStream_t)stream));
+    HIPCHK(launch_merge(metric, nlists, nq, k, S_lists, I_lists, D, I, S, (hipStream_t)stream));
+    return TRX_OK;
+}
+
+int trx_merge_topk_device(int metric, int nlists, int64_t nq, int k, const double* S_lists,
+                          const int64_t* I_lists, float* D, int64_t* I, void* stream) {
+    return trx_merge_topk_device_s64(metric, nlists, nq, k, S_lists, I_lists, D, I, nullptr, stream);
+}
+
+int trx_index_set_tie_rule(trx_index* idx, int rule) {
+    if (!idx) return fail(TRX_EINVAL, "index is null");
+    if (rule != TRX_TIES_BY_ID && rule != TRX_TIES_FAISS) return fail(TRX_EINVAL, "unknown tie rule");
+    if (idx->pend.active) { int rc = set_device(idx); if (rc) return rc; rc = finish_impl(idx); if (rc) return rc; }
+    idx->tie_rule = rule;
+    return TRX_OK;
+}
+
+int trx_faiss_tie_order_device(int64_t nq, int k2, int k, const double* S2, const int64_t* I2, float* D, int64_t* I, void* stream) {
+    if (nq < 0 || k <= 0 || k2 < 2 * k || k2 > TRX_MAX_K) return fail(TRX_EINVAL, "need 1 <= k, 2k <= k2 <= 2048");
+    if (nq > 0 && (!S2 || !I2 || !D || !I)) return fail(TRX_EINVAL, "null pointer");
+    HIPCHK(launch_faiss_ties(nq, k2, k, S2, I2, D, I, nullptr, (hipStream_t)stream));
     return TRX_OK;
 }
 

@@ -986,7 +986,7 @@ hipError_t launch_exact_scan(int metric, int cbf, int qbf, const int* qlist, int
 // One thread per query; nlists * k is at most a few hundred.
 template <bool L2>
 __global__ void merge_lists_kernel(int nlists, int64_t nq, int k, const double* S, const int64_t* Il,
-                                   float* D, int64_t* I) {
+                                   float* D, int64_t* I, double* So) {
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq) return;
     int pos[16];
@@ -1003,17 +1003,76 @@ __global__ void merge_lists_kernel(int nlists, int64_t nq, int k, const double* 
             if (better) { best = l; bs = s; bi = id; }
         }
         const int64_t o = q * k + t;
-        if (best < 0) { D[o] = L2 ? FLT_MAX : -FLT_MAX; I[o] = -1; }
-        else { D[o] = (float)bs; I[o] = bi; pos[best]++; }
+        if (best < 0) { D[o] = L2 ? FLT_MAX : -FLT_MAX; I[o] = -1; if (So) So[o] = L2 ? (double)FLT_MAX : -(double)FLT_MAX; }
+        else { D[o] = (float)bs; I[o] = bi; if (So) So[o] = bs; pos[best]++; }
     }
 }
 
 hipError_t launch_merge(int metric, int nlists, int64_t nq, int k, const double* S, const int64_t* Il,
-                        float* D, int64_t* I, hipStream_t st) {
+                        float* D, int64_t* I, double* So, hipStream_t st) {
     if (nq <= 0) return hipSuccess;
     dim3 grid((unsigned)((nq + 127) / 128)), block(128);
-    if (metric) hipLaunchKernelGGL(merge_lists_kernel<true>, grid, block, 0, st, nlists, nq, k, S, Il, D, I);
-    else hipLaunchKernelGGL(merge_lists_kernel<false>, grid, block, 0, st, nlists, nq, k, S, Il, D, I);
+    if (metric) hipLaunchKernelGGL(merge_lists_kernel<true>, grid, block, 0, st, nlists, nq, k, S, Il, D, I, So);
+    else hipLaunchKernelGGL(merge_lists_kernel<false>, grid, block, 0, st, nlists, nq, k, S, Il, D, I, So);
+    return hipGetLastError();
+}
+
+// ---- FAISS' order among EXACT inner-product ties (TRX_TIES_FAISS, include/trx_knn.h) -------------------------------
+// faiss.IndexFlatIP keeps its k best in a min-heap ordered by (score, id) [faiss/utils/Heap.h, ordered_key_value.h: CMin],
+// fed in id order with a STRICT admission test [faiss/impl/ResultHandler.h], and empties it with heap_reorder
+// (oracle/flat_knn_ref.c restates all three).  What that does to rows with EQUAL scores has a closed form:
+//   * a row whose score ties with the heap's minimum is admitted only while the heap is not full -- so of the rows tied
+//     at the k-th score (G, ids ascending) only those among the first k rows, by id, of {rows above the k-th score} u G
+//     ever enter (t0 of them);
+//   * every row above the k-th score that arrives once the heap is full evicts the heap's top = the tied row with the
+//     SMALLEST id -- so of those t0 the m = k - a with the LARGEST ids remain (a = rows above the k-th score);
+//   * heap_reorder pops smallest (score, id) first into the last place: the output is (score desc, id DESC).
+// Input: the canonical top k2 = 2k of each query (score desc on the fp64 value, id asc; pads id = -1 last), which holds
+// the a < k better rows and the first k tied ones -- all the rule can ask for.  One wave per query.
+__global__ __launch_bounds__(64) void faiss_tie_kernel(int64_t nq, int k2, int k, const double* S2, const int64_t* I2, float* D, int64_t* I, double* So) {
+    const int64_t q = blockIdx.x;
+    const int lane = threadIdx.x;
+    const double* s = S2 + q * k2;
+    const int64_t* id = I2 + q * k2;
+    auto wsum = [](int v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64); return v; };
+    int c = 0;
+    for (int t = lane; t < k2; t += 64) c += id[t] >= 0 ? 1 : 0;
+    const int nvalid = wsum(c);
+    int a, t0 = 0;
+    if (nvalid <= k) a = nvalid;       // fewer rows than k: all of them, tie runs reversed, pads behind
+    else {
+        const double sk = s[k - 1];
+        c = 0;
+        for (int t = lane; t < k; t += 64) c += s[t] > sk ? 1 : 0;
+        a = wsum(c);
+        const int gend = min(nvalid, a + k);
+        c = 0;
+        for (int t = a + lane; t < gend; t += 64) {
+            if (s[t] != sk) continue;      // (the run of the k-th score is contiguous from a on)
+            int below = 0;                 // rows above the k-th score with a smaller id: they come first
+            for (int b = 0; b < a; ++b) below += id[b] < id[t] ? 1 : 0;
+            c += (t - a) + below < k ? 1 : 0;
+        }
+        t0 = wsum(c);
+    }
+    for (int p = lane; p < k; p += 64) {
+        int src;
+        if (p < a) {        // inside the run of equal scores it belongs to, mirrored
+            int rs = p, re = p + 1;
+            while (rs > 0 && s[rs - 1] == s[p]) --rs;
+            while (re < a && s[re] == s[p]) ++re;
+            src = rs + (re - 1 - p);
+        } else if (nvalid > k) src = a + (t0 - 1 - (p - a));
+        else src = -1;
+        const int64_t o = q * k + p;
+        if (src < 0) { D[o] = -FLT_MAX; I[o] = -1; if (So) So[o] = -(double)FLT_MAX; }
+        else { D[o] = (float)s[src]; I[o] = id[src]; if (So) So[o] = s[src]; }
+    }
+}
+
+hipError_t launch_faiss_ties(int64_t nq, int k2, int k, const double* S2, const int64_t* I2, float* D, int64_t* I, double* So, hipStream_t st) {
+    if (nq <= 0) return hipSuccess;
+    hipLaunchKernelGGL(faiss_tie_kernel, dim3((unsigned)nq), dim3(64), 0, st, nq, k2, k, S2, I2, D, I, So);
     return hipGetLastError();
 }
 

@@ -36,7 +36,7 @@ def _is_torch(x):
 class IndexFlat:
     """Exact (brute-force) index.  metric: METRIC_INNER_PRODUCT or METRIC_L2."""
 
-    def __init__(self, d, metric=METRIC_L2, device=None):
+    def __init__(self, d, metric=METRIC_L2, device=None, tie_rule=None):
         self.d = int(d)
         self.metric_type = int(metric)
         self.is_trained = True
@@ -45,6 +45,16 @@ class IndexFlat:
         self.device = int(device)
         self._h = ctypes.c_void_p()
         _lib.check(_lib.lib().trx_index_create(self.d, self.metric_type, self.device, ctypes.byref(self._h)))
+        self.tie_rule = "id"
+        self.set_tie_rule(_default_tie_rule() if tie_rule is None else tie_rule)
+
+    def set_tie_rule(self, rule):
+        """'id' (default): equal scores in id order, the total order of include/trx_knn.h.  'faiss': what faiss.IndexFlat
+        itself returns on exact score ties -- for L2 the same thing, for the inner product its min-heap's order (TRX_TIES_FAISS
+        in include/trx_knn.h).  `TRX_TIE_RULE=faiss` in the environment makes it the default of every index."""
+        assert rule in ("id", "faiss"), "tie_rule is 'id' or 'faiss'"
+        _lib.check(_lib.lib().trx_index_set_tie_rule(self._h, _lib.TIES_FAISS if rule == "faiss" else _lib.TIES_BY_ID))
+        self.tie_rule = rule
 
     # -- faiss surface ------------------------------------------------------------------------
     @property
@@ -210,18 +220,20 @@ class IndexFlat:
 
 
 class IndexFlatIP(IndexFlat):
-    def __init__(self, d, device=None):
-        super().__init__(d, METRIC_INNER_PRODUCT, device)
+    def __init__(self, d, device=None, tie_rule=None):
+        super().__init__(d, METRIC_INNER_PRODUCT, device, tie_rule)
 
 
 class IndexFlatL2(IndexFlat):
-    def __init__(self, d, device=None):
-        super().__init__(d, METRIC_L2, device)
+    def __init__(self, d, device=None, tie_rule=None):
+        super().__init__(d, METRIC_L2, device, tie_rule)
 
 
-def merge_topk(metric, S_lists, I_lists):
+def merge_topk(metric, S_lists, I_lists, faiss_ties_k=None):
     """Cross-shard merge on the GPU (include/trx_knn.h: trx_merge_topk_device).
-    S_lists float64 [nlists, nq, k], I_lists int64 [nlists, nq, k] (global ids), both on one GPU."""
+    S_lists float64 [nlists, nq, k], I_lists int64 [nlists, nq, k] (global ids), both on one GPU.
+    faiss_ties_k: the lists are canonical top-2k lists of an inner-product search and the result is FAISS' own top k of
+    the union (trx_merge_topk_device_s64 + trx_faiss_tie_order_device)."""
     import torch
     assert S_lists.is_cuda and I_lists.is_cuda and S_lists.shape == I_lists.shape and S_lists.dim() == 3
     S_lists = S_lists.contiguous().double()
@@ -230,10 +242,29 @@ def merge_topk(metric, S_lists, I_lists):
     D = torch.empty((nq, k), dtype=torch.float32, device=S_lists.device)
     I = torch.empty((nq, k), dtype=torch.int64, device=S_lists.device)
     st = ctypes.c_void_p(torch.cuda.current_stream(S_lists.device.index).cuda_stream)
-    _lib.check(_lib.lib().trx_merge_topk_device(int(metric), nl, nq, k, ctypes.c_void_p(S_lists.data_ptr()),
-                                                ctypes.c_void_p(I_lists.data_ptr()), ctypes.c_void_p(D.data_ptr()),
-                                                ctypes.c_void_p(I.data_ptr()), st))
-    return D, I
+    if faiss_ties_k is None:
+        _lib.check(_lib.lib().trx_merge_topk_device(int(metric), nl, nq, k, ctypes.c_void_p(S_lists.data_ptr()),
+                                                    ctypes.c_void_p(I_lists.data_ptr()), ctypes.c_void_p(D.data_ptr()),
+                                                    ctypes.c_void_p(I.data_ptr()), st))
+        return D, I
+    S = torch.empty((nq, k), dtype=torch.float64, device=S_lists.device)
+    _lib.check(_lib.lib().trx_merge_topk_device_s64(int(metric), nl, nq, k, ctypes.c_void_p(S_lists.data_ptr()),
+                                                    ctypes.c_void_p(I_lists.data_ptr()), ctypes.c_void_p(D.data_ptr()),
+                                                    ctypes.c_void_p(I.data_ptr()), ctypes.c_void_p(S.data_ptr()), st))
+    kk = int(faiss_ties_k)
+    Df = torch.empty((nq, kk), dtype=torch.float32, device=S_lists.device)
+    If = torch.empty((nq, kk), dtype=torch.int64, device=S_lists.device)
+    _lib.check(_lib.lib().trx_faiss_tie_order_device(nq, k, kk, ctypes.c_void_p(S.data_ptr()), ctypes.c_void_p(I.data_ptr()),
+                                                     ctypes.c_void_p(Df.data_ptr()), ctypes.c_void_p(If.data_ptr()), st))
+    return Df, If
+
+
+def _default_tie_rule():
+    import os
+    rule = os.environ.get("TRX_TIE_RULE", "id").lower()
+    if rule not in ("id", "faiss"):
+        raise ValueError("TRX_TIE_RULE is 'id' or 'faiss', not %r" % rule)
+    return rule
 
 
 def _default_device():

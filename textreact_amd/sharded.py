@@ -45,6 +45,12 @@ class ShardedFlatIndex:
             merge = faiss_compat.merge_topk
         self.local = local_index
         self._merge = merge
+        # FAISS' order among exact inner-product ties (include/trx_knn.h, TRX_TIES_FAISS) is a property of the WHOLE index:
+        # the shards answer with their canonical top 2k, the merge keeps the canonical top 2k of the union, and the rule is
+        # applied once, after the merge -- as one FAISS index over all rows would answer.  The local index hands its rule over.
+        self.tie_rule = getattr(local_index, "tie_rule", "id")
+        if self.tie_rule == "faiss":
+            local_index.set_tie_rule("id")
         # a one-rank group skips the exchange (nothing to exchange); exchange_always runs the collectives and the merge
         # anyway, which is how a one-GPU box drives the RCCL branch of this file (tests/test_knn_gpu.py)
         self.exchange_always = bool(exchange_always)
@@ -70,10 +76,20 @@ class ShardedFlatIndex:
         any rank -- agreed on by a one-word all-reduce), the exchange is simply repeated on the final lists."""
         import torch
         exchange = self.world_size > 1 or self.exchange_always
+        ties = self.tie_rule == "faiss" and self.metric == 0
+        if ties and not exchange:       # one shard, nothing to merge: the local index applies the rule itself
+            self.local.set_tie_rule("faiss")
+            try:
+                D, I_loc = self.local.search(x, k)
+            finally:
+                self.local.set_tie_rule("id")
+            return D, torch.where(I_loc >= 0, I_loc + self.offset, I_loc)
+        k_out, k = k, (2 * k if ties else k)
         begin = getattr(self.local, "search_s64_begin", None) if exchange else None
         D, I_loc, S = begin(x, k) if begin is not None else self.local.search_s64(x, k)
         if not exchange:
             return D, torch.where(I_loc >= 0, I_loc + self.offset, I_loc)
+        self._ties_k = k_out if ties else None
         out = self._exchange_and_merge(S, I_loc, k)
         if begin is not None:
             import torch.distributed as dist
@@ -102,7 +118,11 @@ class ShardedFlatIndex:
         dist.all_to_all_single(got, src, output_split_sizes=[mine] * G, input_split_sizes=[hi - lo for lo, hi in bounds],
                                group=self.group)
         got = got.to(pack.device).view(G, mine, 2, k)
-        Dm, Im = self._merge(self.metric, got[:, :, 0].contiguous().view(torch.float64), got[:, :, 1].contiguous())
+        if getattr(self, "_ties_k", None):
+            Dm, Im = self._merge(self.metric, got[:, :, 0].contiguous().view(torch.float64), got[:, :, 1].contiguous(), faiss_ties_k=self._ties_k)
+            k = self._ties_k
+        else:
+            Dm, Im = self._merge(self.metric, got[:, :, 0].contiguous().view(torch.float64), got[:, :, 1].contiguous())
         return _gather_query_slices(Dm, Im, bounds, mine, k, self.group)
 
 
