@@ -286,7 +286,11 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
     const int pstep = 16 * Kp * 2;      // bytes between pieces i and i + 2
     const int half_elems = 128 * Kp;
     const bf16_t* gA = p.corpus + (int64_t)tile0 * TILE_M * Kp;
+#ifdef TRX_SCAN_DEBUG_BUILD
     const bf16_t* gB = p.queries + qbase * Kp;
+#else
+    const bf16_t* const gB = p.queries + qbase * Kp;
+#endif
     const int lds_piece0 = wave_n * 4 * 1024;
 
     // ---- fragment read geometry ----
@@ -395,11 +399,18 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
     const bf16_t* srcA = gA + (wave_m ? 0 : half_elems) + (wave_m ? 2 : 1) * BK;
     int ksA = wave_m ? 2 : 1;
     if (ksA >= ksteps) { ksA -= ksteps; srcA += 255 * Kp; }     // Kp == 128: K-step 2 is the next tile's K-step 0
+#ifdef TRX_SCAN_DEBUG_BUILD
+    const int wrapA = (p.debug & 32) ? -Kp : 255 * Kp;
+#else
     const int wrapA = 255 * Kp;       // added when a K-step cursor moves on to the next tile
+#endif
 #ifdef TRX_SCAN_DEBUG_BUILD   // timing-only switches (TRX_SCAN_DEBUG bits 1, 2, 8; results are wrong): compiled in on request
     const bool dbg_nodma = (p.debug & 1) != 0;
     const bool dbg_nofilter = (p.debug & 2) != 0;
     const bool dbg_norefresh = (p.debug & 8) != 0;
+    // pricing the L2 misses (round 5): bit 16 -- every workgroup stages query tile 0 (the XCD's query footprint is one tile);
+    // bit 32 -- the corpus stream re-reads the first tile of its split for ever (its footprint is one tile per split)
+    if (p.debug & 16) { gB = p.queries; srcB = gB + (wave_m ? half_elems : 0); }
 #else
     constexpr bool dbg_nodma = false, dbg_nofilter = false, dbg_norefresh = false;
 #endif
