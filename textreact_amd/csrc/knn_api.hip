@@ -421,7 +421,8 @@ static int search_batch(trx_index* idx, const void* q, const float* qnorm2, int6
     { const char* dbg = getenv("TRX_SCAN_DEBUG"); sp.debug = dbg ? atoi(dbg) : 0; }
     sp.stamp_out = nullptr;
 #ifdef TRX_STAMP_BUILD
-    if ((rc = idx->w_stamp.reserve((size_t)nqt * nsplits * 8 * 4 * sizeof(unsigned long long)))) return rc;
+    if ((rc = idx->w_stamp.reserve((size_t)nqt * nsplits * 8 * 12 * sizeof(unsigned long long)))) return rc;
+    HIPCHK(hipMemsetAsync(idx->w_stamp.p, 0, (size_t)nqt * nsplits * 8 * 12 * sizeof(unsigned long long), st));
     sp.stamp_out = (unsigned long long*)idx->w_stamp.p;
 #endif
     sp.g_thr = (u32*)pl.gthr.p;
@@ -524,11 +525,19 @@ static int search_batch(trx_index* idx, const void* q, const float* qnorm2, int6
 #ifdef TRX_STAMP_BUILD
     {
         const int nwg = nqt * nsplits;
-        std::vector<unsigned long long> h((size_t)nwg * 32);
+        std::vector<unsigned long long> h((size_t)nwg * 8 * 12);
         HIPCHK(hipMemcpyAsync(h.data(), sp.stamp_out, h.size() * 8, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
-        double cyc = 0, comp = 0, tiles = 0;
-        for (size_t i = 0; i < h.size(); i += 4) { cyc += (double)h[i]; comp += (double)h[i + 1]; tiles += (double)h[i + 3]; }
+        double cyc = 0, comp = 0, tiles = 0, wt = 0, bl = 0, mf = 0, bm = 0, ld = 0, rounds = 0;
+        for (size_t i = 0; i < h.size(); i += 12) {
+            cyc += (double)h[i]; comp += (double)h[i + 1]; tiles += (double)h[i + 3];
+            wt += (double)h[i + 4]; bl += (double)h[i + 5]; mf += (double)h[i + 6]; bm += (double)h[i + 7]; ld += (double)h[i + 8]; rounds += (double)h[i + 9];
+        }
+        // (s_memtime ticks are shader cycles)
+        if (rounds > 0)
+            fprintf(stderr, "[stamp] per wave and L/M round (shader cycles): load issue %.2f, counter waits %.2f, barrier after L %.2f, MFMA phase %.2f, barrier after M %.2f "
+                            "(sum %.2f; %.0f rounds per wave-tile)\n", ld / rounds, wt / rounds, bl / rounds, mf / rounds, bm / rounds,
+                    (ld + wt + bl + mf + bm) / rounds, rounds / tiles);
         // listed rows: the final list counts (exact when nothing was compacted)
         std::vector<u32> hc((size_t)q_pad * nlists);
         HIPCHK(hipMemcpyAsync(hc.data(), sp.cand_cnt, hc.size() * 4, hipMemcpyDeviceToHost, st));

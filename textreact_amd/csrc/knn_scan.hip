@@ -432,7 +432,46 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
         _Pragma("unroll") for (int mt_ = 0; mt_ < 8; ++mt_)                                                \
             asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[mt_]) : "v"((KK) ? aA1 : aA0), "n"(mt_ * 2048 + (STG) * 32768) : "memory"); \
     }
+    // Diagnostic build (make stamp): where an interval's cycles go, per wave.  s_memtime stamps at the five edges of a wave's
+    // L -> barrier -> M -> barrier round; they are SMEM results, so they are only READ behind the next load phase's own
+    // lgkmcnt(0) (no wait is added anywhere): wt = the counter waits at the end of a load phase (LDS fragment reads + the
+    // previous phase's DMA pieces), bl = the barrier behind them, mf = the MFMA phase, bm = the barrier behind it, ld = the
+    // issue part of the load phase (fragment reads, DMA, a finished tile's bookkeeping).
+#ifdef TRX_STAMP_BUILD
+    unsigned long long tA_ = 0, tB_ = 0, tC_ = 0, tD_ = 0, tE_ = 0;
+    u32 a_wt = 0, a_bl = 0, a_mf = 0, a_bm = 0, a_ld = 0, a_n = 0;      // (cycles of one wave over one launch fit 32 bits)
+#define TRX_T(X) asm volatile("s_memtime %0" : "=s"(X)::"memory")
+#define TRX_ROUND_ACC()                                                                                    \
+    if (tE_ > tD_ && tD_ > tC_ && tC_ > tB_ && tB_ > tA_) {                                                \
+        a_wt += (u32)(tB_ - tA_); a_bl += (u32)(tC_ - tB_); a_mf += (u32)(tD_ - tC_); a_bm += (u32)(tE_ - tD_); ++a_n; \
+    }
+#else
+#define TRX_T(X)
+#define TRX_ROUND_ACC()
+#endif
     // end of a load phase; NV = VMEM operations this wave may leave in flight (4, or 5 with an extra piece)
+#ifdef TRX_STAMP_BUILD
+#define TRX_WAIT_L(NV)                                                                                     \
+    {                                                                                                      \
+        unsigned long long tN_;                                                                            \
+        TRX_T(tN_);                                                                                        \
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(" #NV ")" ::: "memory");                      \
+        TRX_ROUND_ACC();        /* the previous round's stamps have landed (lgkmcnt(0)) */                 \
+        if (tE_ && tN_ > tE_) a_ld += (u32)(tN_ - tE_);                                                         \
+        tA_ = tN_;                                                                                         \
+        TRX_T(tB_);                                                                                        \
+    }                                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+    __builtin_amdgcn_s_barrier();                                                                          \
+    TRX_T(tC_);                                                                                            \
+    __builtin_amdgcn_sched_barrier(0);
+#define TRX_END_M()                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+    TRX_T(tD_);                                                                                            \
+    __builtin_amdgcn_s_barrier();                                                                          \
+    TRX_T(tE_);                                                                                            \
+    __builtin_amdgcn_sched_barrier(0);
+#else
 #define TRX_WAIT_L(NV)                                                                                     \
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(" #NV ")" ::: "memory");                          \
     __builtin_amdgcn_sched_barrier(0);                                                                     \
@@ -442,6 +481,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
     __builtin_amdgcn_sched_barrier(0);                                                                     \
     __builtin_amdgcn_s_barrier();                                                                          \
     __builtin_amdgcn_sched_barrier(0);
+#endif
 // The query block index runs back and forth over consecutive rows of MFMAs (0 1 2 3 | 3 2 1 0 | ...): one operand changes per
 // instruction instead of two at every row end.  Lab (tools/scan_lab.hip -DLAB_SNAKE=1): MFMAs alone -0.9 ... -1.6 %, whole loop
 // -0.5 ... -1.0 %.
@@ -838,8 +878,9 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
     }
 #ifdef TRX_STAMP_BUILD
     if (p.stamp_out && lane == 0) {
-        unsigned long long* o = p.stamp_out + ((size_t)blockIdx.x * 8 + wave) * 4;
+        unsigned long long* o = p.stamp_out + ((size_t)blockIdx.x * 8 + wave) * 12;
         o[0] = st_cyc; o[1] = st_comp; o[2] = 0ull; o[3] = (unsigned long long)ntl;
+        o[4] = a_wt; o[5] = a_bl; o[6] = a_mf; o[7] = a_bm; o[8] = a_ld; o[9] = a_n; o[10] = 0ull; o[11] = 0ull;
     }
 #endif
     // ---- publish count and bound of this lane's 4 lists ----

@@ -1075,6 +1075,7 @@ __global__ __launch_bounds__(XW ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
     TRX_STAMP(31, __builtin_amdgcn_s_memtime()); TRX_STAMP(1, __builtin_amdgcn_s_memrealtime());
 }
 
+#include "attn_fwd_f32.h"
 #include "attn_fwd_pp.h"
 #include "attn_bwd_mfma.h"
 #include "attn_decode.h"
@@ -1386,6 +1387,21 @@ static int attention_fwd_impl(const void* q, const void* k, const void* v, const
             else TRX_LAUNCH_MFMA(TRX_NN_MASK_FULL, false);
         }
 #undef TRX_LAUNCH_MFMA
+    } else if (dtype == TRX_NN_F32 && !force_valu) {
+        // fp32 on the matrix cores (attn_fwd_f32.h: v_mfma_f32_16x16x4_f32, exact fp32): 64 queries per workgroup
+        dim3 gf((unsigned)((int64_t)B * H * ((Lq + 63) / 64))), bf(256);
+#define TRX_LAUNCH_F32(MM_, DROP_) hipLaunchKernelGGL((attention_fwd_f32_mfma_kernel<MM_, DROP_>), gf, bf, 0, st, (const float*)q, (const float*)k, \
+                                                      (const float*)v, mask, causal, B, H, Lq, Lk, scale, (float*)out, lse, da)
+        if (da.thr) {
+            if (mask_mode == TRX_NN_MASK_NONE) TRX_LAUNCH_F32(TRX_NN_MASK_NONE, true);
+            else if (mask_mode == TRX_NN_MASK_KEY) TRX_LAUNCH_F32(TRX_NN_MASK_KEY, true);
+            else TRX_LAUNCH_F32(TRX_NN_MASK_FULL, true);
+        } else {
+            if (mask_mode == TRX_NN_MASK_NONE) TRX_LAUNCH_F32(TRX_NN_MASK_NONE, false);
+            else if (mask_mode == TRX_NN_MASK_KEY) TRX_LAUNCH_F32(TRX_NN_MASK_KEY, false);
+            else TRX_LAUNCH_F32(TRX_NN_MASK_FULL, false);
+        }
+#undef TRX_LAUNCH_F32
     } else {
 #define TRX_LAUNCH_VALU(BF_, DROP_) hipLaunchKernelGGL((attention_fwd_kernel<BF_, DROP_>), grid, block, 0, st, q, k, v, mask, mask_mode, causal, B, H, Lq, Lk, scale, out, lse, da)
         if (dtype == TRX_NN_BF16) { if (da.thr) TRX_LAUNCH_VALU(true, true); else TRX_LAUNCH_VALU(true, false); }
