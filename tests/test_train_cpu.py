@@ -180,3 +180,24 @@ def test_merge_predictions_per_neighbor():
     m = train.merge_predictions_per_neighbor(outs, 3)
     assert m == {0: {"prediction": ["p0", "p1", "p2"], "score": [0.0, 1.0, 2.0]},
                  1: {"prediction": ["p3", "p4", "p5"], "score": [3.0, 4.0, 5.0]}}
+
+
+def test_mark_parameters_updated_sees_a_submodule_added_later():
+    """the module list mark_parameters_updated caches is rebuilt when any module was registered since: a layer added after the
+    first step gets its weight shadows marked stale like the others"""
+    import torch
+    from textreact_amd.predictor import train, ops
+
+    class Holder(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = torch.nn.Linear(4, 4)
+
+    m = Holder()
+    m.a.__dict__["_weight_shadows"] = ops.WeightShadows()
+    train.mark_parameters_updated(m)
+    assert m.a.__dict__["_weight_shadows"].generation == 1
+    m.b = torch.nn.Linear(4, 4)                       # added after the cache was made
+    m.b.__dict__["_weight_shadows"] = ops.WeightShadows()
+    train.mark_parameters_updated(m)
+    assert m.b.__dict__["_weight_shadows"].generation == 1 and m.a.__dict__["_weight_shadows"].generation == 2

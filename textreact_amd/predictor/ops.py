@@ -526,9 +526,17 @@ def gemm_tn_ok(a, b, grouped=False):
     """can trx_gemm_tn_bf16 take dW = a^T b (a [M, N], b [M, K])?  grouped: trx_gemm_tn_grouped (N: any multiple of 8)"""
     M, N = a.shape
     K = b.shape[1]
-    return (a.is_cuda and a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and b.shape[0] == M and M >= 64
-            and N % (8 if grouped else 256) == 0 and K % 256 == 0 and a.stride(1) == 1 and b.stride(1) == 1 and a.stride(0) % 8 == 0
-            and b.stride(0) % 8 == 0 and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0 and "TRX_NN_NO_GEMM" not in os.environ)
+    ok = (a.is_cuda and a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and b.shape[0] == M and M >= 64
+          and N % (8 if grouped else 256) == 0 and K % 256 == 0 and a.stride(1) == 1 and b.stride(1) == 1 and a.stride(0) % 8 == 0
+          and b.stride(0) % 8 == 0 and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0 and "TRX_NN_NO_GEMM" not in os.environ)
+    if ok and grouped:
+        # the limits of the C side (gemm_tn.hip: tn_problem_ok), so that a layer the grouped launch would refuse is never
+        # deferred -- a refusal only shows when the whole list is planned, after autograd was handed None for every deferred
+        # weight: 32-bit byte offsets over M + 256 rows of either operand, at most 4,096 tiles of 256 x 256 per problem (the
+        # fp32 dW it writes is a fresh contiguous [N, K]: its alignment and stride hold by construction)
+        ok = ((M + 256) * a.stride(0) * 2 < (1 << 32) and (M + 256) * b.stride(0) * 2 < (1 << 32)
+              and ((N + 255) // 256) * (K // 256) <= 4096)
+    return ok
 
 
 _tn_ws = {}

@@ -361,16 +361,34 @@ def _portable_scheduler_state(sd):
     return sd
 
 
+# every registration of a submodule anywhere in the process (add_module, register_module, attribute assignment) moves this
+# counter: the module list mark_parameters_updated caches is rebuilt when it has moved, so a submodule added or replaced
+# after the first step (an encoder swap, adapters, a load that re-creates layers) is marked like the others
+_module_tree_epoch = [0]
+
+
+def _on_module_registered(module, name, submodule):
+    _module_tree_epoch[0] += 1
+
+
+try:
+    torch.nn.modules.module.register_module_module_registration_hook(_on_module_registered)
+except AttributeError:      # a torch without the global hook: no caching (see mark_parameters_updated)
+    _module_tree_epoch = None
+
+
 def mark_parameters_updated(module):
     """call after an optimizer step or a load_state_dict: the bf16 weight copies `ops.linear` shares between
     forwards (ops.WeightShadows) belong to a new generation; a backward of an older forward raises instead of reading them"""
     # (the module list is made once: walking the tree of ~400 modules through the generator at every step was 0.5 ms of a
     # step's ~13 ms of host time, tools/host_profile.py; a registry itself is made lazily by the first forward)
-    holders = module.__dict__.get("_shadow_holders")
-    if holders is None:
+    epoch = _module_tree_epoch[0] if _module_tree_epoch is not None else None
+    cached = module.__dict__.get("_shadow_holders")
+    if cached is None or epoch is None or cached[0] != epoch:
         # (without the module itself: a list that holds its owner is a reference cycle, and the model would wait for the
         # cycle collector instead of being freed with its last reference)
-        holders = module.__dict__["_shadow_holders"] = [m for m in module.modules() if m is not module]
+        cached = module.__dict__["_shadow_holders"] = (epoch, [m for m in module.modules() if m is not module])
+    holders = cached[1]
     for m in [module] + holders:
         reg = m.__dict__.get("_weight_shadows")
         if reg is not None:

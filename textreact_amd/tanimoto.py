@@ -186,11 +186,11 @@ class TanimotoIndex:
         den_out = torch.zeros((nq, kk), dtype=torch.int64, device=self.dev)
         if nq == 0 or kk == 0:
             return keys_out, a_out, den_out
-        def run_batch(lo, all_keys):
+        def run_batch(lo, all_keys, rows=batch):
             """one batch of queries -> its rows of the outputs; returns a device flag "some query had more rows above its
             bound than the candidate list holds" (None when every key was formed anyway).  all_keys: form every key of every
             row (the answer to that flag)"""
-            qb = q[lo:lo + batch]
+            qb = q[lo:lo + rows]
             m = qb.shape[0]
             q_t, q_sum = self._pack_queries(qb)
             both = torch.empty((m, n), dtype=torch.int16, device=self.dev)       # sums of minima (< 32768)
@@ -232,7 +232,11 @@ class TanimotoIndex:
         if flags:
             for (lo, _), again in zip(flags, torch.stack([f for _, f in flags]).tolist()):
                 if again:
-                    run_batch(lo, True)
+                    # every key of every row: an [m, n] int64 matrix plus the top-k's workspace -- taken a few queries at a time
+                    # so that it stays near 256 MB whatever the shard size (a 10M-row shard: 3 queries per pass)
+                    sub = max(1, min(batch, (1 << 25) // max(n, 1)))
+                    for l2 in range(lo, min(lo + batch, nq), sub):
+                        run_batch(l2, True, min(sub, lo + batch - l2))
         return keys_out, a_out, den_out
 
 
