@@ -450,10 +450,12 @@ def main():
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
         value = nq * args.steps / elapsed
-        flops_launch = 2.0 * queries.shape[0] * (hi - lo) * d        # algorithmic: 2*Q_local*N_local*d per scan launch
+        # algorithmic: 2*Q_local*N_local*d per step, over the scan launches the step took (one per 65,536 queries)
+        flops_launch = 2.0 * queries.shape[0] * (hi - lo) * d * args.steps / max(launches, 1)
         mean_launch_ms = scan_ms / max(launches, 1)
         achieved = flops_launch / (mean_launch_ms * 1e-3) / 1e12 if mean_launch_ms > 0 else 0.0
-        alg_bytes = 2.0 * ((hi - lo) * d + queries.shape[0] * d) + 8.0 * queries.shape[0] * k
+        q_launch = queries.shape[0] * args.steps / max(launches, 1)
+        alg_bytes = 2.0 * ((hi - lo) * d + q_launch * d) + 8.0 * q_launch * k      # SURVEY 8d, per launch
         hbm_gbs = alg_bytes / (mean_launch_ms * 1e-3) / 1e9 if mean_launch_ms > 0 else 0.0
         traffic, traffic_source = None, None
         if world == 1 and n == N_CORPUS and nq == N_QUERIES:   # measured for exactly this launch

@@ -801,7 +801,10 @@ static int search_device_core(trx_index* idx, const void* q, int64_t nq, int dty
     idx->pend.approx = approx ? 1 : 0; idx->pend.eps_round = eps_round;
     idx->stats.k_split = idx->Kp;
 
-    const int64_t QB = 65536;
+    // queries per scan launch.  One launch of 65,536 queries is 1,024 workgroups = four rounds of the chip's 256 resident
+    // slots; TRX_QUERY_BATCH (a multiple of 256, at most 65,536) cuts a call into shorter launches
+    int64_t QB = 65536;
+    { const char* e = getenv("TRX_QUERY_BATCH"); if (e) QB = std::max<int64_t>(256, std::min<int64_t>(65536, (atoll(e) / 256) * 256)); }
     const size_t esz = is_bf ? 2 : 4;
     const int nbatches = (int)((nq + QB - 1) / QB);
     DevPool& pl = pool_of(idx->device);

@@ -597,25 +597,46 @@ class deferred_wgrad:
     call as before.  (Inside a stream capture the library keeps the plan's pinned block for the life of the process.)"""
 
     def __enter__(self):
-        global _deferred
-        self.prev, _deferred = _deferred, []
+        global _deferred, _deferred_bytes
+        self.prev, _deferred = (_deferred, _deferred_bytes), []
+        _deferred_bytes = 0
         return self
 
     def __exit__(self, et, ev, tb):
-        global _deferred
-        pending, _deferred = _deferred, self.prev
+        global _deferred, _deferred_bytes
+        pending, (_deferred, _deferred_bytes) = _deferred, self.prev
         if et is None and pending:
-            gemm_tn_grouped([(dy, x, dw, db) for (dy, x, dw, db, _) in pending])
-            for (_, _, dw, db, slots) in pending:
-                for (param, is_bias, lo, hi) in slots:
-                    g = db if is_bias else dw
-                    if lo != 0 or hi != g.shape[0]:          # a packed projection: this parameter's row block
-                        g = g[lo:hi]
-                    if param.grad is None:
-                        param.grad = g
-                    else:
-                        param.grad.add_(g)
+            _flush_deferred(pending)
         return False
+
+
+# dY and X of a deferred layer stay alive until its problem has run (the per-call path released them layer by layer), plus an
+# fp32 dW buffer each: past this many bytes the pending problems are launched as a group of their own, in the middle of the
+# backward pass (B32 x L512: a group per ~5 encoder layers instead of 3-4 GB held to the end)
+_DEFERRED_BUDGET = int(os.environ.get("TRX_NN_WGRAD_BUDGET_MB", "2048")) << 20
+_deferred_bytes = 0
+
+
+def _flush_deferred(pending):
+    gemm_tn_grouped([(dy, x, dw, db) for (dy, x, dw, db, _) in pending])
+    for (_, _, dw, db, slots) in pending:
+        for (param, is_bias, lo, hi) in slots:
+            g = db if is_bias else dw
+            if lo != 0 or hi != g.shape[0]:          # a packed projection: this parameter's row block
+                g = g[lo:hi]
+            if param.grad is None:
+                param.grad = g
+            else:
+                param.grad.add_(g)
+
+
+def _has_grad_hooks(params):
+    """a parameter with a tensor hook or a post-accumulate hook wants its gradient from autograd: the deferred path assigns
+    .grad directly and no hook would fire, so such a layer takes the per-call path"""
+    for p in params:
+        if p._backward_hooks or getattr(p, "_post_accumulate_grad_hooks", None):
+            return True
+    return False
 
 
 def backward(loss):
@@ -764,7 +785,8 @@ class _LinearWgrad(torch.autograd.Function):
             dx = torch.matmul(dy2, w16).view(x.shape)
         need_w = any(ctx.needs_input_grad[2:2 + n])
         want_db = ctx.has_bias and any(ctx.needs_input_grad[2 + n:])
-        if need_w and _deferred is not None and ctx.wdtype == torch.float32 and gemm_tn_ok(dy2, x2, grouped=True):
+        if (need_w and _deferred is not None and ctx.wdtype == torch.float32 and gemm_tn_ok(dy2, x2, grouped=True)
+                and not _has_grad_hooks(ctx.params)):
             # deferred_wgrad(): this layer's problem joins the pass's one grouped launch; autograd gets no gradient for the
             # parameters here -- the end of the block assigns them
             ntot = dy2.shape[1]
@@ -778,6 +800,13 @@ class _LinearWgrad(torch.autograd.Function):
                     slots.append((ctx.params[n + j], True, lo, lo + o))
                 lo += o
             _deferred.append((dy2, x2, dwbuf, dbbuf, slots))
+            global _deferred_bytes
+            _deferred_bytes += dy2.numel() * 2 + x2.numel() * 2 + dwbuf.numel() * 4
+            if _deferred_bytes > _DEFERRED_BUDGET:
+                pending = list(_deferred)
+                del _deferred[:]
+                _deferred_bytes = 0
+                _flush_deferred(pending)
             return (dx, None) + (None,) * len(ctx.params)
         if need_w:
             od = torch.float32 if ctx.wdtype == torch.float32 else torch.bfloat16
