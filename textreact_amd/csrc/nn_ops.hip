@@ -1076,6 +1076,7 @@ __global__ __launch_bounds__(XW ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
 }
 
 #include "attn_fwd_f32.h"
+#include "attn_bwd_f32.h"
 #include "attn_fwd_pp.h"
 #include "attn_bwd_mfma.h"
 #include "attn_decode.h"
@@ -1483,6 +1484,34 @@ static int attention_bwd_impl(const void* q, const void* k, const void* v, const
         if (!ws_user) (void)hipFreeAsync(ws, st);
         if (e1 != hipSuccess) return fail(TRX_NN_EHIP, hipGetErrorString(e1));
         return TRX_NN_OK;
+    }
+    if (dtype == TRX_NN_F32 && !force_valu) {
+        // fp32 on the matrix cores (attn_bwd_f32.h): the dq pass makes delta = dO . O and hands it to the dk/dv pass
+        const size_t n = (size_t)B * H * Lq;
+        float* ws = (float*)ws_user;
+        if (!ws && (hipMallocAsync((void**)&ws, n * sizeof(float), st) != hipSuccess || !ws)) {
+            (void)hipGetLastError();
+            return fail(TRX_NN_EHIP, "attention_bwd: scratch allocation failed");
+        }
+        dim3 gfq((unsigned)((int64_t)B * H * ((Lq + 63) / 64))), gfk((unsigned)((int64_t)B * H * ((Lk + 63) / 64))), bf(256);
+#define TRX_LAUNCH_BWD_F32(MM_, DROP_)                                                                                      \
+    hipLaunchKernelGGL((attention_bwd_dq_f32_mfma_kernel<MM_, DROP_>), gfq, bf, 0, st, (const float*)q, (const float*)k,    \
+                       (const float*)v, mask, causal, B, H, Lq, Lk, scale, (const float*)out, (const float*)dout, lse, (float*)dq, ws, da); \
+    hipLaunchKernelGGL((attention_bwd_dkv_f32_mfma_kernel<MM_, DROP_>), gfk, bf, 0, st, (const float*)q, (const float*)k,   \
+                       (const float*)v, mask, causal, B, H, Lq, Lk, scale, (const float*)dout, lse, ws, (float*)dk, (float*)dv, da)
+        if (da.thr) {
+            if (mask_mode == TRX_NN_MASK_NONE) { TRX_LAUNCH_BWD_F32(TRX_NN_MASK_NONE, true); }
+            else if (mask_mode == TRX_NN_MASK_KEY) { TRX_LAUNCH_BWD_F32(TRX_NN_MASK_KEY, true); }
+            else { TRX_LAUNCH_BWD_F32(TRX_NN_MASK_FULL, true); }
+        } else {
+            if (mask_mode == TRX_NN_MASK_NONE) { TRX_LAUNCH_BWD_F32(TRX_NN_MASK_NONE, false); }
+            else if (mask_mode == TRX_NN_MASK_KEY) { TRX_LAUNCH_BWD_F32(TRX_NN_MASK_KEY, false); }
+            else { TRX_LAUNCH_BWD_F32(TRX_NN_MASK_FULL, false); }
+        }
+#undef TRX_LAUNCH_BWD_F32
+        hipError_t e1 = hipGetLastError();
+        if (!ws_user) (void)hipFreeAsync(ws, st);
+        return e1 == hipSuccess ? TRX_NN_OK : fail(TRX_NN_EHIP, hipGetErrorString(e1));
     }
 #define TRX_LAUNCH_VALU_BWD(BF_, DROP_)                                                                                     \
     hipLaunchKernelGGL((attention_bwd_dq_kernel<BF_, DROP_>), gq, block, 0, st, q, k, v, mask, mask_mode, causal, B, H, Lq, Lk, \
