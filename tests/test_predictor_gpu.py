@@ -821,22 +821,33 @@ def test_deferred_weight_gradients_equal_the_per_layer_calls():
     ws = [(_rand(768, 768, seed=2 + i) * 0.05) for i in range(3)]; bs = [_rand(768, seed=7 + i) for i in range(3)]
     w2, dy = _rand(256, 2304, seed=11) * 0.05, _rand(3, 171, 256, dtype=torch.bfloat16, seed=12)
     res = []
-    for mode in ("deferred", "percall"):
+    hooked = []
+    for mode in ("deferred", "percall", "deferred, flushed in groups", "deferred, a hook on one weight"):
         xs = x.clone().requires_grad_(True)
         pw = [w.clone().requires_grad_(True) for w in ws]; pb = [b.clone().requires_grad_(True) for b in bs]
         pw2 = w2.clone().requires_grad_(True)
-        for rep in range(2):                   # the second pass adds to the first's .grad
-            with torch.autocast("cuda", dtype=torch.bfloat16):
-                h = ops.linear_multi(xs, pw, pb)
-                y = ops.linear_multi(h, [pw2])
-            if mode == "deferred":
-                ops.backward((y.float() * dy.float()).sum())
-            else:
-                (y.float() * dy.float()).sum().backward()
+        if "hook" in mode:                     # a parameter with a hook keeps the per-call path: autograd hands it the gradient
+            pw2.register_hook(lambda g: hooked.append(tuple(g.shape)))
+        budget = ops._DEFERRED_BUDGET
+        if "groups" in mode:                   # TRX_NN_WGRAD_BUDGET_MB: past 1 MB of held operands the pending problems run
+            ops._DEFERRED_BUDGET = 1 << 20
+        try:
+            for rep in range(2):               # the second pass adds to the first's .grad
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    h = ops.linear_multi(xs, pw, pb)
+                    y = ops.linear_multi(h, [pw2])
+                if mode != "percall":
+                    ops.backward((y.float() * dy.float()).sum())
+                else:
+                    (y.float() * dy.float()).sum().backward()
+        finally:
+            ops._DEFERRED_BUDGET = budget
         res.append([xs.grad] + [p.grad for p in pw + pb + [pw2]])
-    for a, b in zip(*res):
-        assert a is not None and a.shape == b.shape and a.dtype == b.dtype
-        assert float((a.float() - b.float()).abs().max()) <= 2e-5 * max(1.0, float(b.float().abs().max()))
+    assert hooked == [(256, 2304)] * 2
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            assert a is not None and a.shape == b.shape and a.dtype == b.dtype
+            assert float((a.float() - b.float()).abs().max()) <= 2e-5 * max(1.0, float(b.float().abs().max()))
 
 
 @pytest.mark.parametrize("B,L", [(4, 128), (4, 131), (3, 437), (1, 63)])

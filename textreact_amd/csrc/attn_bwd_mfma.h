@@ -362,16 +362,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
         }
     }
-    if (qidx_e < Lq && kp_s == 0) {
-        bf16_t* op = dq + ((int64_t)b_e * Lq + qidx_e) * (da.ldq ? da.ldq : H * 64) + h_e * 64;
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {   // registers 4gq..4gq+3 = d rows 8gq + 4hh + 0..3
-            uint2 w0, w1;
-            w0.x = pack2bf(a0[4 * gq] * scale, a0[4 * gq + 1] * scale); w0.y = pack2bf(a0[4 * gq + 2] * scale, a0[4 * gq + 3] * scale);
-            w1.x = pack2bf(a1[4 * gq] * scale, a1[4 * gq + 1] * scale); w1.y = pack2bf(a1[4 * gq + 2] * scale, a1[4 * gq + 3] * scale);
-            *reinterpret_cast<uint2*>(op + 8 * gq + 4 * hh_e) = w0;
-            *reinterpret_cast<uint2*>(op + 32 + 8 * gq + 4 * hh_e) = w1;
-        }
+    {
+        const bool live = qidx_e < Lq && kp_s == 0;
+        store_row_bf16(dq + ((int64_t)b_e * Lq + (live ? qidx_e : 0)) * (da.ldq ? da.ldq : H * 64) + h_e * 64, live, TRX_ATT_WIDE_STORE && KS == 1,
+                       hh_e, a0, a1, scale);
     }
 }
 
@@ -604,22 +598,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     int b_e = b_s, h_e = h_s, kblk_e = kblk_s;      // opaque copies, as in the dq pass
     asm volatile("" : "+s"(b_e), "+s"(h_e), "+s"(kblk_e));
     const int lane_e = lane_again(), hh_e = lane_e >> 5, kidx_e = kblk_e * 128 + wave_s * 32 + (lane_e & 31);
-    if (kidx_e < Lk) {
-        const int hh = hh_e;
-        const int64_t ro_e = ((int64_t)b_e * Lk + kidx_e) * (da.ldk ? da.ldk : H * 64) + h_e * 64;
-        bf16_t* kp = dk + ro_e;
-        bf16_t* vp = dv + ro_e;
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-            uint2 w;
-            w.x = pack2bf(ak0[4 * gq] * scale, ak0[4 * gq + 1] * scale); w.y = pack2bf(ak0[4 * gq + 2] * scale, ak0[4 * gq + 3] * scale);
-            *reinterpret_cast<uint2*>(kp + 8 * gq + 4 * hh) = w;
-            w.x = pack2bf(ak1[4 * gq] * scale, ak1[4 * gq + 1] * scale); w.y = pack2bf(ak1[4 * gq + 2] * scale, ak1[4 * gq + 3] * scale);
-            *reinterpret_cast<uint2*>(kp + 32 + 8 * gq + 4 * hh) = w;
-            w.x = pack2bf(av0[4 * gq], av0[4 * gq + 1]); w.y = pack2bf(av0[4 * gq + 2], av0[4 * gq + 3]);
-            *reinterpret_cast<uint2*>(vp + 8 * gq + 4 * hh) = w;
-            w.x = pack2bf(av1[4 * gq], av1[4 * gq + 1]); w.y = pack2bf(av1[4 * gq + 2], av1[4 * gq + 3]);
-            *reinterpret_cast<uint2*>(vp + 32 + 8 * gq + 4 * hh) = w;
-        }
+    {
+        const bool live = kidx_e < Lk;
+        const bool wide = TRX_ATT_WIDE_STORE && kblk_e * 128 + 128 <= Lk;      // (a full block of 128 keys: every lane of the workgroup stores)
+        const int64_t ro_e = ((int64_t)b_e * Lk + (live ? kidx_e : 0)) * (da.ldk ? da.ldk : H * 64) + h_e * 64;
+        store_row_bf16(dk + ro_e, live, wide, hh_e, ak0, ak1, scale);
+        store_row_bf16(dv + ro_e, live, wide, hh_e, av0, av1, 1.0f);
     }
 }

@@ -580,6 +580,46 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
+// A lane's row of 64 values in the transposed accumulator layout of the attention kernels (r0: d 0..31, r1: d 32..63; register
+// 4 gq + j of a half is d 8 gq + 4 hh + j, hh = lane >> 5) -> bf16 in memory, times `mul`.
+// A 16-byte piece of the row (d 8 gq .. 8 gq + 7) is half in this lane and half in lane ^ 32.  wide (wave-uniform; every lane of
+// the wave must get here): the two lanes trade -- the lower one gives its odd pieces and takes the partner's even ones;
+// v_permlane32_swap X, Y leaves [own even | partner's even] in the lower lanes and [partner's odd | own odd] in the upper ones --
+// and the row leaves in 4 dwordx4 stores per lane, 32 contiguous bytes of a row per instruction, instead of 8 dwordx2 with 16.
+// Round 5, same box, interleaved (tools/attn_shapes_ab.py): forward 512 x 512 41.0 -> 38.4 us, 160 x 512 20.4 -> 19.6; blocks
+// with one or two 32-row units (7 queries, the tail of 160) are 1-3 % faster narrow -- the swap sits on their short path --
+// so the callers pass wide = "this workgroup's block is full".
+__device__ __forceinline__ void store_row_bf16(bf16_t* rowp, bool live, bool wide, int hh, const f32x16& r0, const f32x16& r1, float mul) {
+    if (wide) {
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                const int ge = 8 * pr, go = 8 * pr + 4;
+                unsigned xx, xy, yx, yy;
+                if (blk == 0) {
+                    xx = pack2bf(r0[ge] * mul, r0[ge + 1] * mul); xy = pack2bf(r0[ge + 2] * mul, r0[ge + 3] * mul);
+                    yx = pack2bf(r0[go] * mul, r0[go + 1] * mul); yy = pack2bf(r0[go + 2] * mul, r0[go + 3] * mul);
+                } else {
+                    xx = pack2bf(r1[ge] * mul, r1[ge + 1] * mul); xy = pack2bf(r1[ge + 2] * mul, r1[ge + 3] * mul);
+                    yx = pack2bf(r1[go] * mul, r1[go + 1] * mul); yy = pack2bf(r1[go + 2] * mul, r1[go + 3] * mul);
+                }
+                asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(xx), "+v"(yx));
+                asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(xy), "+v"(yy));
+                if (live) *reinterpret_cast<uint4*>(rowp + 32 * blk + 8 * (2 * pr + hh)) = uint4{xx, xy, yx, yy};
+            }
+    } else if (live) {
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            uint2 w0, w1;
+            w0.x = pack2bf(r0[4 * gq] * mul, r0[4 * gq + 1] * mul); w0.y = pack2bf(r0[4 * gq + 2] * mul, r0[4 * gq + 3] * mul);
+            w1.x = pack2bf(r1[4 * gq] * mul, r1[4 * gq + 1] * mul); w1.y = pack2bf(r1[4 * gq + 2] * mul, r1[4 * gq + 3] * mul);
+            *reinterpret_cast<uint2*>(rowp + 8 * gq + 4 * hh) = w0;
+            *reinterpret_cast<uint2*>(rowp + 32 + 8 * gq + 4 * hh) = w1;
+        }
+    }
+}
+
 
 // one 64-key tile of the online softmax, in the transposed accumulator layout: register t of half
 // hb holds key row hb*32 + (t&3) + 8*(t>>2) + 4*hh of the tile for this lane's query.  The additive
@@ -733,6 +773,9 @@ __device__ unsigned long long* g_att_stamp;
 template <int MM, bool DROP, bool XW = false>   // mask mode, dropout: one kernel per case keeps each one's register footprint to what it needs
 #ifndef TRX_ATT_WAVES      // waves per SIMD the register budget is cut for (A/B knob; 3 = 168 registers)
 #define TRX_ATT_WAVES 3
+#endif
+#ifndef TRX_ATT_WIDE_STORE // 1: the output row leaves in 16-byte pieces (lanes r and r ^ 32 trade halves by v_permlane32_swap); A/B in round 5
+#define TRX_ATT_WIDE_STORE 1
 #endif
 #ifndef TRX_ATT_PRIO       // 1: s_setprio 1 around the MFMA clusters: -2.8 % at 512 x 512, -3.7 % at 160 x 512 (profiles/r03_attention_ab.json)
 #define TRX_ATT_PRIO 1
@@ -1059,18 +1102,15 @@ __global__ __launch_bounds__(XW ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
         }
     }
     if (qidx < Lq && kp == 0) {
-        const float inv = (DROP ? da.inv_keep : 1.0f) / ltot;
         // natural-log LSE of the scaled, masked scores (what the backward pass recomputes against)
         if (lse && hh == 0) lse[((int64_t)b * H + h) * Lq + qidx] = (m + __builtin_amdgcn_logf(ltot)) * 0.69314718055994530942f;
-        bf16_t* op = out + ((int64_t)b * Lq + qidx) * H * 64 + (int64_t)h * 64;
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {   // registers 4gq..4gq+3 = d rows 8gq + 4hh + 0..3
-            uint2 w0, w1;
-            w0.x = pack2bf(o0[4 * gq] * inv, o0[4 * gq + 1] * inv); w0.y = pack2bf(o0[4 * gq + 2] * inv, o0[4 * gq + 3] * inv);
-            w1.x = pack2bf(o1[4 * gq] * inv, o1[4 * gq + 1] * inv); w1.y = pack2bf(o1[4 * gq + 2] * inv, o1[4 * gq + 3] * inv);
-            *reinterpret_cast<uint2*>(op + 8 * gq + 4 * hh) = w0;
-            *reinterpret_cast<uint2*>(op + 32 + 8 * gq + 4 * hh) = w1;
-        }
+    }
+    // (whole 128-byte rows through LDS -- a wave parks its 32 rows in the K / V ring and reads them back 8 lanes per row -- were
+    // measured beside the lane trade below: 40.83 against 41.04 us at 512 x 512, not worth a barrier and 36 lines; round 5)
+    {
+        const bool live = qidx < Lq && kp == 0;
+        store_row_bf16(out + ((int64_t)b * Lq + (live ? qidx : 0)) * H * 64 + (int64_t)h * 64, live, TRX_ATT_WIDE_STORE && nuq == 4, hh, o0, o1,
+                       (DROP ? da.inv_keep : 1.0f) / ltot);
     }
     TRX_STAMP(31, __builtin_amdgcn_s_memtime()); TRX_STAMP(1, __builtin_amdgcn_s_memrealtime());
 }

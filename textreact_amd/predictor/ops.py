@@ -611,9 +611,12 @@ class deferred_wgrad:
 
 
 # dY and X of a deferred layer stay alive until its problem has run (the per-call path released them layer by layer), plus an
-# fp32 dW buffer each: past this many bytes the pending problems are launched as a group of their own, in the middle of the
-# backward pass (B32 x L512: a group per ~5 encoder layers instead of 3-4 GB held to the end)
-_DEFERRED_BUDGET = int(os.environ.get("TRX_NN_WGRAD_BUDGET_MB", "2048")) << 20
+# fp32 dW buffer each.  TRX_NN_WGRAD_BUDGET_MB bounds what is held: past it the pending problems are launched as a group of
+# their own in the middle of the backward pass.  Off by default (0), because it was measured (tools/r05/fifth.sh, B32 x L512 x
+# T160, same box): the step's peak allocation is 24.2 GiB with and without a 2 GiB budget -- the peak is the forward's
+# activations at the start of the backward pass, which the held operands never exceed -- while the step goes 20.8 -> 23.2 ms
+# (six launches of ~15 problems fill the chip worse than one of 90); 4 GiB: 21.1 ms.
+_DEFERRED_BUDGET = int(os.environ.get("TRX_NN_WGRAD_BUDGET_MB", "0")) << 20
 _deferred_bytes = 0
 
 
@@ -802,7 +805,7 @@ class _LinearWgrad(torch.autograd.Function):
             _deferred.append((dy2, x2, dwbuf, dbbuf, slots))
             global _deferred_bytes
             _deferred_bytes += dy2.numel() * 2 + x2.numel() * 2 + dwbuf.numel() * 4
-            if _deferred_bytes > _DEFERRED_BUDGET:
+            if _DEFERRED_BUDGET and _deferred_bytes > _DEFERRED_BUDGET:
                 pending = list(_deferred)
                 del _deferred[:]
                 _deferred_bytes = 0
