@@ -2,7 +2,7 @@
 # One gpurun call that takes every measurement a round commits under profiles/ (run it through gpurun; summaries are
 # made afterwards, here, by profiles/summarize*.py from what gpurun merged back into gpurun_out/).
 #   profiles/run_round.sh <tag>
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
@@ -21,5 +21,8 @@ python bench_predictor.py --live > $O/live_bench.jsonl 2> $O/live_bench.err
 bash profiles/run_profile_predictor.sh $TAG > $O/run_profile_predictor.log 2>&1
 bash tools/prof_train.sh 512 160 > $O/prof_train_160.log 2>&1
 python tools/step_ops.py fill > $O/step_fill.txt 2>&1
-python tools/attn_shapes_ab.py r03=tools/ab/libtrxnn_r03.so r04=textreact_amd/csrc/libtrxnn.so > $O/attention_ab.json 2> $O/attention_ab.err
+python tools/attn_shapes_ab.py narrow_stores=tools/ab/libtrxnn_nowide.so $TAG=textreact_amd/csrc/libtrxnn.so > $O/attention_ab.json 2> $O/attention_ab.err
+python tools/shard_costs.py > $O/shard_costs.json 2> $O/shard_costs.err
+python tools/r05/attn_f32_ab.py > $O/attention_f32.jsonl 2> $O/attention_f32.err
+TRX_NN_ATTN_VALU=1 python tools/r05/attn_f32_ab.py >> $O/attention_f32.jsonl 2>> $O/attention_f32.err
 tail -3 $O/gputest.log; grep -c "^{" $O/bench.jsonl $O/predictor_bench.jsonl $O/live_bench.jsonl $O/fingerprint_bench.jsonl $O/c2_rehearsal_bench.jsonl
