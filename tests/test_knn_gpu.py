@@ -420,6 +420,10 @@ def test_a_crowd_around_the_kth_place_is_resolved_by_the_rescan(split, monkeypat
     # wide re-score -- same answers, no second scan)
     if split:
         monkeypatch.setenv("TRX_FP32_SPLIT", "1")
+        # (which tier settles a query depends on where the lists' bound falls inside the crowd; this case was built against the
+        # bootstrap bound of rounds 2-4 -- the main scan's rule -- and keeps it, so that the re-scan tier stays exercised here;
+        # round 5's tighter bootstrap bound puts the same queries through the wide re-score alone: next test)
+        monkeypatch.setenv("TRX_BOOT_J2", "1")
     # the k-th place INSIDE a crowd that reaches down to the lists' bound: scores fall off smoothly (steps far below the rounding
     # bound) over 3000 rows, so whatever the bound is, rows just under it tie with the k-th and the wide re-score cannot
     # certify.  Tier 3 scans again with the threshold fixed at (k-th exact score so far) - 2 eps: the ~1,400 rows above it
@@ -431,6 +435,36 @@ def test_a_crowd_around_the_kth_place_is_resolved_by_the_rescan(split, monkeypat
     for metric in (IP, L2):
         st = _check(metric, x, y, 10)
         assert st["n_rescored"] == 4 and st["n_rescanned"] == (4 if split else 0) and st["n_uncertified"] == 0, st
+
+
+def test_the_bootstrap_bound_changes_tiers_never_answers(monkeypatch):
+    """round 5: the bootstrap publishes the 16th largest of a query's 32 tracked maxima instead of the minimum over its lanes'
+    second bests (TRX_BOOT_J2=1 keeps the old rule).  A threshold is a hint: the same crowd, the three-term operand, both
+    rules -- identical answers (the oracle's), whichever tiers they take; and on benign data neither flags a query"""
+    monkeypatch.setenv("TRX_FP32_SPLIT", "1")
+    y = gaussian(4000, 64, 1)
+    c = gaussian(1, 64, 2)
+    y[500:3500] = c * (1.0 - 1e-7 * np.arange(3000, dtype=np.float32)[:, None])
+    x = np.repeat(c, 4, axis=0)
+    tiers = []
+    for rule in ("1", None):
+        if rule:
+            monkeypatch.setenv("TRX_BOOT_J2", rule)
+        else:
+            monkeypatch.delenv("TRX_BOOT_J2")
+        for metric in (IP, L2):
+            st = _check(metric, x, y, 10)
+            assert st["n_uncertified"] == 0, st
+            tiers.append((st["n_rescored"], st["n_rescanned"]))
+    monkeypatch.delenv("TRX_FP32_SPLIT")
+    for rule in ("1", None):
+        if rule:
+            monkeypatch.setenv("TRX_BOOT_J2", rule)
+        else:
+            monkeypatch.delenv("TRX_BOOT_J2")
+        st = _check(IP, bf16_round(gaussian(700, 768, 5678)), bf16_round(gaussian(60000, 768, 1234)), 10)
+        assert st["n_rescored"] == 0 and st["n_uncertified"] == 0, st
+    assert tiers[0][1] == 4          # (the old rule's bound sends this crowd through the re-scan: what the test above pins)
 
 
 @pytest.mark.parametrize("split", [True, False])

@@ -860,6 +860,55 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
         // publish min(own, partner) -- the partner's value must be its final one here
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        if (J == 4 && p.kprime == 16) {
+            // The bootstrap of a kprime = 16 search (round 5).  The main scan's rule -- the minimum over a query's 8 lanes of each
+            // lane's second-best tile maximum -- is a key that 16 rows reach, but it sits near the 32nd best of the rows seen (the
+            // minimum of eight second-order statistics), and the first 16 tiles of every split run on the bootstrap's bound: half
+            // of all rows a 125,000-row shard lists are listed there.  This launch has time: it tracks FOUR maxima
+            // per lane (J = 4) -- 8 lanes x 4 = 32 different rows of the query -- and publishes their 16th largest, which 16 rows
+            // reach by construction and which is the 16th best of the 4,096 rows seen unless one lane holds more than four of the
+            // top 16.  One thread per query selects it from an LDS image of the 32 values (the staging area is dead by now).
+            float* sc = reinterpret_cast<float*>(smem);      // [256 queries][8 cells][4]
+            {
+                const u32 a_trk = lds0 + S_TRK + (u32)tid * 4;
+                u32 w[8];
+                w[0] = lds_ld32<0>(a_trk); w[1] = lds_ld32<2048>(a_trk); w[2] = lds_ld32<4096>(a_trk); w[3] = lds_ld32<6144>(a_trk);
+                w[4] = lds_ld32<8192>(a_trk); w[5] = lds_ld32<10240>(a_trk); w[6] = lds_ld32<12288>(a_trk); w[7] = lds_ld32<14336>(a_trk);
+                __syncthreads();                             // everybody has read its tracked maxima: S_TRK lies inside nobody's image, but the
+                                                             // image overwrites the DMA stages other waves' last (unused) pieces were aimed at
+                const int cell = wave_m * 4 + fq;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const u32 bits = (j & 1) ? (w[(j >> 1) * 4 + nt] & 0xffff0000u) : (w[(j >> 1) * 4 + nt] << 16);
+                        sc[(ql0 + 16 * nt) * 32 + cell * 4 + j] = __uint_as_float(bits);
+                    }
+            }
+            __syncthreads();
+            if (tid < TILE_N) {
+                float vals[32];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const f32x4 t4 = *reinterpret_cast<const f32x4*>(sc + tid * 32 + 4 * i);
+                    vals[4 * i] = t4[0]; vals[4 * i + 1] = t4[1]; vals[4 * i + 2] = t4[2]; vals[4 * i + 3] = t4[3];
+                }
+                float kth = NEG_INF;      // the value with exactly 15 others in front of it (ties broken by position)
+#pragma unroll
+                for (int i = 0; i < 32; ++i) {
+                    int before = 0;
+#pragma unroll
+                    for (int j = 0; j < 32; ++j) before += (vals[j] > vals[i] || (vals[j] == vals[i] && j < i)) ? 1 : 0;
+                    kth = before == 15 ? vals[i] : kth;
+                }
+                if (kth > NEG_INF) {
+#pragma unroll
+                    for (int sl = 0; sl < 4; ++sl)
+                        __hip_atomic_fetch_max(p.g_thr + (qbase * 4 + sl * 256 + tid), ordkey(KS * kth), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            return;
+        }
         if (wave_m == 0 && fq == 0) {
             auto pubb = [&](auto NT) {
                 constexpr int nt = decltype(NT)::value;
@@ -930,8 +979,11 @@ static hipError_t launch_ks(const ScanParams& p, hipStream_t st) {
 hipError_t launch_scan(const ScanParams& p, int metric, hipStream_t st) {
     const bool l2 = metric == 1, j4 = p.kprime > 16;
     if (p.bootstrap) {
-        if (l2) return j4 ? launch_ks<true, 4, true>(p, st) : launch_ks<true, 2, true>(p, st);
-        return j4 ? launch_ks<false, 4, true>(p, st) : launch_ks<false, 2, true>(p, st);
+        // the bootstrap always tracks four maxima per lane: for kprime = 16 it publishes the 16th largest of a query's 32 (see the
+        // kernel's BOOT epilogue); TRX_BOOT_J2=1 keeps the main scan's rule (the A/B switch of round 5)
+        const bool boot_j2 = getenv("TRX_BOOT_J2") != nullptr;      // (read per launch: tests switch it inside one process)
+        if (boot_j2 && !j4) return l2 ? launch_ks<true, 2, true>(p, st) : launch_ks<false, 2, true>(p, st);
+        return l2 ? launch_ks<true, 4, true>(p, st) : launch_ks<false, 4, true>(p, st);
     }
     if (l2) return j4 ? launch_ks<true, 4, false>(p, st) : launch_ks<true, 2, false>(p, st);
     return j4 ? launch_ks<false, 4, false>(p, st) : launch_ks<false, 2, false>(p, st);
