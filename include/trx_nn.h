@@ -113,6 +113,21 @@ int trx_add_layernorm_bwd_mixed(const void* dy_f32, const void* dy_bf16, const v
                                 const float* mean, const float* rstd, int64_t rows, int cols, float p, uint64_t seed, void* dz_f32,
                                 void* dx_bf16, float* dgamma, float* dbeta, const float* x_bias, float* dx_bias, float* ws,
                                 void* stream);
+/* dgamma == dbeta == NULL (dx_bias then too): the first stage only -- dz and dx are written, the per-workgroup partial column
+ * sums stay in ws.  trx_add_layernorm_bwd_reduce_many finishes any number of such calls in ONE launch: a backward pass makes
+ * ~40 of these calls, each followed by a second stage of a few microseconds that nothing waits for before the optimizer.
+ * Same sums, bit for bit, as the per-call second stage.  items: HOST array (it travels by value in the kernel arguments: no
+ * device copy, capturable); every item's ws must stay alive until the launch has run. */
+#define TRX_LN_REDUCE_MAX 48
+typedef struct trx_ln_reduce_item {
+    const float* ws;   /* the ws of a partials-only trx_add_layernorm_bwd_mixed call: float[(dxbias ? 3 : 2) * nblk * cols] */
+    float* dgamma;     /* float[cols] */
+    float* dbeta;      /* float[cols] */
+    float* dxbias;     /* float[cols] or NULL */
+    int nblk;          /* trx_add_layernorm_bwd_blocks(rows) of that call */
+    int reserved;
+} trx_ln_reduce_item;
+int trx_add_layernorm_bwd_reduce_many(const trx_ln_reduce_item* items, int n, int cols, void* stream);
 /* Packed projections (bf16, matrix-core kernels): q, k, v (and dq, dk, dv) are slices of one projection
  * output, e.g. [B, L, 3 * H * 64] from a single QKV GEMM.  ldq / ldkv = elements between consecutive
  * tokens of q (dq) and of k, v (dk, dv); out, dout, lse are dense as above. */

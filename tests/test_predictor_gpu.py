@@ -850,6 +850,38 @@ def test_deferred_weight_gradients_equal_the_per_layer_calls():
             assert float((a.float() - b.float()).abs().max()) <= 2e-5 * max(1.0, float(b.float().abs().max()))
 
 
+def test_deferred_layernorm_column_sums_equal_the_per_call_second_stage():
+    """ops.backward: the add+LayerNorm backward calls of a pass run their first stage only and ONE launch at the end
+    (trx_add_layernorm_bwd_reduce_many) makes every call's dgamma / dbeta / fused-bias gradient -- bit for bit the per-call second
+    stage's sums, also when a .grad is already there (gradient accumulation), with and without the fused bias, and a parameter
+    with a hook keeps the per-call path"""
+    rows, cols = 3 * 171, 768
+    x = _rand(rows, cols, dtype=torch.bfloat16, seed=1); res = _rand(rows, cols, seed=2)
+    dy = _rand(rows, cols, seed=3)
+    seen = []
+    res_grads = []
+    for mode in ("deferred", "percall", "deferred, hook on gamma"):
+        xs, rs = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
+        ps = [[(_rand(cols, seed=10 + 3 * i + j) * 0.1 + (1.0 if j == 0 else 0.0)).requires_grad_(True) for j in range(3)] for i in range(3)]
+        if "hook" in mode:
+            ps[0][0].register_hook(lambda g: seen.append(tuple(g.shape)))
+        for rep in range(2):
+            h = rs
+            for i, (g, b, bias) in enumerate(ps):
+                h = ops.add_layernorm(xs, h, g, b, 1e-12, dropout_p=0.1, seed=77 + i, bias=bias if i != 1 else None)
+            loss = (h * dy).sum()
+            if mode != "percall":
+                ops.backward(loss)
+            else:
+                loss.backward()
+        res_grads.append([xs.grad, rs.grad] + [t.grad for trio in ps for t in trio if t.grad is not None])
+    assert seen == [(cols,)] * 2
+    for other in res_grads[1:]:
+        assert len(other) == len(res_grads[0]) == 2 + 3 + 2 + 3
+        for a, b in zip(res_grads[0], other):
+            assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("B,L", [(4, 128), (4, 131), (3, 437), (1, 63)])
 def test_linear_with_our_weight_gradient_equals_autograd(B, L):
     """token counts that are not multiples of 64 included (batches padded to their longest sequence); fewer than 64

@@ -492,6 +492,40 @@ __global__ __launch_bounds__(256) void add_ln_bwd_reduce_kernel(const float* ws,
     }
 }
 
+// the second stage for MANY backward calls at once (round 5: trx_add_layernorm_bwd_reduce_many): the table travels by value
+// (a kernel argument of 48 x 40 bytes -- no device copy, nothing a stream capture has to keep alive); blockIdx.z picks the
+// call, the rest is add_ln_bwd_reduce_kernel's walk, so the sums are bit for bit those of the per-call second stage
+struct LnReduceTable { trx_ln_reduce_item it[TRX_LN_REDUCE_MAX]; };
+__global__ __launch_bounds__(256) void add_ln_bwd_reduce_many_kernel(LnReduceTable t, int cols) {
+    __shared__ float part[16][17];
+    const trx_ln_reduce_item& e = t.it[blockIdx.z];
+    float* const dst = blockIdx.y == 0 ? e.dgamma : (blockIdx.y == 1 ? e.dbeta : e.dxbias);
+    if (!dst) return;                                  // (block-uniform: a call without a bias gradient)
+    const int nblk = e.nblk;
+    const int tc = threadIdx.x & 15, tr = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + tc;
+    const float* src = e.ws + (int64_t)blockIdx.y * nblk * cols;
+    float a = 0.f;
+    if (c < cols) {
+        float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int i = tr;
+        for (; i + 7 * 16 < nblk; i += 8 * 16) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a8[u] += src[(int64_t)(i + 16 * u) * cols + c];
+        }
+        for (; i < nblk; i += 16) a8[0] += src[(int64_t)i * cols + c];
+        a = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
+    }
+    part[tr][tc] = a;
+    __syncthreads();
+    if (tr == 0 && c < cols) {
+        float s_ = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s_ += part[i][tc];
+        dst[c] = s_;
+    }
+}
+
 // ---- attention forward, fp32 math, one lane per query row --------------------------------------
 // A wave owns 64 consecutive queries of one (batch, head); K and V rows are the same for every lane,
 // so hipcc fetches them through the scalar cache (s_load) and the products are v_fmac with an SGPR
@@ -1327,8 +1361,11 @@ int trx_add_layernorm_bwd_mixed(const void* dy_f32, const void* dy_bf16, const v
                                 const float* mean, const float* rstd, int64_t rows, int cols, float p, uint64_t seed, void* dz_f32,
                                 void* dx_bf16, float* dgamma, float* dbeta, const float* x_bias, float* dx_bias, float* ws,
                                 void* stream) {
-    if ((x_bias == nullptr) != (dx_bias == nullptr)) return fail(TRX_NN_EINVAL, "add_layernorm_bwd_mixed: x_bias and dx_bias go together");
-    if ((!dy_f32 && !dy_bf16) || !x_bf16 || !res_f32 || !gamma || !mean || !rstd || !dz_f32 || !dx_bf16 || !dgamma || !dbeta || !ws || rows <= 0 || cols <= 0)
+    // dgamma == dbeta == NULL: the first stage only -- the partial column sums stay in ws for trx_add_layernorm_bwd_reduce_many
+    const bool partials_only = !dgamma && !dbeta;
+    if (partials_only ? dx_bias != nullptr : (x_bias == nullptr) != (dx_bias == nullptr))
+        return fail(TRX_NN_EINVAL, "add_layernorm_bwd_mixed: x_bias and dx_bias go together (partials only: no dx_bias)");
+    if ((!dy_f32 && !dy_bf16) || !x_bf16 || !res_f32 || !gamma || !mean || !rstd || !dz_f32 || !dx_bf16 || (!partials_only && (!dgamma || !dbeta)) || !ws || rows <= 0 || cols <= 0)
         return fail(TRX_NN_EINVAL, "add_layernorm_bwd_mixed: bad argument");
     if (!(p >= 0.f && p < 1.f)) return fail(TRX_NN_EINVAL, "dropout probability must be in [0, 1)");
     if (cols % 4 != 0 || cols > 64 * NCH * 4) return fail(TRX_NN_EINVAL, "add_layernorm_bwd_mixed: cols must be a multiple of 4 and <= 1024");
@@ -1343,7 +1380,23 @@ int trx_add_layernorm_bwd_mixed(const void* dy_f32, const void* dy_bf16, const v
                                          rows, cols, dz_f32, dx_bf16, ws, nblk, drop, dy_bf16, x_bias);
     TRX_NC_SWITCH(chunks_per_lane(cols, 4), TRX_LNBM)
 #undef TRX_LNBM
-    hipLaunchKernelGGL(add_ln_bwd_reduce_kernel, dim3((cols + 15) / 16, x_bias ? 3 : 2), dim3(256), 0, st, ws, nblk, cols, dgamma, dbeta, dx_bias);
+    if (!partials_only)
+        hipLaunchKernelGGL(add_ln_bwd_reduce_kernel, dim3((cols + 15) / 16, x_bias ? 3 : 2), dim3(256), 0, st, ws, nblk, cols, dgamma, dbeta, dx_bias);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? TRX_NN_OK : fail(TRX_NN_EHIP, hipGetErrorString(e));
+}
+
+int trx_add_layernorm_bwd_reduce_many(const trx_ln_reduce_item* items, int n, int cols, void* stream) {
+    if (!items || n <= 0 || cols <= 0) return fail(TRX_NN_EINVAL, "add_layernorm_bwd_reduce_many: bad argument");
+    for (int i = 0; i < n; ++i)
+        if (!items[i].ws || !items[i].dgamma || !items[i].dbeta || items[i].nblk <= 0)
+            return fail(TRX_NN_EINVAL, "add_layernorm_bwd_reduce_many: an item without partials, dgamma / dbeta or blocks");
+    for (int i0 = 0; i0 < n; i0 += TRX_LN_REDUCE_MAX) {
+        LnReduceTable t{};
+        const int m = n - i0 < TRX_LN_REDUCE_MAX ? n - i0 : TRX_LN_REDUCE_MAX;
+        for (int i = 0; i < m; ++i) t.it[i] = items[i0 + i];
+        hipLaunchKernelGGL(add_ln_bwd_reduce_many_kernel, dim3((cols + 15) / 16, 3, m), dim3(256), 0, (hipStream_t)stream, t, cols);
+    }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? TRX_NN_OK : fail(TRX_NN_EHIP, hipGetErrorString(e));
 }

@@ -21,7 +21,7 @@ SYMBOLS = ["trx_add_layernorm_fwd", "trx_add_layernorm_bwd", "trx_add_layernorm_
            "trx_attention_fwd", "trx_attention_fwd_lse", "trx_attention_bwd",
            "trx_add_layernorm_fwd_dropout", "trx_add_layernorm_bwd_dropout", "trx_attention_fwd_dropout",
            "trx_attention_bwd_dropout", "trx_dropout_keep_mask", "trx_add_layernorm_fwd_mixed",
-           "trx_add_layernorm_bwd_mixed", "trx_attention_fwd_kvcache", "trx_attention_fwd_strided",
+           "trx_add_layernorm_bwd_mixed", "trx_add_layernorm_bwd_reduce_many", "trx_attention_fwd_kvcache", "trx_attention_fwd_strided",
            "trx_attention_bwd_strided", "trx_attention_decode_gather", "trx_gemm_tn_bf16", "trx_gemm_tn_ws_bytes", "trx_gemm_tn_grouped_block_bytes", "trx_gemm_tn_grouped_plan", "trx_gemm_tn_grouped_run", "trx_gemm_tn_grouped", "trx_nn_last_error", "trx_nn_version",
            "trx_nn_set_seed_device", "trx_attention_bwd_ws", "trx_attention_bwd_ws_bytes"]
 
@@ -52,6 +52,7 @@ def lib():
         L.trx_dropout_keep_mask.argtypes = [u64, f32, i64, i64, i64, vp, vp]
         L.trx_add_layernorm_fwd_mixed.argtypes = [vp, vp, vp, vp, f32, i64, i32, f32, u64, vp, vp, vp, vp, vp, vp]
         L.trx_add_layernorm_bwd_mixed.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, u64, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.trx_add_layernorm_bwd_reduce_many.argtypes = [vp, i32, i32, vp]
         L.trx_attention_fwd_kvcache.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i64, f32, i32, vp, vp]
         L.trx_attention_fwd_strided.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, f32, u64, vp, vp, vp]
         L.trx_attention_bwd_strided.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, f32, u64,
@@ -258,6 +259,7 @@ class _AddLayerNormMixed(torch.autograd.Function):
         if need:
             ctx.save_for_backward(xs, rs, g, mean, rstd, xb if xb is not None else xs.new_empty(0))
             ctx.drop = (float(p), int(seed), xb is not None)
+            ctx.params = (gamma, beta, bias)       # what a deferred second stage hands its sums to (ops.backward)
         return (y, y16) if dual else y
 
     @staticmethod
@@ -274,6 +276,13 @@ class _AddLayerNormMixed(torch.autograd.Function):
         nblk = lib().trx_add_layernorm_bwd_blocks(rows)
         ws = torch.empty((3 if has_bias else 2) * nblk * cols, dtype=torch.float32, device=xs.device)
         dz, dx = torch.empty_like(rs), torch.empty_like(xs)
+        if _deferred_ln is not None and _ln_deferrable(ctx.params, ctx.needs_input_grad):
+            # inside ops.backward(): the first stage only; the column sums of every such call of the pass are finished by ONE
+            # launch at the end (deferred_wgrad.__exit__), which puts them into the parameters' .grad directly
+            _check(lib().trx_add_layernorm_bwd_mixed(_p(dy), _p(dy16), _p(xs), _p(rs), _p(g), _p(mean), _p(rstd), rows, cols, p, seed,
+                                                     _p(dz), _p(dx), None, None, _p(xb), None, _p(ws), _stream(xs)))
+            _deferred_ln.append((ws, nblk, cols, ctx.params))
+            return dx, dz, None, None, None, None, None, None, None
         dg = torch.empty(cols, dtype=torch.float32, device=xs.device)
         db = torch.empty(cols, dtype=torch.float32, device=xs.device)
         dxb = torch.empty(cols, dtype=torch.float32, device=xs.device) if has_bias else None
@@ -591,22 +600,25 @@ _deferred = None      # a list while a deferred_wgrad() block is open: the weigh
 class deferred_wgrad:
     """`with ops.deferred_wgrad(): loss.backward()` -- the Linear layers' weight (and bias) gradients of this backward pass
     are computed at the END of the block by one grouped launch (gemm_tn_grouped) instead of one split-contraction call per
-    layer, and are put into (or added to) the parameters' .grad directly: their backward nodes hand autograd no gradient
+    layer -- and, since round 5, the add+LayerNorm calls' column sums (dgamma, dbeta, the fused bias gradient) by one launch
+    instead of a second stage per call (_flush_deferred_ln) -- and are put into (or added to) the parameters' .grad directly: their backward nodes hand autograd no gradient
     for them, so per-parameter hooks do not fire (DistributedDataParallel's reducer among them; main.py reduces the
     gradients itself after the backward pass).  Outside such a block -- torch.autograd.grad -- every layer makes its own
     call as before.  (Inside a stream capture the library keeps the plan's pinned block for the life of the process.)"""
 
     def __enter__(self):
-        global _deferred, _deferred_bytes
-        self.prev, _deferred = (_deferred, _deferred_bytes), []
-        _deferred_bytes = 0
+        global _deferred, _deferred_bytes, _deferred_ln
+        self.prev, _deferred = (_deferred, _deferred_bytes, _deferred_ln), []
+        _deferred_bytes, _deferred_ln = 0, []
         return self
 
     def __exit__(self, et, ev, tb):
-        global _deferred, _deferred_bytes
-        pending, (_deferred, _deferred_bytes) = _deferred, self.prev
+        global _deferred, _deferred_bytes, _deferred_ln
+        pending, pending_ln, (_deferred, _deferred_bytes, _deferred_ln) = _deferred, _deferred_ln, self.prev
         if et is None and pending:
             _flush_deferred(pending)
+        if et is None and pending_ln:
+            _flush_deferred_ln(pending_ln)
         return False
 
 
@@ -631,6 +643,52 @@ def _flush_deferred(pending):
                 param.grad = g
             else:
                 param.grad.add_(g)
+
+
+# the add+LayerNorm backward calls of the pass whose second stage (the column sums: dgamma, dbeta, the fused bias gradient) is
+# still to run: (ws, nblk, cols, (gamma, beta, bias)).  One launch finishes all of them (trx_add_layernorm_bwd_reduce_many):
+# a B32 x L512 x T160 step makes 42 such calls, each followed by a 5 us second stage that nothing needs before the optimizer.
+_deferred_ln = None
+
+
+class _LnReduceItem(ctypes.Structure):      # include/trx_nn.h: trx_ln_reduce_item
+    _fields_ = [("ws", ctypes.c_void_p), ("dgamma", ctypes.c_void_p), ("dbeta", ctypes.c_void_p), ("dxbias", ctypes.c_void_p),
+                ("nblk", ctypes.c_int), ("reserved", ctypes.c_int)]
+
+
+def _ln_deferrable(params, needs):
+    """gamma and beta (and the fused bias) are fp32 leaves that want a gradient and carry no hooks: their .grad can be assigned
+    behind autograd's back.  needs = ctx.needs_input_grad of (x, res, gamma, beta, eps, p, seed, dual, bias)"""
+    gamma, beta, bias = params
+    if not (needs[2] and needs[3]) or (bias is not None and not needs[8]):
+        return False
+    ps = [t for t in params if t is not None]
+    return all(t.is_leaf and t.dtype == torch.float32 for t in ps) and not _has_grad_hooks(ps)
+
+
+def _flush_deferred_ln(pending):
+    by_cols = {}
+    for item in pending:
+        by_cols.setdefault(item[2], []).append(item)
+    for cols, items in by_cols.items():
+        n = len(items)
+        dev = items[0][0].device
+        sums = torch.empty((n, 3, cols), dtype=torch.float32, device=dev)      # [call][dgamma | dbeta | dbias][cols]
+        arr = (_LnReduceItem * n)()
+        for i, (ws, nblk, _, (gamma, beta, bias)) in enumerate(items):
+            base = sums[i].data_ptr()
+            arr[i].ws, arr[i].dgamma, arr[i].dbeta = ws.data_ptr(), base, base + 4 * cols
+            arr[i].dxbias = base + 8 * cols if bias is not None else None
+            arr[i].nblk = nblk
+        _check(lib().trx_add_layernorm_bwd_reduce_many(ctypes.addressof(arr), n, cols, _stream(items[0][0])))
+        for i, (_, _, _, (gamma, beta, bias)) in enumerate(items):
+            for param, g in ((gamma, sums[i, 0]), (beta, sums[i, 1]), (bias, sums[i, 2])):
+                if param is None:
+                    continue
+                if param.grad is None:
+                    param.grad = g
+                else:
+                    param.grad.add_(g)
 
 
 def _has_grad_hooks(params):

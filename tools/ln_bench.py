@@ -56,6 +56,15 @@ def rows_for(rows):
             fwd(); f = timeit(fwd); bw = timeit(bwd)
             out.append({"rows": rows, "variant": name, "fwd_us": round(f, 2), "fwd_GBs": round(fb / f / 1e3, 1), "fwd_frac": round(fb / f / 8e6, 3), "fwd_bytes": fb,
                         "bwd_us": round(bw, 2), "bwd_GBs": round(bb / bw / 1e3, 1), "bwd_frac": round(bb / bw / 8e6, 3), "bwd_bytes": bb})
+            if name == "mixed":
+                # what a call costs inside ops.backward() since round 5: the first stage only (dgamma = dbeta = NULL: the partial
+                # column sums stay in ws; ONE trx_add_layernorm_bwd_reduce_many launch per backward pass finishes all calls)
+                bwd1 = lambda: _check(L.trx_add_layernorm_bwd_mixed(_p(dy), _p(dy16), _p(x), _p(r), _p(g), _p(mean), _p(rstd), rows, cols, p, seed,
+                                                                     _p(dz), _p(dx), None, None, None, None, _p(ws), st))
+                b1 = timeit(bwd1)
+                out.append({"rows": rows, "variant": "mixed, first stage only (the trainer's per-call cost: column sums deferred to one launch per pass)",
+                            "fwd_us": round(f, 2), "fwd_GBs": round(fb / f / 1e3, 1), "fwd_frac": round(fb / f / 8e6, 3), "fwd_bytes": fb,
+                            "bwd_us": round(b1, 2), "bwd_GBs": round(bb / b1 / 1e3, 1), "bwd_frac": round(bb / b1 / 8e6, 3), "bwd_bytes": bb})
     return out
 
 
