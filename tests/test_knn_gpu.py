@@ -437,6 +437,25 @@ def test_a_crowd_around_the_kth_place_is_resolved_by_the_rescan(split, monkeypat
         assert st["n_rescored"] == 4 and st["n_rescanned"] == (4 if split else 0) and st["n_uncertified"] == 0, st
 
 
+@pytest.mark.parametrize("metric", [IP, L2])
+def test_a_call_cut_into_several_scan_launches(metric, monkeypatch):
+    """TRX_QUERY_BATCH (round 5's experiment: one round of workgroups per launch) cuts a call into batches of that many queries,
+    each with its own bootstrap, scan and select over the shared workspaces: same answers, batch by batch -- also with the FAISS
+    tie rule, whose scratch spans the whole call, and through the host entry point"""
+    import textreact_amd.faiss_compat as faiss
+    from oracle import flat_knn as oracle
+    monkeypatch.setenv("TRX_QUERY_BATCH", "256")
+    st = _check(metric, bf16_round(gaussian(700, 96, 3)), bf16_round(gaussian(9000, 96, 4)), 10)
+    assert st["scan_launches"] == 3 and st["n_uncertified"] == 0, st
+    _check(metric, gaussian(513, 200, 5), gaussian(4000, 200, 6), 30)           # the two-scan path, fp32 data
+    if metric == IP:
+        y, x = grid(5000, 24, 7), grid(600, 24, 8)
+        idx = faiss.IndexFlatIP(24, tie_rule="faiss"); idx.add(y)
+        D, I = idx.search(x, 10)
+        Df, If = oracle.knn_faiss(IP, x, y, 10)
+        assert np.array_equal(I, If) and np.array_equal(D, Df)
+
+
 def test_the_bootstrap_bound_changes_tiers_never_answers(monkeypatch):
     """round 5: the bootstrap publishes the 16th largest of a query's 32 tracked maxima instead of the minimum over its lanes'
     second bests (TRX_BOOT_J2=1 keeps the old rule).  A threshold is a hint: the same crowd, the three-term operand, both

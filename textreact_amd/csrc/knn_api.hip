@@ -217,7 +217,7 @@ void trx_index_destroy(trx_index* idx) {
     if (idx->C8) (void)hipFree(idx->C8);
     if (idx->cbias8) (void)hipFree(idx->cbias8);
     if (idx->C4) (void)hipFree(idx->C4);
-    DevBuf* bufs[] = {&idx->w_stamp, &idx->w_stats, &idx->w_qnorm2, &idx->w_flag, &idx->w_exact, &idx->w_io, &idx->w_tmp, &idx->w_cls};
+    DevBuf* bufs[] = {&idx->w_stamp, &idx->w_stats, &idx->w_qnorm2, &idx->w_flag, &idx->w_exact, &idx->w_io, &idx->w_tmp, &idx->w_cls, &idx->w_tie};
     for (DevBuf* b : bufs) b->release();
     {   // the last index of the process on this device takes the shared workspaces with it
         DevPool& pl = pool_of(idx->device);
