@@ -15,7 +15,7 @@
 #include <vector>
 
 namespace trx {
-hipError_t launch_row_stats(const void*, int, int64_t, int, int64_t, void*, float*, hipStream_t);
+hipError_t launch_row_stats(const void*, int, int64_t, int, int64_t, void*, float*, float*, hipStream_t);
 hipError_t launch_build_operand(const void*, int, int, int64_t, int, int64_t, bf16_t*, int, hipStream_t);
 hipError_t launch_fill_bias(const float*, int64_t, int64_t, float*, hipStream_t);
 hipError_t launch_widen_rows(const bf16_t*, int64_t, int, int64_t, float*, hipStream_t);
@@ -26,8 +26,8 @@ hipError_t launch_classify(const void*, int, int, float, int, int, int, int, int
 hipError_t launch_build_operand_fp4(const void*, int, int64_t, int, int64_t, unsigned char*, int, hipStream_t);
 hipError_t launch_build_operand_i8(const void*, int, int64_t, int, int64_t, signed char*, int, float, hipStream_t);
 hipError_t launch_fill_bias_i32(const float*, int64_t, int64_t, int*, hipStream_t);
-hipError_t launch_slack(const float*, int64_t, int64_t, float, float, float, int, float*, hipStream_t);
-hipError_t launch_bigk_seeds(int, const float*, const int64_t*, int, int, int, const float*, float, float, float, int*, int*, float*, hipStream_t);
+hipError_t launch_slack(const float*, int64_t, int64_t, float, float, float, const float*, float, int, float*, hipStream_t);
+hipError_t launch_bigk_seeds(int, const float*, const int64_t*, int, int, int, const float*, float, float, float, const float*, float, int*, int*, float*, hipStream_t);
 hipError_t launch_merge(int, int, int64_t, int, const double*, const int64_t*, float*, int64_t*, double*, hipStream_t);
 hipError_t launch_faiss_ties(int64_t, int, int, const double*, const int64_t*, float*, int64_t*, double*, hipStream_t);
 }  // namespace trx
@@ -44,7 +44,7 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
                         std::string(#expr) + ": " + hipGetErrorString(e__));               \
     } while (0)
 
-struct HostStats { uint32_t inexact_any, nonint_any, maxabs_bits, maxnorm2_bits, nonfp4_any; };
+struct HostStats { uint32_t inexact_any, nonint_any, maxabs_bits, maxnorm2_bits, nonfp4_any, maxerr2_bits; };
 static float bits2f(uint32_t b) { float f; std::memcpy(&f, &b, 4); return f; }
 
 // grow-only device buffer
@@ -98,6 +98,7 @@ struct trx_index {
     float* cnorm2 = nullptr; // [cap]
     float* cbias = nullptr;  // [cap]
     float maxabs = 0.f, maxnorm2 = 0.f;
+    float maxerr2 = 0.f;      // max over the rows of |y - bf16(y)|^2: the corpus side of the measured rounding bound (knn_common.h: round_term)
     bool nonint = false;
     bool nonfp4 = false;      // some value is not one of 0, +-1, +-2, +-3, +-4, +-6 (what the fp4 form of the scan can hold)
     // the int8 form of the scan for the integer class (knn_scan.hip, I8): an int8 copy of the operand rows and the int32 start
@@ -252,7 +253,7 @@ int trx_index_reset(trx_index* idx) {
     if (idx->C4) (void)hipFree(idx->C4);
     idx->C4 = nullptr; idx->c4_cap = 0; idx->c4_rows = -1; idx->nonfp4 = false;
     idx->n = 0; idx->cap = 0; idx->mode = MODE_EMPTY; idx->Kp = 0;
-    idx->maxabs = 0.f; idx->maxnorm2 = 0.f; idx->nonint = false;
+    idx->maxabs = 0.f; idx->maxnorm2 = 0.f; idx->maxerr2 = 0.f; idx->nonint = false;
     return TRX_OK;
 }
 
@@ -285,7 +286,7 @@ int trx_index_add_device(trx_index* idx, const void* x, int64_t n, int dtype, vo
     rc = idx->w_stats.reserve(sizeof(HostStats)); if (rc) return rc;
     rc = idx->w_tmp.reserve((size_t)n * sizeof(float)); if (rc) return rc;
     HIPCHK(hipMemsetAsync(idx->w_stats.p, 0, sizeof(HostStats), st));
-    HIPCHK(launch_row_stats(x, is_bf, n, idx->d, idx->d, idx->w_stats.p, (float*)idx->w_tmp.p, st));
+    HIPCHK(launch_row_stats(x, is_bf, n, idx->d, idx->d, idx->w_stats.p, (float*)idx->w_tmp.p, nullptr, st));
     HostStats hs; rc = read_stats(idx, st, &hs); if (rc) return rc;
 
     int newmode = idx->mode;
@@ -312,6 +313,7 @@ int trx_index_add_device(trx_index* idx, const void* x, int64_t n, int dtype, vo
     HIPCHK(launch_fill_bias(idx->cnorm2, idx->n, idx->cap + TILE_M, idx->cbias, st));
     idx->maxabs = std::max(idx->maxabs, bits2f(hs.maxabs_bits));
     idx->maxnorm2 = std::max(idx->maxnorm2, bits2f(hs.maxnorm2_bits));
+    idx->maxerr2 = std::max(idx->maxerr2, bits2f(hs.maxerr2_bits));
     idx->nonint = idx->nonint || hs.nonint_any;
     idx->nonfp4 = idx->nonfp4 || hs.nonfp4_any;
     HIPCHK(hipStreamSynchronize(st));  // x may be freed by the caller on return
@@ -361,7 +363,7 @@ constexpr int INLINE_FALLBACK = 4;
 constexpr size_t FLAG_WORDS = 8 + 5 * 65536;      // (8 header words: the four counters, [4] the re-scan tier's form)
 constexpr int RESCAN_MAX = 16384;                 // queries per batch the re-scan is sized for (64 query tiles); more take the exact scan
 
-static int search_batch(trx_index* idx, const void* q, const float* qnorm2, int64_t nq, int is_bf, int q_split, int batch_no,
+static int search_batch(trx_index* idx, const void* q, const float* qnorm2, const float* qerr2, int64_t nq, int is_bf, int q_split, int batch_no,
                         float eps_rel, int k, float* D, int64_t* I, double* S64, hipStream_t st) {
     const int d = idx->d, Kp = idx->Kp;
     const int64_t q_pad = round_up64(nq, TILE_N);
@@ -431,7 +433,7 @@ static int search_batch(trx_index* idx, const void* q, const float* qnorm2, int6
         // approximate operands: a query's listing threshold is its bound minus 2 eps_q (the select kernel's eps_q), so that the
         // lists hold every row that can reach the top k and the candidates certify on their exact scores without a second scan
         if ((rc = pl.slk.reserve((size_t)q_pad * sizeof(float)))) return rc;
-        HIPCHK(launch_slack(qnorm2, nq, q_pad, eps_rel, idx->pend.eps_round, idx->maxnorm2, idx->metric == TRX_METRIC_L2 ? 1 : 0, (float*)pl.slk.p, st));
+        HIPCHK(launch_slack(qnorm2, nq, q_pad, eps_rel, idx->pend.eps_round, idx->maxnorm2, qerr2, idx->maxerr2, idx->metric == TRX_METRIC_L2 ? 1 : 0, (float*)pl.slk.p, st));
         sp.slack = (const float*)pl.slk.p;
     }
     // The integer class has an int8 form of the scan (knn_scan.hip, I8: twice the MACs per instruction, half the bytes per
@@ -556,6 +558,7 @@ static int search_batch(trx_index* idx, const void* q, const float* qnorm2, int6
     se.query_orig = q; se.ld_q = d; se.query_is_bf16 = is_bf;
     se.d = d; se.metric = idx->metric; se.k = kf; se.nq = (int)nq; se.n = idx->n; se.exact_class = (const int*)idx->w_cls.p;
     se.eps_rel = eps_rel; se.eps_round = idx->pend.eps_round; se.qnorm2 = qnorm2; se.ymax_norm2 = idx->maxnorm2;
+    se.qerr2 = qerr2; se.yerr2_max = idx->maxerr2;
     se.D = D; se.I = I; se.S64 = S64; se.flagged = flagged; se.nflagged = nflag; se.flag_seed = seed1; se.compact = 0;
     if (bigk) {      // the first scan's 24 exact scores per query go to a scratch of their own
         if ((rc = pl.d1.reserve((size_t)q_pad * kf * sizeof(float)))) return rc;
@@ -612,7 +615,7 @@ static int search_batch(trx_index* idx, const void* q, const float* qnorm2, int6
         //   third scan has room for, [2] unproven after that (-> exact scan)
         HIPCHK(hipMemsetAsync(nflag, 0, 4 * sizeof(int), st));      // (the select kernel's flags concerned the 24)
         HIPCHK(launch_bigk_seeds(idx->metric == TRX_METRIC_L2 ? 1 : 0, (const float*)pl.d1.p, (const int64_t*)pl.i1.p, (int)nq, kf, k, qnorm2, eps_rel,
-                                 idx->pend.eps_round, idx->maxnorm2, flagged2, nflag + 1, seed2, st));
+                                 idx->pend.eps_round, idx->maxnorm2, qerr2, idx->maxerr2, flagged2, nflag + 1, seed2, st));
         const int rq2 = (int)q_pad;
         if ((rc = pl.qg2.reserve((size_t)rq2 * Kp * sizeof(bf16_t)))) return rc;
         if ((rc = pl.gthr2.reserve((size_t)rq2 * 4 * sizeof(u32)))) return rc;
@@ -770,8 +773,13 @@ static int search_device_core(trx_index* idx, const void* q, int64_t nq, int dty
     rc = idx->w_stats.reserve(sizeof(HostStats)); if (rc) return rc;
     HIPCHK(hipMemsetAsync(idx->w_stats.p, 0, sizeof(HostStats), st));
     // one pass over the queries: the class flags and every query's fp32 norm (the select kernel's error bound)
-    rc = idx->w_qnorm2.reserve((size_t)round_up64(nq, TILE_N) * sizeof(float)); if (rc) return rc;
-    HIPCHK(launch_row_stats(q, is_bf, nq, d, d, idx->w_stats.p, (float*)idx->w_qnorm2.p, st));
+    // ... and, for fp32 queries, the norm of its rounding error to bf16 (second half of the buffer): with the corpus side's
+    // maximum it replaces the a-priori rounding bound of the approximate mode by a measured one (knn_common.h: round_term;
+    // TRX_ROUND_BOUND_APRIORI=1 keeps round 4's bound, the A/B switch)
+    const int64_t nq_pad = round_up64(nq, TILE_N);
+    rc = idx->w_qnorm2.reserve((size_t)2 * nq_pad * sizeof(float)); if (rc) return rc;
+    float* qerr2_all = getenv("TRX_ROUND_BOUND_APRIORI") ? nullptr : (float*)idx->w_qnorm2.p + nq_pad;
+    HIPCHK(launch_row_stats(q, is_bf, nq, d, d, idx->w_stats.p, (float*)idx->w_qnorm2.p, qerr2_all, st));
     // The ONE host decision a search can need: fp32 queries that are not exact in bf16 against an index that holds only
     // bf16 data turn the index into its split form.  bf16 queries are exact by construction, and a split index stays
     // split, so only fp32 queries on a plain index read their statistics back; everything else stays on the device.
@@ -817,7 +825,8 @@ static int search_device_core(trx_index* idx, const void* q, int64_t nq, int dty
     if ((rc = idx->w_exact.reserve((size_t)INLINE_FALLBACK * idx->n * sizeof(double)))) return rc;
     for (int64_t q0 = 0; q0 < nq; q0 += QB) {
         const int64_t m = std::min(QB, nq - q0);
-        rc = search_batch(idx, (const char*)q + (size_t)q0 * d * esz, (const float*)idx->w_qnorm2.p + q0, m, is_bf, q_split, (int)(q0 / QB), eps_rel, k,
+        rc = search_batch(idx, (const char*)q + (size_t)q0 * d * esz, (const float*)idx->w_qnorm2.p + q0, qerr2_all ? qerr2_all + q0 : nullptr, m, is_bf, q_split,
+                          (int)(q0 / QB), eps_rel, k,
                           D + q0 * k, I + q0 * k, S64 ? S64 + q0 * k : nullptr, st);
         if (rc) return rc;
     }

@@ -104,6 +104,25 @@ __device__ __forceinline__ void wave_sort_pairs(u64& skey, u32& id, int lane) {
     }
 }
 
+// ---- the operand-rounding share of a key's error (approximate operands: the scan sees the bf16 roundings x^ = x + dx, y^ = y + dy
+// of fp32 data) ----
+//   x^.y^ - x.y = dx.y^ + x.dy   =>   |x^.y^ - x.y| <= |dx| |y^| + |x| |dy| <= |dx| (1 + 2^-8) max|y| + |x| max|dy|
+// A priori |dx| <= 2^-8 |x| elementwise, which gives eps_round |x| max|y| with eps_round = 2^-7 (1 + 2^-8) -- rounds 4's bound.
+// Round 5 measures the norms instead: |dx|^2 per query comes out of the statistics pass that rounds the queries anyway, max|dy|^2
+// out of the passes over the corpus blocks at add time.  On real-valued data a rounding error is uniform inside its half-ulp, so
+// the norms are ~ 0.29 of their a-priori bound and the listing slack and the certificate's epsilon shrink 3.4 x; the bound stays
+// rigorous (Cauchy-Schwarz on the measured vectors; 1.001 covers the fp32 accumulation of the two sums of squares).  L2: the key
+// is 2 x.y - |y|^2 with |y|^2 from the exact rows: twice the product's error.  qerr2 == nullptr: the a-priori bound.
+__device__ __forceinline__ double round_term(float eps_round, float bx, float xn2, const float* qerr2, int64_t q, float ymax_norm2,
+                                             float yerr2_max, bool l2) {
+    if (eps_round == 0.f) return 0.0;
+    const double apriori = (double)eps_round * (double)bx;
+    if (!qerr2) return apriori;
+    const double e = sqrt((double)qerr2[q]) * sqrt((double)ymax_norm2) * (1.0 + 1.0 / 256.0) + sqrt((double)xn2) * sqrt((double)yerr2_max);
+    const double measured = (l2 ? 2.0 : 1.0) * e * 1.001;
+    return measured < apriori ? measured : apriori;
+}
+
 // ---- parameters ----------------------------------------------------------------------------
 struct ScanParams {
     const bf16_t* corpus;    // [n_pad + TILE_M][Kp] bf16, n_pad multiple of TILE_M, pad rows zero
@@ -159,6 +178,8 @@ struct SelectParams {
     const int* exact_class;   // DEVICE int: 1 = no certificate needed (integer inputs, every partial sum exact)
     float eps_rel;            // certificate slack, relative to bound_q
     float eps_round;          // approximate operands (knn_api.hip, approx mode): their rounding's share of the key error, relative to |x||y| (L2: 2|x||y|)
+    const float* qerr2;       // optional [nq]: |x_q - bf16(x_q)|^2, the rounding error norm of each query (0 for bf16 queries); with
+    float yerr2_max;          // max over the corpus of |y - bf16(y)|^2 it turns the a-priori bound into round_term()'s measured one
     const float* qnorm2;      // fp32 |x_q|^2 (upper-bound use only)
     float ymax_norm2;         // max |y|^2 over the corpus
     float* D;

@@ -20,6 +20,7 @@ struct RowStats {          // device-side accumulators (zeroed before each pass)
     u32 maxabs_bits;       // max |v| as float bits (non-negative floats order like uints)
     u32 maxnorm2_bits;     // max over rows of |row|^2
     u32 nonfp4_any;        // some |value| is not one of 0, 1, 2, 3, 4, 6 (the integers E2M1 holds: the fp4 form of the scan)
+    u32 maxerr2_bits;      // max over rows of |row - bf16(row)|^2 (fp32 rows; knn_common.h: round_term)
 };
 
 template <bool BF>
@@ -32,26 +33,31 @@ __device__ __forceinline__ float load_val(const void* p, int64_t i) {
 // allow it (d and the row stride multiples of 8 bf16 / 4 f32): 4 TB/s class instead of the
 // 0.16 TB/s the 2-byte-per-lane form reached (it was 1.3 % of a C1 search).
 template <bool BF>
-__device__ __forceinline__ void stat_one(float v, float& s, float& maxabs, u32& inexact, u32& nonint) {
+__device__ __forceinline__ void stat_one(float v, float& s, float& maxabs, u32& inexact, u32& nonint, float& e2) {
     s = __builtin_fmaf(v, v, s);
     const float a = fabsf(v);
     maxabs = fmaxf(maxabs, a);
-    if (!BF) inexact |= (bf16_to_f32(f32_to_bf16_rn(v)) != v) ? 1u : 0u;
+    if (!BF) {
+        const float r = bf16_to_f32(f32_to_bf16_rn(v));
+        inexact |= (r != v) ? 1u : 0u;
+        const float dv = v - r;             // exact (r is within 2^-8 of v)
+        e2 = __builtin_fmaf(dv, dv, e2);
+    }
     nonint |= ((rintf(v) != v) ? 1u : 0u) | ((a > 4.f && a != 6.f) ? 2u : 0u);      // bit 1: beyond the integers of E2M1
 }
 template <bool BF>
 __global__ __launch_bounds__(256) void row_stats_kernel(const void* x, int64_t n, int d, int64_t ld,
-                                                        RowStats* st, float* norm2) {
+                                                        RowStats* st, float* norm2, float* err2) {
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * 4;
     constexpr int VEC = BF ? 8 : 4;
     const bool vec = (d % VEC == 0) && (ld % VEC == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
     u32 inexact = 0, nonint = 0;
-    float maxabs = 0.f, maxn2 = 0.f;
+    float maxabs = 0.f, maxn2 = 0.f, maxe2 = 0.f;
     for (int64_t r = wave0; r < n; r += nwaves) {
         const char* row = reinterpret_cast<const char*>(x) + r * ld * (BF ? 2 : 4);
-        float s = 0.f;
+        float s = 0.f, e2 = 0.f;
         if (vec) {
             for (int c = lane * VEC; c < d; c += 64 * VEC) {
                 const uint4 u = *reinterpret_cast<const uint4*>(row + (size_t)c * (BF ? 2 : 4));
@@ -59,20 +65,22 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const void* x, int64_t n
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     if (BF) {
-                        stat_one<BF>(__uint_as_float(w[i] << 16), s, maxabs, inexact, nonint);
-                        stat_one<BF>(__uint_as_float(w[i] & 0xffff0000u), s, maxabs, inexact, nonint);
+                        stat_one<BF>(__uint_as_float(w[i] << 16), s, maxabs, inexact, nonint, e2);
+                        stat_one<BF>(__uint_as_float(w[i] & 0xffff0000u), s, maxabs, inexact, nonint, e2);
                     } else {
-                        stat_one<BF>(__uint_as_float(w[i]), s, maxabs, inexact, nonint);
+                        stat_one<BF>(__uint_as_float(w[i]), s, maxabs, inexact, nonint, e2);
                     }
                 }
             }
         } else {
-            for (int i = lane; i < d; i += 64) stat_one<BF>(load_val<BF>(row, i), s, maxabs, inexact, nonint);
+            for (int i = lane; i < d; i += 64) stat_one<BF>(load_val<BF>(row, i), s, maxabs, inexact, nonint, e2);
         }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); e2 += __shfl_xor(e2, o, 64); }
         if (lane == 0 && norm2) norm2[r] = s;
+        if (lane == 0 && err2) err2[r] = e2;
         maxn2 = fmaxf(maxn2, s);
+        maxe2 = fmaxf(maxe2, e2);
     }
     // wave-reduce, then block-reduce through LDS: ONE set of atomics per block (the four counters
     // are single addresses; 65k waves x 2 atomics on them took longer than streaming the data)
@@ -80,13 +88,14 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const void* x, int64_t n
     for (int o = 32; o > 0; o >>= 1) {
         maxabs = fmaxf(maxabs, __shfl_xor(maxabs, o, 64));
         maxn2 = fmaxf(maxn2, __shfl_xor(maxn2, o, 64));
+        maxe2 = fmaxf(maxe2, __shfl_xor(maxe2, o, 64));
         inexact |= __shfl_xor(inexact, o, 64);
         nonint |= __shfl_xor(nonint, o, 64);
     }
-    __shared__ float sh_abs[4], sh_n2[4];
+    __shared__ float sh_abs[4], sh_n2[4], sh_e2[4];
     __shared__ u32 sh_flags[4];
     const int w = threadIdx.x >> 6;
-    if (lane == 0) { sh_abs[w] = maxabs; sh_n2[w] = maxn2; sh_flags[w] = (inexact ? 1u : 0u) | ((nonint & 1u) ? 2u : 0u) | ((nonint & 3u) ? 4u : 0u); }
+    if (lane == 0) { sh_abs[w] = maxabs; sh_n2[w] = maxn2; sh_e2[w] = maxe2; sh_flags[w] = (inexact ? 1u : 0u) | ((nonint & 1u) ? 2u : 0u) | ((nonint & 3u) ? 4u : 0u); }
     __syncthreads();
     if (threadIdx.x == 0) {
         float a = fmaxf(fmaxf(sh_abs[0], sh_abs[1]), fmaxf(sh_abs[2], sh_abs[3]));
@@ -97,6 +106,7 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const void* x, int64_t n
         if (f & 4u) atomicOr(&st->nonfp4_any, 1u);
         atomicMax(&st->maxabs_bits, __float_as_uint(a));
         atomicMax(&st->maxnorm2_bits, __float_as_uint(m));
+        atomicMax(&st->maxerr2_bits, __float_as_uint(fmaxf(fmaxf(sh_e2[0], sh_e2[1]), fmaxf(sh_e2[2], sh_e2[3]))));
     }
 }
 
@@ -168,7 +178,8 @@ __global__ __launch_bounds__(256) void build_operand_kernel(const void* x, int64
 
 // The listing slack of the approximate mode (knn_api.hip): 2 eps_q in the scan's accumulator units (the L2 form carries key / 2),
 // with eps_q computed exactly as the select kernel computes it (knn_select.hip: the certificate's bound), rounded up.
-__global__ void slack_kernel(const float* qnorm2, int64_t nq, int64_t q_pad, float eps_rel, float eps_round, float ymax_norm2, int l2, float* out) {
+__global__ void slack_kernel(const float* qnorm2, int64_t nq, int64_t q_pad, float eps_rel, float eps_round, float ymax_norm2, const float* qerr2,
+                             float yerr2_max, int l2, float* out) {
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= q_pad) return;
     float r = 0.f;
@@ -176,7 +187,7 @@ __global__ void slack_kernel(const float* qnorm2, int64_t nq, int64_t q_pad, flo
         const float xn2 = qnorm2[q];
         const float bq = l2 ? (2.0f * sqrtf(xn2 * ymax_norm2) + ymax_norm2) : sqrtf(xn2 * ymax_norm2);
         const float bx = l2 ? 2.0f * sqrtf(xn2 * ymax_norm2) : sqrtf(xn2 * ymax_norm2);
-        const double eps = ((double)eps_rel * (double)bq + (double)eps_round * (double)bx) * 1.0001 + 1e-30;
+        const double eps = ((double)eps_rel * (double)bq + round_term(eps_round, bx, xn2, qerr2, q, ymax_norm2, yerr2_max, l2 != 0)) * 1.0001 + 1e-30;
         const double sl = l2 ? eps : 2.0 * eps;        // 2 eps in key units = eps in units of key / 2
         r = (float)sl;
         if ((double)r < sl) r = nextafterf(r, __builtin_inff());
@@ -184,9 +195,10 @@ __global__ void slack_kernel(const float* qnorm2, int64_t nq, int64_t q_pad, flo
     }
     out[q] = r;
 }
-hipError_t launch_slack(const float* qnorm2, int64_t nq, int64_t q_pad, float eps_rel, float eps_round, float ymax_norm2, int l2, float* out, hipStream_t st) {
+hipError_t launch_slack(const float* qnorm2, int64_t nq, int64_t q_pad, float eps_rel, float eps_round, float ymax_norm2, const float* qerr2,
+                        float yerr2_max, int l2, float* out, hipStream_t st) {
     if (q_pad <= 0) return hipSuccess;
-    hipLaunchKernelGGL(slack_kernel, dim3((unsigned)((q_pad + 255) / 256)), dim3(256), 0, st, qnorm2, nq, q_pad, eps_rel, eps_round, ymax_norm2, l2, out);
+    hipLaunchKernelGGL(slack_kernel, dim3((unsigned)((q_pad + 255) / 256)), dim3(256), 0, st, qnorm2, nq, q_pad, eps_rel, eps_round, ymax_norm2, qerr2, yerr2_max, l2, out);
     return hipGetLastError();
 }
 
@@ -282,16 +294,16 @@ __global__ void widen_rows_kernel(const bf16_t* in, int64_t n, int d, int64_t ld
 }
 
 hipError_t launch_row_stats(const void* x, int is_bf16, int64_t n, int d, int64_t ld, void* stats_dev,
-                            float* norm2, hipStream_t st) {
+                            float* norm2, float* err2, hipStream_t st) {
     if (n <= 0) return hipSuccess;
     int64_t blocks = (n + 3) / 4;
     if (blocks > 2048) blocks = 2048;
     if (is_bf16)
         hipLaunchKernelGGL(row_stats_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, x, n, d, ld,
-                           reinterpret_cast<RowStats*>(stats_dev), norm2);
+                           reinterpret_cast<RowStats*>(stats_dev), norm2, err2);
     else
         hipLaunchKernelGGL(row_stats_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, x, n, d, ld,
-                           reinterpret_cast<RowStats*>(stats_dev), norm2);
+                           reinterpret_cast<RowStats*>(stats_dev), norm2, err2);
     return hipGetLastError();
 }
 

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const float xn2 = p.qnorm2[q];
         const float bq = L2 ? (2.0f * sqrtf(xn2 * p.ymax_norm2) + p.ymax_norm2) : sqrtf(xn2 * p.ymax_norm2);
         const float bx = L2 ? 2.0f * sqrtf(xn2 * p.ymax_norm2) : sqrtf(xn2 * p.ymax_norm2);      // what operand rounding scales with: the product term alone
-        const double eps = ((double)p.eps_rel * (double)bq + (double)p.eps_round * (double)bx) * 1.0001 + 1e-30;
+        const double eps = ((double)p.eps_rel * (double)bq + round_term(p.eps_round, bx, xn2, p.qerr2, q, p.ymax_norm2, p.yerr2_max, L2)) * 1.0001 + 1e-30;
         // ---- 1b. epsilon window: |approximate - exact| <= eps for every row, so the k candidates with the best
         // approximate keys all have exact keys >= a_k - eps (a_k = the k-th best approximate key); a candidate whose
         // approximate key is below a_k - 2 eps has an exact key < a_k - eps and cannot reach the top k: it is not
@@ -568,7 +568,7 @@ __global__ __launch_bounds__(256) void wide_rescore_kernel(SelectParams p, const
             const float xn2 = p.qnorm2[q];
             const float bq = L2 ? (2.0f * sqrtf(xn2 * p.ymax_norm2) + p.ymax_norm2) : sqrtf(xn2 * p.ymax_norm2);
             const float bx = L2 ? 2.0f * sqrtf(xn2 * p.ymax_norm2) : sqrtf(xn2 * p.ymax_norm2);      // what operand rounding scales with: the product term alone
-            const double eps = ((double)p.eps_rel * (double)bq + (double)p.eps_round * (double)bx) * 1.0001 + 1e-30;
+            const double eps = ((double)p.eps_rel * (double)bq + round_term(p.eps_round, bx, xn2, p.qerr2, q, p.ymax_norm2, p.yerr2_max, L2)) * 1.0001 + 1e-30;
             const double bound = (double)comp_key(T) + eps;
             double xx = 0.0;
             if (L2) for (int i = 0; i < p.d; ++i) { const double v = load_as_double<QBF>(qrow, i); xx = __builtin_fma(v, v, xx); }
@@ -591,7 +591,7 @@ __global__ __launch_bounds__(256) void wide_rescore_kernel(SelectParams p, const
                 const float xn2 = p.qnorm2[q];
                 const float bq = L2 ? (2.0f * sqrtf(xn2 * p.ymax_norm2) + p.ymax_norm2) : sqrtf(xn2 * p.ymax_norm2);
                 const float bx = L2 ? 2.0f * sqrtf(xn2 * p.ymax_norm2) : sqrtf(xn2 * p.ymax_norm2);      // what operand rounding scales with: the product term alone
-                const double eps = ((double)p.eps_rel * (double)bq + (double)p.eps_round * (double)bx) * 1.0001 + 1e-30;
+                const double eps = ((double)p.eps_rel * (double)bq + round_term(p.eps_round, bx, xn2, p.qerr2, q, p.ymax_norm2, p.yerr2_max, L2)) * 1.0001 + 1e-30;
                 double xx = 0.0;
                 if (L2) for (int i = 0; i < p.d; ++i) { const double v = load_as_double<QBF>(qrow, i); xx = __builtin_fma(v, v, xx); }
                 if (got >= p.k && !exact_class && !overflow) {
@@ -648,7 +648,7 @@ hipError_t launch_wide_rescore(const SelectParams& p, const int* flagged, const 
 // Every query is "flagged": the list is the identity.
 template <bool L2>
 __global__ void bigk_seed_kernel(const float* D1, const int64_t* I1, int nq, int kf, int k, const float* qnorm2, float eps_rel, float eps_round,
-                                 float ymax_norm2, int* list, int* count, float* seed) {
+                                 float ymax_norm2, const float* qerr2, float yerr2_max, int* list, int* count, float* seed) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q == 0) *count = nq;
     if (q >= nq) return;
@@ -660,7 +660,7 @@ __global__ void bigk_seed_kernel(const float* D1, const int64_t* I1, int nq, int
         const double kl = L2 ? (double)xn2 - (double)D1[(int64_t)q * kf + kf - 1] : (double)D1[(int64_t)q * kf + kf - 1];
         const float bq = L2 ? (2.0f * sqrtf(xn2 * ymax_norm2) + ymax_norm2) : sqrtf(xn2 * ymax_norm2);
         const float bx = L2 ? 2.0f * sqrtf(xn2 * ymax_norm2) : sqrtf(xn2 * ymax_norm2);
-        const double eps = ((double)eps_rel * (double)bq + (double)eps_round * (double)bx) * 1.0001 + 1e-30;
+        const double eps = ((double)eps_rel * (double)bq + round_term(eps_round, bx, xn2, qerr2, q, ymax_norm2, yerr2_max, L2)) * 1.0001 + 1e-30;
         // the spacings of the order statistics of an exponential tail are exponentials of mean c / r: s_kf - s_k has mean
         // c ln(k / kf) and deviation c sqrt(1 / kf - 1 / k).  c from ALL kf scores (the mean of r (s_r - s_r+1), each an
         // exponential of mean c: a fifth of the noise of the one difference s_1 - s_kf).  1.8 means + 2.5 deviations: on
@@ -680,11 +680,11 @@ __global__ void bigk_seed_kernel(const float* D1, const int64_t* I1, int nq, int
     seed[q] = sd;
 }
 hipError_t launch_bigk_seeds(int metric, const float* D1, const int64_t* I1, int nq, int kf, int k, const float* qnorm2, float eps_rel, float eps_round,
-                             float ymax_norm2, int* list, int* count, float* seed, hipStream_t st) {
+                             float ymax_norm2, const float* qerr2, float yerr2_max, int* list, int* count, float* seed, hipStream_t st) {
     if (nq <= 0) return hipSuccess;
     dim3 grid((unsigned)((nq + 255) / 256)), block(256);
-    if (metric) hipLaunchKernelGGL(bigk_seed_kernel<true>, grid, block, 0, st, D1, I1, nq, kf, k, qnorm2, eps_rel, eps_round, ymax_norm2, list, count, seed);
-    else hipLaunchKernelGGL(bigk_seed_kernel<false>, grid, block, 0, st, D1, I1, nq, kf, k, qnorm2, eps_rel, eps_round, ymax_norm2, list, count, seed);
+    if (metric) hipLaunchKernelGGL(bigk_seed_kernel<true>, grid, block, 0, st, D1, I1, nq, kf, k, qnorm2, eps_rel, eps_round, ymax_norm2, qerr2, yerr2_max, list, count, seed);
+    else hipLaunchKernelGGL(bigk_seed_kernel<false>, grid, block, 0, st, D1, I1, nq, kf, k, qnorm2, eps_rel, eps_round, ymax_norm2, qerr2, yerr2_max, list, count, seed);
     return hipGetLastError();
 }
 

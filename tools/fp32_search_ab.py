@@ -20,7 +20,9 @@ for metric in ("IP", "L2"):
     st = idx.last_stats()
     import json
     print(json.dumps({"what": "exact top-10, %d x 768 fp32 corpus, %d fp32 queries, one MI355X" % (n, nq), "metric": metric,
-                      "form": "three-term split (TRX_FP32_SPLIT=1)" if os.environ.get("TRX_FP32_SPLIT") else "approx mode (bf16 rounding + listing slack)",
+                      "form": "three-term split (TRX_FP32_SPLIT=1)" if os.environ.get("TRX_FP32_SPLIT") else
+                              ("approx mode, a-priori rounding bound (TRX_ROUND_BOUND_APRIORI=1: round 4)" if os.environ.get("TRX_ROUND_BOUND_APRIORI") else
+                               "approx mode (bf16 rounding + listing slack from the measured rounding-error norms: round 5)"),
                       "K": st["k_split"], "search_ms": (t1 - t0) * 1e3, "scan_ms": st["scan_ms"], "queries_per_s": nq / (t1 - t0),
                       "n_rescored": st["n_rescored"], "n_rescanned": st["n_rescanned"], "n_uncertified": st["n_uncertified"],
                       "checksum_I": int(I.sum().item()) % 1000003, "checksum_D": float(D.double().sum().item())}), flush=True)
