@@ -535,6 +535,37 @@ static int search_batch(trx_index* idx, const void* q, const float* qnorm2, cons
             cyc += (double)h[i]; comp += (double)h[i + 1]; tiles += (double)h[i + 3];
             wt += (double)h[i + 4]; bl += (double)h[i + 5]; mf += (double)h[i + 6]; bm += (double)h[i + 7]; ld += (double)h[i + 8]; rounds += (double)h[i + 9];
         }
+        // how far apart the workgroups that share a corpus stream run: the stream of split s is read by the 8 query tiles an XCD
+        // holds together (v = qtile * nsplits + split, 32 consecutive v per XCD and round); spread = latest - earliest wall clock
+        // (s_memrealtime, 100 MHz) at the head of the split's middle tile, per sharing group
+        {
+            // the kernel's block remap: XCD x gets the contiguous range of v whose size is q or q + 1 (xcd_remap in knn_scan.hip)
+            std::vector<double> mid((size_t)nwg, 0.0);
+            const int qd = nwg >> 3, rr = nwg & 7;
+            for (int bid = 0; bid < nwg; ++bid) {
+                const int x = bid & 7;
+                const int base = x < rr ? x * (qd + 1) : rr * (qd + 1) + (x - rr) * qd;
+                const int v = base + (bid >> 3);
+                mid[v] = (double)h[((size_t)bid * 8 + 0) * 12 + 10];       // wave 0 of the block
+            }
+            double sum = 0, mx = 0; int groups = 0;
+            for (int x = 0; x < 8; ++x) {
+                const int base = x < rr ? x * (qd + 1) : rr * (qd + 1) + (x - rr) * qd, cnt = x < rr ? qd + 1 : qd;
+                for (int c0 = 0; c0 < cnt; c0 += 32) {
+                    for (int sp = 0; sp < nsplits; ++sp) {
+                        double lo = 1e300, hi = 0; int members = 0;
+                        for (int j = c0; j < std::min(cnt, c0 + 32); ++j) {
+                            const int v = base + j;
+                            if (v % nsplits != sp || mid[v] == 0.0) continue;
+                            lo = std::min(lo, mid[v]); hi = std::max(hi, mid[v]); ++members;
+                        }
+                        if (members >= 2) { sum += (hi - lo) * 0.01; mx = std::max(mx, (hi - lo) * 0.01); ++groups; }
+                    }
+                }
+            }
+            if (groups) fprintf(stderr, "[stamp] workgroups sharing a corpus stream (%d groups): mean spread %.1f us, largest %.1f us at the head of the middle tile "
+                                        "(a tile takes ~17.5 us, an L2 line lives ~12 us)\n", groups, sum / groups, mx);
+        }
         // (s_memtime ticks are shader cycles)
         if (rounds > 0)
             fprintf(stderr, "[stamp] per wave and L/M round (shader cycles): load issue %.2f, counter waits %.2f, barrier after L %.2f, MFMA phase %.2f, barrier after M %.2f "

@@ -845,7 +845,13 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
 
     // The bookkeeping of tile tl-1 lives in the first load phase of tile tl; after the last tile that phase runs
     // once more on its own (its reads and pieces are never used: the corpus has a spare tile behind its last row).
+#ifdef TRX_STAMP_BUILD
+    unsigned long long st_mid = 0ull;      // wall clock (100 MHz) at the head of the split's middle tile: how far apart the sharers of a stream run
+#endif
     for (int tl = 0;; ++tl) {
+#ifdef TRX_STAMP_BUILD
+        if (tl == (ntl >> 1)) st_mid = __builtin_amdgcn_s_memrealtime();
+#endif
         TRX_PAIR_HEAD();
         if (tl == ntl) break;
         TRX_PAIR_REST(true, false);
@@ -929,7 +935,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void knn_scan_kernel(ScanParams p)
     if (p.stamp_out && lane == 0) {
         unsigned long long* o = p.stamp_out + ((size_t)blockIdx.x * 8 + wave) * 12;
         o[0] = st_cyc; o[1] = st_comp; o[2] = 0ull; o[3] = (unsigned long long)ntl;
-        o[4] = a_wt; o[5] = a_bl; o[6] = a_mf; o[7] = a_bm; o[8] = a_ld; o[9] = a_n; o[10] = 0ull; o[11] = 0ull;
+        o[4] = a_wt; o[5] = a_bl; o[6] = a_mf; o[7] = a_bm; o[8] = a_ld; o[9] = a_n; o[10] = st_mid; o[11] = __builtin_amdgcn_s_memrealtime();
     }
 #endif
     // ---- publish count and bound of this lane's 4 lists ----
