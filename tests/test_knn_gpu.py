@@ -666,6 +666,33 @@ def test_cli_on_the_real_index(tmp_path):
     assert [e["nn"] for e in got] == I.tolist() and [e["id"] for e in got] == list(range(2000, 2050))
 
 
+def test_cli_tie_rule_flag_gives_the_order_of_the_faiss_heap(tmp_path, monkeypatch):
+    """--metric ip over sparse integer count vectors: integer scores, ties in every list.  --tie_rule faiss writes the neighbour lists the
+    literal restatement of FAISS's heap (oracle.knn_faiss) returns; without the flag ties go smaller id first"""
+    import json
+    import pandas as pd
+    import textreact_amd.retrieve_faiss as rf
+    from oracle import flat_knn as oracle
+    monkeypatch.setenv("TRX_TIE_RULE", "id")                    # main() sets it; monkeypatch puts the environment back
+    fps = reaction_fp_like(700, 256, 9)
+    pd.DataFrame({"id": np.arange(600), "canonical_rxn": ["C>>C"] * 600}).to_csv(tmp_path / "train.csv", index=False)
+    pd.DataFrame({"id": np.arange(50) + 1000, "canonical_rxn": ["C>>C"] * 50}).to_csv(tmp_path / "val.csv", index=False)
+    pd.DataFrame({"id": np.arange(50) + 2000, "canonical_rxn": ["C>>C"] * 50}).to_csv(tmp_path / "test.csv", index=False)
+    for name, sl in (("train", slice(0, 600)), ("val", slice(600, 650)), ("test", slice(650, 700))):
+        np.save(tmp_path / (name + ".npy"), fps[sl].astype(np.float32))
+    argv = ["--data_path", str(tmp_path), "--train_file", "train.csv", "--valid_file", "val.csv", "--test_file", "test.csv",
+            "--train_vectors", str(tmp_path / "train.npy"), "--valid_vectors", str(tmp_path / "val.npy"),
+            "--test_vectors", str(tmp_path / "test.npy"), "--metric", "ip"]
+    rf.main(argv + ["--output_path", str(tmp_path / "faiss"), "--tie_rule", "faiss"])
+    rf.main(argv + ["--output_path", str(tmp_path / "id"), "--tie_rule", "id"])
+    got_f = [e["nn"] for e in json.loads((tmp_path / "faiss" / "test.json").read_text())]
+    got_i = [e["nn"] for e in json.loads((tmp_path / "id" / "test.json").read_text())]
+    _, If = oracle.knn_faiss(IP, fps[650:], fps[:600], 20)
+    _, Ic = oracle.knn_canonical(IP, fps[650:], fps[:600], 20)
+    assert got_f == If.tolist() and got_i == Ic.tolist()
+    assert got_f != got_i                                        # the inputs do tell the two rules apart
+
+
 # ---- BASELINE.json configs[1] at full size: size-independent properties + a sampled oracle check
 def test_c1_full_size_properties():
     import torch

@@ -180,38 +180,63 @@ __global__ __launch_bounds__(256) void add_ln_fwd_vec_kernel(const void* x, cons
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int nchunk = cols / V;
+    // Every load of the row first -- x, res, the bias of x, gamma, beta, as whole 16- / 8-byte pieces with no branch between
+    // them (an absent operand is read from gamma and ANDed away, a chunk past the row's end re-reads the last one) -- then the
+    // arithmetic: the row costs one memory latency, not one per operand and chunk (round 5; see the backward).
     const char* xr = reinterpret_cast<const char*>(x) + row * cols * ((BF || MIX) ? 2 : 4);
-    const char* rr = res ? reinterpret_cast<const char*>(res) + row * cols * (BF ? 2 : 4) : nullptr;
+    const bool has_res = res != nullptr, has_xb = MIX && xbias != nullptr;
+    const char* rr = has_res ? reinterpret_cast<const char*>(res) + row * cols * (BF ? 2 : 4) : reinterpret_cast<const char*>(gamma);
+    const char* xbp = reinterpret_cast<const char*>(has_xb ? xbias : gamma);
+    const unsigned m_res = has_res ? ~0u : 0u, m_xb = has_xb ? ~0u : 0u;
     char* yr = reinterpret_cast<char*>(y) + row * cols * (BF ? 2 : 4);
+    uint4 rx4[MIX ? 1 : NC], rres[NC], rxb[MIX ? NC : 1], rg[NC][V / 4], rb[NC][V / 4];
+    uint2 rx2[MIX ? NC : 1];
+    unsigned lm[NC];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int c = lane + 64 * i;
+        lm[i] = c < nchunk ? ~0u : 0u;
+        const unsigned o16 = (unsigned)min(c, nchunk - 1) * 16u;
+        if (MIX) {
+            rx2[i] = *reinterpret_cast<const uint2*>(xr + (o16 >> 1));
+            rxb[i] = *reinterpret_cast<const uint4*>(xbp + o16);
+        } else rx4[i] = *reinterpret_cast<const uint4*>(xr + o16);
+        rres[i] = *reinterpret_cast<const uint4*>(rr + o16);
+    }
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const size_t oc = (size_t)min(lane + 64 * i, nchunk - 1) * V;
+#pragma unroll
+        for (int j = 0; j < V / 4; ++j) {
+            rg[i][j] = *reinterpret_cast<const uint4*>(gamma + oc + 4 * j);
+            rb[i][j] = *reinterpret_cast<const uint4*>(beta + oc + 4 * j);
+        }
+    }
     float v[NC][V];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
         const int c = lane + 64 * i;
-        if (c < nchunk) {
-            if (MIX) unpack8bf(*reinterpret_cast<const uint2*>(xr + (size_t)c * 8), v[i]);
-            else unpack16<BF>(*reinterpret_cast<const uint4*>(xr + (size_t)c * 16), v[i]);
-            if (MIX && xbias) {   // the bias of the Linear that produced x, kept out of its GEMM (see the backward)
+        if (MIX) {
+            unpack8bf(make_uint2(rx2[i].x & lm[i], rx2[i].y & lm[i]), v[i]);
+            // the bias of the Linear that produced x, kept out of its GEMM (see the backward)
+            const unsigned k = m_xb & lm[i];
+            v[i][0] += __uint_as_float(rxb[i].x & k); v[i][1] += __uint_as_float(rxb[i].y & k);
+            v[i][2] += __uint_as_float(rxb[i].z & k); v[i][3] += __uint_as_float(rxb[i].w & k);
+        } else unpack16<BF>(make_uint4(rx4[i].x & lm[i], rx4[i].y & lm[i], rx4[i].z & lm[i], rx4[i].w & lm[i]), v[i]);
+        if (drop.thr) {   // dropout acts on x only, before the residual is added
 #pragma unroll
-                for (int j = 0; j < V; ++j) v[i][j] += xbias[c * V + j];
+            for (int j = 0; j < V; j += 2) {
+                const unsigned bits = drop_bits(drop.base, (unsigned)row, (unsigned)(c * V + j) >> 1);
+                v[i][j] *= drop_keep(bits, 0, drop.thr) ? drop.inv_keep : 0.f;
+                v[i][j + 1] *= drop_keep(bits, 1, drop.thr) ? drop.inv_keep : 0.f;
             }
-            if (drop.thr) {   // dropout acts on x only, before the residual is added
-#pragma unroll
-                for (int j = 0; j < V; j += 2) {
-                    const unsigned bits = drop_bits(drop.base, (unsigned)row, (unsigned)(c * V + j) >> 1);
-                    v[i][j] *= drop_keep(bits, 0, drop.thr) ? drop.inv_keep : 0.f;
-                    v[i][j + 1] *= drop_keep(bits, 1, drop.thr) ? drop.inv_keep : 0.f;
-                }
-            }
-            if (rr) {
-                float r[V];
-                unpack16<BF>(*reinterpret_cast<const uint4*>(rr + (size_t)c * 16), r);
-#pragma unroll
-                for (int j = 0; j < V; ++j) v[i][j] += r[j];
-            }
-#pragma unroll
-            for (int j = 0; j < V; ++j) s += v[i][j];
         }
+        float r[V];
+        const unsigned k = m_res & lm[i];
+        unpack16<BF>(make_uint4(rres[i].x & k, rres[i].y & k, rres[i].z & k, rres[i].w & k), r);
+#pragma unroll
+        for (int j = 0; j < V; ++j) { v[i][j] += r[j]; s += v[i][j]; }      // (a chunk past the row's end holds zeros)
     }
     const float mu = wave_sum(s) / (float)cols;
     float q = 0.f;
@@ -226,9 +251,16 @@ __global__ __launch_bounds__(256) void add_ln_fwd_vec_kernel(const void* x, cons
     for (int i = 0; i < NC; ++i) {
         const int c = lane + 64 * i;
         if (c < nchunk) {
-            float o[V];
+            float o[V], gv[V], bv[V];
 #pragma unroll
-            for (int j = 0; j < V; ++j) o[j] = (v[i][j] - mu) * rs * gamma[c * V + j] + beta[c * V + j];
+            for (int j = 0; j < V / 4; ++j) {
+                gv[4 * j] = __uint_as_float(rg[i][j].x); gv[4 * j + 1] = __uint_as_float(rg[i][j].y);
+                gv[4 * j + 2] = __uint_as_float(rg[i][j].z); gv[4 * j + 3] = __uint_as_float(rg[i][j].w);
+                bv[4 * j] = __uint_as_float(rb[i][j].x); bv[4 * j + 1] = __uint_as_float(rb[i][j].y);
+                bv[4 * j + 2] = __uint_as_float(rb[i][j].z); bv[4 * j + 3] = __uint_as_float(rb[i][j].w);
+            }
+#pragma unroll
+            for (int j = 0; j < V; ++j) o[j] = (v[i][j] - mu) * rs * gv[j] + bv[j];
             *reinterpret_cast<uint4*>(yr + (size_t)c * 16) = pack16<BF>(o);
             // MIX: a bf16 copy of the fp32 stream for the next Linear (what autocast would cast per use)
             if (MIX && y16) *reinterpret_cast<uint2*>(reinterpret_cast<char*>(y16) + (size_t)row * cols * 2 + (size_t)c * 8) = pack8bf(o);
@@ -285,6 +317,10 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const void* x, const vo
 }
 
 // ---- backward: dz, and per-block partial column sums of dgamma / dbeta ----
+#ifndef TRX_LN_BWD_WAVES   // register budget of the vector kernel, in waves per SIMD (3: 168 registers; the widest rows -- bf16 beyond 1024
+                          // columns, fp32 beyond 768 -- get 2: they would spill at 3)
+#define TRX_LN_BWD_WAVES 3
+#endif
 constexpr int BWD_MAX_BLOCKS = 768;   // workgroups of 4 waves, rows dealt round-robin to the waves (cutting the registers to 128 for a fourth
                                       // workgroup per CU, 1024 blocks: measured, no gain -- 43.8 against 43.4 us mixed, tools/ln_bench.py)
 template <bool BF>
@@ -331,7 +367,7 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const void* dy, const v
 // carries the dgamma / dbeta partial sums of its columns in registers over all its rows; the four
 // waves of a workgroup are combined through LDS at the end.
 template <bool BF, bool MIX, int NC>
-__global__ __launch_bounds__(256) void add_ln_bwd_vec_kernel(const void* dy, const void* x, const void* res,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(((BF && NC >= 3) || NC >= 4) ? 2 : TRX_LN_BWD_WAVES))) void add_ln_bwd_vec_kernel(const void* dy, const void* x, const void* res,
                                                              const float* gamma, const float* mean, const float* rstd,
                                                              int64_t rows, int cols, void* dz, void* dx, float* ws, int nblk, Drop drop_in,
                                                              const void* dy16 = nullptr, const float* xbias = nullptr) {
@@ -348,55 +384,107 @@ __global__ __launch_bounds__(256) void add_ln_bwd_vec_kernel(const void* dy, con
         const int c = lane + 64 * i;
 #pragma unroll
         for (int j = 0; j < V; ++j) {
-            ag[i][j] = 0.f; ab[i][j] = 0.f; gm[i][j] = c < nchunk ? gamma[c * V + j] : 0.f;
+            ag[i][j] = 0.f; ab[i][j] = 0.f;
             if (MIX) ax[i][j] = 0.f;
+        }
+        // gamma of this lane's columns: whole 16-byte loads of the clamped chunk, zeroed past the row's end (no branch per element)
+        const unsigned keep = c < nchunk ? ~0u : 0u;
+        const float* gp = gamma + (size_t)min(c, nchunk - 1) * V;
+#pragma unroll
+        for (int j = 0; j < V; j += 4) {
+            const uint4 u = *reinterpret_cast<const uint4*>(gp + j);
+            gm[i][j] = __uint_as_float(u.x & keep); gm[i][j + 1] = __uint_as_float(u.y & keep);
+            gm[i][j + 2] = __uint_as_float(u.z & keep); gm[i][j + 3] = __uint_as_float(u.w & keep);
+        }
+    }
+    // One row per wave and trip, in two phases: every load of the row is issued first, into raw registers, without a branch
+    // between them -- an operand the call does not have (dy or its bf16 twin, res) is read from gamma with row stride 0 and
+    // ANDed away, a chunk past the row's end re-reads the last one and is ANDed away too -- then the arithmetic.  (Round 5: the
+    // kernel used to test each pointer where it was used; every test was a basic block, every block ended in s_waitcnt
+    // vmcnt(0), and a row cost nine memory latencies one after the other instead of one: mixed 16384 x 768 38.5 -> 35.9 us,
+    // bf16 33.6 -> 28.6, profiles/r05_ln_ab.json.  Requesting the NEXT row as well before this row's arithmetic costs a
+    // wave per SIMD in registers and was slower: 38.4 us.)
+    const bool has_dy = !MIX || dy != nullptr, has_dy16 = MIX && dy16 != nullptr, has_res = res != nullptr;
+    const char* const p_dy = has_dy ? reinterpret_cast<const char*>(dy) : reinterpret_cast<const char*>(gamma);
+    const char* const p_dy16 = has_dy16 ? reinterpret_cast<const char*>(dy16) : reinterpret_cast<const char*>(gamma);
+    const char* const p_res = has_res ? reinterpret_cast<const char*>(res) : reinterpret_cast<const char*>(gamma);
+    const size_t rs_full = (size_t)cols * ES, rs_half = rs_full >> 1;
+    const size_t st_dy = has_dy ? rs_full : 0, st_dy16 = has_dy16 ? rs_half : 0, st_res = has_res ? rs_full : 0;
+    const unsigned m_dy = has_dy ? ~0u : 0u, m_dy16 = has_dy16 ? ~0u : 0u, m_res = has_res ? ~0u : 0u;   // wave-uniform
+    unsigned lm[NC]; unsigned o16[NC];          // lane mask of chunk i (all ones: inside the row), its clamped byte offset
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int c = lane + 64 * i;
+        lm[i] = c < nchunk ? ~0u : 0u;
+        o16[i] = (unsigned)min(c, nchunk - 1) * 16u;
+    }
+    float xb[MIX ? NC : 1][MIX ? V : 1];        // the bias of x, once per kernel (zeros without one)
+    if (MIX) {
+        const unsigned m_xb = xbias ? ~0u : 0u;
+        const char* const p_xb = reinterpret_cast<const char*>(xbias ? xbias : gamma);
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const uint4 u = *reinterpret_cast<const uint4*>(p_xb + o16[i]);
+            const unsigned keep = m_xb & lm[i];
+            xb[i][0] = __uint_as_float(u.x & keep); xb[i][1] = __uint_as_float(u.y & keep);
+            xb[i][2] = __uint_as_float(u.z & keep); xb[i][3] = __uint_as_float(u.w & keep);
         }
     }
     for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
         const size_t rb = (size_t)row * cols * ES;
+        uint4 rdy[NC], rres[NC], rx4[MIX ? 1 : NC];
+        uint2 rdy16[MIX ? NC : 1], rx2[MIX ? NC : 1];
         const float mu = mean[row], rs = rstd[row];
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            rdy[i] = *reinterpret_cast<const uint4*>(p_dy + (size_t)row * st_dy + o16[i]);
+            if (MIX) {
+                rdy16[i] = *reinterpret_cast<const uint2*>(p_dy16 + (size_t)row * st_dy16 + (o16[i] >> 1));
+                rx2[i] = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(x) + (size_t)row * rs_half + (o16[i] >> 1));
+            } else rx4[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(x) + (size_t)row * rs_full + o16[i]);
+            rres[i] = *reinterpret_cast<const uint4*>(p_res + (size_t)row * st_res + o16[i]);
+        }
         float g[NC][V], xh[NC][V];
+        float dd[NC][V], zz[NC][V], rr[NC][V];
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const unsigned k_dy = m_dy & lm[i], k_dy16 = m_dy16 & lm[i], k_res = m_res & lm[i];
+            unpack16<BF>(make_uint4(rdy[i].x & k_dy, rdy[i].y & k_dy, rdy[i].z & k_dy, rdy[i].w & k_dy), dd[i]);
+            if (MIX) {   // + the gradient that arrived through the bf16 copy of y
+                float e[4];
+                unpack8bf(make_uint2(rdy16[i].x & k_dy16, rdy16[i].y & k_dy16), e);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dd[i][j] += e[j];
+                unpack8bf(make_uint2(rx2[i].x & lm[i], rx2[i].y & lm[i]), zz[i]);
+            } else unpack16<BF>(make_uint4(rx4[i].x & lm[i], rx4[i].y & lm[i], rx4[i].z & lm[i], rx4[i].w & lm[i]), zz[i]);
+            unpack16<BF>(make_uint4(rres[i].x & k_res, rres[i].y & k_res, rres[i].z & k_res, rres[i].w & k_res), rr[i]);
+        }
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
             const int c = lane + 64 * i;
-            if (c < nchunk) {
-                float d[V], z[V];
-                if (!MIX || dy) unpack16<BF>(*reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(dy) + rb + (size_t)c * 16), d);
-                else { _Pragma("unroll") for (int j = 0; j < V; ++j) d[j] = 0.f; }
-                if (MIX && dy16) {   // gradient that arrived through the bf16 copy of y
-                    float e[4];
-                    unpack8bf(*reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(dy16) + (rb >> 1) + (size_t)c * 8), e);
+            float* d = dd[i]; float* z = zz[i];
+            if (MIX) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) d[j] += e[j];
-                }
-                if (MIX) unpack8bf(*reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(x) + (rb >> 1) + (size_t)c * 8), z);
-                else unpack16<BF>(*reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(x) + rb + (size_t)c * 16), z);
-                if (MIX && xbias) {
+                for (int j = 0; j < V; ++j) z[j] += xb[i][j];
+            }
+            if (drop.thr) {
 #pragma unroll
-                    for (int j = 0; j < V; ++j) z[j] += xbias[c * V + j];
+                for (int j = 0; j < V; j += 2) {
+                    const unsigned bits = drop_bits(drop.base, (unsigned)row, (unsigned)(c * V + j) >> 1);
+                    z[j] *= drop_keep(bits, 0, drop.thr) ? drop.inv_keep : 0.f;
+                    z[j + 1] *= drop_keep(bits, 1, drop.thr) ? drop.inv_keep : 0.f;
                 }
-                if (drop.thr) {
+            }
 #pragma unroll
-                    for (int j = 0; j < V; j += 2) {
-                        const unsigned bits = drop_bits(drop.base, (unsigned)row, (unsigned)(c * V + j) >> 1);
-                        z[j] *= drop_keep(bits, 0, drop.thr) ? drop.inv_keep : 0.f;
-                        z[j + 1] *= drop_keep(bits, 1, drop.thr) ? drop.inv_keep : 0.f;
-                    }
-                }
-                if (res) {
-                    float r[V];
-                    unpack16<BF>(*reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(res) + rb + (size_t)c * 16), r);
+            for (int j = 0; j < V; ++j) z[j] += rr[i][j];
+            // (a chunk past the row's end: d = 0 and gm = 0, so it adds nothing to s1, s2, ag, ab; its xh is never stored)
 #pragma unroll
-                    for (int j = 0; j < V; ++j) z[j] += r[j];
-                }
-#pragma unroll
-                for (int j = 0; j < V; ++j) {
-                    xh[i][j] = (z[j] - mu) * rs;
-                    g[i][j] = d[j] * gm[i][j];
-                    s1 += g[i][j]; s2 += g[i][j] * xh[i][j];
-                    ag[i][j] += d[j] * xh[i][j]; ab[i][j] += d[j];
-                }
+            for (int j = 0; j < V; ++j) {
+                xh[i][j] = (z[j] - mu) * rs;
+                g[i][j] = d[j] * gm[i][j];
+                s1 += g[i][j]; s2 += g[i][j] * xh[i][j];
+                ag[i][j] += d[j] * xh[i][j]; ab[i][j] += d[j];
             }
         }
         s1 = wave_sum(s1) / (float)cols; s2 = wave_sum(s2) / (float)cols;

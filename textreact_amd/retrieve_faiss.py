@@ -137,6 +137,9 @@ def get_parser():
     parser.add_argument('--test_vectors', type=str, default=None)
     parser.add_argument('--metric', type=str, default='l2', choices=['l2', 'ip'])
     parser.add_argument('--k', type=int, default=20)
+    parser.add_argument('--tie_rule', type=str, default=None, choices=['id', 'faiss'],
+                        help="order of exactly equal scores: 'id' (smaller row id first, the default) or 'faiss' (the order "
+                             "FAISS's heap leaves for --metric ip; include/trx_knn.h TRX_TIES_FAISS)")
     parser.add_argument('--replicas', action='store_true',
                         help='under torch.distributed.run: every GPU holds all train vectors and searches 1/G of the queries '
                              '(FAISS IndexReplicas; sharded.ReplicatedFlatIndex) instead of a row shard of the train vectors')
@@ -260,6 +263,8 @@ def load_or_compute_train_fps(train_df, keep, args, fingerprint_fn, train_fp_fil
 def main(argv=None):
     import pandas as pd
     args = get_parser().parse_args(argv)
+    if args.tie_rule is not None:
+        os.environ["TRX_TIE_RULE"] = args.tie_rule         # read by every index faiss_compat makes from here on
     rank, world = _dist_setup()
     say = print if rank == 0 else (lambda *a, **k: None)
 
