@@ -118,33 +118,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             dof[s] = *reinterpret_cast<const bf16x8*>(dout + rod + 16 * s);
         }
     }
-    const float sl2 = scale * 1.44269504088896340736f;
-    const float inv_scale = 1.0f / scale;
-    const float mask_floor = -268435456.0f / sl2;     // the forward kernel's floor of a masked score (nn_ops.hip: TRX_MASK_INIT)
-    // The per-query scalars are made HERE (rounds 1-3: a launch of their own, 12 us in front of every backward): a lane holds
-    // half of its query's dO row as fragments already, the same half of the O row is four more loads, and the two halves
-    // meet through one cross-half shuffle.  Written out for the dk/dv pass, which runs after this launch.
-    float nd;
-    {
-        const int64_t rod = (((int64_t)b * Lq + qc) * H + h) * 64 + 8 * hh;
-        float part = 0.f;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const uint4 ow = *reinterpret_cast<const uint4*>(o + rod + 16 * s);
-            const uint4 dw = __builtin_bit_cast(uint4, dof[s]);
-            const unsigned aw[4] = {ow.x, ow.y, ow.z, ow.w}, bw[4] = {dw.x, dw.y, dw.z, dw.w};
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                part = __builtin_fmaf(__uint_as_float(aw[w] << 16), __uint_as_float(bw[w] << 16), part);
-                part = __builtin_fmaf(__uint_as_float(aw[w] & 0xffff0000u), __uint_as_float(bw[w] & 0xffff0000u), part);
-            }
-        }
-        nd = -(part + __shfl_xor(part, 32, 64));                      // -delta = -(dO . O)
-    }
-    const int64_t wq_ = ((int64_t)b * H + h) * Lq + qc;
-    const float nl = -lse[wq_] / scale;
-    const float nlsl2 = nl * sl2;                                     // -lse * log2 e
-    if (kp == 0 && hh == 0 && qidx < Lq) { negl[wq_] = nl; negd[wq_] = nd; }
     f32x16 a0, a1;   // dQ^T: d blocks 0..31 / 32..63 x this wave's 32 queries
 #pragma unroll
     for (int t = 0; t < 16; ++t) { a0[t] = 0.f; a1[t] = 0.f; }
@@ -196,20 +169,63 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const unsigned tra0 = ldsbase + (unsigned)((4 * hh + qq) * 128 + ((tc ^ tsw) << 4) + 8 * (pp & 1));
     const unsigned tra1 = ldsbase + (unsigned)((4 * hh + qq) * 128 + ((tc ^ tsw ^ 2) << 4) + 8 * (pp & 1));
 
+    // Everything the prologue reads is requested before anything is waited for (round 5): Q and dO above, here the first 1,024
+    // keys' mask and the LDS-DMA of tiles 0 and 1, then O and the log-sum-exp below.  The per-query scalars used to be finished
+    // -- a wait for Q, dO, O -- before the first tile was staged, and the mask was loaded after that: three memory latencies
+    // in a row in front of the first MFMA, now one.
+    float mv0[4] = {0.f, 0.f, 0.f, 0.f};
+    if (keymask) {
+#pragma unroll
+        for (int i_ = 0; i_ < 4; ++i_) mv0[i_] = mkey[min(4 * tid + i_, Lk - 1)];
+    }
     TRX_BWD1_STAGE(0, 0);
     if (nkb > 1) TRX_BWD1_STAGE(1, 1);
+    const float sl2 = scale * 1.44269504088896340736f;
+    const float inv_scale = 1.0f / scale;
+    const float mask_floor = -268435456.0f / sl2;     // the forward kernel's floor of a masked score (nn_ops.hip: TRX_MASK_INIT)
+    // The per-query scalars are made HERE (rounds 1-3: a launch of their own, 12 us in front of every backward): a lane holds
+    // half of its query's dO row as fragments already, the same half of the O row is four more loads, and the two halves
+    // meet through one cross-half shuffle.  Written out for the dk/dv pass, which runs after this launch.
+    float nd;
+    {
+        const int64_t rod = (((int64_t)b * Lq + qc) * H + h) * 64 + 8 * hh;
+        float part = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const uint4 ow = *reinterpret_cast<const uint4*>(o + rod + 16 * s);
+            const uint4 dw = __builtin_bit_cast(uint4, dof[s]);
+            const unsigned aw[4] = {ow.x, ow.y, ow.z, ow.w}, bw[4] = {dw.x, dw.y, dw.z, dw.w};
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                part = __builtin_fmaf(__uint_as_float(aw[w] << 16), __uint_as_float(bw[w] << 16), part);
+                part = __builtin_fmaf(__uint_as_float(aw[w] & 0xffff0000u), __uint_as_float(bw[w] & 0xffff0000u), part);
+            }
+        }
+        nd = -(part + __shfl_xor(part, 32, 64));                      // -delta = -(dO . O)
+    }
+    const int64_t wq_ = ((int64_t)b * H + h) * Lq + qc;
+    const float nl = -lse[wq_] / scale;
+    const float nlsl2 = nl * sl2;                                     // -lse * log2 e
+    if (kp == 0 && hh == 0 && qidx < Lq) { negl[wq_] = nl; negd[wq_] = nd; }
     asm volatile("" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]));
     asm volatile("" : "+v"(dof[0]), "+v"(dof[1]), "+v"(dof[2]), "+v"(dof[3]));
+    if (keymask) {   // (before the loop: written inside it, the four registers stayed live -- spilled -- across all tiles)
+#pragma unroll
+        for (int i_ = 0; i_ < 4; ++i_) ldsM[4 * tid + i_] = fmaxf(mv0[i_] * inv_scale, mask_floor);
+    }
     int buf = 0;
     for (int kc = 0; kc < nkb; kc += 16) {
-    if (keymask) {
-        if (kc > 0) __syncthreads();
+    if (keymask && kc > 0) {                              // (rare: Lk > 1024) the next 1,024 keys' mask
+        __syncthreads();
         float mv_[4];
         const int tid_ = lane_again() + 64 * wave_s;      // recomputed: the thread id would otherwise be kept (spilled) across the tile loop
 #pragma unroll
         for (int i_ = 0; i_ < 4; ++i_) mv_[i_] = mkey[min(kc * 64 + 4 * tid_ + i_, Lk - 1)];
+        float sc_ = scale;
+        asm volatile("" : "+s"(sc_));        // (opaque: made again here, or hipcc keeps -- spills -- the prologue's 1 / scale across the tiles)
+        const float isc_ = 1.0f / sc_, floor_ = -268435456.0f / (sc_ * 1.44269504088896340736f);
 #pragma unroll
-        for (int i_ = 0; i_ < 4; ++i_) ldsM[4 * tid_ + i_] = fmaxf(mv_[i_] * inv_scale, mask_floor);
+        for (int i_ = 0; i_ < 4; ++i_) ldsM[4 * tid_ + i_] = fmaxf(mv_[i_] * isc_, floor_);
     }
     const int kend = min(nkb, kc + 16);
     for (int kb = kc; kb < kend; ++kb) {

@@ -886,13 +886,11 @@ __device__ unsigned long long* g_att_stamp;
 #else
 #define TRX_STAMP(I, V)
 #endif
-// XW ("extra waves", an experiment kept behind TRX_NN_ATTN_XW=1): for 128 < Lq <= 256 ONE workgroup of ceil(Lq / 32) waves
-// (5 .. 8) takes all queries of a (batch, head) -- waves 0-3 stage K / V, the others only compute -- instead of two
-// 128-query workgroups of which the second is mostly empty (160 = 128 + 32).  It saves 37.5 % of the MFMAs and half the
-// staging and is SLOWER (profiles/r03_attention_ab.json: cross-attention 160 x 512 28.8 against 26.0 us, causal 160 x 160
-// 15.6 against 11.4): these launches are bound by the latency of their key-tile chain, and half as many workgroups hide
-// less of it.
-template <int MM, bool DROP, bool XW = false>   // mask mode, dropout: one kernel per case keeps each one's register footprint to what it needs
+// (An "extra waves" form -- for 128 < Lq <= 256 ONE workgroup of ceil(Lq / 32) waves per (batch, head) instead of two 128-query
+// workgroups of which the second is mostly empty -- saved 37.5 % of the MFMAs and was SLOWER, profiles/r03_attention_ab.json:
+// cross-attention 160 x 512 28.8 against 26.0 us; these launches are bound by the latency of their key-tile chain and half as
+// many workgroups hide less of it.  Removed in round 5.)
+template <int MM, bool DROP>   // mask mode, dropout: one kernel per case keeps each one's register footprint to what it needs
 #ifndef TRX_ATT_WAVES      // waves per SIMD the register budget is cut for (A/B knob; 3 = 168 registers)
 #define TRX_ATT_WAVES 3
 #endif
@@ -902,7 +900,7 @@ template <int MM, bool DROP, bool XW = false>   // mask mode, dropout: one kerne
 #ifndef TRX_ATT_PRIO       // 1: s_setprio 1 around the MFMA clusters: -2.8 % at 512 x 512, -3.7 % at 160 x 512 (profiles/r03_attention_ab.json)
 #define TRX_ATT_PRIO 1
 #endif
-__global__ __launch_bounds__(XW ? 512 : 256) __attribute__((amdgpu_waves_per_eu((DROP || MM == TRX_NN_MASK_FULL) ? 2 : TRX_ATT_WAVES, (DROP || MM == TRX_NN_MASK_FULL) ? 2 : TRX_ATT_WAVES))) void attention_fwd_mfma_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DROP || MM == TRX_NN_MASK_FULL) ? 2 : TRX_ATT_WAVES, (DROP || MM == TRX_NN_MASK_FULL) ? 2 : TRX_ATT_WAVES))) void attention_fwd_mfma_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                                  const bf16_t* __restrict__ v, const float* __restrict__ mask,
                                                                  int causal, int B, int H, int Lq, int Lk,
                                                                  float scale, bf16_t* __restrict__ out, float* __restrict__ lse, DropArgs da) {
@@ -917,7 +915,7 @@ __global__ __launch_bounds__(XW ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     TRX_STAMP(0, __builtin_amdgcn_s_memrealtime()); TRX_STAMP(2, __builtin_amdgcn_s_memtime());
     const int r = lane & 31, hh = lane >> 5;
-    const int nqb = XW ? 1 : (Lq + 127) / 128;
+    const int nqb = (Lq + 127) / 128;
     // workgroups are dealt round-robin to the 8 XCDs; renumber so that the query blocks of one
     // (batch, head) -- which re-read the same K/V -- are neighbours on ONE XCD and share its L2
     int bid = blockIdx.x;
@@ -928,7 +926,7 @@ __global__ __launch_bounds__(XW ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
         // arithmetic.  An XCD hands its workgroups to its 32 CUs in turn, so numbered (full, short, full, short, ...) the three
         // workgroups a CU holds -- j, j + 32, j + 64 of the XCD's list -- would be of ONE kind, half the CUs loaded four times
         // as much as the others; the kinds swap every 32 places instead, and every CU gets a mix.
-        if (!XW && nqb == 2 && !(per & 1) && bid < main_) qsw = (bid >> 3) >> 5;
+        if (nqb == 2 && !(per & 1) && bid < main_) qsw = (bid >> 3) >> 5;
         if (bid < main_) bid = (bid & 7) * per + (bid >> 3);
     }
     const int qb = (bid + qsw) % nqb, h = (bid / nqb) % H, b = bid / (nqb * H);
@@ -938,7 +936,7 @@ __global__ __launch_bounds__(XW ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
     // every barrier, it only skips the arithmetic of the tiles that are not its own -- and the partial (O, m, l) of a unit's
     // waves are merged through LDS at the end (a log-sum-exp merge: any reference common to a row is exact).  The key-tile
     // chain of such a block is a quarter (half) as long; the launch does the arithmetic of 5 units instead of 8 at Lq = 160.
-    const int nuq = XW ? 4 : min(4, (Lq - qb * 128 + 31) / 32);
+    const int nuq = min(4, (Lq - qb * 128 + 31) / 32);
     int KS = nuq == 1 ? 4 : (nuq == 2 ? 2 : 1);               // block-uniform
     {   // ... when the block has key tiles to deal out: with fewer than two per wave (the 160 x 160 causal decoder block: three
         // tiles; 7 x 7: one) the merge costs more than the shorter chain saves (measured: 10.7 -> 11.1 us at causal 160 x 160)
@@ -950,11 +948,27 @@ __global__ __launch_bounds__(XW ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
     const int kp = KS == 4 ? wave : (KS == 2 ? (wave >> 1) : 0);
     const int qidx = qb * 128 + uq * 32 + r;                // this lane's query
     const int qc = qidx < Lq ? qidx : Lq - 1;
+    // The prologue's vector loads, oldest first: the key mask of the first 1,024 keys (4 floats per thread), Q, then the
+    // LDS-DMA of tiles 0 and 1 -- ALL through asm, so that one s_waitcnt vmcnt(4) before the first barrier retires the mask, Q
+    // and tile 0 together while tile 1 stays in flight.  (Until round 5 Q was a C++ load and the mask was loaded after the
+    // staging: hipcc, which does not count the asm DMAs, retired Q with vmcnt(0) -- both tiles -- and the mask then cost a second
+    // memory latency in front of the first tile: ~1 us of a 10-20 us decoder launch.)
+    constexpr bool keymask = MM == TRX_NN_MASK_KEY;
+    const float* mkey = keymask ? mask + (int64_t)b * Lk : nullptr;
+    float mv0[4] = {0.f, 0.f, 0.f, 0.f};
+    if (keymask) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float* mp = mkey + min(4 * tid + i, Lk - 1);
+            asm volatile("global_load_dword %0, %1, off" : "=&v"(mv0[i]) : "v"(mp) : "memory");
+        }
+    }
     bf16x8 qf[4];   // B operand of S^T = K Q^T: B[k = 8hh + j][col r] = Q[query r][d = 16 s + 8 hh + j]
     {
         const bf16_t* qp = q + ((int64_t)b * Lq + qc) * (da.ldq ? da.ldq : H * 64) + h * 64 + 8 * hh;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+        asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:32\n\t"
+                     "global_load_dwordx4 %2, %4, off offset:64\n\tglobal_load_dwordx4 %3, %4, off offset:96"
+                     : "=&v"(qf[0]), "=&v"(qf[1]), "=&v"(qf[2]), "=&v"(qf[3]) : "v"(qp) : "memory");
     }
     f32x16 o0, o1;
 #pragma unroll
@@ -975,7 +989,7 @@ __global__ __launch_bounds__(XW ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
     const int off = Lk - Lq;
     int nkb = (Lk + 63) / 64;
     if (causal) {  // last key any query of this workgroup can see
-        const int lastq = XW ? Lq - 1 : min(Lq - 1, qb * 128 + 127);
+        const int lastq = min(Lq - 1, qb * 128 + 127);
         nkb = min(nkb, (lastq + off) / 64 + 1);
     }
     // last visible key of this lane's query (also bounds the tail tile)
@@ -1023,7 +1037,7 @@ __global__ __launch_bounds__(XW ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
     const unsigned ldsbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
     const unsigned lds_w = (unsigned)__builtin_amdgcn_readfirstlane((int)(ldsbase + (unsigned)(2 * wave * 1024)));   // this wave's pieces, scalar
 #define TRX_ATT_STAGE(KB, BUF)                                                                              \
-    if (!XW || wave < 4) {                                                                                  \
+    {                                                                                                       \
         const unsigned long long kt_ = (unsigned long long)(kbase + (int64_t)(KB) * 64 * rowbytes);         \
         const unsigned long long vt_ = (unsigned long long)(vbase + (int64_t)(KB) * 64 * rowbytes);         \
         const unsigned l_ = lds_w + (unsigned)((BUF) * 16384);                                              \
@@ -1051,14 +1065,12 @@ __global__ __launch_bounds__(XW ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
     unsigned kfa[4];   // K fragment addresses: row r (+32 by offset), chunk (2s + hh) ^ swizzle
 #pragma unroll
     for (int s = 0; s < 4; ++s) kfa[s] = ldsbase + (unsigned)(r * 128 + (((2 * s + hh) ^ kswz) << 4));
-    constexpr bool keymask = MM == TRX_NN_MASK_KEY;
-    const float* mkey = keymask ? mask + (int64_t)b * Lk : nullptr;
     // dropout hash input of (this lane's query, key pair 0): + 2 hh because register t's key is ... + 4 hh
     const unsigned xdrop = DROP ? drop_base_da(da, (unsigned)(b * H + h)) + (unsigned)qidx * DROP_C1 + (unsigned)(2 * hh) * DROP_C2 : 0u;
 
     // the key mask of tiles 16j .. 16j+15 is (re)loaded when tile 16j starts: 4 keys per thread
 #define TRX_MASK_FILL(KB)                                                                                   \
-    if (!XW || tid < 256) {                                                                                 \
+    {                                                                                                       \
         float mv_[4];                                                                                       \
         _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) mv_[i_] = mkey[min((KB) * 64 + 4 * tid + i_, Lk - 1)]; \
         _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) ldsM[4 * tid + i_] = TRX_MASK_INIT(mv_[i_]);       \
@@ -1067,14 +1079,20 @@ __global__ __launch_bounds__(XW ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
     // must have landed while D(j+1)'s four loads may still fly: vmcnt(4).
     TRX_ATT_STAGE(0, 0);
     if (nkb > 1) TRX_ATT_STAGE(1, 1);
-    // retire the Q loads HERE: left pending, their first use inside the loop would put an
-    // s_waitcnt vmcnt(0) in front of every tile's first MFMA and drain the prefetch with it
-    asm volatile("" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]));
+    // the mask and Q have landed -- they are older than the last four DMA pieces, whichever tile those belong to (with two tiles
+    // staged, tile 0 has landed too; the loop's own wait decides about the tiles).  ONE statement names the registers, so that
+    // nothing reads them earlier: with one statement per case hipcc copied the still-empty registers into the other
+    // statement's operands in front of the wait (NaN for every Lk <= 64).
+    asm volatile("s_waitcnt vmcnt(4)" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]), "+v"(mv0[0]), "+v"(mv0[1]), "+v"(mv0[2]), "+v"(mv0[3]) :: "memory");
+    if (keymask) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ldsM[4 * tid + i] = TRX_MASK_INIT(mv0[i]);
+    }
     int buf = 0;
     TRX_STAMP(3, __builtin_amdgcn_s_memtime());
     for (int kc = 0; kc < nkb; kc += 16) {   // chunks of 16 tiles = the 1024 keys whose mask sits in LDS
-    if (keymask) {
-        if (kc > 0) __syncthreads();         // (rare: Lk > 1024) the previous chunk's mask is no longer read
+    if (keymask && kc > 0) {
+        __syncthreads();                     // (rare: Lk > 1024) the previous chunk's mask is no longer read
         TRX_MASK_FILL(kc);
     }
     const int kend = min(nkb, kc + 16);
@@ -1531,9 +1549,7 @@ static int attention_fwd_impl(const void* q, const void* k, const void* v, const
     hipStream_t st = (hipStream_t)stream;
     static const bool force_valu = getenv("TRX_NN_ATTN_VALU") != nullptr;
     if (dtype == TRX_NN_BF16 && !force_valu) {
-        static const bool use_xw = getenv("TRX_NN_ATTN_XW") != nullptr;         // (the experiment above; off: it measured slower)
-        const bool xw = Lq > 128 && Lq <= 256 && use_xw;
-        dim3 g2((unsigned)((int64_t)B * H * (xw ? 1 : (Lq + 127) / 128))), b2(xw ? 64 * ((Lq + 31) / 32) : 256);
+        dim3 g2((unsigned)((int64_t)B * H * ((Lq + 127) / 128))), b2(256);
         // TRX_NN_ATTN_PP=1: the encoder's shape class (Lq >= 256, key mask or none) on the two-group ping-pong kernel of
         // attn_fwd_pp.h -- correct (tests/test_predictor_gpu.py::test_ping_pong_forward_kernel) and 33 % SLOWER than this
         // one at 512 x 512 (69.4 against 52.0 us, profiles/r03_attention_ab.json), so it is not the default
@@ -1554,9 +1570,7 @@ static int attention_fwd_impl(const void* q, const void* k, const void* v, const
             hipLaunchKernelGGL(kern_, g3, b3, PP_LDS_BYTES, st, (const bf16_t*)q, (const bf16_t*)k,                       \
                                (const bf16_t*)v, mask, causal, B, H, Lq, Lk, scale, (bf16_t*)out, lse, da);               \
         }                                                                                                                 \
-        else if (xw) hipLaunchKernelGGL((attention_fwd_mfma_kernel<MM_, DROP_, true>), g2, b2, 0, st, (const bf16_t*)q, (const bf16_t*)k, \
-                                   (const bf16_t*)v, mask, causal, B, H, Lq, Lk, scale, (bf16_t*)out, lse, da);           \
-        else hipLaunchKernelGGL((attention_fwd_mfma_kernel<MM_, DROP_, false>), g2, b2, 0, st, (const bf16_t*)q, (const bf16_t*)k, \
+        else hipLaunchKernelGGL((attention_fwd_mfma_kernel<MM_, DROP_>), g2, b2, 0, st, (const bf16_t*)q, (const bf16_t*)k, \
                                 (const bf16_t*)v, mask, causal, B, H, Lq, Lk, scale, (bf16_t*)out, lse, da);              \
     } while (0)
         if (da.thr) {
