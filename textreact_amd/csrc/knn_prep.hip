@@ -29,6 +29,37 @@ __device__ __forceinline__ float load_val(const void* p, int64_t i) {
     return reinterpret_cast<const float*>(p)[i];
 }
 
+// NV consecutive components [c0, c0 + NV) of a row as floats, zero beyond d: 16-byte loads when the group lies inside the row
+// and the rows allow them (`vec`: base and row stride multiples of 16 bytes; c0 is a multiple of 8), else element by element.
+// (Round 5: the operand builders loaded element by element always -- 8 to 32 two-byte loads per thread, each behind its own
+// s_waitcnt vmcnt(0).)
+template <bool BF, int NV>
+__device__ __forceinline__ void load_group(const char* row, int c0, int d, bool vec, float* v) {
+    if (vec && c0 + NV <= d) {
+        if (BF) {
+#pragma unroll
+            for (int j = 0; j < NV / 8; ++j) {
+                const uint4 u = *reinterpret_cast<const uint4*>(row + (size_t)(c0 + 8 * j) * 2);
+                const u32 w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { v[8 * j + 2 * i] = __uint_as_float(w[i] << 16); v[8 * j + 2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NV / 4; ++j) {
+                const uint4 u = *reinterpret_cast<const uint4*>(row + (size_t)(c0 + 4 * j) * 4);
+                v[4 * j] = __uint_as_float(u.x); v[4 * j + 1] = __uint_as_float(u.y); v[4 * j + 2] = __uint_as_float(u.z); v[4 * j + 3] = __uint_as_float(u.w);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = c0 + i < d ? load_val<BF>(row, c0 + i) : 0.f;
+    }
+}
+__device__ __forceinline__ bool rows_allow_16_byte_loads(const void* x, int64_t ld, bool bf) {
+    return (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (ld * (bf ? 2 : 4)) % 16 == 0;
+}
+
 // one wave per row (grid-stride): stats + fp32 |row|^2.  16 bytes per lane per load when the rows
 // allow it (d and the row stride multiples of 8 bf16 / 4 f32): 4 TB/s class instead of the
 // 0.16 TB/s the 2-byte-per-lane form reached (it was 1.3 % of a C1 search).
@@ -147,9 +178,11 @@ __global__ __launch_bounds__(256) void build_operand_kernel(const void* x, int64
     bf16_t hi[8], lo[8];
     const int c0 = g * 8;
     const int cnt = (d - c0) < 8 ? (d - c0) : 8;
+    float vals[8];
+    load_group<BF, 8>(row, c0, d, rows_allow_16_byte_loads(x, ld, BF), vals);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const float v = i < cnt ? load_val<BF>(row, c0 + i) : 0.f;
+        const float v = vals[i];
         hi[i] = f32_to_bf16_rn(v);
         lo[i] = f32_to_bf16_rn(v - bf16_to_f32(hi[i]));
     }
@@ -215,10 +248,11 @@ __global__ __launch_bounds__(256) void build_operand_fp4_kernel(const void* x, i
     const int g = (int)(t - r * groups);
     const char* row = reinterpret_cast<const char*>(x) + r * ld * (BF ? 2 : 4);
     u32 w[4] = {0u, 0u, 0u, 0u};
+    float vals[32];
+    load_group<BF, 32>(row, g * 32, d, rows_allow_16_byte_loads(x, ld, BF), vals);
 #pragma unroll
     for (int i = 0; i < 32; ++i) {
-        const int c = g * 32 + i;
-        const float v = c < d ? load_val<BF>(row, c) : 0.f;
+        const float v = vals[i];
         const int a = (int)fminf(fabsf(v), 7.f);
         const u32 mag = a <= 2 ? (u32)(2 * a) : (a == 3 ? 5u : (a == 4 ? 6u : 7u));      // (a == 0 -> 0, 1 -> 2, 2 -> 4)
         const u32 code = mag | (v < 0.f ? 8u : 0u);
@@ -247,10 +281,11 @@ __global__ __launch_bounds__(256) void build_operand_i8_kernel(const void* x, in
     const int g = (int)(t - r * groups);
     const char* row = reinterpret_cast<const char*>(x) + r * ld * (BF ? 2 : 4);
     u32 w[4] = {0u, 0u, 0u, 0u};
+    float vals[16];
+    load_group<BF, 16>(row, g * 16, d, rows_allow_16_byte_loads(x, ld, BF), vals);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        const int c = g * 16 + i;
-        const float v = c < d ? load_val<BF>(row, c) * scale : 0.f;
+        const float v = vals[i] * scale;
         const int q = (int)fminf(fmaxf(v, -128.f), 127.f);
         w[i >> 2] |= ((u32)q & 0xffu) << (8 * (i & 3));
     }
