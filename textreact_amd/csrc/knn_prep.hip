@@ -132,12 +132,16 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const void* x, int64_t n
         float a = fmaxf(fmaxf(sh_abs[0], sh_abs[1]), fmaxf(sh_abs[2], sh_abs[3]));
         float m = fmaxf(fmaxf(sh_n2[0], sh_n2[1]), fmaxf(sh_n2[2], sh_n2[3]));
         const u32 f = sh_flags[0] | sh_flags[1] | sh_flags[2] | sh_flags[3];
-        if (f & 1u) atomicOr(&st->inexact_any, 1u);
-        if (f & 2u) atomicOr(&st->nonint_any, 1u);
-        if (f & 4u) atomicOr(&st->nonfp4_any, 1u);
-        atomicMax(&st->maxabs_bits, __float_as_uint(a));
-        atomicMax(&st->maxnorm2_bits, __float_as_uint(m));
-        atomicMax(&st->maxerr2_bits, __float_as_uint(fmaxf(fmaxf(sh_e2[0], sh_e2[1]), fmaxf(sh_e2[2], sh_e2[3]))));
+        // An atomic only where it would change the word: the six words are single addresses, and 2,048 blocks x 6 atomics on
+        // them were 78 us of a 132 us launch over 65,536 query rows (round 5: 132 -> 55 us, tools/r05/fifteenth.sh).  The words only grow, so a value read before
+        // (however stale) that already covers this block's is reason enough to skip.
+        const u32 ab = __float_as_uint(a), mb = __float_as_uint(m), eb = __float_as_uint(fmaxf(fmaxf(sh_e2[0], sh_e2[1]), fmaxf(sh_e2[2], sh_e2[3])));
+        if ((f & 1u) && !__atomic_load_n(&st->inexact_any, __ATOMIC_RELAXED)) atomicOr(&st->inexact_any, 1u);
+        if ((f & 2u) && !__atomic_load_n(&st->nonint_any, __ATOMIC_RELAXED)) atomicOr(&st->nonint_any, 1u);
+        if ((f & 4u) && !__atomic_load_n(&st->nonfp4_any, __ATOMIC_RELAXED)) atomicOr(&st->nonfp4_any, 1u);
+        if (ab > __atomic_load_n(&st->maxabs_bits, __ATOMIC_RELAXED)) atomicMax(&st->maxabs_bits, ab);
+        if (mb > __atomic_load_n(&st->maxnorm2_bits, __ATOMIC_RELAXED)) atomicMax(&st->maxnorm2_bits, mb);
+        if (eb > __atomic_load_n(&st->maxerr2_bits, __ATOMIC_RELAXED)) atomicMax(&st->maxerr2_bits, eb);
     }
 }
 
