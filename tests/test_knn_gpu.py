@@ -522,6 +522,40 @@ def test_torch_device_path_bf16():
     assert np.array_equal(D.cpu().numpy().view(np.uint32), Dr.view(np.uint32))
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f32", "bits"])
+def test_device_rows_that_do_not_start_on_16_bytes(dtype):
+    """the operand builders and the row statistics read 16 bytes per lane when the rows allow it and element by element when
+    they do not: rows that start 2 (bf16) or 4 (fp32) bytes into an allocation give the answers of the aligned rows"""
+    import torch
+    import textreact_amd.faiss_compat as faiss
+    from oracle import flat_knn as oracle
+    n, nq, d, k = 5000, 300, 64, 10
+    if dtype == "bits":
+        y = morgan_like(n, d, 5, density=0.2); x = y[:nq].copy(); metric, tdt = L2, torch.bfloat16
+    else:
+        y = gaussian(n, d, 5); x = gaussian(nq, d, 6); metric = IP
+        tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+        if dtype == "bf16":
+            y, x = bf16_round(y), bf16_round(x)
+
+    def off_by_one(a):
+        flat = torch.zeros(a.size + 1, dtype=tdt, device="cuda")
+        flat[1:] = torch.from_numpy(a).cuda().to(tdt).reshape(-1)
+        v = flat[1:].view(a.shape)
+        assert v.is_contiguous() and v.data_ptr() % 16 != 0
+        return v
+
+    res = []
+    for conv in (lambda a: torch.from_numpy(a).cuda().to(tdt), off_by_one):
+        idx = faiss.IndexFlatIP(d) if metric == IP else faiss.IndexFlatL2(d)
+        idx.add(conv(y))
+        D, I = idx.search(conv(x), k)
+        res.append((D.cpu().numpy(), I.cpu().numpy()))
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][0].view(np.uint32), res[1][0].view(np.uint32))
+    Dr, Ir = oracle.knn_canonical(metric, x, y, k)
+    assert np.array_equal(res[1][1], Ir) and np.array_equal(res[1][0].view(np.uint32), Dr.view(np.uint32))
+
+
 def test_int_inputs_like_reference():
     # the reference hands faiss int64 / int8 arrays (retrieve_faiss.py:26,39)
     import textreact_amd.faiss_compat as faiss
