@@ -363,6 +363,29 @@ constexpr int INLINE_FALLBACK = 4;
 constexpr size_t FLAG_WORDS = 8 + 5 * 65536;      // (8 header words: the four counters, [4] the re-scan tier's form)
 constexpr int RESCAN_MAX = 16384;                 // queries per batch the re-scan is sized for (64 query tiles); more take the exact scan
 
+// The number of corpus splits of a scan launch: the one that a simple price list makes cheapest.  A launch is nqt x S
+// workgroups of ceil(ntiles / S) corpus tiles each, 256 at a time (one per CU); a last round that is not full still costs most
+// of a round (its workgroups run alone on their CUs, at a higher clock: 0.7 + 0.3 x its fill); fewer than 4 splits share
+// thresholds and L2 lines worse (measured at 1M rows: S = 1 + 5.8 %, 2 + 3.8 %), more than 4 slightly worse too (8: + 2 %);
+// and every split adds its lists to the select kernel's work (0.11 ms per split and 65,536 queries).
+static int choose_splits(int nqt, int ntiles, int Kp) {
+    const int smax = std::max(1, std::min(std::min(ntiles, 256), std::max(4, 2048 / std::max(1, nqt))));
+    const double t_tile = 0.0172 * Kp / 768.0;                     // ms per 256 x 256 tile of a bf16 scan on one CU
+    double best = 1e300;
+    int bs = 1;
+    for (int s = 1; s <= smax; ++s) {
+        const int tps = (ntiles + s - 1) / s;
+        if ((ntiles + tps - 1) / tps != s) continue;               // (trailing splits would be empty: the launch of a smaller s)
+        const double r = (double)nqt * s / 256.0;
+        const double full = std::floor(r), frac = r - full;
+        const double rounds = full + (frac > 1e-9 ? 0.7 + 0.3 * frac : 0.0);
+        const double pen = s == 1 ? 0.058 : s == 2 ? 0.038 : s == 3 ? 0.02 : s <= 8 ? 0.005 * (s - 4) : 0.02;
+        const double cost = rounds * tps * t_tile * (1.0 + pen) + 0.11 * s * nqt / 256.0;
+        if (cost < best * (1.0 - 1e-9)) { best = cost; bs = s; }
+    }
+    return bs;
+}
+
 static int search_batch(trx_index* idx, const void* q, const float* qnorm2, const float* qerr2, int64_t nq, int is_bf, int q_split, int batch_no,
                         float eps_rel, int k, float* D, int64_t* I, double* S64, hipStream_t st) {
     const int d = idx->d, Kp = idx->Kp;
@@ -374,8 +397,10 @@ static int search_batch(trx_index* idx, const void* q, const float* qnorm2, cons
     // XCD-contiguous block order of the scan kernel the 32 workgroups that share an XCD are then 8 query tiles x 4
     // splits, so the 8 query tiles (3 MB at K = 768) stay resident in the XCD's 4 MiB L2 while 4 corpus streams
     // pass through it, each read by 8 workgroups (tools/scan_lab.hip: fill path 45 -> 67 GB/s per CU).
-    int nsplits = std::max(4, (256 + nqt - 1) / nqt);
-    nsplits = std::max(1, std::min(nsplits, std::min(ntiles, 256)));
+    // Round 5: that is the rule for query counts that fill whole rounds of 256 workgroups (C1: 256 query tiles x 4).  For the
+    // others choose_splits prices every count: 18 query tiles x 15 splits = 270 workgroups ran two rounds where 14 splits run one
+    // (7.96 -> 4.40 ms over 800,000 rows), 50 x 6 = 300 likewise (11.75 -> 7.52 ms over 500,000; profiles/r05_split_sweep.json).
+    int nsplits = choose_splits(nqt, ntiles, Kp);
     { const char* e = getenv("TRX_NSPLITS"); if (e) nsplits = std::max(1, std::min(atoi(e), ntiles)); }
     int tps = (ntiles + nsplits - 1) / nsplits;
     nsplits = (ntiles + tps - 1) / tps;  // drop empty trailing splits
