@@ -368,8 +368,9 @@ constexpr int RESCAN_MAX = 16384;                 // queries per batch the re-sc
 // of a round (its workgroups run alone on their CUs, at a higher clock: 0.7 + 0.3 x its fill); fewer than 4 splits share
 // thresholds and L2 lines worse (measured at 1M rows: S = 1 + 5.8 %, 2 + 3.8 %), more than 4 slightly worse too (8: + 2 %);
 // and every split adds its lists to the select kernel's work (0.11 ms per split and 65,536 queries).
-static int choose_splits(int nqt, int ntiles, int Kp) {
-    const int smax = std::max(1, std::min(std::min(ntiles, 256), std::max(4, 2048 / std::max(1, nqt))));
+static int choose_splits(int nqt, int ntiles, int Kp, int cap = 0) {      // cap: the most the caller's list storage takes (0: none)
+    int smax = std::max(1, std::min(std::min(ntiles, 256), std::max(4, 2048 / std::max(1, nqt))));
+    if (cap > 0) smax = std::max(1, std::min(smax, cap));
     const double t_tile = 0.0172 * Kp / 768.0;                     // ms per 256 x 256 tile of a bf16 scan on one CU
     double best = 1e300;
     int bs = 1;
@@ -634,7 +635,7 @@ static int search_batch(trx_index* idx, const void* q, const float* qnorm2, cons
         if ((rc2 = pl.qg2.reserve((size_t)cap_q * Kp * sizeof(bf16_t)))) return rc2;
         if ((rc2 = pl.gthr2.reserve((size_t)cap_q * 4 * sizeof(u32)))) return rc2;
         const int tiles = cap_q / TILE_N, small_tiles = std::max(1, tiles / 8), factor = tiles / small_tiles;
-        int ns_small = std::min(std::min(nsplits * factor, ntiles), 256);
+        int ns_small = choose_splits(small_tiles, ntiles, Kp, std::min(std::min(nsplits * factor, ntiles), 256));      // (whole rounds here too)
         const int tps_small = (ntiles + ns_small - 1) / ns_small;
         ns_small = (ntiles + tps_small - 1) / tps_small;
         const bool two = factor > 1 && ns_small > nsplits && !getenv("TRX_RESCAN_ONE_FORM");
