@@ -892,6 +892,10 @@ __device__ unsigned long long* g_att_stamp;
 // workgroups of which the second is mostly empty -- saved 37.5 % of the MFMAs and was SLOWER, profiles/r03_attention_ab.json:
 // cross-attention 160 x 512 28.8 against 26.0 us; these launches are bound by the latency of their key-tile chain and half as
 // many workgroups hide less of it.  Removed in round 5.)
+// Round 5: a tile with hidden keys (out of range, or later than a lane's query under the causal mask) sets them to minus infinity
+// IN PLACE and then takes the same form of attn_softmax_tile as every other tile.  With the hidden-key form instantiated
+// beside the plain one the kernel needed ~40 more registers (dropout: 187, two waves per SIMD); now 151 and three waves for every
+// variant but the full mask: 512 x 512 with dropout 0.1 62.7 -> 56 us (tools/r05/persist_time.py).
 template <int MM, bool DROP>   // mask mode, dropout: one kernel per case keeps each one's register footprint to what it needs
 #ifndef TRX_ATT_WAVES      // waves per SIMD the register budget is cut for (A/B knob; 3 = 168 registers)
 #define TRX_ATT_WAVES 3
@@ -902,7 +906,7 @@ template <int MM, bool DROP>   // mask mode, dropout: one kernel per case keeps 
 #ifndef TRX_ATT_PRIO       // 1: s_setprio 1 around the MFMA clusters: -2.8 % at 512 x 512, -3.7 % at 160 x 512 (profiles/r03_attention_ab.json)
 #define TRX_ATT_PRIO 1
 #endif
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DROP || MM == TRX_NN_MASK_FULL) ? 2 : TRX_ATT_WAVES, (DROP || MM == TRX_NN_MASK_FULL) ? 2 : TRX_ATT_WAVES))) void attention_fwd_mfma_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MM == TRX_NN_MASK_FULL ? 2 : TRX_ATT_WAVES, MM == TRX_NN_MASK_FULL ? 2 : TRX_ATT_WAVES))) void attention_fwd_mfma_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                                  const bf16_t* __restrict__ v, const float* __restrict__ mask,
                                                                  int causal, int B, int H, int Lq, int Lk,
                                                                  float scale, bf16_t* __restrict__ out, float* __restrict__ lse, DropArgs da) {
@@ -1177,8 +1181,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DROP || MM
         const bool vis = key0 + 63 > klim_wave_min;   // wave-uniform: some key of the tile is hidden for some lane
         const unsigned xd = xdrop + (unsigned)(kb * 32) * DROP_C2;
         unsigned pk[2][8];   // the tile's probabilities as bf16 pairs: the B operands of the second product
-        if (vis) attn_softmax_tile<true, DROP>(s0, s1, o0, o1, m, lsum, sl2, key0, hh, klim, xd, da.thr, pk, other_half);
-        else attn_softmax_tile<false, DROP>(s0, s1, o0, o1, m, lsum, sl2, key0, hh, klim, xd, da.thr, pk, other_half);
+        if (vis) {      // keys out of range or hidden by causality: minus infinity, in place -- then ONE form of the tile for all
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int kr_ = (t & 3) + 8 * (t >> 2) + 4 * hh;
+                s0[t] = (key0 + kr_ > klim) ? -__builtin_inff() : s0[t];
+                s1[t] = (key0 + 32 + kr_ > klim) ? -__builtin_inff() : s1[t];
+            }
+        }
+        attn_softmax_tile<false, DROP>(s0, s1, o0, o1, m, lsum, sl2, key0, hh, klim, xd, da.thr, pk, other_half);
         // ---- O^T += V^T P^T: second half's reads fly under the first half's MFMAs ----
         TRX_VT_READ(2) TRX_VT_READ(3)
         TRX_VT_WAIT(0, 1, 8)
@@ -1257,6 +1268,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DROP || MM
     TRX_STAMP(31, __builtin_amdgcn_s_memtime()); TRX_STAMP(1, __builtin_amdgcn_s_memrealtime());
 }
 
+#include "attn_fwd_persist.h"
 #include "attn_fwd_f32.h"
 #include "attn_bwd_f32.h"
 #include "attn_fwd_pp.h"
@@ -1558,9 +1570,22 @@ static int attention_fwd_impl(const void* q, const void* k, const void* v, const
         static const bool use_pp = getenv("TRX_NN_ATTN_PP") != nullptr;
         const bool pp = use_pp && Lq >= 256 && Lk <= 1024 && mask_mode != TRX_NN_MASK_FULL;
         dim3 g3((unsigned)((int64_t)B * H * ((Lq + 255) / 256))), b3(512);
+        // TRX_NN_ATTN_PERSIST=1 (round 5, an experiment until it is measured): the encoder's shape class on persistent
+        // workgroups (attn_fwd_persist.h) -- as many as are resident at once, each taking several 128-query items
+#ifndef TRX_ATT_PERSIST_DEFAULT
+#define TRX_ATT_PERSIST_DEFAULT 0
+#endif
+        static const bool use_persist = getenv("TRX_NN_ATTN_PERSIST") ? atoi(getenv("TRX_NN_ATTN_PERSIST")) != 0 : TRX_ATT_PERSIST_DEFAULT != 0;
+        const int nitems = (int)((int64_t)B * H * (Lq / 128));
+        const int pslots = 768;              // 3 workgroups per CU
+        const bool persist = use_persist && !pp && !causal && Lq % 128 == 0 && Lk % 64 == 0 && Lk >= 128 && Lk <= 512 && mask_mode != TRX_NN_MASK_FULL && nitems > pslots;
 #define TRX_LAUNCH_MFMA(MM_, DROP_)                                                                                       \
     do {                                                                                                                  \
-        if (pp) {                                                                                                         \
+        if (persist) {                                                                                                    \
+            hipLaunchKernelGGL((attention_fwd_persist_kernel<(MM_) == TRX_NN_MASK_FULL ? TRX_NN_MASK_NONE : (MM_), DROP_>), dim3(pslots), b2, 0, st, \
+                               (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, mask, B, H, Lq, Lk, scale, (bf16_t*)out, lse, da, nitems); \
+        }                                                                                                                 \
+        else if (pp) {                                                                                                         \
             auto kern_ = attention_fwd_pp_kernel<(MM_) == TRX_NN_MASK_FULL ? TRX_NN_MASK_NONE : (MM_), DROP_>;            \
             static std::atomic<unsigned long long> attr_devs_{0ull};   /* the LDS limit is a per-device attribute */          \
             int dev_ = 0;                                                                                                 \
