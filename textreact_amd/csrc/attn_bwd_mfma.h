@@ -69,7 +69,10 @@ template <int N> struct ic_ { static constexpr int value = N; };     // a compil
 
 // ---- pass 1: dQ ------------------------------------------------------------------------------------
 template <int MM, bool DROP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attention_bwd_dq_mfma_kernel(
+#ifndef TRX_DQ_WAVES
+#define TRX_DQ_WAVES 2
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRX_DQ_WAVES, TRX_DQ_WAVES))) void attention_bwd_dq_mfma_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, const float* __restrict__ mask,
     int causal, int B, int H, int Lq, int Lk, float scale, const bf16_t* __restrict__ dout,
     const bf16_t* __restrict__ o, const float* __restrict__ lse, float* __restrict__ negl, float* __restrict__ negd,
@@ -299,22 +302,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     else { p0[t] = __builtin_fmaf(p0[t], k0, nd); p0[t + 1] = __builtin_fmaf(p0[t + 1], k1, nd); }
                 }
         }
-        // two copies behind ONE wave-uniform branch: written as `if (vis) pr = ...` inside the loop hipcc if-converts the test into
-        // a v_cmp + v_cndmask (+ s_and with vis) per element on EVERY tile -- a quarter of the loop's vector instructions, for a
-        // condition that holds on the diagonal and tail tiles only
-        auto elementwise = [&](auto VISC) __attribute__((always_inline)) {
-            constexpr bool VIS = decltype(VISC)::value != 0;
+        // (rounds 3-4: two copies of the elementwise block behind one wave-uniform branch -- written as `if (vis) pr = ...` inside the
+        // loop hipcc if-converts the test into a v_cmp + v_cndmask per element on EVERY tile; round 5: the hidden scores are set to
+        // minus infinity in place behind that branch and ONE copy follows: 40-50 registers fewer, 1-2 % faster,
+        // profiles/r05_attention_bwd_inplace_ab.txt)
+        if (vis) {      // hidden keys: a score of minus infinity, in place (its probability is exp2(-inf) = 0), then ONE form for all tiles
 #pragma unroll
-            for (int hb = 0; hb < 2; ++hb)
+            for (int t = 0; t < 16; ++t) {
+                const int kr_ = (t & 3) + 8 * (t >> 2) + 4 * hh;
+                s0[t] = (key0 + kr_ > klim) ? -__builtin_inff() : s0[t];
+                s1[t] = (key0 + 32 + kr_ > klim) ? -__builtin_inff() : s1[t];
+            }
+        }
 #pragma unroll
-                for (int t = 0; t < 16; ++t) {
-                    const int kr_ = hb * 32 + (t & 3) + 8 * (t >> 2) + 4 * hh;
-                    float pr = __builtin_amdgcn_exp2f(fminf(__builtin_fmaf(hb ? s1[t] : s0[t], sl2, nlsl2), 0.f));   // p <= 1
-                    if (VIS) pr = (key0 + kr_ > klim) ? 0.f : pr;
-                    if (hb) s1[t] = pr * p1[t]; else s0[t] = pr * p0[t];
-                }
-        };
-        if (vis) elementwise(ic_<1>{}); else elementwise(ic_<0>{});
+        for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const float pr = __builtin_amdgcn_exp2f(fminf(__builtin_fmaf(hb ? s1[t] : s0[t], sl2, nlsl2), 0.f));   // p <= 1
+                if (hb) s1[t] = pr * p1[t]; else s0[t] = pr * p0[t];
+            }
         // ---- dQ^T += K^T dS^T ----
         TRX_BWD_TRWAIT(kt0, 4)
         {
@@ -554,16 +560,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (MM != TRX_NN_MASK_FULL) { TRX_BWD2_TRANSPOSED() }
             // ---- P = exp2(scale log2e (S - lse/scale) + mask log2e) ; dS = P (dP - delta) ----  (two copies behind one
             // wave-uniform branch, as in the dq pass)
-            auto elementwise = [&](auto VISC) __attribute__((always_inline)) {
-                constexpr bool VIS = decltype(VISC)::value != 0;
+            if (vis) {      // hidden queries: a score of minus infinity in place (probability exp2(-inf) = 0), then ONE form for all tiles
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const int qr_ = q0 + hb * 32 + (t & 3) + 8 * (t >> 2) + 4 * hh;
+                    s[t] = (qr_ >= Lq || qr_ < qmin) ? -__builtin_inff() : s[t];
+                }
+            }
+            {
 #pragma unroll
                 for (int t = 0; t < 16; ++t) {
                     const int qr_ = q0 + hb * 32 + (t & 3) + 8 * (t >> 2) + 4 * hh;
                     float val = __builtin_fmaf(s[t], sl2, mk2);
                     if (MM == TRX_NN_MASK_FULL)   // wave-uniform base + a 32-bit offset: row (uniform) * Lk + this lane's key
                         val += fmaxf(mfull[(unsigned)(min(qr_, Lq - 1) * Lk) + (unsigned)kc] * L2E, -268435456.0f);
-                    float pr = __builtin_amdgcn_exp2f(fminf(val, 0.f));   // p <= 1
-                    if (VIS) pr = (qr_ >= Lq || qr_ < qmin) ? 0.f : pr;
+                    const float pr = __builtin_amdgcn_exp2f(fminf(val, 0.f));   // p <= 1
                     if (DROP) {
                         const unsigned bits = lowbias32(xdrop + (unsigned)(q0 + hb * 32 + (t & 3) + 8 * (t >> 2)) * DROP_C1);
                         const float km = (((bits >> dshift) & 0xffffu) >= da.thr) ? da.inv_keep : 0.f;
@@ -574,8 +585,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         p[t] = pr * p[t];
                     }
                 }
-            };
-            if (vis) elementwise(ic_<1>{}); else elementwise(ic_<0>{});
+            }
             if (MM == TRX_NN_MASK_FULL) { TRX_BWD2_TRANSPOSED() }
 #undef TRX_BWD2_TRANSPOSED
             // ---- dV^T += dO^T P ;  dK^T += Q^T dS ----
