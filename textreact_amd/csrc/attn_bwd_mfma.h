@@ -69,10 +69,13 @@ template <int N> struct ic_ { static constexpr int value = N; };     // a compil
 
 // ---- pass 1: dQ ------------------------------------------------------------------------------------
 template <int MM, bool DROP>
-#ifndef TRX_DQ_WAVES
-#define TRX_DQ_WAVES 2
+#ifndef TRX_DQ_HALF      // 1: the dq pass works on half tiles (32 keys) and fits three waves per SIMD
+#define TRX_DQ_HALF 1
 #endif
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRX_DQ_WAVES, TRX_DQ_WAVES))) void attention_bwd_dq_mfma_kernel(
+#ifndef TRX_DQ_WAVES
+#define TRX_DQ_WAVES (TRX_DQ_HALF ? 3 : 2)
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MM == TRX_NN_MASK_FULL ? 2 : TRX_DQ_WAVES, MM == TRX_NN_MASK_FULL ? 2 : TRX_DQ_WAVES))) void attention_bwd_dq_mfma_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, const float* __restrict__ mask,
     int causal, int B, int H, int Lq, int Lk, float scale, const bf16_t* __restrict__ dout,
     const bf16_t* __restrict__ o, const float* __restrict__ lse, float* __restrict__ negl, float* __restrict__ negd,
@@ -242,6 +245,96 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRX_DQ_WAVE
         if ((kb & (KS - 1)) == kp) {          // wave-uniform: this wave's tile
         const unsigned bofs = (unsigned)(buf * 16384);
         const int key0 = kb * 64;
+#if TRX_DQ_HALF
+        // Round 5: the tile as two halves of 32 keys, one after the other -- S, dP, the elementwise part and the dQ update of a
+        // half use 16 + 16 accumulator registers instead of 32 + 32 and four row fragments instead of eight: 145 registers
+        // instead of 186-198, THREE waves per SIMD instead of two.  Every accumulator sees the same products in the same order
+        // as in the whole-tile form (bit-identical results).
+        const unsigned ta0 = tra0 + bofs, ta1 = tra1 + bofs;
+        const bool vis = key0 + 63 > klim_wave_min;
+        auto half = [&](auto HB) __attribute__((always_inline)) {
+            constexpr int hb = decltype(HB)::value;
+            // ---- S^T = K Q^T (+ mask / scale) ----
+            f32x16 sh;
+            if (keymask) {
+                const float* mt = ldsM + (kb - kc) * 64 + 32 * hb + 4 * hh;
+#pragma unroll
+                for (int t4 = 0; t4 < 4; ++t4) {
+                    const float4 a = *reinterpret_cast<const float4*>(mt + 8 * t4);
+                    sh[4 * t4] = a.x; sh[4 * t4 + 1] = a.y; sh[4 * t4 + 2] = a.z; sh[4 * t4 + 3] = a.w;
+                }
+            } else if (MM == TRX_NN_MASK_FULL) {
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const int kr_ = (t & 3) + 8 * (t >> 2) + 4 * hh;
+                    sh[t] = fmaxf(mrow[min(key0 + 32 * hb + kr_, Lk - 1)] * inv_scale, mask_floor);
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < 16; ++t) sh[t] = 0.f;
+            }
+            bf16x8 fr[4];
+#define TRX_BWD_ROWS4(DST, BASE)                                                                            \
+    _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_)                                                        \
+        asm volatile("ds_read_b128 %0, %1" : "=&v"(DST[s_]) : "v"(rfa[s_] + (BASE)) : "memory");
+#define TRX_BWD_WAIT4(DST) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(DST[0]), "+v"(DST[1]), "+v"(DST[2]), "+v"(DST[3]) :: "memory");
+            TRX_BWD_ROWS4(fr, bofs + (unsigned)(hb * 4096))
+            TRX_BWD_WAIT4(fr)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) sh = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[s], qf[s], sh, 0, 0, 0);
+            // ---- dP^T - delta = V dO^T - delta ----
+            f32x16 ph;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) ph[t] = DROP ? 0.f : nd;   // dropout rescales dP before - delta
+            TRX_BWD_ROWS4(fr, bofs + 8192u + (unsigned)(hb * 4096))
+            TRX_BWD_WAIT4(fr)
+#undef TRX_BWD_ROWS4
+#undef TRX_BWD_WAIT4
+#pragma unroll
+            for (int s = 0; s < 4; ++s) ph = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[s], dof[s], ph, 0, 0, 0);
+            // K^T fragments of this half's 32 keys fly under the elementwise part
+            uint2 kt0[2][2], kt1[2][2];
+            TRX_BWD_TR(kt0, 2 * hb, ta0, ta1)
+            TRX_BWD_TR(kt1, 2 * hb + 1, ta0, ta1)
+            // ---- dS = P (dP - delta), P = exp2(scale log2e S - lse log2e) ----
+            if (DROP) {
+                const unsigned xd = xdrop + (unsigned)(kb * 32) * DROP_C2;
+#pragma unroll
+                for (int t = 0; t < 16; t += 2) {
+                    const unsigned bits = lowbias32(xd + (unsigned)(hb * 16 + ((t & 3) >> 1) + 4 * (t >> 2)) * DROP_C2);
+                    const float k0 = drop_keep(bits, 0, da.thr) ? da.inv_keep : 0.f, k1 = drop_keep(bits, 1, da.thr) ? da.inv_keep : 0.f;
+                    ph[t] = __builtin_fmaf(ph[t], k0, nd); ph[t + 1] = __builtin_fmaf(ph[t + 1], k1, nd);
+                }
+            }
+            if (vis) {      // hidden keys: a score of minus infinity in place (its probability is exp2(-inf) = 0)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const int kr_ = 32 * hb + (t & 3) + 8 * (t >> 2) + 4 * hh;
+                    sh[t] = (key0 + kr_ > klim) ? -__builtin_inff() : sh[t];
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const float pr = __builtin_amdgcn_exp2f(fminf(__builtin_fmaf(sh[t], sl2, nlsl2), 0.f));   // p <= 1
+                sh[t] = pr * ph[t];
+            }
+            // ---- dQ^T += K^T dS^T ----
+            TRX_BWD_TRWAIT(kt0, 4)
+            {
+                const bf16x8 ds = TRX_BWD_PACK8(sh, 0);
+                a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(TRX_BWD_TRFRAG(kt0, 0), ds, a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(TRX_BWD_TRFRAG(kt0, 1), ds, a1, 0, 0, 0);
+            }
+            TRX_BWD_TRWAIT(kt1, 0)
+            {
+                const bf16x8 ds = TRX_BWD_PACK8(sh, 1);
+                a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(TRX_BWD_TRFRAG(kt1, 0), ds, a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(TRX_BWD_TRFRAG(kt1, 1), ds, a1, 0, 0, 0);
+            }
+        };
+        half(ic_<0>{});
+        half(ic_<1>{});
+#else
         // ---- S^T = K Q^T (+ mask / scale) ----
         f32x16 s0, s1;
         if (keymask) {
@@ -348,6 +441,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRX_DQ_WAVE
             a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(TRX_BWD_TRFRAG(kt1, 0), ds, a0, 0, 0, 0);
             a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(TRX_BWD_TRFRAG(kt1, 1), ds, a1, 0, 0, 0);
         }
+#endif
         }
         buf = buf1;
     }
