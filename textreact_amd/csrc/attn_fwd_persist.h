@@ -8,6 +8,9 @@
 // Here 768 workgroups stay and take items w, w + 768, ...: the K / V ring runs on across items -- the last two tiles' staging
 // slots of an item fetch the first two tiles of the next -- and the next item's Q and mask are requested at the start of the
 // epilogue, behind the last MFMA, so they fly under the output stores.
+// MEASURED (profiles/r05_attention_dropout_ab.json, same box, interleaved, outputs bit-identical): 39.8 against 39.9 us at 512 x 512,
+// 52.3 against 52.0 with dropout -- no gain: while one of a CU's three workgroups is in its prologue the other two have the SIMDs.
+// Off by default (TRX_NN_ATTN_PERSIST=1); kept with its test (tests/test_predictor_gpu.py::test_persistent_forward_kernel).
 //
 // Vector-memory order per wave (what the counted waits rely on): ... D(p) D(p+1) | iteration p: D(p+2) ... where p runs over
 // the tiles of ALL of the workgroup's items; between an item's last iteration and the next item's first sit the C++ loads of
