@@ -534,6 +534,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // dropout hash input of (query 4 hh, this lane's key pair); the key's half of the hash is bit 4 of dshift
     const unsigned xdrop = DROP ? drop_base_da(da, (unsigned)(b * H + h)) + (unsigned)(4 * hh) * DROP_C1 + ((unsigned)kc >> 1) * DROP_C2 : 0u;
     const unsigned dshift = ((unsigned)kc & 1u) << 4;
+    const bool lane_odd = (lane & 1) != 0;
+    const unsigned xdrop_p = xdrop + (lane_odd ? DROP_C1 : 0u);      // the hash input of this lane's own parity of queries (see the elementwise part)
 
     const int prow = lane >> 3, pslot = lane & 7;
     const unsigned rowbytes = (unsigned)ldq * 2u, rowbytes_d = (unsigned)H * 128u;   // q rows (maybe packed) / dout rows (dense)
@@ -662,6 +664,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
             }
             {
+                // Dropout decisions.  A hash serves a PAIR of keys (its two 16-bit halves), and here a lane is a key: lanes 2 j and
+                // 2 j + 1 would compute the same 16 hashes each.  Round 5: each computes the eight of its own parity (queries
+                // t = 2 i + (lane & 1)) and takes the other eight from its neighbour with one quad-permute move each -- 8 hashes + 8
+                // moves + 16 selects instead of 16 hashes (a hash is two quarter-rate multiplies and six more instructions).
+                unsigned hbits[16];
+                if (DROP) {
+                    unsigned own[8], nbr[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int ci = ((2 * i) & 3) + 8 * (i >> 1);       // (t & 3) + 8 (t >> 2) of t = 2 i, without the lane's parity
+                        own[i] = lowbias32(xdrop_p + (unsigned)(q0 + hb * 32 + ci) * DROP_C1);
+                        nbr[i] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)own[i], 0xB1, 0xf, 0xf, false);     // quad_perm [1, 0, 3, 2]
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        hbits[2 * i] = lane_odd ? nbr[i] : own[i];
+                        hbits[2 * i + 1] = lane_odd ? own[i] : nbr[i];
+                    }
+                }
 #pragma unroll
                 for (int t = 0; t < 16; ++t) {
                     const int qr_ = q0 + hb * 32 + (t & 3) + 8 * (t >> 2) + 4 * hh;
@@ -670,7 +691,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         val += fmaxf(mfull[(unsigned)(min(qr_, Lq - 1) * Lk) + (unsigned)kc] * L2E, -268435456.0f);
                     const float pr = __builtin_amdgcn_exp2f(fminf(val, 0.f));   // p <= 1
                     if (DROP) {
-                        const unsigned bits = lowbias32(xdrop + (unsigned)(q0 + hb * 32 + (t & 3) + 8 * (t >> 2)) * DROP_C1);
+                        const unsigned bits = hbits[t];
                         const float km = (((bits >> dshift) & 0xffffu) >= da.thr) ? da.inv_keep : 0.f;
                         s[t] = pr * km;                                    // what the forward multiplied V with
                         p[t] = pr * __builtin_fmaf(p[t], km, ndv[t]);
