@@ -812,6 +812,28 @@ def test_more_than_one_query_batch_and_many_splits():
         assert st["n_splits"] > 1
 
 
+
+def test_the_split_count_fills_whole_rounds_of_workgroups():
+    """knn_api.hip: choose_splits -- 18 query tiles take 14 corpus splits (252 workgroups, one round of the 256 CUs), not the
+    ceil(256 / 18) = 15 of the old rule (270: a second round for 14 workgroups); 50 tiles take 5 (250), not 6; a full batch of 256
+    tiles keeps 4; the answers are the oracle's whatever the count"""
+    import torch
+    import textreact_amd.faiss_compat as faiss
+    from oracle import flat_knn as oracle
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    y = torch.randn((200_000, 768), generator=g, device="cuda").bfloat16()
+    idx = faiss.IndexFlatIP(768); idx.add(y)
+    yh = y.float().cpu().numpy()
+    for nq, want in ((4464, 14), (12800, 5), (65536, 4)):
+        x = torch.randn((nq, 768), generator=g, device="cuda").bfloat16()
+        D, I = idx.search(x, 10)
+        st = idx.last_stats()
+        assert st["n_splits"] == want and st["n_uncertified"] == 0, st
+        sel = np.random.default_rng(nq).integers(0, nq, 40)
+        Dr, Ir = oracle.knn_canonical(IP, x[torch.from_numpy(sel).cuda()].float().cpu().numpy(), yh, 10)
+        assert np.array_equal(I.cpu().numpy()[sel], Ir) and np.array_equal(D.cpu().numpy()[sel].view(np.uint32), Dr.view(np.uint32))
+
+
 @pytest.mark.parametrize("nsplits", [1, 3, 4, 5, 8, 13])
 def test_shared_thresholds_with_any_number_of_splits(nsplits, monkeypatch):
     """the splits of a query share thresholds through four slots (slot = split & 3, knn_scan.hip): exact for split counts
