@@ -277,8 +277,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int key0 = j * 64;
         const bool vis = key0 + 63 > klim_wave_min;
         const unsigned xd = xdrop + (unsigned)(j * 32) * DROP_C2;
-        if (vis) attn_softmax_tile<true, DROP>(s0, s1, o0, o1, m, lsum, sl2, key0, hh, klim, xd, da.thr, pk);
-        else attn_softmax_tile<false, DROP>(s0, s1, o0, o1, m, lsum, sl2, key0, hh, klim, xd, da.thr, pk);
+        if (vis) {      // hidden keys: minus infinity in place, then the one tile form (as in attention_fwd_mfma_kernel, round 5)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int kr_ = (t & 3) + 8 * (t >> 2) + 4 * hh;
+                s0[t] = (key0 + kr_ > klim) ? -__builtin_inff() : s0[t];
+                s1[t] = (key0 + 32 + kr_ > klim) ? -__builtin_inff() : s1[t];
+            }
+        }
+        attn_softmax_tile<false, DROP>(s0, s1, o0, o1, m, lsum, sl2, key0, hh, klim, xd, da.thr, pk);
         __builtin_amdgcn_sched_barrier(0);             // the fragment reads below go AFTER the softmax (they would cost it 64 registers)
         PP_READ_V(j);                                  // V_j^T: consumed by PV in M(j+1)
         if (j + 1 < nkb) {
