@@ -52,9 +52,16 @@ typedef struct trx_index trx_index;
 
 enum { TRX_METRIC_IP = 0, TRX_METRIC_L2 = 1 };
 enum { TRX_DTYPE_F32 = 0, TRX_DTYPE_BF16 = 1,
-       TRX_DTYPE_I8 = 2 /* HOST entry points only (trx_index_add, trx_index_search): int8 rows -- the Morgan bit vectors of
-                           retrieve_faiss.py:36-44 -- cross PCIe as bytes and are widened on the device; same values, same
-                           results as their float32 conversion */ };
+       /* HOST entry points only (trx_index_add, trx_index_search) -- the array types the reference hands FAISS: */
+       TRX_DTYPE_I8 = 2,  /* int8 rows -- the Morgan bit vectors of retrieve_faiss.py:36-44 -- cross PCIe as bytes and are
+                             widened on the device; same values, same results as their float32 conversion */
+       TRX_DTYPE_I64 = 3, /* int64 rows -- the reaction difference fingerprints of retrieve_faiss.py:24-27 (numpy's default
+                             integer).  FAISS' Python wrapper turns such an array into float32 on one thread before the index
+                             sees it; here worker threads (TRX_HOST_THREADS, default min(cores, 32)) narrow it to int8 while
+                             every value of a block fits a signed byte -- an eighth of the bytes over PCIe -- and convert a
+                             block that holds a larger value to the float32 FAISS would have seen.  Same values, same results */
+       TRX_DTYPE_I32 = 4, TRX_DTYPE_I16 = 5, TRX_DTYPE_U8 = 6, /* likewise */
+       TRX_DTYPE_F64 = 7  /* float64 rows: rounded to float32 (nearest even) by the worker threads, as the wrapper's astype does */ };
 
 enum {
     TRX_OK = 0,
@@ -78,7 +85,8 @@ enum {
 int trx_index_create(int d, int metric, int device, trx_index** out);
 
 /* index.add(x)  [retrieve_faiss.py:66]: append n vectors (row-major, contiguous, d components
- * each) from HOST memory; the caller keeps ownership of x.  Ids are assigned sequentially. */
+ * each) from HOST memory; the caller keeps ownership of x.  Ids are assigned sequentially.  Any TRX_DTYPE_*: the rows reach
+ * the device through pinned double buffers filled by worker threads, a chunk crossing PCIe while the next is prepared. */
 int trx_index_add(trx_index* idx, const void* x, int64_t n, int dtype);
 
 /* Same, x already in DEVICE memory of the index's device; runs on `stream` (hipStream_t) and
@@ -99,10 +107,19 @@ void trx_index_destroy(trx_index* idx);
 
 /* distance, rank = index.search(q, k)  [retrieve_faiss.py:70-71]: HOST in, HOST out.
  * D: float[nq*k], I: int64[nq*k], caller-allocated.  Queries are taken in blocks of 65,536: the next block's copy to the
- * device runs beside the current block's search; trx_index_last_stats afterwards covers all blocks.  dtype TRX_DTYPE_I8
- * is accepted here and by trx_index_add (bytes over PCIe, widened on the device). */
+ * device runs beside the current block's search; trx_index_last_stats afterwards covers all blocks.  Any TRX_DTYPE_* (the
+ * integer and float64 types are accepted here and by trx_index_add only: see the enum). */
 int trx_index_search(trx_index* idx, const void* q, int64_t nq, int dtype, int k, float* D,
                      int64_t* I);
+
+/* The storage-type change the two host entry points above apply to the caller's array, alone and host to host (no GPU is
+ * touched: CPU tests pin it to numpy's astype): `count` components of `dtype` -> to_dtype TRX_DTYPE_I8 (integer dtypes only)
+ * or TRX_DTYPE_F32 (the float32 FAISS' wrapper makes of every array), on the library's worker threads.  Returns 0, 1 when
+ * to_dtype is I8 and some value does not fit a signed byte (dst is then undefined), or a negative TRX_E* code. */
+int trx_host_convert(const void* src, int dtype, int64_t count, void* dst, int to_dtype);
+
+/* Worker threads of the host entry points: TRX_HOST_THREADS, default min(cores in the affinity mask, 32). */
+int trx_host_threads(void);
 
 /* Same with q, D, I in DEVICE memory; runs on `stream`, blocks until D and I are final (see
  * Threading above).  This is the form bench.py times (inputs resident in HBM) and the one the

@@ -11,6 +11,7 @@ _SO = os.path.join(_CSRC, os.environ.get("TRX_LIB", "libtrxknn.so"))  # TRX_LIB:
 METRIC_IP, METRIC_L2 = 0, 1
 TIES_BY_ID, TIES_FAISS = 0, 1
 DTYPE_F32, DTYPE_BF16, DTYPE_I8 = 0, 1, 2
+DTYPE_I64, DTYPE_I32, DTYPE_I16, DTYPE_U8, DTYPE_F64 = 3, 4, 5, 6, 7      # host entry points only
 MAX_K, FAST_MAX_K = 2048, 24
 
 # every symbol include/trx_knn.h declares (tests/test_abi.py checks the header against this list)
@@ -21,6 +22,7 @@ SYMBOLS = [
     "trx_merge_topk_device", "trx_index_last_stats", "trx_search_stats_size",
     "trx_index_set_timing", "trx_last_error", "trx_version",
     "trx_merge_topk_device_s64", "trx_index_set_tie_rule", "trx_faiss_tie_order_device",
+    "trx_host_convert", "trx_host_threads",
 ]
 
 
@@ -40,7 +42,7 @@ _lib = None
 
 def build(force=False):
     """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hip", ".h"))]
+    srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hip", ".h", ".cpp"))]
     srcs.append(os.path.join(_HERE, "..", "include", "trx_knn.h"))
     newest = max(os.path.getmtime(s) for s in srcs)
     nn = os.path.join(_CSRC, "libtrxnn.so")
@@ -82,6 +84,7 @@ def lib():
     L.trx_merge_topk_device_s64.argtypes = [i32, i32, i64, i32, vp, vp, vp, vp, vp, vp]
     L.trx_index_set_tie_rule.argtypes = [vp, i32]
     L.trx_faiss_tie_order_device.argtypes = [i64, i32, i32, vp, vp, vp, vp, vp]
+    L.trx_host_convert.argtypes = [vp, i32, i64, vp, i32]
     L.trx_index_last_stats.argtypes = [vp, ctypes.POINTER(SearchStats)]
     L.trx_index_set_timing.argtypes = [vp, i32]
     L.trx_last_error.restype = ctypes.c_char_p

@@ -4,6 +4,7 @@
 // point that would compute returns TRX_ENODEV / TRX_EHIP.
 #include "../../include/trx_knn.h"
 #include "knn_common.h"
+#include "knn_host.h"
 
 #include <algorithm>
 #include <mutex>
@@ -109,6 +110,8 @@ struct trx_index {
     int64_t c4_cap = 0, c4_rows = -1; int Kp4 = 0;
     // workspaces
     DevBuf w_stamp, w_stats, w_qnorm2, w_flag, w_exact, w_io, w_tmp, w_cls;      // (the big ones are shared: DevPool)
+    DevBuf w_stage[2], w_wide; // host entry points: a block of the caller's rows as staged (knn_host.h), and int8 rows widened to bf16
+    int64_t reserve_rows = 0;  // trx_index_add: the rows the index will hold when the call is through (one allocation, not one per block)
     DevBuf w_tie;             // TRX_TIES_FAISS: the canonical top 2k (D, I, S) the FAISS order is derived from
     int tie_rule = TRX_TIES_BY_ID;
     trx_search_stats stats{};
@@ -218,7 +221,8 @@ void trx_index_destroy(trx_index* idx) {
     if (idx->C8) (void)hipFree(idx->C8);
     if (idx->cbias8) (void)hipFree(idx->cbias8);
     if (idx->C4) (void)hipFree(idx->C4);
-    DevBuf* bufs[] = {&idx->w_stamp, &idx->w_stats, &idx->w_qnorm2, &idx->w_flag, &idx->w_exact, &idx->w_io, &idx->w_tmp, &idx->w_cls, &idx->w_tie};
+    DevBuf* bufs[] = {&idx->w_stamp, &idx->w_stats, &idx->w_qnorm2, &idx->w_flag, &idx->w_exact, &idx->w_io, &idx->w_tmp, &idx->w_cls, &idx->w_tie,
+                      &idx->w_stage[0], &idx->w_stage[1], &idx->w_wide};
     for (DevBuf* b : bufs) b->release();
     {   // the last index of the process on this device takes the shared workspaces with it
         DevPool& pl = pool_of(idx->device);
@@ -293,7 +297,7 @@ int trx_index_add_device(trx_index* idx, const void* x, int64_t n, int dtype, vo
     if (idx->mode == MODE_EMPTY) newmode = hs.inexact_any ? inexact_mode() : MODE_PLAIN;
     else if (idx->mode == MODE_PLAIN && hs.inexact_any) newmode = inexact_mode();
     int64_t need = idx->n + n, newcap = idx->cap;
-    if (need > newcap) newcap = round_up64(std::max<int64_t>(need, idx->cap + idx->cap / 2), TILE_M);
+    if (need > newcap) newcap = round_up64(std::max<int64_t>(std::max(need, idx->reserve_rows), idx->cap + idx->cap / 2), TILE_M);
     if (newcap != idx->cap || newmode != idx->mode) { rc = restructure(idx, newcap, newmode, st); if (rc) return rc; }
 
     // append
@@ -320,32 +324,39 @@ int trx_index_add_device(trx_index* idx, const void* x, int64_t n, int dtype, vo
     return TRX_OK;
 }
 
+// what a block of host rows of `dtype` can need on the device: integers may fall back to float32 (knn_host.h)
+static size_t stage_capacity(int64_t m, int d, int dtype) {
+    const int worst = dtype == TRX_DTYPE_BF16 ? STAGED_BF16 : dtype == TRX_DTYPE_I8 ? STAGED_I8 : STAGED_F32;
+    return staged_bytes(m, d, worst);
+}
+
 int trx_index_add(trx_index* idx, const void* x, int64_t n, int dtype) {
     if (!idx) return fail(TRX_EINVAL, "index is null");
     if (n < 0 || (n > 0 && !x)) return fail(TRX_EINVAL, "bad vector block");
-    if (dtype != TRX_DTYPE_F32 && dtype != TRX_DTYPE_BF16 && dtype != TRX_DTYPE_I8) return fail(TRX_EINVAL, "unknown dtype");
+    const size_t esz = (size_t)host_dtype_size(dtype);
+    if (!esz) return fail(TRX_EINVAL, "unknown dtype");
     if (n == 0) return TRX_OK;
     int rc = set_device(idx); if (rc) return rc;
-    const size_t esz = dtype == TRX_DTYPE_F32 ? 4 : dtype == TRX_DTYPE_BF16 ? 2 : 1;
-    // stream the block through a bounded staging buffer (<= 1 GiB at a time); int8 rows cross PCIe as bytes and are widened
-    // to bf16 (every int8 value is one) on the device
-    const int64_t rows_per = std::max<int64_t>(1, ((int64_t)1 << 30) / (int64_t)(idx->d * (dtype == TRX_DTYPE_I8 ? 2 : esz)));
-    const int64_t rows = std::min(rows_per, n);
-    char* dev = nullptr; char* wide = nullptr;
-    HIPCHK(hipMalloc((void**)&dev, (size_t)rows * idx->d * esz));
-    if (dtype == TRX_DTYPE_I8 && hipMalloc((void**)&wide, (size_t)rows * idx->d * 2) != hipSuccess) {
-        (void)hipFree(dev);
-        return fail(TRX_EHIP, "out of device memory for the staging copy");
-    }
-    struct Free { char* a; char* b; ~Free() { if (a) (void)hipFree(a); if (b) (void)hipFree(b); } } guard{dev, wide};
+    if (!idx->copy_stream) HIPCHK(hipStreamCreateWithFlags(&idx->copy_stream, hipStreamNonBlocking));
+    // The rows go through the staging pipeline of knn_host.cpp in blocks whose staged + widened copies stay under 1.5 GiB;
+    // int8 rows (given, or narrowed from wider integers) cross PCIe as bytes and become bf16 -- every int8 value is one -- on
+    // the device.
+    const int64_t rows_per = std::max<int64_t>(1, ((int64_t)1 << 30) / ((int64_t)idx->d * 4));
+    struct Release { trx_index* i; ~Release() { i->w_stage[0].release(); i->w_wide.release(); i->reserve_rows = 0; } } guard{idx};
+    idx->reserve_rows = idx->n + n;
+    int prefer = STAGED_I8;
     for (int64_t r0 = 0; r0 < n; r0 += rows_per) {
         const int64_t m = std::min(rows_per, n - r0);
-        HIPCHK(hipMemcpy(dev, (const char*)x + (size_t)r0 * idx->d * esz, (size_t)m * idx->d * esz, hipMemcpyHostToDevice));
-        if (dtype == TRX_DTYPE_I8) {
-            HIPCHK(launch_widen_i8((const signed char*)dev, m, idx->d, (bf16_t*)wide, nullptr));
-            rc = trx_index_add_device(idx, wide, m, TRX_DTYPE_BF16, nullptr);
+        if ((rc = idx->w_stage[0].reserve(stage_capacity(m, idx->d, dtype)))) return rc;
+        int form = prefer;
+        HIPCHK(stage_host_rows((const char*)x + (size_t)r0 * idx->d * esz, dtype, m, idx->d, idx->w_stage[0].p, &form, idx->copy_stream));
+        if (form == STAGED_F32) prefer = STAGED_F32;      // (a wide integer turned up: later blocks do not try the narrow form first)
+        if (form == STAGED_I8) {
+            if ((rc = idx->w_wide.reserve(staged_bytes(m, idx->d, STAGED_BF16)))) return rc;
+            HIPCHK(launch_widen_i8((const signed char*)idx->w_stage[0].p, m, idx->d, (bf16_t*)idx->w_wide.p, nullptr));
+            rc = trx_index_add_device(idx, idx->w_wide.p, m, TRX_DTYPE_BF16, nullptr);
         } else {
-            rc = trx_index_add_device(idx, dev, m, dtype, nullptr);
+            rc = trx_index_add_device(idx, idx->w_stage[0].p, m, form == STAGED_F32 ? TRX_DTYPE_F32 : TRX_DTYPE_BF16, nullptr);
         }
         if (rc) return rc;
     }
@@ -930,49 +941,49 @@ int trx_index_search(trx_index* idx, const void* q, int64_t nq, int dtype, int k
     if (!idx) return fail(TRX_EINVAL, "index is null");
     if (nq < 0 || (nq > 0 && (!q || !D || !I))) return fail(TRX_EINVAL, "null query/result pointer");
     if (k <= 0 || k > TRX_MAX_K) return fail(TRX_EINVAL, "k must be in [1, 2048]");
-    if (dtype != TRX_DTYPE_F32 && dtype != TRX_DTYPE_BF16 && dtype != TRX_DTYPE_I8) return fail(TRX_EINVAL, "unknown dtype");
+    const size_t esz = (size_t)host_dtype_size(dtype);
+    if (!esz) return fail(TRX_EINVAL, "unknown dtype");
     if (nq == 0) return TRX_OK;
     int rc = set_device(idx); if (rc) return rc;
     // Host arrays in, host arrays out (the FAISS protocol as retrieve_faiss.py:71 calls it), in blocks of 65,536 queries: block
-    // c is searched (enqueued, stream-ordered) while block c + 1 crosses PCIe on a stream of its own -- the search of a block
-    // of 1024-d fingerprints takes 16 ms and its 268 MB of float32 longer than that to arrive --, and the results of block c go
-    // back while block c + 1 is searched (two result buffers).
-    // int8 queries travel as bytes and are widened to bf16 on the device.
+    // c is searched (enqueued, stream-ordered) while the worker threads of knn_host.cpp bring block c + 1 into its staged form
+    // (int64 counts narrowed to int8, ...) and across PCIe on a stream of its own, and the results of block c go back while
+    // block c + 1 is searched (two staging buffers, two result buffers).  Rows staged as int8 are widened to bf16 on the device.
     constexpr int64_t BLOCK = 65536;
-    const size_t esz = dtype == TRX_DTYPE_F32 ? 4 : dtype == TRX_DTYPE_BF16 ? 2 : 1;
     const int64_t rows = std::min<int64_t>(BLOCK, nq);
-    const size_t qb = (size_t)round_up64((int64_t)((size_t)rows * idx->d * esz), 256);
-    const size_t wb = dtype == TRX_DTYPE_I8 ? (size_t)round_up64((int64_t)((size_t)rows * idx->d * 2), 256) : 0;
     const size_t db = (size_t)round_up64((int64_t)((size_t)rows * k * sizeof(float)), 256), ib = (size_t)rows * k * sizeof(int64_t);
-    if ((rc = idx->w_io.reserve(2 * qb + wb + 2 * (db + ib)))) return rc;
+    if ((rc = idx->w_io.reserve(2 * (db + ib)))) return rc;
     char* base = (char*)idx->w_io.p;
-    char* stage[2] = {base, base + qb};
-    char* wide = base + 2 * qb;
     float* Dd[2]; int64_t* Id[2];
-    for (int i = 0; i < 2; ++i) { Dd[i] = (float*)(base + 2 * qb + wb + i * (db + ib)); Id[i] = (int64_t*)((char*)Dd[i] + db); }
+    for (int i = 0; i < 2; ++i) { Dd[i] = (float*)(base + i * (db + ib)); Id[i] = (int64_t*)((char*)Dd[i] + db); }
     if (!idx->copy_stream) HIPCHK(hipStreamCreateWithFlags(&idx->copy_stream, hipStreamNonBlocking));
     const char* qh = (const char*)q;
     trx_search_stats acc{};
     const int64_t nblk = (nq + BLOCK - 1) / BLOCK;
     auto rows_of = [&](int64_t c) { return std::min<int64_t>(BLOCK, nq - c * BLOCK); };
-    auto begin = [&](int64_t c) -> int {      // enqueue the search of block c (its queries are in stage[c & 1]) into result set c & 1
-        const void* qd = stage[c & 1];
-        int qdt = dtype;
-        if (dtype == TRX_DTYPE_I8) {
-            HIPCHK(launch_widen_i8((const signed char*)qd, rows_of(c), idx->d, (bf16_t*)wide, nullptr));
-            qd = wide; qdt = TRX_DTYPE_BF16;
+    int form[2] = {STAGED_I8, STAGED_I8}, prefer = STAGED_I8;
+    auto stage = [&](int64_t c) -> int {      // block c of the caller's queries -> w_stage[c & 1] (returns when they are in HBM)
+        int r = idx->w_stage[c & 1].reserve(stage_capacity(rows_of(c), idx->d, dtype)); if (r) return r;
+        form[c & 1] = prefer;
+        HIPCHK(stage_host_rows(qh + (size_t)c * BLOCK * idx->d * esz, dtype, rows_of(c), idx->d, idx->w_stage[c & 1].p, &form[c & 1], idx->copy_stream));
+        if (form[c & 1] == STAGED_F32) prefer = STAGED_F32;
+        return TRX_OK;
+    };
+    auto begin = [&](int64_t c) -> int {      // enqueue the search of block c into result set c & 1
+        const void* qd = idx->w_stage[c & 1].p;
+        int qdt = form[c & 1] == STAGED_F32 ? TRX_DTYPE_F32 : TRX_DTYPE_BF16;
+        if (form[c & 1] == STAGED_I8) {
+            int r = idx->w_wide.reserve(staged_bytes(rows_of(c), idx->d, STAGED_BF16)); if (r) return r;
+            HIPCHK(launch_widen_i8((const signed char*)qd, rows_of(c), idx->d, (bf16_t*)idx->w_wide.p, nullptr));
+            qd = idx->w_wide.p;
         }
         return search_device_impl(idx, qd, rows_of(c), qdt, k, Dd[c & 1], Id[c & 1], nullptr, nullptr);
     };
-    HIPCHK(hipMemcpy(stage[0], qh, (size_t)rows * idx->d * esz, hipMemcpyHostToDevice));
+    if ((rc = stage(0))) return rc;
     if ((rc = begin(0))) return rc;
     for (int64_t c = 0; c < nblk; ++c) {
         const int64_t m = rows_of(c);
-        if (c + 1 < nblk) {      // the next block's queries cross PCIe while this block is being searched
-            HIPCHK(hipMemcpyAsync(stage[(c + 1) & 1], qh + (size_t)(c + 1) * BLOCK * idx->d * esz, (size_t)rows_of(c + 1) * idx->d * esz,
-                                  hipMemcpyHostToDevice, idx->copy_stream));
-            HIPCHK(hipStreamSynchronize(idx->copy_stream));
-        }
+        if (c + 1 < nblk && (rc = stage(c + 1))) return rc;      // the next block is prepared and crosses PCIe while this one is searched
         rc = trx_index_search_finish(idx); if (rc) return rc;
         const trx_search_stats s1 = idx->stats;
         acc.nq += s1.nq; acc.n_uncertified += s1.n_uncertified; acc.n_rescored += s1.n_rescored; acc.n_rescanned += s1.n_rescanned;
@@ -980,13 +991,23 @@ int trx_index_search(trx_index* idx, const void* q, int64_t nq, int dtype, int k
         acc.late_fallback |= s1.late_fallback;
         acc.n_splits = s1.n_splits; acc.k_split = s1.k_split; acc.exact_class = s1.exact_class; acc.int8_scan = s1.int8_scan;
         if (c + 1 < nblk && (rc = begin(c + 1))) return rc;      // ... and this block's results go back while the next one is searched
-        HIPCHK(hipMemcpyAsync(D + c * BLOCK * k, Dd[c & 1], (size_t)m * k * sizeof(float), hipMemcpyDeviceToHost, idx->copy_stream));
-        HIPCHK(hipMemcpyAsync(I + c * BLOCK * k, Id[c & 1], (size_t)m * k * sizeof(int64_t), hipMemcpyDeviceToHost, idx->copy_stream));
-        HIPCHK(hipStreamSynchronize(idx->copy_stream));
+        HIPCHK(unstage_to_host(D + c * BLOCK * k, Dd[c & 1], (size_t)m * k * sizeof(float), idx->copy_stream));
+        HIPCHK(unstage_to_host(I + c * BLOCK * k, Id[c & 1], (size_t)m * k * sizeof(int64_t), idx->copy_stream));
     }
     idx->stats = acc;
     return TRX_OK;
 }
+
+int trx_host_convert(const void* src, int dtype, int64_t count, void* dst, int to_dtype) {
+    if (count < 0 || (count > 0 && (!src || !dst))) return fail(TRX_EINVAL, "null pointer");
+    if (!host_dtype_size(dtype)) return fail(TRX_EINVAL, "unknown dtype");
+    if (to_dtype != TRX_DTYPE_I8 && to_dtype != TRX_DTYPE_F32) return fail(TRX_EINVAL, "to_dtype is TRX_DTYPE_I8 or TRX_DTYPE_F32");
+    if (to_dtype == TRX_DTYPE_I8 && !host_dtype_is_wide_int(dtype) && dtype != TRX_DTYPE_I8) return fail(TRX_EINVAL, "only integer arrays narrow to int8");
+    if (to_dtype == TRX_DTYPE_F32 && (dtype == TRX_DTYPE_BF16 || dtype == TRX_DTYPE_I8)) return fail(TRX_EINVAL, "bf16 / int8 rows are staged as they are");
+    return convert_host_rows(src, dtype, count, dst, to_dtype == TRX_DTYPE_I8 ? STAGED_I8 : STAGED_F32);
+}
+
+int trx_host_threads(void) { return host_threads(); }
 
 int trx_merge_topk_device_s64(int metric, int nlists, int64_t nq, int k, const double* S_lists,
                               const int64_t* I_lists, float* D, int64_t* I, double* S, void* stream) {

@@ -8,8 +8,9 @@ Mirrors the object protocol the reference binds at retrieve/retrieve_faiss.py:65
 
 so ``import textreact_amd.faiss_compat as faiss`` is the whole change on the reference side
 (INTEGRATION.md).  Same names, argument meaning and error behaviour as faiss' Python wrapper:
-``add``/``search`` take C-contiguous 2-D arrays of any numeric dtype (converted to float32, as
-faiss.swigfaiss replacement_add does -- the reference passes int64 / int8 fingerprints), a
+``add``/``search`` take 2-D arrays of any numeric dtype (faiss.swigfaiss replacement_add converts
+them to float32; the reference passes int64 / int8 fingerprints, which the library here narrows on
+its own worker threads -- same values, same results), a
 dimension mismatch raises AssertionError, ``search`` returns ``(D float32[nq,k], I int64[nq,k])``
 best first with ``I = -1`` / ``D = +-3.4e38`` padding when fewer than k vectors are indexed.
 
@@ -64,33 +65,20 @@ class IndexFlat:
     def add(self, x):
         if _is_torch(x):
             return self._add_torch(x)
-        for blk, dt in self._host_blocks(x):
-            _lib.check(_lib.lib().trx_index_add(self._h, blk.ctypes.data_as(ctypes.c_void_p), blk.shape[0], dt))
+        x, dt = self._host_arg(x)
+        _lib.check(_lib.lib().trx_index_add(self._h, x.ctypes.data_as(ctypes.c_void_p), x.shape[0], dt))
 
     def search(self, x, k):
         k = int(k)
         assert k > 0, "k must be positive"
         if _is_torch(x):
             return self._search_torch(x, k)
-        self._stats_override = None
-        nq = np.shape(x)[0]
+        x, dt = self._host_arg(x)
+        nq = x.shape[0]
         D = np.empty((nq, k), dtype=np.float32)
         I = np.empty((nq, k), dtype=np.int64)
-        q0, st = 0, None
-        for blk, dt in self._host_blocks(x):
-            m = blk.shape[0]
-            _lib.check(_lib.lib().trx_index_search(self._h, blk.ctypes.data_as(ctypes.c_void_p), m, dt, k,
-                                                   D[q0:q0 + m].ctypes.data_as(ctypes.c_void_p), I[q0:q0 + m].ctypes.data_as(ctypes.c_void_p)))
-            if m != nq:      # several blocks: the statistics of the call are those of all of them
-                s1 = self.last_stats()
-                if st is None:
-                    st = s1
-                else:
-                    for key in ("nq", "n_uncertified", "n_rescored", "n_rescanned", "scan_launches", "scan_ms", "total_ms"):
-                        st[key] += s1[key]
-                    st["late_fallback"] |= s1["late_fallback"]
-            q0 += m
-        self._stats_override = st
+        _lib.check(_lib.lib().trx_index_search(self._h, x.ctypes.data_as(ctypes.c_void_p), nq, dt, k,
+                                               D.ctypes.data_as(ctypes.c_void_p), I.ctypes.data_as(ctypes.c_void_p)))
         return D, I
 
     def reset(self):
@@ -101,8 +89,6 @@ class IndexFlat:
         _lib.check(_lib.lib().trx_index_set_timing(self._h, 1 if enabled else 0))
 
     def last_stats(self):
-        if getattr(self, "_stats_override", None) is not None:      # a host search that went to the library in several blocks
-            return dict(self._stats_override)
         st = _lib.SearchStats()
         _lib.check(_lib.lib().trx_index_last_stats(self._h, ctypes.byref(st)))
         return {f: getattr(st, f) for f, _ in st._fields_}
@@ -116,7 +102,6 @@ class IndexFlat:
         final after `search_finish()` (include/trx_knn.h, Threading).  Work enqueued on the same stream in between -- the
         all-gather and merge of the row-sharded search -- needs no host round trip."""
         import torch
-        self._stats_override = None
         x, dt = self._torch_arg(x)
         nq, k = x.shape[0], int(k)
         dev = torch.device("cuda", self.device)
@@ -137,38 +122,23 @@ class IndexFlat:
         return bool(self.last_stats()["late_fallback"])
 
     # -- internals ----------------------------------------------------------------------------
-    HOST_BLOCK = 65536
-
-    def _host_blocks(self, x):
-        """(C-contiguous block, dtype code) pairs covering the rows of a host array.  float32, int8 and bool arrays go to the
-        library whole (it blocks and overlaps the copies itself); any other dtype -- the int64 difference fingerprints of
-        retrieve_faiss.py:24-33 -- needs faiss' float32 conversion first, 3 GB a block read at memory speed: block c + 1 is
-        converted by a helper thread (numpy releases the GIL, and so does the ctypes call) while block c is in the library"""
-        x = np.asarray(x)
-        if x.dtype in (np.float32, np.int8, np.bool_) or x.shape[0] <= self.HOST_BLOCK:
-            yield self._host_arg(x)
-            return
-        from concurrent.futures import ThreadPoolExecutor
-        with ThreadPoolExecutor(1) as pool:
-            nxt = pool.submit(self._host_arg, x[:self.HOST_BLOCK])
-            for r0 in range(0, x.shape[0], self.HOST_BLOCK):
-                cur = nxt.result()
-                if r0 + self.HOST_BLOCK < x.shape[0]:
-                    nxt = pool.submit(self._host_arg, x[r0 + self.HOST_BLOCK:r0 + 2 * self.HOST_BLOCK])
-                yield cur
+    _HOST_DTYPES = {"float32": _lib.DTYPE_F32, "int8": _lib.DTYPE_I8, "int64": _lib.DTYPE_I64, "int32": _lib.DTYPE_I32,
+                    "int16": _lib.DTYPE_I16, "uint8": _lib.DTYPE_U8, "float64": _lib.DTYPE_F64}
 
     def _host_arg(self, x):
-        """-> (C-contiguous array, dtype code).  float32 as faiss' wrapper converts everything -- except int8 and bool arrays
-        (the reference's Morgan bit vectors, retrieve_faiss.py:36-44, are int8): those go to the library as they are, a
-        quarter of the bytes over PCIe and no conversion pass on the host; the values, and so the results, are the same"""
+        """-> (C-contiguous array, dtype code).  faiss' wrapper converts every array to float32 on the calling thread; here an
+        integer or float64 array -- the int64 difference fingerprints of retrieve_faiss.py:24-33, the int8 Morgan bits of :36-44 --
+        goes to the library as it is (include/trx_knn.h: TRX_DTYPE_I64 ...), which blocks, converts (worker threads) and overlaps
+        the copies itself: the values the index sees, and so the results, are those of the float32 conversion.  Any other dtype (float16, uint16 ...) is converted here."""
         x = np.asarray(x)
         assert x.ndim == 2, "expected a 2-D array"
         assert x.shape[1] == self.d, "dimension mismatch: got %d, index has d=%d" % (x.shape[1], self.d)
         if x.dtype == np.bool_:
             x = x.view(np.int8)
-        if x.dtype == np.int8:
-            return np.ascontiguousarray(x), _lib.DTYPE_I8
-        return np.ascontiguousarray(x, dtype=np.float32), _lib.DTYPE_F32
+        dt = self._HOST_DTYPES.get(x.dtype.name) if x.dtype.isnative else None
+        if dt is None:
+            return np.ascontiguousarray(x, dtype=np.float32), _lib.DTYPE_F32
+        return np.ascontiguousarray(x), dt
 
     def _torch_arg(self, x):
         import torch
@@ -191,7 +161,6 @@ class IndexFlat:
 
     def _search_torch(self, x, k, want_s64=False):
         import torch
-        self._stats_override = None
         x, dt = self._torch_arg(x)
         nq = x.shape[0]
         dev = torch.device("cuda", self.device)
