@@ -24,5 +24,5 @@ python tools/step_ops.py fill > $O/step_fill.txt 2>&1
 python tools/attn_shapes_ab.py narrow_stores=tools/ab/libtrxnn_nowide.so $TAG=textreact_amd/csrc/libtrxnn.so > $O/attention_ab.json 2> $O/attention_ab.err
 python tools/shard_costs.py > $O/shard_costs.json 2> $O/shard_costs.err
 python tools/r05/attn_f32_ab.py > $O/attention_f32.jsonl 2> $O/attention_f32.err
-TRX_NN_ATTN_VALU=1 python tools/r05/attn_f32_ab.py >> $O/attention_f32.jsonl 2>> $O/attention_f32.err
+TRX_NN_LIB=libtrxnn_lab.so TRX_NN_ATTN_VALU=1 python tools/r05/attn_f32_ab.py >> $O/attention_f32.jsonl 2>> $O/attention_f32.err
 tail -3 $O/gputest.log; grep -c "^{" $O/bench.jsonl $O/predictor_bench.jsonl $O/live_bench.jsonl $O/fingerprint_bench.jsonl $O/c2_rehearsal_bench.jsonl

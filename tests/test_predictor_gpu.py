@@ -1091,34 +1091,6 @@ def test_a_backward_across_a_parameter_update_is_refused():
         l3.backward()
 
 
-def test_ping_pong_forward_kernel():
-    """attn_fwd_pp.h (two wave groups in ping-pong; off by default: it measured slower) stays correct: the randomised
-    attention cases with TRX_NN_ATTN_PP=1, in a process of their own (the switch is read once)"""
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "attn_fuzz.py"), "60", "5"], capture_output=True, text=True,
-                       timeout=600, env=dict(os.environ, TRX_NN_ATTN_PP="1"))
-    assert r.returncode == 0 and "0 failures" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
-
-
-def test_persistent_forward_kernel():
-    """attn_fwd_persist.h (the encoder's shape class on 768 resident workgroups that take several 128-query items each; off by
-    default: it measured no faster, profiles/r05_attention_dropout_ab.json) returns the bits of the default kernel: eight cases
-    with one or two items per workgroup, mask and dropout on and off, hashed in a process with TRX_NN_ATTN_PERSIST=1 and in one without"""
-    import json
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    outs = []
-    for switch in ("1", "0"):
-        r = subprocess.run([sys.executable, os.path.join(root, "tools", "r05", "persist_check.py")], capture_output=True, text=True,
-                           timeout=600, env=dict(os.environ, TRX_NN_ATTN_PERSIST=switch))
-        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
-    assert len(outs[0]) == 8 and outs[0] == outs[1]
-
-
 def _graph_case(seed=0):
     from textreact_amd.predictor import train
     enc = dict(vocab_size=300, hidden_size=256, num_hidden_layers=2, num_attention_heads=4, intermediate_size=512, max_position_embeddings=64)

@@ -616,77 +616,11 @@ __global__ __launch_bounds__(256) void add_ln_bwd_reduce_many_kernel(LnReduceTab
     }
 }
 
-// ---- attention forward, fp32 math, one lane per query row --------------------------------------
-// A wave owns 64 consecutive queries of one (batch, head); K and V rows are the same for every lane,
-// so hipcc fetches them through the scalar cache (s_load) and the products are v_fmac with an SGPR
-// operand: no LDS, no barriers.  q and the running output stay in registers (2 x 64 VGPRs), keys are
-// consumed in chunks of 8 with an online softmax.  FLOPs = 4 * B * H * Lq * Lk * 64.
-constexpr int DH = 64, KC = 8;
-template <bool BF, bool DROP>   // DROP is a template flag: the hash in the key loop costs the plain variant its scalar registers
-__global__ __launch_bounds__(64) void attention_fwd_kernel(const void* __restrict__ q, const void* __restrict__ k,
-                                                           const void* __restrict__ v, const float* __restrict__ mask,
-                                                           int mask_mode, int causal, int B, int H, int Lq, int Lk,
-                                                           float scale, void* __restrict__ out, float* __restrict__ lse, DropArgs da) {
-    const int qblocks = (Lq + 63) / 64;
-    const int bid = blockIdx.x;
-    const int qb = bid % qblocks, h = (bid / qblocks) % H, b = bid / (qblocks * H);
-    const int i = qb * 64 + threadIdx.x;
-    const bool live = i < Lq;
-    const int ii = live ? i : Lq - 1;
-    const unsigned dbase = DROP ? drop_base_da(da, (unsigned)(b * H + h)) : 0u;
-    const int64_t kvbs = da.kv_bs ? da.kv_bs : (int64_t)Lk * H * DH;
-    float qr[DH], o[DH];
-    const int64_t qoff = (((int64_t)b * Lq + ii) * H + h) * DH;
-#pragma unroll
-    for (int d = 0; d < DH; ++d) { qr[d] = ld<BF>(q, qoff + d) * scale; o[d] = 0.f; }
-    float m = -__builtin_inff(), l = 0.f;
-    const int jmax_row = causal ? ii + (Lk - Lq) : Lk - 1;            // last visible key of this row
-    const int jend = causal ? min(Lk, qb * 64 + 63 + (Lk - Lq) + 1) : Lk;  // wave-uniform bound
-    for (int j0 = 0; j0 < jend; j0 += KC) {
-        float s[KC];
-#pragma unroll
-        for (int c = 0; c < KC; ++c) {
-            const int j = j0 + c;
-            const int jj = j < Lk ? j : Lk - 1;
-            const int64_t koff = (int64_t)b * kvbs + ((int64_t)jj * H + h) * DH;   // wave-uniform
-            float a = 0.f;
-#pragma unroll
-            for (int d = 0; d < DH; ++d) a = __builtin_fmaf(qr[d], ld<BF>(k, koff + d), a);
-            if (mask_mode == TRX_NN_MASK_KEY) a += mask[(int64_t)b * Lk + jj];
-            else if (mask_mode == TRX_NN_MASK_FULL) a += mask[((int64_t)b * Lq + ii) * Lk + jj];
-            s[c] = (j < Lk && j <= jmax_row) ? a : -__builtin_inff();   // hidden keys never set the maximum
-        }
-        float cm = s[0];
-#pragma unroll
-        for (int c = 1; c < KC; ++c) cm = fmaxf(cm, s[c]);
-        const float mn = fmaxf(m, cm);
-        const float alpha = (m == mn) ? 1.0f : __expf(m - mn);   // also covers m == mn == -inf
-        l *= alpha;
-#pragma unroll
-        for (int d = 0; d < DH; ++d) o[d] *= alpha;
-#pragma unroll
-        for (int c = 0; c < KC; ++c) {
-            const int j = j0 + c;
-            const int jj = j < Lk ? j : Lk - 1;
-            // rows hidden by the causal / length bound contribute exactly 0 (additive masks with a
-            // finite large negative value behave like the reference: exp underflows to 0)
-            float pj = (j < Lk && j <= jmax_row) ? __expf(s[c] - mn) : 0.f;
-            l += pj;
-            if (DROP) pj = drop_keep(drop_bits(dbase, (unsigned)ii, (unsigned)j >> 1), (unsigned)j, da.thr) ? pj : 0.f;
-            const int64_t voff = (int64_t)b * kvbs + ((int64_t)jj * H + h) * DH;
-#pragma unroll
-            for (int d = 0; d < DH; ++d) o[d] = __builtin_fmaf(pj, ld<BF>(v, voff + d), o[d]);
-        }
-        m = mn;
-    }
-    if (live && lse) lse[((int64_t)b * H + h) * Lq + i] = m + __logf(l);
-    if (live) {
-        const float inv = (DROP ? da.inv_keep : 1.0f) / l;
-        const int64_t ooff = ((int64_t)b * Lq + i) * H * DH + (int64_t)h * DH;
-#pragma unroll
-        for (int d = 0; d < DH; ++d) st<BF>(out, ooff + d, o[d] * inv);
-    }
-}
+#ifdef TRX_NN_LAB      // the vector-ALU kernels of round 1: lab builds only (tools/experiments/attn_valu.h)
+#define TRX_VALU_PART 1
+#include "../../tools/experiments/attn_valu.h"
+#undef TRX_VALU_PART
+#endif
 
 // ---- attention forward on the matrix cores (bf16 storage, fp32 accumulate) -----------------------
 // Workgroup = 4 waves = 128 queries of one (batch, head); a wave owns 32 queries and walks the keys in
@@ -758,6 +692,9 @@ __device__ __forceinline__ void store_row_bf16(bf16_t* rowp, bool live, bool wid
 #ifndef TRX_ATT_ROWSUM_DOT2
 #define TRX_ATT_ROWSUM_DOT2 1
 #endif
+#ifndef TRX_ATT_ABL      // timing-only ablations of the forward tile (tools/attn_ablate.sh; results are WRONG with any bit set): 1 no exponentials,
+#define TRX_ATT_ABL 0    // 2 no row maximum, 4 no barrier, 8 no K fragment reads, 16 no second product, 32 no first product, 64 no V reads
+#endif
 template <bool VIS, bool DROP>
 __device__ __forceinline__ void attn_softmax_tile(f32x16& s0, f32x16& s1, f32x16& o0, f32x16& o1, float& m, float& lsum,
                                                   float sl2, int key0, int hh, int klim, unsigned xd, unsigned thr,
@@ -777,8 +714,9 @@ __device__ __forceinline__ void attn_softmax_tile(f32x16& s0, f32x16& s1, f32x16
                 val = (key0 + kr_ > klim) ? -__builtin_inff() : val;
                 if (hb) s1[t] = val; else s0[t] = val;
             }
-            mb = fmaxf(mb, val);
+            if (!(TRX_ATT_ABL & 2)) mb = fmaxf(mb, val);
         }
+    if (TRX_ATT_ABL & 2) mb = 0.f;
     {   // this query's other 32 keys sit in lane ^ 32.  v_permlane32_swap vdst, src swaps lanes 32-63 of vdst with lanes 0-31 of src:
         // with the maximum in both, vdst = [lo | lo] and src = [hi | hi], and their maximum is the row's in every lane -- one
         // instruction instead of the ds_bpermute round trip of __shfl_xor (~100 cycles on the tile's critical path: -3 %).  asm
@@ -811,11 +749,13 @@ __device__ __forceinline__ void attn_softmax_tile(f32x16& s0, f32x16& s1, f32x16
 #pragma unroll
     for (int t = 0; t < 16; t += 2) {
         const f32x2 a = __builtin_elementwise_fma((f32x2){s0[t], s0[t + 1]}, sl2v, nrefv);
+        if (TRX_ATT_ABL & 1) { s0[t] = a.x; s0[t + 1] = a.y; continue; }
         s0[t] = __builtin_amdgcn_exp2f(a.x); s0[t + 1] = __builtin_amdgcn_exp2f(a.y);
     }
 #pragma unroll
     for (int t = 0; t < 16; t += 2) {
         const f32x2 a = __builtin_elementwise_fma((f32x2){s1[t], s1[t + 1]}, sl2v, nrefv);
+        if (TRX_ATT_ABL & 1) { s1[t] = a.x; s1[t + 1] = a.y; continue; }
         s1[t] = __builtin_amdgcn_exp2f(a.x); s1[t + 1] = __builtin_amdgcn_exp2f(a.y);
     }
 #else
@@ -881,6 +821,13 @@ __device__ __forceinline__ void attn_softmax_tile(f32x16& s0, f32x16& s1, f32x16
         for (int t = 0; t < 16; ++t) { o0[t] *= alpha; o1[t] *= alpha; }
     }
 }
+
+#ifndef TRX_ATT_AUG      // 1: scale and reference through the first product (tools/experiments/attn_aug.h; measured, no faster: lab variant)
+#define TRX_ATT_AUG 0
+#endif
+#if TRX_ATT_AUG
+#include "../../tools/experiments/attn_aug.h"
+#endif
 
 #ifdef TRX_ATT_STAMP   // tools/attn_lab.hip: per workgroup [0] realtime in, [1] realtime out, [2] cycles in, [3] after the prologue, [4..] after tile j
 __device__ unsigned long long* g_att_stamp;
@@ -980,16 +927,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MM == TRX_N
 #pragma unroll
     for (int t = 0; t < 16; ++t) { o0[t] = 0.f; o1[t] = 0.f; }
     const float sl2 = scale * 1.44269504088896340736f;
+    // (TRX_ATT_AUG: Q is multiplied by sl2 below, so "raw-score units" are the exponent's units and inv_scale is log2 e)
     // additive mask enters as the accumulators' starting value, in raw-score units (mask / scale); the
     // clamp keeps finfo.min-style masks finite, so fully masked rows come out uniform like torch's
-    const float inv_scale = 1.0f / scale;
+    const float inv_scale = TRX_ATT_AUG ? 1.44269504088896340736f : 1.0f / scale;
     // The floor of a masked score, in raw-score units: 2^28 in the exponent's units (score * scale * log2 e).  Large enough that
     // a masked key weighs exp2(-2^28) = 0 beside any other and that the q.k term is absorbed (a fully masked row comes out
     // uniform, as torch's finfo.min does), small enough that the exponent's argument fma(s, scale log2e, -reference) of a tile
     // whose keys are ALL masked stays within the rounding of 2^28 (+-16: probabilities up to 2^16, finite).  With the -1e30 of
     // rounds 1-3 that residual was ~1e21 and such a tile -- the first tile of a left-padded row; since round 4 also any tile
     // that opens a key-split wave -- produced inf and NaN.
-    const float mask_floor = -268435456.0f / sl2;
+    const float mask_floor = TRX_ATT_AUG ? -268435456.0f : -268435456.0f / sl2;
 #define TRX_MASK_INIT(X) fmaxf((X) * inv_scale, mask_floor)
     float m = -__builtin_inff(), lsum = 0.f;
     const int off = Lk - Lq;
@@ -1094,6 +1042,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MM == TRX_N
 #pragma unroll
         for (int i = 0; i < 4; ++i) ldsM[4 * tid + i] = TRX_MASK_INIT(mv0[i]);
     }
+#if TRX_ATT_AUG
+    // Q times scale * log2 e, once: the first product then yields the exponent's units (attn_softmax_tile_aug)
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) {
+        uint4 u = __builtin_bit_cast(uint4, qf[s_]);
+        unsigned* w = reinterpret_cast<unsigned*>(&u);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            w[i] = pack2bf(__builtin_bit_cast(float, w[i] << 16) * sl2, __builtin_bit_cast(float, w[i] & 0xffff0000u) * sl2);
+        qf[s_] = __builtin_bit_cast(bf16x8, u);
+    }
+    float mref = 0.f;
+    bf16x8 qaug = attn_aug_operand(0.f, hh);
+    const bf16x8 kones = __builtin_bit_cast(bf16x8, uint4{hh ? 0u : 0x3f803f80u, hh ? 0u : 0x00003f80u, 0u, 0u});
+#endif
     int buf = 0;
     TRX_STAMP(3, __builtin_amdgcn_s_memtime());
     for (int kc = 0; kc < nkb; kc += 16) {   // chunks of 16 tiles = the 1024 keys whose mask sits in LDS
@@ -1108,7 +1071,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MM == TRX_N
         // tile kb is in LDS for everyone; tile kb-1 is no longer read.  Raw barrier: __syncthreads()
         // would drain vmcnt to 0 and with it the prefetch distance
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        if (!(TRX_ATT_ABL & 4)) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         const int buf1 = buf == 2 ? 0 : buf + 1, buf2 = buf == 0 ? 2 : buf - 1;
         if (kb + 2 < nkb) TRX_ATT_STAGE(kb + 2, buf2);
@@ -1142,9 +1105,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MM == TRX_N
         {
             const unsigned kb0 = (unsigned)(buf * 16384);
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+            for (int s = 0; s < 4; ++s) {
+                if (TRX_ATT_ABL & 8) { asm volatile("" : "=v"(ka[s][0]), "=v"(ka[s][1])); continue; }
                 asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:4096"
                              : "=&v"(ka[s][0]), "=&v"(ka[s][1]) : "v"(kfa[s] + kb0) : "memory");
+            }
             asm volatile("s_waitcnt lgkmcnt(0)"
                          : "+v"(ka[0][0]), "+v"(ka[0][1]), "+v"(ka[1][0]), "+v"(ka[1][1]),
                            "+v"(ka[2][0]), "+v"(ka[2][1]), "+v"(ka[3][0]), "+v"(ka[3][1]) :: "memory");
@@ -1152,14 +1117,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MM == TRX_N
         if (TRX_ATT_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
+            if (TRX_ATT_ABL & 32) { asm volatile("" : "+v"(s0), "+v"(s1) : "v"(ka[s][0]), "v"(ka[s][1])); continue; }
             s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[s][0], qf[s], s0, 0, 0, 0);
             s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[s][1], qf[s], s1, 0, 0, 0);
         }
+#if TRX_ATT_AUG
+        s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kones, qaug, s0, 0, 0, 0);      // ... - mref
+        s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kones, qaug, s1, 0, 0, 0);
+#endif
         if (TRX_ATT_PRIO) __builtin_amdgcn_s_setprio(0);
         // ---- V^T fragments, first 32 keys: 8 transposed reads in flight under the softmax ----
         const unsigned vtrA = vtrA0 + (unsigned)(buf * 16384), vtrB = vtrA ^ 64u;   // d block 0 / 1
         uint2 vt[4][2][2];   // [k-step of 16 keys][d block][low / high 4 keys]
 #define TRX_VT_READ(S)                                                                                        \
+    if (TRX_ATT_ABL & 64) asm volatile("" : "=v"(vt[S][0][0]), "=v"(vt[S][0][1]), "=v"(vt[S][1][0]), "=v"(vt[S][1][1])); else \
     asm volatile("ds_read_b64_tr_b16 %0, %4 offset:%6\n\tds_read_b64_tr_b16 %1, %4 offset:%7\n\t"            \
                  "ds_read_b64_tr_b16 %2, %5 offset:%6\n\tds_read_b64_tr_b16 %3, %5 offset:%7"                 \
                  : "=&v"(vt[S][0][0]), "=&v"(vt[S][0][1]), "=&v"(vt[S][1][0]), "=&v"(vt[S][1][1])             \
@@ -1174,8 +1145,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MM == TRX_N
         const bf16x8 pf = __builtin_bit_cast(bf16x8, uint4{pk[HB][4 * ss], pk[HB][4 * ss + 1], pk[HB][4 * ss + 2], pk[HB][4 * ss + 3]}); \
         uint4 v0; v0.x = vt[S][0][0].x; v0.y = vt[S][0][0].y; v0.z = vt[S][0][1].x; v0.w = vt[S][0][1].y;     \
         uint4 v1; v1.x = vt[S][1][0].x; v1.y = vt[S][1][0].y; v1.z = vt[S][1][1].x; v1.w = vt[S][1][1].y;     \
+        if (TRX_ATT_ABL & 16) asm volatile("" : "+v"(o0), "+v"(o1) : "v"(v0.x), "v"(v0.w), "v"(v1.x), "v"(v1.w), "v"(pf)); else {        \
         o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v0), pf, o0, 0, 0, 0);        \
-        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v1), pf, o1, 0, 0, 0);        \
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v1), pf, o1, 0, 0, 0); }      \
     }
         TRX_VT_READ(0) TRX_VT_READ(1)
         const bool vis = key0 + 63 > klim_wave_min;   // wave-uniform: some key of the tile is hidden for some lane
@@ -1189,7 +1161,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MM == TRX_N
                 s1[t] = (key0 + 32 + kr_ > klim) ? -__builtin_inff() : s1[t];
             }
         }
+#if TRX_ATT_AUG
+        attn_softmax_tile_aug<DROP>(s0, s1, o0, o1, m, lsum, mref, qaug, hh, xd, da.thr, pk);
+#else
         attn_softmax_tile<false, DROP>(s0, s1, o0, o1, m, lsum, sl2, key0, hh, klim, xd, da.thr, pk, other_half);
+#endif
         // ---- O^T += V^T P^T: second half's reads fly under the first half's MFMAs ----
         TRX_VT_READ(2) TRX_VT_READ(3)
         TRX_VT_WAIT(0, 1, 8)
@@ -1268,114 +1244,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MM == TRX_N
     TRX_STAMP(31, __builtin_amdgcn_s_memtime()); TRX_STAMP(1, __builtin_amdgcn_s_memrealtime());
 }
 
-#include "attn_fwd_persist.h"
+#ifdef TRX_NN_LAB      // kernels that measured no faster than attention_fwd_mfma_kernel: lab builds only
+#include "../../tools/experiments/attn_fwd_persist.h"
+#include "../../tools/experiments/attn_fwd_pp.h"
+#endif
 #include "attn_fwd_f32.h"
 #include "attn_bwd_f32.h"
-#include "attn_fwd_pp.h"
 #include "attn_bwd_mfma.h"
 #include "attn_decode.h"
 
-// ---- attention backward, fp32 math, probabilities recomputed from lse --------------------------
-// pass 1 (a lane per query row i):  delta_i = dO_i . O_i ;  dS_ij = p_ij (dO_i . V_j - delta_i) ;
-//                                   dQ_i = scale * sum_j dS_ij K_j
-// pass 2 (a lane per key row j):    dV_j = sum_i p_ij dO_i ;  dK_j = scale * sum_i dS_ij Q_i
-// In both passes the "other" operand row (K_j, V_j / Q_i, dO_i) is wave-uniform -> scalar loads.
-template <bool BF, bool DROP>
-__global__ __launch_bounds__(64) void attention_bwd_dq_kernel(const void* __restrict__ q, const void* __restrict__ k,
-                                                              const void* __restrict__ v, const float* __restrict__ mask,
-                                                              int mask_mode, int causal, int B, int H, int Lq, int Lk,
-                                                              float scale, const void* __restrict__ o, const void* __restrict__ dout,
-                                                              const float* __restrict__ lse, void* __restrict__ dq, DropArgs da) {
-    const int qblocks = (Lq + 63) / 64;
-    const int bid = blockIdx.x;
-    const int qb = bid % qblocks, h = (bid / qblocks) % H, b = bid / (qblocks * H);
-    const int i = qb * 64 + threadIdx.x;
-    const bool live = i < Lq;
-    const int ii = live ? i : Lq - 1;
-    const unsigned dbase = DROP ? drop_base_da(da, (unsigned)(b * H + h)) : 0u;
-    float qr[DH], dor[DH], acc[DH];
-    const int64_t qoff = (((int64_t)b * Lq + ii) * H + h) * DH;
-    const int64_t ooff = ((int64_t)b * Lq + ii) * H * DH + (int64_t)h * DH;
-    float delta = 0.f;
-#pragma unroll
-    for (int d = 0; d < DH; ++d) {
-        qr[d] = ld<BF>(q, qoff + d) * scale; dor[d] = ld<BF>(dout, ooff + d); acc[d] = 0.f;
-        delta = __builtin_fmaf(dor[d], ld<BF>(o, ooff + d), delta);
-    }
-    const float L = lse[((int64_t)b * H + h) * Lq + ii];
-    const int jmax_row = causal ? ii + (Lk - Lq) : Lk - 1;
-    const int jend = causal ? min(Lk, qb * 64 + 63 + (Lk - Lq) + 1) : Lk;
-    for (int j = 0; j < jend; ++j) {
-        const int64_t koff = (((int64_t)b * Lk + j) * H + h) * DH;   // wave-uniform
-        float s = 0.f, dp = 0.f;
-#pragma unroll
-        for (int d = 0; d < DH; ++d) { s = __builtin_fmaf(qr[d], ld<BF>(k, koff + d), s); dp = __builtin_fmaf(dor[d], ld<BF>(v, koff + d), dp); }
-        if (mask_mode == TRX_NN_MASK_KEY) s += mask[(int64_t)b * Lk + j];
-        else if (mask_mode == TRX_NN_MASK_FULL) s += mask[((int64_t)b * Lq + ii) * Lk + j];
-        const float p = j <= jmax_row ? __expf(s - L) : 0.f;
-        if (DROP) dp = drop_keep(drop_bits(dbase, (unsigned)ii, (unsigned)j >> 1), (unsigned)j, da.thr) ? dp * da.inv_keep : 0.f;
-        const float ds = p * (dp - delta);
-#pragma unroll
-        for (int d = 0; d < DH; ++d) acc[d] = __builtin_fmaf(ds, ld<BF>(k, koff + d), acc[d]);
-    }
-    if (live) {
-#pragma unroll
-        for (int d = 0; d < DH; ++d) st<BF>(dq, qoff + d, acc[d] * scale);
-    }
-}
-
-template <bool BF, bool DROP>
-__global__ __launch_bounds__(64) void attention_bwd_dkv_kernel(const void* __restrict__ q, const void* __restrict__ k,
-                                                               const void* __restrict__ v, const float* __restrict__ mask,
-                                                               int mask_mode, int causal, int B, int H, int Lq, int Lk,
-                                                               float scale, const void* __restrict__ o, const void* __restrict__ dout,
-                                                               const float* __restrict__ lse, void* __restrict__ dk, void* __restrict__ dv, DropArgs da) {
-    const int kblocks = (Lk + 63) / 64;
-    const int bid = blockIdx.x;
-    const int kb = bid % kblocks, h = (bid / kblocks) % H, b = bid / (kblocks * H);
-    const unsigned dbase = DROP ? drop_base_da(da, (unsigned)(b * H + h)) : 0u;
-    const int j = kb * 64 + threadIdx.x;
-    const bool live = j < Lk;
-    const int jj = live ? j : Lk - 1;
-    float kr[DH], vr[DH], ak[DH], av[DH];
-    const int64_t koff = (((int64_t)b * Lk + jj) * H + h) * DH;
-#pragma unroll
-    for (int d = 0; d < DH; ++d) { kr[d] = ld<BF>(k, koff + d); vr[d] = ld<BF>(v, koff + d); ak[d] = 0.f; av[d] = 0.f; }
-    const float mkey = mask_mode == TRX_NN_MASK_KEY ? mask[(int64_t)b * Lk + jj] : 0.f;
-    // first query row that can see any key of this block (causal): i >= j - (Lk - Lq)
-    const int i0 = causal ? max(0, kb * 64 - (Lk - Lq)) : 0;
-    for (int i = i0; i < Lq; ++i) {
-        const int64_t qoff = (((int64_t)b * Lq + i) * H + h) * DH;          // wave-uniform
-        const int64_t ooff = ((int64_t)b * Lq + i) * H * DH + (int64_t)h * DH;
-        float s = 0.f, dp = 0.f, delta = 0.f;
-#pragma unroll
-        for (int d = 0; d < DH; ++d) {
-            const float qd = ld<BF>(q, qoff + d), dod = ld<BF>(dout, ooff + d);
-            s = __builtin_fmaf(qd, kr[d], s); dp = __builtin_fmaf(dod, vr[d], dp);
-            delta = __builtin_fmaf(dod, ld<BF>(o, ooff + d), delta);        // wave-uniform value
-        }
-        s = s * scale + mkey;
-        if (mask_mode == TRX_NN_MASK_FULL) s += mask[((int64_t)b * Lq + i) * Lk + jj];
-        const float L = lse[((int64_t)b * H + h) * Lq + i];
-        const bool vis = !causal || jj <= i + (Lk - Lq);
-        const float p = vis ? __expf(s - L) : 0.f;
-        float pd = p;   // the probability as the forward used it for the output: dropped and rescaled
-        if (DROP) {
-            const float km = drop_keep(drop_bits(dbase, (unsigned)i, (unsigned)jj >> 1), (unsigned)jj, da.thr) ? da.inv_keep : 0.f;
-            pd = p * km; dp *= km;
-        }
-        const float ds = p * (dp - delta);
-#pragma unroll
-        for (int d = 0; d < DH; ++d) {
-            av[d] = __builtin_fmaf(pd, ld<BF>(dout, ooff + d), av[d]);
-            ak[d] = __builtin_fmaf(ds, ld<BF>(q, qoff + d), ak[d]);
-        }
-    }
-    if (live) {
-#pragma unroll
-        for (int d = 0; d < DH; ++d) { st<BF>(dk, koff + d, ak[d] * scale); st<BF>(dv, koff + d, av[d]); }
-    }
-}
+#ifdef TRX_NN_LAB
+#define TRX_VALU_PART 2
+#include "../../tools/experiments/attn_valu.h"
+#undef TRX_VALU_PART
+#endif
 
 }  // namespace
 
@@ -1545,7 +1427,7 @@ static DropArgs make_drop_args(float p, uint64_t seed) {
 static int attention_fwd_impl(const void* q, const void* k, const void* v, const float* mask, int mask_mode, int causal,
                               int B, int H, int Lq, int Lk, int64_t kv_bs, float scale, int dtype, float p, uint64_t seed,
                               void* out, float* lse, void* stream, int ldq = 0, int ldk = 0) {
-    if ((ldq || ldk) && (dtype != TRX_NN_BF16 || getenv("TRX_NN_ATTN_VALU")))
+    if ((ldq || ldk) && dtype != TRX_NN_BF16)
         return fail(TRX_NN_EINVAL, "attention_fwd: strided operands are supported by the bf16 matrix-core path only");
     if ((ldq && ldq < H * 64) || (ldk && ldk < H * 64) || ((ldq | ldk) & 7))
         return fail(TRX_NN_EINVAL, "attention_fwd: row strides must be >= H * 64 and multiples of 8 elements");
@@ -1558,24 +1440,23 @@ static int attention_fwd_impl(const void* q, const void* k, const void* v, const
     if (!(scale > 0.f)) return fail(TRX_NN_EINVAL, "attention_fwd: scale must be positive");
     DropArgs da = make_drop_args(p, seed);
     da.kv_bs = kv_bs; da.ldq = ldq; da.ldk = ldk;
+    hipStream_t st = (hipStream_t)stream;
+#ifdef TRX_NN_LAB
     const int qblocks = (Lq + 63) / 64;
     dim3 grid((unsigned)((int64_t)B * H * qblocks)), block(64);
-    hipStream_t st = (hipStream_t)stream;
     static const bool force_valu = getenv("TRX_NN_ATTN_VALU") != nullptr;
+#else
+    constexpr bool force_valu = false;
+#endif
     if (dtype == TRX_NN_BF16 && !force_valu) {
         dim3 g2((unsigned)((int64_t)B * H * ((Lq + 127) / 128))), b2(256);
-        // TRX_NN_ATTN_PP=1: the encoder's shape class (Lq >= 256, key mask or none) on the two-group ping-pong kernel of
-        // attn_fwd_pp.h -- correct (tests/test_predictor_gpu.py::test_ping_pong_forward_kernel) and 33 % SLOWER than this
-        // one at 512 x 512 (69.4 against 52.0 us, profiles/r03_attention_ab.json), so it is not the default
+#ifdef TRX_NN_LAB
+        // lab builds: TRX_NN_ATTN_PP=1 / TRX_NN_ATTN_PERSIST=1 put the encoder's shape class on the kernels of
+        // tools/experiments/attn_fwd_pp.h (33 % slower at 512 x 512) / attn_fwd_persist.h (39.8 against 39.9 us)
         static const bool use_pp = getenv("TRX_NN_ATTN_PP") != nullptr;
         const bool pp = use_pp && Lq >= 256 && Lk <= 1024 && mask_mode != TRX_NN_MASK_FULL;
         dim3 g3((unsigned)((int64_t)B * H * ((Lq + 255) / 256))), b3(512);
-        // TRX_NN_ATTN_PERSIST=1 (round 5, an experiment until it is measured): the encoder's shape class on persistent
-        // workgroups (attn_fwd_persist.h) -- as many as are resident at once, each taking several 128-query items
-#ifndef TRX_ATT_PERSIST_DEFAULT
-#define TRX_ATT_PERSIST_DEFAULT 0
-#endif
-        static const bool use_persist = getenv("TRX_NN_ATTN_PERSIST") ? atoi(getenv("TRX_NN_ATTN_PERSIST")) != 0 : TRX_ATT_PERSIST_DEFAULT != 0;
+        static const bool use_persist = getenv("TRX_NN_ATTN_PERSIST") && atoi(getenv("TRX_NN_ATTN_PERSIST")) != 0;
         const int nitems = (int)((int64_t)B * H * (Lq / 128));
         const int pslots = 768;              // 3 workgroups per CU
         const bool persist = use_persist && !pp && !causal && Lq % 128 == 0 && Lk % 64 == 0 && Lk >= 128 && Lk <= 512 && mask_mode != TRX_NN_MASK_FULL && nitems > pslots;
@@ -1600,6 +1481,11 @@ static int attention_fwd_impl(const void* q, const void* k, const void* v, const
         else hipLaunchKernelGGL((attention_fwd_mfma_kernel<MM_, DROP_>), g2, b2, 0, st, (const bf16_t*)q, (const bf16_t*)k, \
                                 (const bf16_t*)v, mask, causal, B, H, Lq, Lk, scale, (bf16_t*)out, lse, da);              \
     } while (0)
+#else
+#define TRX_LAUNCH_MFMA(MM_, DROP_)                                                                                       \
+    hipLaunchKernelGGL((attention_fwd_mfma_kernel<MM_, DROP_>), g2, b2, 0, st, (const bf16_t*)q, (const bf16_t*)k,        \
+                       (const bf16_t*)v, mask, causal, B, H, Lq, Lk, scale, (bf16_t*)out, lse, da)
+#endif
         if (da.thr) {
             if (mask_mode == TRX_NN_MASK_NONE) TRX_LAUNCH_MFMA(TRX_NN_MASK_NONE, true);
             else if (mask_mode == TRX_NN_MASK_KEY) TRX_LAUNCH_MFMA(TRX_NN_MASK_KEY, true);
@@ -1625,12 +1511,15 @@ static int attention_fwd_impl(const void* q, const void* k, const void* v, const
             else TRX_LAUNCH_F32(TRX_NN_MASK_FULL, false);
         }
 #undef TRX_LAUNCH_F32
-    } else {
+    }
+#ifdef TRX_NN_LAB
+    else {
 #define TRX_LAUNCH_VALU(BF_, DROP_) hipLaunchKernelGGL((attention_fwd_kernel<BF_, DROP_>), grid, block, 0, st, q, k, v, mask, mask_mode, causal, B, H, Lq, Lk, scale, out, lse, da)
         if (dtype == TRX_NN_BF16) { if (da.thr) TRX_LAUNCH_VALU(true, true); else TRX_LAUNCH_VALU(true, false); }
         else { if (da.thr) TRX_LAUNCH_VALU(false, true); else TRX_LAUNCH_VALU(false, false); }
 #undef TRX_LAUNCH_VALU
     }
+#endif
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? TRX_NN_OK : fail(TRX_NN_EHIP, hipGetErrorString(e));
 }
@@ -1661,7 +1550,7 @@ static int attention_bwd_impl(const void* q, const void* k, const void* v, const
                               int B, int H, int Lq, int Lk, float scale, int dtype, float p, uint64_t seed, const void* out,
                               const void* dout, const float* lse, void* dq, void* dk, void* dv, void* stream, int ldq, int ldk,
                               void* ws_user = nullptr) {
-    if ((ldq || ldk) && (dtype != TRX_NN_BF16 || getenv("TRX_NN_ATTN_VALU")))
+    if ((ldq || ldk) && dtype != TRX_NN_BF16)
         return fail(TRX_NN_EINVAL, "attention_bwd: strided operands are supported by the bf16 matrix-core path only");
     if ((ldq && ldq < H * 64) || (ldk && ldk < H * 64) || ((ldq | ldk) & 7))
         return fail(TRX_NN_EINVAL, "attention_bwd: row strides must be >= H * 64 and multiples of 8 elements");
@@ -1675,8 +1564,11 @@ static int attention_bwd_impl(const void* q, const void* k, const void* v, const
     DropArgs da = make_drop_args(p, seed);
     da.ldq = ldq; da.ldk = ldk;
     hipStream_t st = (hipStream_t)stream;
-    dim3 gq((unsigned)((int64_t)B * H * ((Lq + 63) / 64))), gk((unsigned)((int64_t)B * H * ((Lk + 63) / 64))), block(64);
+#ifdef TRX_NN_LAB
     static const bool force_valu = getenv("TRX_NN_ATTN_VALU") != nullptr;
+#else
+    constexpr bool force_valu = false;
+#endif
     if (dtype == TRX_NN_BF16 && !force_valu) {
         // matrix-core path; its per-query scalars (-lse/scale, -delta) live in a stream-ordered scratch
         const size_t n = (size_t)B * H * Lq;
@@ -1735,6 +1627,8 @@ static int attention_bwd_impl(const void* q, const void* k, const void* v, const
         if (!ws_user) (void)hipFreeAsync(ws, st);
         return e1 == hipSuccess ? TRX_NN_OK : fail(TRX_NN_EHIP, hipGetErrorString(e1));
     }
+#ifdef TRX_NN_LAB
+    dim3 gq((unsigned)((int64_t)B * H * ((Lq + 63) / 64))), gk((unsigned)((int64_t)B * H * ((Lk + 63) / 64))), block(64);
 #define TRX_LAUNCH_VALU_BWD(BF_, DROP_)                                                                                     \
     hipLaunchKernelGGL((attention_bwd_dq_kernel<BF_, DROP_>), gq, block, 0, st, q, k, v, mask, mask_mode, causal, B, H, Lq, Lk, \
                        scale, out, dout, lse, dq, da);                                                                      \
@@ -1745,6 +1639,9 @@ static int attention_bwd_impl(const void* q, const void* k, const void* v, const
 #undef TRX_LAUNCH_VALU_BWD
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? TRX_NN_OK : fail(TRX_NN_EHIP, hipGetErrorString(e));
+#else
+    return fail(TRX_NN_EINVAL, "attention_bwd: unknown dtype");
+#endif
 }
 
 int trx_attention_bwd_dropout(const void* q, const void* k, const void* v, const float* mask, int mask_mode, int causal,

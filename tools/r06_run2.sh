@@ -1,0 +1,11 @@
+set -x
+mkdir -p gpurun_out/r06
+timeout 1500 python -m pytest tests/test_predictor_gpu.py -x -q -m gpu -k "attention" 2>&1 | tail -8
+timeout 900 python tools/attn_fuzz.py 120 7 2>&1 | tail -4
+timeout 600 python tools/attn_ab.py noaug=tools/ab/libtrxnn_noaug.so aug=textreact_amd/csrc/libtrxnn.so > gpurun_out/r06/attention_ab_aug.json 2> gpurun_out/r06/attention_ab_aug.err; tail -3 gpurun_out/r06/attention_ab_aug.err
+python - <<'PY'
+import json
+j=json.load(open("gpurun_out/r06/attention_ab_aug.json"))
+for r in j["shapes"]:
+    print(r["what"], {n:(round(v["us_median"],2), round(v["us_min"],2), v["max_abs_diff_vs_first"]) for n,v in r["variants"].items()})
+PY
