@@ -321,27 +321,11 @@ def launch_or_refuse(args):
       * WORLD_SIZE unset and --gpus N > 1: this process becomes the launcher's parent -- it starts
         `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same
         arguments>` as a CHILD process (never exec), relays its output (rank 0's JSON line) and exits with its code."""
-    ws = os.environ.get("WORLD_SIZE")
-    if ws is not None:
-        if int(ws) != args.gpus:
-            sys.stderr.write("bench.py: --gpus %d but the launcher set WORLD_SIZE=%s; refusing to measure a different job than "
-                             "the command names\n" % (args.gpus, ws))
-            sys.exit(2)
+    from textreact_amd import _dist      # (imports nothing that touches the GPU)
+    _dist.refuse_mismatch(args.gpus, "bench.py")
+    if os.environ.get("WORLD_SIZE") is not None or args.gpus <= 1:
         return
-    if args.gpus <= 1:
-        return
-    import socket
-    import subprocess
-    port = os.environ.get("TRX_BENCH_MASTER_PORT")
-    if port is None:
-        with socket.socket() as s_:
-            s_.bind(("127.0.0.1", 0))
-            port = s_.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    sys.stderr.write("bench.py: --gpus %d without a launcher: starting %s\n" % (args.gpus, " ".join(cmd)))
-    sys.stderr.flush()
-    sys.exit(subprocess.run(cmd).returncode)      # the child inherits stdout / stderr: rank 0's JSON line goes straight through
+    sys.exit(_dist.launch_children(args.gpus, __file__, sys.argv[1:], port_env="TRX_BENCH_MASTER_PORT"))      # the child inherits stdout / stderr: rank 0's JSON line goes straight through
 
 
 def main():
@@ -372,23 +356,18 @@ def main():
 
     import torch
     import torch.distributed as dist
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the retrieval path has no CPU fallback")
     # TRX_BENCH_BACKEND=gloo TRX_BENCH_DEVICE=0 lets several ranks share one GPU to rehearse the N > 1 path
-    # (RCCL refuses two ranks on one device); the real run is nccl = RCCL, one GPU per rank
-    backend = os.environ.get("TRX_BENCH_BACKEND", "nccl")
-    local_rank = int(os.environ.get("TRX_BENCH_DEVICE", local_rank))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+    # (RCCL refuses two ranks on one device); the real run is nccl = RCCL, one GPU per rank.  The group itself is set up where
+    # every N > 1 entry point sets it up: textreact_amd/_dist.py (set_device, then init_process_group("nccl", device_id=...))
+    from textreact_amd import _dist
+    for mine, theirs in (("TRX_BENCH_BACKEND", "TRX_DIST_BACKEND"), ("TRX_BENCH_DEVICE", "TRX_DEVICE")):
+        if mine in os.environ:
+            os.environ[theirs] = os.environ[mine]
+    backend = os.environ.get("TRX_DIST_BACKEND", "nccl")
+    rank, world, dev = _dist.setup()
+    local_rank = dev.index
 
     import textreact_amd.faiss_compat as faiss
     from textreact_amd.sharded import ShardedFlatIndex, shard_bounds

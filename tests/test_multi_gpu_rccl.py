@@ -97,3 +97,56 @@ def test_sharded_search_over_rccl_equals_the_oracle():
     for r in range(world):
         D, I = ret[r]["faiss_ties"]
         assert np.array_equal(I, If) and np.array_equal(D.view(np.uint32), Df.view(np.uint32)), r
+
+
+def _launch(world, module, argv, port):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "TRX_DIST_BACKEND", "TRX_DEVICE")}
+    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+                           "--master-port", str(port), "-m", module] + argv, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+
+
+@needs2
+def test_retrieve_faiss_cli_over_rccl_writes_the_files_one_gpu_writes(tmp_path):
+    """python -m torch.distributed.run --nproc-per-node G -m textreact_amd.retrieve_faiss (retrieve/retrieve_faiss.py:112-130), the train
+    vectors row-sharded over G GPUs, RCCL transport, group set up by textreact_amd/_dist.py: rank 0's three files are byte for byte
+    those of the one-GPU run -- the sharded and the replicated form"""
+    import pandas as pd
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from _data import reaction_fp_like
+    import textreact_amd.retrieve_faiss as rf
+    world = min(_ngpus(), 4)
+    fps = reaction_fp_like(1101, 2048, 3)
+    fps[700:720] = fps[3]; fps[40:45] = fps[3]                     # ties that straddle shard boundaries
+    pd.DataFrame({"id": np.arange(1001), "canonical_rxn": ["C>>C"] * 1001}).to_csv(tmp_path / "train.csv", index=False)
+    pd.DataFrame({"id": np.arange(50) + 5000, "canonical_rxn": ["C>>C"] * 50}).to_csv(tmp_path / "val.csv", index=False)
+    pd.DataFrame({"id": np.arange(50) + 6000, "canonical_rxn": ["C>>C"] * 50}).to_csv(tmp_path / "test.csv", index=False)
+    for name, sl in (("train", slice(0, 1001)), ("val", slice(1001, 1051)), ("test", slice(1051, 1101))):
+        np.save(tmp_path / (name + ".npy"), fps[sl].astype(np.int64))
+    argv = ["--data_path", str(tmp_path), "--train_file", "train.csv", "--valid_file", "val.csv", "--test_file", "test.csv",
+            "--train_vectors", str(tmp_path / "train.npy"), "--valid_vectors", str(tmp_path / "val.npy"), "--test_vectors", str(tmp_path / "test.npy")]
+    one = tmp_path / "one"
+    assert rf.main(argv + ["--output_path", str(one)]) == 0
+    for case, extra in enumerate(([], ["--replicas"])):
+        many = tmp_path / ("many%d" % case)
+        r = _launch(world, "textreact_amd.retrieve_faiss", argv + extra + ["--output_path", str(many)], 29741 + case)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        for name in ("train.json", "val.json", "test.json"):
+            assert (many / name).read_bytes() == (one / name).read_bytes(), (extra, name)
+
+
+@needs2
+def test_tanimoto_cli_over_rccl_writes_the_unsharded_result(tmp_path):
+    """python -m torch.distributed.run --nproc-per-node G -m textreact_amd.tanimoto (retrieve/retrieve.py:55-66 row-sharded): rank 0's
+    file equals the one-GPU run's"""
+    import textreact_amd.tanimoto as tanimoto
+    world = min(_ngpus(), 4)
+    rng = np.random.default_rng(12)
+    base = (rng.random((40, 2048)) < 0.03) * rng.integers(-3, 4, (40, 2048))
+    corpus = base[rng.integers(0, 40, 3001)]
+    queries = base[:9]
+    np.save(tmp_path / "train.npy", corpus); np.save(tmp_path / "test.npy", queries)
+    argv = ["--train_fps", str(tmp_path / "train.npy"), "--test_fps", str(tmp_path / "test.npy"), "--limit", "-1"]
+    assert tanimoto.main(argv + ["--output", str(tmp_path / "one.json")]) == 0
+    r = _launch(world, "textreact_amd.tanimoto", argv + ["--output", str(tmp_path / "many.json")], 29751)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert json.load(open(tmp_path / "many.json")) == json.load(open(tmp_path / "one.json"))

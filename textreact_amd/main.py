@@ -355,23 +355,18 @@ def main(argv=None):
 
     if args.hip_graph_step:
         T.prepare_graph_runtime()     # an environment switch the HIP runtime reads when it starts: before anything touches the GPU
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from . import _dist
+    # `--gpus N` (main.py:75, `devices=args.gpus` at :372-374) is what runs or nothing does: a launcher that set another WORLD_SIZE
+    # is refused (exit code 2) before anything touches the GPU, as bench.py refuses it
+    _dist.refuse_mismatch(args.gpus, "main.py")
     cuda = torch.cuda.is_available()
-    # TRX_DIST_BACKEND=gloo TRX_DEVICE=0: several ranks share one GPU to rehearse the N > 1 path on a one-GPU box (RCCL
-    # refuses two ranks on one device); the real run is nccl = RCCL, one GPU per rank
-    local_rank = int(os.environ.get("TRX_DEVICE", local_rank))
-    device = torch.device("cuda", local_rank) if cuda else torch.device("cpu")
+    device = torch.device("cuda", _dist.device_ordinal()) if cuda else torch.device("cpu")
     ops.require_device(device)        # the attention / add+LayerNorm ops exist as HIP kernels only: no GPU, no trainer
-    if cuda:
-        torch.cuda.set_device(local_rank)
-    if world > 1 and not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(os.environ.get("TRX_DIST_BACKEND", "nccl" if cuda else "gloo"))
-    if args.gpus != world and rank == 0:
-        print("note: --gpus %d, WORLD_SIZE %d (one process per GPU: launch with torch.distributed.run)" % (args.gpus, world),
-              file=sys.stderr)
+    rank, world, device = _dist.setup()      # set_device, then init_process_group("nccl", device_id=...): textreact_amd/_dist.py
+    local_rank = _dist.device_ordinal()
+    if args.gpus != world and rank == 0:     # (no launcher: WORLD_SIZE unset, one process, one GPU)
+        print("note: --gpus %d without a launcher runs on ONE GPU; start N ranks with `python -m torch.distributed.run "
+              "--nproc-per-node %d -m textreact_amd.main ...`" % (args.gpus, args.gpus), file=sys.stderr)
     ignored = [k for k in ("data_path", "train_file", "valid_file", "test_file", "vocab_file", "corpus_file", "nn_path")
                if getattr(args, k)]
     if ignored and rank == 0:

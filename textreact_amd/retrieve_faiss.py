@@ -147,28 +147,13 @@ def get_parser():
 
 
 def _dist_setup():
-    """(rank, world): one process per GPU when launched by torch.distributed.run, else (0, 1).  TRX_DIST_BACKEND=gloo
-    TRX_DEVICE=0 lets several ranks share one GPU to rehearse the path on a one-GPU box (RCCL refuses two ranks on one
-    device); the real run is nccl = RCCL."""
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world <= 1:
+    """(rank, world): one process per GPU when launched by torch.distributed.run, else (0, 1).  The group is set up by
+    textreact_amd/_dist.py -- set_device, then init_process_group("nccl", device_id=...) -- like every other N > 1 entry point."""
+    from . import _dist
+    if _dist.world_size() <= 1:
         return 0, 1
-    import torch
-    import torch.distributed as dist
-    if not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("TRX_DIST_BACKEND", "nccl")
-        # this rank's GPU is the current device BEFORE the group exists: with the nccl backend the object collectives
-        # (broadcast_object_list of the val / test fingerprints) put their tensors on torch.cuda.current_device(), which
-        # would be cuda:0 on every rank -- RCCL refuses two ranks on one device
-        ordinal = int(os.environ.get("TRX_DEVICE", os.environ.get("LOCAL_RANK", "0")))
-        if torch.cuda.is_available():
-            torch.cuda.set_device(ordinal)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", ordinal))
-        else:
-            dist.init_process_group(backend)
-    return dist.get_rank(), dist.get_world_size()
+    rank, world, _ = _dist.setup()
+    return rank, world
 
 
 class ShardedSearcher:

@@ -356,12 +356,8 @@ def main(argv=None):
         write_results(a.output, retrieve(load(a.test_fps), load(a.train_fps), k=a.k, limit=limit))
         return 0
     import torch.distributed as dist
-    # TRX_DIST_BACKEND=gloo TRX_DEVICE=0: several ranks rehearse on one GPU (RCCL refuses two ranks on one device)
-    if not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(os.environ.get("TRX_DIST_BACKEND", "nccl"))
-    if torch.cuda.is_available():
-        torch.cuda.set_device(int(os.environ.get("TRX_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
+    from . import _dist
+    _dist.setup()          # set_device, then init_process_group("nccl", device_id=...): textreact_amd/_dist.py
     res = retrieve_sharded(load(a.test_fps), load(a.train_fps, mmap=True), k=a.k, limit=limit)
     if dist.get_rank() == 0:
         write_results(a.output, res)
