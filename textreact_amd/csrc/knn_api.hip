@@ -31,6 +31,7 @@ hipError_t launch_slack(const float*, int64_t, int64_t, float, float, float, con
 hipError_t launch_bigk_seeds(int, const float*, const int64_t*, int, int, int, const float*, float, float, float, const float*, float, int*, int*, float*, hipStream_t);
 hipError_t launch_merge(int, int, int64_t, int, const double*, const int64_t*, float*, int64_t*, double*, hipStream_t);
 hipError_t launch_faiss_ties(int64_t, int, int, const double*, const int64_t*, float*, int64_t*, double*, hipStream_t);
+hipError_t launch_sanitize_hostile(float*, int64_t, int64_t, bf16_t*, int, int*, int*, hipStream_t);
 }  // namespace trx
 
 using namespace trx;
@@ -45,7 +46,7 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
                         std::string(#expr) + ": " + hipGetErrorString(e__));               \
     } while (0)
 
-struct HostStats { uint32_t inexact_any, nonint_any, maxabs_bits, maxnorm2_bits, nonfp4_any, maxerr2_bits; };
+struct HostStats { uint32_t inexact_any, nonint_any, maxabs_bits, maxnorm2_bits, nonfp4_any, maxerr2_bits, hostile_any; };
 static float bits2f(uint32_t b) { float f; std::memcpy(&f, &b, 4); return f; }
 
 // grow-only device buffer
@@ -112,6 +113,9 @@ struct trx_index {
     DevBuf w_stamp, w_stats, w_qnorm2, w_flag, w_exact, w_io, w_tmp, w_cls;      // (the big ones are shared: DevPool)
     DevBuf w_stage[2], w_wide; // host entry points: a block of the caller's rows as staged (knn_host.h), and int8 rows widened to bf16
     int64_t reserve_rows = 0;  // trx_index_add: the rows the index will hold when the call is through (one allocation, not one per block)
+    // hostile rows (knn_common.h): their ids, sorted, [MAX_SPECIAL] ints + the device-side counter behind them; more than MAX_SPECIAL
+    // of them and every search of this index is the exact fp64 scan
+    DevBuf w_special; int n_special = 0; bool special_overflow = false;
     DevBuf w_tie;             // TRX_TIES_FAISS: the canonical top 2k (D, I, S) the FAISS order is derived from
     int tie_rule = TRX_TIES_BY_ID;
     trx_search_stats stats{};
@@ -222,7 +226,7 @@ void trx_index_destroy(trx_index* idx) {
     if (idx->cbias8) (void)hipFree(idx->cbias8);
     if (idx->C4) (void)hipFree(idx->C4);
     DevBuf* bufs[] = {&idx->w_stamp, &idx->w_stats, &idx->w_qnorm2, &idx->w_flag, &idx->w_exact, &idx->w_io, &idx->w_tmp, &idx->w_cls, &idx->w_tie,
-                      &idx->w_stage[0], &idx->w_stage[1], &idx->w_wide};
+                      &idx->w_stage[0], &idx->w_stage[1], &idx->w_wide, &idx->w_special};
     for (DevBuf* b : bufs) b->release();
     {   // the last index of the process on this device takes the shared workspaces with it
         DevPool& pl = pool_of(idx->device);
@@ -258,6 +262,7 @@ int trx_index_reset(trx_index* idx) {
     idx->C4 = nullptr; idx->c4_cap = 0; idx->c4_rows = -1; idx->nonfp4 = false;
     idx->n = 0; idx->cap = 0; idx->mode = MODE_EMPTY; idx->Kp = 0;
     idx->maxabs = 0.f; idx->maxnorm2 = 0.f; idx->maxerr2 = 0.f; idx->nonint = false;
+    idx->n_special = 0; idx->special_overflow = false;
     return TRX_OK;
 }
 
@@ -294,8 +299,10 @@ int trx_index_add_device(trx_index* idx, const void* x, int64_t n, int dtype, vo
     HostStats hs; rc = read_stats(idx, st, &hs); if (rc) return rc;
 
     int newmode = idx->mode;
-    if (idx->mode == MODE_EMPTY) newmode = hs.inexact_any ? inexact_mode() : MODE_PLAIN;
-    else if (idx->mode == MODE_PLAIN && hs.inexact_any) newmode = inexact_mode();
+    // a hostile row (knn_common.h) needs the f32 copy: its operand row is zeroed below, its values must survive for the exact pass
+    const bool inexact = hs.inexact_any || hs.hostile_any;
+    if (idx->mode == MODE_EMPTY) newmode = inexact ? inexact_mode() : MODE_PLAIN;
+    else if (idx->mode == MODE_PLAIN && inexact) newmode = inexact_mode();
     int64_t need = idx->n + n, newcap = idx->cap;
     if (need > newcap) newcap = round_up64(std::max<int64_t>(std::max(need, idx->reserve_rows), idx->cap + idx->cap / 2), TILE_M);
     if (newcap != idx->cap || newmode != idx->mode) { rc = restructure(idx, newcap, newmode, st); if (rc) return rc; }
@@ -309,6 +316,21 @@ int trx_index_add_device(trx_index* idx, const void* x, int64_t n, int dtype, vo
         else HIPCHK(hipMemcpyAsync(dsto, x, (size_t)n * idx->d * sizeof(float), hipMemcpyDeviceToDevice, st));
     } else {
         HIPCHK(launch_build_operand(x, is_bf, 0, n, idx->d, idx->d, dstg, idx->Kp, st));
+    }
+    if (hs.hostile_any) {
+        rc = idx->w_special.reserve((MAX_SPECIAL + 1) * sizeof(int)); if (rc) return rc;
+        int* spec = (int*)idx->w_special.p; int* cnt = spec + MAX_SPECIAL;
+        HIPCHK(hipMemcpyAsync(cnt, &idx->n_special, sizeof(int), hipMemcpyHostToDevice, st));
+        HIPCHK(launch_sanitize_hostile((float*)idx->w_tmp.p, n, idx->n, dstg, idx->Kp, spec, cnt, st));
+        int total = 0;
+        HIPCHK(hipMemcpyAsync(&total, cnt, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (total > MAX_SPECIAL) { idx->special_overflow = true; total = MAX_SPECIAL; }
+        std::vector<int> ids((size_t)total);      // appended in any order by the kernel: merge_special_kernel searches a sorted list
+        HIPCHK(hipMemcpy(ids.data(), spec, (size_t)total * sizeof(int), hipMemcpyDeviceToHost));
+        std::sort(ids.begin(), ids.end());
+        HIPCHK(hipMemcpy(spec, ids.data(), (size_t)total * sizeof(int), hipMemcpyHostToDevice));
+        idx->n_special = total;
     }
     HIPCHK(hipMemcpyAsync(idx->cnorm2 + idx->n, idx->w_tmp.p, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, st));
     idx->n += n;
@@ -620,6 +642,7 @@ static int search_batch(trx_index* idx, const void* q, const float* qnorm2, cons
 #endif
 
     SelectParams se{};
+    se.special = (const int*)idx->w_special.p; se.nspecial = idx->n_special;
     se.cand = sp.cand; se.cand_cnt = sp.cand_cnt; se.cand_thr = sp.cand_thr; se.nlists = nlists; se.cap_alloc = cap_alloc;
     if (keeps_f32(idx->mode)) { se.corpus_orig = idx->Co; se.ld_c = d; se.corpus_is_bf16 = 0; }
     else { se.corpus_orig = idx->Cg; se.ld_c = Kp; se.corpus_is_bf16 = 1; }
@@ -819,7 +842,8 @@ static int search_device_core(trx_index* idx, const void* q, int64_t nq, int dty
     idx->pend = trx_index::Pending{};
     idx->pend.active = true; idx->pend.st = st; idx->pend.is_bf = is_bf; idx->pend.k = k;
 
-    if (idx->n == 0 || k > TRX_WIDE_MAX_K) {
+    if (idx->n == 0 || k > TRX_WIDE_MAX_K || idx->special_overflow) {
+        // (more hostile rows than the index folds in per query: knn_common.h)
         // empty index: all pads.  k > TRX_WIDE_MAX_K: exact scan for every query (documented slow path)
         const int64_t per = std::max<int64_t>(1, ((int64_t)1 << 29) / std::max<int64_t>(1, idx->n * 8));
         if ((rc = idx->w_exact.reserve((size_t)std::min<int64_t>(per, nq) * std::max<int64_t>(idx->n, 1) * sizeof(double)))) return rc;
@@ -898,6 +922,9 @@ static int search_device_core(trx_index* idx, const void* q, int64_t nq, int dty
                           D + q0 * k, I + q0 * k, S64 ? S64 + q0 * k : nullptr, st);
         if (rc) return rc;
     }
+    if (idx->n_special > 0)      // the index's hostile rows, by their canonical scores, into every result (knn_select.hip: merge_special_kernel)
+        HIPCHK(launch_merge_special(idx->metric, keeps_f32(idx->mode) ? 0 : 1, is_bf, keeps_f32(idx->mode) ? (const void*)idx->Co : (const void*)idx->Cg,
+                                    keeps_f32(idx->mode) ? d : idx->Kp, q, d, d, nq, k, (const int*)idx->w_special.p, idx->n_special, idx->n, D, I, S64, st));
     HIPCHK(hipEventRecord(pl.last, st));
     if (idx->timing) HIPCHK(hipEventRecord(idx->ev[3], st));
     return TRX_OK;

@@ -123,6 +123,23 @@ __device__ __forceinline__ double round_term(float eps_round, float bx, float xn
     return measured < apriori ? measured : apriori;
 }
 
+// ---- hostile rows ----------------------------------------------------------------------------
+// A row (of the corpus or of the queries) whose fp32 |row|^2 is not a number <= 1e36 -- a NaN or +-inf component, or magnitudes
+// whose products leave float32 -- has no usable approximate key: the MFMA sums overflow to +-inf and inf - inf to NaN.  Such rows
+// are kept out of the statistics every bound is made of (knn_prep.hip: row_stats_kernel) and out of the scan: a corpus row's
+// operand is zeroed and its L2 bias -inf (sanitize_hostile_kernel), its exact values stay in the f32 copy, and its canonical
+// fp64 score -- which may well be finite, or +-inf, and then ranks -- reaches the answer through merge_special_kernel
+// (knn_select.hip), which folds the index's hostile rows into every query's result at the end of a search.  A hostile QUERY
+// is never certified and so takes the exact fp64 scan.  Below the limit |x||y| <= 1e36 < FLT_MAX: no key overflows.
+constexpr float HOSTILE_NORM2 = 1e36f;
+__host__ __device__ __forceinline__ bool hostile_norm2(float n2) { return !(n2 <= HOSTILE_NORM2); }
+__device__ __forceinline__ bool in_sorted_ids(const int* ids, int n, u32 id) {      // binary search; n == 0: no
+    int lo = 0, hi = n;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if ((u32)ids[mid] < id) lo = mid + 1; else hi = mid; }
+    return lo < n && (u32)ids[lo] == id;
+}
+constexpr int MAX_SPECIAL = 1024;      // hostile corpus rows an index folds in per query; beyond that every search is the exact scan
+
 // ---- parameters ----------------------------------------------------------------------------
 struct ScanParams {
     const bf16_t* corpus;    // [n_pad + TILE_M][Kp] bf16, n_pad multiple of TILE_M, pad rows zero
@@ -191,6 +208,8 @@ struct SelectParams {
     int compact;              // 1: the lists are indexed by the position in the flagged list (re-scan), not by the query number
     const int* gate;          // optional DEVICE int: the wide re-score runs only when *gate == gate_want (the two list layouts of the
     int gate_want;            // re-scan tier: few queries x many corpus splits, or many queries x the search's own splits)
+    const int* special;       // the index's hostile rows (sorted ids; knn_common.h): never candidates here -- an inner-product scan may list their
+    int nspecial;             // zeroed operand rows (key 0) -- they are folded in by merge_special_kernel
     int extrap;               // wide re-score of the two-scan path (k > TRX_FAST_MAX_K): a query with fewer than k rows above its guessed
                               // threshold gets a lower one, extrapolated from the rows it did find (seed_out), for one more scan
 };
@@ -200,6 +219,9 @@ hipError_t launch_scan(const ScanParams& p, int metric, hipStream_t st);
 hipError_t launch_select(const SelectParams& p, hipStream_t st);
 hipError_t launch_wide_rescore(const SelectParams& p, const int* flagged, const int* nflagged, const float* seed_in, int* flagged2, int* nflagged2,
                                float* seed_out, hipStream_t st);
+// fold the index's hostile rows (ids special[0 .. nspecial)) into the results: D / I / S64 [nq][k], sorted, pads last
+hipError_t launch_merge_special(int metric, int corpus_is_bf16, int query_is_bf16, const void* corpus_orig, int64_t ld_c, const void* queries, int64_t ld_q,
+                                int d, int64_t nq, int k, const int* special, int nspecial, int64_t n, float* D, int64_t* I, double* S64, hipStream_t st);
 hipError_t launch_append_tail(const int* flagged, const int* nflagged, int from, int* out, int* nout, hipStream_t st);
 hipError_t launch_gather_rescan(const int* flagged, const int* nflagged, const float* seed, int max_q, const bf16_t* queries, int Kp,
                                 bf16_t* qg2, u32* gthr2, int* count_out, int small_q, int* gate_out, hipStream_t st);

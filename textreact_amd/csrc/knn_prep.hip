@@ -11,6 +11,7 @@
 //     hi = bf16(v), lo = bf16(v - hi):  x.y ~= xh.yh + xh.yl + xl.yh, dropped terms <= 3.1 * 2^-18
 //     per component (DESIGN.md "Exactness"); the MFMA sees one contraction of length 3d.
 #include "knn_common.h"
+#include <algorithm>
 
 namespace trx {
 
@@ -21,6 +22,7 @@ struct RowStats {          // device-side accumulators (zeroed before each pass)
     u32 maxnorm2_bits;     // max over rows of |row|^2
     u32 nonfp4_any;        // some |value| is not one of 0, 1, 2, 3, 4, 6 (the integers E2M1 holds: the fp4 form of the scan)
     u32 maxerr2_bits;      // max over rows of |row - bf16(row)|^2 (fp32 rows; knn_common.h: round_term)
+    u32 hostile_any;       // some row is hostile (knn_common.h: hostile_norm2); such rows are in none of the maxima above
 };
 
 template <bool BF>
@@ -84,11 +86,12 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const void* x, int64_t n
     const int64_t nwaves = (int64_t)gridDim.x * 4;
     constexpr int VEC = BF ? 8 : 4;
     const bool vec = (d % VEC == 0) && (ld % VEC == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
-    u32 inexact = 0, nonint = 0;
+    u32 inexact = 0, nonint = 0, hostile = 0;
     float maxabs = 0.f, maxn2 = 0.f, maxe2 = 0.f;
     for (int64_t r = wave0; r < n; r += nwaves) {
         const char* row = reinterpret_cast<const char*>(x) + r * ld * (BF ? 2 : 4);
-        float s = 0.f, e2 = 0.f;
+        float s = 0.f, e2 = 0.f, ra = 0.f;      // (ra: this row's max |v|, folded into the launch's only if the row is benign)
+        u32 r_inexact = 0, r_nonint = 0;
         if (vec) {
             for (int c = lane * VEC; c < d; c += 64 * VEC) {
                 const uint4 u = *reinterpret_cast<const uint4*>(row + (size_t)c * (BF ? 2 : 4));
@@ -96,22 +99,24 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const void* x, int64_t n
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     if (BF) {
-                        stat_one<BF>(__uint_as_float(w[i] << 16), s, maxabs, inexact, nonint, e2);
-                        stat_one<BF>(__uint_as_float(w[i] & 0xffff0000u), s, maxabs, inexact, nonint, e2);
+                        stat_one<BF>(__uint_as_float(w[i] << 16), s, ra, r_inexact, r_nonint, e2);
+                        stat_one<BF>(__uint_as_float(w[i] & 0xffff0000u), s, ra, r_inexact, r_nonint, e2);
                     } else {
-                        stat_one<BF>(__uint_as_float(w[i]), s, maxabs, inexact, nonint, e2);
+                        stat_one<BF>(__uint_as_float(w[i]), s, ra, r_inexact, r_nonint, e2);
                     }
                 }
             }
         } else {
-            for (int i = lane; i < d; i += 64) stat_one<BF>(load_val<BF>(row, i), s, maxabs, inexact, nonint, e2);
+            for (int i = lane; i < d; i += 64) stat_one<BF>(load_val<BF>(row, i), s, ra, r_inexact, r_nonint, e2);
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); e2 += __shfl_xor(e2, o, 64); }
         if (lane == 0 && norm2) norm2[r] = s;
         if (lane == 0 && err2) err2[r] = e2;
+        if (hostile_norm2(s)) { hostile = 1u; continue; }      // (wave-uniform: s is the row's sum in every lane) -- in no maximum, no flag
         maxn2 = fmaxf(maxn2, s);
         maxe2 = fmaxf(maxe2, e2);
+        maxabs = fmaxf(maxabs, ra); inexact |= r_inexact; nonint |= r_nonint;
     }
     // wave-reduce, then block-reduce through LDS: ONE set of atomics per block (the four counters
     // are single addresses; 65k waves x 2 atomics on them took longer than streaming the data)
@@ -126,7 +131,7 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const void* x, int64_t n
     __shared__ float sh_abs[4], sh_n2[4], sh_e2[4];
     __shared__ u32 sh_flags[4];
     const int w = threadIdx.x >> 6;
-    if (lane == 0) { sh_abs[w] = maxabs; sh_n2[w] = maxn2; sh_e2[w] = maxe2; sh_flags[w] = (inexact ? 1u : 0u) | ((nonint & 1u) ? 2u : 0u) | ((nonint & 3u) ? 4u : 0u); }
+    if (lane == 0) { sh_abs[w] = maxabs; sh_n2[w] = maxn2; sh_e2[w] = maxe2; sh_flags[w] = (inexact ? 1u : 0u) | ((nonint & 1u) ? 2u : 0u) | ((nonint & 3u) ? 4u : 0u) | (hostile ? 8u : 0u); }
     __syncthreads();
     if (threadIdx.x == 0) {
         float a = fmaxf(fmaxf(sh_abs[0], sh_abs[1]), fmaxf(sh_abs[2], sh_abs[3]));
@@ -139,6 +144,7 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const void* x, int64_t n
         if ((f & 1u) && !__atomic_load_n(&st->inexact_any, __ATOMIC_RELAXED)) atomicOr(&st->inexact_any, 1u);
         if ((f & 2u) && !__atomic_load_n(&st->nonint_any, __ATOMIC_RELAXED)) atomicOr(&st->nonint_any, 1u);
         if ((f & 4u) && !__atomic_load_n(&st->nonfp4_any, __ATOMIC_RELAXED)) atomicOr(&st->nonfp4_any, 1u);
+        if ((f & 8u) && !__atomic_load_n(&st->hostile_any, __ATOMIC_RELAXED)) atomicOr(&st->hostile_any, 1u);
         if (ab > __atomic_load_n(&st->maxabs_bits, __ATOMIC_RELAXED)) atomicMax(&st->maxabs_bits, ab);
         if (mb > __atomic_load_n(&st->maxnorm2_bits, __ATOMIC_RELAXED)) atomicMax(&st->maxnorm2_bits, mb);
         if (eb > __atomic_load_n(&st->maxerr2_bits, __ATOMIC_RELAXED)) atomicMax(&st->maxerr2_bits, eb);
@@ -404,6 +410,31 @@ hipError_t launch_widen_i8(const signed char* in, int64_t n, int d, bf16_t* out,
     const int64_t total = n * d;
     if (total <= 0) return hipSuccess;
     hipLaunchKernelGGL(widen_i8_kernel, dim3((unsigned)((total + 4095) / 4096)), dim3(256), 0, st, in, total, out);
+    return hipGetLastError();
+}
+
+// Hostile rows of a block just appended (knn_common.h): the operand row becomes zero, |y|^2 becomes +inf (so that fill_bias makes
+// the L2 bias -inf and the scan never lists the row), and the row's id joins the index's special list, from which
+// merge_special_kernel folds its canonical score into every result.  One wave per row; the count may run past MAX_SPECIAL
+// (the host then sends every search to the exact scan).
+__global__ __launch_bounds__(256) void sanitize_hostile_kernel(float* norm2, int64_t n, int64_t id0, bf16_t* op, int Kp, int* special, int* nspecial) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t r = wave0; r < n; r += nwaves) {
+        if (!hostile_norm2(norm2[r])) continue;
+        bf16_t* row = op + r * Kp;
+        for (int c = lane * 8; c < Kp; c += 512) *reinterpret_cast<uint4*>(row + c) = make_uint4(0u, 0u, 0u, 0u);      // Kp is a multiple of 128
+        if (lane == 0) {
+            norm2[r] = __builtin_inff();
+            const int pos = atomicAdd(nspecial, 1);
+            if (pos < MAX_SPECIAL) special[pos] = (int)(id0 + r);
+        }
+    }
+}
+hipError_t launch_sanitize_hostile(float* norm2, int64_t n, int64_t id0, bf16_t* op, int Kp, int* special, int* nspecial, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    const unsigned grid = (unsigned)std::min<int64_t>((n + 3) / 4, 2048);
+    hipLaunchKernelGGL(sanitize_hostile_kernel, dim3(grid), dim3(256), 0, st, norm2, n, id0, op, Kp, special, nspecial);
     return hipGetLastError();
 }
 

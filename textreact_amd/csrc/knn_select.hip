@@ -12,6 +12,7 @@
 #include "../../include/trx_knn.h"
 #include "knn_common.h"
 #include <float.h>
+#include <algorithm>
 #include <cstdlib>
 #include <cstdint>
 
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             }
         };
         auto take = [&](u64 e) {
-            const bool keep = e != 0ull && e >= T && (int64_t)comp_id(e) < p.n;
+            const bool keep = e != 0ull && e >= T && (int64_t)comp_id(e) < p.n && !(p.nspecial && in_sorted_ids(p.special, p.nspecial, comp_id(e)));
             const u64 km = __ballot(keep);
             if (keep) qu[qn + __popcll(km & ((1ull << lane) - 1ull))] = e;
             qn += __popcll(km);
@@ -363,6 +364,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         p.I[o] = ok ? (int64_t)sid : (int64_t)-1;
         if (p.S64) p.S64[o] = ok ? ssc : (L2 ? (double)FLT_MAX : -(double)FLT_MAX);
     }
+    if (live && hostile_norm2(p.qnorm2[q])) certified = false;      // a hostile query (knn_common.h): its keys mean nothing -> the exact scan
     if (!certified && hl == 0 && live && TRX_SEL_ABL == 0) {
         const int pos = atomicAdd(p.nflagged, 1);
         p.flagged[pos] = q;
@@ -383,6 +385,105 @@ hipError_t launch_select(const SelectParams& p, hipStream_t st) {
         case 6: hipLaunchKernelGGL((knn_select_kernel<true, true, false>), grid, block, 0, st, p); break;
         default: hipLaunchKernelGGL((knn_select_kernel<true, true, true>), grid, block, 0, st, p); break;
     }
+    return hipGetLastError();
+}
+
+
+// ------------------------------------------------------------------------------------------
+// merge_special: the hostile rows of the index (knn_common.h) into every query's result.  The scan never lists them (zero operand,
+// -inf bias) and their approximate keys would mean nothing; their canonical fp64 scores do -- finite (|values| ~ 1e30: the fp32
+// sums overflow, the fp64 chain does not), +-inf (an inf component), or NaN (never ranks) -- and the oracle ranks them like any
+// other row.  One workgroup per query: A = the result so far without special ids (scores recomputed by the same chain: the same
+// bits), B = the special rows with a score, ordered by rank counting; the two sorted lists are merged by binary search (ids are
+// distinct, so the total order is strict) and the first k are written back.  Idempotent: results that already hold special rows
+// (the exact fp64 scan sees the original rows) come out as they went in.  Runs only when the index has such rows.
+template <bool L2, bool CBF, bool QBF>
+__global__ __launch_bounds__(256) void merge_special_kernel(const void* corpus, int64_t ld_c, const void* queries, int64_t ld_q, int d, int64_t nq, int k,
+                                                            const int* special, int ns, int64_t n, float* D, int64_t* I, double* S64) {
+    __shared__ u64 a_key[TRX_MAX_K]; __shared__ u32 a_id[TRX_MAX_K];
+    __shared__ u64 b_key[MAX_SPECIAL]; __shared__ u32 b_id[MAX_SPECIAL];
+    __shared__ u64 c_key[MAX_SPECIAL]; __shared__ u32 c_id[MAX_SPECIAL];
+    __shared__ int cnt[257];
+    __shared__ int nb_s;
+    const int tid = threadIdx.x;
+    constexpr int CE = CBF ? 2 : 4, QE = QBF ? 2 : 4;
+    auto is_special = [&](u32 id) { return in_sorted_ids(special, ns, id); };      // (`special` is sorted ascending)
+    auto before = [](u64 ka, u32 ia, u64 kb, u32 ib) { return ka > kb || (ka == kb && ia < ib); };      // larger key = ranked earlier
+    for (int64_t q = blockIdx.x; q < nq; q += gridDim.x) {
+        const char* qrow = reinterpret_cast<const char*>(queries) + q * ld_q * QE;
+        __syncthreads();
+        if (tid == 0) nb_s = 0;
+        // ---- A: the entries that stay, in order (a thread owns a contiguous run so that the compaction keeps the order) ----
+        const int per = (k + 255) / 256, t0 = tid * per, t1 = min(k, t0 + per);
+        int keep = 0;
+        for (int t = t0; t < t1; ++t) { const int64_t id = I[q * k + t]; keep += (id >= 0 && id < n && !is_special((u32)id)) ? 1 : 0; }
+        cnt[tid + 1] = keep;
+        __syncthreads();
+        if (tid == 0) { cnt[0] = 0; for (int i = 1; i <= 256; ++i) cnt[i] += cnt[i - 1]; }
+        __syncthreads();
+        const int na = cnt[256];
+        {
+            int o = cnt[tid];
+            for (int t = t0; t < t1; ++t) {
+                const int64_t id = I[q * k + t];
+                if (id < 0 || id >= n || is_special((u32)id)) continue;      // (id >= n: a query the late fall-back has yet to write)
+                const double sc = canonical_score<L2, CBF, QBF>(qrow, reinterpret_cast<const char*>(corpus) + id * ld_c * CE, d);
+                a_key[o] = orddbl(L2 ? -sc : sc); a_id[o] = (u32)id; ++o;
+            }
+        }
+        // ---- B: the special rows that have a score ----
+        for (int s_ = tid; s_ < ns; s_ += 256) {
+            const u32 id = (u32)special[s_];
+            const double sc = canonical_score<L2, CBF, QBF>(qrow, reinterpret_cast<const char*>(corpus) + (int64_t)id * ld_c * CE, d);
+            if (sc == sc) { const int o = atomicAdd(&nb_s, 1); b_key[o] = orddbl(L2 ? -sc : sc); b_id[o] = id; }
+        }
+        __syncthreads();
+        const int nb = nb_s;
+        for (int i = tid; i < nb; i += 256) {        // rank counting: nb is small
+            int r = 0;
+            for (int j = 0; j < nb; ++j) r += before(b_key[j], b_id[j], b_key[i], b_id[i]) ? 1 : 0;
+            c_key[r] = b_key[i]; c_id[r] = b_id[i];
+        }
+        __syncthreads();
+        // ---- merge: the place of an element = its place in its own list + the elements of the other list before it ----
+        auto put = [&](int pos, u64 key, u32 id) {
+            if (pos >= k) return;
+            const u64 u = (key >> 63) ? (key & 0x7fffffffffffffffull) : ~key;      // orddbl's inverse
+            const double dv = __longlong_as_double((long long)u), sc = L2 ? -dv : dv;
+            const int64_t o = q * k + pos;
+            D[o] = (float)sc; I[o] = (int64_t)id;
+            if (S64) S64[o] = sc;
+        };
+        for (int i = tid; i < na; i += 256) {
+            int lo = 0, hi = nb;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (before(c_key[mid], c_id[mid], a_key[i], a_id[i])) lo = mid + 1; else hi = mid; }
+            put(i + lo, a_key[i], a_id[i]);
+        }
+        for (int j = tid; j < nb; j += 256) {
+            int lo = 0, hi = na;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (before(a_key[mid], a_id[mid], c_key[j], c_id[j])) lo = mid + 1; else hi = mid; }
+            put(j + lo, c_key[j], c_id[j]);
+        }
+        for (int pos = na + nb + tid; pos < k; pos += 256) {
+            const int64_t o = q * k + pos;
+            D[o] = L2 ? FLT_MAX : -FLT_MAX; I[o] = -1;
+            if (S64) S64[o] = L2 ? (double)FLT_MAX : -(double)FLT_MAX;
+        }
+    }
+}
+hipError_t launch_merge_special(int metric, int corpus_is_bf16, int query_is_bf16, const void* corpus_orig, int64_t ld_c, const void* queries, int64_t ld_q,
+                                int d, int64_t nq, int k, const int* special, int nspecial, int64_t n, float* D, int64_t* I, double* S64, hipStream_t st) {
+    if (nq <= 0 || nspecial <= 0) return hipSuccess;
+    const dim3 grid((unsigned)std::min<int64_t>(nq, 65536)), block(256);
+#define TRX_MS(a, b, c) hipLaunchKernelGGL((merge_special_kernel<a, b, c>), grid, block, 0, st, corpus_orig, ld_c, queries, ld_q, d, nq, k, special, nspecial, n, D, I, S64)
+    const int sel = (metric ? 4 : 0) | (corpus_is_bf16 ? 2 : 0) | (query_is_bf16 ? 1 : 0);
+    switch (sel) {
+        case 0: TRX_MS(false, false, false); break; case 1: TRX_MS(false, false, true); break;
+        case 2: TRX_MS(false, true, false); break;  case 3: TRX_MS(false, true, true); break;
+        case 4: TRX_MS(true, false, false); break;  case 5: TRX_MS(true, false, true); break;
+        case 6: TRX_MS(true, true, false); break;   default: TRX_MS(true, true, true); break;
+    }
+#undef TRX_MS
     return hipGetLastError();
 }
 
@@ -458,7 +559,7 @@ __global__ __launch_bounds__(256) void wide_rescore_kernel(SelectParams p, const
                 const int cnt = (int)p.cand_cnt[o];
                 for (int i = tid & 63; i < cnt; i += 64) {
                     const u64 e = p.cand[o * p.cap_alloc + i];
-                    if (e != 0ull && e >= T && (int64_t)comp_id(e) < p.n) {
+                    if (e != 0ull && e >= T && (int64_t)comp_id(e) < p.n && !(p.nspecial && in_sorted_ids(p.special, p.nspecial, comp_id(e)))) {
                         const int pos = atomicAdd(&w_cnt, 1);
                         if (pos < WIDE_MAX) w_id[pos] = comp_id(e);
                         atomicMax(&w_okmax, (u32)(e >> 32));
@@ -477,7 +578,7 @@ __global__ __launch_bounds__(256) void wide_rescore_kernel(SelectParams p, const
                 const int cnt = (int)p.cand_cnt[o];
                 for (int i = tid & 63; i < cnt; i += 64) {
                     const u64 e = p.cand[o * p.cap_alloc + i];
-                    if (e != 0ull && e >= T && (int64_t)comp_id(e) < p.n) atomicAdd(&w_hist[(int)((((u64)((u32)(e >> 32) - ok0)) << 8) / range)], 1);
+                    if (e != 0ull && e >= T && (int64_t)comp_id(e) < p.n && !(p.nspecial && in_sorted_ids(p.special, p.nspecial, comp_id(e)))) atomicAdd(&w_hist[(int)((((u64)((u32)(e >> 32) - ok0)) << 8) / range)], 1);
                 }
             }
             __syncthreads();
@@ -560,7 +661,7 @@ __global__ __launch_bounds__(256) void wide_rescore_kernel(SelectParams p, const
         __syncthreads();
         // ---- certificate (same bound as the select kernel's) ----
         bool certified;
-        if (overflow) certified = false;
+        if (overflow || hostile_norm2(p.qnorm2[q])) certified = false;  // (a hostile query: knn_common.h)
         else if (T == 0ull) certified = true;                         // nothing was ever dropped: every row is listed
         else if (got < p.k) certified = false;
         else if (exact_class) certified = true;                       // approximate order is the exact order
