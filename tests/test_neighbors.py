@@ -58,3 +58,27 @@ def test_convert_tevatron(tmp_path):
     dst = tmp_path / "test.json"
     assert nb.convert_tevatron_file(str(src), str(dst)) == 4
     assert json.loads(dst.read_text())[2] == {"id": "q2", "nn": ["d0", "d1", "d2"]}
+
+
+def test_the_block_writer_emits_json_dumps_bytes(tmp_path):
+    """write_neighbor_file == json.dump(build_result(...)) byte for byte: int ids, numpy ints, strings with quotes / unicode /
+    backslashes, floats, pads (-1) in any place, an empty result, more rows than one block"""
+    import numpy as np
+    from textreact_amd import neighbors as N
+    rng = np.random.default_rng(0)
+    cases = []
+    ids_int = np.arange(1000, 1400)
+    ids_str = ['r"%d\\\\x' % i if i % 7 == 0 else "US0%d-é☃" % i for i in range(400)]
+    ids_mixed = [1.5, "a", 7, True, None] * 80
+    for cids in (ids_int, ids_str, ids_mixed, list(ids_int)):
+        rank = rng.integers(0, len(cids), (95, 20))
+        rank[3, 5:] = -1; rank[4, :] = -1; rank[5, 0] = -1; rank[6, ::2] = -1
+        qids = [cids[i] for i in rng.integers(0, len(cids), 95)]
+        cases.append((qids, rank, cids))
+    cases.append(([], np.empty((0, 20), np.int64), ids_int))
+    cases.append((list(range(5)), np.full((5, 3), -1), []))
+    for i, (qids, rank, cids) in enumerate(cases):
+        a, b = tmp_path / ("a%d.json" % i), tmp_path / ("b%d.json" % i)
+        N.write_neighbors(a, N.build_result(qids, rank, cids))
+        N.write_neighbor_file(b, qids, rank, cids, block=16)
+        assert a.read_bytes() == b.read_bytes(), i

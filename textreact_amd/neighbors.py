@@ -27,6 +27,35 @@ def write_neighbors(path, result):
         json.dump(result, f)  # default separators: byte-identical to the reference's files
 
 
+def write_neighbor_file(path, query_ids, rank, corpus_ids, block=16384):
+    """The same bytes as ``write_neighbors(path, build_result(query_ids, rank, corpus_ids))`` -- ``json.dump`` of the reference's
+    list (retrieve/retrieve_faiss.py:116-118), default separators -- without building 14 million Python objects first: every corpus
+    id is encoded ONCE by the json encoder (ints, strings with escapes, whatever the 'id' column holds), a row's text is the
+    join of its neighbours' encodings, and the file is written a block of rows at a time.  After a 0.4 s search of 680,000
+    queries the reference's two lines (list comprehension + json.dump) are 30+ s of the run; this is a few."""
+    import numpy as np
+    enc = json.JSONEncoder().encode
+    tok = np.empty(len(corpus_ids), dtype=object)
+    for i, c in enumerate(corpus_ids):
+        tok[i] = enc(_py(c))
+    rank = np.asarray(rank)
+    qids = list(query_ids)
+    with open(path, "w") as f:
+        f.write("[")
+        for r0 in range(0, len(qids), block):
+            blk = rank[r0:r0 + block]
+            valid = blk >= 0
+            toks = tok[np.where(valid, blk, 0)] if len(tok) else np.empty(blk.shape, dtype=object)
+            allv = valid.all(axis=1) if blk.ndim == 2 else []
+            rows = []
+            for j, qid in enumerate(qids[r0:r0 + block]):
+                nn = toks[j] if allv[j] else toks[j][valid[j]]
+                rows.append('{"id": %s, "nn": [%s]}' % (enc(_py(qid)), ", ".join(nn)))
+            if rows:
+                f.write((", " if r0 else "") + ", ".join(rows))
+        f.write("]")
+
+
 def read_neighbors(path):
     """{id: nn} as BaseDataset.load_corpus builds it (textreact/dataset.py:42-44)."""
     with open(path) as f:

@@ -26,12 +26,13 @@ Differences, all deliberate:
 import argparse
 import json
 import os
+import sys
 import time
 
 import numpy as np
 
 from . import faiss_compat as faiss
-from .neighbors import build_result, write_neighbors
+from .neighbors import build_result, write_neighbor_file, write_neighbors
 
 CONDITION_FIELDS = ['catalyst1', 'solvent1', 'solvent2', 'reagent1', 'reagent2']
 
@@ -140,6 +141,9 @@ def get_parser():
     parser.add_argument('--tie_rule', type=str, default=None, choices=['id', 'faiss'],
                         help="order of exactly equal scores: 'id' (smaller row id first, the default) or 'faiss' (the order "
                              "FAISS's heap leaves for --metric ip; include/trx_knn.h TRX_TIES_FAISS)")
+    parser.add_argument('--stage_times', action='store_true',
+                        help='print one JSON line with the wall-clock seconds of every stage (read csv, load vectors, index.add, each '
+                             'search, id mapping, json.dump) to stderr when the run ends')
     parser.add_argument('--replicas', action='store_true',
                         help='under torch.distributed.run: every GPU holds all train vectors and searches 1/G of the queries '
                              '(FAISS IndexReplicas; sharded.ReplicatedFlatIndex) instead of a row shard of the train vectors')
@@ -252,11 +256,18 @@ def main(argv=None):
         os.environ["TRX_TIE_RULE"] = args.tie_rule         # read by every index faiss_compat makes from here on
     rank, world = _dist_setup()
     say = print if rank == 0 else (lambda *a, **k: None)
+    stages, t_last = {}, [time.perf_counter()]
+
+    def lap(name):      # seconds since the previous lap, added to stage `name`
+        now = time.perf_counter()
+        stages[name] = stages.get(name, 0.0) + now - t_last[0]
+        t_last[0] = now
 
     train_df = pd.read_csv(os.path.join(args.data_path, args.train_file), keep_default_na=False)
     val_df = pd.read_csv(os.path.join(args.data_path, args.valid_file), keep_default_na=False)
     test_df = pd.read_csv(os.path.join(args.data_path, args.test_file), keep_default_na=False)
 
+    lap("read_csv")
     if args.field == 'canonical_rxn':
         say('Reaction fingerprint')
         fingerprint_fn = compute_reaction_fingerprints
@@ -289,6 +300,7 @@ def main(argv=None):
     assert len(train_fps) == len(train_df), "fingerprints and train ids are misaligned"
     train_id = train_df['id']
 
+    lap("load_train_vectors")
     say('Faiss build index')
     if world == 1:
         index = build_index(train_fps, args.metric)
@@ -308,18 +320,22 @@ def main(argv=None):
         dist.broadcast_object_list(box, src=0)
         return box[0]
 
+    lap("index_add")
     rank_arr = None
     for name, df, fps in (('train', train_df, train_fps),
                           ('val', val_df, None),
                           ('test', test_df, None)):
         if fps is None:
             fps = vectors(df, args.valid_vectors if name == 'val' else args.test_vectors)
+        lap("load_query_vectors")
         if rank == 0:
             rank_arr = index_and_search(train_fps, fps, k=args.k, metric=args.metric, index=index)
-            result = build_result(df['id'], rank_arr, train_id)
-            write_neighbors(os.path.join(args.output_path, name + '.json'), result)
+            lap("search_" + name)
+            write_neighbor_file(os.path.join(args.output_path, name + '.json'), df['id'], rank_arr, train_id)
+            lap("map_ids_and_write_json")
         else:
             index.search(fps, args.k)
+            lap("search_" + name)
 
     if rank == 0 and args.field == 'canonical_rxn' and all(f in test_df.columns for f in CONDITION_FIELDS):
         cnt = hit_rates(rank_arr, test_df, train_df)
@@ -327,6 +343,11 @@ def main(argv=None):
         for x in cnt:
             print(f"Top-{x}: {cnt[x] / len(test_df):.4f}", end='  ')
         print()
+    lap("hit_rates")
+    if args.stage_times and rank == 0:
+        stages["total"] = sum(stages.values())
+        print(json.dumps({"stage_seconds": {k_: round(v, 3) for k_, v in stages.items()}, "train_rows": int(len(train_df)), "k": args.k,
+                          "queries": {"train": int(len(train_df)), "val": int(len(val_df)), "test": int(len(test_df))}}), file=sys.stderr)
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
