@@ -115,12 +115,13 @@ def cpu_baseline(corpus_dev, queries_dev, k, target_seconds=20.0, metric=0):
     mkl = lambda a, b: torch.mm(torch.from_numpy(a), torch.from_numpy(b).t()).numpy()      # noqa: E731
     cands = [("torch.mm (MKL)", cores, mkl), ("numpy (OpenBLAS)", min(cores, 64), None)]
     try:
-        best = None
+        best, probes = None, {}
         for name, workers, gemm in cands:
             yprobe = y[:min(y.shape[0], 2 * 1024 * workers)]
             oracle.knn_faiss_blas_mt(metric, probe[:256], yprobe[:1024 * min(workers, 8)], k, workers, gemm=gemm)
             t0 = time.perf_counter(); oracle.knn_faiss_blas_mt(metric, probe, yprobe, k, workers, gemm=gemm); t1 = time.perf_counter()
             rate = nprobe * yprobe.shape[0] / (t1 - t0)
+            probes[name] = {"workers": workers, "tflops": 2.0 * rate * d / 1e12, "corpus_rows_in_probe": int(yprobe.shape[0])}
             if best is None or rate > best[0]:
                 best = (rate, name, workers, gemm)
         rate, blas_name, workers, gemm = best
@@ -135,12 +136,14 @@ def cpu_baseline(corpus_dev, queries_dev, k, target_seconds=20.0, metric=0):
             "tflops": 2.0 * nq * y.shape[0] * d / (t1 - t0) / 1e12, "blas": blas_mt, "blas_of_the_internal_threading_probe": blas,
             "threads": "%d worker threads over the corpus blocks x 1 BLAS thread per sgemm call" % workers,
             "blas_internal_threading_tflops": internal_tflops, "seconds": t1 - t0,
+            # why the candidate that ran is the one that ran: both candidates' measured rates on the same probe (the faster takes the sample)
+            "candidates_on_the_probe": probes,
             "sample": "%d of %d queries (%s) x full %dx%d corpus, fp32 host-BLAS sgemm 4096x1024 blocks + heap"
                       % (nq, queries_dev.shape[0], "one full FAISS query block" if nq == 4096 else "probe predicted %.0f s for 4096" % est_full,
                          y.shape[0], d)}, I
 
 
-def selfcheck(index, local, shard, lo, queries, k, D, I, world, rank, dev, n_sample=32):
+def selfcheck(index, local, shard, lo, queries, k, D, I, world, rank, dev, n_sample=32, row_groups=None):
     """Before the timed region: (1) every rank holds the same (D, I) -- a hash per rank, gathered; (2) `n_sample` queries
     are re-done with nothing of the search path in it: fp64 scores of the queries against this rank's shard by torch.matmul,
     a local top-k, ONE plain all_gather of the (score, global id) lists, a sort by (score desc, id asc) on every rank.  A
@@ -171,6 +174,7 @@ def selfcheck(index, local, shard, lo, queries, k, D, I, world, rank, dev, n_sam
             hp = [x.cpu() for x in parts]; dist.all_gather(hp, pack.cpu()); parts = [x.to(dev) for x in hp]
         else:
             dist.all_gather(parts, pack)
+        parts = parts[:row_groups or world]      # a rows x queries grid holds every row shard once per column: column 0 = ranks 0 .. Gr - 1
         top = torch.cat([p_[0].view(torch.float64) for p_ in parts], dim=1)
         ids = torch.cat([p_[1] for p_ in parts], dim=1)
     order = torch.argsort(ids, dim=1, stable=True)                        # (score desc, id asc): sort by id, then stably by score
@@ -342,6 +346,9 @@ def main():
     ap.add_argument("--replicas", action="store_true",
                     help="query-sharded replicas (SURVEY 8e, the separate line): every GPU holds the WHOLE corpus and searches "
                          "its 1/G of the queries, no collective on the data path; not the north-star line (row-sharded)")
+    ap.add_argument("--row-groups", type=int, default=0,
+                    help="rows x queries grid (sharded.ShardedFlatIndex(row_groups=Gr)): the corpus row-sharded Gr ways, the queries split "
+                         "over the G / Gr columns; 0 = pure row sharding (Gr = G), the north-star line")
     ap.add_argument("--selfcheck", action="store_true",
                     help="also at N = 1 (always on at N > 1): before the timed region, compare every rank's result hashes and re-do "
                          "32 sampled queries by an independent fp64 matmul + all_gather + sort; exit code 3 on a mismatch")
@@ -375,8 +382,13 @@ def main():
     n, d, nq, k = args.n_corpus * (world if args.weak else 1), DIM, args.n_queries, TOPK
     if args.workload in ("fingerprint", "morgan"):
         return fingerprint_workload(args, dev, local_rank)
-    lo, hi = (0, n) if args.replicas else shard_bounds(n, world, rank)
+    row_groups = args.row_groups if (args.row_groups and not args.replicas) else world
+    if world % row_groups:
+        raise SystemExit("bench.py: --row-groups %d does not divide %d ranks" % (row_groups, world))
+    lo, hi = (0, n) if args.replicas else shard_bounds(n, row_groups, rank % row_groups)
     if args.weak and not args.replicas:      # "8 shards x 1,000,000, shard s uses seed 1234 + s"
+        if row_groups != world:
+            raise SystemExit("bench.py: --weak is the pure row-sharded line (one seed per rank); not with --row-groups")
         shard = make_rows(hi - lo, d, 1234 + rank, dev)
     else:
         shard = make_rows(hi - lo, d, 1234, dev, row0=lo)
@@ -390,7 +402,7 @@ def main():
         index = local                        # a plain flat index per GPU: nothing to exchange
         index.add(shard)
     else:
-        index = ShardedFlatIndex(d, faiss.METRIC_INNER_PRODUCT, local_index=local)
+        index = ShardedFlatIndex(d, faiss.METRIC_INNER_PRODUCT, local_index=local, row_groups=row_groups)
         # fault injection for tests/test_bench_gpu.py: the last rank reports its rows one id too high -- the kind of
         # plumbing error the selfcheck exists for
         wrong = 1 if (os.environ.get("TRX_BENCH_INJECT_FAULT") == "offset" and world > 1 and rank == world - 1) else 0
@@ -407,7 +419,7 @@ def main():
     checked = None
     if (world > 1 or args.selfcheck) and not args.replicas:
         D, I = index.search(queries, k)
-        problems = selfcheck(index, local, shard, lo, queries, k, D, I, world, rank, dev)
+        problems = selfcheck(index, local, shard, lo, queries, k, D, I, world, rank, dev, row_groups=row_groups)
         flag = torch.tensor([len(problems)], dtype=torch.int32, device=dev)
         if world > 1:
             if backend == "nccl":
@@ -463,10 +475,12 @@ def main():
         ms_step = elapsed / args.steps * 1e3
         value = nq * args.steps / elapsed
         # algorithmic: 2*Q_local*N_local*d per step, over the scan launches the step took (one per 65,536 queries)
-        flops_launch = 2.0 * queries.shape[0] * (hi - lo) * d * args.steps / max(launches, 1)
+        q_rank = shard_bounds(queries.shape[0], world // row_groups, rank // row_groups) if not args.replicas else (0, queries.shape[0])
+        q_rank = q_rank[1] - q_rank[0]           # the queries THIS rank searches (all of them unless the grid splits them)
+        flops_launch = 2.0 * q_rank * (hi - lo) * d * args.steps / max(launches, 1)
         mean_launch_ms = scan_ms / max(launches, 1)
         achieved = flops_launch / (mean_launch_ms * 1e-3) / 1e12 if mean_launch_ms > 0 else 0.0
-        q_launch = queries.shape[0] * args.steps / max(launches, 1)
+        q_launch = q_rank * args.steps / max(launches, 1)
         alg_bytes = 2.0 * ((hi - lo) * d + q_launch * d) + 8.0 * q_launch * k      # SURVEY 8d, per launch
         hbm_gbs = alg_bytes / (mean_launch_ms * 1e-3) / 1e9 if mean_launch_ms > 0 else 0.0
         traffic, traffic_source = None, None
@@ -484,7 +498,9 @@ def main():
                                     "exact IP top-%d, %dx%d bf16 corpus row-sharded %d-way, %d queries per step") % (k, n, d, world, nq),
                        "corpus_rows": n, "dim": d, "queries": nq, "k": k,
                        "parallelism": ("query-sharded replicas x%d (whole corpus per GPU, no collective)" % world if args.replicas else
-                                       "corpus row-sharded x%d + RCCL all-gather merge" % world) if world > 1 else "single GPU",
+                                       ("corpus row-sharded x%d + RCCL all-gather merge" % world) if row_groups == world else
+                                       ("rows x queries grid %d x %d: corpus row-sharded x%d, queries split over %d columns, all-to-all inside a column + all-gather"
+                                        % (row_groups, world // row_groups, row_groups, world // row_groups))) if world > 1 else "single GPU",
                        "transport": ("RCCL (nccl backend), one GPU per rank" if backend == "nccl" else
                                      "REHEARSAL: %d ranks share GPU %d, %s backend (host round trip in the all-gather); not a scaling measurement"
                                      % (world, local_rank, backend)) if world > 1 else None,

@@ -902,6 +902,12 @@ def _rank_worker(rank, world, port, ret):
         rep.add(torch.from_numpy(y).cuda())
         D, I = rep.search(torch.from_numpy(x).cuda(), 10)
         out[("replicas", metric)] = (D.cpu().numpy(), I.cpu().numpy())
+        if world == 4:      # round 6: the rows x queries grid, 2 x 2 -- row shard r % 2, query slice r // 2, the exchange inside a column
+            gidx = ShardedFlatIndex(d, metric, row_groups=2)
+            glo, ghi = gidx.shard_rows(n)
+            gidx.add_shard(torch.from_numpy(y[glo:ghi]).cuda(), glo, n)
+            D, I = gidx.search(torch.from_numpy(x).cuda(), 10)
+            out[("grid", metric)] = (D.cpu().numpy(), I.cpu().numpy())
     # FAISS' own order among exact inner-product ties, through the shards: canonical top 2k per shard, merged, the rule once
     import textreact_amd.faiss_compat as fc
     from _data import grid as grid_
@@ -916,7 +922,7 @@ def _rank_worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 4])
 def test_multi_rank_sharded_search_on_one_gpu(world):
     import socket
     import torch.multiprocessing as mp
@@ -930,7 +936,7 @@ def test_multi_rank_sharded_search_on_one_gpu(world):
     for metric in (IP, L2):
         Dr, Ir = oracle.knn_canonical(metric, x, y, 10)
         for r in range(world):
-            for key in (metric, ("replicas", metric)):
+            for key in (metric, ("replicas", metric)) + ((("grid", metric),) if world == 4 else ()):
                 D, I = ret[r][key]
                 assert np.array_equal(I, Ir), (key, r)
                 assert np.array_equal(D.view(np.uint32), Dr.view(np.uint32)), (key, r)

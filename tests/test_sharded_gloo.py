@@ -125,3 +125,57 @@ def test_shard_bounds_cover_and_balance():
             assert all(b[i][1] == b[i + 1][0] for i in range(g - 1))
             sizes = [hi - lo for lo, hi in b]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _grid_worker(rank, world, port, metric, row_groups, n, d, nq, k, ret):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from _data import grid
+    from textreact_amd.sharded import ShardedFlatIndex
+    y, x = grid(n, d, 1), grid(nq, d, 2)
+    idx = ShardedFlatIndex(d, metric, local_index=OracleLocalIndex(metric), merge=oracle_merge, row_groups=row_groups)
+    lo, hi = idx.shard_rows(n)
+    idx.add_shard(torch.from_numpy(y[lo:hi]), lo, n)
+    D, I = idx.search(torch.from_numpy(x), k)
+    ret[rank] = (D.numpy(), I.numpy(), (idx.row_rank, idx.query_rank, lo, hi))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,row_groups,nq", [(4, 2, 37), (4, 1, 9), (4, 4, 37), (6, 3, 5), (6, 2, 101)])
+def test_rows_by_queries_grid_equals_unsharded(world, row_groups, nq):
+    """round 6: G = Gr x Gq.  Rank j Gr + i holds row shard i of Gr and searches query slice j of Gq; the candidate exchange runs
+    inside a column, the final all-gather over all ranks.  2 x 2, the two degenerate grids (Gr = 1: replicas; Gr = G: pure row
+    sharding), 3 x 2 and 2 x 3 with fewer queries than ranks / uneven slices: the unsharded oracle's (D, I) on every rank"""
+    from _data import grid
+    from oracle import flat_knn as oracle
+    from textreact_amd.sharded import shard_bounds
+    n, d, k = 1001, 32, 10
+    for metric in (0, 1):
+        mgr = mp.Manager(); ret = mgr.dict()
+        mp.spawn(_grid_worker, args=(world, _free_port(), metric, row_groups, n, d, nq, k, ret), nprocs=world, join=True)
+        Dr, Ir = oracle.knn_canonical(metric, grid(nq, d, 2), grid(n, d, 1), k)
+        for r in range(world):
+            D, I, (i, j, lo, hi) = ret[r]
+            assert (i, j) == (r % row_groups, r // row_groups) and (lo, hi) == shard_bounds(n, row_groups, i)
+            assert np.array_equal(I, Ir) and np.array_equal(D, Dr), "rank %d of %d x %d" % (r, row_groups, world // row_groups)
+
+
+def test_grid_and_tie_rule_arguments_are_checked_at_construction():
+    from textreact_amd.sharded import ShardedFlatIndex
+
+    class Local(OracleLocalIndex):
+        tie_rule = "faiss"
+
+        def set_tie_rule(self, r):
+            self.tie_rule = r
+    with pytest.raises(TypeError, match="faiss_ties_k"):          # a merge callable without the keyword: found here, not inside a collective
+        ShardedFlatIndex(8, 0, local_index=Local(0), merge=oracle_merge)
+    loc = Local(0)
+    idx = ShardedFlatIndex(8, 0, local_index=loc, merge=lambda m, S, I, faiss_ties_k=None: oracle_merge(m, S, I))
+    assert loc.tie_rule == "id" and idx.tie_rule == "faiss"       # the wrapper took the rule over ...
+    with pytest.raises(AssertionError, match="1024"):
+        idx.search(torch.zeros(1, 8), 1025)
+    assert idx.release_local() is loc and loc.tie_rule == "faiss"  # ... and gives it back
+    with pytest.raises(ValueError, match="does not divide"):
+        ShardedFlatIndex(8, 0, local_index=OracleLocalIndex(0), merge=oracle_merge, row_groups=3)

@@ -37,8 +37,29 @@ for n in (1_000_000, 500_000, 250_000, 125_000):
         del idx
     del shard
 os.environ.pop("TRX_BOOT_TILES", None)
+# round 6: the cells of a rows x queries grid over 8 (and 4) ranks -- sharded.ShardedFlatIndex(row_groups=Gr): Gr row shards x Gq query slices
+grid = []
+for gr, gq in ((4, 2), (2, 4), (1, 8), (2, 2), (1, 4), (1, 2)):
+    n, nq = 1_000_000 // gr, 65536 // gq
+    shard = bench.make_rows(n, 768, 1234, dev)
+    idx = faiss.IndexFlatIP(768, device=0)
+    idx.add(shard); idx.set_timing(True)
+    q = queries[:nq].contiguous()
+    for _ in range(2):
+        idx.search(q, 10)
+    steps, scans = [], []
+    for _ in range(10):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); idx.search(q, 10); b.record(); b.synchronize()
+        steps.append(a.elapsed_time(b)); scans.append(idx.last_stats()["scan_ms"])
+    steps.sort(); scans.sort()
+    grid.append({"row_groups": gr, "query_groups": gq, "ranks": gr * gq, "corpus_rows": n, "queries": nq, "scan_ms_median": scans[5],
+                 "step_ms_median": steps[5], "step_ms_min": steps[0], "n_splits": idx.last_stats()["n_splits"]})
+    del idx, shard
 base = next(r for r in rows if r["corpus_rows"] == 1_000_000)["step_ms_median"]
 for r in rows:
     r["ideal_ms"] = base * r["corpus_rows"] / 1_000_000
+for r in grid:
+    r["ideal_ms"] = base / r["ranks"]
 print(json.dumps({"what": "65,536 queries x 768, exact IP top-10, one MI355X; step = query statistics + bootstrap + scan + select (+ inline fall-back slots)",
-                  "rows": rows}, indent=1))
+                  "rows": rows, "grid_cells": grid}, indent=1))
