@@ -50,14 +50,6 @@ def test_c0_gaussian_fp32(metric):
 
 
 @pytest.mark.parametrize("metric", [IP, L2])
-def test_c0_gaussian_fp32_through_the_three_term_split(metric, monkeypatch):
-    """rounds 1-3's form for fp32 data, kept behind TRX_FP32_SPLIT=1: corpus [hi|lo|hi], queries [hi|hi|lo], K = 3d"""
-    monkeypatch.setenv("TRX_FP32_SPLIT", "1")
-    st = _check(metric, gaussian(1000, 768, 5678), gaussian(10000, 768, 1234), 10)
-    assert st["k_split"] == 3 * 768 and st["n_uncertified"] == 0
-
-
-@pytest.mark.parametrize("metric", [IP, L2])
 def test_fp32_queries_against_a_bf16_index_and_back(metric):
     """the approx mode's other doors: fp32 queries that bf16 does not hold against an index of bf16 values (nothing about the
     index changes), bf16 queries against an fp32 index, fp32 rows added to an index that held bf16 values, ragged sizes"""
@@ -413,28 +405,19 @@ def test_near_duplicate_cluster_is_resolved_by_the_wide_rescore():
     assert st["n_rescored"] == 8 and st["n_uncertified"] == 0
 
 
-@pytest.mark.parametrize("split", [True, False])
-def test_a_crowd_around_the_kth_place_is_resolved_by_the_rescan(split, monkeypatch):
-    # (split: the three-term operand of rounds 1-3, whose tight key error this crowd was built against.  The approx mode's
-    # error bound is 2^-7 |x||y|: the whole crowd lies inside its listing slack, is listed by the FIRST scan and resolved by the
-    # wide re-score -- same answers, no second scan)
-    if split:
-        monkeypatch.setenv("TRX_FP32_SPLIT", "1")
-        # (which tier settles a query depends on where the lists' bound falls inside the crowd; this case was built against the
-        # bootstrap bound of rounds 2-4 -- the main scan's rule -- and keeps it, so that the re-scan tier stays exercised here;
-        # round 5's tighter bootstrap bound puts the same queries through the wide re-score alone: next test)
-        monkeypatch.setenv("TRX_BOOT_J2", "1")
+def test_a_crowd_around_the_kth_place_is_resolved_by_the_wide_rescore():
     # the k-th place INSIDE a crowd that reaches down to the lists' bound: scores fall off smoothly (steps far below the rounding
-    # bound) over 3000 rows, so whatever the bound is, rows just under it tie with the k-th and the wide re-score cannot
-    # certify.  Tier 3 scans again with the threshold fixed at (k-th exact score so far) - 2 eps: the ~1,400 rows above it
-    # are listed by construction and re-scored; no fp64 scan of the index
+    # bound) over 3000 rows.  The approx mode's error bound is 2^-7 |x||y|: the whole crowd lies inside its listing slack, is listed
+    # by the FIRST scan and resolved by the wide re-score -- no second scan, no fp64 scan of the index.  (The three-term operand of
+    # rounds 1-3, whose tight key error sends this crowd through the re-scan tier, is a lab build since round 6:
+    # tools/experiments/lab_checks_knn.py; the re-scan tier itself stays exercised by tests/test_knn_hostile_gpu.py.)
     y = gaussian(4000, 64, 1)
     c = gaussian(1, 64, 2)
     y[500:3500] = c * (1.0 - 1e-7 * np.arange(3000, dtype=np.float32)[:, None])
     x = np.repeat(c, 4, axis=0)
     for metric in (IP, L2):
         st = _check(metric, x, y, 10)
-        assert st["n_rescored"] == 4 and st["n_rescanned"] == (4 if split else 0) and st["n_uncertified"] == 0, st
+        assert st["n_rescored"] == 4 and st["n_rescanned"] == 0 and st["n_uncertified"] == 0, st
 
 
 @pytest.mark.parametrize("metric", [IP, L2])
@@ -458,24 +441,9 @@ def test_a_call_cut_into_several_scan_launches(metric, monkeypatch):
 
 def test_the_bootstrap_bound_changes_tiers_never_answers(monkeypatch):
     """round 5: the bootstrap publishes the 16th largest of a query's 32 tracked maxima instead of the minimum over its lanes'
-    second bests (TRX_BOOT_J2=1 keeps the old rule).  A threshold is a hint: the same crowd, the three-term operand, both
-    rules -- identical answers (the oracle's), whichever tiers they take; and on benign data neither flags a query"""
-    monkeypatch.setenv("TRX_FP32_SPLIT", "1")
-    y = gaussian(4000, 64, 1)
-    c = gaussian(1, 64, 2)
-    y[500:3500] = c * (1.0 - 1e-7 * np.arange(3000, dtype=np.float32)[:, None])
-    x = np.repeat(c, 4, axis=0)
-    tiers = []
-    for rule in ("1", None):
-        if rule:
-            monkeypatch.setenv("TRX_BOOT_J2", rule)
-        else:
-            monkeypatch.delenv("TRX_BOOT_J2")
-        for metric in (IP, L2):
-            st = _check(metric, x, y, 10)
-            assert st["n_uncertified"] == 0, st
-            tiers.append((st["n_rescored"], st["n_rescanned"]))
-    monkeypatch.delenv("TRX_FP32_SPLIT")
+    second bests (TRX_BOOT_J2=1 keeps the old rule).  A threshold is a hint: on benign data neither rule flags a query, and the
+    answers are the oracle's (the crowd that tells the rules' tiers apart needs the lab build's three-term operand:
+    tools/experiments/lab_checks_knn.py)"""
     for rule in ("1", None):
         if rule:
             monkeypatch.setenv("TRX_BOOT_J2", rule)
@@ -483,20 +451,16 @@ def test_the_bootstrap_bound_changes_tiers_never_answers(monkeypatch):
             monkeypatch.delenv("TRX_BOOT_J2")
         st = _check(IP, bf16_round(gaussian(700, 768, 5678)), bf16_round(gaussian(60000, 768, 1234)), 10)
         assert st["n_rescored"] == 0 and st["n_uncertified"] == 0, st
-    assert tiers[0][1] == 4          # (the old rule's bound sends this crowd through the re-scan: what the test above pins)
 
 
-@pytest.mark.parametrize("split", [True, False])
-def test_a_crowd_wider_than_the_lists_still_takes_the_exact_scan(split, monkeypatch):
+def test_a_crowd_wider_than_the_lists_still_takes_the_exact_scan():
     # 10,000 rows within the rounding bound of each other: more than a query's lists (and the wide re-score) hold
-    if split:
-        monkeypatch.setenv("TRX_FP32_SPLIT", "1")
     y = gaussian(12000, 64, 1)
     c = gaussian(1, 64, 2)
     y[1000:11000] = c * (1.0 - 1e-8 * np.arange(10000, dtype=np.float32)[:, None])
     x = np.repeat(c, 4, axis=0)
     st = _check(IP, x, y, 10)
-    assert st["n_uncertified"] == 4 and (st["n_rescanned"] == 4 or not split), st
+    assert st["n_uncertified"] == 4, st
 
 
 def test_dimension_mismatch_raises():

@@ -82,10 +82,14 @@ static DevPool& pool_of(int device) { return g_pool[device & 63]; }
 
 // PLAIN: every value is exact in bf16, the operand IS the data.  APPROX (round 4): the operand is the bf16 ROUNDING of fp32 data
 // (K = d), the fp32 rows are kept for the exact pass, and the key error this admits (2^-7 |x||y|) is paid for by listing every row
-// within twice that error of a query's bound and certifying on the exact scores (search_batch: slack).  SPLIT (rounds 1-3, now
-// behind TRX_FP32_SPLIT=1): a three-term bf16 split of the fp32 data, K = 3d, keys good to 2^-16.
+// within twice that error of a query's bound and certifying on the exact scores (search_batch: slack).  SPLIT (rounds 1-3; since
+// round 6 reachable in the LAB build only, -DTRX_KNN_LAB + TRX_FP32_SPLIT=1): a three-term bf16 split of the fp32 data, K = 3d, keys good to 2^-16.
 enum { MODE_EMPTY = 0, MODE_PLAIN = 1, MODE_SPLIT = 2, MODE_APPROX = 3 };
+#ifdef TRX_KNN_LAB      // lab build (make knnlab; tools/experiments/lab_checks_knn.py): TRX_FP32_SPLIT=1 selects the three-term split
 static int inexact_mode() { return getenv("TRX_FP32_SPLIT") ? MODE_SPLIT : MODE_APPROX; }      // (read when an index first meets such data)
+#else
+static int inexact_mode() { return MODE_APPROX; }
+#endif
 static bool keeps_f32(int mode) { return mode == MODE_SPLIT || mode == MODE_APPROX; }
 static int round_up(int64_t v, int m) { return (int)((v + m - 1) / m * m); }
 static int64_t round_up64(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
