@@ -234,6 +234,14 @@ def fingerprint_workload(args, dev, local_rank):
     peak = {0: PEAK_BF16_TFLOPS, 1: 5000.0, 2: 10000.0}[form]
     mean_launch_ms = scan_ms / max(launches, 1)
     achieved = flops_step * steps / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else 0.0
+    # The second roofline of these forms: the L2 -> LDS fill.  A K-step of a workgroup stages 32 KiB of corpus rows and 32 KiB
+    # of query rows (128 bytes per row) whatever the element type, so with the MFMA time of a K-step halved (int8) or quartered
+    # (fp4) and its fill bytes unchanged the loop runs into the rate at which the LDS-DMA path delivers: 14.0 TB/s over the chip
+    # in this access pattern (tools/fill_bench.hip, DESIGN_HISTORY 3.1).  Per step: query tiles x corpus tiles x K-steps x 64 KiB.
+    row_bytes = {0: 2 * st["k_split"], 1: st["k_split"], 2: st["k_split"] // 2}[form]
+    fill_step = float(-(-n // 256)) * float(-(-n // 256)) * (row_bytes // 128) * 65536.0
+    fill_tbps = fill_step * steps / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else 0.0
+    traffic, traffic_source = forms_traffic("morgan" if morgan else "fingerprint", n)
     line = {"metric": "queries/sec, train self-search IndexFlatL2 k=20 over %dx%d integer fingerprints (the reference's own workload)" % (n, dim),
             "value": n * steps / (t1 - t0), "unit": "queries/s", "n_gpus": 1, "steps": steps, "warmup": args.warmup,
             "ms_per_step": (t1 - t0) / steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -246,8 +254,10 @@ def fingerprint_workload(args, dev, local_rank):
                        "scan_launches_per_step": launches // steps},
             "roofline": {"bound": "mfma", "kernel": "knn_scan_kernel", "achieved": achieved, "peak": peak,
                          "unit": ("TFLOP/s", "Top/s (dense int8 MFMA peak)", "TFLOP/s (dense fp4 MFMA peak: twice fp8's)")[form],
-                         "frac": achieved / peak, "traffic": None, "launch_ms": mean_launch_ms,
-                         "flops_per_launch": flops_step * steps / max(launches, 1)}}
+                         "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_source, "launch_ms": mean_launch_ms,
+                         "flops_per_launch": flops_step * steps / max(launches, 1),
+                         "fill": {"bound": "L2 -> LDS fill (LDS-DMA)", "achieved": fill_tbps, "peak": 14.0, "unit": "TB/s", "frac": fill_tbps / 14.0,
+                                  "bytes_per_step": fill_step, "peak_source": "tools/fill_bench.hip: this loop's access pattern, LDS-DMA, measured"}}}
     if args.host_api:
         line.update(host_api_leg(idx, y, I, "int8" if morgan else "int64", local_rank))
     if not args.no_cpu_baseline:
@@ -258,6 +268,22 @@ def fingerprint_workload(args, dev, local_rank):
     else:
         line["cpu_baseline"] = None
     print(json.dumps(line))
+
+
+def forms_traffic(workload, n, root=ROOT):
+    """roofline.traffic of the int8 / fp4 forms: L2-miss bytes per scan launch from profiles/traffic_forms.json (profiles/pmc_forms.sh:
+    one --pmc pass per counter), reported only for the size it was taken at and the kernel text this run compiled from"""
+    try:
+        tj = json.load(open(os.path.join(root, "profiles", "traffic_forms.json")))
+    except Exception:
+        return None, None
+    if tj.get("scan_source_sha256") != scan_source_sha256(root):
+        return None, "profiles/traffic_forms.json is STALE for this knn_scan.hip / knn_common.h (source hash differs): traffic not reported"
+    if n != {"fingerprint": 680_000, "morgan": 800_000}[workload]:
+        return None, "profiles/traffic_forms.json was taken at another corpus size"
+    e = tj.get(workload) or {}
+    return e.get("hbm_bytes_per_launch"), "profiles/traffic_forms.json@%s (same scan-kernel source; kernel trace %.2f ms per launch there)" % (
+        tj.get("tag"), e.get("avg_launch_ms_kernel_trace") or float("nan"))
 
 
 def host_api_leg(idx_dev, y, I_dev, np_dtype, local_rank):
@@ -510,7 +536,13 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_source, "launch_ms": mean_launch_ms,
                          "flops_per_launch": flops_launch,
                          "hbm_frac": hbm_gbs / 8000.0, "hbm_achieved_GBps": hbm_gbs, "hbm_peak_GBps": 8000.0,
-                         "algorithmic_bytes_per_launch": alg_bytes},
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         # the rate the loop's operands reach the LDS at, against what the LDS-DMA path delivers in this access pattern
+                         # (tools/fill_bench.hip: 14.0 TB/s): query tiles x corpus tiles x K-steps x 64 KiB per launch
+                         "fill": (lambda fb: {"bound": "L2 -> LDS fill (LDS-DMA)", "achieved": fb / (mean_launch_ms * 1e-3) / 1e12 if mean_launch_ms > 0 else 0.0,
+                                              "peak": 14.0, "unit": "TB/s", "frac": (fb / (mean_launch_ms * 1e-3) / 1e12 / 14.0) if mean_launch_ms > 0 else 0.0,
+                                              "bytes_per_launch": fb, "peak_source": "tools/fill_bench.hip: this loop's access pattern, LDS-DMA, measured"})(
+                             float(-(-int(q_launch) // 256)) * float(-(-(hi - lo) // 256)) * (2 * st["k_split"] // 128) * 65536.0)},
         }
         if world == 1 and not args.no_cpu_baseline:
             base, I_cpu = cpu_baseline(shard, queries, k)
