@@ -34,6 +34,42 @@ def test_add_layernorm_forward(rows, cols, dtype, tol, with_res):
         assert y.dtype == dtype and float((y.float() - ref).abs().max()) <= tol
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 3e-2)])
+def test_add_layernorm_parameters_at_an_odd_offset(dtype, tol):
+    """gamma / beta as views of a flattened parameter buffer that start 4 bytes into a 16-byte line (round 5 made the vector
+    kernel read them 16 bytes at a time): the call takes the narrow kernel and gives the same answer, forward and backward"""
+    x, r = _rand(300, 768, dtype=dtype, seed=1), _rand(300, 768, dtype=dtype, seed=2)
+    flat = _rand(2 * 768 + 8, seed=3) * 0.1
+    g, b = (flat[1:769] + 1).detach().clone(), None
+    buf = torch.empty(2 * 768 + 8, device="cuda"); buf[1:769] = g; buf[773:1541] = flat[773:1541]
+    gv, bv = buf[1:769], buf[773:1541]
+    assert gv.data_ptr() % 16 == 4 and bv.data_ptr() % 16 == 4
+    y = ops.add_layernorm(x, r, gv, bv, 1e-5)
+    ref = nn_ref.add_layernorm(x.float(), r.float(), gv, bv, 1e-5)
+    assert float((y.float() - ref).abs().max()) <= tol
+    gp = gv.clone().requires_grad_(True); xp = x.clone().requires_grad_(True)
+    ops.add_layernorm(xp, r, gp[:], bv, 1e-5).float().square().sum().backward()
+    gq = gv.clone().requires_grad_(True); xq = x.float().clone().requires_grad_(True)
+    nn_ref.add_layernorm(xq, r.float(), gq, bv, 1e-5).square().sum().backward()
+    assert float((gp.grad - gq.grad).abs().max()) <= tol * max(1.0, float(gq.grad.abs().max()))
+
+
+def test_attention_refuses_operands_that_are_not_16_byte_aligned():
+    """the matrix-core kernels move rows in 16-byte pieces: an output (or q, k, v) view at an 8-byte offset is an EINVAL, not a
+    misaligned store"""
+    import ctypes
+    L = ops.lib()
+    q = torch.zeros(1 * 128 * 2 * 64 + 8, device="cuda", dtype=torch.bfloat16)
+    o = torch.zeros(1 * 128 * 2 * 64 + 8, device="cuda", dtype=torch.bfloat16)
+    vp = ctypes.c_void_p
+    st = vp(torch.cuda.current_stream().cuda_stream)
+    args = lambda qq, oo: (vp(qq.data_ptr()), vp(qq.data_ptr()), vp(qq.data_ptr()), None, 0, 0, 1, 2, 128, 128, ctypes.c_float(0.125), 1, vp(oo.data_ptr()), st)
+    L.trx_attention_fwd.argtypes = [vp, vp, vp, vp] + [ctypes.c_int] * 6 + [ctypes.c_float, ctypes.c_int, vp, vp]
+    assert L.trx_attention_fwd(*args(q, o)) == 0
+    assert L.trx_attention_fwd(*args(q, o[4:])) == -1 and L.trx_attention_fwd(*args(q[4:], o)) == -1
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("rows,cols", [(1000, 768), (37, 130)])
 def test_add_layernorm_backward(rows, cols):
     x, r = _rand(rows, cols, seed=1), _rand(rows, cols, seed=2)

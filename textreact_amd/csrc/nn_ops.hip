@@ -1279,7 +1279,9 @@ int trx_add_layernorm_fwd_dropout(const void* x, const void* res, const float* g
     dim3 grid((unsigned)((rows + 3) / 4)), block(256);
     hipStream_t st = (hipStream_t)stream;
     const int V = dtype == TRX_NN_BF16 ? 8 : 4;
-    const bool aligned = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(res)) & 15) == 0;
+    // (gamma / beta are read 16 bytes at a time by the vector kernel too: a parameter view at an odd offset takes the narrow kernel)
+    const bool aligned = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(res) |
+                           reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) & 15) == 0;
     const bool vec = aligned && cols % V == 0 && cols <= 64 * NCH * V;
     if (vec) {
 #define TRX_LNF(NC_)                                                                                                              \
@@ -1315,7 +1317,7 @@ int trx_add_layernorm_bwd_dropout(const void* dy, const void* x, const void* res
     const int V = dtype == TRX_NN_BF16 ? 8 : 4;
     const int nblk = trx_add_layernorm_bwd_blocks(rows);
     const bool aligned = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(res) |
-                           reinterpret_cast<uintptr_t>(dz) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0;
+                           reinterpret_cast<uintptr_t>(dz) | reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(gamma)) & 15) == 0;
     const bool vec = aligned && cols % V == 0 && cols <= 64 * NCH * V;
 #define TRX_LAUNCH_LNB(KERNEL)                                                                                              \
     {                                                                                                                       \
@@ -1346,9 +1348,10 @@ int trx_add_layernorm_fwd_mixed(const void* x_bf16, const void* res_f32, const f
     if (!x_bf16 || !res_f32 || !gamma || !beta || !y_f32 || rows < 0 || cols <= 0) return fail(TRX_NN_EINVAL, "add_layernorm_fwd_mixed: bad argument");
     if (!(p >= 0.f && p < 1.f)) return fail(TRX_NN_EINVAL, "dropout probability must be in [0, 1)");
     if (cols % 4 != 0 || cols > 64 * NCH * 4) return fail(TRX_NN_EINVAL, "add_layernorm_fwd_mixed: cols must be a multiple of 4 and <= 1024");
-    if (((reinterpret_cast<uintptr_t>(res_f32) | reinterpret_cast<uintptr_t>(y_f32)) & 15) ||
+    if (((reinterpret_cast<uintptr_t>(res_f32) | reinterpret_cast<uintptr_t>(y_f32) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta) |
+          reinterpret_cast<uintptr_t>(x_bias)) & 15) ||
         ((reinterpret_cast<uintptr_t>(x_bf16) | reinterpret_cast<uintptr_t>(y_bf16)) & 7))
-        return fail(TRX_NN_EINVAL, "add_layernorm_fwd_mixed: operands must be 16-byte (bf16 ones: 8-byte) aligned");
+        return fail(TRX_NN_EINVAL, "add_layernorm_fwd_mixed: operands must be 16-byte (bf16 ones: 8-byte) aligned (gamma, beta and the bias are read 16 bytes at a time)");
     if (rows == 0) return TRX_NN_OK;
     const Drop drop = make_drop(p, seed, 0);
 #define TRX_LNFM(NC_) hipLaunchKernelGGL((add_ln_fwd_vec_kernel<false, true, NC_>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, \
@@ -1371,7 +1374,7 @@ int trx_add_layernorm_bwd_mixed(const void* dy_f32, const void* dy_bf16, const v
         return fail(TRX_NN_EINVAL, "add_layernorm_bwd_mixed: bad argument");
     if (!(p >= 0.f && p < 1.f)) return fail(TRX_NN_EINVAL, "dropout probability must be in [0, 1)");
     if (cols % 4 != 0 || cols > 64 * NCH * 4) return fail(TRX_NN_EINVAL, "add_layernorm_bwd_mixed: cols must be a multiple of 4 and <= 1024");
-    if (((reinterpret_cast<uintptr_t>(res_f32) | reinterpret_cast<uintptr_t>(dy_f32) | reinterpret_cast<uintptr_t>(dz_f32)) & 15) ||
+    if (((reinterpret_cast<uintptr_t>(res_f32) | reinterpret_cast<uintptr_t>(dy_f32) | reinterpret_cast<uintptr_t>(dz_f32) | reinterpret_cast<uintptr_t>(gamma)) & 15) ||
         ((reinterpret_cast<uintptr_t>(x_bf16) | reinterpret_cast<uintptr_t>(dx_bf16) | reinterpret_cast<uintptr_t>(dy_bf16)) & 7))
         return fail(TRX_NN_EINVAL, "add_layernorm_bwd_mixed: operands must be 16-byte (x, dx: 8-byte) aligned");
     const Drop drop = make_drop(p, seed, 0);
@@ -1438,6 +1441,9 @@ static int attention_fwd_impl(const void* q, const void* k, const void* v, const
     if (dtype != TRX_NN_F32 && dtype != TRX_NN_BF16) return fail(TRX_NN_EINVAL, "unknown dtype");
     if (!(p >= 0.f && p < 1.f)) return fail(TRX_NN_EINVAL, "dropout probability must be in [0, 1)");
     if (!(scale > 0.f)) return fail(TRX_NN_EINVAL, "attention_fwd: scale must be positive");
+    // the matrix-core kernels move q, k, v by 16-byte loads / LDS-DMA and store whole 16-byte pieces of an output row
+    if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(out)) & 15)
+        return fail(TRX_NN_EINVAL, "attention_fwd: q, k, v and out must be 16-byte aligned");
     DropArgs da = make_drop_args(p, seed);
     da.kv_bs = kv_bs; da.ldq = ldq; da.ldk = ldk;
     hipStream_t st = (hipStream_t)stream;
@@ -1561,6 +1567,9 @@ static int attention_bwd_impl(const void* q, const void* k, const void* v, const
     if (dtype != TRX_NN_F32 && dtype != TRX_NN_BF16) return fail(TRX_NN_EINVAL, "unknown dtype");
     if (!(p >= 0.f && p < 1.f)) return fail(TRX_NN_EINVAL, "dropout probability must be in [0, 1)");
     if (!(scale > 0.f)) return fail(TRX_NN_EINVAL, "attention_bwd: scale must be positive");
+    if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(dout) |
+         reinterpret_cast<uintptr_t>(dq) | reinterpret_cast<uintptr_t>(dk) | reinterpret_cast<uintptr_t>(dv)) & 15)
+        return fail(TRX_NN_EINVAL, "attention_bwd: q, k, v, out, dout, dq, dk and dv must be 16-byte aligned");
     DropArgs da = make_drop_args(p, seed);
     da.ldq = ldq; da.ldk = ldk;
     hipStream_t st = (hipStream_t)stream;
