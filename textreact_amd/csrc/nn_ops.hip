@@ -693,7 +693,7 @@ __device__ __forceinline__ void store_row_bf16(bf16_t* rowp, bool live, bool wid
 #define TRX_ATT_ROWSUM_DOT2 1
 #endif
 #ifndef TRX_ATT_ABL      // timing-only ablations of the forward tile (tools/attn_ablate.sh; results are WRONG with any bit set): 1 no exponentials,
-#define TRX_ATT_ABL 0    // 2 no row maximum, 4 no barrier, 8 no K fragment reads, 16 no second product, 32 no first product, 64 no V reads
+#define TRX_ATT_ABL 0    // 2 no row maximum, 4 no barrier, 8 no K fragment reads, 16 no second product, 32 no first product, 64 no V reads, 128 no K / V staging (LDS-DMA)
 #endif
 template <bool VIS, bool DROP>
 __device__ __forceinline__ void attn_softmax_tile(f32x16& s0, f32x16& s1, f32x16& o0, f32x16& o1, float& m, float& lsum,
@@ -1031,8 +1031,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MM == TRX_N
     }
     // vector-memory order per wave: D(0) D(1) | iteration j: D(j+2).  At the top of iteration j tile j
     // must have landed while D(j+1)'s four loads may still fly: vmcnt(4).
-    TRX_ATT_STAGE(0, 0);
-    if (nkb > 1) TRX_ATT_STAGE(1, 1);
+    if (!(TRX_ATT_ABL & 128)) { TRX_ATT_STAGE(0, 0); }
+    if (nkb > 1 && !(TRX_ATT_ABL & 128)) TRX_ATT_STAGE(1, 1);
     // the mask and Q have landed -- they are older than the last four DMA pieces, whichever tile those belong to (with two tiles
     // staged, tile 0 has landed too; the loop's own wait decides about the tiles).  ONE statement names the registers, so that
     // nothing reads them earlier: with one statement per case hipcc copied the still-empty registers into the other
@@ -1074,7 +1074,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MM == TRX_N
         if (!(TRX_ATT_ABL & 4)) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         const int buf1 = buf == 2 ? 0 : buf + 1, buf2 = buf == 0 ? 2 : buf - 1;
-        if (kb + 2 < nkb) TRX_ATT_STAGE(kb + 2, buf2);
+        if (kb + 2 < nkb && !(TRX_ATT_ABL & 128)) TRX_ATT_STAGE(kb + 2, buf2);
         if ((kb & (KS - 1)) == kp) {          // wave-uniform: this wave's tile (always, unless the block splits its keys)
         // ---- S^T = K Q^T for both 32-key halves ----
         f32x16 s0, s1;
