@@ -822,6 +822,9 @@ __device__ __forceinline__ void attn_softmax_tile(f32x16& s0, f32x16& s1, f32x16
     }
 }
 
+#ifndef TRX_ATT_INTERLEAVE      // 1: the second product's MFMAs between the groups of the exponential chain (round 6)
+#define TRX_ATT_INTERLEAVE 1
+#endif
 #ifndef TRX_ATT_AUG      // 1: scale and reference through the first product (tools/experiments/attn_aug.h; measured, no faster: lab variant)
 #define TRX_ATT_AUG 0
 #endif
@@ -1145,7 +1148,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MM == TRX_N
         const bf16x8 pf = __builtin_bit_cast(bf16x8, uint4{pk[HB][4 * ss], pk[HB][4 * ss + 1], pk[HB][4 * ss + 2], pk[HB][4 * ss + 3]}); \
         uint4 v0; v0.x = vt[S][0][0].x; v0.y = vt[S][0][0].y; v0.z = vt[S][0][1].x; v0.w = vt[S][0][1].y;     \
         uint4 v1; v1.x = vt[S][1][0].x; v1.y = vt[S][1][0].y; v1.z = vt[S][1][1].x; v1.w = vt[S][1][1].y;     \
-        if (TRX_ATT_ABL & 16) asm volatile("" : "+v"(o0), "+v"(o1) : "v"(v0.x), "v"(v0.w), "v"(v1.x), "v"(v1.w), "v"(pf)); else {        \
+        if (TRX_ATT_ABL & 16) asm volatile("" : "+v"(o0), "+v"(o1) : "v"(v0.x), "v"(v0.w), "v"(v1.x), "v"(v1.w), "v"(pf));               \
+        else {                                                                                                \
         o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v0), pf, o0, 0, 0, 0);        \
         o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v1), pf, o1, 0, 0, 0); }      \
     }
@@ -1161,6 +1165,76 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MM == TRX_N
                 s1[t] = (key0 + 32 + kr_ > klim) ? -__builtin_inff() : s1[t];
             }
         }
+#if TRX_ATT_INTERLEAVE
+        // Round 6: the second product INSIDE the exponential chain.  A k-step of O^T += V^T P^T needs the probabilities of 16 keys = 8
+        // score registers of this lane; so after the row maximum the tile goes in four groups -- 8 exponentials, their bf16 pairs
+        // and row sum, then the group's two MFMAs -- and the matrix core works on group g while the wave issues group g + 1's
+        // exponentials (64 cycles of MFMA under 64+ cycles of v_exp issue), instead of 8 MFMAs after the whole softmax.  The
+        // ablations of profiles/r06_attention_ablation.json price the two products at their full matrix-core time (10.8 of 40 us):
+        // nothing overlapped them.  No register is added: the V^T fragments were in flight already.  Measured (same box, interleaved,
+        // bit-identical; profiles/r06_attention_interleave_ab.json): -3.6 % at 512 x 512, -1.5 % at 160 x 512, -1 % at causal 160 x 160.
+        // (The MFMAs as inline asm, in exactly this order, need two wait states after the last v_cvt_pk -- hipcc pads that hazard for
+        // the builtin only -- and were no faster: 42.5 against 42.7 us.)
+        {
+            float mb = -__builtin_inff();
+#pragma unroll
+            for (int t = 0; t < 16; ++t) mb = fmaxf(mb, s0[t]);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) mb = fmaxf(mb, s1[t]);
+            {
+                float ma = mb, mc = mb;      // (v_permlane32_swap: see attn_softmax_tile)
+                asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(ma), "+v"(mc));
+                mb = fmaxf(ma, mc) * sl2;
+            }
+            const float mt_ = fmaxf(m, mb);
+            const float mn = (TRX_ATT_LAZY > 0 && !(mt_ > m + (float)TRX_ATT_LAZY)) ? m : mt_;
+            const float mref = (mn == -__builtin_inff()) ? 0.f : mn;
+            const float alpha = __builtin_amdgcn_exp2f(m - mref);
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {   // wave-uniform, rare: BEFORE the tile's first MFMA on the outputs
+#pragma unroll
+                for (int t = 0; t < 16; ++t) { o0[t] *= alpha; o1[t] *= alpha; }
+            }
+            typedef __attribute__((ext_vector_type(2))) float f32x2;
+            const f32x2 sl2v = {sl2, sl2}, nrefv = {-mref, -mref};
+            const bf16x2_t ones = __builtin_bit_cast(bf16x2_t, 0x3f803f80u);
+            float ps = 0.f;
+#define TRX_EXP_GROUP(S)                                                                                       \
+    {                                                                                                          \
+        constexpr int hb_ = (S) >> 1, t0_ = 8 * ((S) & 1);                                                     \
+        _Pragma("unroll") for (int t = t0_; t < t0_ + 8; t += 2) {                                            \
+            const f32x2 a_ = __builtin_elementwise_fma((f32x2){hb_ ? s1[t] : s0[t], hb_ ? s1[t + 1] : s0[t + 1]}, sl2v, nrefv); \
+            const float e0_ = __builtin_amdgcn_exp2f(a_.x), e1_ = __builtin_amdgcn_exp2f(a_.y);               \
+            if (DROP) {                                                                                        \
+                ps += e0_ + e1_;                                                                               \
+                const unsigned bits_ = lowbias32(xd + (unsigned)(hb_ * 16 + ((t & 3) >> 1) + 4 * (t >> 2)) * DROP_C2); \
+                pk[hb_][t >> 1] = pack2bf(drop_keep(bits_, 0, da.thr) ? e0_ : 0.f, drop_keep(bits_, 1, da.thr) ? e1_ : 0.f); \
+            } else {                                                                                           \
+                const unsigned w_ = pack2bf(e0_, e1_);                                                         \
+                pk[hb_][t >> 1] = w_;                                                                          \
+                ps = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w_), ones, ps, false);       \
+            }                                                                                                  \
+        }                                                                                                      \
+    }
+            TRX_EXP_GROUP(0)
+            TRX_VT_WAIT(0, 1, 0)
+            TRX_PV_STEP(0, 0)
+            TRX_VT_READ(2) TRX_VT_READ(3)
+            __builtin_amdgcn_sched_barrier(0);
+            TRX_EXP_GROUP(1)
+            TRX_PV_STEP(1, 0)
+            __builtin_amdgcn_sched_barrier(0);
+            TRX_EXP_GROUP(2)
+            TRX_VT_WAIT(2, 3, 0)
+            TRX_PV_STEP(2, 1)
+            __builtin_amdgcn_sched_barrier(0);
+            TRX_EXP_GROUP(3)
+            TRX_PV_STEP(3, 1)
+#undef TRX_EXP_GROUP
+            lsum = lsum * alpha + ps;
+            m = mn;
+        }
+        }
+#else
 #if TRX_ATT_AUG
         attn_softmax_tile_aug<DROP>(s0, s1, o0, o1, m, lsum, mref, qaug, hh, xd, da.thr, pk);
 #else
@@ -1175,6 +1249,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MM == TRX_N
         TRX_PV_STEP(2, 1) TRX_PV_STEP(3, 1)
         if (TRX_ATT_PRIO) __builtin_amdgcn_s_setprio(0);
         }
+#endif
         buf = buf1;
         TRX_STAMP(4 + (kb < 26 ? kb : 26), __builtin_amdgcn_s_memtime());
     }
