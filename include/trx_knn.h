@@ -155,7 +155,9 @@ int trx_merge_topk_device_s64(int metric, int nlists, int64_t nq, int k, const d
  * the total order (FAISS' max-heap ordered by (distance, id) with strict admission keeps the k smallest (distance, id));
  * for the inner product FAISS' min-heap gives another deterministic answer -- of the rows tied at the k-th score, those
  * admitted while the heap was not yet full minus the smallest ids evicted by better rows that arrived later, and the output
- * ordered (score descending, id DESCENDING) -- which this mode reproduces exactly (closed form in knn_select.hip:
+ * ordered (score descending, id DESCENDING) -- which this mode reproduces exactly: the heap of FAISS >= 1.7.3, whose sift compares
+ * (value, id) pairs (faiss/utils/ordered_key_value.h: cmp2); older releases break ties by the heap's structure and are not replayed
+ * (closed form in knn_select.hip:
  * faiss_tie_kernel; checked against the heap replay of oracle/flat_knn_ref.c).  Ties are ties of the canonical fp64 score:
  * duplicates and exact-arithmetic inputs (integer fingerprints, the 2^-3 grid); on inputs whose fp32 sums round, FAISS'
  * own near-tie order depends on its BLAS and is not defined by FAISS either.  Cost: an inner-product search runs for the

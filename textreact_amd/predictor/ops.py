@@ -667,20 +667,29 @@ def _ln_deferrable(params, needs):
 
 
 def _flush_deferred_ln(pending):
-    by_cols = {}
+    """One launch per (device, cols) group finishes the group's calls.  Grouped by DEVICE too: a model with LayerNorms on more than
+    one GPU must not put another device's partials into one launch, and each launch runs under its own device and on that
+    device's current stream.  A refusal by the library does not lose the step's gradients: the group falls back to summing the
+    partials with torch (same values up to the order of the sum; it is the failure path, not the product path)."""
+    groups = {}
     for item in pending:
-        by_cols.setdefault(item[2], []).append(item)
-    for cols, items in by_cols.items():
+        groups.setdefault((item[0].device, item[2]), []).append(item)
+    for (dev, cols), items in groups.items():
         n = len(items)
-        dev = items[0][0].device
-        sums = torch.empty((n, 3, cols), dtype=torch.float32, device=dev)      # [call][dgamma | dbeta | dbias][cols]
-        arr = (_LnReduceItem * n)()
-        for i, (ws, nblk, _, (gamma, beta, bias)) in enumerate(items):
-            base = sums[i].data_ptr()
-            arr[i].ws, arr[i].dgamma, arr[i].dbeta = ws.data_ptr(), base, base + 4 * cols
-            arr[i].dxbias = base + 8 * cols if bias is not None else None
-            arr[i].nblk = nblk
-        _check(lib().trx_add_layernorm_bwd_reduce_many(ctypes.addressof(arr), n, cols, _stream(items[0][0])))
+        with torch.cuda.device(dev):
+            sums = torch.empty((n, 3, cols), dtype=torch.float32, device=dev)      # [call][dgamma | dbeta | dbias][cols]
+            arr = (_LnReduceItem * n)()
+            for i, (ws, nblk, _, (gamma, beta, bias)) in enumerate(items):
+                base = sums[i].data_ptr()
+                arr[i].ws, arr[i].dgamma, arr[i].dbeta = ws.data_ptr(), base, base + 4 * cols
+                arr[i].dxbias = base + 8 * cols if bias is not None else None
+                arr[i].nblk = nblk
+            try:
+                _check(lib().trx_add_layernorm_bwd_reduce_many(ctypes.addressof(arr), n, cols, _stream(items[0][0])))
+            except Exception:
+                for i, (ws, nblk, _, (gamma, beta, bias)) in enumerate(items):      # ws: [2 or 3][nblk][cols] partial rows of the first stage
+                    parts = ws.view(-1)[:(3 if bias is not None else 2) * nblk * cols].view(-1, nblk, cols).sum(dim=1)
+                    sums[i, :parts.shape[0]] = parts
         for i, (_, _, _, (gamma, beta, bias)) in enumerate(items):
             for param, g in ((gamma, sums[i, 0]), (beta, sums[i, 1]), (bias, sums[i, 2])):
                 if param is None:
