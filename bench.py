@@ -241,7 +241,7 @@ def fingerprint_workload(args, dev, local_rank):
     row_bytes = {0: 2 * st["k_split"], 1: st["k_split"], 2: st["k_split"] // 2}[form]
     fill_step = float(-(-n // 256)) * float(-(-n // 256)) * (row_bytes // 128) * 65536.0
     fill_tbps = fill_step * steps / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else 0.0
-    traffic, traffic_source = forms_traffic("morgan" if morgan else "fingerprint", n)
+    traffic, traffic_source = forms_traffic("morgan" if morgan else "fingerprint", n, form)
     line = {"metric": "queries/sec, train self-search IndexFlatL2 k=20 over %dx%d integer fingerprints (the reference's own workload)" % (n, dim),
             "value": n * steps / (t1 - t0), "unit": "queries/s", "n_gpus": 1, "steps": steps, "warmup": args.warmup,
             "ms_per_step": (t1 - t0) / steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -270,7 +270,7 @@ def fingerprint_workload(args, dev, local_rank):
     print(json.dumps(line))
 
 
-def forms_traffic(workload, n, root=ROOT):
+def forms_traffic(workload, n, form, root=ROOT):
     """roofline.traffic of the int8 / fp4 forms: L2-miss bytes per scan launch from profiles/traffic_forms.json (profiles/pmc_forms.sh:
     one --pmc pass per counter), reported only for the size it was taken at and the kernel text this run compiled from"""
     try:
@@ -281,6 +281,8 @@ def forms_traffic(workload, n, root=ROOT):
         return None, "profiles/traffic_forms.json is STALE for this knn_scan.hip / knn_common.h (source hash differs): traffic not reported"
     if n != {"fingerprint": 680_000, "morgan": 800_000}[workload]:
         return None, "profiles/traffic_forms.json was taken at another corpus size"
+    if form != {"fingerprint": 1, "morgan": 2}[workload]:
+        return None, "profiles/traffic_forms.json holds this workload's default form (int8 / fp4), not the one this run was switched to"
     e = tj.get(workload) or {}
     return e.get("hbm_bytes_per_launch"), "profiles/traffic_forms.json@%s (same scan-kernel source; kernel trace %.2f ms per launch there)" % (
         tj.get("tag"), e.get("avg_launch_ms_kernel_trace") or float("nan"))
