@@ -116,6 +116,7 @@ struct trx_index {
     // workspaces
     DevBuf w_stamp, w_stats, w_qnorm2, w_flag, w_exact, w_io, w_tmp, w_cls;      // (the big ones are shared: DevPool)
     DevBuf w_stage[2], w_wide; // host entry points: a block of the caller's rows as staged (knn_host.h), and int8 rows widened to bf16
+    int cus = 0;               // compute units of the device (choose_splits), read once
     int64_t reserve_rows = 0;  // trx_index_add: the rows the index will hold when the call is through (one allocation, not one per block)
     // hostile rows (knn_common.h): their ids, sorted, [MAX_SPECIAL] ints + the device-side counter behind them; more than MAX_SPECIAL
     // of them and every search of this index is the exact fp64 scan
@@ -405,16 +406,22 @@ constexpr int RESCAN_MAX = 16384;                 // queries per batch the re-sc
 // of a round (its workgroups run alone on their CUs, at a higher clock: 0.7 + 0.3 x its fill); fewer than 4 splits share
 // thresholds and L2 lines worse (measured at 1M rows: S = 1 + 5.8 %, 2 + 3.8 %), more than 4 slightly worse too (8: + 2 %);
 // and every split adds its lists to the select kernel's work (0.11 ms per split and 65,536 queries).
-static int choose_splits(int nqt, int ntiles, int Kp, int cap = 0) {      // cap: the most the caller's list storage takes (0: none)
-    int smax = std::max(1, std::min(std::min(ntiles, 256), std::max(4, 2048 / std::max(1, nqt))));
+// cus: the device's compute units = the workgroups resident at once (one per CU: the kernel takes most of a CU's LDS), read from
+// the device (256 on MI355X; the advisor's note on round 5: not a literal).  form_scale: the time of a tile relative to the bf16
+// form at the same Kp -- 0.5 when the int8 form may run, 0.25 for fp4 (which form runs is decided on the device; the host knows
+// which ones the index allows): it weighs the scan against the select pass's cost per split.  The per-split penalties are one
+// MI355X sweep's (profiles/r05_split_sweep.json).
+static int choose_splits(int nqt, int ntiles, int Kp, int cus, double form_scale = 1.0, int cap = 0) {      // cap: the most the caller's list storage takes (0: none)
+    cus = std::max(1, cus);
+    int smax = std::max(1, std::min(std::min(ntiles, cus), std::max(4, 8 * cus / std::max(1, nqt))));
     if (cap > 0) smax = std::max(1, std::min(smax, cap));
-    const double t_tile = 0.0172 * Kp / 768.0;                     // ms per 256 x 256 tile of a bf16 scan on one CU
+    const double t_tile = 0.0172 * Kp / 768.0 * form_scale;        // ms per 256 x 256 tile of the scan on one CU
     double best = 1e300;
     int bs = 1;
     for (int s = 1; s <= smax; ++s) {
         const int tps = (ntiles + s - 1) / s;
         if ((ntiles + tps - 1) / tps != s) continue;               // (trailing splits would be empty: the launch of a smaller s)
-        const double r = (double)nqt * s / 256.0;
+        const double r = (double)nqt * s / (double)cus;
         const double full = std::floor(r), frac = r - full;
         const double rounds = full + (frac > 1e-9 ? 0.7 + 0.3 * frac : 0.0);
         const double pen = s == 1 ? 0.058 : s == 2 ? 0.038 : s == 3 ? 0.02 : s <= 8 ? 0.005 * (s - 4) : 0.02;
@@ -422,6 +429,15 @@ static int choose_splits(int nqt, int ntiles, int Kp, int cap = 0) {      // cap
         if (cost < best * (1.0 - 1e-9)) { best = cost; bs = s; }
     }
     return bs;
+}
+
+static int device_cus(trx_index* idx) {
+    if (idx->cus <= 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, idx->device) != hipSuccess || v <= 0) v = 256;
+        idx->cus = v;
+    }
+    return idx->cus;
 }
 
 static int search_batch(trx_index* idx, const void* q, const float* qnorm2, const float* qerr2, int64_t nq, int is_bf, int q_split, int batch_no,
@@ -438,7 +454,10 @@ static int search_batch(trx_index* idx, const void* q, const float* qnorm2, cons
     // Round 5: that is the rule for query counts that fill whole rounds of 256 workgroups (C1: 256 query tiles x 4).  For the
     // others choose_splits prices every count: 18 query tiles x 15 splits = 270 workgroups ran two rounds where 14 splits run one
     // (7.96 -> 4.40 ms over 800,000 rows), 50 x 6 = 300 likewise (11.75 -> 7.52 ms over 500,000; profiles/r05_split_sweep.json).
-    int nsplits = choose_splits(nqt, ntiles, Kp);
+    // (the forms this index allows: the int8 copy needs small integers in a plain index, the fp4 one values E2M1 holds)
+    const bool may8 = idx->mode == MODE_PLAIN && !idx->nonint && idx->maxabs <= 127.f && d >= 256 && !q_split && !getenv("TRX_NO_I8");
+    const bool may4 = may8 && !idx->nonfp4 && !getenv("TRX_NO_FP4");
+    int nsplits = choose_splits(nqt, ntiles, Kp, device_cus(idx), may4 ? 0.25 : may8 ? 0.5 : 1.0);
     { const char* e = getenv("TRX_NSPLITS"); if (e) nsplits = std::max(1, std::min(atoi(e), ntiles)); }
     int tps = (ntiles + nsplits - 1) / nsplits;
     nsplits = (ntiles + tps - 1) / tps;  // drop empty trailing splits
@@ -673,7 +692,7 @@ static int search_batch(trx_index* idx, const void* q, const float* qnorm2, cons
         if ((rc2 = pl.qg2.reserve((size_t)cap_q * Kp * sizeof(bf16_t)))) return rc2;
         if ((rc2 = pl.gthr2.reserve((size_t)cap_q * 4 * sizeof(u32)))) return rc2;
         const int tiles = cap_q / TILE_N, small_tiles = std::max(1, tiles / 8), factor = tiles / small_tiles;
-        int ns_small = choose_splits(small_tiles, ntiles, Kp, std::min(std::min(nsplits * factor, ntiles), 256));      // (whole rounds here too)
+        int ns_small = choose_splits(small_tiles, ntiles, Kp, device_cus(idx), 1.0, std::min(std::min(nsplits * factor, ntiles), 256));      // (whole rounds here too)
         const int tps_small = (ntiles + ns_small - 1) / ns_small;
         ns_small = (ntiles + tps_small - 1) / tps_small;
         const bool two = factor > 1 && ns_small > nsplits && !getenv("TRX_RESCAN_ONE_FORM");
