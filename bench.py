@@ -270,6 +270,28 @@ def fingerprint_workload(args, dev, local_rank):
     print(json.dumps(line))
 
 
+def dense_host_api_leg(shard, queries, k, I_dev, local_rank):
+    """The drop-in call itself on the headline workload, beside `value` (never instead of it): the FAISS protocol as a dense
+    retriever's script makes it (retrieve_faiss.py:62-74 with IndexFlatIP) -- `index.add(corpus)` and `index.search(queries, k)` on
+    HOST float32 NumPy arrays, host (D, I) back.  PCIe both ways and the library's staging are inside `value_host_api`."""
+    import numpy as np
+    import textreact_amd.faiss_compat as faiss
+    from textreact_amd import _lib
+    yh = shard.float().cpu().numpy(); xh = queries.float().cpu().numpy()
+    idx = faiss.IndexFlatIP(yh.shape[1], device=local_rank)
+    idx.add(yh[:4096]); idx.search(xh[:4096], k); idx.reset()            # warm: worker pool, pinned buffers
+    t0 = time.perf_counter(); idx.add(yh); t_add = time.perf_counter() - t0
+    best, Ih = None, None
+    for _ in range(3):
+        t0 = time.perf_counter(); Dh, Ih = idx.search(xh, k); t = time.perf_counter() - t0
+        best = t if best is None else min(best, t)
+    same = bool(np.array_equal(Ih, I_dev.cpu().numpy()))
+    return {"value_host_api": xh.shape[0] / best,
+            "host_api": {"what": "IndexFlatIP.add / .search on host numpy float32 arrays (the FAISS protocol), host (D, I) out: PCIe and staging included; "
+                                 "not `value`", "add_ms": t_add * 1e3, "search_ms": best * 1e3, "corpus_GB": yh.nbytes / 1e9, "queries_MB": xh.nbytes / 1e6,
+                         "host_threads": _lib.lib().trx_host_threads(), "same_ids_as_device_resident": same}}
+
+
 def forms_traffic(workload, n, form, root=ROOT):
     """roofline.traffic of the int8 / fp4 forms: L2-miss bytes per scan launch from profiles/traffic_forms.json (profiles/pmc_forms.sh:
     one --pmc pass per counter), reported only for the size it was taken at and the kernel text this run compiled from"""
@@ -547,6 +569,7 @@ def main():
                              float(-(-int(q_launch) // 256)) * float(-(-(hi - lo) // 256)) * (2 * st["k_split"] // 128) * 65536.0)},
         }
         if world == 1 and not args.no_cpu_baseline:
+            line.update(dense_host_api_leg(shard, queries, k, I, local_rank))
             base, I_cpu = cpu_baseline(shard, queries, k)
             # the sample doubles as an end-to-end check: same neighbours as the GPU result
             # (fp32 BLAS order differs from the canonical fp64 order only on near-ties)

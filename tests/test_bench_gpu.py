@@ -30,6 +30,10 @@ def test_single_gpu_line_has_the_contract_fields():
     assert j["roofline"]["bound"] == "mfma" and 0 < j["roofline"]["frac"] < 1
     assert j["cpu_baseline"]["kind"] in ("port", "reference") and j["cpu_baseline"]["index_agreement_with_gpu"] == 1.0
     assert j["cpu_baseline"]["tflops"] > 0 and j["cpu_baseline"]["cores"] >= 1
+    # round 6: the second roofline (L2 -> LDS fill), the drop-in call on host arrays beside `value` (same ids), and both CPU candidates' rates
+    assert j["roofline"]["fill"]["peak"] == 14.0 and 0 < j["roofline"]["fill"]["frac"] < 1.2
+    assert j["value_host_api"] > 0 and j["host_api"]["same_ids_as_device_resident"] is True
+    assert j["cpu_baseline"]["kind"] == "reference" or len(j["cpu_baseline"]["candidates_on_the_probe"]) == 2
 
 
 def test_fingerprint_workload_line_runs_the_int8_form():
@@ -42,6 +46,12 @@ def test_fingerprint_workload_line_runs_the_int8_form():
         j = _line(r.stdout)
         assert j["config"]["int8_scan"] == want and j["dtype"] == ("i8" if want else "bf16"), j
         assert j["roofline"]["peak"] == (5000.0 if want else 2500.0) and j["config"]["self_is_first"] and j["config"]["exact_class"] == 1
+        assert j["roofline"]["fill"]["achieved"] > 0 and j["roofline"]["traffic"] is None      # (traffic: measured at the full size only)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "fingerprint", "--steps", "1", "--warmup", "1", "--n-corpus", "20000",
+                        "--no-cpu-baseline", "--host-api"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _line(r.stdout)      # --host-api: the same self-search through host int64 arrays, same neighbours
+    assert j["value_host_api"] > 0 and j["host_api"]["same_ids_as_device_resident"] is True and j["host_api"]["int8_scan"] == 1
 
 
 def test_morgan_workload_line_runs_the_fp4_form():
