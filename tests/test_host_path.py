@@ -165,3 +165,27 @@ def test_float64_embeddings_are_rounded_to_float32_first():
         D, I = idx.search(x, 10)
         Dr, Ir = oracle.knn_canonical(metric, x.astype(np.float32), y.astype(np.float32), 10)
         assert np.array_equal(I, Ir) and np.array_equal(D.view(np.uint32), Dr.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_odd_dimensions_through_the_integer_types_and_the_exact_scan():
+    """the extended fuzzer's find (round 6): integer host rows reach the device as int8 and are widened to bf16 rows of d components --
+    for an odd d every other row starts on an odd halfword, and the exact fp64 scan's 16-byte loads of such rows returned garbage
+    (device bf16 queries of an odd d always could; nothing passed them until the host path did).  d = 65, bit vectors, L2, the
+    two-scan path (k = 100) and k beyond the corpus (k = 256 over 7 rows): the oracle's answer for every host type"""
+    import textreact_amd.faiss_compat as faiss
+    from oracle import flat_knn as oracle
+    from _data import morgan_like
+    for (seed, n, nq, k) in ((146, 7, 255, 256), (124, 5000, 63, 100)):
+        y, x = morgan_like(n, 65, seed).astype(np.float32), morgan_like(nq, 65, seed + 1).astype(np.float32)
+        Dr, Ir = oracle.knn_canonical(L2, x, y, k)
+        for dt in (np.float32, np.int8, np.int64):
+            idx = faiss.IndexFlatL2(65)
+            idx.add(y.astype(dt))
+            D, I = idx.search(x.astype(dt), k)
+            assert np.array_equal(I, Ir) and np.array_equal(D.view(np.uint32), Dr.view(np.uint32)), (dt, n, k, idx.last_stats())
+    import torch
+    yb, xb = torch.from_numpy(y).cuda().bfloat16(), torch.from_numpy(x).cuda().bfloat16()      # device bf16 rows of an odd d: the same loads
+    idx = faiss.IndexFlatL2(65); idx.add(yb)
+    D, I = idx.search(xb, k)
+    assert np.array_equal(I.cpu().numpy(), Ir) and np.array_equal(D.cpu().numpy().view(np.uint32), Dr.view(np.uint32))

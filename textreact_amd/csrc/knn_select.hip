@@ -28,9 +28,13 @@ __device__ __forceinline__ double load_as_double(const void* base, int64_t off) 
 template <bool L2, bool CBF, bool QBF>
 __device__ __forceinline__ double canonical_score(const void* qrow, const void* crow, int d) {
     double s = 0.0;
-    // 8 components per step: 16-byte loads for bf16 rows, 2 x 16 bytes for f32 rows
+    // 8 components per step: 16-byte loads for bf16 rows, 2 x 16 bytes for f32 rows -- when both rows start on a dword: a
+    // multi-dword load needs that much, and bf16 rows of an odd d start on odd halfwords every other row (device bf16 queries; since
+    // round 6 also every integer host array, which reaches the device as int8 and is widened to bf16 rows of d components: the fuzzer
+    // found d = 65).  Otherwise component by component: the same chain in the same order, the same bits.
     int k = 0;
-    for (; k + 8 <= d; k += 8) {
+    const bool dword_rows = ((reinterpret_cast<uintptr_t>(qrow) | reinterpret_cast<uintptr_t>(crow)) & 3u) == 0;
+    for (; dword_rows && k + 8 <= d; k += 8) {
         double x[8], y[8];
         if (QBF) {
             uint4 u = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(qrow) + k);

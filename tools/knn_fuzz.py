@@ -44,20 +44,41 @@ for it in range(n_cases):
         base = gaussian(max(1, n // 8), d, 2 * it)
         y = base[np.random.default_rng(it).integers(0, base.shape[0], n)]
         x = gaussian(nq, d, 2 * it + 1)
+    # round 6: hostile values in a third of the cases -- NaN / +-inf components, rows of float32's largest magnitudes, an all-NaN
+    # query -- in random rows of the corpus and of the queries; and the host dtype the arrays are handed over in
+    hostile = rng.random() < 0.33
+    if hostile:
+        r3 = np.random.default_rng(5000 + it)
+        for arr, frac in ((y, 0.004), (x, 0.03)):
+            for row in r3.choice(arr.shape[0], size=max(1, int(arr.shape[0] * frac)), replace=False):
+                what = r3.integers(0, 5)
+                col = r3.integers(0, d)
+                if what == 0: arr[row, col] = np.nan
+                elif what == 1: arr[row, col] = np.inf
+                elif what == 2: arr[row, col] = -np.inf
+                elif what == 3: arr[row, :] = np.float32(3.0e38) * (1 if r3.random() < 0.5 else -1)
+                else: arr[row, :] = np.nan
+    as_dtype = None
+    if kind in ("fp", "grid") and not hostile and rng.random() < 0.5:      # integer-valued data through the integer host types
+        if kind == "grid":
+            y, x = np.round(y * 8), np.round(x * 8)
+        as_dtype = rng.choice([np.int64, np.int32, np.int16, np.int8])
+        y, x = y.astype(np.float32), x.astype(np.float32)
     idx = faiss.IndexFlat(d, metric)
     chunks = rng.choice([1, 1, 3])
     if os.environ.get("TRX_FUZZ_VERBOSE"):
         print("case", it, dict(metric=metric, kind=kind, d=d, n=n, nq=nq, k=k, chunks=chunks), flush=True)
     for part in np.array_split(y, chunks):
         if part.shape[0]:
-            idx.add(part)
-    D, I = idx.search(x, k)
-    Dr, Ir = oracle.knn_canonical(metric, x, y, k)
+            idx.add(part if as_dtype is None else part.astype(as_dtype))
+    D, I = idx.search(x if as_dtype is None else x.astype(as_dtype), k)
+    with np.errstate(all="ignore"):
+        Dr, Ir = oracle.knn_canonical(metric, x, y, k)
     ok = np.array_equal(I, Ir) and np.array_equal(D.view(np.uint32), Dr.view(np.uint32))
     if not ok:
         nfail += 1
         bad = np.argwhere(I != Ir)
-        print("FAIL", it, dict(metric=metric, kind=kind, d=d, n=n, nq=nq, k=k, chunks=chunks), "first bad", bad[:3].tolist(), idx.last_stats())
+        print("FAIL", it, dict(metric=metric, kind=kind, d=d, n=n, nq=nq, k=k, chunks=chunks, hostile=hostile, as_dtype=str(as_dtype)), "first bad", bad[:3].tolist(), idx.last_stats())
     tiers = idx.last_stats()
     seen = globals().setdefault("seen", [0, 0, 0])
     seen[0] += tiers["n_rescored"]; seen[1] += tiers["n_rescanned"]; seen[2] += tiers["n_uncertified"] if k <= 24 else 0
