@@ -80,3 +80,28 @@ def test_rccl_ranks_without_a_gpu_each_are_refused_with_the_reason(module, tmp_p
     r = subprocess.run([sys.executable, "-m", module] + argv, capture_output=True, text=True, timeout=300, cwd=ROOT,
                        env=_env(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", TRX_DIST_BACKEND="nccl", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999"))
     assert r.returncode == 2 and "one GPU per" in r.stderr, (r.returncode, r.stderr[-1500:])
+
+
+def _setup_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank))
+    os.environ.pop("TRX_DIST_BACKEND", None)
+    import torch.distributed as dist
+    from textreact_amd import _dist
+    r, w, dev = _dist.setup()                 # no GPU here: the gloo backend, device cpu
+    again = _dist.setup()                     # a second call finds the group and changes nothing
+    import torch
+    t = torch.tensor([r + 1.0]); dist.all_reduce(t)
+    ret[rank] = (r, w, str(dev), again[:2] == (r, w), float(t), dist.get_backend())
+    dist.destroy_process_group()
+
+
+def test_setup_makes_the_group_once_for_every_rank():
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]
+    mgr = mp.Manager(); ret = mgr.dict()
+    mp.spawn(_setup_worker, args=(2, port, ret), nprocs=2, join=True)
+    for r in (0, 1):
+        assert ret[r] == (r, 2, "cpu", True, 3.0, "gloo"), ret[r]
