@@ -189,3 +189,21 @@ def test_odd_dimensions_through_the_integer_types_and_the_exact_scan():
     idx = faiss.IndexFlatL2(65); idx.add(yb)
     D, I = idx.search(xb, k)
     assert np.array_equal(I.cpu().numpy(), Ir) and np.array_equal(D.cpu().numpy().view(np.uint32), Dr.view(np.uint32))
+
+
+def test_conversions_from_several_threads_take_turns():
+    """the worker pool serves one caller at a time: eight Python threads converting at once (ctypes releases the GIL) all get numpy's answer"""
+    import threading
+    rng = np.random.default_rng(5)
+    xs = [rng.integers(-100, 100, (300, 1000 + 37 * i)).astype(np.int64) for i in range(8)]
+    outs = [None] * 8
+
+    def work(i):
+        for _ in range(20):
+            rc, out = _convert(xs[i], 2)
+            assert rc == 0
+        outs[i] = out
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(8)]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    for i in range(8):
+        assert outs[i] is not None and np.array_equal(outs[i], xs[i].astype(np.int8))

@@ -31,6 +31,7 @@ public:
     int workers() const { return (int)th_.size(); }
     void run(int ntasks, const std::function<void(int)>& f) {
         if (ntasks <= 0) return;
+        std::lock_guard<std::mutex> one_caller(run_mu_);      // callers on different threads (two indexes, trx_host_convert) take turns
         {
             std::unique_lock<std::mutex> g(mu_);
             cv_done_.wait(g, [this] { return active_ == 0; });      // no straggler of the previous call is still looking at the counter
@@ -67,7 +68,7 @@ private:
         }
     }
     std::vector<std::thread> th_;
-    std::mutex mu_;
+    std::mutex mu_, run_mu_;
     std::condition_variable cv_go_, cv_done_;
     const std::function<void(int)>* fn_ = nullptr;
     int ntasks_ = 0, left_ = 0, active_ = 0;
