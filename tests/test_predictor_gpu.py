@@ -1188,3 +1188,36 @@ def test_graphed_step_refuses_a_runtime_that_was_started_without_its_switch():
     opt, _ = train.configure_optimizer(p, 1e-3, 0.01, 100, 0.1, capturable=True)
     with pytest.raises(ops.TrxNNError, match=train.GRAPH_RUNTIME_ENV[0]):
         train.GraphedStep(p, opt)
+
+
+def test_deferred_layernorm_sums_survive_a_refused_grouped_launch(monkeypatch):
+    """ops._flush_deferred_ln (round 6, advisor): when the one-launch-per-pass reduction is refused, the calls are reduced one by one
+    by the same kernel -- same gradients bit for bit -- instead of losing every LayerNorm's dgamma / dbeta of the step"""
+    def grads(refuse):
+        torch.manual_seed(0)
+        x = [_rand(500, 768, seed=i) for i in range(3)]      # (the deferred second stage belongs to the trainer's mixed storage: bf16 x, fp32 stream)
+        g = [(_rand(768, seed=10 + i) * 0.1 + 1).requires_grad_(True) for i in range(3)]
+        b = [(_rand(768, seed=20 + i) * 0.1).requires_grad_(True) for i in range(3)]
+        real = ops.lib().trx_add_layernorm_bwd_reduce_many
+        calls = []
+        if refuse:
+            class Lib:
+                def __getattr__(self, name):
+                    if name == "trx_add_layernorm_bwd_reduce_many":
+                        def f(arr, n, cols, st):
+                            calls.append(n)
+                            return -1 if n > 1 else real(arr, n, cols, st)
+                        return f
+                    return getattr(ops._LIB_REAL, name)
+            ops._LIB_REAL = ops.lib()
+            monkeypatch.setattr(ops, "lib", lambda: Lib())
+        with ops.deferred_wgrad():
+            loss = sum(ops.add_layernorm(x[i].bfloat16().requires_grad_(True), x[(i + 1) % 3], g[i], b[i], 1e-5).square().sum() for i in range(3))
+            loss.backward()
+        if refuse:
+            monkeypatch.undo()
+            assert calls[0] == 3 and calls[1:] == [1, 1, 1], calls
+        return [t.grad.clone() for t in g + b]
+    a, c = grads(False), grads(True)
+    for u, v in zip(a, c):
+        assert torch.equal(u, v)

@@ -669,11 +669,12 @@ def _ln_deferrable(params, needs):
 def _flush_deferred_ln(pending):
     """One launch per (device, cols) group finishes the group's calls.  Grouped by DEVICE too: a model with LayerNorms on more than
     one GPU must not put another device's partials into one launch, and each launch runs under its own device and on that
-    device's current stream.  A refusal by the library does not lose the step's gradients: the group falls back to summing the
-    partials with torch (same values up to the order of the sum; it is the failure path, not the product path)."""
+    device's current stream.  A refusal of a grouped launch does not lose the step's gradients: the group's calls are launched one by one
+    (the same HIP kernel), every call that succeeds gets its gradients, and the first error is raised when all groups are through."""
     groups = {}
     for item in pending:
         groups.setdefault((item[0].device, item[2]), []).append(item)
+    first_error = None
     for (dev, cols), items in groups.items():
         n = len(items)
         with torch.cuda.device(dev):
@@ -687,9 +688,18 @@ def _flush_deferred_ln(pending):
             try:
                 _check(lib().trx_add_layernorm_bwd_reduce_many(ctypes.addressof(arr), n, cols, _stream(items[0][0])))
             except Exception:
-                for i, (ws, nblk, _, (gamma, beta, bias)) in enumerate(items):      # ws: [2 or 3][nblk][cols] partial rows of the first stage
-                    parts = ws.view(-1)[:(3 if bias is not None else 2) * nblk * cols].view(-1, nblk, cols).sum(dim=1)
-                    sums[i, :parts.shape[0]] = parts
+                # the grouped launch was refused: one launch per call instead (the same kernel, the same sums), so that a single bad
+                # item costs its own gradients and an error, not every LayerNorm's of the step
+                failed = None
+                for i in range(n):
+                    one = (_LnReduceItem * 1)(arr[i])
+                    try:
+                        _check(lib().trx_add_layernorm_bwd_reduce_many(ctypes.addressof(one), 1, cols, _stream(items[i][0])))
+                    except Exception as e:      # noqa: PERF203
+                        failed = e
+                        sums[i].zero_()
+                if failed is not None:
+                    first_error = first_error or failed
         for i, (_, _, _, (gamma, beta, bias)) in enumerate(items):
             for param, g in ((gamma, sums[i, 0]), (beta, sums[i, 1]), (bias, sums[i, 2])):
                 if param is None:
@@ -698,6 +708,8 @@ def _flush_deferred_ln(pending):
                     param.grad = g
                 else:
                     param.grad.add_(g)
+    if first_error is not None:
+        raise first_error
 
 
 def _has_grad_hooks(params):
