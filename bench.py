@@ -399,6 +399,9 @@ def main():
     ap.add_argument("--row-groups", type=int, default=0,
                     help="rows x queries grid (sharded.ShardedFlatIndex(row_groups=Gr)): the corpus row-sharded Gr ways, the queries split "
                          "over the G / Gr columns; 0 = pure row sharding (Gr = G), the north-star line")
+    ap.add_argument("--finish-first", action="store_true",
+                    help="row-sharded search: finish the local search (one host wait) before the exchange is enqueued, instead of enqueuing "
+                         "it behind the search and agreeing on late fall-backs with a one-word all-reduce (ShardedFlatIndex(stream_ordered=False))")
     ap.add_argument("--selfcheck", action="store_true",
                     help="also at N = 1 (always on at N > 1): before the timed region, compare every rank's result hashes and re-do "
                          "32 sampled queries by an independent fp64 matmul + all_gather + sort; exit code 3 on a mismatch")
@@ -452,7 +455,7 @@ def main():
         index = local                        # a plain flat index per GPU: nothing to exchange
         index.add(shard)
     else:
-        index = ShardedFlatIndex(d, faiss.METRIC_INNER_PRODUCT, local_index=local, row_groups=row_groups)
+        index = ShardedFlatIndex(d, faiss.METRIC_INNER_PRODUCT, local_index=local, row_groups=row_groups, stream_ordered=not args.finish_first)
         # fault injection for tests/test_bench_gpu.py: the last rank reports its rows one id too high -- the kind of
         # plumbing error the selfcheck exists for
         wrong = 1 if (os.environ.get("TRX_BENCH_INJECT_FAULT") == "offset" and world > 1 and rank == world - 1) else 0
@@ -554,6 +557,8 @@ def main():
                        "transport": ("RCCL (nccl backend), one GPU per rank" if backend == "nccl" else
                                      "REHEARSAL: %d ranks share GPU %d, %s backend (host round trip in the all-gather); not a scaling measurement"
                                      % (world, local_rank, backend)) if world > 1 else None,
+                       "exchange": (None if world == 1 or args.replicas else "finish first, then the exchange" if args.finish_first else
+                                    "stream-ordered behind the local search + a one-word agreement all-reduce"),
                        "uncertified_queries_per_step": uncert / args.steps, "selfcheck": checked},
             "roofline": {"bound": "mfma", "kernel": "knn_scan_kernel", "achieved": achieved,
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,

@@ -866,6 +866,11 @@ def _rank_worker(rank, world, port, ret):
         rep.add(torch.from_numpy(y).cuda())
         D, I = rep.search(torch.from_numpy(x).cuda(), 10)
         out[("replicas", metric)] = (D.cpu().numpy(), I.cpu().numpy())
+        if world == 2:      # round 6: the exchange on finished lists (no agreement collective): the same answer
+            fidx = ShardedFlatIndex(d, metric, stream_ordered=False)
+            fidx.add_shard(torch.from_numpy(y[lo:hi]).cuda(), lo, n)
+            D, I = fidx.search(torch.from_numpy(x).cuda(), 10)
+            out[("finish_first", metric)] = (D.cpu().numpy(), I.cpu().numpy())
         if world == 4:      # round 6: the rows x queries grid, 2 x 2 -- row shard r % 2, query slice r // 2, the exchange inside a column
             gidx = ShardedFlatIndex(d, metric, row_groups=2)
             glo, ghi = gidx.shard_rows(n)
@@ -900,7 +905,7 @@ def test_multi_rank_sharded_search_on_one_gpu(world):
     for metric in (IP, L2):
         Dr, Ir = oracle.knn_canonical(metric, x, y, 10)
         for r in range(world):
-            for key in (metric, ("replicas", metric)) + ((("grid", metric),) if world == 4 else ()):
+            for key in (metric, ("replicas", metric)) + ((("grid", metric),) if world == 4 else ()) + ((("finish_first", metric),) if world == 2 else ()):
                 D, I = ret[r][key]
                 assert np.array_equal(I, Ir), (key, r)
                 assert np.array_equal(D.view(np.uint32), Dr.view(np.uint32)), (key, r)

@@ -36,7 +36,7 @@ class ShardedFlatIndex:
     500,000 rows x 16,384 queries per rank instead of 125,000 x 65,536; the corpus then has to fit Gr GPUs."""
 
     def __init__(self, d: int, metric: int, group=None, local_index=None, merge: Optional[Callable] = None,
-                 exchange_always: bool = False, row_groups: Optional[int] = None):
+                 exchange_always: bool = False, row_groups: Optional[int] = None, stream_ordered: bool = True):
         import torch.distributed as dist
         self.d, self.metric = int(d), int(metric)
         self.group = group
@@ -85,6 +85,12 @@ class ShardedFlatIndex:
         # a one-rank group skips the exchange (nothing to exchange); exchange_always runs the collectives and the merge
         # anyway, which is how a one-GPU box drives the RCCL branch of this file (tests/test_knn_gpu.py)
         self.exchange_always = bool(exchange_always)
+        # stream_ordered (default): the exchange is enqueued behind the local search without a host wait, and ONE extra collective -- a
+        # one-word all-reduce after the wait -- makes the ranks agree on whether any of them had to re-do queries late (then the
+        # exchange repeats).  False: the local search is finished first (one host wait), then the exchange runs on final lists:
+        # no agreement collective, no repeat, at the price of the host's wake-up latency between the scan and the all-to-all.  Which
+        # is cheaper at 8 ranks has never been measured (no multi-GPU node): bench.py --finish-first is the A/B for the first run.
+        self.stream_ordered = bool(stream_ordered)
         self.late_fallbacks = 0
         self.offset = 0      # global id of this shard's first row
         self.ntotal = 0      # rows over all shards
@@ -133,7 +139,7 @@ class ShardedFlatIndex:
         nq = x.shape[0]
         qlo, qhi = shard_bounds(nq, self.query_groups, self.query_rank)      # this column's slice of the queries (all of them: Gq = 1)
         xs = x if self.query_groups == 1 else x[qlo:qhi].contiguous()
-        begin = getattr(self.local, "search_s64_begin", None) if exchange else None
+        begin = getattr(self.local, "search_s64_begin", None) if (exchange and self.stream_ordered) else None
         D, I_loc, S = begin(xs, k) if begin is not None else self.local.search_s64(xs, k)
         if not exchange:
             return D, torch.where(I_loc >= 0, I_loc + self.offset, I_loc)
