@@ -207,3 +207,24 @@ def test_conversions_from_several_threads_take_turns():
     [t.start() for t in ts]; [t.join() for t in ts]
     for i in range(8):
         assert outs[i] is not None and np.array_equal(outs[i], xs[i].astype(np.int8))
+
+
+def test_conversion_properties_hold_for_arbitrary_arrays():
+    """property test (hypothesis, 60 examples): for any int64 array, narrowing succeeds exactly when every value fits a signed byte and
+    then reproduces the values; the float32 route equals numpy's astype bit for bit"""
+    from hypothesis import given, settings, strategies as st
+    from hypothesis.extra import numpy as hnp
+
+    @settings(max_examples=60, deadline=None)
+    @given(hnp.arrays(np.int64, hnp.array_shapes(min_dims=2, max_dims=2, min_side=1, max_side=300),
+                      elements=st.one_of(st.integers(-128, 127), st.integers(-2 ** 63, 2 ** 63 - 1), st.integers(-300, 300))))
+    def check(x):
+        x = np.ascontiguousarray(x)
+        rc, out = _convert(x, 2)
+        fits = bool(((x >= -128) & (x <= 127)).all())
+        assert rc == (0 if fits else 1)
+        if fits:
+            assert np.array_equal(out.astype(np.int64), x)
+        rc, of = _convert(x, 0)
+        assert rc == 0 and np.array_equal(of.view(np.uint32), x.astype(np.float32).view(np.uint32))
+    check()

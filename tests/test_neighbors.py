@@ -82,3 +82,24 @@ def test_the_block_writer_emits_json_dumps_bytes(tmp_path):
         N.write_neighbors(a, N.build_result(qids, rank, cids))
         N.write_neighbor_file(b, qids, rank, cids, block=16)
         assert a.read_bytes() == b.read_bytes(), i
+
+
+def test_the_block_writer_equals_json_dump_for_arbitrary_ids():
+    """property test (hypothesis): any mix of string / integer ids, any ranks with pads, any block size -> json.dump's bytes"""
+    import numpy as np
+    import tempfile, os
+    from hypothesis import given, settings, strategies as st
+    from textreact_amd import neighbors as N
+    ids = st.one_of(st.integers(-10 ** 12, 10 ** 12), st.text(max_size=12))
+
+    @settings(max_examples=40, deadline=None)
+    @given(st.lists(ids, min_size=1, max_size=30), st.integers(1, 6), st.integers(0, 25), st.integers(1, 9), st.randoms(use_true_random=False))
+    def check(cids, k, nq, block, rnd):
+        rank = np.array([[rnd.randint(-1, len(cids) - 1) for _ in range(k)] for _ in range(nq)], dtype=np.int64).reshape(nq, k)
+        qids = [cids[rnd.randrange(len(cids))] for _ in range(nq)]
+        with tempfile.TemporaryDirectory() as td:
+            a, b = os.path.join(td, "a.json"), os.path.join(td, "b.json")
+            N.write_neighbors(a, N.build_result(qids, rank, cids))
+            N.write_neighbor_file(b, qids, rank, cids, block=block)
+            assert open(a, "rb").read() == open(b, "rb").read()
+    check()
