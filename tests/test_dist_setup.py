@@ -67,7 +67,7 @@ def test_bench_refuses_the_same_way():
 @pytest.mark.parametrize("module", ["textreact_amd.retrieve_faiss", "textreact_amd.tanimoto"])
 def test_rccl_ranks_without_a_gpu_each_are_refused_with_the_reason(module, tmp_path):
     """the two retrieval CLIs have no --gpus flag (the reference's have none): what they refuse is a rank of an RCCL group
-    that has no GPU of its own -- here: no GPU at all -- in _dist.setup, exit code 2, not a hang inside the first collective"""
+    that has no GPU of its own -- here: local rank 63 of a box with fewer GPUs -- in _dist.setup, exit code 2, not a hang inside the first collective"""
     import numpy as np
     np.save(tmp_path / "a.npy", np.zeros((4, 8), np.int8))
     if module.endswith("tanimoto"):
@@ -78,8 +78,9 @@ def test_rccl_ranks_without_a_gpu_each_are_refused_with_the_reason(module, tmp_p
         argv = ["--data_path", str(tmp_path), "--train_file", "t.csv", "--valid_file", "t.csv", "--test_file", "t.csv", "--output_path", str(tmp_path / "out"),
                 "--train_vectors", str(tmp_path / "a.npy"), "--valid_vectors", str(tmp_path / "a.npy"), "--test_vectors", str(tmp_path / "a.npy")]
     r = subprocess.run([sys.executable, "-m", module] + argv, capture_output=True, text=True, timeout=300, cwd=ROOT,
-                       env=_env(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", TRX_DIST_BACKEND="nccl", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999"))
-    assert r.returncode == 2 and "one GPU per" in r.stderr, (r.returncode, r.stderr[-1500:])
+                       env=_env(WORLD_SIZE="64", RANK="63", LOCAL_RANK="63", TRX_DIST_BACKEND="nccl", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999"))
+    # (local rank 63: refused on this box whether it has no GPU or eight)
+    assert r.returncode == 2 and "one GPU per" in r.stderr and "cuda:63" in r.stderr, (r.returncode, r.stderr[-1500:])
 
 
 def _setup_worker(rank, world, port, ret):
