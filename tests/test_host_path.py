@@ -228,3 +228,20 @@ def test_conversion_properties_hold_for_arbitrary_arrays():
         rc, of = _convert(x, 0)
         assert rc == 0 and np.array_equal(of.view(np.uint32), x.astype(np.float32).view(np.uint32))
     check()
+
+
+@pytest.mark.gpu
+def test_int64_values_whose_float32_squares_leave_float32():
+    """a count of 2^62 in an int64 fingerprint (garbage upstream, but it is what the array holds): as float32 it is 4.6e18, its row's
+    |row|^2 overflows float32 -- a hostile row that arrived through the integer route; the answer is the oracle's on
+    the float32 values, both metrics"""
+    import textreact_amd.faiss_compat as faiss
+    from oracle import flat_knn as oracle
+    y = reaction_fp_like(3000, 128, 9).astype(np.int64); x = reaction_fp_like(100, 128, 10).astype(np.int64)
+    y[77, 5] = 2 ** 62; y[78, 6] = -(2 ** 62); x[3, 5] = 2 ** 61
+    for metric, cls in ((0, faiss.IndexFlatIP), (1, faiss.IndexFlatL2)):
+        idx = cls(128); idx.add(y)
+        D, I = idx.search(x, 10)
+        with np.errstate(all="ignore"):
+            Dr, Ir = oracle.knn_canonical(metric, x.astype(np.float32), y.astype(np.float32), 10)
+        assert np.array_equal(I, Ir) and np.array_equal(D.view(np.uint32), Dr.view(np.uint32)), (metric, idx.last_stats())
